@@ -1,0 +1,133 @@
+"""ORACLE (test infrastructure only — never imported by the product path).
+
+numpy fp32 restatement of the reference's agent.update() step for TD3+BC, TD3, BC and the
+DDPG (states) backbone:
+  /root/reference/agents/offline_learning/td3_bc.py:119-189, td3.py:117-186, bc.py:78-110,
+  /root/reference/agents/unsupervised_learning/ddpg.py:240-328.
+Noise is an explicit input (two _standard_normal((B,A)) draws per update, critic-target
+first, actor second). Pinned by tests/golden/tiny_*.npz and full_*.json (reference outputs).
+"""
+import numpy as np
+
+from . import nets
+from .nets import F32, ActorNet, TwinCritic, SharedTrunkCritic, Adam
+
+ACTOR_KEYS_OFFLINE = ['policy.0.weight', 'policy.0.bias', 'policy.1.weight', 'policy.1.bias',
+                      'policy.3.weight', 'policy.3.bias', 'policy.5.weight', 'policy.5.bias']
+CRITIC_KEYS_OFFLINE = [f'{q}.{i}.{w}' for q in ('q1_net', 'q2_net') for i in (0, 1, 3, 5) for w in ('weight', 'bias')]
+ACTOR_KEYS_DDPG = ['trunk.0.weight', 'trunk.0.bias', 'trunk.1.weight', 'trunk.1.bias',
+                   'policy.0.weight', 'policy.0.bias', 'policy.2.weight', 'policy.2.bias']
+CRITIC_KEYS_DDPG = (['trunk.0.weight', 'trunk.0.bias', 'trunk.1.weight', 'trunk.1.bias'] +
+                    [f'{q}.{i}.{w}' for q in ('Q1', 'Q2') for i in (0, 2) for w in ('weight', 'bias')])
+
+
+def param_shapes(kind, O, A, H):
+    """(actor [(key, shape)], critic [(key, shape)] or None) in the reference's parameter order."""
+    tr = lambda i: [(H, i), (H,), (H,), (H,)]
+    hd = lambda o: [(H, H), (H,), (o, H), (o,)]
+    ddpg = kind == 'ddpg'
+    actor = list(zip(ACTOR_KEYS_DDPG if ddpg else ACTOR_KEYS_OFFLINE, tr(O) + hd(A)))
+    if kind == 'bc':
+        return actor, None
+    if ddpg:
+        critic = list(zip(CRITIC_KEYS_DDPG, tr(O + A) + hd(1) + hd(1)))
+    else:
+        critic = list(zip(CRITIC_KEYS_OFFLINE, tr(O + A) + hd(1) + tr(O + A) + hd(1)))
+    return actor, critic
+
+
+def _min_grad(q1, q2):
+    """torch.min(a, b) backward: gradient to the smaller, split evenly on ties."""
+    w1 = np.where(q1 < q2, F32(1), np.where(q1 == q2, F32(0.5), F32(0)))
+    return w1, (F32(1) - w1)
+
+
+class OracleAgent:
+    """kind in {'td3_bc','td3','bc','ddpg'}; params are lists of float32 arrays (reference order)."""
+
+    def __init__(self, kind, actor_params, critic_params=None, lr=1e-4, tau=0.01, stddev_schedule='0.2',
+                 stddev_clip=0.3, alpha=2.5, update_every_steps=2):
+        self.kind = kind
+        self.actor = [np.array(p, F32) for p in actor_params]
+        self.actor_opt = Adam(self.actor, lr)
+        self.C = SharedTrunkCritic if kind == 'ddpg' else TwinCritic
+        if kind != 'bc':
+            self.critic = [np.array(p, F32) for p in critic_params]
+            self.critic_target = [p.copy() for p in self.critic]      # td3_bc.py:93
+            self.critic_opt = Adam(self.critic, lr)
+        self.tau, self.sched, self.clip, self.alpha = tau, stddev_schedule, stddev_clip, alpha
+        self.update_every_steps = update_every_steps
+
+    # td3_bc.py:119-143 / td3.py:117-141 / ddpg.py:240-268
+    def update_critic(self, obs, action, reward, discount, next_obs, std, noise):
+        mu_n, _ = ActorNet.fwd(self.actor, next_obs)
+        next_action = nets.truncated_normal_sample(mu_n, noise, std, self.clip)
+        tq1, tq2, _ = self.C.fwd(self.critic_target, next_obs, next_action)
+        target_q = (reward + (discount * np.minimum(tq1, tq2)).astype(F32)).astype(F32)
+        q1, q2, caches = self.C.fwd(self.critic, obs, action)
+        B = F32(obs.shape[0])
+        e1, e2 = (q1 - target_q).astype(F32), (q2 - target_q).astype(F32)
+        loss = (e1 * e1).mean(dtype=F32) + (e2 * e2).mean(dtype=F32)
+        grads, _ = self.C.bwd(self.critic, caches, (F32(2) * e1 / B).astype(F32), (F32(2) * e2 / B).astype(F32),
+                              need_dx=False)
+        self.critic_opt.step(self.critic, grads)
+        return dict(critic_target_q=float(target_q.mean(dtype=F32)), critic_q1=float(q1.mean(dtype=F32)),
+                    critic_q2=float(q2.mean(dtype=F32)), critic_loss=float(loss)), grads
+
+    # td3_bc.py:145-166 / td3.py:143-163 / ddpg.py:270-292
+    def update_actor(self, obs, action, std, noise):
+        mu, cache = ActorNet.fwd(self.actor, obs)
+        a = nets.truncated_normal_sample(mu, noise, std, self.clip)
+        q1, q2, caches = self.C.fwd(self.critic, obs, a)
+        q = np.minimum(q1, q2)
+        B, A = obs.shape[0], mu.shape[1]
+        m = {}
+        if self.kind == 'td3_bc':
+            lmbda = F32(self.alpha) / np.abs(q).mean(dtype=F32)
+            bc = ((mu - action) ** 2).mean(dtype=F32)
+            loss = -lmbda * q.mean(dtype=F32) + bc
+            dq = np.full_like(q, -lmbda / F32(B))
+            dmu_extra = (F32(2) * (mu - action) / F32(B * A)).astype(F32)
+        else:
+            loss = -q.mean(dtype=F32)
+            dq = np.full_like(q, F32(-1.0) / F32(B))
+            dmu_extra = 0
+        w1, w2 = _min_grad(q1, q2)
+        _, dx = self.C.bwd(self.critic, caches, (dq * w1).astype(F32), (dq * w2).astype(F32), need_dx=True)
+        dmu = (dx[:, obs.shape[1]:] + dmu_extra).astype(F32)      # straight-through sample, utils.py:135-138
+        grads = ActorNet.bwd(self.actor, cache, dmu)
+        self.actor_opt.step(self.actor, grads)
+        m['actor_loss'] = float(loss)
+        m['actor_ent'] = float(nets.normal_entropy(std) * A)
+        if self.kind == 'ddpg':
+            m['actor_logprob'] = float(nets.normal_log_prob(a, mu, std).sum(-1).mean(dtype=F32))
+        return m, grads
+
+    # bc.py:78-95
+    def update_bc(self, obs, action, std):
+        mu, cache = ActorNet.fwd(self.actor, obs)
+        B, A = mu.shape
+        logp = nets.normal_log_prob(action, mu, std).sum(-1, keepdims=True)
+        loss = (-logp).mean(dtype=F32)
+        dmu = (-(action - mu) / (F32(std) * F32(std)) / F32(B)).astype(F32)
+        grads = ActorNet.bwd(self.actor, cache, dmu)
+        self.actor_opt.step(self.actor, grads)
+        return dict(actor_loss=float(loss), actor_ent=float(nets.normal_entropy(std) * A)), grads
+
+    # td3_bc.py:168-189 / bc.py:97-110 / ddpg.py:298-328
+    def update(self, batch, step, noise_critic=None, noise_actor=None):
+        if self.kind == 'ddpg' and step % self.update_every_steps != 0:
+            return {}
+        obs, action, reward, discount, next_obs = [np.asarray(x, F32) for x in batch[:5]]
+        std = nets.schedule(self.sched, step)
+        m = dict(batch_reward=float(reward.mean(dtype=F32)))
+        if self.kind == 'bc':
+            mm, self.last_actor_grads = self.update_bc(obs, action, std)
+            m.update(mm)
+            return m
+        mc, self.last_critic_grads = self.update_critic(obs, action, reward, discount, next_obs, std, noise_critic)
+        m.update(mc)
+        ma, self.last_actor_grads = self.update_actor(obs, action, std, noise_actor)
+        m.update(ma)
+        nets.soft_update(self.critic, self.critic_target, self.tau)
+        return m

@@ -1,0 +1,301 @@
+"""Generates tests/golden/* by running the REFERENCE hot path (read-only /root/reference) on CPU.
+
+Run in the build container only:  python tools/gen_golden.py [--only replay|utils|tiny|full]
+The outputs are data (inputs + the reference's outputs); no reference source is copied.
+Inputs that are seed-regenerable live in tests/_synth.py and are NOT stored in the fixtures.
+
+What each fixture pins:
+  replay_*.npz     G1: replay_buffer.py:153-277 (index streams, eviction order, n-step values)
+  utils_g2.npz     G2: utils.py single ops (TruncatedNormal, schedule, soft update, RMS, PBE) + Adam
+  tiny_<agent>.npz G3: 5 update() steps at H=32,B=8 with explicit weights, noise, metrics, final params
+  full_<agent>.json G4: 10 update() steps at BASELINE dims, scalar metrics + parameter checksums,
+                        fp32 (1 thread) and an fp64 adjudication run
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+sys.path.insert(0, str(HERE.parent / 'tests'))
+from ref_harness import load_reference  # noqa: E402
+import _synth  # noqa: E402
+
+GOLD = HERE.parent / 'tests' / 'golden'
+
+
+# ----------------------------------------------------------------------------- replay (G1)
+def gen_replay(ref):
+    rb = ref.rb
+    scenarios = {
+        # name: (lengths, obs_dim, act_dim, meta_dim, nstep, max_size, batch, nbatches, seed, obs_u8)
+        'a_nstep1': ([7, 3, 12, 5, 9, 4, 3, 15, 6, 8, 10, 3, 11], 5, 2, 0, 1, 10**6, 16, 4, 3, False),
+        'b_nstep3': ([7, 3, 12, 5, 9, 4, 3, 15, 6, 8, 10, 3, 11], 5, 2, 0, 3, 10**6, 16, 4, 4, False),
+        'c_evict': ([7, 3, 12, 5, 9, 4, 3, 15, 6, 8, 10, 3, 11], 5, 2, 0, 3, 40, 16, 4, 5, False),
+        'd_meta': ([6, 9, 4, 11, 5], 4, 3, 2, 2, 10**6, 8, 3, 6, False),
+        'e_single': ([5], 3, 1, 0, 5, 10**6, 8, 2, 7, False),   # one episode, len == nstep
+        'f_pixels': ([6, 4, 9], 48, 2, 0, 3, 10**6, 8, 2, 8, True),  # uint8 observations
+    }
+    for name, (lengths, O, A, M, nstep, max_size, B, NB, seed, u8) in scenarios.items():
+        eps = _synth.synth_episodes(seed, lengths, O, A, M, u8)
+        with tempfile.TemporaryDirectory() as td:
+            specs = (ref.Array((O,), np.uint8 if u8 else np.float32, 'observation'),
+                     ref.Array((A,), np.float32, 'action'),
+                     ref.Array((1,), np.float32, 'reward'),
+                     ref.Array((1,), np.float32, 'discount'))
+            meta_specs = (ref.Array((M,), np.float32, 'skill'),) if M else tuple()
+            storage = rb.ReplayBufferStorage(specs, meta_specs, Path(td) / 'buffer')
+            for ep in eps:
+                storage._store_episode(ep)          # replay_buffer.py:143-150
+            assert len(storage) == sum(lengths)
+            loader = rb.make_replay_loader(storage, max_size, B, 0, True, nstep, 0.99)
+            picks, starts = [], []
+            orig_se = rb.ReplayBuffer._sample_episode
+            orig_ri = np.random.randint
+
+            def rec_se(self):
+                fn = random.choice(self._episode_fns)
+                picks.append(int(fn.stem.split('_')[1]))
+                return self._episodes[fn]
+
+            def rec_ri(*a, **k):
+                v = orig_ri(*a, **k)
+                starts.append(int(v) + 1)
+                return v
+
+            rb.ReplayBuffer._sample_episode = rec_se
+            np.random.randint = rec_ri
+            try:
+                random.seed(seed)
+                np.random.seed(seed)
+                it = iter(loader)
+                batches = [next(it) for _ in range(NB)]
+                resident = [int(fn.stem.split('_')[1]) for fn in loader.dataset._episode_fns]
+            finally:
+                rb.ReplayBuffer._sample_episode = orig_se
+                np.random.randint = orig_ri
+        out = dict(lengths=np.array(lengths), dims=np.array([O, A, M, nstep, max_size, B, NB, seed, int(u8)]),
+                   picks=np.array(picks, np.int64), starts=np.array(starts, np.int64),
+                   resident=np.array(resident, np.int64))
+        for bi, b in enumerate(batches):
+            for ti, t in enumerate(b):
+                out[f'batch{bi}_{ti}'] = t.numpy()
+        np.savez_compressed(GOLD / f'replay_{name}.npz', **out)
+        print('replay', name, 'resident', resident, 'first picks', picks[:5], starts[:5])
+
+
+# ----------------------------------------------------------------------------- utils (G2)
+def gen_utils(ref):
+    U = ref.utils
+    rs = np.random.RandomState(11)
+    out = {}
+    # TruncatedNormal.sample, utils.py:128-149 (noise recorded)
+    mu = np.tanh(rs.standard_normal((6, 4)) * 1.5).astype(np.float32)
+    noise = rs.standard_normal((6, 4)).astype(np.float32) * 2.0
+    orig = U._standard_normal
+    U._standard_normal = lambda shape, dtype, device: torch.from_numpy(noise.copy()).to(dtype)
+    try:
+        for tag, clip in (('clip', 0.3), ('noclip', None)):
+            loc = torch.from_numpy(mu.copy()).requires_grad_(True)
+            d = U.TruncatedNormal(loc, torch.ones_like(loc) * 0.2)
+            x = d.sample(clip=clip)
+            (x * torch.arange(24.).view(6, 4)).sum().backward()
+            out[f'tn_{tag}_x'] = x.detach().numpy()
+            out[f'tn_{tag}_grad'] = loc.grad.numpy()
+        d = U.TruncatedNormal(torch.from_numpy(mu), torch.ones(6, 4) * 0.2)
+        a = torch.from_numpy(rs.uniform(-1, 1, (6, 4)).astype(np.float32))
+        out['tn_a'] = a.numpy()
+        out['tn_logprob'] = d.log_prob(a).numpy()
+        out['tn_entropy'] = d.entropy().numpy()
+    finally:
+        U._standard_normal = orig
+    out['tn_mu'], out['tn_noise'] = mu, noise
+    # schedule, utils.py:199-219
+    sch = ['0.2', 'linear(1.0,0.1,100)', 'step_linear(1.0,0.5,50,0.1,100)']
+    steps = [0, 10, 50, 75, 100, 1000]
+    out['schedule'] = np.array([[U.schedule(s, t) for t in steps] for s in sch], np.float64)
+    # soft update, utils.py:44-47
+    net = torch.nn.Linear(7, 5)
+    tgt = torch.nn.Linear(7, 5)
+    out['soft_w'], out['soft_b'] = net.weight.detach().numpy().copy(), net.bias.detach().numpy().copy()
+    out['soft_tw0'], out['soft_tb0'] = tgt.weight.detach().numpy().copy(), tgt.bias.detach().numpy().copy()
+    U.soft_update_params(net, tgt, 0.01)
+    out['soft_tw1'], out['soft_tb1'] = tgt.weight.detach().numpy().copy(), tgt.bias.detach().numpy().copy()
+    # Adam (torch.optim.Adam defaults as td3_bc.py:96-97), 4 steps on explicit grads
+    p = torch.nn.Parameter(torch.from_numpy(rs.standard_normal(33).astype(np.float32)))
+    opt = torch.optim.Adam([p], lr=1e-4)
+    out['adam_p0'] = p.detach().numpy().copy()
+    grads = rs.standard_normal((4, 33)).astype(np.float32) * np.array([1, 1e-3, 10, 1e-6], np.float32)[:, None]
+    out['adam_grads'] = grads
+    ps = []
+    for g in grads:
+        opt.zero_grad(set_to_none=True)
+        p.grad = torch.from_numpy(g.copy())
+        opt.step()
+        ps.append(p.detach().numpy().copy())
+    out['adam_p'] = np.stack(ps)
+    # RMS + PBE, utils.py:257-319
+    rep = rs.standard_normal((16, 8)).astype(np.float32)
+    out['pbe_rep'] = rep
+    for tag, (avg, use_rms, clip, k) in dict(avg=(True, False, 0.0, 3), kth=(False, False, 0.0, 3),
+                                            avg_rms=(True, True, 0.0005, 4), kth_rms_noclip=(False, True, -1.0, 2)).items():
+        rms = U.RMS('cpu')
+        pbe = U.PBE(rms, clip, k, avg, use_rms, 'cpu')
+        r1 = pbe(torch.from_numpy(rep.copy()))
+        r2 = pbe(torch.from_numpy(rep.copy() * 1.5))        # second call exercises the running stats
+        out[f'pbe_{tag}_r1'], out[f'pbe_{tag}_r2'] = r1.numpy(), r2.numpy()
+        out[f'pbe_{tag}_M'], out[f'pbe_{tag}_S'] = rms.M.numpy(), rms.S.numpy()
+    rms = U.RMS('cpu')
+    xs = rs.standard_normal((3, 10, 1)).astype(np.float32)
+    out['rms_x'] = xs
+    ms = [np.stack([t.numpy() for t in rms(torch.from_numpy(x))]) for x in xs]
+    out['rms_MS'] = np.stack(ms)
+    # Proto-style kNN reward (proto.py:114-119): distances to a queue, 3rd smallest
+    z = rs.standard_normal((10, 6)).astype(np.float32)
+    queue = rs.standard_normal((20, 6)).astype(np.float32)
+    zt, qt = torch.from_numpy(z), torch.from_numpy(queue)
+    z_to_q = torch.norm(zt[:, None, :] - qt[None, :, :], dim=2, p=2)
+    all_dists, _ = torch.topk(z_to_q, 3, dim=1, largest=False)
+    out['knn_z'], out['knn_queue'], out['knn_reward'] = z, queue, all_dists[:, -1:].numpy()
+    # orthogonal init plumbing (utils.py:59-69) under a fixed torch seed
+    torch.manual_seed(5)
+    lin = torch.nn.Linear(5, 32)
+    lin.apply(U.weight_init)
+    lin2 = torch.nn.Linear(32, 3)
+    lin2.apply(U.weight_init)
+    out['init_w_5_32'], out['init_w_32_3'] = lin.weight.detach().numpy(), lin2.weight.detach().numpy()
+    np.savez_compressed(GOLD / 'utils_g2.npz', **out)
+    print('utils g2 keys', len(out))
+
+
+# ----------------------------------------------------------------------------- agents (G3/G4)
+def make_agent(ref, kind, O, A, H, B, device='cpu', use_tb=True):
+    if kind == 'td3_bc':
+        return ref.td3_bc.TD3BCAgent('td3_bc', (O,), (A,), device, 1e-4, H, 0.01, 0.2, 1, B, 0.3, use_tb, 2.5)
+    if kind == 'td3':
+        return ref.td3.TD3Agent('td3', (O,), (A,), device, 1e-4, H, 0.01, 0.2, 1, B, 0.3, use_tb)
+    if kind == 'bc':
+        return ref.bc.BCAgent('bc', (O,), (A,), device, 1e-4, H, B, 0.2, use_tb)
+    if kind == 'ddpg':
+        return ref.ddpg.DDPGAgent('ddpg', True, 'states', (O,), (A,), device, 1e-4, 50, H, 0.01, 2000, 2,
+                                  0.2, 3, B, 0.3, True, use_tb, False)
+    raise ValueError(kind)
+
+
+def nets_of(agent):
+    nets = [('actor', agent.actor)]
+    if hasattr(agent, 'critic'):
+        nets += [('critic', agent.critic), ('critic_target', agent.critic_target)]
+    return nets
+
+
+def run_agent(ref, agent, kind, nsteps, batch_fn, noise, dtype):
+    """Drives agent.update() exactly as train_offline.py:114 / pretrain.py:280-283 do."""
+    U = ref.utils
+    orig = U._standard_normal
+    U._standard_normal = lambda shape, dtype, device: torch.from_numpy(noise.draw(shape)).to(dtype)
+    metrics = []
+    try:
+        for i in range(nsteps):
+            step = 2 * i if kind == 'ddpg' else i           # ddpg.py:302 update_every_steps=2
+            batch = tuple(x.astype(dtype) for x in batch_fn(i))
+            m = agent.update(iter([batch]), step)
+            metrics.append({k: float(v) for k, v in m.items()})
+    finally:
+        U._standard_normal = orig
+    return metrics
+
+
+def checksums(agent):
+    cs = {}
+    for nm, net in nets_of(agent):
+        flat = torch.cat([p.detach().double().reshape(-1) for p in net.parameters()])
+        cs[nm] = [float(flat.sum()), float((flat * flat).sum()), float(flat.abs().max())]
+    return cs
+
+
+def gen_tiny(ref):
+    O, A, H, B, N = 5, 3, 32, 8, 5
+    for kind in ('td3_bc', 'td3', 'bc', 'ddpg'):
+        torch.manual_seed(21)
+        agent = make_agent(ref, kind, O, A, H, B)
+        out = {}
+        for nm, net in nets_of(agent):
+            for k, v in net.state_dict().items():
+                out[f'init/{nm}/{k}'] = v.numpy().copy()
+
+        class Rec:
+            def __init__(self):
+                self.inner = _synth.NoiseStream(77)
+                self.log = []
+
+            def draw(self, shape):
+                x = self.inner.draw(shape)
+                self.log.append(x.copy())      # sample() scales the returned tensor in place (utils.py:145)
+                return x
+        rec = Rec()
+        batches = [_synth.synth_batch(31, i, B, O, A) for i in range(N)]
+        metrics = run_agent(ref, agent, kind, N, lambda i: batches[i], rec, np.float32)
+        for i, b in enumerate(batches):
+            for j, t in enumerate(b):
+                out[f'batch/{i}/{j}'] = t
+        for i, x in enumerate(rec.log):
+            out[f'noise/{i}'] = x
+        keys = sorted(metrics[0].keys())
+        out['metric_keys'] = np.array(keys)
+        out['metrics'] = np.array([[m[k] for k in keys] for m in metrics], np.float64)
+        for nm, net in nets_of(agent):
+            for k, v in net.state_dict().items():
+                out[f'final/{nm}/{k}'] = v.numpy().copy()
+        np.savez_compressed(GOLD / f'tiny_{kind}.npz', **out)
+        print('tiny', kind, keys, out['metrics'][-1])
+
+
+FULL = {  # kind: (O, A, H, B)  — BASELINE.json configs (walker / cheetah shapes)
+    'td3_bc': (24, 6, 1024, 1024),
+    'td3': (17, 6, 1024, 1024),
+    'bc': (24, 6, 1024, 256),
+    'ddpg': (24, 6, 1024, 1024),
+}
+
+
+def gen_full(ref, nsteps=10):
+    torch.set_num_threads(1)
+    for kind, (O, A, H, B) in FULL.items():
+        res = {'dims': [O, A, H, B], 'nsteps': nsteps, 'param_seed': 5, 'batch_seed': 9, 'noise_seed': 13}
+        for tag, dtype, tdt in (('fp32', np.float32, torch.float32), ('fp64', np.float64, torch.float64)):
+            agent = make_agent(ref, kind, O, A, H, B)
+            for nm, net in nets_of(agent):
+                if nm == 'critic_target':
+                    continue
+                shapes = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+                params = _synth.synth_params(shapes, 5 + (0 if nm == 'actor' else 1))
+                net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+            if hasattr(agent, 'critic'):
+                agent.critic_target.load_state_dict(agent.critic.state_dict())
+            for nm, net in nets_of(agent):
+                net.to(tdt)
+            metrics = run_agent(ref, agent, kind, nsteps, lambda i: _synth.synth_batch(9, i, B, O, A),
+                                _synth.NoiseStream(13), dtype)
+            res[tag] = {'metrics': metrics, 'checksums': checksums(agent)}
+            print('full', kind, tag, metrics[-1])
+        with open(GOLD / f'full_{kind}.json', 'w') as f:
+            json.dump(res, f, indent=1)
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default=None)
+    args = ap.parse_args()
+    GOLD.mkdir(parents=True, exist_ok=True)
+    ref = load_reference()
+    todo = [args.only] if args.only else ['replay', 'utils', 'tiny', 'full']
+    for t in todo:
+        {'replay': gen_replay, 'utils': gen_utils, 'tiny': gen_tiny, 'full': gen_full}[t](ref)
