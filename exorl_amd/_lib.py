@@ -1,0 +1,125 @@
+"""ctypes binding of libexorl_hip.so (include/exorl_hip.h). No fallback: if the HIP library is
+missing or a call fails, this raises — the product path never routes around the GPU kernels."""
+import ctypes as C
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+LIB_PATH = HERE / 'libexorl_hip.so'
+
+c_void_p, c_int32, c_int64, c_float, c_size_t, c_uint64, c_uint32 = (
+    C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_uint64, C.c_uint32)
+P = C.POINTER
+
+# constants mirrored from include/exorl_hip.h
+SAMPLER_MT19937, SAMPLER_PHILOX, SAMPLER_GIVEN = 0, 1, 2
+AGENT_TD3_BC, AGENT_TD3, AGENT_BC, AGENT_DDPG = 0, 1, 2, 3
+PREC_F32, PREC_BF16 = 0, 1
+NET_ACTOR, NET_CRITIC, NET_CRITIC_TARGET = 0, 1, 2
+T_PARAM, T_GRAD, T_ADAM_M, T_ADAM_V = 0, 1, 2, 3
+M_BATCH_REWARD, M_CRITIC_TARGET_Q, M_CRITIC_Q1, M_CRITIC_Q2, M_CRITIC_LOSS, M_ACTOR_LOSS, M_ACTOR_LOGPROB = range(7)
+N_METRICS = 16
+
+
+class ReplayCfg(C.Structure):
+    _fields_ = [('obs_bytes', c_int32), ('act_dim', c_int32), ('meta_dim', c_int32), ('max_episodes', c_int32),
+                ('capacity_rows', c_int64)]
+
+
+class BatchOut(C.Structure):
+    _fields_ = [('obs', c_void_p), ('obs_stride', c_int64), ('action', c_void_p), ('action_stride', c_int64),
+                ('reward', c_void_p), ('discount', c_void_p), ('next_obs', c_void_p), ('next_obs_stride', c_int64),
+                ('meta', c_void_p), ('meta_stride', c_int64)]
+
+
+class AgentCfg(C.Structure):
+    _fields_ = [('kind', c_int32), ('obs_dim', c_int32), ('act_dim', c_int32), ('hidden_dim', c_int32),
+                ('batch', c_int32), ('precision', c_int32), ('world_size', c_int32), ('reserved', c_int32),
+                ('lr', c_float), ('tau', c_float), ('alpha', c_float), ('stddev_clip', c_float), ('seed', c_uint64)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/exorl_hip.h
+PROTOTYPES = {
+    'exorl_last_error': (C.c_char_p, []),
+    'exorl_abi_version': (C.c_int, []),
+    'exorl_device_info': (C.c_int, [C.c_char_p, C.c_int, P(C.c_int), P(c_int64)]),
+    'exorl_replay_create': (C.c_int, [P(ReplayCfg), P(c_void_p)]),
+    'exorl_replay_destroy': (C.c_int, [c_void_p]),
+    'exorl_replay_append_episode': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, P(c_int32)]),
+    'exorl_replay_evict': (C.c_int, [c_void_p, c_int32]),
+    'exorl_replay_set_order': (C.c_int, [c_void_p, c_void_p, c_int32]),
+    'exorl_replay_num_rows': (C.c_int, [c_void_p, P(c_int64), P(c_int64)]),
+    'exorl_replay_seed_mt': (C.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32]),
+    'exorl_replay_seed_mt_ints': (C.c_int, [c_void_p, c_uint64, c_uint32]),
+    'exorl_replay_get_mt': (C.c_int, [c_void_p, c_void_p, P(c_int32), c_void_p, P(c_int32)]),
+    'exorl_replay_seed_philox': (C.c_int, [c_void_p, c_uint64]),
+    'exorl_replay_sample': (C.c_int, [c_void_p, c_int32, c_int32, c_float, c_int32, c_void_p, P(BatchOut), c_void_p, c_void_p]),
+    'exorl_replay_last_pairs': (C.c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
+    'exorl_agent_workspace_bytes': (c_size_t, [P(AgentCfg)]),
+    'exorl_agent_create': (C.c_int, [P(AgentCfg), c_void_p, c_size_t, P(c_void_p)]),
+    'exorl_agent_destroy': (C.c_int, [c_void_p]),
+    'exorl_agent_num_tensors': (C.c_int, [c_void_p, c_int32, P(c_int32)]),
+    'exorl_agent_tensor': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, P(c_void_p), P(c_int64), P(c_int64)]),
+    'exorl_agent_flat': (C.c_int, [c_void_p, c_int32, c_int32, P(c_void_p), P(c_int64)]),
+    'exorl_agent_params_changed': (C.c_int, [c_void_p, c_int32, c_void_p]),
+    'exorl_agent_batch_slots': (C.c_int, [c_void_p, P(BatchOut)]),
+    'exorl_agent_set_batch': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'exorl_agent_update': (C.c_int, [c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    'exorl_agent_update_phase': (C.c_int, [c_void_p, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
+    'exorl_agent_stats_buffer': (C.c_int, [c_void_p, P(c_void_p), P(c_int64)]),
+    'exorl_agent_act': (C.c_int, [c_void_p, c_void_p, c_int32, c_float, c_int32, c_void_p, c_void_p, c_void_p]),
+    'exorl_agent_metrics': (C.c_int, [c_void_p, c_void_p, c_void_p]),
+    'exorl_agent_opt_steps': (C.c_int, [c_void_p, P(c_int64), P(c_int64)]),
+    'exorl_agent_set_opt_steps': (C.c_int, [c_void_p, c_int64, c_int64]),
+    'exorl_agent_enable_graph': (C.c_int, [c_void_p, c_void_p, c_int32, c_float, c_float]),
+    'exorl_agent_step_graph': (C.c_int, [c_void_p, c_void_p]),
+    'exorl_gemm': (C.c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int64,
+                             c_void_p, c_int64, c_void_p, c_int32, c_int32, c_void_p]),
+    'exorl_adam_step': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
+                                  c_int64, c_void_p, c_float, c_void_p]),
+    'exorl_soft_update': (C.c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
+    'exorl_ln_tanh_fwd': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    'exorl_knn_topk': (C.c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+}
+
+
+class ExorlError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Loads the in-tree HIP library (built by exorl_amd/build.py or __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ExorlError(f'{LIB_PATH} is missing: build it with `python exorl_amd/build.py` '
+                         '(hipcc --offload-arch=gfx950). There is no CPU fallback.')
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise ExorlError(load().exorl_last_error().decode())
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor or numpy array (None -> NULL)."""
+    if t is None:
+        return None
+    if hasattr(t, 'data_ptr'):
+        return t.data_ptr()
+    return t.ctypes.data
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,346 @@
+"""Agent classes with the reference's constructor kwargs and act()/update() signatures, running on
+libexorl_hip.so. Hydra drop-in: `agent._target_=exorl_amd.agents.TD3BCAgent`.
+
+Reference classes mirrored (file:line in /root/reference):
+  TD3BCAgent  agents/offline_learning/td3_bc.py:59-189      TD3Agent  agents/offline_learning/td3.py:59-186
+  BCAgent     agents/offline_learning/bc.py:34-110           DDPGAgent agents/unsupervised_learning/ddpg.py:126-328 (states)
+
+Python here is orchestration only: it builds the initial weights with torch's CPU RNG in the reference's
+construction order (so a given torch.manual_seed yields the reference's initial parameters), hands batches
+to the engine and — under torch.distributed — all-reduces the flat gradient buffers between update phases.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import utils
+from .engine import AgentEngine
+from .replay_buffer import DeviceReplayIterator
+
+_OFFLINE_ACTOR_KEYS = ['policy.0.weight', 'policy.0.bias', 'policy.1.weight', 'policy.1.bias',
+                       'policy.3.weight', 'policy.3.bias', 'policy.5.weight', 'policy.5.bias']
+_OFFLINE_CRITIC_KEYS = [f'{q}.{i}.{w}' for q in ('q1_net', 'q2_net') for i in (0, 1, 3, 5) for w in ('weight', 'bias')]
+_DDPG_ACTOR_KEYS = ['trunk.0.weight', 'trunk.0.bias', 'trunk.1.weight', 'trunk.1.bias',
+                    'policy.0.weight', 'policy.0.bias', 'policy.2.weight', 'policy.2.bias']
+_DDPG_CRITIC_KEYS = (['trunk.0.weight', 'trunk.0.bias', 'trunk.1.weight', 'trunk.1.bias'] +
+                     [f'{q}.{i}.{w}' for q in ('Q1', 'Q2') for i in (0, 2) for w in ('weight', 'bias')])
+
+
+def _mlp_init(in_dim, hidden, out_dim, n_trunks, n_heads):
+    """Initial tensors of one net, drawn from torch's CPU generator in the order the reference's constructors
+    consume it: every nn.Linear is default-initialised at construction, then `apply(utils.weight_init)`
+    re-draws each Linear weight orthogonally and zeroes its bias (utils.py:59-69)."""
+    mods = []
+    if n_trunks == n_heads:                       # [trunk_i, head_i] per net (offline Actor/Critic, DDPG Actor)
+        for _ in range(n_trunks):
+            mods.append([nn.Linear(in_dim, hidden), nn.LayerNorm(hidden), nn.Linear(hidden, hidden), nn.Linear(hidden, out_dim)])
+    else:                                         # DDPG Critic: trunk, then Q1, Q2 (ddpg.py:91-111)
+        mods.append([nn.Linear(in_dim, hidden), nn.LayerNorm(hidden)])
+        for _ in range(n_heads):
+            mods.append([nn.Linear(hidden, hidden), nn.Linear(hidden, out_dim)])
+    out = []
+    for group in mods:
+        for m in group:
+            if isinstance(m, nn.Linear):
+                nn.init.orthogonal_(m.weight.data)
+                m.bias.data.fill_(0.0)
+            out += [m.weight.data, m.bias.data]
+    return out
+
+
+class NetView:
+    """Stands where the reference has an nn.Module (agent.actor / .critic / .critic_target): parameters(),
+    state_dict(), load_state_dict(), train() over torch views of the engine's device buffers."""
+
+    def __init__(self, engine, net, keys, on_change=None):
+        self._engine, self._net, self._keys, self._on_change = engine, net, keys, on_change
+        self.training = True
+        self._params = []
+        n = engine.num_tensors(net)
+        assert n == len(keys), (n, len(keys))
+        for i in range(n):
+            self._params.append(engine.tensor(net, i, L.T_PARAM))
+
+    def parameters(self):
+        return list(self._params)
+
+    def named_parameters(self):
+        return list(zip(self._keys, self._params))
+
+    def grads(self):
+        return [self._engine.tensor(self._net, i, L.T_GRAD) for i in range(len(self._keys))]
+
+    def state_dict(self):
+        return OrderedDict((k, p.detach().clone()) for k, p in zip(self._keys, self._params))
+
+    def load_state_dict(self, sd, strict=True):
+        missing = [k for k in self._keys if k not in sd]
+        if strict and (missing or len(sd) != len(self._keys)):
+            raise KeyError(f'state_dict mismatch: missing {missing}, unexpected {[k for k in sd if k not in self._keys]}')
+        for k, p in zip(self._keys, self._params):
+            if k in sd:
+                p.copy_(torch.as_tensor(sd[k]).to(p.device, torch.float32).reshape(p.shape))
+        if self._on_change:
+            self._on_change()
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+
+class _AgentBase:
+    KIND = None
+
+    def _build(self, obs_dim, action_dim, hidden_dim, batch_size, lr, tau, alpha, stddev_clip, device, precision, seed):
+        ddpg = self.KIND == 'ddpg'
+        ws = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            ws = torch.distributed.get_world_size()
+        self.world_size = ws
+        # initial weights first (CPU RNG order: actor, critic, critic_target — td3_bc.py:86-93)
+        actor0 = _mlp_init(obs_dim, hidden_dim, action_dim, 1, 1)
+        critic0 = None
+        if self.KIND != 'bc':
+            nt = 1 if ddpg else 2
+            critic0 = _mlp_init(obs_dim + action_dim, hidden_dim, 1, nt, 2)
+            _mlp_init(obs_dim + action_dim, hidden_dim, 1, nt, 2)       # critic_target's draws, overwritten by the copy
+        self.engine = AgentEngine(self.KIND, obs_dim, action_dim, hidden_dim, batch_size, lr=lr, tau=tau, alpha=alpha,
+                                  stddev_clip=stddev_clip, precision=precision, world_size=ws, seed=seed, device=device)
+        self.actor = NetView(self.engine, L.NET_ACTOR, _DDPG_ACTOR_KEYS if ddpg else _OFFLINE_ACTOR_KEYS)
+        for p, w in zip(self.actor.parameters(), actor0):
+            p.copy_(w.reshape(p.shape))
+        if critic0 is not None:
+            keys = _DDPG_CRITIC_KEYS if ddpg else _OFFLINE_CRITIC_KEYS
+            self.critic = NetView(self.engine, L.NET_CRITIC, keys)
+            self.critic_target = NetView(self.engine, L.NET_CRITIC_TARGET, keys)
+            for p, w in zip(self.critic.parameters(), critic0):
+                p.copy_(w.reshape(p.shape))
+            self.engine.params_changed(sync_target=True)               # critic_target.load_state_dict(critic.state_dict())
+        self.noise_hook = None      # tests: callable(shape) -> np.ndarray standing in for _standard_normal
+
+    # -- nn.Module-ish surface used by utils.eval_mode and the training scripts
+    def train(self, training=True):
+        self.training = training
+        self.actor.train(training)
+        if hasattr(self, 'critic'):
+            self.critic.train(training)
+
+    def _stddev(self, step):
+        return utils.schedule(self.stddev_schedule, step)
+
+    def _load_batch(self, replay_iter):
+        if isinstance(replay_iter, DeviceReplayIterator):
+            replay_iter.sample_into(self.engine.batch_slots(), self.engine.batch)       # replay -> update, zero copy
+        else:
+            batch = next(replay_iter)                                                   # any iterator of 5-tuples
+            self.engine.set_batch(*batch[:5])
+
+    def _noise(self):
+        if self.noise_hook is None:
+            return None
+        return self.noise_hook((self.engine.batch, self.action_dim))
+
+    def _run_update(self, stddev):
+        """One gradient step; under torch.distributed the three global quantities are sum-all-reduced."""
+        eng = self.engine
+        if self.KIND == 'bc':
+            nc = na = None
+        else:
+            nc, na = self._noise(), self._noise()        # reference draw order: critic target, then actor
+        if self.world_size == 1:
+            eng.update(stddev, nc, na)
+            return
+        dist = torch.distributed
+        eng.update_phase(0, stddev, nc, na)
+        if eng.has_critic:
+            dist.all_reduce(eng.flat(L.NET_CRITIC, L.T_GRAD))
+        eng.update_phase(1, stddev, nc, na)
+        if self.KIND == 'td3_bc':
+            dist.all_reduce(eng.stats())
+        eng.update_phase(2, stddev, nc, na)
+        dist.all_reduce(eng.flat(L.NET_ACTOR, L.T_GRAD))
+        eng.update_phase(3, stddev, nc, na)
+
+    def _metrics(self, keys, stddev):
+        raw = self.engine.metrics_raw()
+        if self.world_size > 1:                          # partial means -> global means
+            t = torch.from_numpy(raw.copy()).to(self.engine.device)
+            torch.distributed.all_reduce(t)
+            raw = t.cpu().numpy()
+        m = {}
+        for idx, name in keys:
+            m[name] = float(raw[idx])
+        # TruncatedNormal inherits Normal.entropy: 0.5 + 0.5 log(2 pi) + log(std), summed over action dims
+        m['actor_ent'] = float(np.float32(0.5 + 0.5 * np.log(2 * np.pi) + np.log(stddev)) * self.action_dim)
+        return m
+
+    def _act(self, obs_vec, step, eval_mode):
+        stddev = self._stddev(step)
+        if eval_mode:
+            a = self.engine.act(obs_vec, stddev, True)
+        else:
+            noise = self.noise_hook((1, self.action_dim)) if self.noise_hook else None
+            a = self.engine.act(obs_vec, stddev, False, noise)
+            if step < self.num_expl_steps:
+                a.uniform_(-1.0, 1.0)
+        return a.cpu().numpy()[0]
+
+
+_CRITIC_METRICS = [(L.M_BATCH_REWARD, 'batch_reward'), (L.M_CRITIC_TARGET_Q, 'critic_target_q'), (L.M_CRITIC_Q1, 'critic_q1'),
+                   (L.M_CRITIC_Q2, 'critic_q2'), (L.M_CRITIC_LOSS, 'critic_loss'), (L.M_ACTOR_LOSS, 'actor_loss')]
+
+
+class TD3BCAgent(_AgentBase):
+    KIND = 'td3_bc'
+
+    def __init__(self, name, obs_shape, action_shape, device, lr, hidden_dim, critic_target_tau, stddev_schedule, nstep,
+                 batch_size, stddev_clip, use_tb, alpha, has_next_action=False, *, precision='fp32', seed=0):
+        self.action_dim = action_shape[0]
+        self.hidden_dim = hidden_dim
+        self.lr = lr
+        self.device = device
+        self.critic_target_tau = critic_target_tau
+        self.use_tb = use_tb
+        self.stddev_schedule = stddev_schedule
+        self.stddev_clip = stddev_clip
+        self.alpha = alpha
+        self._build(obs_shape[0], action_shape[0], hidden_dim, batch_size, lr, critic_target_tau, alpha, stddev_clip, device,
+                    precision, seed)
+        self.train()
+        self.critic_target.train()
+
+    def act(self, obs, step, eval_mode):
+        return self._act(np.asarray(obs, np.float32), step, eval_mode)
+
+    def update(self, replay_iter, step):
+        metrics = dict()
+        self._load_batch(replay_iter)
+        stddev = self._stddev(step)
+        self._run_update(stddev)
+        if self.use_tb:
+            metrics.update(self._metrics(_CRITIC_METRICS, stddev))
+        return metrics
+
+
+class TD3Agent(TD3BCAgent):
+    KIND = 'td3'
+
+    def __init__(self, name, obs_shape, action_shape, device, lr, hidden_dim, critic_target_tau, stddev_schedule, nstep,
+                 batch_size, stddev_clip, use_tb, has_next_action=False, *, precision='fp32', seed=0):
+        super().__init__(name, obs_shape, action_shape, device, lr, hidden_dim, critic_target_tau, stddev_schedule, nstep,
+                         batch_size, stddev_clip, use_tb, 0.0, has_next_action, precision=precision, seed=seed)
+
+
+class BCAgent(_AgentBase):
+    KIND = 'bc'
+
+    def __init__(self, name, obs_shape, action_shape, device, lr, hidden_dim, batch_size, stddev_schedule, use_tb,
+                 has_next_action=False, *, precision='fp32', seed=0):
+        self.lr = lr
+        self.action_dim = action_shape[0]
+        self.hidden_dim = hidden_dim
+        self.device = device
+        self.stddev_schedule = stddev_schedule
+        self.use_tb = use_tb
+        self._build(obs_shape[0], action_shape[0], hidden_dim, batch_size, lr, 0.0, 0.0, 0.0, device, precision, seed)
+        self.train()
+
+    def act(self, obs, step, eval_mode):
+        return self._act(np.asarray(obs, np.float32), step, eval_mode)
+
+    def update(self, replay_iter, step):
+        metrics = dict()
+        self._load_batch(replay_iter)
+        stddev = self._stddev(step)
+        self._run_update(stddev)
+        if self.use_tb:
+            metrics.update(self._metrics([(L.M_BATCH_REWARD, 'batch_reward'), (L.M_ACTOR_LOSS, 'actor_loss')], stddev))
+        return metrics
+
+
+class DDPGAgent(_AgentBase):
+    KIND = 'ddpg'
+
+    def __init__(self, name, reward_free, obs_type, obs_shape, action_shape, device, lr, feature_dim, hidden_dim,
+                 critic_target_tau, num_expl_steps, update_every_steps, stddev_schedule, nstep, batch_size, stddev_clip,
+                 init_critic, use_tb, use_wandb, meta_dim=0, skill_type='uniform', *, precision='fp32', seed=0):
+        if obs_type != 'states':
+            raise NotImplementedError("exorl_amd DDPGAgent: obs_type='pixels' (conv encoder, SURVEY K14-K15) is not built yet")
+        self.reward_free = reward_free
+        self.obs_type = obs_type
+        self.obs_shape = obs_shape
+        self.action_dim = action_shape[0]
+        self.hidden_dim = hidden_dim
+        self.lr = lr
+        self.device = device
+        self.critic_target_tau = critic_target_tau
+        self.update_every_steps = update_every_steps
+        self.use_tb = use_tb
+        self.use_wandb = use_wandb
+        self.num_expl_steps = num_expl_steps
+        self.stddev_schedule = stddev_schedule
+        self.stddev_clip = stddev_clip
+        self.init_critic = init_critic
+        self.feature_dim = feature_dim
+        self.solved_meta = None
+        self.obs_dim = obs_shape[0] + meta_dim
+        self.aug = self.encoder = _Identity()
+        self.encoder_opt = None
+        self._build(self.obs_dim, action_shape[0], hidden_dim, batch_size, lr, critic_target_tau, 0.0, stddev_clip, device,
+                    precision, seed)
+        self.train()
+        self.critic_target.train()
+
+    def train(self, training=True):
+        super().train(training)
+        self.encoder.train(training)
+
+    def init_from(self, other):
+        utils.hard_update_params(other.actor, self.actor)
+        if self.init_critic:          # critic.trunk = first 4 tensors (ddpg.py:209-210)
+            for p, t in zip(other.critic.parameters()[:4], self.critic.parameters()[:4]):
+                t.copy_(p)
+
+    def get_meta_specs(self):
+        return tuple()
+
+    def init_meta(self):
+        return OrderedDict()
+
+    def update_meta(self, meta, global_step, time_step, finetune=False):
+        return meta
+
+    def act(self, obs, meta, step, eval_mode):
+        parts = [np.asarray(obs, np.float32).reshape(-1)] + [np.asarray(v, np.float32).reshape(-1) for v in meta.values()]
+        return self._act(np.concatenate(parts), step, eval_mode)
+
+    def update(self, replay_iter, step):
+        metrics = dict()
+        if step % self.update_every_steps != 0:      # ddpg.py:302-303 — no batch is consumed
+            return metrics
+        self._load_batch(replay_iter)
+        stddev = self._stddev(step)
+        self._run_update(stddev)
+        if self.use_tb or self.use_wandb:
+            metrics.update(self._metrics(_CRITIC_METRICS + [(L.M_ACTOR_LOGPROB, 'actor_logprob')], stddev))
+        return metrics
+
+
+class _Identity:
+    training = True
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def parameters(self):
+        return []
+
+    def __call__(self, x):
+        return x

@@ -1,0 +1,496 @@
+// Agent update orchestration: TD3+BC, TD3, BC and the DDPG (states) backbone as one stream-ordered chain of
+// the kernels in gemm.hip / rowops.hip / loss.hip / optim.hip.
+// Replaces (file:line in the reference repo):
+//   td3_bc.py:119-189 update_critic/update_actor/update    td3.py:117-186    bc.py:78-110
+//   unsupervised_learning/ddpg.py:240-328
+// Structure exploited (what the reference's autograd graph hides):
+//   * the actor is evaluated on next_obs (critic target, td3_bc.py:124) and on obs (actor loss, :149) with the
+//     SAME weights -> one stacked 2B-row forward;
+//   * the twin critics / twin heads are independent nets -> every layer is a 2-problem grouped GEMM;
+//   * the actor step needs only the critic's dgrad, and of dX only the action columns (the reference also
+//     computes and discards the critic wgrad there — SURVEY 8d);
+//   * Polyak averaging of the target is fused into the critic's Adam pass.
+// Data parallel: the step is split in 4 phases at the three points where a global batch quantity is needed
+// (critic grads, sum|Q| for lambda (td3_bc.py:154), actor grads); the caller all-reduces between phases.
+#include <cmath>
+#include <vector>
+
+#include "kernels.h"
+
+namespace exorl {
+
+struct TensorDesc { int64_t off, rows, cols; };
+
+// A net = n_trunks x [Linear(in,H) LN Tanh] feeding n_heads x [Linear(H,H) ReLU Linear(H,out)].
+// twin critic: 2 trunks, 2 heads (head i on trunk i); shared critic: 1 trunk, 2 heads; actor: 1, 1.
+struct NetDesc {
+    int in_dim = 0, out_dim = 0, H = 0, n_trunks = 0, n_heads = 0;
+    int64_t W0 = 0, b0 = 0, g = 0, beta = 0, trunk_stride = 0;   // offsets of trunk 0's tensors; stride to trunk 1
+    int64_t W1 = 0, b1 = 0, W2 = 0, b2 = 0, head_stride = 0;     // offsets of head 0's tensors; stride to head 1
+    int64_t total = 0;                                           // padded flat size (floats)
+    std::vector<TensorDesc> tensors;                             // reference parameters() order
+};
+
+static int64_t pad4(int64_t n) { return round_up(n, 4); }
+
+static NetDesc make_net(int in_dim, int out_dim, int H, int n_trunks, int n_heads) {
+    NetDesc d;
+    d.in_dim = in_dim; d.out_dim = out_dim; d.H = H; d.n_trunks = n_trunks; d.n_heads = n_heads;
+    int64_t off = 0;
+    auto add = [&](int64_t rows, int64_t cols) { const int64_t o = off; d.tensors.push_back({o, rows, cols}); off += pad4(rows * cols); return o; };
+    auto add_trunk = [&](bool first) {
+        const int64_t w = add(H, in_dim), b = add(H, 1), gg = add(H, 1), be = add(H, 1);
+        if (first) { d.W0 = w; d.b0 = b; d.g = gg; d.beta = be; }
+        return w;
+    };
+    auto add_head = [&](bool first) {
+        const int64_t w1 = add(H, H), bb1 = add(H, 1), w2 = add(out_dim, H), bb2 = add(out_dim, 1);
+        if (first) { d.W1 = w1; d.b1 = bb1; d.W2 = w2; d.b2 = bb2; }
+        return w1;
+    };
+    if (n_trunks == n_heads) {             // [trunk0 head0][trunk1 head1]
+        int64_t t0 = 0, h0 = 0;
+        for (int i = 0; i < n_trunks; ++i) {
+            const int64_t t = add_trunk(i == 0);
+            const int64_t h = add_head(i == 0);
+            if (i == 0) { t0 = t; h0 = h; }
+            if (i == 1) { d.trunk_stride = t - t0; d.head_stride = h - h0; }
+        }
+    } else {                               // [trunk][head0][head1]
+        add_trunk(true);
+        int64_t h0 = 0;
+        for (int i = 0; i < n_heads; ++i) {
+            const int64_t h = add_head(i == 0);
+            if (i == 0) h0 = h;
+            if (i == 1) d.head_stride = h - h0;
+        }
+    }
+    d.total = round_up(off, 64);
+    return d;
+}
+
+struct FwdBufs { float *h1, *xhat, *rstd, *h2, *out; };
+struct BwdBufs { float *dz2, *dh1; };
+
+static int net_forward(const NetDesc& d, const float* P, const float* x, int64_t ldx, int rows, const FwdBufs& f,
+                       bool save, bool tanh_out, int prec, hipStream_t s) {
+    const int H = d.H;
+    const int64_t act = (int64_t)rows * H;
+    GemmProblem p[2];
+    for (int t = 0; t < d.n_trunks; ++t)
+        p[t] = GemmProblem{x, P + d.W0 + t * d.trunk_stride, f.h1 + t * act, P + d.b0 + t * d.trunk_stride,
+                           rows, H, d.in_dim, ldx, d.in_dim, H};
+    EXORL_TRY(gemm_grouped(prec, 0, 0, p, d.n_trunks, false, false, s));
+    EXORL_TRY(ln_tanh_fwd(f.h1, P + d.g, P + d.beta, f.h1, save ? f.xhat : nullptr, save ? f.rstd : nullptr, rows, H,
+                          d.n_trunks, act, d.trunk_stride, s));
+    for (int i = 0; i < d.n_heads; ++i)
+        p[i] = GemmProblem{f.h1 + (d.n_trunks == d.n_heads ? i : 0) * act, P + d.W1 + i * d.head_stride, f.h2 + i * act,
+                           P + d.b1 + i * d.head_stride, rows, H, H, H, H, H};
+    EXORL_TRY(gemm_grouped(prec, 0, 0, p, d.n_heads, true, false, s));
+    EXORL_TRY(head_fwd(f.h2, P + d.W2, P + d.b2, f.out, rows, H, d.out_dim, tanh_out ? 1 : 0, d.n_heads, act, d.head_stride,
+                       (int64_t)rows * d.out_dim, s));
+    return 0;
+}
+
+// G == nullptr: dgrad only (no parameter gradients). dx (rows x dx_cols) receives d/dx[:, col0:col0+dx_cols].
+static int net_backward(const NetDesc& d, const float* P, float* G, const float* x, int64_t ldx, int rows,
+                        const FwdBufs& f, const float* dout, const BwdBufs& b, float* dx, int dx_col0, int dx_cols,
+                        int prec, hipStream_t s) {
+    const int H = d.H;
+    const int64_t act = (int64_t)rows * H;
+    const bool paired = d.n_trunks == d.n_heads;
+    GemmProblem p[2];
+    EXORL_TRY(head_bwd_dx(dout, P + d.W2, f.h2, b.dz2, rows, H, d.out_dim, d.n_heads, act, d.head_stride,
+                          (int64_t)rows * d.out_dim, s));
+    if (G) {
+        EXORL_TRY(head_bwd_params(dout, f.h2, b.dz2, G + d.W2, G + d.b1, G + d.b2, rows, H, d.out_dim, d.n_heads, act,
+                                  d.head_stride, (int64_t)rows * d.out_dim, s));
+        for (int i = 0; i < d.n_heads; ++i)          // dW1_i[n][k] = sum_m dz2_i[m][n] h1[m][k]
+            p[i] = GemmProblem{b.dz2 + i * act, f.h1 + (paired ? i : 0) * act, G + d.W1 + i * d.head_stride, nullptr,
+                               H, H, rows, H, H, H};
+        EXORL_TRY(gemm_grouped(prec, 1, 1, p, d.n_heads, false, false, s));
+    }
+    for (int i = 0; i < d.n_heads; ++i)              // dh1[m][k] = sum_n dz2_i[m][n] W1_i[n][k]
+        p[i] = GemmProblem{b.dz2 + i * act, P + d.W1 + i * d.head_stride, b.dh1 + (paired ? i : 0) * act, nullptr,
+                           rows, H, H, H, H, H};
+    if (paired) {
+        EXORL_TRY(gemm_grouped(prec, 0, 1, p, d.n_heads, false, false, s));
+    } else {
+        for (int i = 0; i < d.n_heads; ++i) EXORL_TRY(gemm_grouped(prec, 0, 1, p + i, 1, false, i > 0, s));
+    }
+    if (G) EXORL_TRY(ln_param_grad(b.dh1, f.h1, f.xhat, G + d.g, G + d.beta, rows, H, d.n_trunks, act, d.trunk_stride, s));
+    EXORL_TRY(ln_tanh_bwd(b.dh1, f.h1, f.xhat, f.rstd, P + d.g, b.dh1, rows, H, d.n_trunks, act, d.trunk_stride, s));
+    if (G) {
+        EXORL_TRY(colsum(b.dh1, G + d.b0, rows, H, d.n_trunks, act, d.trunk_stride, s));
+        for (int t = 0; t < d.n_trunks; ++t)         // dW0_t[n][k] = sum_m dz0_t[m][n] x[m][k]
+            p[t] = GemmProblem{b.dh1 + t * act, x, G + d.W0 + t * d.trunk_stride, nullptr, H, d.in_dim, rows, H, ldx, d.in_dim};
+        EXORL_TRY(gemm_grouped(prec, 1, 1, p, d.n_trunks, false, false, s));
+    }
+    if (dx) {
+        for (int t = 0; t < d.n_trunks; ++t) {       // dx[m][c] = sum_n dz0_t[m][n] W0_t[n][col0+c]
+            GemmProblem q{b.dh1 + t * act, P + d.W0 + t * d.trunk_stride + dx_col0, dx, nullptr, rows, dx_cols, H, H, d.in_dim, dx_cols};
+            EXORL_TRY(gemm_grouped(prec, 0, 1, &q, 1, false, t > 0, s));
+        }
+    }
+    return 0;
+}
+
+struct Carver {           // lays sub-buffers out in one workspace; base == nullptr -> sizing pass
+    float* base;
+    int64_t off = 0;
+    explicit Carver(float* b) : base(b) {}
+    float* take(int64_t n) {
+        float* p = base ? base + off : nullptr;
+        off += round_up(n, 64);
+        return p;
+    }
+};
+
+constexpr int ACT_ROWS = 64;
+
+}  // namespace exorl
+
+using namespace exorl;
+
+struct exorl_agent {
+    exorl_agent_cfg cfg;
+    NetDesc actor, critic;
+    bool has_critic = false;
+    bool owns_ws = false;
+    float* ws = nullptr;
+    size_t ws_bytes = 0;
+    // flat parameter state: [net][what]
+    float* flat[3][4] = {{nullptr}};
+    // batch slots
+    float *obs = nullptr, *action = nullptr, *reward = nullptr, *discount = nullptr, *next_obs = nullptr;
+    // staged inputs
+    float *xa = nullptr, *xc_cur = nullptr, *xc_next = nullptr, *xc_pi = nullptr;
+    FwdBufs fa{}, ft{}, fc{};    // actor (2B rows), target critic, critic
+    BwdBufs bc{}, ba{};
+    float *dq = nullptr, *da = nullptr, *dpre = nullptr;
+    float *stats = nullptr, *metrics = nullptr;      // contiguous: stats[4] then metrics[EXORL_N_METRICS]
+    float *act_x = nullptr, *act_noise = nullptr;
+    FwdBufs fact{};
+    int64_t actor_t = 0, critic_t = 0;
+    uint64_t noise_counter = 0;
+    float inv_bg = 0.f;
+};
+
+namespace exorl {
+
+static void carve(exorl_agent* a, Carver& c) {
+    const auto& cfg = a->cfg;
+    const int64_t B = cfg.batch, O = cfg.obs_dim, A = cfg.act_dim, H = cfg.hidden_dim, W = O + A;
+    for (int w = 0; w < 4; ++w) a->flat[EXORL_NET_ACTOR][w] = c.take(a->actor.total);
+    if (a->has_critic) {
+        for (int w = 0; w < 4; ++w) a->flat[EXORL_NET_CRITIC][w] = c.take(a->critic.total);
+        a->flat[EXORL_NET_CRITIC_TARGET][EXORL_T_PARAM] = c.take(a->critic.total);
+    }
+    a->obs = c.take(B * O); a->action = c.take(B * A); a->reward = c.take(B); a->discount = c.take(B); a->next_obs = c.take(B * O);
+    a->xa = c.take(2 * B * O);
+    a->fa = FwdBufs{c.take(2 * B * H), c.take(2 * B * H), c.take(2 * B), c.take(2 * B * H), c.take(2 * B * A)};
+    a->ba = BwdBufs{c.take(B * H), c.take(B * H)};
+    a->dpre = c.take(B * A);
+    a->stats = c.take(4 + EXORL_N_METRICS);
+    a->metrics = a->stats ? a->stats + 4 : nullptr;
+    a->act_x = c.take(ACT_ROWS * O);
+    a->act_noise = c.take(ACT_ROWS * A);
+    a->fact = FwdBufs{c.take(ACT_ROWS * H), nullptr, nullptr, c.take(ACT_ROWS * H), c.take(ACT_ROWS * A)};
+    if (a->has_critic) {
+        const int64_t nt = a->critic.n_trunks;
+        a->xc_cur = c.take(B * W); a->xc_next = c.take(B * W); a->xc_pi = c.take(B * W);
+        a->ft = FwdBufs{c.take(nt * B * H), nullptr, nullptr, c.take(2 * B * H), c.take(2 * B)};
+        a->fc = FwdBufs{c.take(nt * B * H), c.take(nt * B * H), c.take(nt * B), c.take(2 * B * H), c.take(2 * B)};
+        a->bc = BwdBufs{c.take(2 * B * H), c.take(nt * B * H)};
+        a->dq = c.take(2 * B);
+        a->da = c.take(B * A);
+    }
+}
+
+static int describe(exorl_agent* a, const exorl_agent_cfg* cfg) {
+    EXORL_REQUIRE(cfg, "agent: null cfg");
+    EXORL_REQUIRE(cfg->kind >= EXORL_AGENT_TD3_BC && cfg->kind <= EXORL_AGENT_DDPG, "agent: unknown kind %d", cfg->kind);
+    EXORL_REQUIRE(cfg->obs_dim > 0 && cfg->act_dim > 0 && cfg->act_dim <= 16 && cfg->hidden_dim > 0 && cfg->hidden_dim <= 1024 &&
+                  cfg->batch > 0, "agent: unsupported dims O=%d A=%d (<=16) H=%d (<=1024) B=%d", cfg->obs_dim, cfg->act_dim,
+                  cfg->hidden_dim, cfg->batch);
+    EXORL_REQUIRE(cfg->precision == EXORL_PREC_F32 || cfg->precision == EXORL_PREC_BF16, "agent: unknown precision %d", cfg->precision);
+    EXORL_REQUIRE(cfg->world_size >= 1, "agent: world_size must be >= 1");
+    a->cfg = *cfg;
+    a->has_critic = cfg->kind != EXORL_AGENT_BC;
+    a->actor = make_net(cfg->obs_dim, cfg->act_dim, cfg->hidden_dim, 1, 1);
+    if (a->has_critic)
+        a->critic = make_net(cfg->obs_dim + cfg->act_dim, 1, cfg->hidden_dim, cfg->kind == EXORL_AGENT_DDPG ? 1 : 2, 2);
+    a->inv_bg = 1.0f / ((float)cfg->batch * (float)cfg->world_size);
+    return 0;
+}
+
+static NoiseSpec noise_spec(exorl_agent* a, const float* buf) {
+    NoiseSpec n{buf, a->cfg.seed, 0};
+    if (!buf) n.counter = a->noise_counter++;
+    return n;
+}
+
+// -- phase 0: everything up to the critic gradients -------------------------------------------------
+static int phase0(exorl_agent* a, float stddev, const float* noise_c, hipStream_t s) {
+    const auto& cfg = a->cfg;
+    const int B = cfg.batch, O = cfg.obs_dim, A = cfg.act_dim, W = O + A, prec = cfg.precision;
+    EXORL_TRY(prepare_inputs(a->obs, a->action, a->next_obs, a->xa, a->xc_cur, a->xc_next, a->xc_pi, B, O, A, a->has_critic, s));
+    if (!a->has_critic) return 0;
+    const float* Pa = a->flat[EXORL_NET_ACTOR][EXORL_T_PARAM];
+    const float* Pc = a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM];
+    const float* Pt = a->flat[EXORL_NET_CRITIC_TARGET][EXORL_T_PARAM];
+    // actor on [next_obs; obs] in one pass (td3_bc.py:124 and :149 use the same weights)
+    EXORL_TRY(net_forward(a->actor, Pa, a->xa, O, 2 * B, a->fa, true, true, prec, s));
+    // next_action = dist.sample(clip) (td3_bc.py:125) straight into the target critic's input
+    EXORL_TRY(sample_action(a->fa.out, noise_spec(a, noise_c), stddev, cfg.stddev_clip, 1, a->xc_next + O, W, B, A, nullptr, s));
+    EXORL_TRY(net_forward(a->critic, Pt, a->xc_next, W, B, a->ft, false, false, prec, s));     // td3_bc.py:126
+    EXORL_TRY(net_forward(a->critic, Pc, a->xc_cur, W, B, a->fc, true, false, prec, s));       // td3_bc.py:130
+    EXORL_TRY(critic_loss(a->fc.out, a->ft.out, a->reward, a->discount, a->dq, a->metrics, B, a->inv_bg, s));   // :127-131
+    EXORL_TRY(net_backward(a->critic, Pc, a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD], a->xc_cur, W, B, a->fc, a->dq, a->bc,
+                           nullptr, 0, 0, prec, s));                                                     // :141
+    return 0;
+}
+
+// -- phase 1: critic optimiser step (+ fused soft update), critic re-evaluated at pi(obs) -------------
+static int phase1(exorl_agent* a, float stddev, const float* noise_a, hipStream_t s) {
+    if (!a->has_critic) return 0;
+    const auto& cfg = a->cfg;
+    const int B = cfg.batch, O = cfg.obs_dim, A = cfg.act_dim, W = O + A, prec = cfg.precision;
+    a->critic_t += 1;
+    EXORL_TRY(adam_step(a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD],
+                        a->flat[EXORL_NET_CRITIC][EXORL_T_ADAM_M], a->flat[EXORL_NET_CRITIC][EXORL_T_ADAM_V], a->critic.total,
+                        cfg.lr, 0.9f, 0.999f, 1e-8f, a->critic_t, a->flat[EXORL_NET_CRITIC_TARGET][EXORL_T_PARAM], cfg.tau, s));
+    // policy.sample(clip) on obs (td3_bc.py:151): mu rows B..2B of the stacked actor forward
+    float* logprob = cfg.kind == EXORL_AGENT_DDPG ? a->metrics + EXORL_M_ACTOR_LOGPROB : nullptr;
+    EXORL_TRY(sample_action(a->fa.out + (int64_t)B * A, noise_spec(a, noise_a), stddev, cfg.stddev_clip, 1, a->xc_pi + O, W, B, A,
+                            logprob, s));
+    EXORL_TRY(net_forward(a->critic, a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->xc_pi, W, B, a->fc, true, false, prec, s));
+    EXORL_TRY(actor_stats(a->fc.out, a->stats, B, s));
+    return 0;
+}
+
+// -- phase 2: actor gradients -----------------------------------------------------------------------
+static int phase2(exorl_agent* a, float stddev, hipStream_t s) {
+    const auto& cfg = a->cfg;
+    const int B = cfg.batch, O = cfg.obs_dim, A = cfg.act_dim, W = O + A, H = cfg.hidden_dim, prec = cfg.precision;
+    const float* Pa = a->flat[EXORL_NET_ACTOR][EXORL_T_PARAM];
+    if (a->has_critic) {
+        EXORL_TRY(actor_dq(a->fc.out, a->stats, a->dq, B, a->inv_bg, cfg.alpha, cfg.kind == EXORL_AGENT_TD3_BC, s));
+        EXORL_TRY(net_backward(a->critic, a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], nullptr, a->xc_pi, W, B, a->fc, a->dq, a->bc,
+                               a->da, O, A, prec, s));
+    }
+    // the obs half (rows B..2B) of the stacked actor forward
+    FwdBufs f{a->fa.h1 + (int64_t)B * H, a->fa.xhat + (int64_t)B * H, a->fa.rstd + B, a->fa.h2 + (int64_t)B * H,
+              a->fa.out + (int64_t)B * A};
+    if (!a->has_critic)       // BC (bc.py:82): the only forward of the step
+        EXORL_TRY(net_forward(a->actor, Pa, a->xa + (int64_t)B * O, O, B, f, true, true, prec, s));
+    EXORL_TRY(actor_dmu(a->da, A, f.out, a->action, a->has_critic ? nullptr : a->reward, a->dpre, a->stats, a->metrics, B, A,
+                        a->inv_bg, cfg.alpha, cfg.kind, stddev, s));
+    EXORL_TRY(net_backward(a->actor, Pa, a->flat[EXORL_NET_ACTOR][EXORL_T_GRAD], a->xa + (int64_t)B * O, O, B, f, a->dpre, a->ba,
+                           nullptr, 0, 0, prec, s));
+    return 0;
+}
+
+static int phase3(exorl_agent* a, hipStream_t s) {
+    const auto& cfg = a->cfg;
+    a->actor_t += 1;
+    return adam_step(a->flat[EXORL_NET_ACTOR][EXORL_T_PARAM], a->flat[EXORL_NET_ACTOR][EXORL_T_GRAD],
+                     a->flat[EXORL_NET_ACTOR][EXORL_T_ADAM_M], a->flat[EXORL_NET_ACTOR][EXORL_T_ADAM_V], a->actor.total, cfg.lr,
+                     0.9f, 0.999f, 1e-8f, a->actor_t, nullptr, 0.f, s);
+}
+
+}  // namespace exorl
+
+extern "C" {
+
+size_t exorl_agent_workspace_bytes(const exorl_agent_cfg* cfg) {
+    exorl_agent tmp;
+    if (describe(&tmp, cfg) != 0) return 0;
+    Carver c(nullptr);
+    carve(&tmp, c);
+    return (size_t)c.off * sizeof(float);
+}
+
+int exorl_agent_create(const exorl_agent_cfg* cfg, void* workspace, size_t workspace_bytes, exorl_agent_t** out) {
+    EXORL_REQUIRE(out, "agent_create: null out");
+    auto* a = new exorl_agent();
+    if (int rc = describe(a, cfg)) { delete a; return rc; }
+    Carver sizing(nullptr);
+    carve(a, sizing);
+    const size_t need = (size_t)sizing.off * sizeof(float);
+    if (workspace) {
+        if (workspace_bytes < need || (uintptr_t)workspace % 256 != 0) {
+            set_error("agent_create: workspace %zu B (need %zu B, 256-byte aligned)", workspace_bytes, need);
+            delete a;
+            return 2;
+        }
+        a->ws = static_cast<float*>(workspace);
+    } else {
+        hipError_t e = hipMalloc((void**)&a->ws, need);
+        if (e != hipSuccess) { set_error("agent_create: hipMalloc(%zu) -> %s", need, hipGetErrorString(e)); delete a; return 1; }
+        a->owns_ws = true;
+    }
+    a->ws_bytes = need;
+    hipError_t e = hipMemset(a->ws, 0, need);
+    if (e != hipSuccess) { set_error("agent_create: hipMemset -> %s", hipGetErrorString(e)); if (a->owns_ws) (void)hipFree(a->ws); delete a; return 1; }
+    Carver c(a->ws);
+    carve(a, c);
+    *out = a;
+    return 0;
+}
+
+int exorl_agent_destroy(exorl_agent_t* a) {
+    if (!a) return 0;
+    if (a->owns_ws) (void)hipFree(a->ws);
+    delete a;
+    return 0;
+}
+
+static const NetDesc* net_of(exorl_agent_t* a, int32_t net) {
+    if (net == EXORL_NET_ACTOR) return &a->actor;
+    if ((net == EXORL_NET_CRITIC || net == EXORL_NET_CRITIC_TARGET) && a->has_critic) return &a->critic;
+    return nullptr;
+}
+
+int exorl_agent_num_tensors(exorl_agent_t* a, int32_t net, int32_t* n) {
+    EXORL_REQUIRE(a && n, "agent_num_tensors: null argument");
+    const NetDesc* d = net_of(a, net);
+    EXORL_REQUIRE(d, "agent_num_tensors: agent has no net %d", net);
+    *n = (int32_t)d->tensors.size();
+    return 0;
+}
+
+int exorl_agent_tensor(exorl_agent_t* a, int32_t net, int32_t index, int32_t what, void** ptr, int64_t* rows, int64_t* cols) {
+    EXORL_REQUIRE(a && ptr && rows && cols, "agent_tensor: null argument");
+    const NetDesc* d = net_of(a, net);
+    EXORL_REQUIRE(d, "agent_tensor: agent has no net %d", net);
+    EXORL_REQUIRE(index >= 0 && index < (int)d->tensors.size(), "agent_tensor: index %d out of range", index);
+    EXORL_REQUIRE(what >= 0 && what < 4 && a->flat[net][what], "agent_tensor: net %d has no buffer kind %d", net, what);
+    *ptr = a->flat[net][what] + d->tensors[index].off;
+    *rows = d->tensors[index].rows;
+    *cols = d->tensors[index].cols;
+    return 0;
+}
+
+int exorl_agent_flat(exorl_agent_t* a, int32_t net, int32_t what, void** ptr, int64_t* numel) {
+    EXORL_REQUIRE(a && ptr && numel, "agent_flat: null argument");
+    const NetDesc* d = net_of(a, net);
+    EXORL_REQUIRE(d && what >= 0 && what < 4 && a->flat[net][what], "agent_flat: no buffer net=%d what=%d", net, what);
+    *ptr = a->flat[net][what];
+    *numel = d->total;
+    return 0;
+}
+
+int exorl_agent_params_changed(exorl_agent_t* a, int32_t sync_target, void* stream) {
+    EXORL_REQUIRE(a, "agent_params_changed: null handle");
+    if (sync_target && a->has_critic)
+        EXORL_CHECK_HIP(hipMemcpyAsync(a->flat[EXORL_NET_CRITIC_TARGET][EXORL_T_PARAM], a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM],
+                                       a->critic.total * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)));
+    return 0;
+}
+
+int exorl_agent_batch_slots(exorl_agent_t* a, exorl_batch_out* out) {
+    EXORL_REQUIRE(a && out, "agent_batch_slots: null argument");
+    const int64_t O = a->cfg.obs_dim, A = a->cfg.act_dim;
+    out->obs = a->obs; out->obs_stride = O * 4;
+    out->action = a->action; out->action_stride = A;
+    out->reward = a->reward; out->discount = a->discount;
+    out->next_obs = a->next_obs; out->next_obs_stride = O * 4;
+    out->meta = nullptr; out->meta_stride = 0;
+    return 0;
+}
+
+int exorl_agent_set_batch(exorl_agent_t* a, const float* obs, const float* action, const float* reward, const float* discount,
+                          const float* next_obs, void* stream) {
+    EXORL_REQUIRE(a && obs && action && reward && discount && next_obs, "agent_set_batch: null argument");
+    hipStream_t s = as_stream(stream);
+    const size_t B = a->cfg.batch, O = a->cfg.obs_dim, A = a->cfg.act_dim;
+    EXORL_CHECK_HIP(hipMemcpyAsync(a->obs, obs, B * O * 4, hipMemcpyDeviceToDevice, s));
+    EXORL_CHECK_HIP(hipMemcpyAsync(a->action, action, B * A * 4, hipMemcpyDeviceToDevice, s));
+    EXORL_CHECK_HIP(hipMemcpyAsync(a->reward, reward, B * 4, hipMemcpyDeviceToDevice, s));
+    EXORL_CHECK_HIP(hipMemcpyAsync(a->discount, discount, B * 4, hipMemcpyDeviceToDevice, s));
+    EXORL_CHECK_HIP(hipMemcpyAsync(a->next_obs, next_obs, B * O * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int exorl_agent_update_phase(exorl_agent_t* a, int32_t phase, float stddev, const float* noise_c, const float* noise_a, void* stream) {
+    EXORL_REQUIRE(a, "agent_update_phase: null handle");
+    EXORL_REQUIRE(stddev > 0.f, "agent_update_phase: stddev must be > 0");
+    hipStream_t s = as_stream(stream);
+    switch (phase) {
+        case 0: return phase0(a, stddev, noise_c, s);
+        case 1: return phase1(a, stddev, noise_a, s);
+        case 2: return phase2(a, stddev, s);
+        case 3: return phase3(a, s);
+    }
+    set_error("agent_update_phase: phase %d out of range", phase);
+    return 2;
+}
+
+int exorl_agent_update(exorl_agent_t* a, float stddev, const float* noise_c, const float* noise_a, void* stream) {
+    for (int p = 0; p < 4; ++p) EXORL_TRY(exorl_agent_update_phase(a, p, stddev, noise_c, noise_a, stream));
+    return 0;
+}
+
+int exorl_agent_stats_buffer(exorl_agent_t* a, void** ptr, int64_t* numel) {
+    EXORL_REQUIRE(a && ptr && numel, "agent_stats_buffer: null argument");
+    *ptr = a->stats;
+    *numel = 4;
+    return 0;
+}
+
+int exorl_agent_act(exorl_agent_t* a, const float* obs, int32_t n, float stddev, int32_t eval_mode, const float* noise,
+                    float* out, void* stream) {
+    EXORL_REQUIRE(a && obs && out && n > 0, "agent_act: bad arguments");
+    hipStream_t s = as_stream(stream);
+    const int O = a->cfg.obs_dim, A = a->cfg.act_dim;
+    for (int r0 = 0; r0 < n; r0 += ACT_ROWS) {
+        const int rows = n - r0 < ACT_ROWS ? n - r0 : ACT_ROWS;
+        EXORL_TRY(net_forward(a->actor, a->flat[EXORL_NET_ACTOR][EXORL_T_PARAM], obs + (int64_t)r0 * O, O, rows, a->fact, false, true,
+                              a->cfg.precision, s));
+        if (eval_mode) {
+            EXORL_CHECK_HIP(hipMemcpyAsync(out + (int64_t)r0 * A, a->fact.out, (size_t)rows * A * 4, hipMemcpyDeviceToDevice, s));
+        } else {
+            EXORL_REQUIRE(stddev > 0.f, "agent_act: stddev must be > 0 in sampling mode");
+            EXORL_TRY(sample_action(a->fact.out, noise_spec(a, noise ? noise + (int64_t)r0 * A : nullptr), stddev, 0.f, 0,
+                                    out + (int64_t)r0 * A, A, rows, A, nullptr, s));
+        }
+    }
+    return 0;
+}
+
+int exorl_agent_metrics(exorl_agent_t* a, float* host, void* stream) {
+    EXORL_REQUIRE(a && host, "agent_metrics: null argument");
+    hipStream_t s = as_stream(stream);
+    EXORL_CHECK_HIP(hipMemcpyAsync(host, a->metrics, EXORL_N_METRICS * sizeof(float), hipMemcpyDeviceToHost, s));
+    EXORL_CHECK_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+int exorl_agent_opt_steps(exorl_agent_t* a, int64_t* actor_steps, int64_t* critic_steps) {
+    EXORL_REQUIRE(a, "agent_opt_steps: null handle");
+    if (actor_steps) *actor_steps = a->actor_t;
+    if (critic_steps) *critic_steps = a->critic_t;
+    return 0;
+}
+
+int exorl_agent_set_opt_steps(exorl_agent_t* a, int64_t actor_steps, int64_t critic_steps) {
+    EXORL_REQUIRE(a && actor_steps >= 0 && critic_steps >= 0, "agent_set_opt_steps: bad arguments");
+    a->actor_t = actor_steps;
+    a->critic_t = critic_steps;
+    return 0;
+}
+
+int exorl_agent_enable_graph(exorl_agent_t* a, exorl_replay_t* r, int32_t nstep, float gamma, float stddev) {
+    (void)a; (void)r; (void)nstep; (void)gamma; (void)stddev;
+    set_error("agent_enable_graph: hipGraph capture is not built in this revision");
+    return 3;
+}
+
+int exorl_agent_step_graph(exorl_agent_t* a, void* stream) {
+    (void)a; (void)stream;
+    set_error("agent_step_graph: no captured graph");
+    return 3;
+}
+
+}  // extern "C"

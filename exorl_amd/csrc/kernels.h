@@ -1,0 +1,57 @@
+// Internal C++ interface between the kernel translation units of libexorl_hip.so.
+#pragma once
+#include "common.h"
+
+namespace exorl {
+
+struct GemmProblem {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    int M, N, K;
+    int64_t lda, ldb, ldc;
+};
+int gemm_grouped(int precision, int a_layout, int b_layout, const GemmProblem* probs, int count, bool relu,
+                 bool accumulate, hipStream_t s);
+
+// ---- row-wise / column-wise layer kernels (rowops.hip). `nets` independent nets are processed by one
+// launch (blockIdx.y); a* strides are in floats between nets for activations, p* for parameters.
+int ln_tanh_fwd(const float* z, const float* gain, const float* beta, float* h, float* xhat, float* rstd,
+                int rows, int H, int nets, int64_t astride, int64_t pstride, hipStream_t s);
+int ln_tanh_bwd(const float* dh, const float* h, const float* xhat, const float* rstd, const float* gain, float* dz,
+                int rows, int H, int nets, int64_t astride, int64_t pstride, hipStream_t s);
+int ln_param_grad(const float* dh, const float* h, const float* xhat, float* dgain, float* dbeta,
+                  int rows, int H, int nets, int64_t astride, int64_t pstride, hipStream_t s);
+int colsum(const float* x, float* out, int rows, int cols, int nets, int64_t astride, int64_t pstride, hipStream_t s);
+int head_fwd(const float* a, const float* W, const float* b, float* out, int rows, int H, int nout, int tanh_out,
+             int nets, int64_t astride, int64_t pstride, int64_t ostride, hipStream_t s);
+int head_bwd_dx(const float* dout, const float* W, const float* a, float* dz, int rows, int H, int nout,
+                int nets, int64_t astride, int64_t pstride, int64_t dstride, hipStream_t s);
+int head_bwd_params(const float* dout, const float* a, const float* dz, float* dW, float* db_hidden, float* db_out,
+                    int rows, int H, int nout, int nets, int64_t astride, int64_t pstride, int64_t dstride, hipStream_t s);
+
+// ---- loss / sampling kernels (loss.hip)
+struct NoiseSpec {           // where TruncatedNormal noise comes from
+    const float* buf;        // (B,A) standard normal draws, or nullptr -> Philox(seed, counter)
+    uint64_t seed;
+    uint64_t counter;
+};
+int prepare_inputs(const float* obs, const float* action, const float* next_obs, float* xa, float* xc_cur,
+                   float* xc_next, float* xc_pi, int B, int O, int A, int has_critic, hipStream_t s);
+int sample_action(const float* mu, NoiseSpec noise, float stddev, float clip, int use_clip, float* dst, int64_t dst_ld,
+                  int B, int A, float* logprob_sum, hipStream_t s);
+int critic_loss(const float* q, const float* tq, const float* reward, const float* discount, float* dq,
+                float* metrics, int B, float inv_bg, hipStream_t s);
+int actor_stats(const float* q, float* stats, int B, hipStream_t s);
+int actor_dq(const float* q, const float* stats, float* dq, int B, float inv_bg, float alpha, int use_lambda,
+             hipStream_t s);
+int actor_dmu(const float* da, int64_t da_ld, const float* mu, const float* a_data, const float* reward, float* dpre, float* stats,
+              float* metrics, int B, int A, float inv_bg, float alpha, int kind, float stddev, hipStream_t s);
+
+// ---- optimiser (optim.hip)
+int adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+              int64_t t, float* target, float tau, hipStream_t s);
+int soft_update(const float* p, float* target, int64_t n, float tau, hipStream_t s);
+
+}  // namespace exorl

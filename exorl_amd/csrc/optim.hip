@@ -1,0 +1,94 @@
+// Fused Adam step (+ optional Polyak target update) over a net's flat parameter buffer:
+//   torch.optim.Adam defaults as constructed at td3_bc.py:96-97 (single-tensor CPU arithmetic)
+//   utils.soft_update_params, utils/utils.py:44-47 — fused into the critic's Adam pass: the target is not
+//   read between the critic step (td3_bc.py:142) and the soft update (td3_bc.py:186-187).
+// HBM-bound: 7 words/param (p,g,m,v read; p,m,v written) + 2 for the target (read+write); float4 streams.
+#include "kernels.h"
+
+namespace exorl {
+
+struct AdamConst {
+    float one_minus_b1, b2, one_minus_b2, bc2_sqrt, eps, neg_step_size, tau, one_minus_tau;
+};
+
+__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const AdamConst& c) {
+    // exp_avg.lerp_(g, 1-b1); exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2); p.addcdiv_(m, sqrt(v)/bc2_sqrt + eps, -lr/bc1)
+    m = m + c.one_minus_b1 * (g - m);
+    v = v * c.b2 + (c.one_minus_b2 * g) * g;
+    const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
+    p = p + (c.neg_step_size * m) / denom;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   float* __restrict__ target, int64_t n4, AdamConst c) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 mv = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        adam_elem(pv.x, gv.x, mv.x, vv.x, c);
+        adam_elem(pv.y, gv.y, mv.y, vv.y, c);
+        adam_elem(pv.z, gv.z, mv.z, vv.z, c);
+        adam_elem(pv.w, gv.w, mv.w, vv.w, c);
+        reinterpret_cast<float4*>(p)[i] = pv;
+        reinterpret_cast<float4*>(m)[i] = mv;
+        reinterpret_cast<float4*>(v)[i] = vv;
+        if (target) {
+            float4 tv = reinterpret_cast<float4*>(target)[i];
+            tv.x = c.tau * pv.x + c.one_minus_tau * tv.x;
+            tv.y = c.tau * pv.y + c.one_minus_tau * tv.y;
+            tv.z = c.tau * pv.z + c.one_minus_tau * tv.z;
+            tv.w = c.tau * pv.w + c.one_minus_tau * tv.w;
+            reinterpret_cast<float4*>(target)[i] = tv;
+        }
+    }
+}
+
+int adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+              int64_t t, float* target, float tau, hipStream_t s) {
+    EXORL_REQUIRE(n % 4 == 0, "adam_step: n=%lld must be a multiple of 4 (flat buffers are padded)", (long long)n);
+    EXORL_REQUIRE(t >= 1, "adam_step: step count t=%lld must be >= 1", (long long)t);
+    // Python-double scalar math of torch's _single_tensor_adam, then cast to fp32 like the tensor ops do
+    const double bc1 = 1.0 - pow((double)b1, (double)t);
+    const double bc2 = 1.0 - pow((double)b2, (double)t);
+    AdamConst c;
+    c.one_minus_b1 = (float)(1.0 - (double)b1);
+    c.b2 = b2;
+    c.one_minus_b2 = (float)(1.0 - (double)b2);
+    c.bc2_sqrt = (float)sqrt(bc2);
+    c.eps = eps;
+    c.neg_step_size = (float)(-((double)lr / bc1));
+    c.tau = tau;
+    c.one_minus_tau = (float)(1.0 - (double)tau);
+    const int64_t n4 = n / 4;
+    int blocks = cdiv(n4, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, target, n4, c);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void soft_update_kernel(const float* __restrict__ p, float* __restrict__ target,
+                                                          int64_t n, float tau, float one_minus_tau) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        target[i] = tau * p[i] + one_minus_tau * target[i];
+}
+
+int soft_update(const float* p, float* target, int64_t n, float tau, hipStream_t s) {
+    int blocks = cdiv(n, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(soft_update_kernel, dim3(blocks), dim3(256), 0, s, p, target, n, tau, (float)(1.0 - (double)tau));
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace exorl
+
+extern "C" int exorl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                               float beta2, float eps, int64_t t, float* target, float tau, void* stream) {
+    return exorl::adam_step(p, g, m, v, n, lr, beta1, beta2, eps, t, target, tau, exorl::as_stream(stream));
+}
+extern "C" int exorl_soft_update(const float* p, float* target, int64_t n, float tau, void* stream) {
+    return exorl::soft_update(p, target, n, tau, exorl::as_stream(stream));
+}

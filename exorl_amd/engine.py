@@ -1,0 +1,235 @@
+"""Thin object wrappers over the C ABI handles (exorl_agent_t, exorl_replay_t).
+
+torch is used here only as plumbing: it owns the device workspace (so parameters can be exposed as
+torch tensors for state_dict / pickling / torch.distributed all-reduce) and provides the stream.
+All arithmetic happens in libexorl_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+KIND = {'td3_bc': L.AGENT_TD3_BC, 'td3': L.AGENT_TD3, 'bc': L.AGENT_BC, 'ddpg': L.AGENT_DDPG}
+PRECISION = {'fp32': L.PREC_F32, 'f32': L.PREC_F32, 'bf16': L.PREC_BF16}
+METRIC_KEYS = {L.M_BATCH_REWARD: 'batch_reward', L.M_CRITIC_TARGET_Q: 'critic_target_q', L.M_CRITIC_Q1: 'critic_q1',
+               L.M_CRITIC_Q2: 'critic_q2', L.M_CRITIC_LOSS: 'critic_loss', L.M_ACTOR_LOSS: 'actor_loss',
+               L.M_ACTOR_LOGPROB: 'actor_logprob'}
+
+
+def _require_gpu(device):
+    if not torch.cuda.is_available():
+        raise L.ExorlError('exorl_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU path')
+    dev = torch.device(device)
+    if dev.type != 'cuda':
+        raise L.ExorlError(f"exorl_amd agents run on the GPU only; got device={device!r}")
+    return dev
+
+
+class AgentEngine:
+    def __init__(self, kind, obs_dim, act_dim, hidden_dim, batch, lr=1e-4, tau=0.01, alpha=2.5, stddev_clip=0.3,
+                 precision='fp32', world_size=1, seed=0, device='cuda'):
+        self.lib = L.load()
+        self.device = _require_gpu(device)
+        self.kind = kind
+        self.cfg = L.AgentCfg(KIND[kind], obs_dim, act_dim, hidden_dim, batch, PRECISION[precision], world_size, 0,
+                              lr, tau, alpha, stddev_clip if stddev_clip is not None else 0.0, seed)
+        self.obs_dim, self.act_dim, self.hidden_dim, self.batch = obs_dim, act_dim, hidden_dim, batch
+        nbytes = self.lib.exorl_agent_workspace_bytes(C.byref(self.cfg))
+        if nbytes == 0:
+            raise L.ExorlError(self.lib.exorl_last_error().decode())
+        with torch.cuda.device(self.device):
+            self.workspace = torch.zeros(nbytes + 256, dtype=torch.uint8, device=self.device)
+            base = self.workspace.data_ptr()
+            self._ws_off = (-base) % 256
+            handle = C.c_void_p()
+            L.check(self.lib.exorl_agent_create(C.byref(self.cfg), base + self._ws_off, nbytes, C.byref(handle)))
+        self.h = handle
+        self._f32 = self.workspace[self._ws_off:self._ws_off + nbytes].view(torch.float32)
+        self.has_critic = kind != 'bc'
+
+    def __del__(self):
+        h, self.h = getattr(self, 'h', None), None
+        if h:
+            self.lib.exorl_agent_destroy(h)
+
+    # ---- views of library-laid-out memory as torch tensors ------------------------------------------
+    def _view(self, ptr, numel):
+        off = (ptr - self._f32.data_ptr()) // 4
+        return self._f32[off:off + numel]
+
+    def num_tensors(self, net):
+        n = C.c_int32()
+        L.check(self.lib.exorl_agent_num_tensors(self.h, net, C.byref(n)))
+        return n.value
+
+    def tensor(self, net, index, what=L.T_PARAM):
+        p, r, c = C.c_void_p(), C.c_int64(), C.c_int64()
+        L.check(self.lib.exorl_agent_tensor(self.h, net, index, what, C.byref(p), C.byref(r), C.byref(c)))
+        v = self._view(p.value, r.value * c.value)
+        return v.view(r.value, c.value) if c.value > 1 else v
+
+    def tensor_shaped(self, net, index, shape, what=L.T_PARAM):
+        p, r, c = C.c_void_p(), C.c_int64(), C.c_int64()
+        L.check(self.lib.exorl_agent_tensor(self.h, net, index, what, C.byref(p), C.byref(r), C.byref(c)))
+        assert int(np.prod(shape)) == r.value * c.value, (shape, r.value, c.value)
+        return self._view(p.value, r.value * c.value).view(*shape)
+
+    def flat(self, net, what=L.T_PARAM):
+        p, n = C.c_void_p(), C.c_int64()
+        L.check(self.lib.exorl_agent_flat(self.h, net, what, C.byref(p), C.byref(n)))
+        return self._view(p.value, n.value)
+
+    def stats(self):
+        p, n = C.c_void_p(), C.c_int64()
+        L.check(self.lib.exorl_agent_stats_buffer(self.h, C.byref(p), C.byref(n)))
+        return self._view(p.value, n.value)
+
+    def batch_slots(self):
+        out = L.BatchOut()
+        L.check(self.lib.exorl_agent_batch_slots(self.h, C.byref(out)))
+        return out
+
+    # ---- operations ----------------------------------------------------------------------------------
+    def params_changed(self, sync_target=False):
+        L.check(self.lib.exorl_agent_params_changed(self.h, int(sync_target), L.current_stream()))
+
+    def set_batch(self, obs, action, reward, discount, next_obs):
+        ts = [self._dev(x) for x in (obs, action, reward, discount, next_obs)]
+        B = self.batch
+        for t, n in zip(ts, (B * self.obs_dim, B * self.act_dim, B, B, B * self.obs_dim)):
+            if t.numel() != n:
+                raise L.ExorlError(f'batch tensor has {t.numel()} elements, expected {n}')
+        L.check(self.lib.exorl_agent_set_batch(self.h, *[t.data_ptr() for t in ts], L.current_stream()))
+        self._keep = ts
+
+    def _dev(self, x):
+        t = torch.as_tensor(x)
+        if t.dtype != torch.float32:
+            t = t.float()
+        return t.to(self.device, non_blocking=True).contiguous()
+
+    def update(self, stddev, noise_critic=None, noise_actor=None):
+        nc = self._dev(noise_critic) if noise_critic is not None else None
+        na = self._dev(noise_actor) if noise_actor is not None else None
+        L.check(self.lib.exorl_agent_update(self.h, stddev, L.ptr(nc), L.ptr(na), L.current_stream()))
+        self._keep_noise = (nc, na)
+
+    def update_phase(self, phase, stddev, noise_critic=None, noise_actor=None):
+        nc = self._dev(noise_critic) if noise_critic is not None else None
+        na = self._dev(noise_actor) if noise_actor is not None else None
+        L.check(self.lib.exorl_agent_update_phase(self.h, phase, stddev, L.ptr(nc), L.ptr(na), L.current_stream()))
+        self._keep_noise = (nc, na)
+
+    def act(self, obs, stddev, eval_mode, noise=None):
+        o = self._dev(obs).view(-1, self.obs_dim)
+        n = o.shape[0]
+        out = torch.empty(n, self.act_dim, dtype=torch.float32, device=self.device)
+        nz = self._dev(noise) if noise is not None else None
+        L.check(self.lib.exorl_agent_act(self.h, o.data_ptr(), n, stddev, int(eval_mode), L.ptr(nz), out.data_ptr(),
+                                         L.current_stream()))
+        return out
+
+    def metrics_raw(self):
+        host = np.zeros(L.N_METRICS, np.float32)
+        L.check(self.lib.exorl_agent_metrics(self.h, host.ctypes.data, L.current_stream()))
+        return host
+
+    def opt_steps(self):
+        a, c = C.c_int64(), C.c_int64()
+        L.check(self.lib.exorl_agent_opt_steps(self.h, C.byref(a), C.byref(c)))
+        return a.value, c.value
+
+    def set_opt_steps(self, actor_steps, critic_steps):
+        L.check(self.lib.exorl_agent_set_opt_steps(self.h, actor_steps, critic_steps))
+
+
+class ReplayEngine:
+    """HBM-resident episodic arena (exorl_replay_t)."""
+
+    def __init__(self, obs_shape, obs_dtype, act_dim, meta_dim, capacity_rows, max_episodes, device='cuda'):
+        self.lib = L.load()
+        self.device = _require_gpu(device)
+        self.obs_shape = tuple(obs_shape)
+        self.obs_dtype = np.dtype(obs_dtype)
+        self.obs_bytes = int(np.prod(self.obs_shape)) * self.obs_dtype.itemsize
+        self.act_dim, self.meta_dim = act_dim, meta_dim
+        cfg = L.ReplayCfg(self.obs_bytes, act_dim, meta_dim, max_episodes, capacity_rows)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.exorl_replay_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        h, self.h = getattr(self, 'h', None), None
+        if h:
+            self.lib.exorl_replay_destroy(h)
+
+    def append_episode(self, ep, meta_keys=()):
+        obs = np.ascontiguousarray(ep['observation'])
+        rows = obs.shape[0]
+        assert obs.dtype == self.obs_dtype and obs.reshape(rows, -1).shape[1] * obs.itemsize == self.obs_bytes
+        act = np.ascontiguousarray(ep['action'], np.float32).reshape(rows, -1)
+        rew = np.ascontiguousarray(ep['reward'], np.float32).reshape(rows)
+        disc = np.ascontiguousarray(ep['discount'], np.float32).reshape(rows)
+        meta = None
+        if self.meta_dim:
+            meta = np.ascontiguousarray(np.concatenate([np.asarray(ep[k], np.float32).reshape(rows, -1) for k in meta_keys], 1))
+            assert meta.shape[1] == self.meta_dim
+        slot = C.c_int32()
+        L.check(self.lib.exorl_replay_append_episode(self.h, obs.ctypes.data, act.ctypes.data, rew.ctypes.data,
+                                                     disc.ctypes.data, L.ptr(meta), rows, C.byref(slot)))
+        return slot.value
+
+    def evict(self, slot):
+        L.check(self.lib.exorl_replay_evict(self.h, slot))
+
+    def set_order(self, slots):
+        arr = np.ascontiguousarray(slots, np.int32)
+        L.check(self.lib.exorl_replay_set_order(self.h, arr.ctypes.data, len(arr)))
+
+    def seed_mt_from_globals(self):
+        """Adopts the CURRENT state of Python's `random` and NumPy's legacy global generator — the two
+        streams replay_buffer.py:169,222 draw from — so the index stream continues exactly where the
+        reference's would (valid for num_workers=0; workers reseed unreproducibly, replay_buffer.py:241-244)."""
+        import random
+        st = random.getstate()[1]
+        py_key, py_pos = np.array(st[:-1], np.uint32), int(st[-1])
+        ns = np.random.get_state()
+        np_key, np_pos = np.ascontiguousarray(ns[1], np.uint32), int(ns[2])
+        L.check(self.lib.exorl_replay_seed_mt(self.h, py_key.ctypes.data, py_pos, np_key.ctypes.data, np_pos))
+
+    def seed_mt_ints(self, py_seed, np_seed):
+        L.check(self.lib.exorl_replay_seed_mt_ints(self.h, py_seed, np_seed))
+
+    def seed_philox(self, seed):
+        L.check(self.lib.exorl_replay_seed_philox(self.h, seed))
+
+    def sample_into(self, out, batch, nstep, gamma, sampler, pairs=None, want_pairs=False):
+        pin = np.ascontiguousarray(pairs, np.int32) if pairs is not None else None
+        pout = np.zeros((batch, 2), np.int32) if want_pairs else None
+        L.check(self.lib.exorl_replay_sample(self.h, batch, nstep, gamma, sampler, L.ptr(pin), C.byref(out), L.ptr(pout),
+                                             L.current_stream()))
+        return pout
+
+    def last_pairs(self, batch):
+        out = np.zeros((batch, 2), np.int32)
+        L.check(self.lib.exorl_replay_last_pairs(self.h, batch, out.ctypes.data, L.current_stream()))
+        return out
+
+    def sample(self, batch, nstep, gamma, sampler=L.SAMPLER_MT19937, pairs=None, want_pairs=False):
+        """Allocates fresh output tensors (B,*obs_shape) (B,A) (B,1) (B,1) (B,*obs_shape) [(B,meta)]."""
+        tdt = torch.uint8 if self.obs_dtype == np.uint8 else torch.float32
+        dev = self.device
+        obs = torch.empty((batch,) + self.obs_shape, dtype=tdt, device=dev)
+        nobs = torch.empty_like(obs)
+        act = torch.empty(batch, self.act_dim, dtype=torch.float32, device=dev)
+        rew = torch.empty(batch, 1, dtype=torch.float32, device=dev)
+        disc = torch.empty(batch, 1, dtype=torch.float32, device=dev)
+        meta = torch.empty(batch, self.meta_dim, dtype=torch.float32, device=dev) if self.meta_dim else None
+        out = L.BatchOut(obs.data_ptr(), self.obs_bytes, act.data_ptr(), self.act_dim, rew.data_ptr(), disc.data_ptr(),
+                         nobs.data_ptr(), self.obs_bytes, L.ptr(meta), self.meta_dim)
+        p = self.sample_into(out, batch, nstep, gamma, sampler, pairs, want_pairs)
+        res = (obs, act, rew, disc, nobs) + ((meta,) if meta is not None else ())
+        return (res, p) if want_pairs else res

@@ -1,0 +1,289 @@
+"""Host-side mirror of the reference's replay interface, backed by the HBM arena in libexorl_hip.so.
+
+Same names, arguments and on-disk format as /root/reference/utils/replay_buffer.py:
+  ReplayBufferStorage(data_specs, meta_specs, replay_dir)      :103-150   (episode_{idx}_{len}.npz writer)
+  make_replay_loader(storage, max_size, batch_size, num_workers, save_snapshot, nstep, discount)  :260-277
+  iter(loader) / next(it) -> (obs, action, reward, discount, next_obs, *meta) batched           :214-239
+
+What is host logic here (file discovery, lexicographic ordering, eviction bookkeeping — :172-212) stays in
+Python; what was per-sample Python (episode pick, start index, gathers, n-step loop — :214-235, 30 us/sample)
+is one HIP launch per batch. Tensors come back on the GPU (the reference's next step was an H2D copy,
+utils.py:55-56, so agents accept either).
+"""
+import io
+import os
+from collections import defaultdict
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .engine import ReplayEngine
+
+
+def episode_len(episode):
+    # first row of every array is the reset step (zero action / reward): replay_buffer.py:13-15
+    return next(iter(episode.values())).shape[0] - 1
+
+
+def save_episode(episode, fn):
+    with io.BytesIO() as bs:
+        np.savez_compressed(bs, **episode)
+        bs.seek(0)
+        with Path(fn).open('wb') as f:
+            f.write(bs.read())
+
+
+def load_episode(fn):
+    with Path(fn).open('rb') as f:
+        z = np.load(f)
+        return {k: z[k] for k in z.keys()}
+
+
+class ReplayBufferStorage:
+    """Accumulates time-steps and writes finished episodes as episode_{idx}_{len}.npz."""
+
+    def __init__(self, data_specs, meta_specs, replay_dir):
+        self._data_specs = data_specs
+        self._meta_specs = meta_specs
+        self._replay_dir = Path(replay_dir)
+        self._replay_dir.mkdir(exist_ok=True)
+        self._current_episode = defaultdict(list)
+        self._num_episodes = 0
+        self._num_transitions = 0
+        for fn in self._replay_dir.glob('*.npz'):           # resume counters from what is on disk
+            self._num_episodes += 1
+            self._num_transitions += int(fn.stem.split('_')[2])
+
+    def __len__(self):
+        return self._num_transitions
+
+    def add(self, time_step, meta):
+        for key, value in meta.items():
+            self._current_episode[key].append(value)
+        for spec in self._data_specs:
+            value = time_step[spec.name]
+            if np.isscalar(value):
+                value = np.full(spec.shape, value, spec.dtype)
+            assert spec.shape == value.shape and spec.dtype == value.dtype
+            self._current_episode[spec.name].append(value)
+        if time_step.last():
+            episode = {}
+            for spec in list(self._data_specs) + list(self._meta_specs):
+                episode[spec.name] = np.array(self._current_episode[spec.name], spec.dtype)
+            self._current_episode = defaultdict(list)
+            self._store_episode(episode)
+
+    def _store_episode(self, episode):
+        idx, length = self._num_episodes, episode_len(episode)
+        self._num_episodes += 1
+        self._num_transitions += length
+        save_episode(episode, self._replay_dir / f'episode_{idx}_{length}.npz')
+
+
+class _Shard:
+    """One reference 'worker': its own resident set, limits and index streams (replay_buffer.py:153-212)."""
+
+    def __init__(self, loader, worker_id):
+        self.loader = loader
+        self.worker_id = worker_id
+        self.size = 0
+        self.fns = []                  # sorted, like ReplayBuffer._episode_fns
+        self.slot = {}                 # fn -> arena slot
+        self.length = {}
+        self.since_fetch = loader.fetch_every
+        self.dir_stamp = None
+        self.engine = None
+        self.seeded = False
+
+    def _ensure_engine(self, episode):
+        if self.engine is not None:
+            return
+        ld = self.loader
+        obs = episode['observation']
+        meta_dim = sum(int(np.prod(episode[k].shape[1:])) for k in ld.meta_keys)
+        max_eps = ld.max_episodes or max(4096, ld.max_size // 64)
+        cap = ld.capacity_rows or (ld.max_size + max_eps + obs.shape[0] + 1024)
+        self.engine = ReplayEngine(obs.shape[1:], obs.dtype, int(np.prod(episode['action'].shape[1:])), meta_dim, cap,
+                                   max_eps, ld.device)
+
+    def _store(self, fn):
+        ld = self.loader
+        try:
+            episode = load_episode(fn)
+        except Exception:
+            return False
+        n = episode_len(episode)
+        self._ensure_engine(episode)
+        while n + self.size > ld.max_size:
+            early = self.fns.pop(0)                       # lexicographically first (replay_buffer.py:178-182)
+            self.engine.evict(self.slot.pop(early))
+            self.size -= self.length.pop(early)
+            early.unlink(missing_ok=True)
+        self.slot[fn] = self.engine.append_episode(episode, ld.meta_keys)
+        self.length[fn] = n
+        self.fns.append(fn)
+        self.fns.sort()
+        self.size += n
+        self.engine.set_order([self.slot[f] for f in self.fns])
+        if not ld.save_snapshot:
+            fn.unlink(missing_ok=True)
+        return True
+
+    def try_fetch(self):
+        ld = self.loader
+        if self.since_fetch < ld.fetch_every:
+            return
+        self.since_fetch = 0
+        d = ld.storage._replay_dir
+        stamp = os.stat(d).st_mtime_ns
+        if stamp == self.dir_stamp and self.fns:
+            return                                         # nothing was added since the last scan
+        fetched = 0
+        for fn in sorted(d.glob('*.npz'), reverse=True):
+            idx, n = (int(x) for x in fn.stem.split('_')[1:])
+            if idx % ld.num_workers != self.worker_id:
+                continue
+            if fn in self.slot:
+                break
+            if fetched + n > ld.max_size:
+                break
+            fetched += n
+            if not self._store(fn):
+                break
+        self.dir_stamp = os.stat(d).st_mtime_ns
+
+
+class DeviceReplayLoader:
+    """What make_replay_loader returns: iterable whose iterator yields device-resident minibatches."""
+
+    def __init__(self, storage, max_size, batch_size, num_workers, save_snapshot, nstep, discount, fetch_every=1000,
+                 device='cuda', sampler='mt19937', seed=None, worker_ids=None, max_episodes=None, capacity_rows=None):
+        self.storage = storage
+        self.num_workers = max(1, num_workers)
+        self.max_size = max_size // self.num_workers          # replay_buffer.py:262
+        self.batch_size = batch_size
+        self.save_snapshot = save_snapshot
+        self.nstep = nstep
+        self.discount = discount
+        self.fetch_every = fetch_every
+        self.device = device
+        self.sampler = {'mt19937': L.SAMPLER_MT19937, 'philox': L.SAMPLER_PHILOX}[sampler]
+        self.seed = seed
+        self.meta_keys = tuple(s.name for s in getattr(storage, '_meta_specs', ()))
+        self.max_episodes = max_episodes
+        self.capacity_rows = capacity_rows
+        # which reference workers this process plays: all of them (single process) or a subset (one per DP rank)
+        self.worker_ids = list(range(self.num_workers)) if worker_ids is None else list(worker_ids)
+
+    def __iter__(self):
+        return DeviceReplayIterator(self)
+
+
+class DeviceReplayIterator:
+    def __init__(self, loader):
+        self.loader = loader
+        self.shards = [_Shard(loader, w) for w in loader.worker_ids]
+        self.turn = 0
+        self._seeded = False
+
+    def __iter__(self):
+        return self
+
+    def _seed(self, shard):
+        ld = self.loader
+        if ld.sampler == L.SAMPLER_MT19937:
+            if ld.num_workers == 1 and ld.seed is None:
+                shard.engine.seed_mt_from_globals()          # continue random / np.random exactly (num_workers=0 case)
+            else:                                            # _worker_init_fn: seed = np state word 0 + worker_id
+                base = int(np.random.get_state()[1][0]) if ld.seed is None else int(ld.seed)
+                shard.engine.seed_mt_ints(base + shard.worker_id, (base + shard.worker_id) & 0xFFFFFFFF)
+        else:
+            base = int(np.random.get_state()[1][0]) if ld.seed is None else int(ld.seed)
+            shard.engine.seed_philox(base + shard.worker_id)
+        shard.seeded = True
+
+    def _segments(self, shard, batch):
+        """Splits a batch where the reference would re-scan the directory mid-batch: it checks before EVERY
+        sample (replay_buffer.py:216,193) and scans once `fetch_every` samples have been drawn."""
+        done = 0
+        while done < batch:
+            if shard.since_fetch >= self.loader.fetch_every:
+                shard.try_fetch()
+                if not getattr(shard, 'seeded', False) and shard.engine is not None:
+                    self._seed(shard)
+            n = min(self.loader.fetch_every - shard.since_fetch, batch - done)
+            yield done, n
+            shard.since_fetch += n
+            done += n
+
+    def sample_into(self, out, batch=None):
+        """Zero-copy path: writes the next minibatch straight into caller-owned device memory (exorl_batch_out)."""
+        ld = self.loader
+        batch = batch or ld.batch_size
+        shard = self.shards[self.turn % len(self.shards)]
+        self.turn += 1
+        for start, n in self._segments(shard, batch):
+            if shard.engine is None or not shard.fns:
+                raise IndexError('replay buffer is empty (random.choice on an empty list, replay_buffer.py:169)')
+            seg = L.BatchOut(out.obs + start * out.obs_stride, out.obs_stride,
+                             out.action + start * out.action_stride * 4, out.action_stride,
+                             out.reward + start * 4, out.discount + start * 4,
+                             out.next_obs + start * out.next_obs_stride, out.next_obs_stride,
+                             (out.meta + start * out.meta_stride * 4) if out.meta else None, out.meta_stride)
+            shard.engine.sample_into(seg, n, ld.nstep, ld.discount, ld.sampler)
+
+    def __next__(self):
+        ld = self.loader
+        B = ld.batch_size
+        shard = self.shards[self.turn % len(self.shards)]
+        if shard.engine is None:                              # first batch: the scan that sample 0 would trigger
+            shard.try_fetch()
+            if shard.engine is None:
+                raise IndexError('replay buffer is empty (random.choice on an empty list, replay_buffer.py:169)')
+            self._seed(shard)
+        eng = shard.engine
+        tdt = torch.uint8 if eng.obs_dtype == np.uint8 else torch.float32
+        obs = torch.empty((B,) + eng.obs_shape, dtype=tdt, device=eng.device)
+        nobs = torch.empty_like(obs)
+        act = torch.empty(B, eng.act_dim, dtype=torch.float32, device=eng.device)
+        rew = torch.empty(B, 1, dtype=torch.float32, device=eng.device)
+        disc = torch.empty(B, 1, dtype=torch.float32, device=eng.device)
+        meta = torch.empty(B, eng.meta_dim, dtype=torch.float32, device=eng.device) if eng.meta_dim else None
+        out = L.BatchOut(obs.data_ptr(), eng.obs_bytes, act.data_ptr(), eng.act_dim, rew.data_ptr(), disc.data_ptr(),
+                         nobs.data_ptr(), eng.obs_bytes, L.ptr(meta), eng.meta_dim)
+        self.sample_into(out, B)
+        res = [obs, act, rew, disc, nobs]
+        if meta is not None:                                  # one tensor per meta spec, like the reference's *meta
+            o = 0
+            for spec in ld.storage._meta_specs:
+                w = int(np.prod(spec.shape))
+                res.append(meta[:, o:o + w].reshape((B,) + tuple(spec.shape)))
+                o += w
+        return tuple(res)
+
+
+def make_replay_loader(storage, max_size, batch_size, num_workers, save_snapshot, nstep=None, discount=None, **kw):
+    """replay_buffer.py:260-261 signature. Also accepts the 6-argument offline call shape that
+    train_offline.py:90-93 uses — (env, replay_dir, max_size, batch_size, num_workers, discount) — which the
+    reference's own 7-parameter function rejects."""
+    if discount is None and isinstance(max_size, (str, os.PathLike)):
+        env, replay_dir, max_size, batch_size, num_workers, discount = (storage, max_size, batch_size, num_workers,
+                                                                       save_snapshot, nstep)
+        return make_offline_replay_loader(env, replay_dir, max_size, batch_size, num_workers, discount, **kw)
+    return DeviceReplayLoader(storage, max_size, batch_size, num_workers, save_snapshot, nstep, discount, **kw)
+
+
+class _DirStorage:
+    """Minimal storage stand-in for a directory of pre-collected episodes (offline datasets)."""
+
+    def __init__(self, replay_dir, meta_specs=()):
+        self._replay_dir = Path(replay_dir)
+        self._meta_specs = tuple(meta_specs)
+
+
+def make_offline_replay_loader(env, replay_dir, max_size, batch_size, num_workers, discount, **kw):
+    """replay_buffer.py:246-258 (OfflineReplayBuffer semantics: nstep=1, files kept on disk). Reward
+    re-labelling through MuJoCo physics (relabel_episode, :31-42) is the caller's concern and out of scope."""
+    return DeviceReplayLoader(_DirStorage(replay_dir), max_size, batch_size, num_workers, True, 1, discount, **kw)

@@ -1,0 +1,212 @@
+/*
+ * exorl_hip.h — C ABI of libexorl_hip.so, the MI355X (gfx950) backend for the exorl RL-update hot path.
+ *
+ * Drop-in boundary. Each entry point names the reference interface it replaces
+ * (paths relative to the reference repo AOS55/exorl):
+ *
+ *   exorl_replay_*          utils/replay_buffer.py:153-239  ReplayBuffer (_store_episode, eviction,
+ *                           _sample: episode pick + start index + gather + n-step return) and
+ *                           :241-277 make_replay_loader / DataLoader collate (batched output)
+ *   exorl_agent_create      agents/offline_learning/td3_bc.py:59-100 (and td3.py, bc.py,
+ *                           agents/unsupervised_learning/ddpg.py:126-197) constructors
+ *   exorl_agent_update*     td3_bc.py:119-189, td3.py:117-186, bc.py:78-110, ddpg.py:240-328
+ *                           (update_critic / update_actor / soft_update_params / update)
+ *   exorl_agent_act         td3_bc.py:107-117, ddpg.py:221-238
+ *   exorl_adam_step         torch.optim.Adam.step as used at td3_bc.py:96-97,142,160
+ *   exorl_soft_update       utils/utils.py:44-47
+ *   exorl_knn_*             utils/utils.py:279-319 (PBE) and unsupervised_learning/proto.py:114-119
+ *
+ * Conventions: plain pointers and sizes only (no torch types). Every function returns 0 on success,
+ * non-zero on error; exorl_last_error() returns the message of the calling thread's last error.
+ * All device work is enqueued on the `stream` argument (a hipStream_t passed as void*; NULL = the
+ * default stream) and is asynchronous unless stated. Pointers named *_dev are device pointers,
+ * *_host host pointers. One host thread per GPU; handles are not thread-safe.
+ */
+#ifndef EXORL_HIP_H
+#define EXORL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EXORL_ABI_VERSION 1
+
+const char* exorl_last_error(void);
+int exorl_abi_version(void);
+/* device name / CU count of the current HIP device (fails if none). */
+int exorl_device_info(char* name_out, int name_len, int* num_cus, int64_t* hbm_bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * Replay: episodic buffer resident in HBM.
+ * Arena layout (SoA, row = one time-step; episode = len+1 consecutive rows, row 0 the dummy reset step):
+ *   obs[rows][obs_bytes]  action[rows][act_dim] f32  reward[rows] f32  discount[rows] f32  meta[rows][meta_dim] f32
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct exorl_replay exorl_replay_t;
+
+typedef struct {
+    int32_t obs_bytes;      /* bytes per observation row: O*4 (f32 states) or C*H*W (u8 pixels); multiple of 4 */
+    int32_t act_dim;
+    int32_t meta_dim;       /* total width of the concatenated meta columns (0 = none) */
+    int32_t max_episodes;
+    int64_t capacity_rows;  /* arena rows = transitions + one dummy row per episode */
+} exorl_replay_cfg;
+
+typedef struct {            /* where one sampled minibatch is written (device memory, caller-owned) */
+    void*   obs;       int64_t obs_stride;       /* bytes between consecutive samples */
+    float*  action;    int64_t action_stride;    /* floats between consecutive samples */
+    float*  reward;                              /* (B) contiguous */
+    float*  discount;                            /* (B) contiguous */
+    void*   next_obs;  int64_t next_obs_stride;  /* bytes */
+    float*  meta;      int64_t meta_stride;      /* floats; may be NULL when meta_dim == 0 */
+} exorl_batch_out;
+
+#define EXORL_SAMPLER_MT19937 0   /* reference-exact index stream (CPython random + NumPy legacy RandomState) */
+#define EXORL_SAMPLER_PHILOX  1   /* device-side counter-based stream, same distribution */
+#define EXORL_SAMPLER_GIVEN   2   /* (episode position, start idx) pairs supplied by the caller */
+
+int exorl_replay_create(const exorl_replay_cfg* cfg, exorl_replay_t** out);
+int exorl_replay_destroy(exorl_replay_t* r);
+/* Copies one episode (rows = len+1 host rows per array) into the arena; returns its slot id. */
+int exorl_replay_append_episode(exorl_replay_t* r, const void* obs_host, const float* act_host,
+                                const float* rew_host, const float* disc_host, const float* meta_host,
+                                int32_t rows, int32_t* slot_out);
+int exorl_replay_evict(exorl_replay_t* r, int32_t slot);
+/* Sampling order of resident episodes = the reference's sorted `_episode_fns` list (replay_buffer.py:184). */
+int exorl_replay_set_order(exorl_replay_t* r, const int32_t* slots_host, int32_t n);
+int exorl_replay_num_rows(exorl_replay_t* r, int64_t* live_rows, int64_t* used_rows);
+/* MT19937 states as exposed by random.getstate()[1] / np.random.get_state()[1:3]. */
+int exorl_replay_seed_mt(exorl_replay_t* r, const uint32_t* py_key624, int32_t py_pos,
+                         const uint32_t* np_key624, int32_t np_pos);
+/* Convenience for callers without a Python interpreter: random.seed(py_seed); np.random.seed(np_seed). */
+int exorl_replay_seed_mt_ints(exorl_replay_t* r, uint64_t py_seed, uint32_t np_seed);
+int exorl_replay_get_mt(exorl_replay_t* r, uint32_t* py_key624, int32_t* py_pos,
+                        uint32_t* np_key624, int32_t* np_pos);
+int exorl_replay_seed_philox(exorl_replay_t* r, uint64_t seed);
+/* One minibatch: B x (obs[idx-1], action[idx], n-step reward, n-step discount, obs[idx+n-1], meta[idx-1]).
+ * pairs_host: for EXORL_SAMPLER_GIVEN, B x {position in order, start idx >= 1};
+ * pairs_out_host: if non-NULL receives the pairs drawn (MT19937 mode only; host-generated). */
+int exorl_replay_sample(exorl_replay_t* r, int32_t batch, int32_t nstep, float gamma, int32_t sampler,
+                        const int32_t* pairs_host, const exorl_batch_out* out, int32_t* pairs_out_host,
+                        void* stream);
+
+/* Synchronous: the (position, start idx) pairs of the last sample call, read back from the device. */
+int exorl_replay_last_pairs(exorl_replay_t* r, int32_t batch, int32_t* pairs_host, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Agents
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct exorl_agent exorl_agent_t;
+
+#define EXORL_AGENT_TD3_BC 0
+#define EXORL_AGENT_TD3    1
+#define EXORL_AGENT_BC     2
+#define EXORL_AGENT_DDPG   3   /* states; shared-trunk critic (ddpg.py:79-123) */
+
+#define EXORL_PREC_F32  0      /* v_mfma_f32_32x32x2_f32: exact fp32 products, parity mode */
+#define EXORL_PREC_BF16 1      /* v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulate, fp32 master weights */
+
+#define EXORL_NET_ACTOR         0
+#define EXORL_NET_CRITIC        1
+#define EXORL_NET_CRITIC_TARGET 2
+
+#define EXORL_T_PARAM 0
+#define EXORL_T_GRAD  1
+#define EXORL_T_ADAM_M 2
+#define EXORL_T_ADAM_V 3
+
+/* metrics[] layout written by exorl_agent_metrics (same keys as the reference's metrics dict) */
+#define EXORL_M_BATCH_REWARD    0
+#define EXORL_M_CRITIC_TARGET_Q 1
+#define EXORL_M_CRITIC_Q1       2
+#define EXORL_M_CRITIC_Q2       3
+#define EXORL_M_CRITIC_LOSS     4
+#define EXORL_M_ACTOR_LOSS      5
+#define EXORL_M_ACTOR_LOGPROB   6
+#define EXORL_M_Q_ABS_SUM       7   /* local sum |Q| (DP scalar all-reduce operand) */
+#define EXORL_M_Q_SUM           8   /* local sum  Q  */
+#define EXORL_M_BC_SUM          9   /* local sum (mu-a)^2 */
+#define EXORL_N_METRICS        16
+
+typedef struct {
+    int32_t kind;
+    int32_t obs_dim, act_dim, hidden_dim;
+    int32_t batch;            /* rows per update on THIS rank */
+    int32_t precision;        /* EXORL_PREC_* */
+    int32_t world_size;       /* data-parallel ranks; losses are means over batch*world_size */
+    int32_t reserved;
+    float   lr, tau, alpha, stddev_clip;
+    uint64_t seed;            /* Philox stream for action noise when no noise buffer is given */
+} exorl_agent_cfg;
+
+size_t exorl_agent_workspace_bytes(const exorl_agent_cfg* cfg);
+/* workspace_dev: caller-allocated device memory of at least exorl_agent_workspace_bytes (e.g. a torch
+ * tensor's data_ptr) or NULL to let the library hipMalloc it. Contents are zero-initialised. */
+int exorl_agent_create(const exorl_agent_cfg* cfg, void* workspace_dev, size_t workspace_bytes,
+                       exorl_agent_t** out);
+int exorl_agent_destroy(exorl_agent_t* a);
+/* Number of parameter tensors of a net, in the reference's nn.Module.parameters() order. */
+int exorl_agent_num_tensors(exorl_agent_t* a, int32_t net, int32_t* n);
+/* Device pointer + logical shape (rows x cols; cols = 1 for vectors) of one tensor. */
+int exorl_agent_tensor(exorl_agent_t* a, int32_t net, int32_t index, int32_t what,
+                       void** ptr_dev, int64_t* rows, int64_t* cols);
+/* The flat (padded) buffer that holds all tensors of a net back to back: all-reduce operand. */
+int exorl_agent_flat(exorl_agent_t* a, int32_t net, int32_t what, void** ptr_dev, int64_t* numel);
+/* Must be called after parameters were written from outside (load_state_dict, init): refreshes derived
+ * copies (bf16 shadows) and, if sync_target != 0, copies critic -> critic_target (td3_bc.py:93). */
+int exorl_agent_params_changed(exorl_agent_t* a, int32_t sync_target, void* stream);
+/* Where the sampler should write this agent's minibatch (zero-copy hand-off replay -> update). */
+int exorl_agent_batch_slots(exorl_agent_t* a, exorl_batch_out* out);
+/* Copies a caller-provided device batch (contiguous f32 (B,O) (B,A) (B) (B) (B,O)) into the batch slots. */
+int exorl_agent_set_batch(exorl_agent_t* a, const float* obs_dev, const float* action_dev,
+                          const float* reward_dev, const float* discount_dev, const float* next_obs_dev,
+                          void* stream);
+/* One gradient step on the batch currently in the batch slots.
+ * noise_critic_dev / noise_actor_dev: (B,A) standard-normal draws (reference order) or NULL
+ * for device Philox. Runs phases 0..3 back to back (world_size 1). */
+int exorl_agent_update(exorl_agent_t* a, float stddev, const float* noise_critic_dev,
+                       const float* noise_actor_dev, void* stream);
+/* Data-parallel form: the caller all-reduces (sum) between phases:
+ *   phase 0 -> critic grads ready       (all-reduce EXORL_NET_CRITIC / EXORL_T_GRAD flat buffer)
+ *   phase 1 -> critic Adam + soft update, actor-side Q statistics ready (all-reduce the 4-float stats buffer)
+ *   phase 2 -> actor grads ready        (all-reduce EXORL_NET_ACTOR / EXORL_T_GRAD flat buffer)
+ *   phase 3 -> actor Adam
+ * BC has phases 2 and 3 only. */
+int exorl_agent_update_phase(exorl_agent_t* a, int32_t phase, float stddev, const float* noise_critic_dev,
+                             const float* noise_actor_dev, void* stream);
+int exorl_agent_stats_buffer(exorl_agent_t* a, void** ptr_dev, int64_t* numel);
+/* Policy inference for n rows: out = mean (eval) or TruncatedNormal sample (clip=None). */
+int exorl_agent_act(exorl_agent_t* a, const float* obs_dev, int32_t n, float stddev, int32_t eval_mode,
+                    const float* noise_dev, float* action_out_dev, void* stream);
+/* Synchronous: copies the metric block of the last update to host. */
+int exorl_agent_metrics(exorl_agent_t* a, float* metrics_host, void* stream);
+int exorl_agent_opt_steps(exorl_agent_t* a, int64_t* actor_steps, int64_t* critic_steps);
+int exorl_agent_set_opt_steps(exorl_agent_t* a, int64_t actor_steps, int64_t critic_steps);
+/* Captures exorl_replay_sample(PHILOX)+exorl_agent_update into a hipGraph replayed by exorl_agent_step_graph. */
+int exorl_agent_enable_graph(exorl_agent_t* a, exorl_replay_t* r, int32_t nstep, float gamma, float stddev);
+int exorl_agent_step_graph(exorl_agent_t* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stand-alone operators (used by the agents above; exported for tests and for callers' own nets)
+ * ---------------------------------------------------------------------------------------------- */
+/* C[M,N] = op(A) * op(B) (+bias[N]) (ReLU) (C +=), fp32 in memory.
+ * a_layout: 0 = A stored [M][K] (lda >= K), 1 = A stored [K][M] (lda >= M)
+ * b_layout: 0 = B stored [N][K] (ldb >= K)  (nn.Linear weight), 1 = B stored [K][N] (ldb >= N) */
+int exorl_gemm(int32_t precision, int32_t a_layout, int32_t b_layout, int32_t M, int32_t N, int32_t K,
+               const float* A_dev, int64_t lda, const float* B_dev, int64_t ldb, float* C_dev, int64_t ldc,
+               const float* bias_dev, int32_t relu, int32_t accumulate, void* stream);
+int exorl_adam_step(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, float lr,
+                    float beta1, float beta2, float eps, int64_t t, float* target_dev, float tau, void* stream);
+int exorl_soft_update(const float* p_dev, float* target_dev, int64_t n, float tau, void* stream);
+int exorl_ln_tanh_fwd(const float* z_dev, const float* gain_dev, const float* beta_dev, float* h_dev,
+                      float* xhat_dev, float* rstd_dev, int32_t rows, int32_t H, void* stream);
+/* kNN particle-entropy building block: out[i][j] = j-th smallest L2 distance from src row i to the tgt rows (sorted). */
+int exorl_knn_topk(const float* src_dev, int32_t n_src, const float* tgt_dev, int32_t n_tgt, int32_t dim,
+                   int32_t k, float* out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EXORL_HIP_H */

@@ -1,0 +1,153 @@
+"""GPU parity of the stand-alone operators, called through the C ABI (libexorl_hip.so) and checked
+against the oracle / fp64 numpy on the same seeded inputs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from exorl_amd import _lib
+    return _lib.load()
+
+
+def dev(x):
+    return torch.as_tensor(np.ascontiguousarray(x)).cuda()
+
+
+def bf16_round(x):
+    return torch.from_numpy(x).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+SHAPES = [(64, 64, 32), (100, 70, 50), (1, 6, 1024), (1024, 1024, 1024), (1024, 30, 1024), (37, 129, 67), (2048, 1024, 24)]
+
+
+@pytest.mark.parametrize('prec', [0, 1])
+@pytest.mark.parametrize('al,bl', [(0, 0), (0, 1), (1, 1), (1, 0)])
+@pytest.mark.parametrize('M,N,K', SHAPES)
+def test_gemm(lib, prec, al, bl, M, N, K):
+    from exorl_amd import _lib as L
+    rs = np.random.RandomState(M * 7 + N * 3 + K + al * 2 + bl)
+    A = rs.standard_normal((M, K)).astype(np.float32)
+    B = rs.standard_normal((K, N)).astype(np.float32)         # logical [K][N]
+    bias = rs.standard_normal(N).astype(np.float32)
+    C0 = rs.standard_normal((M, N)).astype(np.float32)
+    A_st = A if al == 0 else np.ascontiguousarray(A.T)         # al=1: stored [K][M]
+    B_st = np.ascontiguousarray(B.T) if bl == 0 else B         # bl=0: stored [N][K]
+    a, b, c, bi = dev(A_st), dev(B_st), dev(C0.copy()), dev(bias)
+    for relu, acc in ((0, 0), (1, 0), (0, 1)):
+        c.copy_(torch.from_numpy(C0))
+        L.check(lib.exorl_gemm(prec, al, bl, M, N, K, a.data_ptr(), A_st.shape[1], b.data_ptr(), B_st.shape[1],
+                               c.data_ptr(), N, bi.data_ptr(), relu, acc, None))
+        torch.cuda.synchronize()
+        Ar, Br = (A, B) if prec == 0 else (bf16_round(A), bf16_round(B))
+        ref = Ar.astype(np.float64) @ Br.astype(np.float64) + bias
+        if relu:
+            ref = np.maximum(ref, 0)
+        if acc:
+            ref = ref + C0
+        scale = np.abs(Ar).astype(np.float64) @ np.abs(Br).astype(np.float64) + 1.0
+        err = np.abs(c.cpu().numpy() - ref) / scale
+        assert err.max() < 2e-6, (prec, al, bl, M, N, K, relu, acc, err.max())   # fp32 accumulation order only
+
+
+def test_gemm_f32_is_exact_fp32_products(lib):
+    """Parity mode must not round operands: integers up to 2^12 multiply exactly in fp32 MFMA."""
+    from exorl_amd import _lib as L
+    rs = np.random.RandomState(0)
+    A = rs.randint(-4096, 4096, (64, 64)).astype(np.float32)
+    B = rs.randint(-4, 4, (64, 64)).astype(np.float32)
+    B[np.arange(64), np.arange(64)] += 7              # asymmetric
+    a, b, c = dev(A), dev(np.ascontiguousarray(B.T)), torch.zeros(64, 64, device='cuda')
+    L.check(lib.exorl_gemm(0, 0, 0, 64, 64, 64, a.data_ptr(), 64, b.data_ptr(), 64, c.data_ptr(), 64, None, 0, 0, None))
+    assert np.array_equal(c.cpu().numpy(), (A.astype(np.float64) @ B.astype(np.float64)).astype(np.float32))
+
+
+@pytest.mark.parametrize('rows,H', [(8, 32), (5, 50), (1024, 1024), (3, 1000)])
+def test_ln_tanh_fwd(lib, rows, H):
+    from exorl_amd import _lib as L
+    from oracle import nets
+    rs = np.random.RandomState(rows + H)
+    z = (rs.standard_normal((rows, H)) * 2 + 0.3).astype(np.float32)
+    g = (1 + 0.1 * rs.standard_normal(H)).astype(np.float32)
+    b = (0.1 * rs.standard_normal(H)).astype(np.float32)
+    zd, gd, bd = dev(z), dev(g), dev(b)
+    h, xh, rstd = torch.empty_like(zd), torch.empty_like(zd), torch.empty(rows, device='cuda')
+    L.check(lib.exorl_ln_tanh_fwd(zd.data_ptr(), gd.data_ptr(), bd.data_ptr(), h.data_ptr(), xh.data_ptr(), rstd.data_ptr(),
+                                  rows, H, None))
+    y, xhat, rs_ = nets.layernorm_fwd(z, g, b)
+    np.testing.assert_allclose(xh.cpu().numpy(), xhat, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(h.cpu().numpy(), np.tanh(y), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(rstd.cpu().numpy(), rs_[:, 0], rtol=2e-6)
+    # in place (z aliases h) is how the agent calls it
+    L.check(lib.exorl_ln_tanh_fwd(zd.data_ptr(), gd.data_ptr(), bd.data_ptr(), zd.data_ptr(), None, None, rows, H, None))
+    assert torch.equal(zd, h)
+
+
+def test_adam_and_soft_update_golden(lib, gold):
+    """Against the reference's own torch.optim.Adam / soft_update_params outputs (utils_g2.npz)."""
+    from exorl_amd import _lib as L
+    z = np.load(gold / 'utils_g2.npz')
+    n = 36                                              # 33 padded to a multiple of 4
+    p = torch.zeros(n, device='cuda'); p[:33] = dev(z['adam_p0'])
+    m, v, g = torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    for t, (grad, want) in enumerate(zip(z['adam_grads'], z['adam_p']), 1):
+        g[:33] = dev(grad)
+        L.check(lib.exorl_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-4, 0.9, 0.999, 1e-8, t,
+                                    None, 0.0, None))
+        np.testing.assert_allclose(p[:33].cpu().numpy(), want, rtol=0, atol=1e-9)
+    assert float(p[33:].abs().max()) == 0.0             # padding stays zero
+    w, tw = dev(z['soft_w']).reshape(-1), dev(z['soft_tw0']).reshape(-1)
+    L.check(lib.exorl_soft_update(w.data_ptr(), tw.data_ptr(), w.numel(), 0.01, None))
+    np.testing.assert_allclose(tw.cpu().numpy(), z['soft_tw1'].reshape(-1), rtol=0, atol=6e-8)
+
+
+def test_adam_fused_soft_update_equals_separate(lib):
+    from exorl_amd import _lib as L
+    rs = np.random.RandomState(3)
+    n = 4096
+    p0, g0, t0 = [rs.standard_normal(n).astype(np.float32) for _ in range(3)]
+    pa, ga, ma, va, ta = dev(p0), dev(g0), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda'), dev(t0)
+    pb, mb, vb, tb = dev(p0), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda'), dev(t0)
+    L.check(lib.exorl_adam_step(pa.data_ptr(), ga.data_ptr(), ma.data_ptr(), va.data_ptr(), n, 1e-4, 0.9, 0.999, 1e-8, 1,
+                                ta.data_ptr(), 0.01, None))
+    L.check(lib.exorl_adam_step(pb.data_ptr(), ga.data_ptr(), mb.data_ptr(), vb.data_ptr(), n, 1e-4, 0.9, 0.999, 1e-8, 1, None, 0.0, None))
+    L.check(lib.exorl_soft_update(pb.data_ptr(), tb.data_ptr(), n, 0.01, None))
+    assert torch.equal(pa, pb) and torch.equal(ta, tb)
+
+
+@pytest.mark.parametrize('ns,nt,dim,k', [(16, 16, 8, 3), (10, 20, 6, 3), (1024, 1024, 512, 12), (1024, 2048, 128, 3), (7, 100, 70, 5)])
+def test_knn_topk(lib, gold, ns, nt, dim, k):
+    from exorl_amd import _lib as L
+    from oracle import knn
+    rs = np.random.RandomState(ns + nt)
+    same = ns == nt
+    src = rs.standard_normal((ns, dim)).astype(np.float32)
+    tgt = src if same else rs.standard_normal((nt, dim)).astype(np.float32)
+    out = torch.empty(ns, k, device='cuda')
+    L.check(lib.exorl_knn_topk(dev(src).data_ptr(), ns, dev(tgt).data_ptr(), nt, dim, k, out.data_ptr(), None))
+    want = knn.topk_smallest(knn.pairwise_l2(src[:64], tgt), k) if ns > 64 else knn.topk_smallest(knn.pairwise_l2(src, tgt), k)
+    got = out.cpu().numpy()[:want.shape[0]]
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-6)
+    if same:
+        assert np.all(got[:, 0] == 0.0)            # self-distance is an exact zero (PBE relies on it)
+    assert np.all(np.diff(out.cpu().numpy(), axis=1) >= 0)
+
+
+def test_knn_golden_pbe_and_proto(lib, gold):
+    """The reference's PBE / Proto rewards (utils_g2.npz) rebuilt from the HIP top-k."""
+    from exorl_amd import _lib as L
+    z = np.load(gold / 'utils_g2.npz')
+    rep = z['pbe_rep']
+    out = torch.empty(16, 3, device='cuda')
+    L.check(lib.exorl_knn_topk(dev(rep).data_ptr(), 16, dev(rep).data_ptr(), 16, 8, 3, out.data_ptr(), None))
+    topk = out.cpu().numpy()
+    np.testing.assert_allclose(np.log(np.maximum(topk, 0).mean(1, keepdims=True) + 1), z['pbe_avg_r1'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(np.log(topk[:, -1:] + 1), z['pbe_kth_r1'], rtol=1e-5, atol=1e-6)
+    out = torch.empty(10, 3, device='cuda')
+    L.check(lib.exorl_knn_topk(dev(z['knn_z']).data_ptr(), 10, dev(z['knn_queue']).data_ptr(), 20, 6, 3, out.data_ptr(), None))
+    np.testing.assert_allclose(out.cpu().numpy()[:, -1:], z['knn_reward'], rtol=1e-5)

@@ -1,0 +1,105 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads and exports every symbol the header
+declares, and the Python mirror's init plumbing reproduces the reference's initial weights."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _declared_symbols():
+    text = (ROOT / 'include' / 'exorl_hip.h').read_text()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(exorl_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from exorl_amd import build, _lib
+    build.build(verbose=False)
+    lib = ctypes.CDLL(str(_lib.LIB_PATH))
+    syms = _declared_symbols()
+    assert len(syms) >= 35
+    for s in syms:
+        assert hasattr(lib, s), f'{s} declared in include/exorl_hip.h but not exported'
+        assert s in _lib.PROTOTYPES, f'{s} has no ctypes prototype'
+    assert set(_lib.PROTOTYPES) == set(syms)
+    lib.exorl_abi_version.restype = ctypes.c_int
+    assert lib.exorl_abi_version() == 1
+
+
+def test_product_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from exorl_amd import agents, _lib
+    with pytest.raises(_lib.ExorlError):
+        agents.TD3BCAgent('td3_bc', (5,), (3,), 'cuda', 1e-4, 32, 0.01, 0.2, 1, 8, 0.3, True, 2.5)
+    with pytest.raises(_lib.ExorlError):
+        agents.TD3BCAgent('td3_bc', (5,), (3,), 'cpu', 1e-4, 32, 0.01, 0.2, 1, 8, 0.3, True, 2.5)
+
+
+@pytest.mark.parametrize('kind', ['td3_bc', 'bc', 'ddpg'])
+def test_init_matches_reference_rng_order(gold, kind):
+    """torch.manual_seed(21) + the reference constructor (fixture) == our _mlp_init draw order."""
+    from exorl_amd import agents
+    z = np.load(gold / f'tiny_{kind}.npz')
+    O, A, H = 5, 3, 32
+    torch.manual_seed(21)
+    actor0 = agents._mlp_init(O, H, A, 1, 1)
+    keys = agents._DDPG_ACTOR_KEYS if kind == 'ddpg' else agents._OFFLINE_ACTOR_KEYS
+    for k, w in zip(keys, actor0):
+        np.testing.assert_array_equal(w.numpy(), z[f'init/actor/{k}'], err_msg=k)
+    if kind != 'bc':
+        critic0 = agents._mlp_init(O + A, H, 1, 1 if kind == 'ddpg' else 2, 2)
+        ckeys = agents._DDPG_CRITIC_KEYS if kind == 'ddpg' else agents._OFFLINE_CRITIC_KEYS
+        for k, w in zip(ckeys, critic0):
+            np.testing.assert_array_equal(w.numpy(), z[f'init/critic/{k}'], err_msg=k)
+
+
+def test_schedule_and_helpers(gold):
+    from exorl_amd import utils
+    z = np.load(gold / 'utils_g2.npz')
+    sch = ['0.2', 'linear(1.0,0.1,100)', 'step_linear(1.0,0.5,50,0.1,100)']
+    steps = [0, 10, 50, 75, 100, 1000]
+    got = np.array([[utils.schedule(s, t) for t in steps] for s in sch])
+    assert np.array_equal(got, z['schedule'])
+    with pytest.raises(NotImplementedError):
+        utils.schedule('cosine(1,2)', 0)
+    assert utils.Until(10)(9) and not utils.Until(10)(10) and utils.Until(None)(10**9)
+    assert utils.Every(4)(8) and not utils.Every(4)(9) and not utils.Every(None)(0)
+
+
+def test_storage_writes_reference_format(tmp_path):
+    """ReplayBufferStorage: episode_{idx}_{len}.npz, len = rows-1, arrays per spec (replay_buffer.py:115-150)."""
+    from exorl_amd.replay_buffer import ReplayBufferStorage, load_episode, episode_len
+
+    class Spec:
+        def __init__(self, shape, dtype, name):
+            self.shape, self.dtype, self.name = shape, np.dtype(dtype), name
+
+    class TS(dict):
+        def __init__(self, last, **kw):
+            super().__init__(**kw)
+            self._last = last
+
+        def last(self):
+            return self._last
+
+    specs = (Spec((3,), np.float32, 'observation'), Spec((2,), np.float32, 'action'), Spec((1,), np.float32, 'reward'),
+             Spec((1,), np.float32, 'discount'))
+    st = ReplayBufferStorage(specs, (Spec((2,), np.float32, 'skill'),), tmp_path / 'buffer')
+    for ep in range(2):
+        for t in range(4 + ep):
+            st.add(TS(t == 3 + ep, observation=np.full(3, t, np.float32), action=np.zeros(2, np.float32), reward=0.5,
+                      discount=1.0), {'skill': np.ones(2, np.float32)})
+    assert len(st) == 3 + 4
+    names = sorted(p.name for p in (tmp_path / 'buffer').glob('*.npz'))
+    assert names == ['episode_0_3.npz', 'episode_1_4.npz']
+    ep = load_episode(tmp_path / 'buffer' / 'episode_1_4.npz')
+    assert episode_len(ep) == 4 and ep['reward'].shape == (5, 1) and ep['reward'].dtype == np.float32
+    assert ep['skill'].shape == (5, 2)
+    st2 = ReplayBufferStorage(specs, (), tmp_path / 'buffer')      # _preload resumes the counters
+    assert len(st2) == 7 and st2._num_episodes == 2
