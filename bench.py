@@ -1,0 +1,204 @@
+"""North-star benchmark: gradient-steps/sec, TD3+BC, walker_walk shapes (O=24, A=6, H=1024), batch 1024,
+replay resident in HBM (BASELINE.json configs[1]; SURVEY.md 8d "Config 2").
+
+    python bench.py --gpus 1 --steps 2000 --warmup 200
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one agent.update(replay_iter, step): HBM gather + n-step relabel of a 1024-row minibatch, critic
+update, actor update, target update (use_tb=False, as configs/offline.yaml:25). Inputs are resident in HBM
+before the timed region. N > 1: one process per GPU, weak scaling — every rank keeps batch 1024 on its own
+episode-modulo shard of the replay (the reference's worker sharding rule, replay_buffer.py:203-205) and the
+gradients / lambda statistic are sum-all-reduced over RCCL, i.e. one global step of batch N*1024; `value`
+counts batch-1024 step-equivalents (N per global step) per second.
+
+Prints ONE JSON line on rank 0. Extra legs (rank 0, N=1 only): `roofline` — the dominant kernel (the grouped
+1024^3 MFMA GEMM) timed per launch with HIP events on its own stream in a separate instrumented pass of the
+same loop; `cpu_baseline` — the numpy oracle of the same update, bounded to a few seconds, on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+O, A, H, B = 24, 6, 1024, 1024          # walker_walk states / td3_bc.yaml
+EPISODES, EP_LEN = 1000, 1000           # 1 M transitions
+GAMMA = 0.99
+PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}     # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+
+
+def algorithmic_flops_per_step(batch=B):
+    actor = O * H + H * H + H * A
+    critic = 2 * ((O + A) * H + H * H + H)
+    a_f, c_f = 2 * actor * batch, 2 * critic * batch
+    return 4 * a_f + 6 * c_f              # 35.39 GFLOP at B=1024
+
+
+def synth_replay(rank, world, device):
+    """Config-2 replay: obs~N(0,1), action~U(-1,1), reward~U(0,1), discount=1; this rank's episode-modulo shard."""
+    from exorl_amd.engine import ReplayEngine
+    mine = [e for e in range(EPISODES) if e % world == rank]
+    eng = ReplayEngine((O,), np.float32, A, 0, len(mine) * (EP_LEN + 1) + 64, len(mine) + 8, device)
+    slots = []
+    for e in mine:
+        rs = np.random.RandomState(1000003 + e)
+        rows = EP_LEN + 1
+        ep = dict(observation=rs.standard_normal((rows, O)).astype(np.float32),
+                  action=rs.uniform(-1, 1, (rows, A)).astype(np.float32),
+                  reward=rs.uniform(0, 1, (rows, 1)).astype(np.float32), discount=np.ones((rows, 1), np.float32))
+        ep['action'][0] = 0
+        ep['reward'][0] = 0
+        slots.append(eng.append_episode(ep))
+    eng.set_order(slots)            # episode_{idx}_{len} names sort lexicographically; order is irrelevant to Philox
+    eng.seed_philox(1 + rank)
+    return eng
+
+
+def cpu_baseline(budget_s=12.0):
+    """The oracle (numpy fp32, BLAS threads of this host) on a bounded sample of the same workload."""
+    from oracle.agents import OracleAgent, param_shapes
+    from oracle.replay import gather_nstep_batch
+    sys.path.insert(0, str(ROOT / 'tests'))
+    import _synth
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    ash, csh = param_shapes('td3_bc', O, A, H)
+    ag = OracleAgent('td3_bc', list(_synth.synth_params(ash, 5).values()), list(_synth.synth_params(csh, 6).values()))
+    rs = np.random.RandomState(0)
+    n_eps = 100                                                    # 100k-transition slice of the arena: same gather
+    rows = n_eps * (EP_LEN + 1)
+    obs = rs.standard_normal((rows, O)).astype(np.float32)
+    act = rs.uniform(-1, 1, (rows, A)).astype(np.float32)
+    rew = rs.uniform(0, 1, (rows, 1)).astype(np.float32)
+    disc = np.ones((rows, 1), np.float32)
+
+    def step(i):
+        e = rs.randint(0, n_eps, B)
+        idx = rs.randint(0, EP_LEN, B) + 1
+        batch = gather_nstep_batch(obs, act, rew, disc, e.astype(np.int64) * (EP_LEN + 1), idx, 1, GAMMA)
+        ag.update(batch, i, rs.standard_normal((B, A)).astype(np.float32), rs.standard_normal((B, A)).astype(np.float32))
+    step(0)
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s and n < 400:
+        step(n + 1)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {'value': n / dt, 'unit': 'gradient-steps/s', 'cores': int(cores), 'kind': 'port',
+            'sample': f'{n} TD3+BC update() steps incl. vectorised n-step gather from a 100k-transition slice, B={B}, '
+                      f'numpy fp32 oracle (oracle/agents.py), {dt:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2000)
+    ap.add_argument('--warmup', type=int, default=200)
+    ap.add_argument('--precision', default=os.environ.get('EXORL_PRECISION', 'bf16'), choices=['bf16', 'fp32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--graph', type=int, default=int(os.environ.get('EXORL_GRAPH', '1')))
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}')
+    torch.cuda.set_device(local_rank)
+    device = f'cuda:{local_rank}'
+    dist = torch.distributed
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(device))
+
+    from exorl_amd import agents, _lib as L
+    from exorl_amd.replay_buffer import ArenaIterator
+    lib = L.load()
+
+    torch.manual_seed(1)
+    agent = agents.TD3BCAgent('td3_bc', (O,), (A,), device, 1e-4, H, 0.01, '0.2', 1, B, 0.3, False, 2.5,
+                              precision=args.precision, seed=1 + rank)
+    if world > 1:                       # identical initial weights on every rank
+        for net in (agent.actor, agent.critic, agent.critic_target):
+            for p in net.parameters():
+                dist.broadcast(p, 0)
+    replay = synth_replay(rank, world, device)
+    it = ArenaIterator(replay, B, 1, GAMMA, 'philox')
+    use_graph = bool(args.graph) and world == 1 and agent.enable_graph(it)
+
+    def run(n, step0):
+        for i in range(n):
+            agent.update(it, step0 + i)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run(args.warmup, 0)
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    out = None
+    if rank == 0:
+        flops = algorithmic_flops_per_step()
+        out = {
+            'metric': 'gradient-steps/sec TD3+BC walker_walk batch=1024', 'value': world * args.steps / dt,
+            'unit': 'gradient-steps/s (batch-1024 step-equivalents)', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'bf16' if args.precision == 'bf16' else 'f32', 'data': 'synthetic',
+            'config': {'workload': 'TD3+BC walker_walk (O=24,A=6,H=1024), 1M-transition replay in HBM, batch 1024/GPU, '
+                                   'nstep=1, Philox sampler, use_tb=False', 'global_batch': B * world,
+                       'parallelism': f'dp{world}', 'hip_graph': use_graph,
+                       'mfma_operands': 'bf16 (fp32 accumulate, fp32 master weights)' if args.precision == 'bf16' else 'fp32'},
+            'algorithmic_gflop_per_step': flops / 1e9,
+            'step_frac_of_mfma_peak': (world * args.steps / dt) * flops / 1e12 / (PEAK_TFLOPS[args.precision] * world),
+        }
+    if world == 1 and not args.no_roofline:
+        # instrumented pass of the same loop (eager launches so each GEMM can be bracketed by events)
+        agent.disable_graph()
+        L.check(lib.exorl_profile_gemm(1))
+        nprof = 50
+        run(nprof, args.warmup + args.steps)
+        cap = 1 << 15
+        fl, ms, n = np.zeros(cap, np.float64), np.zeros(cap, np.float32), L.C.c_int32()
+        L.check(lib.exorl_profile_gemm_read(fl.ctypes.data, ms.ctypes.data, cap, L.C.byref(n)))
+        L.check(lib.exorl_profile_gemm(0))
+        fl, ms = fl[:n.value], ms[:n.value]
+        big = fl >= 2.0 * 2 * B * H * H * 0.99           # the two-problem 1024^3 launches (fwd / dgrad / wgrad of Linear(H,H))
+        ach = float(fl[big].mean() / (ms[big].mean() * 1e-3) / 1e12)
+        peak = PEAK_TFLOPS[args.precision]
+        out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
+                           'kernel': 'gemm_kernel (grouped 2x[1024x1024x1024])', 'launches': int(big.sum()),
+                           'avg_us': float(ms[big].mean() * 1e3), 'flop_per_launch': float(fl[big].mean()),
+                           'all_gemm_us_per_step': float(ms.sum() * 1e3 / nprof), 'gemm_launches_per_step': n.value / nprof}
+    if world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -72,8 +72,11 @@ PROTOTYPES = {
     'exorl_agent_set_opt_steps': (C.c_int, [c_void_p, c_int64, c_int64]),
     'exorl_agent_enable_graph': (C.c_int, [c_void_p, c_void_p, c_int32, c_float, c_float]),
     'exorl_agent_step_graph': (C.c_int, [c_void_p, c_void_p]),
+    'exorl_agent_disable_graph': (C.c_int, [c_void_p]),
     'exorl_gemm': (C.c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int64,
                              c_void_p, c_int64, c_void_p, c_int32, c_int32, c_void_p]),
+    'exorl_profile_gemm': (C.c_int, [c_int32]),
+    'exorl_profile_gemm_read': (C.c_int, [c_void_p, c_void_p, c_int32, P(c_int32)]),
     'exorl_adam_step': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                   c_int64, c_void_p, c_float, c_void_p]),
     'exorl_soft_update': (C.c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),

@@ -18,7 +18,6 @@ import torch.nn as nn
 from . import _lib as L
 from . import utils
 from .engine import AgentEngine
-from .replay_buffer import DeviceReplayIterator
 
 _OFFLINE_ACTOR_KEYS = ['policy.0.weight', 'policy.0.bias', 'policy.1.weight', 'policy.1.bias',
                        'policy.3.weight', 'policy.3.bias', 'policy.5.weight', 'policy.5.bias']
@@ -122,6 +121,9 @@ class _AgentBase:
             for p, w in zip(self.critic.parameters(), critic0):
                 p.copy_(w.reshape(p.shape))
             self.engine.params_changed(sync_target=True)               # critic_target.load_state_dict(critic.state_dict())
+        self._slots = None
+        self._graph_iter = None
+        self._graph_stddev = None
         self.noise_hook = None      # tests: callable(shape) -> np.ndarray standing in for _standard_normal
 
     # -- nn.Module-ish surface used by utils.eval_mode and the training scripts
@@ -134,9 +136,38 @@ class _AgentBase:
     def _stddev(self, step):
         return utils.schedule(self.stddev_schedule, step)
 
+    # -- hipGraph fast path: sampler + whole update captured once, replayed with one launch per step
+    def enable_graph(self, replay_iter, step=0):
+        """Binds `replay_iter` (an ArenaIterator with the Philox sampler) and captures sample+update.
+        Returns False (and stays eager) when the iterator cannot be captured or under data parallelism."""
+        eng = getattr(replay_iter, 'engine', None)
+        if self.world_size != 1 or eng is None or getattr(replay_iter, 'sampler', None) != L.SAMPLER_PHILOX:
+            return False
+        self._graph_stddev = self._stddev(step)
+        self.engine.enable_graph(eng, replay_iter.nstep, replay_iter.discount, self._graph_stddev)
+        self._graph_iter = replay_iter
+        return True
+
+    def disable_graph(self):
+        if self._graph_iter is not None:
+            self.engine.disable_graph()
+        self._graph_iter = None
+
+    def _step(self, replay_iter, stddev):
+        if replay_iter is self._graph_iter and self.noise_hook is None:
+            if stddev != self._graph_stddev:          # stddev schedule moved: re-capture with the new constant
+                self._graph_stddev = stddev
+                self.engine.enable_graph(replay_iter.engine, replay_iter.nstep, replay_iter.discount, stddev)
+            self.engine.step_graph()
+            return
+        self._load_batch(replay_iter)
+        self._run_update(stddev)
+
     def _load_batch(self, replay_iter):
-        if isinstance(replay_iter, DeviceReplayIterator):
-            replay_iter.sample_into(self.engine.batch_slots(), self.engine.batch)       # replay -> update, zero copy
+        if hasattr(replay_iter, 'sample_into'):                                         # HBM sampler: replay -> update, zero copy
+            if self._slots is None:
+                self._slots = self.engine.batch_slots()
+            replay_iter.sample_into(self._slots, self.engine.batch)
         else:
             batch = next(replay_iter)                                                   # any iterator of 5-tuples
             self.engine.set_batch(*batch[:5])
@@ -220,9 +251,8 @@ class TD3BCAgent(_AgentBase):
 
     def update(self, replay_iter, step):
         metrics = dict()
-        self._load_batch(replay_iter)
         stddev = self._stddev(step)
-        self._run_update(stddev)
+        self._step(replay_iter, stddev)
         if self.use_tb:
             metrics.update(self._metrics(_CRITIC_METRICS, stddev))
         return metrics
@@ -256,9 +286,8 @@ class BCAgent(_AgentBase):
 
     def update(self, replay_iter, step):
         metrics = dict()
-        self._load_batch(replay_iter)
         stddev = self._stddev(step)
-        self._run_update(stddev)
+        self._step(replay_iter, stddev)
         if self.use_tb:
             metrics.update(self._metrics([(L.M_BATCH_REWARD, 'batch_reward'), (L.M_ACTOR_LOSS, 'actor_loss')], stddev))
         return metrics
@@ -324,9 +353,8 @@ class DDPGAgent(_AgentBase):
         metrics = dict()
         if step % self.update_every_steps != 0:      # ddpg.py:302-303 — no batch is consumed
             return metrics
-        self._load_batch(replay_iter)
         stddev = self._stddev(step)
-        self._run_update(stddev)
+        self._step(replay_iter, stddev)
         if self.use_tb or self.use_wandb:
             metrics.update(self._metrics(_CRITIC_METRICS + [(L.M_ACTOR_LOGPROB, 'actor_logprob')], stddev))
         return metrics

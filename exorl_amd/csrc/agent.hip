@@ -171,9 +171,16 @@ struct exorl_agent {
     float *stats = nullptr, *metrics = nullptr;      // contiguous: stats[4] then metrics[EXORL_N_METRICS]
     float *act_x = nullptr, *act_noise = nullptr;
     FwdBufs fact{};
-    int64_t actor_t = 0, critic_t = 0;
-    uint64_t noise_counter = 0;
+    StepState* state = nullptr;  // device-resident counters + Adam scalars (graph-replayable)
+    int64_t actor_t = 0, critic_t = 0;       // host mirrors of state->t_*
+    uint64_t act_noise_counter = 0;
     float inv_bg = 0.f;
+    // captured step (sample + update) — exorl_agent_enable_graph
+    hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t graph = nullptr;
+    hipStream_t capture_stream = nullptr;
+    exorl_replay* graph_replay = nullptr;
+    bool capturing = false;
 };
 
 namespace exorl {
@@ -193,6 +200,7 @@ static void carve(exorl_agent* a, Carver& c) {
     a->dpre = c.take(B * A);
     a->stats = c.take(4 + EXORL_N_METRICS);
     a->metrics = a->stats ? a->stats + 4 : nullptr;
+    a->state = reinterpret_cast<StepState*>(c.take((sizeof(StepState) + 3) / 4));
     a->act_x = c.take(ACT_ROWS * O);
     a->act_noise = c.take(ACT_ROWS * A);
     a->fact = FwdBufs{c.take(ACT_ROWS * H), nullptr, nullptr, c.take(ACT_ROWS * H), c.take(ACT_ROWS * A)};
@@ -224,16 +232,30 @@ static int describe(exorl_agent* a, const exorl_agent_cfg* cfg) {
     return 0;
 }
 
-static NoiseSpec noise_spec(exorl_agent* a, const float* buf) {
-    NoiseSpec n{buf, a->cfg.seed, 0};
-    if (!buf) n.counter = a->noise_counter++;
+// update(): draw `which` (0 = critic target, 1 = actor) of this step, counter base lives in StepState
+static NoiseSpec noise_spec(exorl_agent* a, const float* buf, int which) {
+    return NoiseSpec{buf, a->cfg.seed, (uint64_t)which, buf ? nullptr : &a->state->noise_counter};
+}
+// act(): separate counter space (top bit set) so exploration draws never collide with update draws
+static NoiseSpec act_noise_spec(exorl_agent* a, const float* buf) {
+    NoiseSpec n{buf, a->cfg.seed, 0, nullptr};
+    if (!buf) n.counter = (1ull << 63) | a->act_noise_counter++;
     return n;
+}
+
+static int push_opt_steps(exorl_agent* a) {
+    long long t[2] = {a->actor_t, a->critic_t};
+    EXORL_CHECK_HIP(hipMemcpy(&a->state->t_actor, t, sizeof(t), hipMemcpyHostToDevice));
+    return 0;
 }
 
 // -- phase 0: everything up to the critic gradients -------------------------------------------------
 static int phase0(exorl_agent* a, float stddev, const float* noise_c, hipStream_t s) {
     const auto& cfg = a->cfg;
     const int B = cfg.batch, O = cfg.obs_dim, A = cfg.act_dim, W = O + A, prec = cfg.precision;
+    EXORL_TRY(step_begin(a->state, a->capturing ? 1 : 0, s));     // counters += ; Adam scalars for this step
+    a->actor_t += 1;
+    if (a->has_critic) a->critic_t += 1;
     EXORL_TRY(prepare_inputs(a->obs, a->action, a->next_obs, a->xa, a->xc_cur, a->xc_next, a->xc_pi, B, O, A, a->has_critic, s));
     if (!a->has_critic) return 0;
     const float* Pa = a->flat[EXORL_NET_ACTOR][EXORL_T_PARAM];
@@ -242,7 +264,7 @@ static int phase0(exorl_agent* a, float stddev, const float* noise_c, hipStream_
     // actor on [next_obs; obs] in one pass (td3_bc.py:124 and :149 use the same weights)
     EXORL_TRY(net_forward(a->actor, Pa, a->xa, O, 2 * B, a->fa, true, true, prec, s));
     // next_action = dist.sample(clip) (td3_bc.py:125) straight into the target critic's input
-    EXORL_TRY(sample_action(a->fa.out, noise_spec(a, noise_c), stddev, cfg.stddev_clip, 1, a->xc_next + O, W, B, A, nullptr, s));
+    EXORL_TRY(sample_action(a->fa.out, noise_spec(a, noise_c, 0), stddev, cfg.stddev_clip, 1, a->xc_next + O, W, B, A, nullptr, s));
     EXORL_TRY(net_forward(a->critic, Pt, a->xc_next, W, B, a->ft, false, false, prec, s));     // td3_bc.py:126
     EXORL_TRY(net_forward(a->critic, Pc, a->xc_cur, W, B, a->fc, true, false, prec, s));       // td3_bc.py:130
     EXORL_TRY(critic_loss(a->fc.out, a->ft.out, a->reward, a->discount, a->dq, a->metrics, B, a->inv_bg, s));   // :127-131
@@ -256,13 +278,12 @@ static int phase1(exorl_agent* a, float stddev, const float* noise_a, hipStream_
     if (!a->has_critic) return 0;
     const auto& cfg = a->cfg;
     const int B = cfg.batch, O = cfg.obs_dim, A = cfg.act_dim, W = O + A, prec = cfg.precision;
-    a->critic_t += 1;
-    EXORL_TRY(adam_step(a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD],
-                        a->flat[EXORL_NET_CRITIC][EXORL_T_ADAM_M], a->flat[EXORL_NET_CRITIC][EXORL_T_ADAM_V], a->critic.total,
-                        cfg.lr, 0.9f, 0.999f, 1e-8f, a->critic_t, a->flat[EXORL_NET_CRITIC_TARGET][EXORL_T_PARAM], cfg.tau, s));
+    EXORL_TRY(adam_step_dev(a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD],
+                            a->flat[EXORL_NET_CRITIC][EXORL_T_ADAM_M], a->flat[EXORL_NET_CRITIC][EXORL_T_ADAM_V], a->critic.total,
+                            &a->state->critic, a->flat[EXORL_NET_CRITIC_TARGET][EXORL_T_PARAM], s));
     // policy.sample(clip) on obs (td3_bc.py:151): mu rows B..2B of the stacked actor forward
     float* logprob = cfg.kind == EXORL_AGENT_DDPG ? a->metrics + EXORL_M_ACTOR_LOGPROB : nullptr;
-    EXORL_TRY(sample_action(a->fa.out + (int64_t)B * A, noise_spec(a, noise_a), stddev, cfg.stddev_clip, 1, a->xc_pi + O, W, B, A,
+    EXORL_TRY(sample_action(a->fa.out + (int64_t)B * A, noise_spec(a, noise_a, 1), stddev, cfg.stddev_clip, 1, a->xc_pi + O, W, B, A,
                             logprob, s));
     EXORL_TRY(net_forward(a->critic, a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->xc_pi, W, B, a->fc, true, false, prec, s));
     EXORL_TRY(actor_stats(a->fc.out, a->stats, B, s));
@@ -292,11 +313,16 @@ static int phase2(exorl_agent* a, float stddev, hipStream_t s) {
 }
 
 static int phase3(exorl_agent* a, hipStream_t s) {
-    const auto& cfg = a->cfg;
-    a->actor_t += 1;
-    return adam_step(a->flat[EXORL_NET_ACTOR][EXORL_T_PARAM], a->flat[EXORL_NET_ACTOR][EXORL_T_GRAD],
-                     a->flat[EXORL_NET_ACTOR][EXORL_T_ADAM_M], a->flat[EXORL_NET_ACTOR][EXORL_T_ADAM_V], a->actor.total, cfg.lr,
-                     0.9f, 0.999f, 1e-8f, a->actor_t, nullptr, 0.f, s);
+    return adam_step_dev(a->flat[EXORL_NET_ACTOR][EXORL_T_PARAM], a->flat[EXORL_NET_ACTOR][EXORL_T_GRAD],
+                         a->flat[EXORL_NET_ACTOR][EXORL_T_ADAM_M], a->flat[EXORL_NET_ACTOR][EXORL_T_ADAM_V], a->actor.total,
+                         &a->state->actor, nullptr, s);
+}
+
+static int release_graph(exorl_agent* a) {
+    if (a->graph_exec) { EXORL_CHECK_HIP(hipGraphExecDestroy(a->graph_exec)); a->graph_exec = nullptr; }
+    if (a->graph) { EXORL_CHECK_HIP(hipGraphDestroy(a->graph)); a->graph = nullptr; }
+    a->graph_replay = nullptr;
+    return 0;
 }
 
 }  // namespace exorl
@@ -335,12 +361,19 @@ int exorl_agent_create(const exorl_agent_cfg* cfg, void* workspace, size_t works
     if (e != hipSuccess) { set_error("agent_create: hipMemset -> %s", hipGetErrorString(e)); if (a->owns_ws) (void)hipFree(a->ws); delete a; return 1; }
     Carver c(a->ws);
     carve(a, c);
+    StepState st{};
+    st.lr = cfg->lr; st.b1 = 0.9f; st.b2 = 0.999f; st.eps = 1e-8f; st.tau = cfg->tau;      // torch.optim.Adam defaults
+    st.has_critic = a->has_critic ? 1 : 0;
+    e = hipMemcpy(a->state, &st, sizeof(st), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { set_error("agent_create: state upload -> %s", hipGetErrorString(e)); if (a->owns_ws) (void)hipFree(a->ws); delete a; return 1; }
     *out = a;
     return 0;
 }
 
 int exorl_agent_destroy(exorl_agent_t* a) {
     if (!a) return 0;
+    (void)release_graph(a);
+    if (a->capture_stream) (void)hipStreamDestroy(a->capture_stream);
     if (a->owns_ws) (void)hipFree(a->ws);
     delete a;
     return 0;
@@ -452,7 +485,7 @@ int exorl_agent_act(exorl_agent_t* a, const float* obs, int32_t n, float stddev,
             EXORL_CHECK_HIP(hipMemcpyAsync(out + (int64_t)r0 * A, a->fact.out, (size_t)rows * A * 4, hipMemcpyDeviceToDevice, s));
         } else {
             EXORL_REQUIRE(stddev > 0.f, "agent_act: stddev must be > 0 in sampling mode");
-            EXORL_TRY(sample_action(a->fact.out, noise_spec(a, noise ? noise + (int64_t)r0 * A : nullptr), stddev, 0.f, 0,
+            EXORL_TRY(sample_action(a->fact.out, act_noise_spec(a, noise ? noise + (int64_t)r0 * A : nullptr), stddev, 0.f, 0,
                                     out + (int64_t)r0 * A, A, rows, A, nullptr, s));
         }
     }
@@ -478,19 +511,54 @@ int exorl_agent_set_opt_steps(exorl_agent_t* a, int64_t actor_steps, int64_t cri
     EXORL_REQUIRE(a && actor_steps >= 0 && critic_steps >= 0, "agent_set_opt_steps: bad arguments");
     a->actor_t = actor_steps;
     a->critic_t = critic_steps;
-    return 0;
+    return push_opt_steps(a);
 }
 
 int exorl_agent_enable_graph(exorl_agent_t* a, exorl_replay_t* r, int32_t nstep, float gamma, float stddev) {
-    (void)a; (void)r; (void)nstep; (void)gamma; (void)stddev;
-    set_error("agent_enable_graph: hipGraph capture is not built in this revision");
-    return 3;
+    EXORL_REQUIRE(a && r, "agent_enable_graph: null argument");
+    EXORL_REQUIRE(a->cfg.world_size == 1, "agent_enable_graph: data-parallel steps need host-side all-reduces between phases");
+    EXORL_REQUIRE(stddev > 0.f && nstep >= 1, "agent_enable_graph: bad stddev/nstep");
+    EXORL_TRY(release_graph(a));
+    if (!a->capture_stream) EXORL_CHECK_HIP(hipStreamCreateWithFlags(&a->capture_stream, hipStreamNonBlocking));
+    exorl_batch_out slots;
+    EXORL_TRY(exorl_agent_batch_slots(a, &slots));
+    // one eager sample: uploads the episode table, sizes the pair buffer, validates nstep vs episode lengths
+    EXORL_TRY(replay_sample_impl(r, a->cfg.batch, nstep, gamma, EXORL_SAMPLER_PHILOX, nullptr, &slots, nullptr, a->capture_stream, nullptr));
+    const uint64_t ctr = replay_philox_counter(r);
+    EXORL_CHECK_HIP(hipMemcpyAsync(&a->state->replay_counter, &ctr, sizeof(ctr), hipMemcpyHostToDevice, a->capture_stream));
+    EXORL_CHECK_HIP(hipStreamSynchronize(a->capture_stream));
+    const int64_t t_a = a->actor_t, t_c = a->critic_t;
+    EXORL_CHECK_HIP(hipStreamBeginCapture(a->capture_stream, hipStreamCaptureModeThreadLocal));
+    a->capturing = true;
+    int rc = replay_sample_impl(r, a->cfg.batch, nstep, gamma, EXORL_SAMPLER_PHILOX, nullptr, &slots, nullptr, a->capture_stream,
+                                &a->state->replay_counter);
+    for (int p = 0; p < 4 && rc == 0; ++p) rc = exorl_agent_update_phase(a, p, stddev, nullptr, nullptr, a->capture_stream);
+    a->capturing = false;
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(a->capture_stream, &g);
+    a->actor_t = t_a; a->critic_t = t_c;             // capture enqueued nothing: undo the host-side bookkeeping
+    replay_advance_philox(r, (uint64_t)-1);
+    if (rc != 0) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess) { set_error("agent_enable_graph: hipStreamEndCapture -> %s", hipGetErrorString(e)); return 1; }
+    a->graph = g;
+    EXORL_CHECK_HIP(hipGraphInstantiate(&a->graph_exec, g, nullptr, nullptr, 0));
+    a->graph_replay = r;
+    return 0;
 }
 
+int exorl_agent_disable_graph(exorl_agent_t* a) {
+    EXORL_REQUIRE(a, "agent_disable_graph: null handle");
+    return release_graph(a);
+}
+
+// One captured step: replay sample (Philox) + update phases 0..3, one hipGraphLaunch.
 int exorl_agent_step_graph(exorl_agent_t* a, void* stream) {
-    (void)a; (void)stream;
-    set_error("agent_step_graph: no captured graph");
-    return 3;
+    EXORL_REQUIRE(a && a->graph_exec, "agent_step_graph: no captured graph (call exorl_agent_enable_graph)");
+    EXORL_CHECK_HIP(hipGraphLaunch(a->graph_exec, as_stream(stream)));
+    a->actor_t += 1;
+    if (a->has_critic) a->critic_t += 1;
+    replay_advance_philox(a->graph_replay, 1);
+    return 0;
 }
 
 }  // extern "C"

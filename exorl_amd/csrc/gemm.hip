@@ -14,9 +14,22 @@
 //    and written to the other LDS buffer after them — one barrier per k-tile.
 //  * operands whose reduction index is the slow dimension (dgrad B, wgrad A and B) are transposed in
 //    registers on the way to LDS (two rows x KU k's per thread), so all three GEMM forms share one inner loop.
+#include <vector>
+
 #include "kernels.h"
 
 namespace exorl {
+
+// Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg): off by default,
+// the product path never pays for it.
+struct GemmProfile {
+    bool on = false;
+    std::vector<hipEvent_t> ev;      // pairs
+    std::vector<double> flops;
+    size_t used = 0;
+};
+static GemmProfile g_prof;
+constexpr size_t PROF_MAX_LAUNCHES = 1 << 15;
 
 struct GemmBatch {
     GemmProblem p[4];
@@ -185,9 +198,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
 template <int PREC, int AL, int BL>
 static int launch_layout(const GemmBatch& gb, int count, int max_tiles, bool vec, hipStream_t s) {
     dim3 grid(max_tiles, 1, count), block(256);
+    const bool prof = g_prof.on && g_prof.used < PROF_MAX_LAUNCHES;
+    if (prof) {
+        if (g_prof.ev.size() < 2 * (g_prof.used + 1)) {
+            hipEvent_t a, b;
+            EXORL_CHECK_HIP(hipEventCreate(&a));
+            EXORL_CHECK_HIP(hipEventCreate(&b));
+            g_prof.ev.push_back(a);
+            g_prof.ev.push_back(b);
+        }
+        double f = 0;
+        for (int i = 0; i < count; ++i) f += 2.0 * gb.p[i].M * (double)gb.p[i].N * gb.p[i].K;
+        g_prof.flops.push_back(f);
+        EXORL_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.used], s));
+    }
     if (vec) hipLaunchKernelGGL((gemm_kernel<PREC, AL, BL, true>), grid, block, 0, s, gb);
     else     hipLaunchKernelGGL((gemm_kernel<PREC, AL, BL, false>), grid, block, 0, s, gb);
     EXORL_LAUNCH_CHECK();
+    if (prof) {
+        EXORL_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s));
+        g_prof.used += 1;
+    }
     return 0;
 }
 
@@ -234,6 +265,29 @@ int gemm_grouped(int precision, int a_layout, int b_layout, const GemmProblem* p
 }
 
 }  // namespace exorl
+
+extern "C" int exorl_profile_gemm(int32_t enable) {
+    exorl::g_prof.on = enable != 0;
+    if (enable) { exorl::g_prof.used = 0; exorl::g_prof.flops.clear(); }
+    return 0;
+}
+
+// Synchronises, then returns per-launch (algorithmic FLOPs, milliseconds) of the GEMM launches recorded
+// since exorl_profile_gemm(1); n_out = number of launches written (<= cap).
+extern "C" int exorl_profile_gemm_read(double* flops_out, float* ms_out, int32_t cap, int32_t* n_out) {
+    using namespace exorl;
+    EXORL_REQUIRE(flops_out && ms_out && n_out, "profile_gemm_read: null argument");
+    EXORL_CHECK_HIP(hipDeviceSynchronize());
+    int n = 0;
+    for (size_t i = 0; i < g_prof.used && n < cap; ++i, ++n) {
+        float ms = 0.f;
+        EXORL_CHECK_HIP(hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
+        flops_out[n] = g_prof.flops[i];
+        ms_out[n] = ms;
+    }
+    *n_out = n;
+    return 0;
+}
 
 extern "C" int exorl_gemm(int32_t precision, int32_t a_layout, int32_t b_layout, int32_t M, int32_t N, int32_t K,
                           const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,

@@ -35,8 +35,25 @@ int head_bwd_params(const float* dout, const float* a, const float* dz, float* d
 struct NoiseSpec {           // where TruncatedNormal noise comes from
     const float* buf;        // (B,A) standard normal draws, or nullptr -> Philox(seed, counter)
     uint64_t seed;
-    uint64_t counter;
+    uint64_t counter;              // draw id = counter + (counter_ptr ? *counter_ptr : 0)
+    const uint64_t* counter_ptr;   // device-resident base (advanced by step_begin) so a captured graph replays fresh draws
 };
+
+struct AdamConst {           // fp32 scalars of one torch.optim.Adam step (bias corrections folded in)
+    float one_minus_b1, b2, one_minus_b2, bc2_sqrt, eps, neg_step_size, tau, one_minus_tau;
+};
+
+// Device-resident per-agent step state: everything that changes from one update() to the next, so the whole
+// step can be captured once in a hipGraph and replayed with no host-side argument patching.
+struct StepState {
+    uint64_t replay_counter;     // Philox batch counter of the sampler bound to the graph
+    uint64_t noise_counter;      // Philox draw counter for action noise (2 draws per step)
+    long long t_actor, t_critic; // Adam step counts
+    AdamConst actor, critic;
+    float lr, b1, b2, eps, tau;
+    int has_critic;
+};
+int step_begin(StepState* st, int advance_replay, hipStream_t s);
 int prepare_inputs(const float* obs, const float* action, const float* next_obs, float* xa, float* xc_cur,
                    float* xc_next, float* xc_pi, int B, int O, int A, int has_critic, hipStream_t s);
 int sample_action(const float* mu, NoiseSpec noise, float stddev, float clip, int use_clip, float* dst, int64_t dst_ld,
@@ -53,5 +70,15 @@ int actor_dmu(const float* da, int64_t da_ld, const float* mu, const float* a_da
 int adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
               int64_t t, float* target, float tau, hipStream_t s);
 int soft_update(const float* p, float* target, int64_t n, float tau, hipStream_t s);
+// Adam with the scalars read from device memory (StepState), for graph-replayable steps.
+int adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const AdamConst* c_dev, float* target,
+                  hipStream_t s);
+
+// ---- replay (replay.hip) internal entry points used by the agent's graph capture
+int replay_sample_impl(exorl_replay* r, int32_t batch, int32_t nstep, float gamma, int32_t sampler,
+                       const int32_t* pairs_host, const exorl_batch_out* out, int32_t* pairs_out_host, hipStream_t s,
+                       const uint64_t* dev_counter);
+uint64_t replay_philox_counter(exorl_replay* r);
+void replay_advance_philox(exorl_replay* r, uint64_t n);
 
 }  // namespace exorl

@@ -80,7 +80,8 @@ __global__ __launch_bounds__(1024) void sample_action_kernel(const float* __rest
     const float log_norm = -__logf(stddev) - 0.9189385332046727f;   // -log(std) - log(sqrt(2 pi))
     for (int i = threadIdx.x; i < B * A; i += blockDim.x) {
         const int m = i / A, j = i % A;
-        const float z = noise.buf ? noise.buf[i] : philox_normal(noise.seed, noise.counter, (uint32_t)i);
+        const float z = noise.buf ? noise.buf[i]
+                                  : philox_normal(noise.seed, noise.counter + (noise.counter_ptr ? *noise.counter_ptr : 0ull), (uint32_t)i);
         float eps = z * stddev;
         if (use_clip) eps = fminf(fmaxf(eps, -clip), clip);
         const float mv = mu[i];

@@ -7,11 +7,16 @@
 
 namespace exorl {
 
-struct AdamConst {
-    float one_minus_b1, b2, one_minus_b2, bc2_sqrt, eps, neg_step_size, tau, one_minus_tau;
-};
+// Products and sums are rounded separately (no FMA contraction): the op order of torch's CPU kernels.
+__device__ __forceinline__ float polyak(float p, float t, float tau, float one_minus_tau) {
+#pragma clang fp contract(off)
+    const float a = tau * p;
+    const float b = one_minus_tau * t;
+    return a + b;
+}
 
 __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const AdamConst& c) {
+#pragma clang fp contract(off)
     // exp_avg.lerp_(g, 1-b1); exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2); p.addcdiv_(m, sqrt(v)/bc2_sqrt + eps, -lr/bc1)
     m = m + c.one_minus_b1 * (g - m);
     v = v * c.b2 + (c.one_minus_b2 * g) * g;
@@ -19,9 +24,12 @@ __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v,
     p = p + (c.neg_step_size * m) / denom;
 }
 
+template <bool DEV>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
-                                                   float* __restrict__ target, int64_t n4, AdamConst c) {
+                                                   float* __restrict__ target, int64_t n4, AdamConst cv,
+                                                   const AdamConst* __restrict__ cp) {
+    const AdamConst c = DEV ? *cp : cv;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         float4 pv = reinterpret_cast<float4*>(p)[i];
         const float4 gv = reinterpret_cast<const float4*>(g)[i];
@@ -36,10 +44,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         reinterpret_cast<float4*>(v)[i] = vv;
         if (target) {
             float4 tv = reinterpret_cast<float4*>(target)[i];
-            tv.x = c.tau * pv.x + c.one_minus_tau * tv.x;
-            tv.y = c.tau * pv.y + c.one_minus_tau * tv.y;
-            tv.z = c.tau * pv.z + c.one_minus_tau * tv.z;
-            tv.w = c.tau * pv.w + c.one_minus_tau * tv.w;
+            tv.x = polyak(pv.x, tv.x, c.tau, c.one_minus_tau);
+            tv.y = polyak(pv.y, tv.y, c.tau, c.one_minus_tau);
+            tv.z = polyak(pv.z, tv.z, c.tau, c.one_minus_tau);
+            tv.w = polyak(pv.w, tv.w, c.tau, c.one_minus_tau);
             reinterpret_cast<float4*>(target)[i] = tv;
         }
     }
@@ -64,7 +72,52 @@ int adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr,
     const int64_t n4 = n / 4;
     int blocks = cdiv(n4, 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, target, n4, c);
+    hipLaunchKernelGGL((adam_kernel<false>), dim3(blocks), dim3(256), 0, s, p, g, m, v, target, n4, c, (const AdamConst*)nullptr);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
+int adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const AdamConst* c_dev, float* target,
+                  hipStream_t s) {
+    EXORL_REQUIRE(n % 4 == 0, "adam_step_dev: n must be a multiple of 4");
+    const int64_t n4 = n / 4;
+    int blocks = cdiv(n4, 256);
+    if (blocks > 2048) blocks = 2048;
+    AdamConst dummy{};
+    hipLaunchKernelGGL((adam_kernel<true>), dim3(blocks), dim3(256), 0, s, p, g, m, v, target, n4, dummy, c_dev);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
+__device__ void fill_adam_const(AdamConst& c, long long t, float lr, float b1, float b2, float eps, float tau) {
+    // double-precision scalar math, as torch's _single_tensor_adam does in Python floats
+    const double bc1 = 1.0 - pow((double)b1, (double)t);
+    const double bc2 = 1.0 - pow((double)b2, (double)t);
+    c.one_minus_b1 = (float)(1.0 - (double)b1);
+    c.b2 = b2;
+    c.one_minus_b2 = (float)(1.0 - (double)b2);
+    c.bc2_sqrt = (float)sqrt(bc2);
+    c.eps = eps;
+    c.neg_step_size = (float)(-((double)lr / bc1));
+    c.tau = tau;
+    c.one_minus_tau = (float)(1.0 - (double)tau);
+}
+
+// One thread: advance the counters and pre-compute both optimisers' scalars for this step.
+__global__ void step_begin_kernel(StepState* st, int advance_replay) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (advance_replay) st->replay_counter += 1;
+    st->noise_counter += 2;
+    st->t_actor += 1;
+    fill_adam_const(st->actor, st->t_actor, st->lr, st->b1, st->b2, st->eps, 0.f);
+    if (st->has_critic) {
+        st->t_critic += 1;
+        fill_adam_const(st->critic, st->t_critic, st->lr, st->b1, st->b2, st->eps, st->tau);
+    }
+}
+
+int step_begin(StepState* st, int advance_replay, hipStream_t s) {
+    hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(64), 0, s, st, advance_replay);
     EXORL_LAUNCH_CHECK();
     return 0;
 }
@@ -72,7 +125,7 @@ int adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr,
 __global__ __launch_bounds__(256) void soft_update_kernel(const float* __restrict__ p, float* __restrict__ target,
                                                           int64_t n, float tau, float one_minus_tau) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        target[i] = tau * p[i] + one_minus_tau * target[i];
+        target[i] = polyak(p[i], target[i], tau, one_minus_tau);
 }
 
 int soft_update(const float* p, float* target, int64_t n, float tau, hipStream_t s) {

@@ -139,8 +139,10 @@ __device__ __forceinline__ void copy_row(const unsigned char* __restrict__ src, 
 __global__ __launch_bounds__(256) void gather_nstep_kernel(ReplayView v, const int32_t* pairs_in,
                                                            int32_t* pairs_out, exorl_batch_out out,
                                                            int batch, int nstep, float gamma, int sampler,
-                                                           uint64_t seed, uint64_t counter, int vec16) {
+                                                           uint64_t seed, uint64_t counter_val,
+                                                           const uint64_t* counter_ptr, int vec16) {
 #pragma clang fp contract(off)
+    const uint64_t counter = counter_ptr ? *counter_ptr : counter_val;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (b >= batch) return;
@@ -363,15 +365,20 @@ int exorl_replay_seed_philox(exorl_replay_t* r, uint64_t seed) {
     return 0;
 }
 
-int exorl_replay_sample(exorl_replay_t* r, int32_t batch, int32_t nstep, float gamma, int32_t sampler,
-                        const int32_t* pairs_host, const exorl_batch_out* out, int32_t* pairs_out_host, void* stream) {
+}  // extern "C"
+
+namespace exorl {
+// dev_counter != nullptr: Philox batch counter is read from device memory (graph-replayable); the host copy is
+// still advanced so eager sampling continues the stream afterwards.
+int replay_sample_impl(exorl_replay* r, int32_t batch, int32_t nstep, float gamma, int32_t sampler,
+                       const int32_t* pairs_host, const exorl_batch_out* out, int32_t* pairs_out_host, hipStream_t s,
+                       const uint64_t* dev_counter) {
     EXORL_REQUIRE(r && out, "replay_sample: null argument");
     EXORL_REQUIRE(batch > 0 && nstep >= 1, "replay_sample: batch=%d nstep=%d", batch, nstep);
     EXORL_REQUIRE(out->obs && out->action && out->reward && out->discount && out->next_obs, "replay_sample: null output");
     EXORL_REQUIRE((r->cfg.meta_dim > 0) || out->meta == nullptr, "replay_sample: meta output without meta columns");
     const int n = (int)r->order.size();
     EXORL_REQUIRE(n > 0, "replay_sample: no resident episodes (IndexError in random.choice, replay_buffer.py:169)");
-    hipStream_t s = as_stream(stream);
     EXORL_TRY(upload_table(r, s));
     if (batch > r->pairs_cap) {
         if (r->d_pairs) EXORL_CHECK_HIP(hipFree(r->d_pairs));
@@ -414,10 +421,21 @@ int exorl_replay_sample(exorl_replay_t* r, int32_t batch, int32_t nstep, float g
     const int vec16 = (r->cfg.obs_bytes % 16 == 0) && (out->obs_stride % 16 == 0) && (out->next_obs_stride % 16 == 0) &&
                       ((uintptr_t)out->obs % 16 == 0) && ((uintptr_t)out->next_obs % 16 == 0);
     hipLaunchKernelGGL(gather_nstep_kernel, dim3(cdiv(batch, 4)), dim3(256), 0, s, v, r->d_pairs, r->d_pairs, *out, batch, nstep,
-                       gamma, sampler, r->philox_seed, r->philox_counter, vec16);
+                       gamma, sampler, r->philox_seed, r->philox_counter, dev_counter, vec16);
     EXORL_LAUNCH_CHECK();
     if (sampler == EXORL_SAMPLER_PHILOX) r->philox_counter += 1;
     return 0;
+}
+
+uint64_t replay_philox_counter(exorl_replay* r) { return r->philox_counter; }
+void replay_advance_philox(exorl_replay* r, uint64_t n) { r->philox_counter += n; }
+}  // namespace exorl
+
+extern "C" {
+
+int exorl_replay_sample(exorl_replay_t* r, int32_t batch, int32_t nstep, float gamma, int32_t sampler,
+                        const int32_t* pairs_host, const exorl_batch_out* out, int32_t* pairs_out_host, void* stream) {
+    return replay_sample_impl(r, batch, nstep, gamma, sampler, pairs_host, out, pairs_out_host, as_stream(stream), nullptr);
 }
 
 int exorl_replay_last_pairs(exorl_replay_t* r, int32_t batch, int32_t* pairs_host, void* stream) {

@@ -131,6 +131,15 @@ class AgentEngine:
                                          L.current_stream()))
         return out
 
+    def enable_graph(self, replay_engine, nstep, gamma, stddev):
+        L.check(self.lib.exorl_agent_enable_graph(self.h, replay_engine.h, nstep, gamma, stddev))
+
+    def disable_graph(self):
+        L.check(self.lib.exorl_agent_disable_graph(self.h))
+
+    def step_graph(self):
+        L.check(self.lib.exorl_agent_step_graph(self.h, L.current_stream()))
+
     def metrics_raw(self):
         host = np.zeros(L.N_METRICS, np.float32)
         L.check(self.lib.exorl_agent_metrics(self.h, host.ctypes.data, L.current_stream()))

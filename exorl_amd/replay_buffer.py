@@ -264,6 +264,24 @@ class DeviceReplayIterator:
         return tuple(res)
 
 
+class ArenaIterator:
+    """Iterator over an already-filled ReplayEngine (no directory behind it): what bench.py and callers that
+    ingest datasets themselves use. Same next()/sample_into() contract as DeviceReplayIterator."""
+
+    def __init__(self, engine, batch_size, nstep, discount, sampler='philox'):
+        self.engine, self.batch_size, self.nstep, self.discount = engine, batch_size, nstep, discount
+        self.sampler = {'mt19937': L.SAMPLER_MT19937, 'philox': L.SAMPLER_PHILOX}[sampler]
+
+    def __iter__(self):
+        return self
+
+    def sample_into(self, out, batch=None):
+        self.engine.sample_into(out, batch or self.batch_size, self.nstep, self.discount, self.sampler)
+
+    def __next__(self):
+        return self.engine.sample(self.batch_size, self.nstep, self.discount, self.sampler)
+
+
 def make_replay_loader(storage, max_size, batch_size, num_workers, save_snapshot, nstep=None, discount=None, **kw):
     """replay_buffer.py:260-261 signature. Also accepts the 6-argument offline call shape that
     train_offline.py:90-93 uses — (env, replay_dir, max_size, batch_size, num_workers, discount) — which the

@@ -184,9 +184,12 @@ int exorl_agent_act(exorl_agent_t* a, const float* obs_dev, int32_t n, float std
 int exorl_agent_metrics(exorl_agent_t* a, float* metrics_host, void* stream);
 int exorl_agent_opt_steps(exorl_agent_t* a, int64_t* actor_steps, int64_t* critic_steps);
 int exorl_agent_set_opt_steps(exorl_agent_t* a, int64_t actor_steps, int64_t critic_steps);
-/* Captures exorl_replay_sample(PHILOX)+exorl_agent_update into a hipGraph replayed by exorl_agent_step_graph. */
+/* Captures exorl_replay_sample(PHILOX) into the agent's batch slots + exorl_agent_update into one hipGraph;
+ * exorl_agent_step_graph replays it (all per-step counters and Adam scalars live in device memory).
+ * The stream passed to step_graph must not be the one used by other un-synchronised work on the same buffers. */
 int exorl_agent_enable_graph(exorl_agent_t* a, exorl_replay_t* r, int32_t nstep, float gamma, float stddev);
 int exorl_agent_step_graph(exorl_agent_t* a, void* stream);
+int exorl_agent_disable_graph(exorl_agent_t* a);
 
 /* ------------------------------------------------------------------------------------------------
  * Stand-alone operators (used by the agents above; exported for tests and for callers' own nets)
@@ -197,6 +200,9 @@ int exorl_agent_step_graph(exorl_agent_t* a, void* stream);
 int exorl_gemm(int32_t precision, int32_t a_layout, int32_t b_layout, int32_t M, int32_t N, int32_t K,
                const float* A_dev, int64_t lda, const float* B_dev, int64_t ldb, float* C_dev, int64_t ldc,
                const float* bias_dev, int32_t relu, int32_t accumulate, void* stream);
+/* Measurement hook (bench.py roofline leg): time every GEMM launch with HIP events on its own stream. */
+int exorl_profile_gemm(int32_t enable);
+int exorl_profile_gemm_read(double* flops_out_host, float* ms_out_host, int32_t cap, int32_t* n_out);
 int exorl_adam_step(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, float lr,
                     float beta1, float beta2, float eps, int64_t t, float* target_dev, float tau, void* stream);
 int exorl_soft_update(const float* p_dev, float* target_dev, int64_t n, float tau, void* stream);

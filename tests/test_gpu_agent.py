@@ -36,7 +36,9 @@ def test_tiny_trajectory_vs_reference(gold, kind):
     ag = make(kind, 5, 3, 32, 8)
     for nm, net in nets_of(ag):
         for k, v in net.state_dict().items():
-            assert np.array_equal(v.cpu().numpy(), z[f'init/{nm}/{k}']), (nm, k)
+            # same RNG draw order as the reference; QR itself differs in the last ulp across host CPUs
+            np.testing.assert_allclose(v.cpu().numpy(), z[f'init/{nm}/{k}'], rtol=0, atol=2e-6, err_msg=f'{nm}.{k}')
+        net.load_state_dict({k: torch.from_numpy(z[f'init/{nm}/{k}']) for k in net.state_dict()})
     noise = iter([z[f'noise/{i}'] for i in range(len([k for k in z.files if k.startswith('noise/')]))])
     ag.noise_hook = lambda shape: next(noise)
     keys = [str(k) for k in z['metric_keys']]
@@ -177,3 +179,40 @@ def test_device_replay_iterator_zero_copy_path(tmp_path):
         assert m1 == m2
     for p, q in zip(a1.actor.parameters(), a2.actor.parameters()):
         assert torch.equal(p, q)
+
+
+def _arena(seed):
+    from exorl_amd.engine import ReplayEngine
+    from exorl_amd.replay_buffer import ArenaIterator
+    O, A = 24, 6
+    eng = ReplayEngine((O,), np.float32, A, 0, 4096, 64)
+    eng.set_order([eng.append_episode(ep) for ep in _synth.synth_episodes(seed, [200, 300, 250], O, A)])
+    eng.seed_philox(77)
+    return eng, ArenaIterator(eng, 64, 1, 0.99, 'philox')
+
+
+@pytest.mark.parametrize('kind', ['td3_bc', 'bc', 'ddpg'])
+def test_hip_graph_step_equals_eager(kind):
+    """The captured sample+update graph replays exactly what the eager launches do (counters live on device)."""
+    O, A, H, B = 24, 6, 128, 64
+    torch.manual_seed(3)
+    a1 = make(kind, O, A, H, B)
+    torch.manual_seed(3)
+    a2 = make(kind, O, A, H, B)
+    e1, it1 = _arena(9)
+    e2, it2 = _arena(9)
+    assert a1.enable_graph(it1)
+    it2.sample_into(a2.engine.batch_slots())               # capture spends one Philox batch: keep the streams aligned
+    steps = [0, 2, 4, 6] if kind == 'ddpg' else [0, 1, 2, 3]
+    for s in steps:
+        m1, m2 = a1.update(it1, s), a2.update(it2, s)
+        assert m1.keys() == m2.keys()
+        for k in m1:
+            assert m1[k] == m2[k], (kind, s, k, m1[k], m2[k])
+    for (n1, net1), (n2, net2) in zip(nets_of(a1), nets_of(a2)):
+        for p, q in zip(net1.parameters(), net2.parameters()):
+            assert torch.equal(p, q), n1
+    assert a1.engine.opt_steps() == a2.engine.opt_steps()
+    a1.disable_graph()
+    m1, m2 = a1.update(it1, 8), a2.update(it2, 8)           # back to eager: streams continue in lock-step
+    assert m1 == m2

@@ -129,7 +129,9 @@ def test_knn_topk(lib, gold, ns, nt, dim, k):
     src = rs.standard_normal((ns, dim)).astype(np.float32)
     tgt = src if same else rs.standard_normal((nt, dim)).astype(np.float32)
     out = torch.empty(ns, k, device='cuda')
-    L.check(lib.exorl_knn_topk(dev(src).data_ptr(), ns, dev(tgt).data_ptr(), nt, dim, k, out.data_ptr(), None))
+    sd, td = dev(src), dev(tgt)
+    L.check(lib.exorl_knn_topk(sd.data_ptr(), ns, td.data_ptr(), nt, dim, k, out.data_ptr(), None))
+    torch.cuda.synchronize()
     want = knn.topk_smallest(knn.pairwise_l2(src[:64], tgt), k) if ns > 64 else knn.topk_smallest(knn.pairwise_l2(src, tgt), k)
     got = out.cpu().numpy()[:want.shape[0]]
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-6)
@@ -144,10 +146,11 @@ def test_knn_golden_pbe_and_proto(lib, gold):
     z = np.load(gold / 'utils_g2.npz')
     rep = z['pbe_rep']
     out = torch.empty(16, 3, device='cuda')
-    L.check(lib.exorl_knn_topk(dev(rep).data_ptr(), 16, dev(rep).data_ptr(), 16, 8, 3, out.data_ptr(), None))
+    rd, zd, qd = dev(rep), dev(z['knn_z']), dev(z['knn_queue'])
+    L.check(lib.exorl_knn_topk(rd.data_ptr(), 16, rd.data_ptr(), 16, 8, 3, out.data_ptr(), None))
     topk = out.cpu().numpy()
     np.testing.assert_allclose(np.log(np.maximum(topk, 0).mean(1, keepdims=True) + 1), z['pbe_avg_r1'], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(np.log(topk[:, -1:] + 1), z['pbe_kth_r1'], rtol=1e-5, atol=1e-6)
     out = torch.empty(10, 3, device='cuda')
-    L.check(lib.exorl_knn_topk(dev(z['knn_z']).data_ptr(), 10, dev(z['knn_queue']).data_ptr(), 20, 6, 3, out.data_ptr(), None))
+    L.check(lib.exorl_knn_topk(zd.data_ptr(), 10, qd.data_ptr(), 20, 6, 3, out.data_ptr(), None))
     np.testing.assert_allclose(out.cpu().numpy()[:, -1:], z['knn_reward'], rtol=1e-5)

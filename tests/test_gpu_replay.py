@@ -73,7 +73,7 @@ def test_index_stream_equals_reference_recording(gold, tmp_path):
 def test_error_behaviour(tmp_path):
     from exorl_amd.engine import ReplayEngine
     from exorl_amd import _lib as L
-    eng = ReplayEngine((4,), np.float32, 2, 0, 64, 4)
+    eng = ReplayEngine((4,), np.float32, 2, 0, 64, 32)
     with pytest.raises(L.ExorlError, match='no resident episodes'):
         eng.sample(4, 1, 0.99, L.SAMPLER_PHILOX)
     ep = _synth.synth_episodes(0, [3], 4, 2)[0]
