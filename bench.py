@@ -134,6 +134,7 @@ def main():
         for net in (agent.actor, agent.critic, agent.critic_target):
             for p in net.parameters():
                 dist.broadcast(p, 0)
+        agent.params_changed()
     replay = synth_replay(rank, world, device)
     it = ArenaIterator(replay, B, 1, GAMMA, 'philox')
     use_graph = bool(args.graph) and world == 1 and agent.enable_graph(it)

@@ -111,20 +111,26 @@ class _AgentBase:
             _mlp_init(obs_dim + action_dim, hidden_dim, 1, nt, 2)       # critic_target's draws, overwritten by the copy
         self.engine = AgentEngine(self.KIND, obs_dim, action_dim, hidden_dim, batch_size, lr=lr, tau=tau, alpha=alpha,
                                   stddev_clip=stddev_clip, precision=precision, world_size=ws, seed=seed, device=device)
-        self.actor = NetView(self.engine, L.NET_ACTOR, _DDPG_ACTOR_KEYS if ddpg else _OFFLINE_ACTOR_KEYS)
+        self.actor = NetView(self.engine, L.NET_ACTOR, _DDPG_ACTOR_KEYS if ddpg else _OFFLINE_ACTOR_KEYS, self.params_changed)
         for p, w in zip(self.actor.parameters(), actor0):
             p.copy_(w.reshape(p.shape))
         if critic0 is not None:
             keys = _DDPG_CRITIC_KEYS if ddpg else _OFFLINE_CRITIC_KEYS
-            self.critic = NetView(self.engine, L.NET_CRITIC, keys)
-            self.critic_target = NetView(self.engine, L.NET_CRITIC_TARGET, keys)
+            self.critic = NetView(self.engine, L.NET_CRITIC, keys, self.params_changed)
+            self.critic_target = NetView(self.engine, L.NET_CRITIC_TARGET, keys, self.params_changed)
             for p, w in zip(self.critic.parameters(), critic0):
                 p.copy_(w.reshape(p.shape))
-            self.engine.params_changed(sync_target=True)               # critic_target.load_state_dict(critic.state_dict())
+        self.engine.params_changed(sync_target=True)                   # critic_target.load_state_dict(critic.state_dict())
         self._slots = None
         self._graph_iter = None
         self._graph_stddev = None
         self.noise_hook = None      # tests: callable(shape) -> np.ndarray standing in for _standard_normal
+
+    def params_changed(self):
+        """Call after writing parameter tensors in place (copy_ on .parameters(), dist.broadcast, ...): the kernels
+        read derived copies (transposed first-layer weights, bf16 hidden weights) that must be rebuilt.
+        load_state_dict / init_from / utils.hard_update_params do it themselves."""
+        self.engine.params_changed(sync_target=False)
 
     # -- nn.Module-ish surface used by utils.eval_mode and the training scripts
     def train(self, training=True):
@@ -335,6 +341,7 @@ class DDPGAgent(_AgentBase):
         if self.init_critic:          # critic.trunk = first 4 tensors (ddpg.py:209-210)
             for p, t in zip(other.critic.parameters()[:4], self.critic.parameters()[:4]):
                 t.copy_(p)
+        self.params_changed()
 
     def get_meta_specs(self):
         return tuple()

@@ -69,42 +69,54 @@ static NetDesc make_net(int in_dim, int out_dim, int H, int n_trunks, int n_head
     return d;
 }
 
-struct FwdBufs { float *h1, *xhat, *rstd, *h2, *out; };
-struct BwdBufs { float *dz2, *dh1; };
+struct FwdBufs { float *h1, *xhat, *rstd, *h2, *out; unsigned short* h1b; };
+struct BwdBufs { float *dz2, *dh1; unsigned short* dz2b; };
+struct NetShadow { float* w0t; unsigned short* w1b; };     // W0 transposed per trunk; W1 as bf16 per head
+struct Partials { float *Ph, *Pt; };                       // per-chunk partial gradients (fused.hip)
 
-static int net_forward(const NetDesc& d, const float* P, const float* x, int64_t ldx, int rows, const FwdBufs& f,
-                       bool save, bool tanh_out, int prec, hipStream_t s) {
+static ShadowSpec shadow_spec(const NetDesc& d, const NetShadow& sh, const NetShadow* target) {
+    ShadowSpec s{};
+    s.n_trunks = d.n_trunks; s.n_heads = d.n_heads; s.in_dim = d.in_dim; s.H = d.H;
+    for (int t = 0; t < d.n_trunks; ++t) s.w0_off[t] = d.W0 + t * d.trunk_stride;
+    for (int i = 0; i < d.n_heads; ++i) s.w1_off[i] = d.W1 + i * d.head_stride;
+    s.w0t = sh.w0t; s.w1b = sh.w1b;
+    s.t_w0t = target ? target->w0t : nullptr;
+    s.t_w1b = target ? target->w1b : nullptr;
+    return s;
+}
+
+static int net_forward(const NetDesc& d, const float* P, const NetShadow& sh, const float* x, int64_t ldx, int rows,
+                       const FwdBufs& f, bool save, bool tanh_out, int prec, hipStream_t s) {
     const int H = d.H;
     const int64_t act = (int64_t)rows * H;
+    EXORL_TRY(trunk_fwd(x, ldx, sh.w0t, P + d.b0, P + d.g, P + d.beta, f.h1, save ? f.xhat : nullptr, save ? f.rstd : nullptr,
+                        nullptr, rows, d.in_dim, H, d.n_trunks, act, d.trunk_stride, (int64_t)d.in_dim * H, s));
     GemmProblem p[2];
-    for (int t = 0; t < d.n_trunks; ++t)
-        p[t] = GemmProblem{x, P + d.W0 + t * d.trunk_stride, f.h1 + t * act, P + d.b0 + t * d.trunk_stride,
-                           rows, H, d.in_dim, ldx, d.in_dim, H};
-    EXORL_TRY(gemm_grouped(prec, 0, 0, p, d.n_trunks, false, false, s));
-    EXORL_TRY(ln_tanh_fwd(f.h1, P + d.g, P + d.beta, f.h1, save ? f.xhat : nullptr, save ? f.rstd : nullptr, rows, H,
-                          d.n_trunks, act, d.trunk_stride, s));
     for (int i = 0; i < d.n_heads; ++i)
         p[i] = GemmProblem{f.h1 + (d.n_trunks == d.n_heads ? i : 0) * act, P + d.W1 + i * d.head_stride, f.h2 + i * act,
                            P + d.b1 + i * d.head_stride, rows, H, H, H, H, H};
     EXORL_TRY(gemm_grouped(prec, 0, 0, p, d.n_heads, true, false, s));
-    EXORL_TRY(head_fwd(f.h2, P + d.W2, P + d.b2, f.out, rows, H, d.out_dim, tanh_out ? 1 : 0, d.n_heads, act, d.head_stride,
-                       (int64_t)rows * d.out_dim, s));
+    if (H % 4 == 0)
+        EXORL_TRY(head_fwd4(f.h2, P + d.W2, P + d.b2, f.out, rows, H, d.out_dim, tanh_out ? 1 : 0, d.n_heads, act, d.head_stride,
+                            (int64_t)rows * d.out_dim, s));
+    else
+        EXORL_TRY(head_fwd(f.h2, P + d.W2, P + d.b2, f.out, rows, H, d.out_dim, tanh_out ? 1 : 0, d.n_heads, act, d.head_stride,
+                           (int64_t)rows * d.out_dim, s));
     return 0;
 }
 
-// G == nullptr: dgrad only (no parameter gradients). dx (rows x dx_cols) receives d/dx[:, col0:col0+dx_cols].
-static int net_backward(const NetDesc& d, const float* P, float* G, const float* x, int64_t ldx, int rows,
-                        const FwdBufs& f, const float* dout, const BwdBufs& b, float* dx, int dx_col0, int dx_cols,
-                        int prec, hipStream_t s) {
+// G == nullptr: dgrad only (no parameter gradients). dx (n_trunks x rows x dx_cols, one slab per trunk — the
+// consumer adds them) receives d/dx[:, col0:col0+dx_cols].
+static int net_backward(const NetDesc& d, const float* P, const NetShadow& sh, float* G, const Partials& pt, const float* x,
+                        int64_t ldx, int rows, const FwdBufs& f, const float* dout, const BwdBufs& b, float* dx, int dx_col0,
+                        int dx_cols, int prec, hipStream_t s) {
     const int H = d.H;
     const int64_t act = (int64_t)rows * H;
     const bool paired = d.n_trunks == d.n_heads;
     GemmProblem p[2];
-    EXORL_TRY(head_bwd_dx(dout, P + d.W2, f.h2, b.dz2, rows, H, d.out_dim, d.n_heads, act, d.head_stride,
-                          (int64_t)rows * d.out_dim, s));
+    EXORL_TRY(head_bwd(dout, P + d.W2, f.h2, b.dz2, nullptr, G ? pt.Ph : nullptr, rows, H, d.out_dim, d.n_heads, act, d.head_stride,
+                       (int64_t)rows * d.out_dim, G ? 1 : 0, s));
     if (G) {
-        EXORL_TRY(head_bwd_params(dout, f.h2, b.dz2, G + d.W2, G + d.b1, G + d.b2, rows, H, d.out_dim, d.n_heads, act,
-                                  d.head_stride, (int64_t)rows * d.out_dim, s));
         for (int i = 0; i < d.n_heads; ++i)          // dW1_i[n][k] = sum_m dz2_i[m][n] h1[m][k]
             p[i] = GemmProblem{b.dz2 + i * act, f.h1 + (paired ? i : 0) * act, G + d.W1 + i * d.head_stride, nullptr,
                                H, H, rows, H, H, H};
@@ -118,19 +130,16 @@ static int net_backward(const NetDesc& d, const float* P, float* G, const float*
     } else {
         for (int i = 0; i < d.n_heads; ++i) EXORL_TRY(gemm_grouped(prec, 0, 1, p + i, 1, false, i > 0, s));
     }
-    if (G) EXORL_TRY(ln_param_grad(b.dh1, f.h1, f.xhat, G + d.g, G + d.beta, rows, H, d.n_trunks, act, d.trunk_stride, s));
-    EXORL_TRY(ln_tanh_bwd(b.dh1, f.h1, f.xhat, f.rstd, P + d.g, b.dh1, rows, H, d.n_trunks, act, d.trunk_stride, s));
+    EXORL_TRY(trunk_bwd(b.dh1, f.h1, f.xhat, f.rstd, P + d.g, x, ldx, sh.w0t, pt.Pt, dx, dx_col0, dx_cols, rows, d.in_dim, H,
+                        d.n_trunks, act, d.trunk_stride, (int64_t)d.in_dim * H, G ? 1 : 0, s));
     if (G) {
-        EXORL_TRY(colsum(b.dh1, G + d.b0, rows, H, d.n_trunks, act, d.trunk_stride, s));
-        for (int t = 0; t < d.n_trunks; ++t)         // dW0_t[n][k] = sum_m dz0_t[m][n] x[m][k]
-            p[t] = GemmProblem{b.dh1 + t * act, x, G + d.W0 + t * d.trunk_stride, nullptr, H, d.in_dim, rows, H, ldx, d.in_dim};
-        EXORL_TRY(gemm_grouped(prec, 1, 1, p, d.n_trunks, false, false, s));
-    }
-    if (dx) {
-        for (int t = 0; t < d.n_trunks; ++t) {       // dx[m][c] = sum_n dz0_t[m][n] W0_t[n][col0+c]
-            GemmProblem q{b.dh1 + t * act, P + d.W0 + t * d.trunk_stride + dx_col0, dx, nullptr, rows, dx_cols, H, H, d.in_dim, dx_cols};
-            EXORL_TRY(gemm_grouped(prec, 0, 1, &q, 1, false, t > 0, s));
-        }
+        FinalizeArgs fa{};
+        fa.Ph = pt.Ph; fa.head_chunks = head_chunks(rows); fa.n_heads = d.n_heads; fa.head_stride = d.head_stride;
+        fa.gW2 = d.W2; fa.gb1 = d.b1; fa.gb2 = d.b2;
+        fa.Pt = pt.Pt; fa.trunk_chunks = trunk_chunks(rows); fa.n_trunks = d.n_trunks; fa.trunk_stride = d.trunk_stride;
+        fa.gW0 = d.W0; fa.gb0 = d.b0; fa.gg = d.g; fa.gbeta = d.beta;
+        fa.H = H; fa.nout = d.out_dim; fa.in_dim = d.in_dim; fa.G = G;
+        EXORL_TRY(finalize_grads(fa, s));
     }
     return 0;
 }
@@ -168,6 +177,9 @@ struct exorl_agent {
     FwdBufs fa{}, ft{}, fc{};    // actor (2B rows), target critic, critic
     BwdBufs bc{}, ba{};
     float *dq = nullptr, *da = nullptr, *dpre = nullptr;
+    NetShadow sh_actor{}, sh_critic{}, sh_target{};
+    ShadowSpec spec_actor{}, spec_critic{};
+    Partials pa{}, pc{};
     float *stats = nullptr, *metrics = nullptr;      // contiguous: stats[4] then metrics[EXORL_N_METRICS]
     float *act_x = nullptr, *act_noise = nullptr;
     FwdBufs fact{};
@@ -195,23 +207,30 @@ static void carve(exorl_agent* a, Carver& c) {
     }
     a->obs = c.take(B * O); a->action = c.take(B * A); a->reward = c.take(B); a->discount = c.take(B); a->next_obs = c.take(B * O);
     a->xa = c.take(2 * B * O);
-    a->fa = FwdBufs{c.take(2 * B * H), c.take(2 * B * H), c.take(2 * B), c.take(2 * B * H), c.take(2 * B * A)};
-    a->ba = BwdBufs{c.take(B * H), c.take(B * H)};
+    auto take_u16 = [&](int64_t n) { return reinterpret_cast<unsigned short*>(c.take((n + 1) / 2)); };
+    const bool bf = cfg.precision == EXORL_PREC_BF16;
+    a->fa = FwdBufs{c.take(2 * B * H), c.take(2 * B * H), c.take(2 * B), c.take(2 * B * H), c.take(2 * B * A), bf ? take_u16(2 * B * H) : nullptr};
+    a->ba = BwdBufs{c.take(B * H), c.take(B * H), bf ? take_u16(B * H) : nullptr};
+    a->sh_actor = NetShadow{c.take(O * H), bf ? take_u16(H * H) : nullptr};
+    a->pa = Partials{c.take((int64_t)head_chunks(B) * ((A + 1) * H + 16)), c.take((int64_t)trunk_chunks(B) * (3 + O) * H)};
     a->dpre = c.take(B * A);
     a->stats = c.take(4 + EXORL_N_METRICS);
     a->metrics = a->stats ? a->stats + 4 : nullptr;
     a->state = reinterpret_cast<StepState*>(c.take((sizeof(StepState) + 3) / 4));
     a->act_x = c.take(ACT_ROWS * O);
     a->act_noise = c.take(ACT_ROWS * A);
-    a->fact = FwdBufs{c.take(ACT_ROWS * H), nullptr, nullptr, c.take(ACT_ROWS * H), c.take(ACT_ROWS * A)};
+    a->fact = FwdBufs{c.take(ACT_ROWS * H), nullptr, nullptr, c.take(ACT_ROWS * H), c.take(ACT_ROWS * A), nullptr};
     if (a->has_critic) {
         const int64_t nt = a->critic.n_trunks;
         a->xc_cur = c.take(B * W); a->xc_next = c.take(B * W); a->xc_pi = c.take(B * W);
-        a->ft = FwdBufs{c.take(nt * B * H), nullptr, nullptr, c.take(2 * B * H), c.take(2 * B)};
-        a->fc = FwdBufs{c.take(nt * B * H), c.take(nt * B * H), c.take(nt * B), c.take(2 * B * H), c.take(2 * B)};
-        a->bc = BwdBufs{c.take(2 * B * H), c.take(nt * B * H)};
+        a->ft = FwdBufs{c.take(nt * B * H), nullptr, nullptr, c.take(2 * B * H), c.take(2 * B), bf ? take_u16(nt * B * H) : nullptr};
+        a->fc = FwdBufs{c.take(nt * B * H), c.take(nt * B * H), c.take(nt * B), c.take(2 * B * H), c.take(2 * B), bf ? take_u16(nt * B * H) : nullptr};
+        a->bc = BwdBufs{c.take(2 * B * H), c.take(nt * B * H), bf ? take_u16(2 * B * H) : nullptr};
         a->dq = c.take(2 * B);
-        a->da = c.take(B * A);
+        a->da = c.take(nt * B * A);
+        a->sh_critic = NetShadow{c.take(nt * W * H), bf ? take_u16(2 * H * H) : nullptr};
+        a->sh_target = NetShadow{c.take(nt * W * H), bf ? take_u16(2 * H * H) : nullptr};
+        a->pc = Partials{c.take(2 * (int64_t)head_chunks(B) * (2 * H + 16)), c.take(nt * (int64_t)trunk_chunks(B) * (3 + W) * H)};
     }
 }
 
@@ -262,14 +281,14 @@ static int phase0(exorl_agent* a, float stddev, const float* noise_c, hipStream_
     const float* Pc = a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM];
     const float* Pt = a->flat[EXORL_NET_CRITIC_TARGET][EXORL_T_PARAM];
     // actor on [next_obs; obs] in one pass (td3_bc.py:124 and :149 use the same weights)
-    EXORL_TRY(net_forward(a->actor, Pa, a->xa, O, 2 * B, a->fa, true, true, prec, s));
+    EXORL_TRY(net_forward(a->actor, Pa, a->sh_actor, a->xa, O, 2 * B, a->fa, true, true, prec, s));
     // next_action = dist.sample(clip) (td3_bc.py:125) straight into the target critic's input
     EXORL_TRY(sample_action(a->fa.out, noise_spec(a, noise_c, 0), stddev, cfg.stddev_clip, 1, a->xc_next + O, W, B, A, nullptr, s));
-    EXORL_TRY(net_forward(a->critic, Pt, a->xc_next, W, B, a->ft, false, false, prec, s));     // td3_bc.py:126
-    EXORL_TRY(net_forward(a->critic, Pc, a->xc_cur, W, B, a->fc, true, false, prec, s));       // td3_bc.py:130
+    EXORL_TRY(net_forward(a->critic, Pt, a->sh_target, a->xc_next, W, B, a->ft, false, false, prec, s));     // td3_bc.py:126
+    EXORL_TRY(net_forward(a->critic, Pc, a->sh_critic, a->xc_cur, W, B, a->fc, true, false, prec, s));       // td3_bc.py:130
     EXORL_TRY(critic_loss(a->fc.out, a->ft.out, a->reward, a->discount, a->dq, a->metrics, B, a->inv_bg, s));   // :127-131
-    EXORL_TRY(net_backward(a->critic, Pc, a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD], a->xc_cur, W, B, a->fc, a->dq, a->bc,
-                           nullptr, 0, 0, prec, s));                                                     // :141
+    EXORL_TRY(net_backward(a->critic, Pc, a->sh_critic, a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD], a->pc, a->xc_cur, W, B, a->fc, a->dq,
+                           a->bc, nullptr, 0, 0, prec, s));                                                     // :141
     return 0;
 }
 
@@ -280,12 +299,12 @@ static int phase1(exorl_agent* a, float stddev, const float* noise_a, hipStream_
     const int B = cfg.batch, O = cfg.obs_dim, A = cfg.act_dim, W = O + A, prec = cfg.precision;
     EXORL_TRY(adam_step_dev(a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD],
                             a->flat[EXORL_NET_CRITIC][EXORL_T_ADAM_M], a->flat[EXORL_NET_CRITIC][EXORL_T_ADAM_V], a->critic.total,
-                            &a->state->critic, a->flat[EXORL_NET_CRITIC_TARGET][EXORL_T_PARAM], s));
+                            &a->state->critic, a->flat[EXORL_NET_CRITIC_TARGET][EXORL_T_PARAM], &a->spec_critic, s));
     // policy.sample(clip) on obs (td3_bc.py:151): mu rows B..2B of the stacked actor forward
     float* logprob = cfg.kind == EXORL_AGENT_DDPG ? a->metrics + EXORL_M_ACTOR_LOGPROB : nullptr;
     EXORL_TRY(sample_action(a->fa.out + (int64_t)B * A, noise_spec(a, noise_a, 1), stddev, cfg.stddev_clip, 1, a->xc_pi + O, W, B, A,
                             logprob, s));
-    EXORL_TRY(net_forward(a->critic, a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->xc_pi, W, B, a->fc, true, false, prec, s));
+    EXORL_TRY(net_forward(a->critic, a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->sh_critic, a->xc_pi, W, B, a->fc, true, false, prec, s));
     EXORL_TRY(actor_stats(a->fc.out, a->stats, B, s));
     return 0;
 }
@@ -297,25 +316,26 @@ static int phase2(exorl_agent* a, float stddev, hipStream_t s) {
     const float* Pa = a->flat[EXORL_NET_ACTOR][EXORL_T_PARAM];
     if (a->has_critic) {
         EXORL_TRY(actor_dq(a->fc.out, a->stats, a->dq, B, a->inv_bg, cfg.alpha, cfg.kind == EXORL_AGENT_TD3_BC, s));
-        EXORL_TRY(net_backward(a->critic, a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], nullptr, a->xc_pi, W, B, a->fc, a->dq, a->bc,
-                               a->da, O, A, prec, s));
+        EXORL_TRY(net_backward(a->critic, a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->sh_critic, nullptr, a->pc, a->xc_pi, W, B, a->fc,
+                               a->dq, a->bc, a->da, O, A, prec, s));
     }
     // the obs half (rows B..2B) of the stacked actor forward
     FwdBufs f{a->fa.h1 + (int64_t)B * H, a->fa.xhat + (int64_t)B * H, a->fa.rstd + B, a->fa.h2 + (int64_t)B * H,
-              a->fa.out + (int64_t)B * A};
+              a->fa.out + (int64_t)B * A, a->fa.h1b ? a->fa.h1b + (int64_t)B * H : nullptr};
     if (!a->has_critic)       // BC (bc.py:82): the only forward of the step
-        EXORL_TRY(net_forward(a->actor, Pa, a->xa + (int64_t)B * O, O, B, f, true, true, prec, s));
-    EXORL_TRY(actor_dmu(a->da, A, f.out, a->action, a->has_critic ? nullptr : a->reward, a->dpre, a->stats, a->metrics, B, A,
-                        a->inv_bg, cfg.alpha, cfg.kind, stddev, s));
-    EXORL_TRY(net_backward(a->actor, Pa, a->flat[EXORL_NET_ACTOR][EXORL_T_GRAD], a->xa + (int64_t)B * O, O, B, f, a->dpre, a->ba,
-                           nullptr, 0, 0, prec, s));
+        EXORL_TRY(net_forward(a->actor, Pa, a->sh_actor, a->xa + (int64_t)B * O, O, B, f, true, true, prec, s));
+    EXORL_TRY(actor_dmu(a->da, A, a->has_critic ? a->critic.n_trunks : 0, (int64_t)B * A, f.out, a->action,
+                        a->has_critic ? nullptr : a->reward, a->dpre, a->stats, a->metrics, B, A, a->inv_bg, cfg.alpha, cfg.kind,
+                        stddev, s));
+    EXORL_TRY(net_backward(a->actor, Pa, a->sh_actor, a->flat[EXORL_NET_ACTOR][EXORL_T_GRAD], a->pa, a->xa + (int64_t)B * O, O, B, f,
+                           a->dpre, a->ba, nullptr, 0, 0, prec, s));
     return 0;
 }
 
 static int phase3(exorl_agent* a, hipStream_t s) {
     return adam_step_dev(a->flat[EXORL_NET_ACTOR][EXORL_T_PARAM], a->flat[EXORL_NET_ACTOR][EXORL_T_GRAD],
                          a->flat[EXORL_NET_ACTOR][EXORL_T_ADAM_M], a->flat[EXORL_NET_ACTOR][EXORL_T_ADAM_V], a->actor.total,
-                         &a->state->actor, nullptr, s);
+                         &a->state->actor, nullptr, &a->spec_actor, s);
 }
 
 static int release_graph(exorl_agent* a) {
@@ -361,6 +381,8 @@ int exorl_agent_create(const exorl_agent_cfg* cfg, void* workspace, size_t works
     if (e != hipSuccess) { set_error("agent_create: hipMemset -> %s", hipGetErrorString(e)); if (a->owns_ws) (void)hipFree(a->ws); delete a; return 1; }
     Carver c(a->ws);
     carve(a, c);
+    a->spec_actor = shadow_spec(a->actor, a->sh_actor, nullptr);
+    if (a->has_critic) a->spec_critic = shadow_spec(a->critic, a->sh_critic, &a->sh_target);
     StepState st{};
     st.lr = cfg->lr; st.b1 = 0.9f; st.b2 = 0.999f; st.eps = 1e-8f; st.tau = cfg->tau;      // torch.optim.Adam defaults
     st.has_critic = a->has_critic ? 1 : 0;
@@ -416,9 +438,15 @@ int exorl_agent_flat(exorl_agent_t* a, int32_t net, int32_t what, void** ptr, in
 
 int exorl_agent_params_changed(exorl_agent_t* a, int32_t sync_target, void* stream) {
     EXORL_REQUIRE(a, "agent_params_changed: null handle");
+    hipStream_t s = as_stream(stream);
     if (sync_target && a->has_critic)
         EXORL_CHECK_HIP(hipMemcpyAsync(a->flat[EXORL_NET_CRITIC_TARGET][EXORL_T_PARAM], a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM],
-                                       a->critic.total * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)));
+                                       a->critic.total * sizeof(float), hipMemcpyDeviceToDevice, s));
+    EXORL_TRY(refresh_shadows(a->flat[EXORL_NET_ACTOR][EXORL_T_PARAM], a->actor.total, a->spec_actor, false, s));
+    if (a->has_critic) {
+        EXORL_TRY(refresh_shadows(a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->critic.total, a->spec_critic, false, s));
+        EXORL_TRY(refresh_shadows(a->flat[EXORL_NET_CRITIC_TARGET][EXORL_T_PARAM], a->critic.total, a->spec_critic, true, s));
+    }
     return 0;
 }
 
@@ -479,7 +507,7 @@ int exorl_agent_act(exorl_agent_t* a, const float* obs, int32_t n, float stddev,
     const int O = a->cfg.obs_dim, A = a->cfg.act_dim;
     for (int r0 = 0; r0 < n; r0 += ACT_ROWS) {
         const int rows = n - r0 < ACT_ROWS ? n - r0 : ACT_ROWS;
-        EXORL_TRY(net_forward(a->actor, a->flat[EXORL_NET_ACTOR][EXORL_T_PARAM], obs + (int64_t)r0 * O, O, rows, a->fact, false, true,
+        EXORL_TRY(net_forward(a->actor, a->flat[EXORL_NET_ACTOR][EXORL_T_PARAM], a->sh_actor, obs + (int64_t)r0 * O, O, rows, a->fact, false, true,
                               a->cfg.precision, s));
         if (eval_mode) {
             EXORL_CHECK_HIP(hipMemcpyAsync(out + (int64_t)r0 * A, a->fact.out, (size_t)rows * A * 4, hipMemcpyDeviceToDevice, s));

@@ -31,6 +31,41 @@ int head_bwd_dx(const float* dout, const float* W, const float* a, float* dz, in
 int head_bwd_params(const float* dout, const float* a, const float* dz, float* dW, float* db_hidden, float* db_out,
                     int rows, int H, int nout, int nets, int64_t astride, int64_t pstride, int64_t dstride, hipStream_t s);
 
+// ---- fused layer kernels (fused.hip)
+int trunk_fwd(const float* x, int64_t ldx, const float* W0T, const float* b0, const float* gain, const float* beta,
+              float* h, float* xhat, float* rstd, unsigned short* h_bf16, int rows, int in_dim, int H, int nets,
+              int64_t astride, int64_t pstride, int64_t tstride, hipStream_t s);
+int trunk_bwd(const float* dh, const float* h, const float* xhat, const float* rstd, const float* gain, const float* x,
+              int64_t ldx, const float* W0T, float* P, float* dx, int dx_col0, int dx_cols, int rows, int in_dim, int H,
+              int nets, int64_t astride, int64_t pstride, int64_t tstride, int want_params, hipStream_t s);
+int trunk_chunks(int rows);
+int head_fwd4(const float* a, const float* W, const float* b, float* out, int rows, int H, int nout, int tanh_out,
+              int nets, int64_t astride, int64_t pstride, int64_t ostride, hipStream_t s);
+int head_bwd(const float* dout, const float* W, const float* a, float* dz, unsigned short* dz_bf16, float* P, int rows,
+             int H, int nout, int nets, int64_t astride, int64_t pstride, int64_t dstride, int want_params, hipStream_t s);
+int head_chunks(int rows);
+struct FinalizeArgs {
+    const float* Ph; int head_chunks; int n_heads; int64_t head_stride;    // head partials; stride between heads in G
+    int64_t gW2, gb1, gb2;                                                 // offsets of head 0's tensors in G
+    const float* Pt; int trunk_chunks; int n_trunks; int64_t trunk_stride; // trunk partials
+    int64_t gW0, gb0, gg, gbeta;
+    int H, nout, in_dim;
+    float* G;
+};
+int finalize_grads(const FinalizeArgs& f, hipStream_t s);
+
+// Derived copies of a net's weights that the kernels read: W0T[in][H] per trunk (coalesced first-layer reads)
+// and, in bf16 mode, W1 as bf16 per head (MFMA operand). Kept current by the Adam kernel itself.
+struct ShadowSpec {
+    int n_trunks, n_heads, in_dim, H;
+    int64_t w0_off[2], w1_off[2];      // flat offsets of W0 (per trunk) and W1 (per head)
+    float* w0t;                        // [n_trunks][in][H]
+    unsigned short* w1b;               // [n_heads][H][H] bf16, or nullptr
+    float* t_w0t;                      // same for the Polyak target (nullptr if none)
+    unsigned short* t_w1b;
+};
+int refresh_shadows(const float* p, int64_t n, const ShadowSpec& sh, bool target, hipStream_t s);
+
 // ---- loss / sampling kernels (loss.hip)
 struct NoiseSpec {           // where TruncatedNormal noise comes from
     const float* buf;        // (B,A) standard normal draws, or nullptr -> Philox(seed, counter)
@@ -63,7 +98,7 @@ int critic_loss(const float* q, const float* tq, const float* reward, const floa
 int actor_stats(const float* q, float* stats, int B, hipStream_t s);
 int actor_dq(const float* q, const float* stats, float* dq, int B, float inv_bg, float alpha, int use_lambda,
              hipStream_t s);
-int actor_dmu(const float* da, int64_t da_ld, const float* mu, const float* a_data, const float* reward, float* dpre, float* stats,
+int actor_dmu(const float* da, int64_t da_ld, int da_nets, int64_t da_net_stride, const float* mu, const float* a_data, const float* reward, float* dpre, float* stats,
               float* metrics, int B, int A, float inv_bg, float alpha, int kind, float stddev, hipStream_t s);
 
 // ---- optimiser (optim.hip)
@@ -72,7 +107,7 @@ int adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr,
 int soft_update(const float* p, float* target, int64_t n, float tau, hipStream_t s);
 // Adam with the scalars read from device memory (StepState), for graph-replayable steps.
 int adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const AdamConst* c_dev, float* target,
-                  hipStream_t s);
+                  const ShadowSpec* shadows, hipStream_t s);
 
 // ---- replay (replay.hip) internal entry points used by the agent's graph capture
 int replay_sample_impl(exorl_replay* r, int32_t batch, int32_t nstep, float gamma, int32_t sampler,

@@ -186,7 +186,8 @@ int actor_dq(const float* q, const float* stats, float* dq, int B, float inv_bg,
 // Gradient at the actor's pre-tanh output.
 //  TD3+BC: dmu = da + 2 (mu - a)/(Bg*A);  TD3/DDPG: dmu = da;  BC: dmu = -(a - mu)/std^2 / Bg
 //  dpre = dmu * (1 - mu^2).  Also writes the actor_loss metric (partial over the global batch).
-__global__ __launch_bounds__(1024) void actor_dmu_kernel(const float* __restrict__ da, int64_t da_ld,
+__global__ __launch_bounds__(1024) void actor_dmu_kernel(const float* __restrict__ da, int64_t da_ld, int da_nets,
+                                                         int64_t da_net_stride,
                                                          const float* __restrict__ mu, const float* __restrict__ a_data,
                                                          const float* __restrict__ reward, float* __restrict__ dpre, const float* __restrict__ stats,
                                                          float* __restrict__ metrics, int B, int A, float inv_bg,
@@ -204,14 +205,17 @@ __global__ __launch_bounds__(1024) void actor_dmu_kernel(const float* __restrict
         float dmu;
         if (kind == EXORL_AGENT_TD3_BC) {
             const float d = mv - a_data[i];
-            dmu = da[(int64_t)m * da_ld + j] + bc_coef * d;
+            float dav = 0.f;
+            for (int t = 0; t < da_nets; ++t) dav += da[t * da_net_stride + (int64_t)m * da_ld + j];
+            dmu = dav + bc_coef * d;
             v[0] += d * d;
         } else if (kind == EXORL_AGENT_BC) {
             const float d = a_data[i] - mv;
             dmu = -d * inv_var * inv_bg;
             v[0] += d * d * 0.5f * inv_var - log_norm;     // -log N(a; mu, std)
         } else {
-            dmu = da[(int64_t)m * da_ld + j];
+            dmu = 0.f;
+            for (int t = 0; t < da_nets; ++t) dmu += da[t * da_net_stride + (int64_t)m * da_ld + j];
         }
         dpre[i] = dmu * (1.0f - mv * mv);
     }
@@ -232,9 +236,9 @@ __global__ __launch_bounds__(1024) void actor_dmu_kernel(const float* __restrict
     }
 }
 
-int actor_dmu(const float* da, int64_t da_ld, const float* mu, const float* a_data, const float* reward, float* dpre, float* stats,
+int actor_dmu(const float* da, int64_t da_ld, int da_nets, int64_t da_net_stride, const float* mu, const float* a_data, const float* reward, float* dpre, float* stats,
               float* metrics, int B, int A, float inv_bg, float alpha, int kind, float stddev, hipStream_t s) {
-    hipLaunchKernelGGL(actor_dmu_kernel, dim3(1), dim3(1024), 0, s, da, da_ld, mu, a_data, reward, dpre, stats, metrics, B, A,
+    hipLaunchKernelGGL(actor_dmu_kernel, dim3(1), dim3(1024), 0, s, da, da_ld, da_nets, da_net_stride, mu, a_data, reward, dpre, stats, metrics, B, A,
                        inv_bg, alpha, kind, stddev);
     EXORL_LAUNCH_CHECK();
     return 0;

@@ -65,6 +65,8 @@ def hard_update_params(net, target_net):
     """utils.py:50-52 (init_from, snapshot interchange)."""
     for p, t in zip(net.parameters(), target_net.parameters()):
         t.data.copy_(p.data)
+    if getattr(target_net, '_on_change', None):
+        target_net._on_change()
 
 
 def soft_update_params(net, target_net, tau):
@@ -73,6 +75,8 @@ def soft_update_params(net, target_net, tau):
     lib = L.load()
     for p, t in zip(net.parameters(), target_net.parameters()):
         L.check(lib.exorl_soft_update(p.data_ptr(), t.data_ptr(), p.numel(), tau, L.current_stream()))
+    if getattr(target_net, '_on_change', None):
+        target_net._on_change()
 
 
 class Until:
