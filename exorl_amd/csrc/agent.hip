@@ -72,7 +72,7 @@ static NetDesc make_net(int in_dim, int out_dim, int H, int n_trunks, int n_head
 struct FwdBufs { float *h1, *xhat, *rstd, *h2, *out; unsigned short* h1b; };
 struct BwdBufs { float *dz2, *dh1; unsigned short* dz2b; };
 struct NetShadow { float* w0t; unsigned short* w1b; };     // W0 transposed per trunk; W1 as bf16 per head
-struct Partials { float *Ph, *Pt; };                       // per-chunk partial gradients (fused.hip)
+struct Partials { float *Ph, *Pt, *Pw; };                  // per-chunk partial gradients (fused.hip)
 
 static ShadowSpec shadow_spec(const NetDesc& d, const NetShadow& sh, const NetShadow* target) {
     ShadowSpec s{};
@@ -130,13 +130,17 @@ static int net_backward(const NetDesc& d, const float* P, const NetShadow& sh, f
     } else {
         for (int i = 0; i < d.n_heads; ++i) EXORL_TRY(gemm_grouped(prec, 0, 1, p + i, 1, false, i > 0, s));
     }
-    EXORL_TRY(trunk_bwd(b.dh1, f.h1, f.xhat, f.rstd, P + d.g, x, ldx, sh.w0t, pt.Pt, dx, dx_col0, dx_cols, rows, d.in_dim, H,
-                        d.n_trunks, act, d.trunk_stride, (int64_t)d.in_dim * H, G ? 1 : 0, s));
+    EXORL_TRY(ln_bwd(b.dh1, f.h1, f.xhat, f.rstd, P + d.g, pt.Pt, rows, H, d.n_trunks, act, d.trunk_stride, G ? 1 : 0, s));
+    if (dx)       // dx[m][j] = sum_c dz0[m][c] W0[c][col0+j]: a row-dot against rows col0.. of the transposed shadow
+        EXORL_TRY(head_fwd4(b.dh1, sh.w0t + (int64_t)dx_col0 * H, nullptr, dx, rows, H, dx_cols, 0, d.n_trunks, act,
+                            (int64_t)d.in_dim * H, (int64_t)rows * dx_cols, s));
     if (G) {
+        EXORL_TRY(outer_reduce(x, ldx, d.in_dim, b.dh1, pt.Pw, rows, H, d.n_trunks, act, s));
         FinalizeArgs fa{};
         fa.Ph = pt.Ph; fa.head_chunks = head_chunks(rows); fa.n_heads = d.n_heads; fa.head_stride = d.head_stride;
         fa.gW2 = d.W2; fa.gb1 = d.b1; fa.gb2 = d.b2;
         fa.Pt = pt.Pt; fa.trunk_chunks = trunk_chunks(rows); fa.n_trunks = d.n_trunks; fa.trunk_stride = d.trunk_stride;
+        fa.Pw = pt.Pw; fa.w_chunks = outer_chunks(rows);
         fa.gW0 = d.W0; fa.gb0 = d.b0; fa.gg = d.g; fa.gbeta = d.beta;
         fa.H = H; fa.nout = d.out_dim; fa.in_dim = d.in_dim; fa.G = G;
         EXORL_TRY(finalize_grads(fa, s));
@@ -212,7 +216,8 @@ static void carve(exorl_agent* a, Carver& c) {
     a->fa = FwdBufs{c.take(2 * B * H), c.take(2 * B * H), c.take(2 * B), c.take(2 * B * H), c.take(2 * B * A), bf ? take_u16(2 * B * H) : nullptr};
     a->ba = BwdBufs{c.take(B * H), c.take(B * H), bf ? take_u16(B * H) : nullptr};
     a->sh_actor = NetShadow{c.take(O * H), bf ? take_u16(H * H) : nullptr};
-    a->pa = Partials{c.take((int64_t)head_chunks(B) * ((A + 1) * H + 16)), c.take((int64_t)trunk_chunks(B) * (3 + O) * H)};
+    a->pa = Partials{c.take((int64_t)head_chunks(B) * ((A + 1) * H + 16)), c.take((int64_t)trunk_chunks(B) * 3 * H),
+                     c.take((int64_t)outer_chunks(B) * O * H)};
     a->dpre = c.take(B * A);
     a->stats = c.take(4 + EXORL_N_METRICS);
     a->metrics = a->stats ? a->stats + 4 : nullptr;
@@ -230,15 +235,17 @@ static void carve(exorl_agent* a, Carver& c) {
         a->da = c.take(nt * B * A);
         a->sh_critic = NetShadow{c.take(nt * W * H), bf ? take_u16(2 * H * H) : nullptr};
         a->sh_target = NetShadow{c.take(nt * W * H), bf ? take_u16(2 * H * H) : nullptr};
-        a->pc = Partials{c.take(2 * (int64_t)head_chunks(B) * (2 * H + 16)), c.take(nt * (int64_t)trunk_chunks(B) * (3 + W) * H)};
+        a->pc = Partials{c.take(2 * (int64_t)head_chunks(B) * (2 * H + 16)), c.take(nt * (int64_t)trunk_chunks(B) * 3 * H),
+                         c.take(nt * (int64_t)outer_chunks(B) * W * H)};
     }
 }
 
 static int describe(exorl_agent* a, const exorl_agent_cfg* cfg) {
     EXORL_REQUIRE(cfg, "agent: null cfg");
     EXORL_REQUIRE(cfg->kind >= EXORL_AGENT_TD3_BC && cfg->kind <= EXORL_AGENT_DDPG, "agent: unknown kind %d", cfg->kind);
-    EXORL_REQUIRE(cfg->obs_dim > 0 && cfg->act_dim > 0 && cfg->act_dim <= 16 && cfg->hidden_dim > 0 && cfg->hidden_dim <= 1024 &&
-                  cfg->batch > 0, "agent: unsupported dims O=%d A=%d (<=16) H=%d (<=1024) B=%d", cfg->obs_dim, cfg->act_dim,
+    EXORL_REQUIRE(cfg->obs_dim > 0 && cfg->act_dim > 0 && cfg->act_dim <= 16 && cfg->hidden_dim >= 4 && cfg->hidden_dim <= 1024 && cfg->hidden_dim % 4 == 0 &&
+                  cfg->obs_dim + cfg->act_dim <= 256 &&
+                  cfg->batch > 0, "agent: unsupported dims O=%d A=%d (<=16) H=%d (multiple of 4, <=1024) B=%d; O+A <= 256", cfg->obs_dim, cfg->act_dim,
                   cfg->hidden_dim, cfg->batch);
     EXORL_REQUIRE(cfg->precision == EXORL_PREC_F32 || cfg->precision == EXORL_PREC_BF16, "agent: unknown precision %d", cfg->precision);
     EXORL_REQUIRE(cfg->world_size >= 1, "agent: world_size must be >= 1");

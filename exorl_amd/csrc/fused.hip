@@ -14,8 +14,6 @@
 
 namespace exorl {
 
-constexpr int TR = 16;            // rows per trunk workgroup
-constexpr int CPT = 4;            // columns per thread (H <= 1024)
 constexpr int MAX_IN = 256;       // first-layer fan-in limit of the fused trunk kernels
 constexpr float LN_EPS2 = 1e-5f;
 typedef __bf16 bf16_t;
@@ -25,261 +23,245 @@ __device__ __forceinline__ unsigned short f2bf(float x) {
     return __builtin_bit_cast(unsigned short, b);
 }
 
-// sums v[0..N) over the 256-thread block; result valid in all threads
-template <int N>
-__device__ __forceinline__ void block_sum256(float (&v)[N], float* red /* [N][4] */) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const float s = wave_sum(v[i]);
-        if (lane == 0) red[i * 4 + wave] = s;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = red[i * 4 + 0] + red[i * 4 + 1] + red[i * 4 + 2] + red[i * 4 + 3];
-    __syncthreads();
-}
-
 // ------------------------------------------------------------------------------------------------
-// trunk forward: h = tanh(LN(x W0^T + b0) * g + beta)
-__global__ __launch_bounds__(256) void trunk_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+// trunk forward: h = tanh(LN(x W0^T + b0) * g + beta).
+// 512 threads = 8 waves, one row per wave, lane owns columns 4*lane + 256*i (+0..3), i < 4 (H <= 1024, H % 4 == 0).
+// W0T is staged through LDS in 16-row k-chunks (64 KB: two workgroups per CU) and read back as conflict-free
+// ds_read_b128; LayerNorm statistics are wave-local (no workgroup barrier on the critical path).
+constexpr int TF_ROWS = 8;
+constexpr int TF_KC = 16;
+__global__ __launch_bounds__(512) void trunk_fwd_kernel(const float* __restrict__ x, int64_t ldx,
                                                         const float* __restrict__ W0T, const float* __restrict__ b0,
                                                         const float* __restrict__ gain, const float* __restrict__ beta,
                                                         float* __restrict__ h, float* __restrict__ xhat,
                                                         float* __restrict__ rstd, unsigned short* __restrict__ hb,
                                                         int rows, int in_dim, int H, int64_t astride, int64_t pstride,
                                                         int64_t tstride) {
-    __shared__ __attribute__((aligned(16))) float xs[MAX_IN * TR];     // [k][r]
-    __shared__ float red[TR * 4];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* ws = smem;                          // [TF_KC][H]
+    float* xs = smem + TF_KC * H;              // [TF_ROWS][MAX_IN]
     const int net = blockIdx.y;
-    const int row0 = blockIdx.x * TR;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < TR * in_dim; i += 256) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = blockIdx.x * TF_ROWS + wave;
+    const bool live = row < rows;
+    for (int i = tid; i < TF_ROWS * in_dim; i += 512) {
         const int r = i / in_dim, k = i % in_dim;
-        xs[k * TR + r] = (row0 + r < rows) ? x[(int64_t)(row0 + r) * ldx + k] : 0.f;
+        const int rr = blockIdx.x * TF_ROWS + r;
+        xs[r * MAX_IN + k] = rr < rows ? x[(int64_t)rr * ldx + k] : 0.f;
     }
-    __syncthreads();
     const float* Wt = W0T + net * tstride;
-    float z[CPT][TR];
+    const int H4 = H >> 2;
+    float4 z[4];
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-        const int c = tid + 256 * i;
-        const float b = c < H ? b0[net * pstride + c] : 0.f;
-#pragma unroll
-        for (int r = 0; r < TR; ++r) z[i][r] = b;
+    for (int i = 0; i < 4; ++i) {
+        const int c4 = lane + 64 * i;
+        z[i] = c4 < H4 ? reinterpret_cast<const float4*>(b0 + net * pstride)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int k = 0; k < in_dim; ++k) {
-        float w[CPT];
+    for (int k0 = 0; k0 < in_dim; k0 += TF_KC) {
+        const int kc = in_dim - k0 < TF_KC ? in_dim - k0 : TF_KC;
+        __syncthreads();
+        for (int i = tid; i < kc * H4; i += 512)
+            reinterpret_cast<float4*>(ws)[i] = reinterpret_cast<const float4*>(Wt + (int64_t)k0 * H)[i];
+        __syncthreads();
+        for (int k = 0; k < kc; ++k) {
+            const float xv = xs[wave * MAX_IN + k0 + k];
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            const int c = tid + 256 * i;
-            w[i] = c < H ? Wt[(int64_t)k * H + c] : 0.f;
-        }
-#pragma unroll
-        for (int r4 = 0; r4 < TR / 4; ++r4) {
-            const float4 xv = *reinterpret_cast<const float4*>(&xs[k * TR + 4 * r4]);
-#pragma unroll
-            for (int i = 0; i < CPT; ++i) {
-                z[i][4 * r4 + 0] += w[i] * xv.x;
-                z[i][4 * r4 + 1] += w[i] * xv.y;
-                z[i][4 * r4 + 2] += w[i] * xv.z;
-                z[i][4 * r4 + 3] += w[i] * xv.w;
+            for (int i = 0; i < 4; ++i) {
+                const int c4 = lane + 64 * i;
+                if (c4 < H4) {
+                    const float4 w = reinterpret_cast<const float4*>(ws + k * H)[c4];
+                    z[i].x += xv * w.x; z[i].y += xv * w.y; z[i].z += xv * w.z; z[i].w += xv * w.w;
+                }
             }
         }
     }
-    // LayerNorm statistics (two-pass), biased variance
-    float s[TR];
+    float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < TR; ++r) {
-        s[r] = 0.f;
+    for (int i = 0; i < 4; ++i)
+        if (lane + 64 * i < H4) s += (z[i].x + z[i].y) + (z[i].z + z[i].w);
+    const float mean = wave_sum(s) / (float)H;
+    float s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) s[r] += (tid + 256 * i < H) ? z[i][r] : 0.f;
-    }
-    block_sum256<TR>(s, red);
-    float mean[TR];
-#pragma unroll
-    for (int r = 0; r < TR; ++r) {
-        mean[r] = s[r] / (float)H;
-        s[r] = 0.f;
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            const float d = (tid + 256 * i < H) ? z[i][r] - mean[r] : 0.f;
-            z[i][r] = d;
-            s[r] += d * d;
+    for (int i = 0; i < 4; ++i) {
+        if (lane + 64 * i < H4) {
+            z[i].x -= mean; z[i].y -= mean; z[i].z -= mean; z[i].w -= mean;
+            s2 += (z[i].x * z[i].x + z[i].y * z[i].y) + (z[i].z * z[i].z + z[i].w * z[i].w);
         }
     }
-    block_sum256<TR>(s, red);
+    const float rs = 1.0f / sqrtf(wave_sum(s2) / (float)H + LN_EPS2);
+    if (!live) return;
+    const int64_t o = net * astride + (int64_t)row * H;
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-        const int c = tid + 256 * i;
-        if (c >= H) continue;
-        const float g = gain[net * pstride + c], be = beta[net * pstride + c];
-#pragma unroll
-        for (int r = 0; r < TR; ++r) {
-            if (row0 + r >= rows) continue;
-            const float rs = 1.0f / sqrtf(s[r] / (float)H + LN_EPS2);
-            const float xh = z[i][r] * rs;
-            const float hv = tanhf(xh * g + be);
-            const int64_t o = net * astride + (int64_t)(row0 + r) * H + c;
-            h[o] = hv;
-            if (xhat) xhat[o] = xh;
-            if (hb) hb[o] = f2bf(hv);
+    for (int i = 0; i < 4; ++i) {
+        const int c4 = lane + 64 * i;
+        if (c4 >= H4) continue;
+        const float4 g = reinterpret_cast<const float4*>(gain + net * pstride)[c4];
+        const float4 be = reinterpret_cast<const float4*>(beta + net * pstride)[c4];
+        const float4 xh = make_float4(z[i].x * rs, z[i].y * rs, z[i].z * rs, z[i].w * rs);
+        const float4 hv = make_float4(tanhf(xh.x * g.x + be.x), tanhf(xh.y * g.y + be.y), tanhf(xh.z * g.z + be.z),
+                                      tanhf(xh.w * g.w + be.w));
+        reinterpret_cast<float4*>(h + o)[c4] = hv;
+        if (xhat) reinterpret_cast<float4*>(xhat + o)[c4] = xh;
+        if (hb) {
+            ushort4 q;
+            q.x = f2bf(hv.x); q.y = f2bf(hv.y); q.z = f2bf(hv.z); q.w = f2bf(hv.w);
+            reinterpret_cast<ushort4*>(hb + o)[c4] = q;
         }
     }
-    if (rstd && tid < TR && row0 + tid < rows) rstd[net * (int64_t)rows + row0 + tid] = 1.0f / sqrtf(s[tid] / (float)H + LN_EPS2);
+    if (rstd && lane == 0) rstd[net * (int64_t)rows + row] = rs;
 }
 
 int trunk_fwd(const float* x, int64_t ldx, const float* W0T, const float* b0, const float* gain, const float* beta,
               float* h, float* xhat, float* rstd, unsigned short* h_bf16, int rows, int in_dim, int H, int nets,
               int64_t astride, int64_t pstride, int64_t tstride, hipStream_t s) {
-    EXORL_REQUIRE(H >= 1 && H <= 256 * CPT && in_dim >= 1 && in_dim <= MAX_IN, "trunk_fwd: unsupported H=%d in=%d", H, in_dim);
-    hipLaunchKernelGGL(trunk_fwd_kernel, dim3(cdiv(rows, TR), nets), dim3(256), 0, s, x, ldx, W0T, b0, gain, beta, h, xhat, rstd,
-                       h_bf16, rows, in_dim, H, astride, pstride, tstride);
+    EXORL_REQUIRE(H >= 4 && H <= 1024 && H % 4 == 0 && in_dim >= 1 && in_dim <= MAX_IN, "trunk_fwd: unsupported H=%d in=%d", H, in_dim);
+    const size_t lds = ((size_t)TF_KC * H + TF_ROWS * MAX_IN) * sizeof(float);
+    hipLaunchKernelGGL(trunk_fwd_kernel, dim3(cdiv(rows, TF_ROWS), nets), dim3(512), lds, s, x, ldx, W0T, b0, gain, beta, h, xhat,
+                       rstd, h_bf16, rows, in_dim, H, astride, pstride, tstride);
     EXORL_LAUNCH_CHECK();
     return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
-// trunk backward: dz0 = LN/tanh backward of dh; per-workgroup partials of dgain, dbeta, db0, dW0 (transposed
-// [k][c]); optional dx[:, col0:col0+ncols] partial per net.  P layout per (net, chunk): [dg H][dbeta H][db0 H][dW0T in*H]
-template <bool PARAMS, bool DX>
-__global__ __launch_bounds__(256) void trunk_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ h,
-                                                        const float* __restrict__ xhat, const float* __restrict__ rstd,
-                                                        const float* __restrict__ gain, const float* __restrict__ x,
-                                                        int64_t ldx, const float* __restrict__ W0T, float* __restrict__ P,
-                                                        float* __restrict__ dx, int dx_col0, int dx_cols, int rows,
-                                                        int in_dim, int H, int64_t astride, int64_t pstride,
-                                                        int64_t tstride) {
-    __shared__ __attribute__((aligned(16))) float xs[PARAMS ? MAX_IN * TR : 4];
-    __shared__ float red[2 * TR * 4];
-    __shared__ float dxs[DX ? 4 : 1][TR * 16];
+// trunk backward, part 1: LayerNorm/tanh backward. One row per wave; 8 waves x 2 rows per workgroup.
+//   dz0 = rstd * (dxh - mean(dxh) - xhat * mean(dxh*xhat)),  dxh = dh*(1-h^2)*gain      (written in place over dh)
+// and per-workgroup partial column sums P[chunk] = [dgain H][dbeta H][db0 H] (PARAMS only).
+constexpr int TB_ROWS = 16;
+template <bool PARAMS>
+__global__ __launch_bounds__(512) void ln_bwd_kernel(float* dh, const float* __restrict__ h, const float* __restrict__ xhat,
+                                                     const float* __restrict__ rstd, const float* __restrict__ gain,
+                                                     float* __restrict__ P, int rows, int H, int64_t astride,
+                                                     int64_t pstride) {
+    __shared__ __attribute__((aligned(16))) float red[PARAMS ? 8 * 1024 : 4];
     const int net = blockIdx.y;
-    const int row0 = blockIdx.x * TR;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if constexpr (PARAMS) {
-        for (int i = tid; i < TR * in_dim; i += 256) {
-            const int r = i / in_dim, k = i % in_dim;
-            xs[k * TR + r] = (row0 + r < rows) ? x[(int64_t)(row0 + r) * ldx + k] : 0.f;
-        }
-    }
-    // pass 1 (row-major so only one row's loads are in flight: VGPR budget): dxh = dh*(1-h^2)*gain, row sums
-    float dz[CPT][TR];
-    float pg[CPT], pb[CPT], pb0[CPT], g[CPT];
+    const int H4 = H >> 2;
+    float4 g[4], pg[4], pb[4], pb0[4];
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-        const int c = tid + 256 * i;
-        pg[i] = pb[i] = pb0[i] = 0.f;
-        g[i] = c < H ? gain[net * pstride + c] : 0.f;
+    for (int i = 0; i < 4; ++i) {
+        const int c4 = lane + 64 * i;
+        g[i] = c4 < H4 ? reinterpret_cast<const float4*>(gain + net * pstride)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        pg[i] = pb[i] = pb0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const int64_t base = net * astride + (int64_t)row0 * H;
-#pragma unroll
-    for (int r = 0; r < TR; ++r) {
+    for (int it = 0; it < TB_ROWS / 8; ++it) {
+        const int row = blockIdx.x * TB_ROWS + it * 8 + wave;
+        if (row >= rows) continue;                      // wave-uniform
+        const int64_t o = net * astride + (int64_t)row * H;
+        float4 d[4], xh[4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            const int c = tid + 256 * i;
-            float d = 0.f;
-            if (c < H && row0 + r < rows) {
-                const int64_t o = base + (int64_t)r * H + c;
-                const float hv = h[o], xh = xhat[o];
-                const float dy = dh[o] * (1.0f - hv * hv);
-                pg[i] += dy * xh;
-                pb[i] += dy;
-                d = dy * g[i];
-                s1 += d;
-                s2 += d * xh;
+        for (int i = 0; i < 4; ++i) {
+            const int c4 = lane + 64 * i;
+            d[i] = xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c4 < H4) {
+                const float4 hv = reinterpret_cast<const float4*>(h + o)[c4];
+                const float4 dv = reinterpret_cast<const float4*>(dh + o)[c4];
+                xh[i] = reinterpret_cast<const float4*>(xhat + o)[c4];
+                float4 dy;
+                dy.x = dv.x * (1.0f - hv.x * hv.x); dy.y = dv.y * (1.0f - hv.y * hv.y);
+                dy.z = dv.z * (1.0f - hv.z * hv.z); dy.w = dv.w * (1.0f - hv.w * hv.w);
+                if constexpr (PARAMS) {
+                    pg[i].x += dy.x * xh[i].x; pg[i].y += dy.y * xh[i].y; pg[i].z += dy.z * xh[i].z; pg[i].w += dy.w * xh[i].w;
+                    pb[i].x += dy.x; pb[i].y += dy.y; pb[i].z += dy.z; pb[i].w += dy.w;
+                }
+                d[i].x = dy.x * g[i].x; d[i].y = dy.y * g[i].y; d[i].z = dy.z * g[i].z; d[i].w = dy.w * g[i].w;
+                s1 += (d[i].x + d[i].y) + (d[i].z + d[i].w);
+                s2 += (d[i].x * xh[i].x + d[i].y * xh[i].y) + (d[i].z * xh[i].z + d[i].w * xh[i].w);
             }
-            dz[i][r] = d;
         }
-        s1 = wave_sum(s1);
-        s2 = wave_sum(s2);
-        if (lane == 0) { red[(2 * r) * 4 + wave] = s1; red[(2 * r + 1) * 4 + wave] = s2; }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();
-    // pass 2: dz0 = rstd * (dxh - mean(dxh) - xhat * mean(dxh*xhat))
+        const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
+        const float rs = rstd[net * (int64_t)rows + row];
 #pragma unroll
-    for (int r = 0; r < TR; ++r) {
-        const float m1 = (red[(2 * r) * 4] + red[(2 * r) * 4 + 1] + red[(2 * r) * 4 + 2] + red[(2 * r) * 4 + 3]) / (float)H;
-        const float m2 = (red[(2 * r + 1) * 4] + red[(2 * r + 1) * 4 + 1] + red[(2 * r + 1) * 4 + 2] + red[(2 * r + 1) * 4 + 3]) / (float)H;
-        const float rs = (row0 + r < rows) ? rstd[net * (int64_t)rows + row0 + r] : 0.f;
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            const int c = tid + 256 * i;
-            float d = 0.f;
-            if (c < H && row0 + r < rows) d = rs * (dz[i][r] - m1 - xhat[base + (int64_t)r * H + c] * m2);
-            dz[i][r] = d;
-            pb0[i] += d;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (PARAMS) {
-        const int64_t psz = (int64_t)(3 + in_dim) * H;
-        float* Pn = P + ((int64_t)net * gridDim.x + blockIdx.x) * psz;
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            const int c = tid + 256 * i;
-            if (c < H) { Pn[c] = pg[i]; Pn[H + c] = pb[i]; Pn[2 * H + c] = pb0[i]; }
-        }
-        for (int k = 0; k < in_dim; ++k) {
-            float acc[CPT] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int r4 = 0; r4 < TR / 4; ++r4) {
-                const float4 xv = *reinterpret_cast<const float4*>(&xs[k * TR + 4 * r4]);
-#pragma unroll
-                for (int i = 0; i < CPT; ++i)
-                    acc[i] += dz[i][4 * r4] * xv.x + dz[i][4 * r4 + 1] * xv.y + dz[i][4 * r4 + 2] * xv.z + dz[i][4 * r4 + 3] * xv.w;
-            }
-#pragma unroll
-            for (int i = 0; i < CPT; ++i) {
-                const int c = tid + 256 * i;
-                if (c < H) Pn[(int64_t)(3 + k) * H + c] = acc[i];
+        for (int i = 0; i < 4; ++i) {
+            const int c4 = lane + 64 * i;
+            if (c4 < H4) {
+                float4 v;
+                v.x = rs * (d[i].x - m1 - xh[i].x * m2); v.y = rs * (d[i].y - m1 - xh[i].y * m2);
+                v.z = rs * (d[i].z - m1 - xh[i].z * m2); v.w = rs * (d[i].w - m1 - xh[i].w * m2);
+                reinterpret_cast<float4*>(dh + o)[c4] = v;
+                if constexpr (PARAMS) { pb0[i].x += v.x; pb0[i].y += v.y; pb0[i].z += v.z; pb0[i].w += v.w; }
             }
         }
     }
-    if constexpr (DX) {       // dx[r][j] = sum_c dz0[r][c] W0[c][col0+j]  (reduction over the columns held by all threads)
-        const float* Wt = W0T + net * tstride;
-        for (int j = 0; j < dx_cols; ++j) {
-            float w[CPT];
+    if constexpr (PARAMS) {        // cross-wave sums of the three column vectors, one at a time through 32 KB of LDS
+        float* Pn = P + ((int64_t)net * gridDim.x + blockIdx.x) * 3 * H;
 #pragma unroll
-            for (int i = 0; i < CPT; ++i) {
-                const int c = tid + 256 * i;
-                w[i] = c < H ? Wt[(int64_t)(dx_col0 + j) * H + c] : 0.f;
+        for (int q = 0; q < 3; ++q) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c4 = lane + 64 * i;
+                if (c4 < H4) reinterpret_cast<float4*>(red + wave * 1024)[c4] = q == 0 ? pg[i] : (q == 1 ? pb[i] : pb0[i]);
             }
+            __syncthreads();
+            for (int c = tid; c < H; c += 512) {
+                float sacc = 0.f;
 #pragma unroll
-            for (int r = 0; r < TR; ++r) {
-                float v = 0.f;
-#pragma unroll
-                for (int i = 0; i < CPT; ++i) v += dz[i][r] * w[i];
-                v = wave_sum(v);
-                if (lane == 0) dxs[wave][r * 16 + j] = v;
+                for (int w = 0; w < 8; ++w) sacc += red[w * 1024 + c];
+                Pn[q * H + c] = sacc;
             }
-        }
-        __syncthreads();
-        for (int i = tid; i < TR * dx_cols; i += 256) {
-            const int r = i / dx_cols, j = i % dx_cols;
-            if (row0 + r < rows)
-                dx[((int64_t)net * rows + row0 + r) * dx_cols + j] = dxs[0][r * 16 + j] + dxs[1][r * 16 + j] + dxs[2][r * 16 + j] + dxs[3][r * 16 + j];
         }
     }
 }
 
-int trunk_bwd(const float* dh, const float* h, const float* xhat, const float* rstd, const float* gain, const float* x,
-              int64_t ldx, const float* W0T, float* P, float* dx, int dx_col0, int dx_cols, int rows, int in_dim, int H,
-              int nets, int64_t astride, int64_t pstride, int64_t tstride, int want_params, hipStream_t s) {
-    EXORL_REQUIRE(H >= 1 && H <= 256 * CPT && in_dim >= 1 && in_dim <= MAX_IN && dx_cols <= 16, "trunk_bwd: unsupported H=%d in=%d", H, in_dim);
-    const dim3 grid(cdiv(rows, TR), nets), block(256);
-#define EXORL_TB(PA, DXX) hipLaunchKernelGGL((trunk_bwd_kernel<PA, DXX>), grid, block, 0, s, dh, h, xhat, rstd, gain, x, ldx, W0T, P, dx, \
-                                             dx_col0, dx_cols, rows, in_dim, H, astride, pstride, tstride)
-    if (want_params && dx) EXORL_TB(true, true);
-    else if (want_params) EXORL_TB(true, false);
-    else if (dx) EXORL_TB(false, true);
-    else { set_error("trunk_bwd: nothing to compute"); return 2; }
-#undef EXORL_TB
+int ln_bwd(float* dh, const float* h, const float* xhat, const float* rstd, const float* gain, float* P, int rows, int H,
+           int nets, int64_t astride, int64_t pstride, int want_params, hipStream_t s) {
+    EXORL_REQUIRE(H >= 4 && H <= 1024 && H % 4 == 0, "ln_bwd: unsupported H=%d", H);
+    const dim3 grid(cdiv(rows, TB_ROWS), nets);
+    if (want_params) hipLaunchKernelGGL((ln_bwd_kernel<true>), grid, dim3(512), 0, s, dh, h, xhat, rstd, gain, P, rows, H, astride, pstride);
+    else hipLaunchKernelGGL((ln_bwd_kernel<false>), grid, dim3(512), 0, s, dh, h, xhat, rstd, gain, P, rows, H, astride, pstride);
     EXORL_LAUNCH_CHECK();
     return 0;
 }
-int trunk_chunks(int rows) { return cdiv(rows, TR); }
+int trunk_chunks(int rows) { return cdiv(rows, TB_ROWS); }
+
+// ------------------------------------------------------------------------------------------------
+// outer-product column reduction: P[chunk][j][c] = sum_{m in chunk} u[m][j] * v[m][c]   (first-layer wgrad:
+// u = x (rows x J), v = dz0).  Thread = column, 16 rows per workgroup, u rows broadcast from LDS.
+constexpr int OR_ROWS = 16;
+__global__ __launch_bounds__(256) void outer_reduce_kernel(const float* __restrict__ u, int64_t ldu, int J,
+                                                           const float* __restrict__ v, float* __restrict__ P, int rows,
+                                                           int H, int64_t vstride) {
+    __shared__ __attribute__((aligned(16))) float us[OR_ROWS][32];
+    const int net = blockIdx.z;
+    const int row0 = blockIdx.y * OR_ROWS;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    float* Pn = P + ((int64_t)net * gridDim.y + blockIdx.y) * (int64_t)J * H;
+    const int nr = rows - row0 < OR_ROWS ? rows - row0 : OR_ROWS;
+    for (int j0 = 0; j0 < J; j0 += 32) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < OR_ROWS * 32; i += 256) {
+            const int r = i >> 5, j = i & 31;
+            us[r][j] = (r < nr && j0 + j < J) ? u[(int64_t)(row0 + r) * ldu + j0 + j] : 0.f;
+        }
+        __syncthreads();
+        if (c < H) {
+            float acc[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+            for (int r = 0; r < nr; ++r) {
+                const float vv = v[net * vstride + (int64_t)(row0 + r) * H + c];
+#pragma unroll
+                for (int j4 = 0; j4 < 8; ++j4) {
+                    const float4 uu = *reinterpret_cast<const float4*>(&us[r][4 * j4]);
+                    acc[4 * j4] += uu.x * vv; acc[4 * j4 + 1] += uu.y * vv; acc[4 * j4 + 2] += uu.z * vv; acc[4 * j4 + 3] += uu.w * vv;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 32; ++j)
+                if (j0 + j < J) Pn[(int64_t)(j0 + j) * H + c] = acc[j];
+        }
+    }
+}
+
+int outer_reduce(const float* u, int64_t ldu, int J, const float* v, float* P, int rows, int H, int nets, int64_t vstride,
+                 hipStream_t s) {
+    hipLaunchKernelGGL(outer_reduce_kernel, dim3(cdiv(H, 256), cdiv(rows, OR_ROWS), nets), dim3(256), 0, s, u, ldu, J, v, P, rows,
+                       H, vstride);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+int outer_chunks(int rows) { return cdiv(rows, OR_ROWS); }
 
 // ------------------------------------------------------------------------------------------------
 // head forward v2: out[m][j] = b[j] + sum_c a[m][c] W[j][c]; one wave per row, float4 streams (H % 4 == 0)
@@ -310,7 +292,7 @@ __global__ __launch_bounds__(256) void head_fwd4_kernel(const float* __restrict_
 #pragma unroll
     for (int j = 0; j < NO; ++j) {
         if (j < nout) {
-            float v = wave_sum(acc[j]) + b[net * pstride + j];
+            float v = wave_sum(acc[j]) + (b ? b[net * pstride + j] : 0.f);
             if (tanh_out) v = tanhf(v);
             if (lane == 0) out[net * ostride + (int64_t)row * nout + j] = v;
         }
@@ -330,9 +312,10 @@ int head_fwd4(const float* a, const float* W, const float* b, float* out, int ro
 
 // ------------------------------------------------------------------------------------------------
 // head backward: dz[m][c] = (sum_j dout[m][j] W[j][c]) * (a[m][c] > 0), written fp32 and/or bf16, plus
-// per-chunk partials of db_hidden[c] = sum_m dz and dW[j][c] = sum_m dout[m][j] a[m][c].
+// per-chunk partials of db_hidden[c] = sum_m dz and dW[j][c] = sum_m dout[m][j] a[m][c] and db_out[j].
+// Thread = 4 consecutive columns (float4 streams), 8 rows per workgroup.
 // P layout per (net, chunk): [dW nout*H][db_hidden H][db_out 16]
-constexpr int HB_ROWS = 32;
+constexpr int HB_ROWS = 8;
 template <int NO>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ W,
                                                        const float* __restrict__ a, float* __restrict__ dz,
@@ -340,57 +323,64 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                        int H, int nout, int64_t astride, int64_t pstride, int64_t dstride,
                                                        int want_params) {
     __shared__ float ds[HB_ROWS * 16];
-    const int net = blockIdx.z;
-    const int row0 = blockIdx.y * HB_ROWS;
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    for (int i = threadIdx.x; i < HB_ROWS * nout; i += 256) {
-        const int r = i / nout, j = i % nout;
-        ds[r * 16 + j] = (row0 + r < rows) ? dout[net * dstride + (int64_t)(row0 + r) * nout + j] : 0.f;
+    const int net = blockIdx.y;
+    const int row0 = blockIdx.x * HB_ROWS;
+    const int c4 = threadIdx.x;
+    const int H4 = H >> 2;
+    if (threadIdx.x < HB_ROWS * 16) {
+        const int r = threadIdx.x >> 4, j = threadIdx.x & 15;
+        ds[threadIdx.x] = (row0 + r < rows && j < nout) ? dout[net * dstride + (int64_t)(row0 + r) * nout + j] : 0.f;
     }
     __syncthreads();
     const int64_t nh = (int64_t)(nout + 1) * H + 16;
-    float* Pn = P ? P + ((int64_t)net * gridDim.y + blockIdx.y) * nh : nullptr;
-    if (want_params && blockIdx.x == 0 && threadIdx.x < nout) {      // db_out[j] partial over this chunk's rows
+    float* Pn = P ? P + ((int64_t)net * gridDim.x + blockIdx.x) * nh : nullptr;
+    if (want_params && threadIdx.x < nout) {      // db_out[j] partial over this chunk's rows
         float sj = 0.f;
         for (int r = 0; r < HB_ROWS; ++r) sj += ds[r * 16 + threadIdx.x];
         Pn[(int64_t)(nout + 1) * H + threadIdx.x] = sj;
     }
-    if (c >= H) return;
-    float w[NO], pw[NO];
+    if (c4 >= H4) return;
+    float4 w[NO], pw[NO];
 #pragma unroll
     for (int j = 0; j < NO; ++j) {
-        w[j] = j < nout ? W[net * pstride + (int64_t)j * H + c] : 0.f;
-        pw[j] = 0.f;
+        w[j] = j < nout ? reinterpret_cast<const float4*>(W + net * pstride + (int64_t)j * H)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        pw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    float pb = 0.f;
+    float4 pb = make_float4(0.f, 0.f, 0.f, 0.f);
     const int nr = rows - row0 < HB_ROWS ? rows - row0 : HB_ROWS;
     for (int r = 0; r < nr; ++r) {
-        const int64_t o = net * astride + (int64_t)(row0 + r) * H + c;
-        const float av = a[o];
-        float sacc = 0.f;
+        const int64_t o = net * astride + (int64_t)(row0 + r) * H;
+        const float4 av = reinterpret_cast<const float4*>(a + o)[c4];
+        float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < NO; ++j) {
             const float d = ds[r * 16 + j];
-            sacc += d * w[j];
-            pw[j] += d * av;
+            sacc.x += d * w[j].x; sacc.y += d * w[j].y; sacc.z += d * w[j].z; sacc.w += d * w[j].w;
+            pw[j].x += d * av.x; pw[j].y += d * av.y; pw[j].z += d * av.z; pw[j].w += d * av.w;
         }
-        const float v = av > 0.f ? sacc : 0.f;
-        if (dz) dz[o] = v;
-        if (dzb) dzb[o] = f2bf(v);
-        pb += v;
+        float4 v;
+        v.x = av.x > 0.f ? sacc.x : 0.f; v.y = av.y > 0.f ? sacc.y : 0.f;
+        v.z = av.z > 0.f ? sacc.z : 0.f; v.w = av.w > 0.f ? sacc.w : 0.f;
+        if (dz) reinterpret_cast<float4*>(dz + o)[c4] = v;
+        if (dzb) {
+            ushort4 q;
+            q.x = f2bf(v.x); q.y = f2bf(v.y); q.z = f2bf(v.z); q.w = f2bf(v.w);
+            reinterpret_cast<ushort4*>(dzb + o)[c4] = q;
+        }
+        pb.x += v.x; pb.y += v.y; pb.z += v.z; pb.w += v.w;
     }
     if (want_params) {
 #pragma unroll
         for (int j = 0; j < NO; ++j)
-            if (j < nout) Pn[(int64_t)j * H + c] = pw[j];
-        Pn[(int64_t)nout * H + c] = pb;
+            if (j < nout) reinterpret_cast<float4*>(Pn + (int64_t)j * H)[c4] = pw[j];
+        reinterpret_cast<float4*>(Pn + (int64_t)nout * H)[c4] = pb;
     }
 }
 
 int head_bwd(const float* dout, const float* W, const float* a, float* dz, unsigned short* dz_bf16, float* P, int rows,
              int H, int nout, int nets, int64_t astride, int64_t pstride, int64_t dstride, int want_params, hipStream_t s) {
-    EXORL_REQUIRE(nout >= 1 && nout <= 16, "head_bwd: nout=%d unsupported", nout);
-    dim3 grid(cdiv(H, 256), cdiv(rows, HB_ROWS), nets);
+    EXORL_REQUIRE(nout >= 1 && nout <= 16 && H % 4 == 0 && H <= 1024, "head_bwd: nout=%d H=%d unsupported", nout, H);
+    dim3 grid(cdiv(rows, HB_ROWS), nets);
     if (nout == 1) hipLaunchKernelGGL((head_bwd_kernel<1>), grid, dim3(256), 0, s, dout, W, a, dz, dz_bf16, P, rows, H, nout, astride, pstride, dstride, want_params);
     else if (nout <= 8) hipLaunchKernelGGL((head_bwd_kernel<8>), grid, dim3(256), 0, s, dout, W, a, dz, dz_bf16, P, rows, H, nout, astride, pstride, dstride, want_params);
     else hipLaunchKernelGGL((head_bwd_kernel<16>), grid, dim3(256), 0, s, dout, W, a, dz, dz_bf16, P, rows, H, nout, astride, pstride, dstride, want_params);
@@ -401,37 +391,55 @@ int head_chunks(int rows) { return cdiv(rows, HB_ROWS); }
 
 // ------------------------------------------------------------------------------------------------
 // finalize: sums the per-chunk partials in chunk order and scatters into the flat gradient buffer.
+// sum of n partials spaced `stride` apart, 8 loads in flight
+__device__ __forceinline__ float chunk_sum(const float* __restrict__ p, int n, int64_t stride) {
+    float acc = 0.f;
+    int ch = 0;
+    for (; ch + 8 <= n; ch += 8) {
+        float t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = p[(int64_t)(ch + q) * stride];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += t[q];
+    }
+    for (; ch < n; ++ch) acc += p[(int64_t)ch * stride];
+    return acc;
+}
+
 __global__ __launch_bounds__(256) void finalize_grads_kernel(FinalizeArgs f) {
     const int H = f.H;
-    const int64_t nh = (int64_t)(f.nout + 1) * H + 16;       // head elements per net (see head_bwd_kernel)
-    const int64_t nt = (int64_t)(3 + f.in_dim) * H;          // trunk elements per net (see trunk_bwd_kernel)
-    const int64_t total = f.n_heads * nh + f.n_trunks * nt;
+    const int64_t nh = (int64_t)(f.nout + 1) * H + 16;       // head elements per net   (head_bwd_kernel)
+    const int64_t nt = 3 * (int64_t)H;                       // LN/bias column sums      (ln_bwd_kernel)
+    const int64_t nw = (int64_t)f.in_dim * H;                // first-layer weight grad  (outer_reduce_kernel)
+    const int64_t total = f.n_heads * nh + f.n_trunks * (nt + nw);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         if (i < f.n_heads * nh) {
             const int net = (int)(i / nh);
             const int64_t e = i % nh;
             const int64_t j = e / H;
             if (j > f.nout && e - (int64_t)(f.nout + 1) * H >= f.nout) continue;      // padding of the db_out slot
-            const float* p = f.Ph + (int64_t)net * f.head_chunks * nh + e;
-            float sacc = 0.f;
-            for (int ch = 0; ch < f.head_chunks; ++ch) sacc += p[(int64_t)ch * nh];
+            const float sacc = chunk_sum(f.Ph + (int64_t)net * f.head_chunks * nh + e, f.head_chunks, nh);
             float* Gn = f.G + net * f.head_stride;
             if (j < f.nout) Gn[f.gW2 + e] = sacc;
             else if (j == f.nout) Gn[f.gb1 + (e - (int64_t)f.nout * H)] = sacc;
             else Gn[f.gb2 + (e - (int64_t)(f.nout + 1) * H)] = sacc;
         } else {
             const int64_t ii = i - f.n_heads * nh;
-            const int net = (int)(ii / nt);
-            const int64_t e = ii % nt;
-            const float* p = f.Pt + (int64_t)net * f.trunk_chunks * nt + e;
-            float sacc = 0.f;
-            for (int ch = 0; ch < f.trunk_chunks; ++ch) sacc += p[(int64_t)ch * nt];
-            const int seg = (int)(e / H), c = (int)(e % H);
+            const int net = (int)(ii / (nt + nw));
+            const int64_t e = ii % (nt + nw);
             float* Gn = f.G + net * f.trunk_stride;
-            if (seg == 0) Gn[f.gg + c] = sacc;
-            else if (seg == 1) Gn[f.gbeta + c] = sacc;
-            else if (seg == 2) Gn[f.gb0 + c] = sacc;
-            else Gn[f.gW0 + (int64_t)c * f.in_dim + (seg - 3)] = sacc;
+            if (e < nt) {
+                const float sacc = chunk_sum(f.Pt + (int64_t)net * f.trunk_chunks * nt + e, f.trunk_chunks, nt);
+                const int seg = (int)(e / H), c = (int)(e % H);
+                if (seg == 0) Gn[f.gg + c] = sacc;
+                else if (seg == 1) Gn[f.gbeta + c] = sacc;
+                else Gn[f.gb0 + c] = sacc;
+            } else {
+                const int64_t ew = e - nt;
+                const float sacc = chunk_sum(f.Pw + (int64_t)net * f.w_chunks * nw + ew, f.w_chunks, nw);
+                const int k = (int)(ew / H), c = (int)(ew % H);
+                Gn[f.gW0 + (int64_t)c * f.in_dim + k] = sacc;
+            }
         }
     }
 }

@@ -35,10 +35,12 @@ int head_bwd_params(const float* dout, const float* a, const float* dz, float* d
 int trunk_fwd(const float* x, int64_t ldx, const float* W0T, const float* b0, const float* gain, const float* beta,
               float* h, float* xhat, float* rstd, unsigned short* h_bf16, int rows, int in_dim, int H, int nets,
               int64_t astride, int64_t pstride, int64_t tstride, hipStream_t s);
-int trunk_bwd(const float* dh, const float* h, const float* xhat, const float* rstd, const float* gain, const float* x,
-              int64_t ldx, const float* W0T, float* P, float* dx, int dx_col0, int dx_cols, int rows, int in_dim, int H,
-              int nets, int64_t astride, int64_t pstride, int64_t tstride, int want_params, hipStream_t s);
+int ln_bwd(float* dh, const float* h, const float* xhat, const float* rstd, const float* gain, float* P, int rows, int H,
+           int nets, int64_t astride, int64_t pstride, int want_params, hipStream_t s);
 int trunk_chunks(int rows);
+int outer_reduce(const float* u, int64_t ldu, int J, const float* v, float* P, int rows, int H, int nets, int64_t vstride,
+                 hipStream_t s);
+int outer_chunks(int rows);
 int head_fwd4(const float* a, const float* W, const float* b, float* out, int rows, int H, int nout, int tanh_out,
               int nets, int64_t astride, int64_t pstride, int64_t ostride, hipStream_t s);
 int head_bwd(const float* dout, const float* W, const float* a, float* dz, unsigned short* dz_bf16, float* P, int rows,
@@ -47,7 +49,8 @@ int head_chunks(int rows);
 struct FinalizeArgs {
     const float* Ph; int head_chunks; int n_heads; int64_t head_stride;    // head partials; stride between heads in G
     int64_t gW2, gb1, gb2;                                                 // offsets of head 0's tensors in G
-    const float* Pt; int trunk_chunks; int n_trunks; int64_t trunk_stride; // trunk partials
+    const float* Pt; int trunk_chunks; int n_trunks; int64_t trunk_stride; // LN/bias column-sum partials
+    const float* Pw; int w_chunks;                                         // first-layer weight partials [k][c]
     int64_t gW0, gb0, gg, gbeta;
     int H, nout, in_dim;
     float* G;
