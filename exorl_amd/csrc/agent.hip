@@ -89,13 +89,22 @@ static int net_forward(const NetDesc& d, const float* P, const NetShadow& sh, co
                        const FwdBufs& f, bool save, bool tanh_out, int prec, hipStream_t s) {
     const int H = d.H;
     const int64_t act = (int64_t)rows * H;
+    const bool bf = prec == EXORL_PREC_BF16;
     EXORL_TRY(trunk_fwd(x, ldx, sh.w0t, P + d.b0, P + d.g, P + d.beta, f.h1, save ? f.xhat : nullptr, save ? f.rstd : nullptr,
-                        nullptr, rows, d.in_dim, H, d.n_trunks, act, d.trunk_stride, (int64_t)d.in_dim * H, s));
-    GemmProblem p[2];
-    for (int i = 0; i < d.n_heads; ++i)
-        p[i] = GemmProblem{f.h1 + (d.n_trunks == d.n_heads ? i : 0) * act, P + d.W1 + i * d.head_stride, f.h2 + i * act,
-                           P + d.b1 + i * d.head_stride, rows, H, H, H, H, H};
-    EXORL_TRY(gemm_grouped(prec, 0, 0, p, d.n_heads, true, false, s));
+                        bf ? f.h1b : nullptr, rows, d.in_dim, H, d.n_trunks, act, d.trunk_stride, (int64_t)d.in_dim * H, s));
+    if (bf) {
+        Gemm16Problem q[2];
+        for (int i = 0; i < d.n_heads; ++i)
+            q[i] = Gemm16Problem{f.h1b + (d.n_trunks == d.n_heads ? i : 0) * act, sh.w1b + (int64_t)i * H * H, f.h2 + i * act,
+                                 P + d.b1 + i * d.head_stride, rows, H, H, H, H, H};
+        EXORL_TRY(gemm16_grouped(0, 0, q, d.n_heads, true, false, s));
+    } else {
+        GemmProblem p[2];
+        for (int i = 0; i < d.n_heads; ++i)
+            p[i] = GemmProblem{f.h1 + (d.n_trunks == d.n_heads ? i : 0) * act, P + d.W1 + i * d.head_stride, f.h2 + i * act,
+                               P + d.b1 + i * d.head_stride, rows, H, H, H, H, H};
+        EXORL_TRY(gemm_grouped(prec, 0, 0, p, d.n_heads, true, false, s));
+    }
     if (H % 4 == 0)
         EXORL_TRY(head_fwd4(f.h2, P + d.W2, P + d.b2, f.out, rows, H, d.out_dim, tanh_out ? 1 : 0, d.n_heads, act, d.head_stride,
                             (int64_t)rows * d.out_dim, s));
@@ -113,22 +122,41 @@ static int net_backward(const NetDesc& d, const float* P, const NetShadow& sh, f
     const int H = d.H;
     const int64_t act = (int64_t)rows * H;
     const bool paired = d.n_trunks == d.n_heads;
-    GemmProblem p[2];
-    EXORL_TRY(head_bwd(dout, P + d.W2, f.h2, b.dz2, nullptr, G ? pt.Ph : nullptr, rows, H, d.out_dim, d.n_heads, act, d.head_stride,
-                       (int64_t)rows * d.out_dim, G ? 1 : 0, s));
-    if (G) {
-        for (int i = 0; i < d.n_heads; ++i)          // dW1_i[n][k] = sum_m dz2_i[m][n] h1[m][k]
-            p[i] = GemmProblem{b.dz2 + i * act, f.h1 + (paired ? i : 0) * act, G + d.W1 + i * d.head_stride, nullptr,
-                               H, H, rows, H, H, H};
-        EXORL_TRY(gemm_grouped(prec, 1, 1, p, d.n_heads, false, false, s));
-    }
-    for (int i = 0; i < d.n_heads; ++i)              // dh1[m][k] = sum_n dz2_i[m][n] W1_i[n][k]
-        p[i] = GemmProblem{b.dz2 + i * act, P + d.W1 + i * d.head_stride, b.dh1 + (paired ? i : 0) * act, nullptr,
-                           rows, H, H, H, H, H};
-    if (paired) {
-        EXORL_TRY(gemm_grouped(prec, 0, 1, p, d.n_heads, false, false, s));
+    const bool bf = prec == EXORL_PREC_BF16;
+    EXORL_TRY(head_bwd(dout, P + d.W2, f.h2, bf ? nullptr : b.dz2, bf ? b.dz2b : nullptr, G ? pt.Ph : nullptr, rows, H, d.out_dim,
+                       d.n_heads, act, d.head_stride, (int64_t)rows * d.out_dim, G ? 1 : 0, s));
+    if (bf) {
+        Gemm16Problem q[2];
+        if (G) {
+            for (int i = 0; i < d.n_heads; ++i)      // dW1_i[n][k] = sum_m dz2_i[m][n] h1[m][k]
+                q[i] = Gemm16Problem{b.dz2b + i * act, f.h1b + (paired ? i : 0) * act, G + d.W1 + i * d.head_stride, nullptr,
+                                     H, H, rows, H, H, H};
+            EXORL_TRY(gemm16_grouped(1, 1, q, d.n_heads, false, false, s));
+        }
+        for (int i = 0; i < d.n_heads; ++i)          // dh1[m][k] = sum_n dz2_i[m][n] W1_i[n][k]
+            q[i] = Gemm16Problem{b.dz2b + i * act, sh.w1b + (int64_t)i * H * H, b.dh1 + (paired ? i : 0) * act, nullptr,
+                                 rows, H, H, H, H, H};
+        if (paired) {
+            EXORL_TRY(gemm16_grouped(0, 1, q, d.n_heads, false, false, s));
+        } else {
+            for (int i = 0; i < d.n_heads; ++i) EXORL_TRY(gemm16_grouped(0, 1, q + i, 1, false, i > 0, s));
+        }
     } else {
-        for (int i = 0; i < d.n_heads; ++i) EXORL_TRY(gemm_grouped(prec, 0, 1, p + i, 1, false, i > 0, s));
+        GemmProblem p[2];
+        if (G) {
+            for (int i = 0; i < d.n_heads; ++i)
+                p[i] = GemmProblem{b.dz2 + i * act, f.h1 + (paired ? i : 0) * act, G + d.W1 + i * d.head_stride, nullptr,
+                                   H, H, rows, H, H, H};
+            EXORL_TRY(gemm_grouped(prec, 1, 1, p, d.n_heads, false, false, s));
+        }
+        for (int i = 0; i < d.n_heads; ++i)
+            p[i] = GemmProblem{b.dz2 + i * act, P + d.W1 + i * d.head_stride, b.dh1 + (paired ? i : 0) * act, nullptr,
+                               rows, H, H, H, H, H};
+        if (paired) {
+            EXORL_TRY(gemm_grouped(prec, 0, 1, p, d.n_heads, false, false, s));
+        } else {
+            for (int i = 0; i < d.n_heads; ++i) EXORL_TRY(gemm_grouped(prec, 0, 1, p + i, 1, false, i > 0, s));
+        }
     }
     EXORL_TRY(ln_bwd(b.dh1, f.h1, f.xhat, f.rstd, P + d.g, pt.Pt, rows, H, d.n_trunks, act, d.trunk_stride, G ? 1 : 0, s));
     if (dx)       // dx[m][j] = sum_c dz0[m][c] W0[c][col0+j]: a row-dot against rows col0.. of the transposed shadow
@@ -224,7 +252,7 @@ static void carve(exorl_agent* a, Carver& c) {
     a->state = reinterpret_cast<StepState*>(c.take((sizeof(StepState) + 3) / 4));
     a->act_x = c.take(ACT_ROWS * O);
     a->act_noise = c.take(ACT_ROWS * A);
-    a->fact = FwdBufs{c.take(ACT_ROWS * H), nullptr, nullptr, c.take(ACT_ROWS * H), c.take(ACT_ROWS * A), nullptr};
+    a->fact = FwdBufs{c.take(ACT_ROWS * H), nullptr, nullptr, c.take(ACT_ROWS * H), c.take(ACT_ROWS * A), bf ? take_u16(ACT_ROWS * H) : nullptr};
     if (a->has_critic) {
         const int64_t nt = a->critic.n_trunks;
         a->xc_cur = c.take(B * W); a->xc_next = c.take(B * W); a->xc_pi = c.take(B * W);
@@ -249,6 +277,8 @@ static int describe(exorl_agent* a, const exorl_agent_cfg* cfg) {
                   cfg->hidden_dim, cfg->batch);
     EXORL_REQUIRE(cfg->precision == EXORL_PREC_F32 || cfg->precision == EXORL_PREC_BF16, "agent: unknown precision %d", cfg->precision);
     EXORL_REQUIRE(cfg->world_size >= 1, "agent: world_size must be >= 1");
+    EXORL_REQUIRE(cfg->precision != EXORL_PREC_BF16 || (cfg->hidden_dim % 8 == 0 && cfg->batch % 8 == 0),
+                  "agent: bf16 precision needs hidden_dim and batch to be multiples of 8 (got H=%d B=%d)", cfg->hidden_dim, cfg->batch);
     a->cfg = *cfg;
     a->has_critic = cfg->kind != EXORL_AGENT_BC;
     a->actor = make_net(cfg->obs_dim, cfg->act_dim, cfg->hidden_dim, 1, 1);

@@ -195,6 +195,207 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16-operand variant (fast mode): A and B already live in memory as bf16 (written by the producing kernels:
+// trunk_fwd -> h1, head_bwd -> dz2, Adam -> W1 shadow), so staging moves half the bytes and does no conversion.
+// The per-CU L2->LDS path (~64 B/clk) bounds these 1024^3 layers, so the tile is BM x 64 with BM = 128 when that
+// still yields >= 256 workgroups: (128+64) rows of 128 B per k-tile instead of 2 x (64+64).
+// Layout-1 operands (reduction index slow) are transposed in registers: 8 k-rows x 2 columns per thread as
+// 4-byte loads, v_perm_b32 splits the low/high bf16 into two 16-byte k-contiguous units.
+template <int L, int NU>
+__device__ __forceinline__ void load_tile16(const unsigned short* __restrict__ ptr, int64_t ld, int R, int K, int r0, int k0,
+                                            int tid, uint4 (&reg)[NU]) {
+    if constexpr (L == 0) {
+        const int unit = tid & 7;
+        const int k = k0 + unit * 8;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int row = r0 + (tid >> 3) + 32 * u;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (row < R && k + 8 <= K) v = *reinterpret_cast<const uint4*>(ptr + (int64_t)row * ld + k);
+            reg[u] = v;
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < NU / 2; ++g) {
+            const int row = r0 + 2 * (tid & 31) + 64 * g;
+            const int k = k0 + (tid >> 5) * 8;
+            uint32_t d[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                d[j] = 0u;
+                if (k + j < K && row + 2 <= R) d[j] = *reinterpret_cast<const uint32_t*>(ptr + (int64_t)(k + j) * ld + row);
+            }
+            // low halves -> row, high halves -> row+1
+            reg[2 * g].x = __builtin_amdgcn_perm(d[1], d[0], 0x05040100u);
+            reg[2 * g].y = __builtin_amdgcn_perm(d[3], d[2], 0x05040100u);
+            reg[2 * g].z = __builtin_amdgcn_perm(d[5], d[4], 0x05040100u);
+            reg[2 * g].w = __builtin_amdgcn_perm(d[7], d[6], 0x05040100u);
+            reg[2 * g + 1].x = __builtin_amdgcn_perm(d[1], d[0], 0x07060302u);
+            reg[2 * g + 1].y = __builtin_amdgcn_perm(d[3], d[2], 0x07060302u);
+            reg[2 * g + 1].z = __builtin_amdgcn_perm(d[5], d[4], 0x07060302u);
+            reg[2 * g + 1].w = __builtin_amdgcn_perm(d[7], d[6], 0x07060302u);
+        }
+    }
+}
+
+template <int L, int NU>
+__device__ __forceinline__ void store_tile16(unsigned char* lds, int tid, const uint4 (&reg)[NU]) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        int row, unit;
+        if constexpr (L == 0) { row = (tid >> 3) + 32 * u; unit = tid & 7; }
+        else                  { row = 2 * (tid & 31) + (u & 1) + 64 * (u >> 1); unit = tid >> 5; }
+        *reinterpret_cast<uint4*>(lds + lds_off(row, unit)) = reg[u];
+    }
+}
+
+struct Gemm16Batch {
+    Gemm16Problem p[4];
+    int relu;
+    int accumulate;
+};
+
+template <int AL, int BL, int BM>
+__global__ __launch_bounds__(256) void gemm16_kernel(const Gemm16Batch gb) {
+    constexpr int KPT = 64;                   // bf16 k per LDS tile (128 B rows)
+    constexpr int NUA = BM / 32, NUB = 2;     // 16-byte units per thread
+    constexpr int MT = BM / 64;               // 32x32 accumulator tiles per wave along M
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][(BM + 64) * ROWB];
+
+    const Gemm16Problem& P = gb.p[blockIdx.z];
+    const int M = P.M, N = P.N, K = P.K;
+    const int tiles_n = (N + 63) / 64;
+    const int tiles_m = (M + BM - 1) / BM;
+    if ((int)blockIdx.x >= tiles_n * tiles_m) return;
+    const int m0 = ((int)blockIdx.x / tiles_n) * BM;
+    const int n0 = ((int)blockIdx.x % tiles_n) * 64;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5;
+
+    uint4 ra[NUA], rb[NUB];
+    f32x16 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    const int nk = (K + KPT - 1) / KPT;
+    load_tile16<AL, NUA>(P.A, P.lda, M, K, m0, 0, tid, ra);
+    load_tile16<BL, NUB>(P.B, P.ldb, N, K, n0, 0, tid, rb);
+    store_tile16<AL, NUA>(smem[0], tid, ra);
+    store_tile16<BL, NUB>(smem[0] + BM * ROWB, tid, rb);
+    __syncthreads();
+
+    const int arow = wm * (BM / 2) + (lane & 31);
+    const int brow = wn * 32 + (lane & 31);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            load_tile16<AL, NUA>(P.A, P.lda, M, K, m0, (kt + 1) * KPT, tid, ra);
+            load_tile16<BL, NUB>(P.B, P.ldb, N, K, n0, (kt + 1) * KPT, tid, rb);
+        }
+        const unsigned char* As = smem[cur];
+        const unsigned char* Bs = smem[cur] + BM * ROWB;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 b = *reinterpret_cast<const uint4*>(Bs + lds_off(brow, 2 * q + h));
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const uint4 a = *reinterpret_cast<const uint4*>(As + lds_off(arow + 32 * t, 2 * q + h));
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                                 acc[t], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) {
+            store_tile16<AL, NUA>(smem[cur ^ 1], tid, ra);
+            store_tile16<BL, NUB>(smem[cur ^ 1] + BM * ROWB, tid, rb);
+        }
+        __syncthreads();
+    }
+
+    const int n = n0 + wn * 32 + (lane & 31);
+    if (n < N) {
+        const float bias = P.bias ? P.bias[n] : 0.f;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (BM / 2) + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < M) {
+                    float v = acc[t][r] + bias;
+                    if (gb.relu) v = fmaxf(v, 0.f);
+                    float* dst = P.C + (int64_t)m * P.ldc + n;
+                    if (gb.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+template <int AL, int BL>
+static int launch16(const Gemm16Batch& gb, int count, int tiles64, int tiles128, hipStream_t s) {
+    const bool prof = g_prof.on && g_prof.used < PROF_MAX_LAUNCHES;
+    if (prof) {
+        if (g_prof.ev.size() < 2 * (g_prof.used + 1)) {
+            hipEvent_t a, b;
+            EXORL_CHECK_HIP(hipEventCreate(&a));
+            EXORL_CHECK_HIP(hipEventCreate(&b));
+            g_prof.ev.push_back(a);
+            g_prof.ev.push_back(b);
+        }
+        double f = 0;
+        for (int i = 0; i < count; ++i) f += 2.0 * gb.p[i].M * (double)gb.p[i].N * gb.p[i].K;
+        g_prof.flops.push_back(f);
+        EXORL_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.used], s));
+    }
+    if (tiles128 * count >= 256) hipLaunchKernelGGL((gemm16_kernel<AL, BL, 128>), dim3(tiles128, 1, count), dim3(256), 0, s, gb);
+    else                         hipLaunchKernelGGL((gemm16_kernel<AL, BL, 64>), dim3(tiles64, 1, count), dim3(256), 0, s, gb);
+    EXORL_LAUNCH_CHECK();
+    if (prof) {
+        EXORL_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s));
+        g_prof.used += 1;
+    }
+    return 0;
+}
+
+// bf16-in-memory operands, fp32 output. Requirements (checked): 16-byte aligned rows for layout 0 (ld % 8 == 0,
+// K % 8 == 0), 4-byte aligned pairs for layout 1 (ld % 2 == 0, R % 2 == 0).
+int gemm16_grouped(int a_layout, int b_layout, const Gemm16Problem* probs, int count, bool relu, bool accumulate, hipStream_t s) {
+    EXORL_REQUIRE(count >= 1 && count <= 4, "gemm16_grouped: count %d out of range", count);
+    Gemm16Batch gb;
+    memset(&gb, 0, sizeof(gb));
+    int t64 = 0, t128 = 0;
+    for (int i = 0; i < count; ++i) {
+        const Gemm16Problem& p = probs[i];
+        gb.p[i] = p;
+        EXORL_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm16_grouped: empty problem %d", i);
+        auto ok = [](const unsigned short* ptr, int64_t ld, int R, int K, int layout) {
+            const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+            if (layout == 0) return (a % 16 == 0) && (ld % 8 == 0) && (K % 8 == 0);
+            return (a % 4 == 0) && (ld % 2 == 0) && (R % 2 == 0);
+        };
+        EXORL_REQUIRE(ok(p.A, p.lda, p.M, p.K, a_layout) && ok(p.B, p.ldb, p.N, p.K, b_layout),
+                      "gemm16_grouped: problem %d (M=%d N=%d K=%d lda=%lld ldb=%lld) violates the bf16 path's alignment rules "
+                      "(hidden_dim and batch must be multiples of 8 in bf16 precision)", i, p.M, p.N, p.K, (long long)p.lda, (long long)p.ldb);
+        const int a64 = cdiv(p.M, 64) * cdiv(p.N, 64), a128 = cdiv(p.M, 128) * cdiv(p.N, 64);
+        t64 = a64 > t64 ? a64 : t64;
+        t128 = a128 > t128 ? a128 : t128;
+    }
+    gb.relu = relu ? 1 : 0;
+    gb.accumulate = accumulate ? 1 : 0;
+    if (a_layout == 0 && b_layout == 0) return launch16<0, 0>(gb, count, t64, t128, s);
+    if (a_layout == 0 && b_layout == 1) return launch16<0, 1>(gb, count, t64, t128, s);
+    if (a_layout == 1 && b_layout == 1) return launch16<1, 1>(gb, count, t64, t128, s);
+    set_error("gemm16_grouped: unsupported layout combination %d %d", a_layout, b_layout);
+    return 2;
+}
+
 template <int PREC, int AL, int BL>
 static int launch_layout(const GemmBatch& gb, int count, int max_tiles, bool vec, hipStream_t s) {
     dim3 grid(max_tiles, 1, count), block(256);
@@ -287,6 +488,13 @@ extern "C" int exorl_profile_gemm_read(double* flops_out, float* ms_out, int32_t
     }
     *n_out = n;
     return 0;
+}
+
+extern "C" int exorl_gemm_bf16(int32_t a_layout, int32_t b_layout, int32_t M, int32_t N, int32_t K, const uint16_t* A,
+                               int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
+                               int32_t relu, int32_t accumulate, void* stream) {
+    exorl::Gemm16Problem p{A, B, C, bias, M, N, K, lda, ldb, ldc};
+    return exorl::gemm16_grouped(a_layout, b_layout, &p, 1, relu != 0, accumulate != 0, exorl::as_stream(stream));
 }
 
 extern "C" int exorl_gemm(int32_t precision, int32_t a_layout, int32_t b_layout, int32_t M, int32_t N, int32_t K,

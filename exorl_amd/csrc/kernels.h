@@ -15,6 +15,17 @@ struct GemmProblem {
 int gemm_grouped(int precision, int a_layout, int b_layout, const GemmProblem* probs, int count, bool relu,
                  bool accumulate, hipStream_t s);
 
+struct Gemm16Problem {
+    const unsigned short* A;
+    const unsigned short* B;
+    float* C;
+    const float* bias;
+    int M, N, K;
+    int64_t lda, ldb, ldc;
+};
+// operands stored as bf16 in memory (fast mode); same layout conventions as gemm_grouped
+int gemm16_grouped(int a_layout, int b_layout, const Gemm16Problem* probs, int count, bool relu, bool accumulate, hipStream_t s);
+
 // ---- row-wise / column-wise layer kernels (rowops.hip). `nets` independent nets are processed by one
 // launch (blockIdx.y); a* strides are in floats between nets for activations, p* for parameters.
 int ln_tanh_fwd(const float* z, const float* gain, const float* beta, float* h, float* xhat, float* rstd,

@@ -200,6 +200,10 @@ int exorl_agent_disable_graph(exorl_agent_t* a);
 int exorl_gemm(int32_t precision, int32_t a_layout, int32_t b_layout, int32_t M, int32_t N, int32_t K,
                const float* A_dev, int64_t lda, const float* B_dev, int64_t ldb, float* C_dev, int64_t ldc,
                const float* bias_dev, int32_t relu, int32_t accumulate, void* stream);
+/* Same with A and B stored as bf16 in memory (the fast mode's operand format); fp32 accumulate and output. */
+int exorl_gemm_bf16(int32_t a_layout, int32_t b_layout, int32_t M, int32_t N, int32_t K, const uint16_t* A_dev, int64_t lda,
+                    const uint16_t* B_dev, int64_t ldb, float* C_dev, int64_t ldc, const float* bias_dev, int32_t relu,
+                    int32_t accumulate, void* stream);
 /* Measurement hook (bench.py roofline leg): time every GEMM launch with HIP events on its own stream. */
 int exorl_profile_gemm(int32_t enable);
 int exorl_profile_gemm_read(double* flops_out_host, float* ms_out_host, int32_t cap, int32_t* n_out);

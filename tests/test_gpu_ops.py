@@ -55,6 +55,38 @@ def test_gemm(lib, prec, al, bl, M, N, K):
         assert err.max() < 2e-6, (prec, al, bl, M, N, K, relu, acc, err.max())   # fp32 accumulation order only
 
 
+@pytest.mark.parametrize('al,bl', [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize('M,N,K', [(64, 64, 64), (128, 64, 32), (1024, 1024, 1024), (2048, 1024, 1024), (96, 200, 72), (8, 32, 8)])
+def test_gemm_bf16_operands(lib, al, bl, M, N, K):
+    """Fast-mode kernel: operands already bf16 in memory; exact up to fp32 accumulation order."""
+    from exorl_amd import _lib as L
+    rs = np.random.RandomState(M + N + K + 5 * al + bl)
+    A = bf16_round(rs.standard_normal((M, K)).astype(np.float32))
+    B = bf16_round(rs.standard_normal((K, N)).astype(np.float32))
+    B[0, :] += bf16_round(np.arange(N, dtype=np.float32) % 7)       # asymmetric
+    B = bf16_round(B)
+    bias = rs.standard_normal(N).astype(np.float32)
+    C0 = rs.standard_normal((M, N)).astype(np.float32)
+    A_st = A if al == 0 else np.ascontiguousarray(A.T)
+    B_st = np.ascontiguousarray(B.T) if bl == 0 else B
+    a = torch.from_numpy(A_st).cuda().to(torch.bfloat16).contiguous()
+    b = torch.from_numpy(B_st).cuda().to(torch.bfloat16).contiguous()
+    c, bi = dev(C0.copy()), dev(bias)
+    for relu, acc in ((0, 0), (1, 0), (0, 1)):
+        c.copy_(torch.from_numpy(C0))
+        L.check(lib.exorl_gemm_bf16(al, bl, M, N, K, a.data_ptr(), A_st.shape[1], b.data_ptr(), B_st.shape[1], c.data_ptr(), N,
+                                    bi.data_ptr(), relu, acc, None))
+        torch.cuda.synchronize()
+        ref = A.astype(np.float64) @ B.astype(np.float64) + bias
+        if relu:
+            ref = np.maximum(ref, 0)
+        if acc:
+            ref = ref + C0
+        scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64) + 1.0
+        err = np.abs(c.cpu().numpy() - ref) / scale
+        assert err.max() < 2e-6, (al, bl, M, N, K, relu, acc, err.max())
+
+
 def test_gemm_f32_is_exact_fp32_products(lib):
     """Parity mode must not round operands: integers up to 2^12 multiply exactly in fp32 MFMA."""
     from exorl_amd import _lib as L
