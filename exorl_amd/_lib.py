@@ -77,6 +77,7 @@ PROTOTYPES = {
                              c_void_p, c_int64, c_void_p, c_int32, c_int32, c_void_p]),
     'exorl_gemm_bf16': (C.c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                   c_void_p, c_int32, c_int32, c_void_p]),
+    'exorl_gemm_tune': (C.c_int, [c_int32]),
     'exorl_profile_gemm': (C.c_int, [c_int32]),
     'exorl_profile_gemm_read': (C.c_int, [c_void_p, c_void_p, c_int32, P(c_int32)]),
     'exorl_adam_step': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,

@@ -14,6 +14,7 @@
 //    and written to the other LDS buffer after them — one barrier per k-tile.
 //  * operands whose reduction index is the slow dimension (dgrad B, wgrad A and B) are transposed in
 //    registers on the way to LDS (two rows x KU k's per thread), so all three GEMM forms share one inner loop.
+#include <type_traits>
 #include <vector>
 
 #include "kernels.h"
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
 // still yields >= 256 workgroups: (128+64) rows of 128 B per k-tile instead of 2 x (64+64).
 // Layout-1 operands (reduction index slow) are transposed in registers: 8 k-rows x 2 columns per thread as
 // 4-byte loads, v_perm_b32 splits the low/high bf16 into two 16-byte k-contiguous units.
-template <int L, int NU>
+template <int L, int NU, bool GUARD>
 __device__ __forceinline__ void load_tile16(const unsigned short* __restrict__ ptr, int64_t ld, int R, int K, int r0, int k0,
                                             int tid, uint4 (&reg)[NU]) {
     if constexpr (L == 0) {
@@ -212,10 +213,10 @@ __device__ __forceinline__ void load_tile16(const unsigned short* __restrict__ p
         for (int u = 0; u < NU; ++u) {
             const int row = r0 + (tid >> 3) + 32 * u;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (row < R && k + 8 <= K) v = *reinterpret_cast<const uint4*>(ptr + (int64_t)row * ld + k);
+            if (!GUARD || (row < R && k + 8 <= K)) v = *reinterpret_cast<const uint4*>(ptr + (int64_t)row * ld + k);
             reg[u] = v;
         }
-    } else {
+    } else {       // raw: reg[2g] = k rows 0..3, reg[2g+1] = k rows 4..7, each dword = {col, col+1}; permuted at store time
 #pragma unroll
         for (int g = 0; g < NU / 2; ++g) {
             const int row = r0 + 2 * (tid & 31) + 64 * g;
@@ -224,29 +225,33 @@ __device__ __forceinline__ void load_tile16(const unsigned short* __restrict__ p
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 d[j] = 0u;
-                if (k + j < K && row + 2 <= R) d[j] = *reinterpret_cast<const uint32_t*>(ptr + (int64_t)(k + j) * ld + row);
+                if (!GUARD || (k + j < K && row + 2 <= R)) d[j] = *reinterpret_cast<const uint32_t*>(ptr + (int64_t)(k + j) * ld + row);
             }
-            // low halves -> row, high halves -> row+1
-            reg[2 * g].x = __builtin_amdgcn_perm(d[1], d[0], 0x05040100u);
-            reg[2 * g].y = __builtin_amdgcn_perm(d[3], d[2], 0x05040100u);
-            reg[2 * g].z = __builtin_amdgcn_perm(d[5], d[4], 0x05040100u);
-            reg[2 * g].w = __builtin_amdgcn_perm(d[7], d[6], 0x05040100u);
-            reg[2 * g + 1].x = __builtin_amdgcn_perm(d[1], d[0], 0x07060302u);
-            reg[2 * g + 1].y = __builtin_amdgcn_perm(d[3], d[2], 0x07060302u);
-            reg[2 * g + 1].z = __builtin_amdgcn_perm(d[5], d[4], 0x07060302u);
-            reg[2 * g + 1].w = __builtin_amdgcn_perm(d[7], d[6], 0x07060302u);
+            reg[2 * g] = make_uint4(d[0], d[1], d[2], d[3]);
+            reg[2 * g + 1] = make_uint4(d[4], d[5], d[6], d[7]);
         }
     }
 }
 
 template <int L, int NU>
 __device__ __forceinline__ void store_tile16(unsigned char* lds, int tid, const uint4 (&reg)[NU]) {
+    if constexpr (L == 0) {
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        int row, unit;
-        if constexpr (L == 0) { row = (tid >> 3) + 32 * u; unit = tid & 7; }
-        else                  { row = 2 * (tid & 31) + (u & 1) + 64 * (u >> 1); unit = tid >> 5; }
-        *reinterpret_cast<uint4*>(lds + lds_off(row, unit)) = reg[u];
+        for (int u = 0; u < NU; ++u)
+            *reinterpret_cast<uint4*>(lds + lds_off((tid >> 3) + 32 * u, tid & 7)) = reg[u];
+    } else {
+#pragma unroll
+        for (int g = 0; g < NU / 2; ++g) {
+            const uint4 lo = reg[2 * g], hi = reg[2 * g + 1];
+            uint4 e, o;      // low halves -> column `row`, high halves -> column `row+1`
+            e.x = __builtin_amdgcn_perm(lo.y, lo.x, 0x05040100u); e.y = __builtin_amdgcn_perm(lo.w, lo.z, 0x05040100u);
+            e.z = __builtin_amdgcn_perm(hi.y, hi.x, 0x05040100u); e.w = __builtin_amdgcn_perm(hi.w, hi.z, 0x05040100u);
+            o.x = __builtin_amdgcn_perm(lo.y, lo.x, 0x07060302u); o.y = __builtin_amdgcn_perm(lo.w, lo.z, 0x07060302u);
+            o.z = __builtin_amdgcn_perm(hi.y, hi.x, 0x07060302u); o.w = __builtin_amdgcn_perm(hi.w, hi.z, 0x07060302u);
+            const int row = 2 * (tid & 31) + 64 * g, unit = tid >> 5;
+            *reinterpret_cast<uint4*>(lds + lds_off(row, unit)) = e;
+            *reinterpret_cast<uint4*>(lds + lds_off(row + 1, unit)) = o;
+        }
     }
 }
 
@@ -254,9 +259,11 @@ struct Gemm16Batch {
     Gemm16Problem p[4];
     int relu;
     int accumulate;
+    int swizzle;      // 1: XCD-aware tile order (blocks that share an XCD take neighbouring tiles)
 };
+static int g_gemm16_variant = -1;    // experiment switch (exorl_gemm_tune): -1 = default heuristics
 
-template <int AL, int BL, int BM>
+template <int AL, int BL, int BM, int NS, bool GUARD>
 __global__ __launch_bounds__(256) void gemm16_kernel(const Gemm16Batch gb) {
     constexpr int KPT = 64;                   // bf16 k per LDS tile (128 B rows)
     constexpr int NUA = BM / 32, NUB = 2;     // 16-byte units per thread
@@ -267,9 +274,17 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const Gemm16Batch gb) {
     const int M = P.M, N = P.N, K = P.K;
     const int tiles_n = (N + 63) / 64;
     const int tiles_m = (M + BM - 1) / BM;
-    if ((int)blockIdx.x >= tiles_n * tiles_m) return;
-    const int m0 = ((int)blockIdx.x / tiles_n) * BM;
-    const int n0 = ((int)blockIdx.x % tiles_n) * 64;
+    const int ntiles = tiles_n * tiles_m;
+    if ((int)blockIdx.x >= ntiles) return;
+    int tile = blockIdx.x;
+    if (gb.swizzle && (ntiles & 7) == 0) {
+        // blocks b, b+8, b+16.. share an XCD (round-robin dispatch): give each XCD a contiguous run of tiles so its
+        // private L2 holds one A row-panel set and the B panels instead of the whole of A
+        const int per = ntiles >> 3;
+        tile = (tile & 7) * per + (tile >> 3);
+    }
+    const int m0 = (tile / tiles_n) * BM;
+    const int n0 = (tile % tiles_n) * 64;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -277,7 +292,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const Gemm16Batch gb) {
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5;
 
-    uint4 ra[NUA], rb[NUB];
+    uint4 ra[NS][NUA], rb[NS][NUB];      // NS register stages: loads run NS-1 k-tiles ahead of their LDS store
     f32x16 acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t)
@@ -285,55 +300,228 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const Gemm16Batch gb) {
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
     const int nk = (K + KPT - 1) / KPT;
-    load_tile16<AL, NUA>(P.A, P.lda, M, K, m0, 0, tid, ra);
-    load_tile16<BL, NUB>(P.B, P.ldb, N, K, n0, 0, tid, rb);
-    store_tile16<AL, NUA>(smem[0], tid, ra);
-    store_tile16<BL, NUB>(smem[0] + BM * ROWB, tid, rb);
-    __syncthreads();
-
     const int arow = wm * (BM / 2) + (lane & 31);
     const int brow = wn * 32 + (lane & 31);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            load_tile16<AL, NUA>(P.A, P.lda, M, K, m0, (kt + 1) * KPT, tid, ra);
-            load_tile16<BL, NUB>(P.B, P.ldb, N, K, n0, (kt + 1) * KPT, tid, rb);
-        }
+    auto compute = [&](int cur) {
         const unsigned char* As = smem[cur];
         const unsigned char* Bs = smem[cur] + BM * ROWB;
+        uint4 af[MT][4], bfr[4];          // all fragment reads of the k-tile first (one exposed LDS latency), then MFMAs
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const uint4 b = *reinterpret_cast<const uint4*>(Bs + lds_off(brow, 2 * q + h));
+            bfr[q] = *reinterpret_cast<const uint4*>(Bs + lds_off(brow, 2 * q + h));
 #pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                const uint4 a = *reinterpret_cast<const uint4*>(As + lds_off(arow + 32 * t, 2 * q + h));
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
-                                                                 acc[t], 0, 0, 0);
-            }
+            for (int t = 0; t < MT; ++t) af[t][q] = *reinterpret_cast<const uint4*>(As + lds_off(arow + 32 * t, 2 * q + h));
         }
-        if (kt + 1 < nk) {
-            store_tile16<AL, NUA>(smem[cur ^ 1], tid, ra);
-            store_tile16<BL, NUB>(smem[cur ^ 1] + BM * ROWB, tid, rb);
-        }
+        __builtin_amdgcn_sched_barrier(0);      // keep the reads batched: hipcc otherwise sinks each pair to its MFMA
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[t][q]),
+                                                                 __builtin_bit_cast(bf16x8, bfr[q]), acc[t], 0, 0, 0);
+    };
+    auto issue = [&](auto sc, int kt) {          // loads of k-tile kt into register stage sc (clamped: never past K)
+        constexpr int st = decltype(sc)::value;
+        const int k0 = (kt < nk ? kt : nk - 1) * KPT;
+        load_tile16<AL, NUA, GUARD>(P.A, P.lda, M, K, m0, k0, tid, ra[st]);
+        load_tile16<BL, NUB, GUARD>(P.B, P.ldb, N, K, n0, k0, tid, rb[st]);
+    };
+    auto commit = [&](auto sc, int buf) {        // register stage sc -> LDS buffer buf
+        constexpr int st = decltype(sc)::value;
+        store_tile16<AL, NUA>(smem[buf], tid, ra[st]);
+        store_tile16<BL, NUB>(smem[buf] + BM * ROWB, tid, rb[st]);
+    };
+    auto step = [&](auto sc, int kt) {           // k-tile kt lives in LDS[kt&1]; tile kt+1 is in stage (sc+1)%NS
+        constexpr int st = decltype(sc)::value;
+        issue(sc, kt + NS);                      // stage sc was committed last step: refill it NS tiles ahead
+        compute(kt & 1);
+        if (kt + 1 < nk) commit(std::integral_constant<int, (st + 1) % NS>{}, (kt & 1) ^ 1);
         __syncthreads();
+    };
+    // prologue: tiles 0..NS-1 in flight, tile 0 committed
+    issue(std::integral_constant<int, 0>{}, 0);
+    if constexpr (NS > 1) issue(std::integral_constant<int, 1>{}, 1);
+    if constexpr (NS > 2) issue(std::integral_constant<int, 2>{}, 2);
+    if constexpr (NS > 3) issue(std::integral_constant<int, 3>{}, 3);
+    commit(std::integral_constant<int, 0>{}, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += NS) {
+        step(std::integral_constant<int, 0>{}, kt);
+        if constexpr (NS > 1) { if (kt + 1 >= nk) break; step(std::integral_constant<int, 1>{}, kt + 1); }
+        if constexpr (NS > 2) { if (kt + 2 >= nk) break; step(std::integral_constant<int, 2>{}, kt + 2); }
+        if constexpr (NS > 3) { if (kt + 3 >= nk) break; step(std::integral_constant<int, 3>{}, kt + 3); }
     }
 
     const int n = n0 + wn * 32 + (lane & 31);
     if (n < N) {
         const float bias = P.bias ? P.bias[n] : 0.f;
+        const bool relu = gb.relu != 0;
+        if (gb.accumulate) {
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
+            for (int t = 0; t < MT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * (BM / 2) + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m < M) {
-                    float v = acc[t][r] + bias;
-                    if (gb.relu) v = fmaxf(v, 0.f);
-                    float* dst = P.C + (int64_t)m * P.ldc + n;
-                    if (gb.accumulate) v += *dst;
-                    *dst = v;
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * (BM / 2) + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (m < M) {
+                        float* dst = P.C + (int64_t)m * P.ldc + n;
+                        float v = acc[t][r] + bias;
+                        if (relu) v = fmaxf(v, 0.f);
+                        *dst = v + *dst;
+                    }
                 }
-            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * (BM / 2) + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (m < M) {
+                        float v = acc[t][r] + bias;
+                        if (relu) v = fmaxf(v, 0.f);
+                        P.C[(int64_t)m * P.ldc + n] = v;
+                    }
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant for exactly-tiled problems (M, N, K multiples of 64): the production path of the 1024-wide layers.
+// Operand tiles go global -> LDS with `global_load_lds_dwordx4` (no VGPR round trip, no ds_write), four stages deep,
+// paced by counted s_waitcnt vmcnt + one raw s_barrier per k-tile (the loads of tiles t+1, t+2 stay in flight
+// across the barrier). LDS images are lane-linear per wave-instruction; the bank swizzles are applied to the per-lane
+// SOURCE address and again on the fragment read:
+//   k-contiguous operand ("row image", [row][64 k]):   unit' = unit ^ ((row>>1)&7), fragments by ds_read_b128
+//   reduction-slow operand ("k image", [k][64 rows], a straight copy of memory): unit' = unit ^ 4*((k>>1)&1),
+//     fragments by ds_read_b64_tr_b16 (hardware transpose: 4 k-rows x 16 columns per 16-lane group), so dgrad and
+//     wgrad need no transposed copies of W1 / dZ / H in memory and no register shuffles.
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <bool AT, bool BT>
+__global__ __launch_bounds__(256) void gemm16g_kernel(const Gemm16Batch gb) {
+    constexpr int NSTG = 4;
+    constexpr int IMG = 64 * ROWB;                 // 8 KB per operand image
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NSTG * 2 * IMG];
+
+    const Gemm16Problem& P = gb.p[blockIdx.z];
+    const int M = P.M, N = P.N, K = P.K;
+    const int tiles_n = N >> 6, tiles_m = M >> 6;
+    const int ntiles = tiles_n * tiles_m;
+    if ((int)blockIdx.x >= ntiles) return;
+    int tile = blockIdx.x;
+    if (gb.swizzle && (ntiles & 7) == 0) tile = (tile & 7) * (ntiles >> 3) + (tile >> 3);
+    const int m0 = (tile / tiles_n) << 6;
+    const int n0 = (tile % tiles_n) << 6;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5;
+    const int nk = K >> 6;                         // multiple of NSTG (checked by the launcher)
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    // ---- LDS-DMA source pointers: this wave's two 1-KB pieces per operand image (image rows 16*wave+8j + lane/8);
+    // everything per-lane is computed once, the k-loop only adds a constant stride
+    const unsigned short* src[4];
+    int64_t kstep[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rr = 16 * wave + 8 * j + (lane >> 3), p = lane & 7;
+        if constexpr (!AT) src[j] = P.A + (int64_t)(m0 + rr) * P.lda + 8 * (p ^ ((rr >> 1) & 7));
+        else               src[j] = P.A + (int64_t)rr * P.lda + m0 + 8 * (p ^ (4 * ((rr >> 1) & 1)));
+        if constexpr (!BT) src[2 + j] = P.B + (int64_t)(n0 + rr) * P.ldb + 8 * (p ^ ((rr >> 1) & 7));
+        else               src[2 + j] = P.B + (int64_t)rr * P.ldb + n0 + 8 * (p ^ (4 * ((rr >> 1) & 1)));
+    }
+    kstep[0] = AT ? 64 * P.lda : 64;
+    kstep[1] = BT ? 64 * P.ldb : 64;
+    const int piece = 16 * wave * ROWB;            // wave-uniform LDS offset of this wave's pieces inside an image
+
+    // ---- fragment read offsets (per lane, stage-relative; stage and q enter as immediates)
+    const int arow = wm * 32 + (lane & 31), brow = wn * 32 + (lane & 31);
+    const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    auto tr_off = [&](int rbase) {      // k image: k-row 8*(g>>1)+qq, columns rbase + 16*(g&1) + 4*pp ..+3
+        const int c = rbase + 16 * (g & 1) + 4 * pp;
+        return (8 * (g >> 1) + qq) * ROWB + (((c >> 3) ^ (4 * ((qq >> 1) & 1))) << 4) + ((c & 7) << 1);
+    };
+    int aoff[4], boff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        aoff[q] = AT ? tr_off(wm * 32) + q * 16 * ROWB : lds_off(arow, 2 * q + h);
+        boff[q] = BT ? tr_off(wn * 32) + q * 16 * ROWB : lds_off(brow, 2 * q + h);
+    }
+
+    auto fill = [&](auto sc) {                     // issue the 4 DMA pieces of the next k-tile into stage sc
+        constexpr int st = decltype(sc)::value;
+        unsigned char* base = smem + st * 2 * IMG + piece;
+        __builtin_amdgcn_global_load_lds((const void*)src[0], (lds_void*)(base), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)src[1], (lds_void*)(base + 8 * ROWB), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)src[2], (lds_void*)(base + IMG), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)src[3], (lds_void*)(base + IMG + 8 * ROWB), 16, 0, 0);
+        src[0] += kstep[0]; src[1] += kstep[0]; src[2] += kstep[1]; src[3] += kstep[1];
+    };
+    auto frag = [&](const unsigned char* img, bool tr, int off) -> bf16x8 {
+        if (!tr) return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(img + off));
+        const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(img + off));
+        const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(img + off + 4 * ROWB));
+        typedef short v8s16 __attribute__((ext_vector_type(8)));
+        const v8s16 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    auto step = [&](auto sc, int t) {              // k-tile t sits in stage sc
+        constexpr int st = decltype(sc)::value;
+        // tile t has landed once at most the fills of the two younger tiles remain outstanding (4 DMA pieces per tile per wave)
+        const int younger = nk - 1 - t;
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // every wave's pieces of tile t are in LDS; stage st-1 is no longer being read
+        asm volatile("" ::: "memory");
+        if (t + NSTG - 1 < nk) fill(std::integral_constant<int, (st + NSTG - 1) % NSTG>{});
+        const unsigned char* As = smem + st * 2 * IMG;
+        const unsigned char* Bs = As + IMG;
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            af[q] = frag(As, AT, aoff[q]);
+            bfr[q] = frag(Bs, BT, boff[q]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q], bfr[q], acc, 0, 0, 0);
+    };
+
+    fill(std::integral_constant<int, 0>{});
+    fill(std::integral_constant<int, 1>{});
+    fill(std::integral_constant<int, 2>{});
+    for (int t = 0; t < nk; t += NSTG) {
+        step(std::integral_constant<int, 0>{}, t);
+        step(std::integral_constant<int, 1>{}, t + 1);
+        step(std::integral_constant<int, 2>{}, t + 2);
+        step(std::integral_constant<int, 3>{}, t + 3);
+    }
+
+    const int n = n0 + wn * 32 + (lane & 31);
+    const float bias = P.bias ? P.bias[n] : 0.f;
+    const bool relu = gb.relu != 0;
+    float* crow = P.C + (int64_t)(m0 + wm * 32 + 4 * h) * P.ldc + n;
+    if (gb.accumulate) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float* dst = crow + (int64_t)((r & 3) + 8 * (r >> 2)) * P.ldc;
+            float v = acc[r] + bias;
+            if (relu) v = fmaxf(v, 0.f);
+            *dst = v + *dst;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[r] + bias;
+            if (relu) v = fmaxf(v, 0.f);
+            crow[(int64_t)((r & 3) + 8 * (r >> 2)) * P.ldc] = v;
         }
     }
 }
@@ -354,8 +542,38 @@ static int launch16(const Gemm16Batch& gb, int count, int tiles64, int tiles128,
         g_prof.flops.push_back(f);
         EXORL_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.used], s));
     }
-    if (tiles128 * count >= 256) hipLaunchKernelGGL((gemm16_kernel<AL, BL, 128>), dim3(tiles128, 1, count), dim3(256), 0, s, gb);
-    else                         hipLaunchKernelGGL((gemm16_kernel<AL, BL, 64>), dim3(tiles64, 1, count), dim3(256), 0, s, gb);
+    // variant bits (tuning): 1 = force BM 64, 2 = force BM 128, 8 = no XCD swizzle, 16 = keep guards,
+    // 32 = 2 register stages, 64 = 4 register stages (default 3)
+    const int var = g_gemm16_variant < 0 ? 0 : g_gemm16_variant;
+    const bool big = (var & 2) ? true : ((var & 1) ? false : tiles128 * count >= 256);
+    Gemm16Batch g2 = gb;
+    g2.swizzle = (var & 8) ? 0 : 1;
+    bool exact = true;      // every problem tiles exactly: loads need no bounds guards
+    for (int i = 0; i < count; ++i)
+        exact = exact && gb.p[i].M % 128 == 0 && gb.p[i].N % 64 == 0 && gb.p[i].K % 64 == 0;
+    if (var & 16) exact = false;
+    bool exact64 = true;
+    for (int i = 0; i < count; ++i)
+        exact64 = exact64 && gb.p[i].M % 64 == 0 && gb.p[i].N % 64 == 0 && gb.p[i].K % 256 == 0 && gb.p[i].lda % 8 == 0 &&
+                  gb.p[i].ldb % 8 == 0 && reinterpret_cast<uintptr_t>(gb.p[i].A) % 16 == 0 && reinterpret_cast<uintptr_t>(gb.p[i].B) % 16 == 0;
+    if (exact64 && !(var & 128)) {         // LDS-DMA pipeline (bit 128 of the tuning variant forces the register-staged kernels)
+        hipLaunchKernelGGL((gemm16g_kernel<AL != 0, BL != 0>), dim3(tiles64, 1, count), dim3(256), 0, s, g2);
+        EXORL_LAUNCH_CHECK();
+        if (prof) {
+            EXORL_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s));
+            g_prof.used += 1;
+        }
+        return 0;
+    }
+    const int ns = (var & 32) ? 2 : ((var & 64) ? 4 : 3);
+#define EXORL_G16(BMv, NSv, Gv) hipLaunchKernelGGL((gemm16_kernel<AL, BL, BMv, NSv, Gv>), dim3(big ? tiles128 : tiles64, 1, count), dim3(256), 0, s, g2)
+    if (exact) {
+        if (big) { if (ns == 2) EXORL_G16(128, 2, false); else if (ns == 3) EXORL_G16(128, 3, false); else EXORL_G16(128, 4, false); }
+        else     { if (ns == 2) EXORL_G16(64, 2, false); else if (ns == 3) EXORL_G16(64, 3, false); else EXORL_G16(64, 4, false); }
+    } else {
+        if (big) EXORL_G16(128, 2, true); else EXORL_G16(64, 2, true);
+    }
+#undef EXORL_G16
     EXORL_LAUNCH_CHECK();
     if (prof) {
         EXORL_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s));
@@ -487,6 +705,11 @@ extern "C" int exorl_profile_gemm_read(double* flops_out, float* ms_out, int32_t
         ms_out[n] = ms;
     }
     *n_out = n;
+    return 0;
+}
+
+extern "C" int exorl_gemm_tune(int32_t variant) {
+    exorl::g_gemm16_variant = variant;
     return 0;
 }
 

@@ -204,6 +204,8 @@ int exorl_gemm(int32_t precision, int32_t a_layout, int32_t b_layout, int32_t M,
 int exorl_gemm_bf16(int32_t a_layout, int32_t b_layout, int32_t M, int32_t N, int32_t K, const uint16_t* A_dev, int64_t lda,
                     const uint16_t* B_dev, int64_t ldb, float* C_dev, int64_t ldc, const float* bias_dev, int32_t relu,
                     int32_t accumulate, void* stream);
+/* Tuning switch for the bf16-operand GEMM (tools/micro/gemm_bench.py): -1 = default heuristics. */
+int exorl_gemm_tune(int32_t variant);
 /* Measurement hook (bench.py roofline leg): time every GEMM launch with HIP events on its own stream. */
 int exorl_profile_gemm(int32_t enable);
 int exorl_profile_gemm_read(double* flops_out_host, float* ms_out_host, int32_t cap, int32_t* n_out);
