@@ -121,6 +121,7 @@ class _AgentBase:
             for p, w in zip(self.critic.parameters(), critic0):
                 p.copy_(w.reshape(p.shape))
         self.engine.params_changed(sync_target=True)                   # critic_target.load_state_dict(critic.state_dict())
+        self.engine.set_metrics(bool(getattr(self, 'use_tb', False) or getattr(self, 'use_wandb', False)))
         self._slots = None
         self._graph_iter = None
         self._graph_stddev = None

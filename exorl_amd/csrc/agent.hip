@@ -117,14 +117,14 @@ static int net_forward(const NetDesc& d, const float* P, const NetShadow& sh, co
 // G == nullptr: dgrad only (no parameter gradients). dx (n_trunks x rows x dx_cols, one slab per trunk — the
 // consumer adds them) receives d/dx[:, col0:col0+dx_cols].
 static int net_backward(const NetDesc& d, const float* P, const NetShadow& sh, float* G, const Partials& pt, const float* x,
-                        int64_t ldx, int rows, const FwdBufs& f, const float* dout, const BwdBufs& b, float* dx, int dx_col0,
+                        int64_t ldx, int rows, const FwdBufs& f, const DoutSpec& dout, const BwdBufs& b, float* dx, int dx_col0,
                         int dx_cols, int prec, hipStream_t s) {
     const int H = d.H;
     const int64_t act = (int64_t)rows * H;
     const bool paired = d.n_trunks == d.n_heads;
     const bool bf = prec == EXORL_PREC_BF16;
     EXORL_TRY(head_bwd(dout, P + d.W2, f.h2, bf ? nullptr : b.dz2, bf ? b.dz2b : nullptr, G ? pt.Ph : nullptr, rows, H, d.out_dim,
-                       d.n_heads, act, d.head_stride, (int64_t)rows * d.out_dim, G ? 1 : 0, s));
+                       d.n_heads, act, d.head_stride, G ? 1 : 0, s));
     if (bf) {
         Gemm16Problem q[2];
         if (G) {
@@ -216,6 +216,7 @@ struct exorl_agent {
     float *act_x = nullptr, *act_noise = nullptr;
     FwdBufs fact{};
     StepState* state = nullptr;  // device-resident counters + Adam scalars (graph-replayable)
+    const float *noise_c = nullptr, *noise_a = nullptr;   // caller-supplied noise of the step in flight (parity tests)
     int64_t actor_t = 0, critic_t = 0;       // host mirrors of state->t_*
     uint64_t act_noise_counter = 0;
     float inv_bg = 0.f;
@@ -225,6 +226,7 @@ struct exorl_agent {
     hipStream_t capture_stream = nullptr;
     exorl_replay* graph_replay = nullptr;
     bool capturing = false;
+    bool want_metrics = true;    // the (B,1)-sized metric reductions are skipped when the caller never reads them (use_tb=False)
 };
 
 namespace exorl {
@@ -302,6 +304,10 @@ static NoiseSpec act_noise_spec(exorl_agent* a, const float* buf) {
 static int push_opt_steps(exorl_agent* a) {
     long long t[2] = {a->actor_t, a->critic_t};
     EXORL_CHECK_HIP(hipMemcpy(&a->state->t_actor, t, sizeof(t), hipMemcpyHostToDevice));
+    const double p[4] = {std::pow(0.9, (double)a->actor_t), 0.0, std::pow(0.9, (double)a->critic_t), std::pow(0.999, (double)a->critic_t)};
+    const double p2 = std::pow(0.999, (double)a->actor_t);
+    EXORL_CHECK_HIP(hipMemcpy(&a->state->b1t, p, sizeof(p), hipMemcpyHostToDevice));
+    EXORL_CHECK_HIP(hipMemcpy(&a->state->b2t, &p2, sizeof(p2), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -309,22 +315,29 @@ static int push_opt_steps(exorl_agent* a) {
 static int phase0(exorl_agent* a, float stddev, const float* noise_c, hipStream_t s) {
     const auto& cfg = a->cfg;
     const int B = cfg.batch, O = cfg.obs_dim, A = cfg.act_dim, W = O + A, prec = cfg.precision;
-    EXORL_TRY(step_begin(a->state, a->capturing ? 1 : 0, s));     // counters += ; Adam scalars for this step
+    // stages the inputs and (thread 0) advances the device-side step state: counters, Adam scalars of this step
+    EXORL_TRY(prepare_inputs(a->obs, a->action, a->next_obs, a->xa, a->xc_cur, a->xc_next, a->xc_pi, B, O, A, a->has_critic, a->state,
+                             a->capturing ? 1 : 0, s));
     a->actor_t += 1;
     if (a->has_critic) a->critic_t += 1;
-    EXORL_TRY(prepare_inputs(a->obs, a->action, a->next_obs, a->xa, a->xc_cur, a->xc_next, a->xc_pi, B, O, A, a->has_critic, s));
     if (!a->has_critic) return 0;
     const float* Pa = a->flat[EXORL_NET_ACTOR][EXORL_T_PARAM];
     const float* Pc = a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM];
     const float* Pt = a->flat[EXORL_NET_CRITIC_TARGET][EXORL_T_PARAM];
     // actor on [next_obs; obs] in one pass (td3_bc.py:124 and :149 use the same weights)
     EXORL_TRY(net_forward(a->actor, Pa, a->sh_actor, a->xa, O, 2 * B, a->fa, true, true, prec, s));
-    // next_action = dist.sample(clip) (td3_bc.py:125) straight into the target critic's input
-    EXORL_TRY(sample_action(a->fa.out, noise_spec(a, noise_c, 0), stddev, cfg.stddev_clip, 1, a->xc_next + O, W, B, A, nullptr, s));
+    // next_action = dist.sample(clip) (td3_bc.py:125) and the actor-step sample pi(obs) (:151, it does not depend on the
+    // critic update) straight into the two critic input buffers
+    a->noise_c = noise_c;
+    EXORL_TRY(sample_actions2(a->fa.out, noise_c, a->noise_a, cfg.seed, &a->state->noise_counter, stddev, cfg.stddev_clip,
+                              a->xc_next + O, a->xc_pi + O, W, B, A, s));
     EXORL_TRY(net_forward(a->critic, Pt, a->sh_target, a->xc_next, W, B, a->ft, false, false, prec, s));     // td3_bc.py:126
     EXORL_TRY(net_forward(a->critic, Pc, a->sh_critic, a->xc_cur, W, B, a->fc, true, false, prec, s));       // td3_bc.py:130
-    EXORL_TRY(critic_loss(a->fc.out, a->ft.out, a->reward, a->discount, a->dq, a->metrics, B, a->inv_bg, s));   // :127-131
-    EXORL_TRY(net_backward(a->critic, Pc, a->sh_critic, a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD], a->pc, a->xc_cur, W, B, a->fc, a->dq,
+    if (a->want_metrics)
+        EXORL_TRY(critic_loss(a->fc.out, a->ft.out, a->reward, a->discount, a->dq, a->metrics, B, a->inv_bg, s));   // :133-137
+    DoutSpec td{};                              // d(2 x MSE)/dQ computed where it is consumed (:127-131)
+    td.mode = EXORL_DOUT_TD; td.q = a->fc.out; td.tq = a->ft.out; td.reward = a->reward; td.discount = a->discount; td.inv_bg = a->inv_bg;
+    EXORL_TRY(net_backward(a->critic, Pc, a->sh_critic, a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD], a->pc, a->xc_cur, W, B, a->fc, td,
                            a->bc, nullptr, 0, 0, prec, s));                                                     // :141
     return 0;
 }
@@ -337,10 +350,10 @@ static int phase1(exorl_agent* a, float stddev, const float* noise_a, hipStream_
     EXORL_TRY(adam_step_dev(a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD],
                             a->flat[EXORL_NET_CRITIC][EXORL_T_ADAM_M], a->flat[EXORL_NET_CRITIC][EXORL_T_ADAM_V], a->critic.total,
                             &a->state->critic, a->flat[EXORL_NET_CRITIC_TARGET][EXORL_T_PARAM], &a->spec_critic, s));
-    // policy.sample(clip) on obs (td3_bc.py:151): mu rows B..2B of the stacked actor forward
-    float* logprob = cfg.kind == EXORL_AGENT_DDPG ? a->metrics + EXORL_M_ACTOR_LOGPROB : nullptr;
-    EXORL_TRY(sample_action(a->fa.out + (int64_t)B * A, noise_spec(a, noise_a, 1), stddev, cfg.stddev_clip, 1, a->xc_pi + O, W, B, A,
-                            logprob, s));
+    // pi(obs) sample already sits in xc_pi (phase 0); DDPG logs its log-prob (ddpg.py:276,289)
+    if (cfg.kind == EXORL_AGENT_DDPG && a->want_metrics)
+        EXORL_TRY(sample_action(a->fa.out + (int64_t)B * A, noise_spec(a, noise_a, 1), stddev, cfg.stddev_clip, 1, a->xc_pi + O, W, B, A,
+                                a->metrics + EXORL_M_ACTOR_LOGPROB, s));
     EXORL_TRY(net_forward(a->critic, a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->sh_critic, a->xc_pi, W, B, a->fc, true, false, prec, s));
     EXORL_TRY(actor_stats(a->fc.out, a->stats, B, s));
     return 0;
@@ -352,20 +365,26 @@ static int phase2(exorl_agent* a, float stddev, hipStream_t s) {
     const int B = cfg.batch, O = cfg.obs_dim, A = cfg.act_dim, W = O + A, H = cfg.hidden_dim, prec = cfg.precision;
     const float* Pa = a->flat[EXORL_NET_ACTOR][EXORL_T_PARAM];
     if (a->has_critic) {
-        EXORL_TRY(actor_dq(a->fc.out, a->stats, a->dq, B, a->inv_bg, cfg.alpha, cfg.kind == EXORL_AGENT_TD3_BC, s));
+        DoutSpec dq{};                          // -lambda/Bg routed to the smaller Q (td3_bc.py:152-155)
+        dq.mode = EXORL_DOUT_ACTOR_Q; dq.q = a->fc.out; dq.stats = a->stats; dq.inv_bg = a->inv_bg; dq.alpha = cfg.alpha;
+        dq.use_lambda = cfg.kind == EXORL_AGENT_TD3_BC;
         EXORL_TRY(net_backward(a->critic, a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->sh_critic, nullptr, a->pc, a->xc_pi, W, B, a->fc,
-                               a->dq, a->bc, a->da, O, A, prec, s));
+                               dq, a->bc, a->da, O, A, prec, s));
     }
     // the obs half (rows B..2B) of the stacked actor forward
     FwdBufs f{a->fa.h1 + (int64_t)B * H, a->fa.xhat + (int64_t)B * H, a->fa.rstd + B, a->fa.h2 + (int64_t)B * H,
               a->fa.out + (int64_t)B * A, a->fa.h1b ? a->fa.h1b + (int64_t)B * H : nullptr};
     if (!a->has_critic)       // BC (bc.py:82): the only forward of the step
         EXORL_TRY(net_forward(a->actor, Pa, a->sh_actor, a->xa + (int64_t)B * O, O, B, f, true, true, prec, s));
-    EXORL_TRY(actor_dmu(a->da, A, a->has_critic ? a->critic.n_trunks : 0, (int64_t)B * A, f.out, a->action,
-                        a->has_critic ? nullptr : a->reward, a->dpre, a->stats, a->metrics, B, A, a->inv_bg, cfg.alpha, cfg.kind,
-                        stddev, s));
+    if (a->want_metrics)                        // actor_loss / batch_reward(BC) metrics only (the gradient is formed in head_bwd)
+        EXORL_TRY(actor_dmu(a->da, A, a->has_critic ? a->critic.n_trunks : 0, (int64_t)B * A, f.out, a->action,
+                            a->has_critic ? nullptr : a->reward, a->dpre, a->stats, a->metrics, B, A, a->inv_bg, cfg.alpha, cfg.kind,
+                            stddev, s));
+    DoutSpec dm{};
+    dm.mode = EXORL_DOUT_ACTOR_MU; dm.da = a->da; dm.da_nets = a->has_critic ? a->critic.n_trunks : 0; dm.mu = f.out; dm.a_data = a->action;
+    dm.kind = cfg.kind; dm.inv_bg = a->inv_bg; dm.stddev = stddev;
     EXORL_TRY(net_backward(a->actor, Pa, a->sh_actor, a->flat[EXORL_NET_ACTOR][EXORL_T_GRAD], a->pa, a->xa + (int64_t)B * O, O, B, f,
-                           a->dpre, a->ba, nullptr, 0, 0, prec, s));
+                           dm, a->ba, nullptr, 0, 0, prec, s));
     return 0;
 }
 
@@ -423,6 +442,7 @@ int exorl_agent_create(const exorl_agent_cfg* cfg, void* workspace, size_t works
     StepState st{};
     st.lr = cfg->lr; st.b1 = 0.9f; st.b2 = 0.999f; st.eps = 1e-8f; st.tau = cfg->tau;      // torch.optim.Adam defaults
     st.has_critic = a->has_critic ? 1 : 0;
+    st.b1t = st.b2t = st.b1t_c = st.b2t_c = 1.0;
     e = hipMemcpy(a->state, &st, sizeof(st), hipMemcpyHostToDevice);
     if (e != hipSuccess) { set_error("agent_create: state upload -> %s", hipGetErrorString(e)); if (a->owns_ws) (void)hipFree(a->ws); delete a; return 1; }
     *out = a;
@@ -515,6 +535,7 @@ int exorl_agent_update_phase(exorl_agent_t* a, int32_t phase, float stddev, cons
     EXORL_REQUIRE(a, "agent_update_phase: null handle");
     EXORL_REQUIRE(stddev > 0.f, "agent_update_phase: stddev must be > 0");
     hipStream_t s = as_stream(stream);
+    a->noise_a = noise_a;
     switch (phase) {
         case 0: return phase0(a, stddev, noise_c, s);
         case 1: return phase1(a, stddev, noise_a, s);
@@ -608,6 +629,13 @@ int exorl_agent_enable_graph(exorl_agent_t* a, exorl_replay_t* r, int32_t nstep,
     a->graph = g;
     EXORL_CHECK_HIP(hipGraphInstantiate(&a->graph_exec, g, nullptr, nullptr, 0));
     a->graph_replay = r;
+    return 0;
+}
+
+int exorl_agent_set_metrics(exorl_agent_t* a, int32_t enable) {
+    EXORL_REQUIRE(a, "agent_set_metrics: null handle");
+    EXORL_REQUIRE(!a->graph_exec, "agent_set_metrics: disable the captured graph first");
+    a->want_metrics = enable != 0;
     return 0;
 }
 

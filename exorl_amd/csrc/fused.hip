@@ -29,14 +29,23 @@ __device__ __forceinline__ unsigned short f2bf(float x) {
 // W0T is staged through LDS in 16-row k-chunks (64 KB: two workgroups per CU) and read back as conflict-free
 // ds_read_b128; LayerNorm statistics are wave-local (no workgroup barrier on the critical path).
 constexpr int TF_ROWS = 8;
-constexpr int TF_KC = 16;
+constexpr int TF_LDS_FLOATS = 35 * 1024;      // 140 KB for the W0T chunk: all of a (O+A <= 35) x 1024 first layer at once
+
+// tanh(x) = 1 - 2/(1 + e^{2x}) on the hardware exp2/rcp units (abs. error ~1e-7; used in the bf16 fast mode, where
+// the 1024^2 tanh evaluations of libm quality would cost more VALU time than the layer's FMAs)
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float e = __expf(2.0f * x);
+    return 1.0f - 2.0f * __frcp_rn(1.0f + e);
+}
+
+template <bool FAST>
 __global__ __launch_bounds__(512) void trunk_fwd_kernel(const float* __restrict__ x, int64_t ldx,
                                                         const float* __restrict__ W0T, const float* __restrict__ b0,
                                                         const float* __restrict__ gain, const float* __restrict__ beta,
                                                         float* __restrict__ h, float* __restrict__ xhat,
                                                         float* __restrict__ rstd, unsigned short* __restrict__ hb,
                                                         int rows, int in_dim, int H, int64_t astride, int64_t pstride,
-                                                        int64_t tstride) {
+                                                        int64_t tstride, int TF_KC) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* ws = smem;                          // [TF_KC][H]
     float* xs = smem + TF_KC * H;              // [TF_ROWS][MAX_IN]
@@ -98,8 +107,13 @@ __global__ __launch_bounds__(512) void trunk_fwd_kernel(const float* __restrict_
         const float4 g = reinterpret_cast<const float4*>(gain + net * pstride)[c4];
         const float4 be = reinterpret_cast<const float4*>(beta + net * pstride)[c4];
         const float4 xh = make_float4(z[i].x * rs, z[i].y * rs, z[i].z * rs, z[i].w * rs);
-        const float4 hv = make_float4(tanhf(xh.x * g.x + be.x), tanhf(xh.y * g.y + be.y), tanhf(xh.z * g.z + be.z),
-                                      tanhf(xh.w * g.w + be.w));
+        float4 hv;
+        if constexpr (FAST)
+            hv = make_float4(tanh_fast(xh.x * g.x + be.x), tanh_fast(xh.y * g.y + be.y), tanh_fast(xh.z * g.z + be.z),
+                             tanh_fast(xh.w * g.w + be.w));
+        else
+            hv = make_float4(tanhf(xh.x * g.x + be.x), tanhf(xh.y * g.y + be.y), tanhf(xh.z * g.z + be.z),
+                             tanhf(xh.w * g.w + be.w));
         reinterpret_cast<float4*>(h + o)[c4] = hv;
         if (xhat) reinterpret_cast<float4*>(xhat + o)[c4] = xh;
         if (hb) {
@@ -115,9 +129,20 @@ int trunk_fwd(const float* x, int64_t ldx, const float* W0T, const float* b0, co
               float* h, float* xhat, float* rstd, unsigned short* h_bf16, int rows, int in_dim, int H, int nets,
               int64_t astride, int64_t pstride, int64_t tstride, hipStream_t s) {
     EXORL_REQUIRE(H >= 4 && H <= 1024 && H % 4 == 0 && in_dim >= 1 && in_dim <= MAX_IN, "trunk_fwd: unsupported H=%d in=%d", H, in_dim);
-    const size_t lds = ((size_t)TF_KC * H + TF_ROWS * MAX_IN) * sizeof(float);
-    hipLaunchKernelGGL(trunk_fwd_kernel, dim3(cdiv(rows, TF_ROWS), nets), dim3(512), lds, s, x, ldx, W0T, b0, gain, beta, h, xhat,
-                       rstd, h_bf16, rows, in_dim, H, astride, pstride, tstride);
+    int kc = TF_LDS_FLOATS / H;                // k-rows of W0T staged per pass
+    if (kc > in_dim) kc = in_dim;
+    const size_t lds = ((size_t)kc * H + TF_ROWS * MAX_IN) * sizeof(float);
+    const dim3 grid(cdiv(rows, TF_ROWS), nets);
+    static bool attr_set = false;
+    if (!attr_set) {       // > 64 KB of dynamic LDS needs the opt-in on HIP
+        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)trunk_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)trunk_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    if (h_bf16) hipLaunchKernelGGL((trunk_fwd_kernel<true>), grid, dim3(512), lds, s, x, ldx, W0T, b0, gain, beta, h, xhat, rstd, h_bf16,
+                                   rows, in_dim, H, astride, pstride, tstride, kc);
+    else        hipLaunchKernelGGL((trunk_fwd_kernel<false>), grid, dim3(512), lds, s, x, ldx, W0T, b0, gain, beta, h, xhat, rstd, h_bf16,
+                                   rows, in_dim, H, astride, pstride, tstride, kc);
     EXORL_LAUNCH_CHECK();
     return 0;
 }
@@ -126,7 +151,7 @@ int trunk_fwd(const float* x, int64_t ldx, const float* W0T, const float* b0, co
 // trunk backward, part 1: LayerNorm/tanh backward. One row per wave; 8 waves x 2 rows per workgroup.
 //   dz0 = rstd * (dxh - mean(dxh) - xhat * mean(dxh*xhat)),  dxh = dh*(1-h^2)*gain      (written in place over dh)
 // and per-workgroup partial column sums P[chunk] = [dgain H][dbeta H][db0 H] (PARAMS only).
-constexpr int TB_ROWS = 16;
+constexpr int TB_ROWS = 8;
 template <bool PARAMS>
 __global__ __launch_bounds__(512) void ln_bwd_kernel(float* dh, const float* __restrict__ h, const float* __restrict__ xhat,
                                                      const float* __restrict__ rstd, const float* __restrict__ gain,
@@ -239,12 +264,15 @@ __global__ __launch_bounds__(256) void outer_reduce_kernel(const float* __restri
             float acc[32];
 #pragma unroll
             for (int j = 0; j < 32; ++j) acc[j] = 0.f;
-            for (int r = 0; r < nr; ++r) {
-                const float vv = v[net * vstride + (int64_t)(row0 + r) * H + c];
+            float vv[OR_ROWS];             // all of this thread's rows in flight at once (memory-level parallelism)
+#pragma unroll
+            for (int r = 0; r < OR_ROWS; ++r) vv[r] = r < nr ? v[net * vstride + (int64_t)(row0 + r) * H + c] : 0.f;
+#pragma unroll
+            for (int r = 0; r < OR_ROWS; ++r) {
 #pragma unroll
                 for (int j4 = 0; j4 < 8; ++j4) {
                     const float4 uu = *reinterpret_cast<const float4*>(&us[r][4 * j4]);
-                    acc[4 * j4] += uu.x * vv; acc[4 * j4 + 1] += uu.y * vv; acc[4 * j4 + 2] += uu.z * vv; acc[4 * j4 + 3] += uu.w * vv;
+                    acc[4 * j4] += uu.x * vv[r]; acc[4 * j4 + 1] += uu.y * vv[r]; acc[4 * j4 + 2] += uu.z * vv[r]; acc[4 * j4 + 3] += uu.w * vv[r];
                 }
             }
 #pragma unroll
@@ -316,12 +344,38 @@ int head_fwd4(const float* a, const float* W, const float* b, float* out, int ro
 // Thread = 4 consecutive columns (float4 streams), 8 rows per workgroup.
 // P layout per (net, chunk): [dW nout*H][db_hidden H][db_out 16]
 constexpr int HB_ROWS = 8;
+// d(loss)/d(head output) for row m, output j of net `net` (see DoutSpec)
+__device__ __forceinline__ float dout_value(const DoutSpec& d, int net, int m, int j, int rows, int nout) {
+    if (d.mode == EXORL_DOUT_BUFFER) return d.buf[((int64_t)net * rows + m) * nout + j];
+    if (d.mode == EXORL_DOUT_TD) {
+        const float y = d.reward[m] + d.discount[m] * fminf(d.tq[m], d.tq[rows + m]);
+        return 2.0f * (d.q[net * rows + m] - y) * d.inv_bg;
+    }
+    if (d.mode == EXORL_DOUT_ACTOR_Q) {
+        const float lambda = d.use_lambda ? d.alpha / (d.stats[0] * d.inv_bg) : 1.0f;
+        const float q1 = d.q[m], q2 = d.q[rows + m];
+        const float w1 = q1 < q2 ? 1.0f : (q1 == q2 ? 0.5f : 0.0f);      // torch.min backward: ties split evenly
+        return -lambda * d.inv_bg * (net == 0 ? w1 : 1.0f - w1);
+    }
+    // EXORL_DOUT_ACTOR_MU: gradient at the actor's pre-tanh output
+    const int i = m * nout + j;
+    const float mv = d.mu[i];
+    float dmu;
+    if (d.kind == EXORL_AGENT_BC) {
+        dmu = -(d.a_data[i] - mv) / (d.stddev * d.stddev) * d.inv_bg;
+    } else {
+        dmu = 0.f;
+        for (int t = 0; t < d.da_nets; ++t) dmu += d.da[((int64_t)t * rows + m) * nout + j];
+        if (d.kind == EXORL_AGENT_TD3_BC) dmu += 2.0f * d.inv_bg / (float)nout * (mv - d.a_data[i]);
+    }
+    return dmu * (1.0f - mv * mv);
+}
+
 template <int NO>
-__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ W,
+__global__ __launch_bounds__(256) void head_bwd_kernel(const DoutSpec dspec, const float* __restrict__ W,
                                                        const float* __restrict__ a, float* __restrict__ dz,
                                                        unsigned short* __restrict__ dzb, float* __restrict__ P, int rows,
-                                                       int H, int nout, int64_t astride, int64_t pstride, int64_t dstride,
-                                                       int want_params) {
+                                                       int H, int nout, int64_t astride, int64_t pstride, int want_params) {
     __shared__ float ds[HB_ROWS * 16];
     const int net = blockIdx.y;
     const int row0 = blockIdx.x * HB_ROWS;
@@ -329,7 +383,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     const int H4 = H >> 2;
     if (threadIdx.x < HB_ROWS * 16) {
         const int r = threadIdx.x >> 4, j = threadIdx.x & 15;
-        ds[threadIdx.x] = (row0 + r < rows && j < nout) ? dout[net * dstride + (int64_t)(row0 + r) * nout + j] : 0.f;
+        ds[threadIdx.x] = (row0 + r < rows && j < nout) ? dout_value(dspec, net, row0 + r, j, rows, nout) : 0.f;
     }
     __syncthreads();
     const int64_t nh = (int64_t)(nout + 1) * H + 16;
@@ -348,9 +402,15 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     }
     float4 pb = make_float4(0.f, 0.f, 0.f, 0.f);
     const int nr = rows - row0 < HB_ROWS ? rows - row0 : HB_ROWS;
-    for (int r = 0; r < nr; ++r) {
+    float4 avs[HB_ROWS];
+#pragma unroll
+    for (int r = 0; r < HB_ROWS; ++r)
+        avs[r] = r < nr ? reinterpret_cast<const float4*>(a + net * astride + (int64_t)(row0 + r) * H)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < HB_ROWS; ++r) {
+        if (r >= nr) break;
         const int64_t o = net * astride + (int64_t)(row0 + r) * H;
-        const float4 av = reinterpret_cast<const float4*>(a + o)[c4];
+        const float4 av = avs[r];
         float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < NO; ++j) {
@@ -377,13 +437,13 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     }
 }
 
-int head_bwd(const float* dout, const float* W, const float* a, float* dz, unsigned short* dz_bf16, float* P, int rows,
-             int H, int nout, int nets, int64_t astride, int64_t pstride, int64_t dstride, int want_params, hipStream_t s) {
+int head_bwd(const DoutSpec& dspec, const float* W, const float* a, float* dz, unsigned short* dz_bf16, float* P, int rows,
+             int H, int nout, int nets, int64_t astride, int64_t pstride, int want_params, hipStream_t s) {
     EXORL_REQUIRE(nout >= 1 && nout <= 16 && H % 4 == 0 && H <= 1024, "head_bwd: nout=%d H=%d unsupported", nout, H);
     dim3 grid(cdiv(rows, HB_ROWS), nets);
-    if (nout == 1) hipLaunchKernelGGL((head_bwd_kernel<1>), grid, dim3(256), 0, s, dout, W, a, dz, dz_bf16, P, rows, H, nout, astride, pstride, dstride, want_params);
-    else if (nout <= 8) hipLaunchKernelGGL((head_bwd_kernel<8>), grid, dim3(256), 0, s, dout, W, a, dz, dz_bf16, P, rows, H, nout, astride, pstride, dstride, want_params);
-    else hipLaunchKernelGGL((head_bwd_kernel<16>), grid, dim3(256), 0, s, dout, W, a, dz, dz_bf16, P, rows, H, nout, astride, pstride, dstride, want_params);
+    if (nout == 1) hipLaunchKernelGGL((head_bwd_kernel<1>), grid, dim3(256), 0, s, dspec, W, a, dz, dz_bf16, P, rows, H, nout, astride, pstride, want_params);
+    else if (nout <= 8) hipLaunchKernelGGL((head_bwd_kernel<8>), grid, dim3(256), 0, s, dspec, W, a, dz, dz_bf16, P, rows, H, nout, astride, pstride, want_params);
+    else hipLaunchKernelGGL((head_bwd_kernel<16>), grid, dim3(256), 0, s, dspec, W, a, dz, dz_bf16, P, rows, H, nout, astride, pstride, want_params);
     EXORL_LAUNCH_CHECK();
     return 0;
 }
@@ -391,16 +451,16 @@ int head_chunks(int rows) { return cdiv(rows, HB_ROWS); }
 
 // ------------------------------------------------------------------------------------------------
 // finalize: sums the per-chunk partials in chunk order and scatters into the flat gradient buffer.
-// sum of n partials spaced `stride` apart, 8 loads in flight
+// sum of n partials spaced `stride` apart, 16 loads in flight
 __device__ __forceinline__ float chunk_sum(const float* __restrict__ p, int n, int64_t stride) {
     float acc = 0.f;
     int ch = 0;
-    for (; ch + 8 <= n; ch += 8) {
-        float t[8];
+    for (; ch + 16 <= n; ch += 16) {
+        float t[16];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) t[q] = p[(int64_t)(ch + q) * stride];
+        for (int q = 0; q < 16; ++q) t[q] = p[(int64_t)(ch + q) * stride];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc += t[q];
+        for (int q = 0; q < 16; ++q) acc += t[q];
     }
     for (; ch < n; ++ch) acc += p[(int64_t)ch * stride];
     return acc;

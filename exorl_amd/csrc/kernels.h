@@ -54,8 +54,25 @@ int outer_reduce(const float* u, int64_t ldu, int J, const float* v, float* P, i
 int outer_chunks(int rows);
 int head_fwd4(const float* a, const float* W, const float* b, float* out, int rows, int H, int nout, int tanh_out,
               int nets, int64_t astride, int64_t pstride, int64_t ostride, hipStream_t s);
-int head_bwd(const float* dout, const float* W, const float* a, float* dz, unsigned short* dz_bf16, float* P, int rows,
-             int H, int nout, int nets, int64_t astride, int64_t pstride, int64_t dstride, int want_params, hipStream_t s);
+// Where head_bwd takes d(loss)/d(head output) from: a buffer, or computed on the fly from the loss definition so that
+// the (B,1)/(B,A)-sized loss kernels need not sit between the forward and the backward pass.
+#define EXORL_DOUT_BUFFER   0
+#define EXORL_DOUT_TD       1   /* 2 (q_net - (r + D min(tq1,tq2))) * inv_bg                    td3_bc.py:127-131 */
+#define EXORL_DOUT_ACTOR_Q  2   /* -lambda * inv_bg * [q_net is the min] (0.5 on ties)            td3_bc.py:152-155 */
+#define EXORL_DOUT_ACTOR_MU 3   /* (sum_t da_t + bc term) * (1 - mu^2)  /  BC: -(a-mu)/std^2*inv_bg td3_bc.py:155, bc.py:83 */
+struct DoutSpec {
+    int mode;
+    const float* buf;        // BUFFER: (nets, rows, nout)
+    const float *q, *tq, *reward, *discount;   // TD / ACTOR_Q: q, tq are (2, rows)
+    const float* stats;      // ACTOR_Q: stats[0] = sum |Q| over the global batch
+    const float *da, *mu, *a_data;             // ACTOR_MU: da (da_nets, rows, nout), mu / a_data (rows, nout)
+    int da_nets;
+    int kind;                // EXORL_AGENT_*
+    int use_lambda;
+    float inv_bg, alpha, stddev;
+};
+int head_bwd(const DoutSpec& dspec, const float* W, const float* a, float* dz, unsigned short* dz_bf16, float* P, int rows,
+             int H, int nout, int nets, int64_t astride, int64_t pstride, int want_params, hipStream_t s);
 int head_chunks(int rows);
 struct FinalizeArgs {
     const float* Ph; int head_chunks; int n_heads; int64_t head_stride;    // head partials; stride between heads in G
@@ -98,13 +115,53 @@ struct StepState {
     uint64_t replay_counter;     // Philox batch counter of the sampler bound to the graph
     uint64_t noise_counter;      // Philox draw counter for action noise (2 draws per step)
     long long t_actor, t_critic; // Adam step counts
+    double b1t, b2t_actor_unused, b1t_c, b2t_c;   // running beta^t products: [actor b1^t, (pad), critic b1^t, critic b2^t]
+    double b2t;                  // actor b2^t
     AdamConst actor, critic;
     float lr, b1, b2, eps, tau;
     int has_critic;
 };
 int step_begin(StepState* st, int advance_replay, hipStream_t s);
+
+__device__ inline void fill_adam_const(AdamConst& c, double b1t, double b2t, float lr, float b1, float b2, float eps, float tau) {
+    // double-precision scalar math, as torch's _single_tensor_adam does in Python floats; beta^t comes from a running
+    // product kept in the step state (one multiply per step instead of two software pow() calls on the critical path)
+    const double bc1 = 1.0 - b1t;
+    const double bc2 = 1.0 - b2t;
+    c.one_minus_b1 = (float)(1.0 - (double)b1);
+    c.b2 = b2;
+    c.one_minus_b2 = (float)(1.0 - (double)b2);
+    c.bc2_sqrt = (float)sqrt(bc2);
+    c.eps = eps;
+    c.neg_step_size = (float)(-((double)lr / bc1));
+    c.tau = tau;
+    c.one_minus_tau = (float)(1.0 - (double)tau);
+}
+
+// One thread: advance the counters and pre-compute both optimisers' scalars for this step.
+__device__ inline void step_begin_device(StepState* st, int advance_replay) {
+    if (advance_replay) st->replay_counter += 1;
+    st->noise_counter += 2;
+    st->t_actor += 1;
+    st->b1t *= (double)st->b1;
+    st->b2t *= (double)st->b2;
+    fill_adam_const(st->actor, st->b1t, st->b2t, st->lr, st->b1, st->b2, st->eps, 0.f);
+    if (st->has_critic) {
+        st->t_critic += 1;
+        st->b1t_c *= (double)st->b1;
+        st->b2t_c *= (double)st->b2;
+        fill_adam_const(st->critic, st->b1t_c, st->b2t_c, st->lr, st->b1, st->b2, st->eps, st->tau);
+    }
+}
+
+
 int prepare_inputs(const float* obs, const float* action, const float* next_obs, float* xa, float* xc_cur,
-                   float* xc_next, float* xc_pi, int B, int O, int A, int has_critic, hipStream_t s);
+                   float* xc_next, float* xc_pi, int B, int O, int A, int has_critic, StepState* st, int advance_replay,
+                   hipStream_t s);
+// both TruncatedNormal draws of a DDPG-family step in one launch: rows 0..B-1 of mu2 -> next_action (draw 0),
+// rows B..2B-1 -> pi(obs) sample (draw 1)
+int sample_actions2(const float* mu2, const float* noise_c, const float* noise_a, uint64_t seed, const uint64_t* counter_ptr,
+                    float stddev, float clip, float* dst_next, float* dst_pi, int64_t dst_ld, int B, int A, hipStream_t s);
 int sample_action(const float* mu, NoiseSpec noise, float stddev, float clip, int use_clip, float* dst, int64_t dst_ld,
                   int B, int A, float* logprob_sum, hipStream_t s);
 int critic_loss(const float* q, const float* tq, const float* reward, const float* discount, float* dq,

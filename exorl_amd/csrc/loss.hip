@@ -34,7 +34,9 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float (*sm)[16]) {
 __global__ void prepare_inputs_kernel(const float* __restrict__ obs, const float* __restrict__ action,
                                       const float* __restrict__ next_obs, float* __restrict__ xa,
                                       float* __restrict__ xc_cur, float* __restrict__ xc_next,
-                                      float* __restrict__ xc_pi, int B, int O, int A, int has_critic) {
+                                      float* __restrict__ xc_pi, int B, int O, int A, int has_critic, StepState* st,
+                                      int advance_replay) {
+    if (st && blockIdx.x == 0 && threadIdx.x == 0) step_begin_device(st, advance_replay);   // counters += ; Adam scalars
     const int W = O + A;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * W; i += gridDim.x * blockDim.x) {
         const int m = i / W, c = i % W;
@@ -54,10 +56,11 @@ __global__ void prepare_inputs_kernel(const float* __restrict__ obs, const float
 }
 
 int prepare_inputs(const float* obs, const float* action, const float* next_obs, float* xa, float* xc_cur,
-                   float* xc_next, float* xc_pi, int B, int O, int A, int has_critic, hipStream_t s) {
+                   float* xc_next, float* xc_pi, int B, int O, int A, int has_critic, StepState* st, int advance_replay,
+                   hipStream_t s) {
     const int n = B * (O + A);
     hipLaunchKernelGGL(prepare_inputs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, obs, action, next_obs, xa, xc_cur,
-                       xc_next, xc_pi, B, O, A, has_critic);
+                       xc_next, xc_pi, B, O, A, has_critic, st, advance_replay);
     EXORL_LAUNCH_CHECK();
     return 0;
 }
@@ -95,6 +98,30 @@ __global__ __launch_bounds__(1024) void sample_action_kernel(const float* __rest
         block_sum<1>(lp, sm);
         if (threadIdx.x == 0) *logprob_out = lp[0] * logprob_scale;
     }
+}
+
+__global__ __launch_bounds__(256) void sample_actions2_kernel(const float* __restrict__ mu2, const float* __restrict__ noise_c,
+                                                              const float* __restrict__ noise_a, uint64_t seed,
+                                                              const uint64_t* __restrict__ counter_ptr, float stddev, float clip,
+                                                              float* __restrict__ dst_next, float* __restrict__ dst_pi,
+                                                              int64_t dst_ld, int B, int A) {
+    const int n = B * A;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n; i += gridDim.x * blockDim.x) {
+        const int half = i >= n, e = half ? i - n : i;
+        const float* nb = half ? noise_a : noise_c;
+        const float z = nb ? nb[e] : philox_normal(seed, (uint64_t)half + (counter_ptr ? *counter_ptr : 0ull), (uint32_t)e);
+        const float eps = fminf(fmaxf(z * stddev, -clip), clip);
+        const float x = fminf(fmaxf(mu2[i] + eps, -1.0f + 1e-6f), 1.0f - 1e-6f);
+        (half ? dst_pi : dst_next)[(int64_t)(e / A) * dst_ld + e % A] = x;
+    }
+}
+
+int sample_actions2(const float* mu2, const float* noise_c, const float* noise_a, uint64_t seed, const uint64_t* counter_ptr,
+                    float stddev, float clip, float* dst_next, float* dst_pi, int64_t dst_ld, int B, int A, hipStream_t s) {
+    hipLaunchKernelGGL(sample_actions2_kernel, dim3(cdiv(2 * B * A, 256)), dim3(256), 0, s, mu2, noise_c, noise_a, seed, counter_ptr,
+                       stddev, clip, dst_next, dst_pi, dst_ld, B, A);
+    EXORL_LAUNCH_CHECK();
+    return 0;
 }
 
 int sample_action(const float* mu, NoiseSpec noise, float stddev, float clip, int use_clip, float* dst, int64_t dst_ld,

@@ -140,31 +140,8 @@ int adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const
     return 0;
 }
 
-__device__ void fill_adam_const(AdamConst& c, long long t, float lr, float b1, float b2, float eps, float tau) {
-    // double-precision scalar math, as torch's _single_tensor_adam does in Python floats
-    const double bc1 = 1.0 - pow((double)b1, (double)t);
-    const double bc2 = 1.0 - pow((double)b2, (double)t);
-    c.one_minus_b1 = (float)(1.0 - (double)b1);
-    c.b2 = b2;
-    c.one_minus_b2 = (float)(1.0 - (double)b2);
-    c.bc2_sqrt = (float)sqrt(bc2);
-    c.eps = eps;
-    c.neg_step_size = (float)(-((double)lr / bc1));
-    c.tau = tau;
-    c.one_minus_tau = (float)(1.0 - (double)tau);
-}
-
-// One thread: advance the counters and pre-compute both optimisers' scalars for this step.
 __global__ void step_begin_kernel(StepState* st, int advance_replay) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (advance_replay) st->replay_counter += 1;
-    st->noise_counter += 2;
-    st->t_actor += 1;
-    fill_adam_const(st->actor, st->t_actor, st->lr, st->b1, st->b2, st->eps, 0.f);
-    if (st->has_critic) {
-        st->t_critic += 1;
-        fill_adam_const(st->critic, st->t_critic, st->lr, st->b1, st->b2, st->eps, st->tau);
-    }
+    if (threadIdx.x == 0 && blockIdx.x == 0) step_begin_device(st, advance_replay);
 }
 
 int step_begin(StepState* st, int advance_replay, hipStream_t s) {

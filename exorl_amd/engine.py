@@ -140,6 +140,9 @@ class AgentEngine:
     def step_graph(self):
         L.check(self.lib.exorl_agent_step_graph(self.h, L.current_stream()))
 
+    def set_metrics(self, enable):
+        L.check(self.lib.exorl_agent_set_metrics(self.h, int(bool(enable))))
+
     def metrics_raw(self):
         host = np.zeros(L.N_METRICS, np.float32)
         L.check(self.lib.exorl_agent_metrics(self.h, host.ctypes.data, L.current_stream()))

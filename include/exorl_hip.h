@@ -182,6 +182,9 @@ int exorl_agent_act(exorl_agent_t* a, const float* obs_dev, int32_t n, float std
                     const float* noise_dev, float* action_out_dev, void* stream);
 /* Synchronous: copies the metric block of the last update to host. */
 int exorl_agent_metrics(exorl_agent_t* a, float* metrics_host, void* stream);
+/* The reference computes its metrics dict only under use_tb (td3_bc.py:133,162,175); enable = 0 skips the metric
+ * reductions of the step (default: enabled). */
+int exorl_agent_set_metrics(exorl_agent_t* a, int32_t enable);
 int exorl_agent_opt_steps(exorl_agent_t* a, int64_t* actor_steps, int64_t* critic_steps);
 int exorl_agent_set_opt_steps(exorl_agent_t* a, int64_t actor_steps, int64_t critic_steps);
 /* Captures exorl_replay_sample(PHILOX) into the agent's batch slots + exorl_agent_update into one hipGraph;
