@@ -69,8 +69,23 @@ __global__ __launch_bounds__(512) void trunk_fwd_kernel(const float* __restrict_
     for (int k0 = 0; k0 < in_dim; k0 += TF_KC) {
         const int kc = in_dim - k0 < TF_KC ? in_dim - k0 : TF_KC;
         __syncthreads();
-        for (int i = tid; i < kc * H4; i += 512)
-            reinterpret_cast<float4*>(ws)[i] = reinterpret_cast<const float4*>(Wt + (int64_t)k0 * H)[i];
+        {   // stage the W0T chunk: 8 independent 16-byte loads in flight per thread, then the LDS writes
+            const float4* gsrc = reinterpret_cast<const float4*>(Wt + (int64_t)k0 * H);
+            const int n4 = kc * H4;
+            for (int i0 = tid; i0 < n4; i0 += 8 * 512) {
+                float4 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + u * 512;
+                    t[u] = i < n4 ? gsrc[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + u * 512;
+                    if (i < n4) reinterpret_cast<float4*>(ws)[i] = t[u];
+                }
+            }
+        }
         __syncthreads();
         for (int k = 0; k < kc; ++k) {
             const float xv = xs[wave * MAX_IN + k0 + k];
@@ -264,15 +279,19 @@ __global__ __launch_bounds__(256) void outer_reduce_kernel(const float* __restri
             float acc[32];
 #pragma unroll
             for (int j = 0; j < 32; ++j) acc[j] = 0.f;
-            float vv[OR_ROWS];             // all of this thread's rows in flight at once (memory-level parallelism)
+#pragma unroll 1
+            for (int rb = 0; rb < OR_ROWS; rb += 8) {
+                float vv[8];               // 8 rows in flight at once (memory-level parallelism)
 #pragma unroll
-            for (int r = 0; r < OR_ROWS; ++r) vv[r] = r < nr ? v[net * vstride + (int64_t)(row0 + r) * H + c] : 0.f;
+                for (int r = 0; r < 8; ++r) vv[r] = rb + r < nr ? v[net * vstride + (int64_t)(row0 + rb + r) * H + c] : 0.f;
 #pragma unroll
-            for (int r = 0; r < OR_ROWS; ++r) {
+                for (int r = 0; r < 8; ++r) {
 #pragma unroll
-                for (int j4 = 0; j4 < 8; ++j4) {
-                    const float4 uu = *reinterpret_cast<const float4*>(&us[r][4 * j4]);
-                    acc[4 * j4] += uu.x * vv[r]; acc[4 * j4 + 1] += uu.y * vv[r]; acc[4 * j4 + 2] += uu.z * vv[r]; acc[4 * j4 + 3] += uu.w * vv[r];
+                    for (int j4 = 0; j4 < 8; ++j4) {
+                        const float4 uu = *reinterpret_cast<const float4*>(&us[rb + r][4 * j4]);
+                        acc[4 * j4] += uu.x * vv[r]; acc[4 * j4 + 1] += uu.y * vv[r]; acc[4 * j4 + 2] += uu.z * vv[r]; acc[4 * j4 + 3] += uu.w * vv[r];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);     // keep one row's 8 LDS reads live at a time (VGPR budget)
                 }
             }
 #pragma unroll
