@@ -185,12 +185,15 @@ def main():
         fl, ms, n = np.zeros(cap, np.float64), np.zeros(cap, np.float32), L.C.c_int32()
         L.check(lib.exorl_profile_gemm_read(fl.ctypes.data, ms.ctypes.data, cap, L.C.byref(n)))
         L.check(lib.exorl_profile_gemm(0))
-        fl, ms = fl[:n.value], ms[:n.value]
+        ovh = L.C.c_float()
+        L.check(lib.exorl_profile_event_overhead(L.C.byref(ovh), L.current_stream()))
+        fl, ms = fl[:n.value], np.maximum(ms[:n.value] - ovh.value, 1e-4)       # minus the empty event-bracket time
         big = fl >= 2.0 * 2 * B * H * H * 0.99           # the two-problem 1024^3 launches (fwd / dgrad / wgrad of Linear(H,H))
         ach = float(fl[big].mean() / (ms[big].mean() * 1e-3) / 1e12)
         peak = PEAK_TFLOPS[args.precision]
         out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
-                           'kernel': 'gemm_kernel (grouped 2x[1024x1024x1024])', 'launches': int(big.sum()),
+                           'kernel': ('gemm16g_kernel' if args.precision == 'bf16' else 'gemm_kernel') + ' (grouped 2x[1024x1024x1024], fwd/dgrad/wgrad of Linear(H,H))',
+                           'launches': int(big.sum()), 'event_overhead_us': float(ovh.value * 1e3),
                            'avg_us': float(ms[big].mean() * 1e3), 'flop_per_launch': float(fl[big].mean()),
                            'all_gemm_us_per_step': float(ms.sum() * 1e3 / nprof), 'gemm_launches_per_step': n.value / nprof}
     if world == 1 and not args.no_cpu_baseline:

@@ -81,6 +81,7 @@ PROTOTYPES = {
     'exorl_gemm_tune': (C.c_int, [c_int32]),
     'exorl_profile_gemm': (C.c_int, [c_int32]),
     'exorl_profile_gemm_read': (C.c_int, [c_void_p, c_void_p, c_int32, P(c_int32)]),
+    'exorl_profile_event_overhead': (C.c_int, [c_void_p, c_void_p]),
     'exorl_adam_step': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                   c_int64, c_void_p, c_float, c_void_p]),
     'exorl_soft_update': (C.c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),

@@ -14,6 +14,7 @@
 //    and written to the other LDS buffer after them — one barrier per k-tile.
 //  * operands whose reduction index is the slow dimension (dgrad B, wgrad A and B) are transposed in
 //    registers on the way to LDS (two rows x KU k's per thread), so all three GEMM forms share one inner loop.
+#include <algorithm>
 #include <type_traits>
 #include <vector>
 
@@ -705,6 +706,28 @@ extern "C" int exorl_profile_gemm_read(double* flops_out, float* ms_out, int32_t
         ms_out[n] = ms;
     }
     *n_out = n;
+    return 0;
+}
+
+// Median duration of an EMPTY start/stop event bracket on `stream`: the fixed cost hipEvent timing adds to every
+// bracketed launch (subtracted by bench.py so its per-launch figure is comparable with rocprofv3's kernel durations).
+extern "C" int exorl_profile_event_overhead(float* ms_out, void* stream) {
+    using namespace exorl;
+    EXORL_REQUIRE(ms_out, "profile_event_overhead: null argument");
+    hipStream_t s = as_stream(stream);
+    const int n = 31;
+    hipEvent_t ev[2 * n];
+    for (int i = 0; i < 2 * n; ++i) EXORL_CHECK_HIP(hipEventCreate(&ev[i]));
+    for (int i = 0; i < n; ++i) {
+        EXORL_CHECK_HIP(hipEventRecord(ev[2 * i], s));
+        EXORL_CHECK_HIP(hipEventRecord(ev[2 * i + 1], s));
+    }
+    EXORL_CHECK_HIP(hipStreamSynchronize(s));
+    std::vector<float> t(n);
+    for (int i = 0; i < n; ++i) EXORL_CHECK_HIP(hipEventElapsedTime(&t[i], ev[2 * i], ev[2 * i + 1]));
+    for (int i = 0; i < 2 * n; ++i) (void)hipEventDestroy(ev[i]);
+    std::sort(t.begin(), t.end());
+    *ms_out = t[n / 2];
     return 0;
 }
 

@@ -212,6 +212,7 @@ int exorl_gemm_tune(int32_t variant);
 /* Measurement hook (bench.py roofline leg): time every GEMM launch with HIP events on its own stream. */
 int exorl_profile_gemm(int32_t enable);
 int exorl_profile_gemm_read(double* flops_out_host, float* ms_out_host, int32_t cap, int32_t* n_out);
+int exorl_profile_event_overhead(float* ms_out_host, void* stream);
 int exorl_adam_step(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, float lr,
                     float beta1, float beta2, float eps, int64_t t, float* target_dev, float tau, void* stream);
 int exorl_soft_update(const float* p_dev, float* target_dev, int64_t n, float tau, void* stream);

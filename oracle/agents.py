@@ -46,7 +46,12 @@ class OracleAgent:
     """kind in {'td3_bc','td3','bc','ddpg'}; params are lists of float32 arrays (reference order)."""
 
     def __init__(self, kind, actor_params, critic_params=None, lr=1e-4, tau=0.01, stddev_schedule='0.2',
-                 stddev_clip=0.3, alpha=2.5, update_every_steps=2):
+                 stddev_clip=0.3, alpha=2.5, update_every_steps=2, world_size=1, allreduce=None):
+        """world_size > 1: this instance is one data-parallel rank holding a shard of the global batch; `allreduce`
+        (list of float32 arrays -> summed in place across ranks) is called at the three points where the reference's
+        single-process update needs a batch-global quantity: critic grads, sum|Q| (td3_bc.py:154),
+        actor grads. Means are over batch*world_size, so the ranks end up with the large-batch update."""
+        self.world_size, self.allreduce = world_size, allreduce
         self.kind = kind
         self.actor = [np.array(p, F32) for p in actor_params]
         self.actor_opt = Adam(self.actor, lr)
@@ -65,14 +70,16 @@ class OracleAgent:
         tq1, tq2, _ = self.C.fwd(self.critic_target, next_obs, next_action)
         target_q = (reward + (discount * np.minimum(tq1, tq2)).astype(F32)).astype(F32)
         q1, q2, caches = self.C.fwd(self.critic, obs, action)
-        B = F32(obs.shape[0])
+        B = F32(obs.shape[0] * self.world_size)
         e1, e2 = (q1 - target_q).astype(F32), (q2 - target_q).astype(F32)
-        loss = (e1 * e1).mean(dtype=F32) + (e2 * e2).mean(dtype=F32)
         grads, _ = self.C.bwd(self.critic, caches, (F32(2) * e1 / B).astype(F32), (F32(2) * e2 / B).astype(F32),
                               need_dx=False)
+        m = np.array([target_q.sum(dtype=F32), q1.sum(dtype=F32), q2.sum(dtype=F32),
+                      (e1 * e1).sum(dtype=F32) + (e2 * e2).sum(dtype=F32)], F32) / B
+        if self.world_size > 1:
+            self.allreduce(grads + [m])
         self.critic_opt.step(self.critic, grads)
-        return dict(critic_target_q=float(target_q.mean(dtype=F32)), critic_q1=float(q1.mean(dtype=F32)),
-                    critic_q2=float(q2.mean(dtype=F32)), critic_loss=float(loss)), grads
+        return dict(critic_target_q=float(m[0]), critic_q1=float(m[1]), critic_q2=float(m[2]), critic_loss=float(m[3])), grads
 
     # td3_bc.py:145-166 / td3.py:143-163 / ddpg.py:270-292
     def update_actor(self, obs, action, std, noise):
@@ -80,37 +87,47 @@ class OracleAgent:
         a = nets.truncated_normal_sample(mu, noise, std, self.clip)
         q1, q2, caches = self.C.fwd(self.critic, obs, a)
         q = np.minimum(q1, q2)
-        B, A = obs.shape[0], mu.shape[1]
+        B, A = obs.shape[0] * self.world_size, mu.shape[1]
         m = {}
+        stats = np.array([np.abs(q).sum(dtype=F32), q.sum(dtype=F32), ((mu - action) ** 2).sum(dtype=F32)], F32)
+        if self.world_size > 1:
+            self.allreduce([stats])
         if self.kind == 'td3_bc':
-            lmbda = F32(self.alpha) / np.abs(q).mean(dtype=F32)
-            bc = ((mu - action) ** 2).mean(dtype=F32)
-            loss = -lmbda * q.mean(dtype=F32) + bc
+            lmbda = F32(self.alpha) / (stats[0] / F32(B))
+            loss = -lmbda * stats[1] / F32(B) + stats[2] / F32(B * A)
             dq = np.full_like(q, -lmbda / F32(B))
             dmu_extra = (F32(2) * (mu - action) / F32(B * A)).astype(F32)
         else:
-            loss = -q.mean(dtype=F32)
+            loss = -stats[1] / F32(B)
             dq = np.full_like(q, F32(-1.0) / F32(B))
             dmu_extra = 0
         w1, w2 = _min_grad(q1, q2)
         _, dx = self.C.bwd(self.critic, caches, (dq * w1).astype(F32), (dq * w2).astype(F32), need_dx=True)
         dmu = (dx[:, obs.shape[1]:] + dmu_extra).astype(F32)      # straight-through sample, utils.py:135-138
         grads = ActorNet.bwd(self.actor, cache, dmu)
+        if self.world_size > 1:
+            self.allreduce(grads)
         self.actor_opt.step(self.actor, grads)
         m['actor_loss'] = float(loss)
         m['actor_ent'] = float(nets.normal_entropy(std) * A)
         if self.kind == 'ddpg':
-            m['actor_logprob'] = float(nets.normal_log_prob(a, mu, std).sum(-1).mean(dtype=F32))
+            lp = np.array([nets.normal_log_prob(a, mu, std).sum(dtype=F32) / F32(B)], F32)
+            if self.world_size > 1:
+                self.allreduce([lp])
+            m['actor_logprob'] = float(lp[0])
         return m, grads
 
     # bc.py:78-95
     def update_bc(self, obs, action, std):
         mu, cache = ActorNet.fwd(self.actor, obs)
-        B, A = mu.shape
+        B, A = mu.shape[0] * self.world_size, mu.shape[1]
         logp = nets.normal_log_prob(action, mu, std).sum(-1, keepdims=True)
-        loss = (-logp).mean(dtype=F32)
+        loss = np.array([(-logp).sum(dtype=F32) / F32(B)], F32)
         dmu = (-(action - mu) / (F32(std) * F32(std)) / F32(B)).astype(F32)
         grads = ActorNet.bwd(self.actor, cache, dmu)
+        if self.world_size > 1:
+            self.allreduce(grads + [loss])
+        loss = loss[0]
         self.actor_opt.step(self.actor, grads)
         return dict(actor_loss=float(loss), actor_ent=float(nets.normal_entropy(std) * A)), grads
 
@@ -120,7 +137,10 @@ class OracleAgent:
             return {}
         obs, action, reward, discount, next_obs = [np.asarray(x, F32) for x in batch[:5]]
         std = nets.schedule(self.sched, step)
-        m = dict(batch_reward=float(reward.mean(dtype=F32)))
+        br = np.array([reward.sum(dtype=F32) / F32(reward.shape[0] * self.world_size)], F32)
+        if self.world_size > 1:
+            self.allreduce([br])
+        m = dict(batch_reward=float(br[0]))
         if self.kind == 'bc':
             mm, self.last_actor_grads = self.update_bc(obs, action, std)
             m.update(mm)

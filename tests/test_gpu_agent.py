@@ -216,3 +216,63 @@ def test_hip_graph_step_equals_eager(kind):
     a1.disable_graph()
     m1, m2 = a1.update(it1, 8), a2.update(it2, 8)           # back to eager: streams continue in lock-step
     assert m1 == m2
+
+
+@pytest.mark.parametrize('kind', ['td3_bc', 'ddpg', 'bc'])
+def test_virtual_ranks_equal_single_rank(kind):
+    """The HIP engine's phase split (exorl_agent_update_phase) under data parallelism: two engines configured with
+    world_size=2 each take half of a global batch; summing their gradient / statistic buffers between phases (what
+    RCCL all-reduce does across GPUs) must reproduce the single-engine update on the whole batch."""
+    from exorl_amd.engine import AgentEngine
+    from exorl_amd import _lib as L
+    O, A, H, B = 24, 6, 128, 64
+    ash, csh = param_shapes(kind, O, A, H)
+    pa = list(_synth.synth_params(ash, 1).values())
+    pc = list(_synth.synth_params(csh, 2).values()) if csh else None
+
+    def engine(batch, world):
+        e = AgentEngine(kind, O, A, H, batch, world_size=world)
+        for i, w in enumerate(pa):
+            e.tensor(L.NET_ACTOR, i).copy_(torch.from_numpy(w).reshape(e.tensor(L.NET_ACTOR, i).shape))
+        if pc:
+            for i, w in enumerate(pc):
+                e.tensor(L.NET_CRITIC, i).copy_(torch.from_numpy(w).reshape(e.tensor(L.NET_CRITIC, i).shape))
+        e.params_changed(sync_target=True)
+        return e
+    single, ranks = engine(B, 1), [engine(B // 2, 2), engine(B // 2, 2)]
+
+    def allreduce(bufs):
+        tot = bufs[0] + bufs[1]
+        for b in bufs:
+            b.copy_(tot)
+    ns = _synth.NoiseStream(4)
+    for step in range(3):
+        batch = _synth.synth_batch(6, step, B, O, A)
+        n1, n2 = ns.draw((B, A)), ns.draw((B, A))
+        single.set_batch(*batch)
+        single.update(0.2, n1, n2)
+        for r, e in enumerate(ranks):
+            sl = slice(r * B // 2, (r + 1) * B // 2)
+            e.set_batch(*[x[sl] for x in batch])
+        sh = [(n1[:B // 2], n2[:B // 2]), (n1[B // 2:], n2[B // 2:])]
+        for e, (a, b) in zip(ranks, sh):
+            e.update_phase(0, 0.2, a, b)
+        if pc:
+            allreduce([e.flat(L.NET_CRITIC, L.T_GRAD) for e in ranks])
+        for e, (a, b) in zip(ranks, sh):
+            e.update_phase(1, 0.2, a, b)
+        allreduce([e.stats() for e in ranks])
+        for e, (a, b) in zip(ranks, sh):
+            e.update_phase(2, 0.2, a, b)
+        allreduce([e.flat(L.NET_ACTOR, L.T_GRAD) for e in ranks])
+        for e, (a, b) in zip(ranks, sh):
+            e.update_phase(3, 0.2, a, b)
+        msum = ranks[0].metrics_raw() + ranks[1].metrics_raw()          # partial means add up to the global means
+        ms = single.metrics_raw()
+        for k in (L.M_BATCH_REWARD, L.M_CRITIC_LOSS, L.M_ACTOR_LOSS, L.M_CRITIC_Q1) if pc else (L.M_BATCH_REWARD, L.M_ACTOR_LOSS):
+            assert abs(msum[k] - ms[k]) <= 2e-5 * abs(ms[k]) + 1e-6, (kind, step, k, msum[k], ms[k])
+    nets = [L.NET_ACTOR] + ([L.NET_CRITIC, L.NET_CRITIC_TARGET] if pc else [])
+    for net in nets:
+        p0, p1, ps = ranks[0].flat(net), ranks[1].flat(net), single.flat(net)
+        assert torch.equal(p0, p1)                                       # replicas stay bit-identical
+        np.testing.assert_allclose(p0.cpu().numpy(), ps.cpu().numpy(), rtol=2e-5, atol=2e-7)
