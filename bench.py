@@ -108,6 +108,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--graph', type=int, default=int(os.environ.get('EXORL_GRAPH', '1')))
+    ap.add_argument('--branches', type=int, default=int(os.environ.get('EXORL_BRANCHES', '1')))
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -137,6 +138,7 @@ def main():
         agent.params_changed()
     replay = synth_replay(rank, world, device)
     it = ArenaIterator(replay, B, 1, GAMMA, 'philox')
+    agent.engine.set_parallel_branches(args.branches)
     use_graph = bool(args.graph) and world == 1 and agent.enable_graph(it)
 
     def run(n, step0):
@@ -170,7 +172,7 @@ def main():
             'vs_baseline': None, 'dtype': 'bf16' if args.precision == 'bf16' else 'f32', 'data': 'synthetic',
             'config': {'workload': 'TD3+BC walker_walk (O=24,A=6,H=1024), 1M-transition replay in HBM, batch 1024/GPU, '
                                    'nstep=1, Philox sampler, use_tb=False', 'global_batch': B * world,
-                       'parallelism': f'dp{world}', 'hip_graph': use_graph,
+                       'parallelism': f'dp{world}', 'hip_graph': use_graph, 'graph_parallel_branches': bool(args.branches) and use_graph,
                        'mfma_operands': 'bf16 (fp32 accumulate, fp32 master weights)' if args.precision == 'bf16' else 'fp32'},
             'algorithmic_gflop_per_step': flops / 1e9,
             'step_frac_of_mfma_peak': (world * args.steps / dt) * flops / 1e12 / (PEAK_TFLOPS[args.precision] * world),

@@ -69,6 +69,7 @@ PROTOTYPES = {
     'exorl_agent_act': (C.c_int, [c_void_p, c_void_p, c_int32, c_float, c_int32, c_void_p, c_void_p, c_void_p]),
     'exorl_agent_metrics': (C.c_int, [c_void_p, c_void_p, c_void_p]),
     'exorl_agent_set_metrics': (C.c_int, [c_void_p, c_int32]),
+    'exorl_agent_set_parallel_branches': (C.c_int, [c_void_p, c_int32]),
     'exorl_agent_opt_steps': (C.c_int, [c_void_p, P(c_int64), P(c_int64)]),
     'exorl_agent_set_opt_steps': (C.c_int, [c_void_p, c_int64, c_int64]),
     'exorl_agent_enable_graph': (C.c_int, [c_void_p, c_void_p, c_int32, c_float, c_float]),

@@ -69,6 +69,28 @@ static NetDesc make_net(int in_dim, int out_dim, int H, int n_trunks, int n_head
     return d;
 }
 
+// Second stream for independent branches of the step (target forward || critic forward, wgrad || dgrad chain).
+// Used while capturing: the hipGraph then has parallel branches, so kernels that fill only part of the 256 CUs
+// (64x64-tile GEMMs, row kernels) overlap instead of queueing behind each other.
+struct Fork {
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool on = false;
+    int fork(hipStream_t s) const {            // aux continues after everything enqueued on s so far
+        if (!on) return 0;
+        EXORL_CHECK_HIP(hipEventRecord(ev_fork, s));
+        EXORL_CHECK_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
+        return 0;
+    }
+    int join(hipStream_t s) const {            // s waits for everything enqueued on aux
+        if (!on) return 0;
+        EXORL_CHECK_HIP(hipEventRecord(ev_join, aux));
+        EXORL_CHECK_HIP(hipStreamWaitEvent(s, ev_join, 0));
+        return 0;
+    }
+    hipStream_t side(hipStream_t s) const { return on ? aux : s; }
+};
+
 struct FwdBufs { float *h1, *xhat, *rstd, *h2, *out; unsigned short* h1b; };
 struct BwdBufs { float *dz2, *dh1; unsigned short* dz2b; };
 struct NetShadow { float* w0t; unsigned short* w1b; };     // W0 transposed per trunk; W1 as bf16 per head
@@ -118,7 +140,7 @@ static int net_forward(const NetDesc& d, const float* P, const NetShadow& sh, co
 // consumer adds them) receives d/dx[:, col0:col0+dx_cols].
 static int net_backward(const NetDesc& d, const float* P, const NetShadow& sh, float* G, const Partials& pt, const float* x,
                         int64_t ldx, int rows, const FwdBufs& f, const DoutSpec& dout, const BwdBufs& b, float* dx, int dx_col0,
-                        int dx_cols, int prec, hipStream_t s) {
+                        int dx_cols, int prec, hipStream_t s, const Fork& fk) {
     const int H = d.H;
     const int64_t act = (int64_t)rows * H;
     const bool paired = d.n_trunks == d.n_heads;
@@ -131,7 +153,8 @@ static int net_backward(const NetDesc& d, const float* P, const NetShadow& sh, f
             for (int i = 0; i < d.n_heads; ++i)      // dW1_i[n][k] = sum_m dz2_i[m][n] h1[m][k]
                 q[i] = Gemm16Problem{b.dz2b + i * act, f.h1b + (paired ? i : 0) * act, G + d.W1 + i * d.head_stride, nullptr,
                                      H, H, rows, H, H, H};
-            EXORL_TRY(gemm16_grouped(1, 1, q, d.n_heads, false, false, s));
+            EXORL_TRY(fk.fork(s));                 // wgrad only feeds the optimiser: off the dgrad -> LN-backward chain
+            EXORL_TRY(gemm16_grouped(1, 1, q, d.n_heads, false, false, fk.side(s)));
         }
         for (int i = 0; i < d.n_heads; ++i)          // dh1[m][k] = sum_n dz2_i[m][n] W1_i[n][k]
             q[i] = Gemm16Problem{b.dz2b + i * act, sh.w1b + (int64_t)i * H * H, b.dh1 + (paired ? i : 0) * act, nullptr,
@@ -147,7 +170,8 @@ static int net_backward(const NetDesc& d, const float* P, const NetShadow& sh, f
             for (int i = 0; i < d.n_heads; ++i)
                 p[i] = GemmProblem{b.dz2 + i * act, f.h1 + (paired ? i : 0) * act, G + d.W1 + i * d.head_stride, nullptr,
                                    H, H, rows, H, H, H};
-            EXORL_TRY(gemm_grouped(prec, 1, 1, p, d.n_heads, false, false, s));
+            EXORL_TRY(fk.fork(s));
+            EXORL_TRY(gemm_grouped(prec, 1, 1, p, d.n_heads, false, false, fk.side(s)));
         }
         for (int i = 0; i < d.n_heads; ++i)
             p[i] = GemmProblem{b.dz2 + i * act, P + d.W1 + i * d.head_stride, b.dh1 + (paired ? i : 0) * act, nullptr,
@@ -164,6 +188,7 @@ static int net_backward(const NetDesc& d, const float* P, const NetShadow& sh, f
                             (int64_t)d.in_dim * H, (int64_t)rows * dx_cols, s));
     if (G) {
         EXORL_TRY(outer_reduce(x, ldx, d.in_dim, b.dh1, pt.Pw, rows, H, d.n_trunks, act, s));
+        EXORL_TRY(fk.join(s));                     // wgrad branch done before the gradients are finalised
         FinalizeArgs fa{};
         fa.Ph = pt.Ph; fa.head_chunks = head_chunks(rows); fa.n_heads = d.n_heads; fa.head_stride = d.head_stride;
         fa.gW2 = d.W2; fa.gb1 = d.b1; fa.gb2 = d.b2;
@@ -226,6 +251,8 @@ struct exorl_agent {
     hipStream_t capture_stream = nullptr;
     exorl_replay* graph_replay = nullptr;
     bool capturing = false;
+    Fork fk{};                   // parallel-branch plumbing (active while capturing)
+    bool parallel_branches = true;
     bool want_metrics = true;    // the (B,1)-sized metric reductions are skipped when the caller never reads them (use_tb=False)
 };
 
@@ -331,14 +358,16 @@ static int phase0(exorl_agent* a, float stddev, const float* noise_c, hipStream_
     a->noise_c = noise_c;
     EXORL_TRY(sample_actions2(a->fa.out, noise_c, a->noise_a, cfg.seed, &a->state->noise_counter, stddev, cfg.stddev_clip,
                               a->xc_next + O, a->xc_pi + O, W, B, A, s));
-    EXORL_TRY(net_forward(a->critic, Pt, a->sh_target, a->xc_next, W, B, a->ft, false, false, prec, s));     // td3_bc.py:126
-    EXORL_TRY(net_forward(a->critic, Pc, a->sh_critic, a->xc_cur, W, B, a->fc, true, false, prec, s));       // td3_bc.py:130
+    EXORL_TRY(a->fk.fork(s));                   // target critic (td3_bc.py:126) and critic (td3_bc.py:130) forwards are independent
+    EXORL_TRY(net_forward(a->critic, Pt, a->sh_target, a->xc_next, W, B, a->ft, false, false, prec, a->fk.side(s)));
+    EXORL_TRY(net_forward(a->critic, Pc, a->sh_critic, a->xc_cur, W, B, a->fc, true, false, prec, s));
+    EXORL_TRY(a->fk.join(s));
     if (a->want_metrics)
         EXORL_TRY(critic_loss(a->fc.out, a->ft.out, a->reward, a->discount, a->dq, a->metrics, B, a->inv_bg, s));   // :133-137
     DoutSpec td{};                              // d(2 x MSE)/dQ computed where it is consumed (:127-131)
     td.mode = EXORL_DOUT_TD; td.q = a->fc.out; td.tq = a->ft.out; td.reward = a->reward; td.discount = a->discount; td.inv_bg = a->inv_bg;
     EXORL_TRY(net_backward(a->critic, Pc, a->sh_critic, a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD], a->pc, a->xc_cur, W, B, a->fc, td,
-                           a->bc, nullptr, 0, 0, prec, s));                                                     // :141
+                           a->bc, nullptr, 0, 0, prec, s, a->fk));                                                     // :141
     return 0;
 }
 
@@ -369,7 +398,7 @@ static int phase2(exorl_agent* a, float stddev, hipStream_t s) {
         dq.mode = EXORL_DOUT_ACTOR_Q; dq.q = a->fc.out; dq.stats = a->stats; dq.inv_bg = a->inv_bg; dq.alpha = cfg.alpha;
         dq.use_lambda = cfg.kind == EXORL_AGENT_TD3_BC;
         EXORL_TRY(net_backward(a->critic, a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->sh_critic, nullptr, a->pc, a->xc_pi, W, B, a->fc,
-                               dq, a->bc, a->da, O, A, prec, s));
+                               dq, a->bc, a->da, O, A, prec, s, a->fk));
     }
     // the obs half (rows B..2B) of the stacked actor forward
     FwdBufs f{a->fa.h1 + (int64_t)B * H, a->fa.xhat + (int64_t)B * H, a->fa.rstd + B, a->fa.h2 + (int64_t)B * H,
@@ -384,7 +413,7 @@ static int phase2(exorl_agent* a, float stddev, hipStream_t s) {
     dm.mode = EXORL_DOUT_ACTOR_MU; dm.da = a->da; dm.da_nets = a->has_critic ? a->critic.n_trunks : 0; dm.mu = f.out; dm.a_data = a->action;
     dm.kind = cfg.kind; dm.inv_bg = a->inv_bg; dm.stddev = stddev;
     EXORL_TRY(net_backward(a->actor, Pa, a->sh_actor, a->flat[EXORL_NET_ACTOR][EXORL_T_GRAD], a->pa, a->xa + (int64_t)B * O, O, B, f,
-                           dm, a->ba, nullptr, 0, 0, prec, s));
+                           dm, a->ba, nullptr, 0, 0, prec, s, a->fk));
     return 0;
 }
 
@@ -453,6 +482,7 @@ int exorl_agent_destroy(exorl_agent_t* a) {
     if (!a) return 0;
     (void)release_graph(a);
     if (a->capture_stream) (void)hipStreamDestroy(a->capture_stream);
+    if (a->fk.aux) { (void)hipStreamDestroy(a->fk.aux); (void)hipEventDestroy(a->fk.ev_fork); (void)hipEventDestroy(a->fk.ev_join); }
     if (a->owns_ws) (void)hipFree(a->ws);
     delete a;
     return 0;
@@ -614,12 +644,19 @@ int exorl_agent_enable_graph(exorl_agent_t* a, exorl_replay_t* r, int32_t nstep,
     EXORL_CHECK_HIP(hipMemcpyAsync(&a->state->replay_counter, &ctr, sizeof(ctr), hipMemcpyHostToDevice, a->capture_stream));
     EXORL_CHECK_HIP(hipStreamSynchronize(a->capture_stream));
     const int64_t t_a = a->actor_t, t_c = a->critic_t;
+    if (!a->fk.aux) {
+        EXORL_CHECK_HIP(hipStreamCreateWithFlags(&a->fk.aux, hipStreamNonBlocking));
+        EXORL_CHECK_HIP(hipEventCreateWithFlags(&a->fk.ev_fork, hipEventDisableTiming));
+        EXORL_CHECK_HIP(hipEventCreateWithFlags(&a->fk.ev_join, hipEventDisableTiming));
+    }
     EXORL_CHECK_HIP(hipStreamBeginCapture(a->capture_stream, hipStreamCaptureModeThreadLocal));
     a->capturing = true;
+    a->fk.on = a->parallel_branches;
     int rc = replay_sample_impl(r, a->cfg.batch, nstep, gamma, EXORL_SAMPLER_PHILOX, nullptr, &slots, nullptr, a->capture_stream,
                                 &a->state->replay_counter);
     for (int p = 0; p < 4 && rc == 0; ++p) rc = exorl_agent_update_phase(a, p, stddev, nullptr, nullptr, a->capture_stream);
     a->capturing = false;
+    a->fk.on = false;
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(a->capture_stream, &g);
     a->actor_t = t_a; a->critic_t = t_c;             // capture enqueued nothing: undo the host-side bookkeeping
@@ -629,6 +666,13 @@ int exorl_agent_enable_graph(exorl_agent_t* a, exorl_replay_t* r, int32_t nstep,
     a->graph = g;
     EXORL_CHECK_HIP(hipGraphInstantiate(&a->graph_exec, g, nullptr, nullptr, 0));
     a->graph_replay = r;
+    return 0;
+}
+
+int exorl_agent_set_parallel_branches(exorl_agent_t* a, int32_t enable) {
+    EXORL_REQUIRE(a, "agent_set_parallel_branches: null handle");
+    EXORL_REQUIRE(!a->graph_exec, "agent_set_parallel_branches: disable the captured graph first");
+    a->parallel_branches = enable != 0;
     return 0;
 }
 

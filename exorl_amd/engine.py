@@ -140,6 +140,9 @@ class AgentEngine:
     def step_graph(self):
         L.check(self.lib.exorl_agent_step_graph(self.h, L.current_stream()))
 
+    def set_parallel_branches(self, enable):
+        L.check(self.lib.exorl_agent_set_parallel_branches(self.h, int(bool(enable))))
+
     def set_metrics(self, enable):
         L.check(self.lib.exorl_agent_set_metrics(self.h, int(bool(enable))))
 

@@ -185,6 +185,9 @@ int exorl_agent_metrics(exorl_agent_t* a, float* metrics_host, void* stream);
 /* The reference computes its metrics dict only under use_tb (td3_bc.py:133,162,175); enable = 0 skips the metric
  * reductions of the step (default: enabled). */
 int exorl_agent_set_metrics(exorl_agent_t* a, int32_t enable);
+/* Captured graphs run independent parts of the step (target || critic forward, wgrad || dgrad chain) as parallel
+ * branches on a second stream; enable = 0 captures a single chain (default: enabled). */
+int exorl_agent_set_parallel_branches(exorl_agent_t* a, int32_t enable);
 int exorl_agent_opt_steps(exorl_agent_t* a, int64_t* actor_steps, int64_t* critic_steps);
 int exorl_agent_set_opt_steps(exorl_agent_t* a, int64_t actor_steps, int64_t critic_steps);
 /* Captures exorl_replay_sample(PHILOX) into the agent's batch slots + exorl_agent_update into one hipGraph;
