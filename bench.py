@@ -108,7 +108,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--graph', type=int, default=int(os.environ.get('EXORL_GRAPH', '1')))
-    ap.add_argument('--branches', type=int, default=int(os.environ.get('EXORL_BRANCHES', '1')))
+    ap.add_argument('--branches', type=int, default=int(os.environ.get('EXORL_BRANCHES', '0')))
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))

@@ -91,7 +91,7 @@ struct Fork {
     hipStream_t side(hipStream_t s) const { return on ? aux : s; }
 };
 
-struct FwdBufs { float *h1, *xhat, *rstd, *h2, *out; unsigned short* h1b; };
+struct FwdBufs { float *h1, *xhat, *rstd, *h2, *out; unsigned short *h1b, *xhatb; };
 struct BwdBufs { float *dz2, *dh1; unsigned short* dz2b; };
 struct NetShadow { float* w0t; unsigned short* w1b; };     // W0 transposed per trunk; W1 as bf16 per head
 struct Partials { float *Ph, *Pt, *Pw; };                  // per-chunk partial gradients (fused.hip)
@@ -112,8 +112,10 @@ static int net_forward(const NetDesc& d, const float* P, const NetShadow& sh, co
     const int H = d.H;
     const int64_t act = (int64_t)rows * H;
     const bool bf = prec == EXORL_PREC_BF16;
-    EXORL_TRY(trunk_fwd(x, ldx, sh.w0t, P + d.b0, P + d.g, P + d.beta, f.h1, save ? f.xhat : nullptr, save ? f.rstd : nullptr,
-                        bf ? f.h1b : nullptr, rows, d.in_dim, H, d.n_trunks, act, d.trunk_stride, (int64_t)d.in_dim * H, s));
+    // fast mode keeps the trunk activations as bf16 only (MFMA operand + LN backward input): 4 B/elem written instead of 10
+    EXORL_TRY(trunk_fwd(x, ldx, sh.w0t, P + d.b0, P + d.g, P + d.beta, bf ? nullptr : f.h1, (save && !bf) ? f.xhat : nullptr,
+                        save ? f.rstd : nullptr, bf ? f.h1b : nullptr, (bf && save) ? f.xhatb : nullptr, rows, d.in_dim, H,
+                        d.n_trunks, act, d.trunk_stride, (int64_t)d.in_dim * H, s));
     if (bf) {
         Gemm16Problem q[2];
         for (int i = 0; i < d.n_heads; ++i)
@@ -182,7 +184,8 @@ static int net_backward(const NetDesc& d, const float* P, const NetShadow& sh, f
             for (int i = 0; i < d.n_heads; ++i) EXORL_TRY(gemm_grouped(prec, 0, 1, p + i, 1, false, i > 0, s));
         }
     }
-    EXORL_TRY(ln_bwd(b.dh1, f.h1, f.xhat, f.rstd, P + d.g, pt.Pt, rows, H, d.n_trunks, act, d.trunk_stride, G ? 1 : 0, s));
+    EXORL_TRY(ln_bwd(b.dh1, f.h1, f.xhat, bf ? f.h1b : nullptr, bf ? f.xhatb : nullptr, f.rstd, P + d.g, pt.Pt, rows, H, d.n_trunks,
+                     act, d.trunk_stride, G ? 1 : 0, s));
     if (dx)       // dx[m][j] = sum_c dz0[m][c] W0[c][col0+j]: a row-dot against rows col0.. of the transposed shadow
         EXORL_TRY(head_fwd4(b.dh1, sh.w0t + (int64_t)dx_col0 * H, nullptr, dx, rows, H, dx_cols, 0, d.n_trunks, act,
                             (int64_t)d.in_dim * H, (int64_t)rows * dx_cols, s));
@@ -252,7 +255,7 @@ struct exorl_agent {
     exorl_replay* graph_replay = nullptr;
     bool capturing = false;
     Fork fk{};                   // parallel-branch plumbing (active while capturing)
-    bool parallel_branches = true;
+    bool parallel_branches = false;  // measured slower than one chain on MI355X (2987 vs 3259 steps/s): opt-in
     bool want_metrics = true;    // the (B,1)-sized metric reductions are skipped when the caller never reads them (use_tb=False)
 };
 
@@ -270,7 +273,8 @@ static void carve(exorl_agent* a, Carver& c) {
     a->xa = c.take(2 * B * O);
     auto take_u16 = [&](int64_t n) { return reinterpret_cast<unsigned short*>(c.take((n + 1) / 2)); };
     const bool bf = cfg.precision == EXORL_PREC_BF16;
-    a->fa = FwdBufs{c.take(2 * B * H), c.take(2 * B * H), c.take(2 * B), c.take(2 * B * H), c.take(2 * B * A), bf ? take_u16(2 * B * H) : nullptr};
+    a->fa = FwdBufs{c.take(2 * B * H), c.take(2 * B * H), c.take(2 * B), c.take(2 * B * H), c.take(2 * B * A), bf ? take_u16(2 * B * H) : nullptr,
+                    bf ? take_u16(2 * B * H) : nullptr};
     a->ba = BwdBufs{c.take(B * H), c.take(B * H), bf ? take_u16(B * H) : nullptr};
     a->sh_actor = NetShadow{c.take(O * H), bf ? take_u16(H * H) : nullptr};
     a->pa = Partials{c.take((int64_t)head_chunks(B) * ((A + 1) * H + 16)), c.take((int64_t)trunk_chunks(B) * 3 * H),
@@ -281,12 +285,13 @@ static void carve(exorl_agent* a, Carver& c) {
     a->state = reinterpret_cast<StepState*>(c.take((sizeof(StepState) + 3) / 4));
     a->act_x = c.take(ACT_ROWS * O);
     a->act_noise = c.take(ACT_ROWS * A);
-    a->fact = FwdBufs{c.take(ACT_ROWS * H), nullptr, nullptr, c.take(ACT_ROWS * H), c.take(ACT_ROWS * A), bf ? take_u16(ACT_ROWS * H) : nullptr};
+    a->fact = FwdBufs{c.take(ACT_ROWS * H), nullptr, nullptr, c.take(ACT_ROWS * H), c.take(ACT_ROWS * A), bf ? take_u16(ACT_ROWS * H) : nullptr, nullptr};
     if (a->has_critic) {
         const int64_t nt = a->critic.n_trunks;
         a->xc_cur = c.take(B * W); a->xc_next = c.take(B * W); a->xc_pi = c.take(B * W);
-        a->ft = FwdBufs{c.take(nt * B * H), nullptr, nullptr, c.take(2 * B * H), c.take(2 * B), bf ? take_u16(nt * B * H) : nullptr};
-        a->fc = FwdBufs{c.take(nt * B * H), c.take(nt * B * H), c.take(nt * B), c.take(2 * B * H), c.take(2 * B), bf ? take_u16(nt * B * H) : nullptr};
+        a->ft = FwdBufs{c.take(nt * B * H), nullptr, nullptr, c.take(2 * B * H), c.take(2 * B), bf ? take_u16(nt * B * H) : nullptr, nullptr};
+        a->fc = FwdBufs{c.take(nt * B * H), c.take(nt * B * H), c.take(nt * B), c.take(2 * B * H), c.take(2 * B), bf ? take_u16(nt * B * H) : nullptr,
+                        bf ? take_u16(nt * B * H) : nullptr};
         a->bc = BwdBufs{c.take(2 * B * H), c.take(nt * B * H), bf ? take_u16(2 * B * H) : nullptr};
         a->dq = c.take(2 * B);
         a->da = c.take(nt * B * A);
@@ -402,7 +407,8 @@ static int phase2(exorl_agent* a, float stddev, hipStream_t s) {
     }
     // the obs half (rows B..2B) of the stacked actor forward
     FwdBufs f{a->fa.h1 + (int64_t)B * H, a->fa.xhat + (int64_t)B * H, a->fa.rstd + B, a->fa.h2 + (int64_t)B * H,
-              a->fa.out + (int64_t)B * A, a->fa.h1b ? a->fa.h1b + (int64_t)B * H : nullptr};
+              a->fa.out + (int64_t)B * A, a->fa.h1b ? a->fa.h1b + (int64_t)B * H : nullptr,
+              a->fa.xhatb ? a->fa.xhatb + (int64_t)B * H : nullptr};
     if (!a->has_critic)       // BC (bc.py:82): the only forward of the step
         EXORL_TRY(net_forward(a->actor, Pa, a->sh_actor, a->xa + (int64_t)B * O, O, B, f, true, true, prec, s));
     if (a->want_metrics)                        // actor_loss / batch_reward(BC) metrics only (the gradient is formed in head_bwd)

@@ -44,8 +44,8 @@ __global__ __launch_bounds__(512) void trunk_fwd_kernel(const float* __restrict_
                                                         const float* __restrict__ gain, const float* __restrict__ beta,
                                                         float* __restrict__ h, float* __restrict__ xhat,
                                                         float* __restrict__ rstd, unsigned short* __restrict__ hb,
-                                                        int rows, int in_dim, int H, int64_t astride, int64_t pstride,
-                                                        int64_t tstride, int TF_KC) {
+                                                        unsigned short* __restrict__ xhb, int rows, int in_dim, int H,
+                                                        int64_t astride, int64_t pstride, int64_t tstride, int TF_KC) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* ws = smem;                          // [TF_KC][H]
     float* xs = smem + TF_KC * H;              // [TF_ROWS][MAX_IN]
@@ -129,20 +129,25 @@ __global__ __launch_bounds__(512) void trunk_fwd_kernel(const float* __restrict_
         else
             hv = make_float4(tanhf(xh.x * g.x + be.x), tanhf(xh.y * g.y + be.y), tanhf(xh.z * g.z + be.z),
                              tanhf(xh.w * g.w + be.w));
-        reinterpret_cast<float4*>(h + o)[c4] = hv;
+        if (h) reinterpret_cast<float4*>(h + o)[c4] = hv;
         if (xhat) reinterpret_cast<float4*>(xhat + o)[c4] = xh;
         if (hb) {
             ushort4 q;
             q.x = f2bf(hv.x); q.y = f2bf(hv.y); q.z = f2bf(hv.z); q.w = f2bf(hv.w);
             reinterpret_cast<ushort4*>(hb + o)[c4] = q;
         }
+        if (xhb) {
+            ushort4 q;
+            q.x = f2bf(xh.x); q.y = f2bf(xh.y); q.z = f2bf(xh.z); q.w = f2bf(xh.w);
+            reinterpret_cast<ushort4*>(xhb + o)[c4] = q;
+        }
     }
     if (rstd && lane == 0) rstd[net * (int64_t)rows + row] = rs;
 }
 
 int trunk_fwd(const float* x, int64_t ldx, const float* W0T, const float* b0, const float* gain, const float* beta,
-              float* h, float* xhat, float* rstd, unsigned short* h_bf16, int rows, int in_dim, int H, int nets,
-              int64_t astride, int64_t pstride, int64_t tstride, hipStream_t s) {
+              float* h, float* xhat, float* rstd, unsigned short* h_bf16, unsigned short* xhat_bf16, int rows, int in_dim,
+              int H, int nets, int64_t astride, int64_t pstride, int64_t tstride, hipStream_t s) {
     EXORL_REQUIRE(H >= 4 && H <= 1024 && H % 4 == 0 && in_dim >= 1 && in_dim <= MAX_IN, "trunk_fwd: unsupported H=%d in=%d", H, in_dim);
     int kc = TF_LDS_FLOATS / H;                // k-rows of W0T staged per pass
     if (kc > in_dim) kc = in_dim;
@@ -155,9 +160,9 @@ int trunk_fwd(const float* x, int64_t ldx, const float* W0T, const float* b0, co
         attr_set = true;
     }
     if (h_bf16) hipLaunchKernelGGL((trunk_fwd_kernel<true>), grid, dim3(512), lds, s, x, ldx, W0T, b0, gain, beta, h, xhat, rstd, h_bf16,
-                                   rows, in_dim, H, astride, pstride, tstride, kc);
+                                   xhat_bf16, rows, in_dim, H, astride, pstride, tstride, kc);
     else        hipLaunchKernelGGL((trunk_fwd_kernel<false>), grid, dim3(512), lds, s, x, ldx, W0T, b0, gain, beta, h, xhat, rstd, h_bf16,
-                                   rows, in_dim, H, astride, pstride, tstride, kc);
+                                   xhat_bf16, rows, in_dim, H, astride, pstride, tstride, kc);
     EXORL_LAUNCH_CHECK();
     return 0;
 }
@@ -167,8 +172,15 @@ int trunk_fwd(const float* x, int64_t ldx, const float* W0T, const float* b0, co
 //   dz0 = rstd * (dxh - mean(dxh) - xhat * mean(dxh*xhat)),  dxh = dh*(1-h^2)*gain      (written in place over dh)
 // and per-workgroup partial column sums P[chunk] = [dgain H][dbeta H][db0 H] (PARAMS only).
 constexpr int TB_ROWS = 8;
-template <bool PARAMS>
+__device__ __forceinline__ float4 bf4_to_f4(ushort4 q) {
+    return make_float4(__uint_as_float((unsigned)q.x << 16), __uint_as_float((unsigned)q.y << 16),
+                       __uint_as_float((unsigned)q.z << 16), __uint_as_float((unsigned)q.w << 16));
+}
+
+// B16: h and xhat are read from their bf16 copies (fast mode keeps no fp32 copies of the trunk activations)
+template <bool PARAMS, bool B16>
 __global__ __launch_bounds__(512) void ln_bwd_kernel(float* dh, const float* __restrict__ h, const float* __restrict__ xhat,
+                                                     const unsigned short* __restrict__ hb, const unsigned short* __restrict__ xhb,
                                                      const float* __restrict__ rstd, const float* __restrict__ gain,
                                                      float* __restrict__ P, int rows, int H, int64_t astride,
                                                      int64_t pstride) {
@@ -194,9 +206,15 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(float* dh, const float* __r
             const int c4 = lane + 64 * i;
             d[i] = xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (c4 < H4) {
-                const float4 hv = reinterpret_cast<const float4*>(h + o)[c4];
+                float4 hv;
+                if constexpr (B16) {
+                    hv = bf4_to_f4(reinterpret_cast<const ushort4*>(hb + o)[c4]);
+                    xh[i] = bf4_to_f4(reinterpret_cast<const ushort4*>(xhb + o)[c4]);
+                } else {
+                    hv = reinterpret_cast<const float4*>(h + o)[c4];
+                    xh[i] = reinterpret_cast<const float4*>(xhat + o)[c4];
+                }
                 const float4 dv = reinterpret_cast<const float4*>(dh + o)[c4];
-                xh[i] = reinterpret_cast<const float4*>(xhat + o)[c4];
                 float4 dy;
                 dy.x = dv.x * (1.0f - hv.x * hv.x); dy.y = dv.y * (1.0f - hv.y * hv.y);
                 dy.z = dv.z * (1.0f - hv.z * hv.z); dy.w = dv.w * (1.0f - hv.w * hv.w);
@@ -244,12 +262,16 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(float* dh, const float* __r
     }
 }
 
-int ln_bwd(float* dh, const float* h, const float* xhat, const float* rstd, const float* gain, float* P, int rows, int H,
-           int nets, int64_t astride, int64_t pstride, int want_params, hipStream_t s) {
+int ln_bwd(float* dh, const float* h, const float* xhat, const unsigned short* h_bf16, const unsigned short* xhat_bf16,
+           const float* rstd, const float* gain, float* P, int rows, int H, int nets, int64_t astride, int64_t pstride,
+           int want_params, hipStream_t s) {
     EXORL_REQUIRE(H >= 4 && H <= 1024 && H % 4 == 0, "ln_bwd: unsupported H=%d", H);
     const dim3 grid(cdiv(rows, TB_ROWS), nets);
-    if (want_params) hipLaunchKernelGGL((ln_bwd_kernel<true>), grid, dim3(512), 0, s, dh, h, xhat, rstd, gain, P, rows, H, astride, pstride);
-    else hipLaunchKernelGGL((ln_bwd_kernel<false>), grid, dim3(512), 0, s, dh, h, xhat, rstd, gain, P, rows, H, astride, pstride);
+    const bool b16 = h_bf16 && xhat_bf16;
+#define EXORL_LNB(PA, BB) hipLaunchKernelGGL((ln_bwd_kernel<PA, BB>), grid, dim3(512), 0, s, dh, h, xhat, h_bf16, xhat_bf16, rstd, gain, P, rows, H, astride, pstride)
+    if (want_params) { if (b16) EXORL_LNB(true, true); else EXORL_LNB(true, false); }
+    else             { if (b16) EXORL_LNB(false, true); else EXORL_LNB(false, false); }
+#undef EXORL_LNB
     EXORL_LAUNCH_CHECK();
     return 0;
 }
@@ -258,7 +280,7 @@ int trunk_chunks(int rows) { return cdiv(rows, TB_ROWS); }
 // ------------------------------------------------------------------------------------------------
 // outer-product column reduction: P[chunk][j][c] = sum_{m in chunk} u[m][j] * v[m][c]   (first-layer wgrad:
 // u = x (rows x J), v = dz0).  Thread = column, 16 rows per workgroup, u rows broadcast from LDS.
-constexpr int OR_ROWS = 16;
+constexpr int OR_ROWS = 32;
 __global__ __launch_bounds__(256) void outer_reduce_kernel(const float* __restrict__ u, int64_t ldu, int J,
                                                            const float* __restrict__ v, float* __restrict__ P, int rows,
                                                            int H, int64_t vstride) {
@@ -326,8 +348,15 @@ __global__ __launch_bounds__(256) void head_fwd4_kernel(const float* __restrict_
     float acc[NO];
 #pragma unroll
     for (int j = 0; j < NO; ++j) acc[j] = 0.f;
-    for (int c4 = lane; c4 < H / 4; c4 += 64) {
-        const float4 av = ar[c4];
+    const int H4 = H >> 2;
+    float4 avs[4];                 // the whole row (H <= 1024) in flight before any use: one memory round trip, not four
+#pragma unroll
+    for (int i = 0; i < 4; ++i) avs[i] = lane + 64 * i < H4 ? ar[lane + 64 * i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c4 = lane + 64 * i;
+        if (c4 >= H4) break;
+        const float4 av = avs[i];
 #pragma unroll
         for (int j = 0; j < NO; ++j) {
             if (j < nout) {
@@ -348,7 +377,7 @@ __global__ __launch_bounds__(256) void head_fwd4_kernel(const float* __restrict_
 
 int head_fwd4(const float* a, const float* W, const float* b, float* out, int rows, int H, int nout, int tanh_out,
               int nets, int64_t astride, int64_t pstride, int64_t ostride, hipStream_t s) {
-    EXORL_REQUIRE(nout >= 1 && nout <= 16 && H % 4 == 0, "head_fwd4: nout=%d H=%d unsupported", nout, H);
+    EXORL_REQUIRE(nout >= 1 && nout <= 16 && H % 4 == 0 && H <= 1024, "head_fwd4: nout=%d H=%d unsupported", nout, H);
     dim3 grid(cdiv(rows, 4), nets);
     if (nout == 1) hipLaunchKernelGGL((head_fwd4_kernel<1>), grid, dim3(256), 0, s, a, W, b, out, rows, H, nout, tanh_out, astride, pstride, ostride);
     else if (nout <= 8) hipLaunchKernelGGL((head_fwd4_kernel<8>), grid, dim3(256), 0, s, a, W, b, out, rows, H, nout, tanh_out, astride, pstride, ostride);

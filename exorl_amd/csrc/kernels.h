@@ -44,10 +44,11 @@ int head_bwd_params(const float* dout, const float* a, const float* dz, float* d
 
 // ---- fused layer kernels (fused.hip)
 int trunk_fwd(const float* x, int64_t ldx, const float* W0T, const float* b0, const float* gain, const float* beta,
-              float* h, float* xhat, float* rstd, unsigned short* h_bf16, int rows, int in_dim, int H, int nets,
-              int64_t astride, int64_t pstride, int64_t tstride, hipStream_t s);
-int ln_bwd(float* dh, const float* h, const float* xhat, const float* rstd, const float* gain, float* P, int rows, int H,
-           int nets, int64_t astride, int64_t pstride, int want_params, hipStream_t s);
+              float* h, float* xhat, float* rstd, unsigned short* h_bf16, unsigned short* xhat_bf16, int rows, int in_dim,
+              int H, int nets, int64_t astride, int64_t pstride, int64_t tstride, hipStream_t s);
+int ln_bwd(float* dh, const float* h, const float* xhat, const unsigned short* h_bf16, const unsigned short* xhat_bf16,
+           const float* rstd, const float* gain, float* P, int rows, int H, int nets, int64_t astride, int64_t pstride,
+           int want_params, hipStream_t s);
 int trunk_chunks(int rows);
 int outer_reduce(const float* u, int64_t ldu, int J, const float* v, float* P, int rows, int H, int nets, int64_t vstride,
                  hipStream_t s);

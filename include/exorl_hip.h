@@ -186,7 +186,7 @@ int exorl_agent_metrics(exorl_agent_t* a, float* metrics_host, void* stream);
  * reductions of the step (default: enabled). */
 int exorl_agent_set_metrics(exorl_agent_t* a, int32_t enable);
 /* Captured graphs run independent parts of the step (target || critic forward, wgrad || dgrad chain) as parallel
- * branches on a second stream; enable = 0 captures a single chain (default: enabled). */
+ * branches on a second stream (default: off — one chain measured faster on MI355X). */
 int exorl_agent_set_parallel_branches(exorl_agent_t* a, int32_t enable);
 int exorl_agent_opt_steps(exorl_agent_t* a, int64_t* actor_steps, int64_t* critic_steps);
 int exorl_agent_set_opt_steps(exorl_agent_t* a, int64_t actor_steps, int64_t critic_steps);
