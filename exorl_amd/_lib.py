@@ -12,7 +12,8 @@ P = C.POINTER
 
 # constants mirrored from include/exorl_hip.h
 SAMPLER_MT19937, SAMPLER_PHILOX, SAMPLER_GIVEN = 0, 1, 2
-AGENT_TD3_BC, AGENT_TD3, AGENT_BC, AGENT_DDPG = 0, 1, 2, 3
+AGENT_TD3_BC, AGENT_TD3, AGENT_BC, AGENT_DDPG, AGENT_CRR = 0, 1, 2, 3, 4
+CRR_WEIGHT = {'identity': 0, 'indicator': 1, 'exp': 2}
 PREC_F32, PREC_BF16 = 0, 1
 NET_ACTOR, NET_CRITIC, NET_CRITIC_TARGET = 0, 1, 2
 T_PARAM, T_GRAD, T_ADAM_M, T_ADAM_V = 0, 1, 2, 3
@@ -34,7 +35,8 @@ class BatchOut(C.Structure):
 class AgentCfg(C.Structure):
     _fields_ = [('kind', c_int32), ('obs_dim', c_int32), ('act_dim', c_int32), ('hidden_dim', c_int32),
                 ('batch', c_int32), ('precision', c_int32), ('world_size', c_int32), ('reserved', c_int32),
-                ('lr', c_float), ('tau', c_float), ('alpha', c_float), ('stddev_clip', c_float), ('seed', c_uint64)]
+                ('lr', c_float), ('tau', c_float), ('alpha', c_float), ('stddev_clip', c_float), ('seed', c_uint64),
+                ('num_value_samples', c_int32), ('weight_func', c_int32)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/exorl_hip.h

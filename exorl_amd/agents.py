@@ -96,7 +96,8 @@ class NetView:
 class _AgentBase:
     KIND = None
 
-    def _build(self, obs_dim, action_dim, hidden_dim, batch_size, lr, tau, alpha, stddev_clip, device, precision, seed):
+    def _build(self, obs_dim, action_dim, hidden_dim, batch_size, lr, tau, alpha, stddev_clip, device, precision, seed,
+               **engine_kw):
         ddpg = self.KIND == 'ddpg'
         ws = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
@@ -110,7 +111,8 @@ class _AgentBase:
             critic0 = _mlp_init(obs_dim + action_dim, hidden_dim, 1, nt, 2)
             _mlp_init(obs_dim + action_dim, hidden_dim, 1, nt, 2)       # critic_target's draws, overwritten by the copy
         self.engine = AgentEngine(self.KIND, obs_dim, action_dim, hidden_dim, batch_size, lr=lr, tau=tau, alpha=alpha,
-                                  stddev_clip=stddev_clip, precision=precision, world_size=ws, seed=seed, device=device)
+                                  stddev_clip=stddev_clip, precision=precision, world_size=ws, seed=seed, device=device,
+                                  **engine_kw)
         self.actor = NetView(self.engine, L.NET_ACTOR, _DDPG_ACTOR_KEYS if ddpg else _OFFLINE_ACTOR_KEYS, self.params_changed)
         for p, w in zip(self.actor.parameters(), actor0):
             p.copy_(w.reshape(p.shape))
@@ -179,10 +181,10 @@ class _AgentBase:
             batch = next(replay_iter)                                                   # any iterator of 5-tuples
             self.engine.set_batch(*batch[:5])
 
-    def _noise(self):
+    def _noise(self, rows=None):
         if self.noise_hook is None:
             return None
-        return self.noise_hook((self.engine.batch, self.action_dim))
+        return self.noise_hook((rows or self.engine.batch, self.action_dim))
 
     def _run_update(self, stddev):
         """One gradient step; under torch.distributed the three global quantities are sum-all-reduced."""
@@ -190,7 +192,8 @@ class _AgentBase:
         if self.KIND == 'bc':
             nc = na = None
         else:
-            nc, na = self._noise(), self._noise()        # reference draw order: critic target, then actor
+            # reference draw order: critic target, then actor; CRR's second draw is (B*n, A) (crr.py:125)
+            nc, na = self._noise(), self._noise(getattr(self, '_second_noise_rows', None))
         if self.world_size == 1:
             eng.update(stddev, nc, na)
             return
@@ -199,7 +202,7 @@ class _AgentBase:
         if eng.has_critic:
             dist.all_reduce(eng.flat(L.NET_CRITIC, L.T_GRAD))
         eng.update_phase(1, stddev, nc, na)
-        if self.KIND == 'td3_bc':
+        if self.KIND == 'td3_bc':                    # only TD3+BC's lambda needs a batch-global statistic
             dist.all_reduce(eng.stats())
         eng.update_phase(2, stddev, nc, na)
         dist.all_reduce(eng.flat(L.NET_ACTOR, L.T_GRAD))
@@ -272,6 +275,41 @@ class TD3Agent(TD3BCAgent):
                  batch_size, stddev_clip, use_tb, has_next_action=False, *, precision='fp32', seed=0):
         super().__init__(name, obs_shape, action_shape, device, lr, hidden_dim, critic_target_tau, stddev_schedule, nstep,
                          batch_size, stddev_clip, use_tb, 0.0, has_next_action, precision=precision, seed=seed)
+
+
+class CRRAgent(_AgentBase):
+    """agents/offline_learning/crr.py:59-219."""
+    KIND = 'crr'
+
+    def __init__(self, name, obs_shape, action_shape, device, lr, hidden_dim, critic_target_tau, num_value_samples, weight_func,
+                 stddev_schedule, nstep, batch_size, stddev_clip, use_tb, has_next_action=False, *, precision='fp32', seed=0):
+        assert weight_func in ['identity', 'indicator', 'exp']
+        self.action_dim = action_shape[0]
+        self.hidden_dim = hidden_dim
+        self.lr = lr
+        self.device = device
+        self.critic_target_tau = critic_target_tau
+        self.use_tb = use_tb
+        self.stddev_schedule = stddev_schedule
+        self.stddev_clip = stddev_clip
+        self.num_value_samples = num_value_samples
+        self.weight_func = weight_func
+        self._build(obs_shape[0], action_shape[0], hidden_dim, batch_size, lr, critic_target_tau, 0.0, stddev_clip, device, precision,
+                    seed, num_value_samples=num_value_samples, weight_func=weight_func)
+        self._second_noise_rows = batch_size * num_value_samples
+        self.train()
+        self.critic_target.train()
+
+    def act(self, obs, step, eval_mode):
+        return self._act(np.asarray(obs, np.float32), step, eval_mode)
+
+    def update(self, replay_iter, step):
+        metrics = dict()
+        stddev = self._stddev(step)
+        self._step(replay_iter, stddev)
+        if self.use_tb:
+            metrics.update(self._metrics(_CRITIC_METRICS, stddev))
+        return metrics
 
 
 class BCAgent(_AgentBase):

@@ -237,6 +237,8 @@ struct exorl_agent {
     FwdBufs fa{}, ft{}, fc{};    // actor (2B rows), target critic, critic
     BwdBufs bc{}, ba{};
     float *dq = nullptr, *da = nullptr, *dpre = nullptr;
+    float *xc_rep = nullptr, *crr_w = nullptr;     // CRR: repeated (obs, sampled action) inputs; advantage weights
+    FwdBufs fr{};                                   // CRR: critic forward on B*num_value_samples rows (no grad)
     NetShadow sh_actor{}, sh_critic{}, sh_target{};
     ShadowSpec spec_actor{}, spec_critic{};
     Partials pa{}, pc{};
@@ -295,6 +297,12 @@ static void carve(exorl_agent* a, Carver& c) {
         a->bc = BwdBufs{c.take(2 * B * H), c.take(nt * B * H), bf ? take_u16(2 * B * H) : nullptr};
         a->dq = c.take(2 * B);
         a->da = c.take(nt * B * A);
+        if (cfg.kind == EXORL_AGENT_CRR) {
+            const int64_t R = B * cfg.num_value_samples;
+            a->xc_rep = c.take(R * W);
+            a->crr_w = c.take(B);
+            a->fr = FwdBufs{bf ? nullptr : c.take(nt * R * H), nullptr, nullptr, c.take(2 * R * H), c.take(2 * R), bf ? take_u16(nt * R * H) : nullptr, nullptr};
+        }
         a->sh_critic = NetShadow{c.take(nt * W * H), bf ? take_u16(2 * H * H) : nullptr};
         a->sh_target = NetShadow{c.take(nt * W * H), bf ? take_u16(2 * H * H) : nullptr};
         a->pc = Partials{c.take(2 * (int64_t)head_chunks(B) * (2 * H + 16)), c.take(nt * (int64_t)trunk_chunks(B) * 3 * H),
@@ -304,7 +312,10 @@ static void carve(exorl_agent* a, Carver& c) {
 
 static int describe(exorl_agent* a, const exorl_agent_cfg* cfg) {
     EXORL_REQUIRE(cfg, "agent: null cfg");
-    EXORL_REQUIRE(cfg->kind >= EXORL_AGENT_TD3_BC && cfg->kind <= EXORL_AGENT_DDPG, "agent: unknown kind %d", cfg->kind);
+    EXORL_REQUIRE(cfg->kind >= EXORL_AGENT_TD3_BC && cfg->kind <= EXORL_AGENT_CRR, "agent: unknown kind %d", cfg->kind);
+    EXORL_REQUIRE(cfg->kind != EXORL_AGENT_CRR || (cfg->num_value_samples >= 1 && cfg->num_value_samples <= 64 &&
+                  cfg->weight_func >= EXORL_CRR_IDENTITY && cfg->weight_func <= EXORL_CRR_EXP),
+                  "agent: CRR needs 1 <= num_value_samples <= 64 and a valid weight_func (got %d, %d)", cfg->num_value_samples, cfg->weight_func);
     EXORL_REQUIRE(cfg->obs_dim > 0 && cfg->act_dim > 0 && cfg->act_dim <= 16 && cfg->hidden_dim >= 4 && cfg->hidden_dim <= 1024 && cfg->hidden_dim % 4 == 0 &&
                   cfg->obs_dim + cfg->act_dim <= 256 &&
                   cfg->batch > 0, "agent: unsupported dims O=%d A=%d (<=16) H=%d (multiple of 4, <=1024) B=%d; O+A <= 256", cfg->obs_dim, cfg->act_dim,
@@ -361,8 +372,8 @@ static int phase0(exorl_agent* a, float stddev, const float* noise_c, hipStream_
     // next_action = dist.sample(clip) (td3_bc.py:125) and the actor-step sample pi(obs) (:151, it does not depend on the
     // critic update) straight into the two critic input buffers
     a->noise_c = noise_c;
-    EXORL_TRY(sample_actions2(a->fa.out, noise_c, a->noise_a, cfg.seed, &a->state->noise_counter, stddev, cfg.stddev_clip,
-                              a->xc_next + O, a->xc_pi + O, W, B, A, s));
+    EXORL_TRY(sample_actions2(a->fa.out, noise_c, cfg.kind == EXORL_AGENT_CRR ? nullptr : a->noise_a, cfg.seed,
+                              &a->state->noise_counter, stddev, cfg.stddev_clip, a->xc_next + O, a->xc_pi + O, W, B, A, s));
     EXORL_TRY(a->fk.fork(s));                   // target critic (td3_bc.py:126) and critic (td3_bc.py:130) forwards are independent
     EXORL_TRY(net_forward(a->critic, Pt, a->sh_target, a->xc_next, W, B, a->ft, false, false, prec, a->fk.side(s)));
     EXORL_TRY(net_forward(a->critic, Pc, a->sh_critic, a->xc_cur, W, B, a->fc, true, false, prec, s));
@@ -384,6 +395,16 @@ static int phase1(exorl_agent* a, float stddev, const float* noise_a, hipStream_
     EXORL_TRY(adam_step_dev(a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD],
                             a->flat[EXORL_NET_CRITIC][EXORL_T_ADAM_M], a->flat[EXORL_NET_CRITIC][EXORL_T_ADAM_V], a->critic.total,
                             &a->state->critic, a->flat[EXORL_NET_CRITIC_TARGET][EXORL_T_PARAM], &a->spec_critic, s));
+    if (cfg.kind == EXORL_AGENT_CRR) {          // crr.py:170-179 with the updated critic, no gradients
+        const int n = cfg.num_value_samples;
+        const float* Pc = a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM];
+        EXORL_TRY(repeat_sample(a->obs, a->fa.out + (int64_t)B * A, noise_a, cfg.seed, noise_a ? nullptr : &a->state->noise_counter, 1,
+                                stddev, cfg.stddev_clip, a->xc_rep, B, O, A, n, s));
+        EXORL_TRY(net_forward(a->critic, Pc, a->sh_critic, a->xc_rep, W, B * n, a->fr, false, false, prec, s));      // compute_value
+        EXORL_TRY(net_forward(a->critic, Pc, a->sh_critic, a->xc_cur, W, B, a->fc, false, false, prec, s));          // Q(s, a_data)
+        EXORL_TRY(crr_weights(a->fr.out, a->fc.out, a->crr_w, B, n, cfg.weight_func, s));
+        return 0;
+    }
     // pi(obs) sample already sits in xc_pi (phase 0); DDPG logs its log-prob (ddpg.py:276,289)
     if (cfg.kind == EXORL_AGENT_DDPG && a->want_metrics)
         EXORL_TRY(sample_action(a->fa.out + (int64_t)B * A, noise_spec(a, noise_a, 1), stddev, cfg.stddev_clip, 1, a->xc_pi + O, W, B, A,
@@ -398,7 +419,7 @@ static int phase2(exorl_agent* a, float stddev, hipStream_t s) {
     const auto& cfg = a->cfg;
     const int B = cfg.batch, O = cfg.obs_dim, A = cfg.act_dim, W = O + A, H = cfg.hidden_dim, prec = cfg.precision;
     const float* Pa = a->flat[EXORL_NET_ACTOR][EXORL_T_PARAM];
-    if (a->has_critic) {
+    if (a->has_critic && cfg.kind != EXORL_AGENT_CRR) {
         DoutSpec dq{};                          // -lambda/Bg routed to the smaller Q (td3_bc.py:152-155)
         dq.mode = EXORL_DOUT_ACTOR_Q; dq.q = a->fc.out; dq.stats = a->stats; dq.inv_bg = a->inv_bg; dq.alpha = cfg.alpha;
         dq.use_lambda = cfg.kind == EXORL_AGENT_TD3_BC;
@@ -413,11 +434,11 @@ static int phase2(exorl_agent* a, float stddev, hipStream_t s) {
         EXORL_TRY(net_forward(a->actor, Pa, a->sh_actor, a->xa + (int64_t)B * O, O, B, f, true, true, prec, s));
     if (a->want_metrics)                        // actor_loss / batch_reward(BC) metrics only (the gradient is formed in head_bwd)
         EXORL_TRY(actor_dmu(a->da, A, a->has_critic ? a->critic.n_trunks : 0, (int64_t)B * A, f.out, a->action,
-                            a->has_critic ? nullptr : a->reward, a->dpre, a->stats, a->metrics, B, A, a->inv_bg, cfg.alpha, cfg.kind,
-                            stddev, s));
+                            a->has_critic ? nullptr : a->reward, a->crr_w, a->dpre, a->stats, a->metrics, B, A, a->inv_bg, cfg.alpha,
+                            cfg.kind, stddev, s));
     DoutSpec dm{};
     dm.mode = EXORL_DOUT_ACTOR_MU; dm.da = a->da; dm.da_nets = a->has_critic ? a->critic.n_trunks : 0; dm.mu = f.out; dm.a_data = a->action;
-    dm.kind = cfg.kind; dm.inv_bg = a->inv_bg; dm.stddev = stddev;
+    dm.kind = cfg.kind; dm.inv_bg = a->inv_bg; dm.stddev = stddev; dm.w = a->crr_w;
     EXORL_TRY(net_backward(a->actor, Pa, a->sh_actor, a->flat[EXORL_NET_ACTOR][EXORL_T_GRAD], a->pa, a->xa + (int64_t)B * O, O, B, f,
                            dm, a->ba, nullptr, 0, 0, prec, s, a->fk));
     return 0;

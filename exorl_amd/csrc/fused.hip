@@ -66,28 +66,9 @@ __global__ __launch_bounds__(512) void trunk_fwd_kernel(const float* __restrict_
         const int c4 = lane + 64 * i;
         z[i] = c4 < H4 ? reinterpret_cast<const float4*>(b0 + net * pstride)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int k0 = 0; k0 < in_dim; k0 += TF_KC) {
-        const int kc = in_dim - k0 < TF_KC ? in_dim - k0 : TF_KC;
-        __syncthreads();
-        {   // stage the W0T chunk: 8 independent 16-byte loads in flight per thread, then the LDS writes
-            const float4* gsrc = reinterpret_cast<const float4*>(Wt + (int64_t)k0 * H);
-            const int n4 = kc * H4;
-            for (int i0 = tid; i0 < n4; i0 += 8 * 512) {
-                float4 t[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = i0 + u * 512;
-                    t[u] = i < n4 ? gsrc[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = i0 + u * 512;
-                    if (i < n4) reinterpret_cast<float4*>(ws)[i] = t[u];
-                }
-            }
-        }
-        __syncthreads();
-        for (int k = 0; k < kc; ++k) {
+    auto accumulate = [&](int kbeg, int kend, int k0) {        // z += x[k0+k] * W0T[k0+k][:] for staged k in [kbeg, kend)
+#pragma unroll 5
+        for (int k = kbeg; k < kend; ++k) {
             const float xv = xs[wave * MAX_IN + k0 + k];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -98,6 +79,40 @@ __global__ __launch_bounds__(512) void trunk_fwd_kernel(const float* __restrict_
                 }
             }
         }
+    };
+    for (int k0 = 0; k0 < in_dim; k0 += TF_KC) {
+        const int kc = in_dim - k0 < TF_KC ? in_dim - k0 : TF_KC;
+        // The chunk is staged in two halves: the global loads of the second half are in flight (8 x 16 B per thread)
+        // while the first half is being consumed, so only one memory round trip is exposed per chunk.
+        const float4* gsrc = reinterpret_cast<const float4*>(Wt + (int64_t)k0 * H);
+        const int kh = (kc + 1) >> 1;
+        const int n4a = kh * H4, n4 = kc * H4;
+        __syncthreads();                                       // previous chunk fully consumed
+        for (int i0 = tid; i0 < n4a; i0 += 8 * 512) {
+            float4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = i0 + u * 512 < n4a ? gsrc[i0 + u * 512] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + u * 512 < n4a) reinterpret_cast<float4*>(ws)[i0 + u * 512] = t[u];
+        }
+        float4 t2[8];                                          // second half (fits one batch for kc <= 32 at H = 1024)
+        const bool one_batch = n4 - n4a <= 8 * 512;
+        if (one_batch) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t2[u] = n4a + tid + u * 512 < n4 ? gsrc[n4a + tid + u * 512] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        accumulate(0, kh, k0);
+        if (one_batch) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (n4a + tid + u * 512 < n4) reinterpret_cast<float4*>(ws)[n4a + tid + u * 512] = t2[u];
+        } else {
+            for (int i = n4a + tid; i < n4; i += 512) reinterpret_cast<float4*>(ws)[i] = gsrc[i];
+        }
+        __syncthreads();
+        accumulate(kh, kc, k0);
     }
     float s = 0.f;
 #pragma unroll
@@ -332,6 +347,30 @@ int outer_reduce(const float* u, int64_t ldu, int J, const float* v, float* P, i
 }
 int outer_chunks(int rows) { return cdiv(rows, OR_ROWS); }
 
+// Sums 8 per-lane values over the wave with 10 cross-lane exchanges instead of 48: three butterfly steps that each
+// halve the number of live values (lane l ends up owning value index l & 7), then three plain steps over the remaining
+// 8-lane groups. Returns the wave total of value (lane & 7) in every lane.
+__device__ __forceinline__ float wave_sum8(const float (&v)[8], int lane) {
+    float a[4], b[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float keep = (lane & 1) ? v[2 * j + 1] : v[2 * j];
+        const float send = (lane & 1) ? v[2 * j] : v[2 * j + 1];
+        a[j] = keep + __shfl_xor(send, 1, 64);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float keep = (lane & 2) ? a[2 * j + 1] : a[2 * j];
+        const float send = (lane & 2) ? a[2 * j] : a[2 * j + 1];
+        b[j] = keep + __shfl_xor(send, 2, 64);
+    }
+    float r = ((lane & 4) ? b[1] : b[0]) + __shfl_xor((lane & 4) ? b[0] : b[1], 4, 64);
+    r += __shfl_xor(r, 8, 64);
+    r += __shfl_xor(r, 16, 64);
+    r += __shfl_xor(r, 32, 64);
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // head forward v2: out[m][j] = b[j] + sum_c a[m][c] W[j][c]; one wave per row, float4 streams (H % 4 == 0)
 template <int NO>
@@ -365,12 +404,23 @@ __global__ __launch_bounds__(256) void head_fwd4_kernel(const float* __restrict_
             }
         }
     }
+    if constexpr (NO == 1) {
+        float v = wave_sum(acc[0]) + (b ? b[net * pstride] : 0.f);
+        if (tanh_out) v = tanhf(v);
+        if (lane == 0) out[net * ostride + (int64_t)row * nout] = v;
+    } else {
 #pragma unroll
-    for (int j = 0; j < NO; ++j) {
-        if (j < nout) {
-            float v = wave_sum(acc[j]) + (b ? b[net * pstride + j] : 0.f);
-            if (tanh_out) v = tanhf(v);
-            if (lane == 0) out[net * ostride + (int64_t)row * nout + j] = v;
+        for (int g8 = 0; g8 < NO / 8; ++g8) {
+            float part[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part[j] = acc[8 * g8 + j];
+            const int j = 8 * g8 + (lane & 7);
+            float v = wave_sum8(part, lane);
+            if (lane < 8 && j < nout) {
+                v += b ? b[net * pstride + j] : 0.f;
+                if (tanh_out) v = tanhf(v);
+                out[net * ostride + (int64_t)row * nout + j] = v;
+            }
         }
     }
 }
@@ -411,6 +461,8 @@ __device__ __forceinline__ float dout_value(const DoutSpec& d, int net, int m, i
     float dmu;
     if (d.kind == EXORL_AGENT_BC) {
         dmu = -(d.a_data[i] - mv) / (d.stddev * d.stddev) * d.inv_bg;
+    } else if (d.kind == EXORL_AGENT_CRR) {
+        dmu = -d.w[m] * (d.a_data[i] - mv) / (d.stddev * d.stddev) * d.inv_bg;     // -(log_prob * w).mean(), crr.py:185-186
     } else {
         dmu = 0.f;
         for (int t = 0; t < d.da_nets; ++t) dmu += d.da[((int64_t)t * rows + m) * nout + j];

@@ -67,6 +67,7 @@ struct DoutSpec {
     const float *q, *tq, *reward, *discount;   // TD / ACTOR_Q: q, tq are (2, rows)
     const float* stats;      // ACTOR_Q: stats[0] = sum |Q| over the global batch
     const float *da, *mu, *a_data;             // ACTOR_MU: da (da_nets, rows, nout), mu / a_data (rows, nout)
+    const float* w;          // ACTOR_MU, CRR: per-sample advantage weight (rows)
     int da_nets;
     int kind;                // EXORL_AGENT_*
     int use_lambda;
@@ -165,12 +166,17 @@ int sample_actions2(const float* mu2, const float* noise_c, const float* noise_a
                     float stddev, float clip, float* dst_next, float* dst_pi, int64_t dst_ld, int B, int A, hipStream_t s);
 int sample_action(const float* mu, NoiseSpec noise, float stddev, float clip, int use_clip, float* dst, int64_t dst_ld,
                   int B, int A, float* logprob_sum, hipStream_t s);
+// CRR (crr.py:121-142): xc_rep[(b*n+i)] = [obs_b | TruncatedNormal(mu_b).sample(clip)] for i < n
+int repeat_sample(const float* obs, const float* mu, const float* noise, uint64_t seed, const uint64_t* counter_ptr, uint64_t counter,
+                  float stddev, float clip, float* xc_rep, int B, int O, int A, int n, hipStream_t s);
+// w_b = f(min(Q1,Q2)(s_b, a_b) - mean_i min(Q1,Q2)(s_b, a_bi))
+int crr_weights(const float* q_rep, const float* q_data, float* w, int B, int n, int weight_func, hipStream_t s);
 int critic_loss(const float* q, const float* tq, const float* reward, const float* discount, float* dq,
                 float* metrics, int B, float inv_bg, hipStream_t s);
 int actor_stats(const float* q, float* stats, int B, hipStream_t s);
 int actor_dq(const float* q, const float* stats, float* dq, int B, float inv_bg, float alpha, int use_lambda,
              hipStream_t s);
-int actor_dmu(const float* da, int64_t da_ld, int da_nets, int64_t da_net_stride, const float* mu, const float* a_data, const float* reward, float* dpre, float* stats,
+int actor_dmu(const float* da, int64_t da_ld, int da_nets, int64_t da_net_stride, const float* mu, const float* a_data, const float* reward, const float* w, float* dpre, float* stats,
               float* metrics, int B, int A, float inv_bg, float alpha, int kind, float stddev, hipStream_t s);
 
 // ---- optimiser (optim.hip)

@@ -124,6 +124,58 @@ int sample_actions2(const float* mu2, const float* noise_c, const float* noise_a
     return 0;
 }
 
+__global__ __launch_bounds__(256) void repeat_sample_kernel(const float* __restrict__ obs, const float* __restrict__ mu,
+                                                            const float* __restrict__ noise, uint64_t seed,
+                                                            const uint64_t* __restrict__ counter_ptr, uint64_t counter,
+                                                            float stddev, float clip, float* __restrict__ xc, int B, int O,
+                                                            int A, int n) {
+    const int W = O + A;
+    const int64_t total = (int64_t)B * n * W;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / W), c = (int)(i % W);
+        const int b = row / n;                              // einops 'b x -> (b n) x': row = b*n + sample
+        if (c < O) {
+            xc[i] = obs[b * O + c];
+        } else {
+            const int j = c - O, e = row * A + j;
+            const float z = noise ? noise[e] : philox_normal(seed, counter + (counter_ptr ? *counter_ptr : 0ull), (uint32_t)e);
+            const float eps = fminf(fmaxf(z * stddev, -clip), clip);
+            xc[i] = fminf(fmaxf(mu[b * A + j] + eps, -1.0f + 1e-6f), 1.0f - 1e-6f);
+        }
+    }
+}
+
+int repeat_sample(const float* obs, const float* mu, const float* noise, uint64_t seed, const uint64_t* counter_ptr, uint64_t counter,
+                  float stddev, float clip, float* xc_rep, int B, int O, int A, int n, hipStream_t s) {
+    const int64_t total = (int64_t)B * n * (O + A);
+    int blocks = cdiv(total, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(repeat_sample_kernel, dim3(blocks), dim3(256), 0, s, obs, mu, noise, seed, counter_ptr, counter, stddev, clip,
+                       xc_rep, B, O, A, n);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void crr_weights_kernel(const float* __restrict__ q_rep, const float* __restrict__ q_data,
+                                                          float* __restrict__ w, int B, int n, int weight_func) {
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+        float vsum = 0.f;
+        for (int i = 0; i < n; ++i) vsum += fminf(q_rep[b * n + i], q_rep[(int64_t)B * n + b * n + i]);
+        const float adv = fminf(q_data[b], q_data[B + b]) - vsum / (float)n;
+        float wv;
+        if (weight_func == EXORL_CRR_IDENTITY) wv = adv;
+        else if (weight_func == EXORL_CRR_INDICATOR) wv = adv > 0.f ? 1.0f : 0.0f;       // sign(relu(A))
+        else wv = fminf(fmaxf(expf(adv), 0.0f), 20.0f);
+        w[b] = wv;
+    }
+}
+
+int crr_weights(const float* q_rep, const float* q_data, float* w, int B, int n, int weight_func, hipStream_t s) {
+    hipLaunchKernelGGL(crr_weights_kernel, dim3(cdiv(B, 256)), dim3(256), 0, s, q_rep, q_data, w, B, n, weight_func);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
 int sample_action(const float* mu, NoiseSpec noise, float stddev, float clip, int use_clip, float* dst, int64_t dst_ld,
                   int B, int A, float* logprob_sum, hipStream_t s) {
     hipLaunchKernelGGL(sample_action_kernel, dim3(1), dim3(1024), 0, s, mu, noise, stddev, clip, use_clip, dst, dst_ld,
@@ -216,7 +268,8 @@ int actor_dq(const float* q, const float* stats, float* dq, int B, float inv_bg,
 __global__ __launch_bounds__(1024) void actor_dmu_kernel(const float* __restrict__ da, int64_t da_ld, int da_nets,
                                                          int64_t da_net_stride,
                                                          const float* __restrict__ mu, const float* __restrict__ a_data,
-                                                         const float* __restrict__ reward, float* __restrict__ dpre, const float* __restrict__ stats,
+                                                         const float* __restrict__ reward, const float* __restrict__ w,
+                                                         float* __restrict__ dpre, const float* __restrict__ stats,
                                                          float* __restrict__ metrics, int B, int A, float inv_bg,
                                                          float alpha, int kind, float stddev) {
     __shared__ float sm[2][16];
@@ -240,6 +293,10 @@ __global__ __launch_bounds__(1024) void actor_dmu_kernel(const float* __restrict
             const float d = a_data[i] - mv;
             dmu = -d * inv_var * inv_bg;
             v[0] += d * d * 0.5f * inv_var - log_norm;     // -log N(a; mu, std)
+        } else if (kind == EXORL_AGENT_CRR) {
+            const float d = a_data[i] - mv;
+            dmu = -w[m] * d * inv_var * inv_bg;
+            v[0] += w[m] * (d * d * 0.5f * inv_var - log_norm);   // -(log_prob * w), crr.py:186
         } else {
             dmu = 0.f;
             for (int t = 0; t < da_nets; ++t) dmu += da[t * da_net_stride + (int64_t)m * da_ld + j];
@@ -254,7 +311,7 @@ __global__ __launch_bounds__(1024) void actor_dmu_kernel(const float* __restrict
             const float lambda = alpha / (stats[0] * inv_bg);
             loss = -lambda * metrics[EXORL_M_Q_SUM] * inv_bg + v[0] * inv_bg / (float)A;
             metrics[EXORL_M_BC_SUM] = v[0];
-        } else if (kind == EXORL_AGENT_BC) {
+        } else if (kind == EXORL_AGENT_BC || kind == EXORL_AGENT_CRR) {
             loss = v[0] * inv_bg;
         } else {
             loss = -metrics[EXORL_M_Q_SUM] * inv_bg;
@@ -263,9 +320,9 @@ __global__ __launch_bounds__(1024) void actor_dmu_kernel(const float* __restrict
     }
 }
 
-int actor_dmu(const float* da, int64_t da_ld, int da_nets, int64_t da_net_stride, const float* mu, const float* a_data, const float* reward, float* dpre, float* stats,
+int actor_dmu(const float* da, int64_t da_ld, int da_nets, int64_t da_net_stride, const float* mu, const float* a_data, const float* reward, const float* w, float* dpre, float* stats,
               float* metrics, int B, int A, float inv_bg, float alpha, int kind, float stddev, hipStream_t s) {
-    hipLaunchKernelGGL(actor_dmu_kernel, dim3(1), dim3(1024), 0, s, da, da_ld, da_nets, da_net_stride, mu, a_data, reward, dpre, stats, metrics, B, A,
+    hipLaunchKernelGGL(actor_dmu_kernel, dim3(1), dim3(1024), 0, s, da, da_ld, da_nets, da_net_stride, mu, a_data, reward, w, dpre, stats, metrics, B, A,
                        inv_bg, alpha, kind, stddev);
     EXORL_LAUNCH_CHECK();
     return 0;

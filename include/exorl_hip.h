@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EXORL_ABI_VERSION 1
+#define EXORL_ABI_VERSION 2
 
 const char* exorl_last_error(void);
 int exorl_abi_version(void);
@@ -104,6 +104,11 @@ typedef struct exorl_agent exorl_agent_t;
 #define EXORL_AGENT_TD3    1
 #define EXORL_AGENT_BC     2
 #define EXORL_AGENT_DDPG   3   /* states; shared-trunk critic (ddpg.py:79-123) */
+#define EXORL_AGENT_CRR    4   /* agents/offline_learning/crr.py:59-219 */
+
+#define EXORL_CRR_IDENTITY  0   /* crr.py:132-142 adv_transform */
+#define EXORL_CRR_INDICATOR 1
+#define EXORL_CRR_EXP       2
 
 #define EXORL_PREC_F32  0      /* v_mfma_f32_32x32x2_f32: exact fp32 products, parity mode */
 #define EXORL_PREC_BF16 1      /* v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulate, fp32 master weights */
@@ -139,6 +144,8 @@ typedef struct {
     int32_t reserved;
     float   lr, tau, alpha, stddev_clip;
     uint64_t seed;            /* Philox stream for action noise when no noise buffer is given */
+    int32_t num_value_samples; /* CRR: actions sampled per state for V(s) (crr.yaml: 10) */
+    int32_t weight_func;       /* CRR: EXORL_CRR_* */
 } exorl_agent_cfg;
 
 size_t exorl_agent_workspace_bytes(const exorl_agent_cfg* cfg);
@@ -164,8 +171,8 @@ int exorl_agent_set_batch(exorl_agent_t* a, const float* obs_dev, const float* a
                           const float* reward_dev, const float* discount_dev, const float* next_obs_dev,
                           void* stream);
 /* One gradient step on the batch currently in the batch slots.
- * noise_critic_dev / noise_actor_dev: (B,A) standard-normal draws (reference order) or NULL
- * for device Philox. Runs phases 0..3 back to back (world_size 1). */
+ * noise_critic_dev / noise_actor_dev: (B,A) standard-normal draws (reference order; for CRR the second
+ * draw is (B*num_value_samples, A), crr.py:125) or NULL for device Philox. Runs phases 0..3 back to back (world_size 1). */
 int exorl_agent_update(exorl_agent_t* a, float stddev, const float* noise_critic_dev,
                        const float* noise_actor_dev, void* stream);
 /* Data-parallel form: the caller all-reduces (sum) between phases:

@@ -29,6 +29,8 @@ def param_shapes(kind, O, A, H):
     actor = list(zip(ACTOR_KEYS_DDPG if ddpg else ACTOR_KEYS_OFFLINE, tr(O) + hd(A)))
     if kind == 'bc':
         return actor, None
+    if kind == 'cql':
+        actor = list(zip(ACTOR_KEYS_OFFLINE, tr(O) + hd(2 * A)))
     if ddpg:
         critic = list(zip(CRITIC_KEYS_DDPG, tr(O + A) + hd(1) + hd(1)))
     else:
@@ -43,15 +45,17 @@ def _min_grad(q1, q2):
 
 
 class OracleAgent:
-    """kind in {'td3_bc','td3','bc','ddpg'}; params are lists of float32 arrays (reference order)."""
+    """kind in {'td3_bc','td3','bc','ddpg','crr'}; params are lists of float32 arrays (reference order)."""
 
     def __init__(self, kind, actor_params, critic_params=None, lr=1e-4, tau=0.01, stddev_schedule='0.2',
-                 stddev_clip=0.3, alpha=2.5, update_every_steps=2, world_size=1, allreduce=None):
+                 stddev_clip=0.3, alpha=2.5, update_every_steps=2, world_size=1, allreduce=None,
+                 num_value_samples=10, weight_func='indicator'):
         """world_size > 1: this instance is one data-parallel rank holding a shard of the global batch; `allreduce`
         (list of float32 arrays -> summed in place across ranks) is called at the three points where the reference's
         single-process update needs a batch-global quantity: critic grads, sum|Q| (td3_bc.py:154),
         actor grads. Means are over batch*world_size, so the ranks end up with the large-batch update."""
         self.world_size, self.allreduce = world_size, allreduce
+        self.num_value_samples, self.weight_func = num_value_samples, weight_func
         self.kind = kind
         self.actor = [np.array(p, F32) for p in actor_params]
         self.actor_opt = Adam(self.actor, lr)
@@ -117,6 +121,33 @@ class OracleAgent:
             m['actor_logprob'] = float(lp[0])
         return m, grads
 
+    # crr.py:121-142,170-196
+    def update_actor_crr(self, obs, action, std, noise):
+        n, (Bl, A) = self.num_value_samples, action.shape
+        B = Bl * self.world_size
+        mu, cache = ActorNet.fwd(self.actor, obs)
+        obses = np.repeat(obs, n, axis=0)                       # 'b x -> (b n) x'
+        acts = nets.truncated_normal_sample(np.repeat(mu, n, axis=0), noise, std, self.clip)
+        q1r, q2r, _ = self.C.fwd(self.critic, obses, acts)
+        V = np.minimum(q1r, q2r).reshape(Bl, n, 1).mean(1, dtype=F32)
+        q1, q2, _ = self.C.fwd(self.critic, obs, action)
+        adv = (np.minimum(q1, q2) - V).astype(F32)
+        if self.weight_func == 'identity':
+            w = adv
+        elif self.weight_func == 'indicator':
+            w = np.sign(np.maximum(adv, F32(0))).astype(F32)
+        else:
+            w = np.clip(np.exp(adv), F32(0), F32(20.0)).astype(F32)
+        logp = nets.normal_log_prob(action, mu, std).sum(-1, keepdims=True)
+        loss = np.array([-(logp * w).sum(dtype=F32) / F32(B)], F32)
+        dmu = (-w * (action - mu) / (F32(std) * F32(std)) / F32(B)).astype(F32)
+        grads = ActorNet.bwd(self.actor, cache, dmu)
+        if self.world_size > 1:
+            self.allreduce(grads + [loss])
+        self.actor_opt.step(self.actor, grads)
+        self.last_w = w
+        return dict(actor_loss=float(loss[0]), actor_ent=float(nets.normal_entropy(std) * A)), grads
+
     # bc.py:78-95
     def update_bc(self, obs, action, std):
         mu, cache = ActorNet.fwd(self.actor, obs)
@@ -147,7 +178,10 @@ class OracleAgent:
             return m
         mc, self.last_critic_grads = self.update_critic(obs, action, reward, discount, next_obs, std, noise_critic)
         m.update(mc)
-        ma, self.last_actor_grads = self.update_actor(obs, action, std, noise_actor)
+        if self.kind == 'crr':
+            ma, self.last_actor_grads = self.update_actor_crr(obs, action, std, noise_actor)
+        else:
+            ma, self.last_actor_grads = self.update_actor(obs, action, std, noise_actor)
         m.update(ma)
         nets.soft_update(self.critic, self.critic_target, self.tau)
         return m

@@ -18,6 +18,9 @@ def make(kind, O, A, H, B, use_tb=True, precision='fp32'):
         return agents.TD3BCAgent('td3_bc', (O,), (A,), 'cuda', 1e-4, H, 0.01, 0.2, 1, B, 0.3, use_tb, 2.5, precision=precision)
     if kind == 'td3':
         return agents.TD3Agent('td3', (O,), (A,), 'cuda', 1e-4, H, 0.01, 0.2, 1, B, 0.3, use_tb, precision=precision)
+    if kind.startswith('crr'):
+        wf = kind.partition('-')[2] or 'indicator'
+        return agents.CRRAgent('crr', (O,), (A,), 'cuda', 1e-4, H, 0.01, 10, wf, 0.2, 1, B, 0.3, use_tb, precision=precision)
     if kind == 'bc':
         return agents.BCAgent('bc', (O,), (A,), 'cuda', 1e-4, H, B, 0.2, use_tb, precision=precision)
     return agents.DDPGAgent('ddpg', True, 'states', (O,), (A,), 'cuda', 1e-4, 50, H, 0.01, 2000, 2, 0.2, 3, B, 0.3, True,
@@ -28,7 +31,7 @@ def nets_of(ag):
     return [('actor', ag.actor)] + ([('critic', ag.critic), ('critic_target', ag.critic_target)] if hasattr(ag, 'critic') else [])
 
 
-@pytest.mark.parametrize('kind', ['td3_bc', 'td3', 'bc', 'ddpg'])
+@pytest.mark.parametrize('kind', ['td3_bc', 'td3', 'bc', 'ddpg', 'crr', 'crr-exp', 'crr-identity'])
 def test_tiny_trajectory_vs_reference(gold, kind):
     """Seeded construction reproduces the reference's init; 5 update() calls reproduce its metrics and weights."""
     z = np.load(gold / f'tiny_{kind}.npz')
@@ -57,7 +60,7 @@ def test_tiny_trajectory_vs_reference(gold, kind):
 
 
 def load_synth(ag, kind, O, A, H, seed):
-    ash, csh = param_shapes(kind, O, A, H)
+    ash, csh = param_shapes(kind.partition('-')[0], O, A, H)
     pa = _synth.synth_params(ash, seed)
     ag.actor.load_state_dict({k: torch.from_numpy(v) for k, v in pa.items()})
     pc = None
@@ -68,7 +71,7 @@ def load_synth(ag, kind, O, A, H, seed):
     return list(pa.values()), (list(pc.values()) if pc else None)
 
 
-@pytest.mark.parametrize('kind', ['td3_bc', 'td3', 'bc', 'ddpg'])
+@pytest.mark.parametrize('kind', ['td3_bc', 'td3', 'bc', 'ddpg', 'crr'])
 def test_full_size_vs_reference_fp32(gold, kind):
     """BASELINE dims (H=1024; B=1024, BC 256). North-star bar: per-step losses within 1e-4 rtol of the
     reference PyTorch-CPU fp32 path (tests/golden/full_*.json), 10 steps; final parameter checksums too."""
@@ -191,7 +194,7 @@ def _arena(seed):
     return eng, ArenaIterator(eng, 64, 1, 0.99, 'philox')
 
 
-@pytest.mark.parametrize('kind', ['td3_bc', 'bc', 'ddpg'])
+@pytest.mark.parametrize('kind', ['td3_bc', 'bc', 'ddpg', 'crr'])
 def test_hip_graph_step_equals_eager(kind):
     """The captured sample+update graph replays exactly what the eager launches do (counters live on device)."""
     O, A, H, B = 24, 6, 128, 64
@@ -218,7 +221,7 @@ def test_hip_graph_step_equals_eager(kind):
     assert m1 == m2
 
 
-@pytest.mark.parametrize('kind', ['td3_bc', 'ddpg', 'bc'])
+@pytest.mark.parametrize('kind', ['td3_bc', 'ddpg', 'bc', 'crr'])
 def test_virtual_ranks_equal_single_rank(kind):
     """The HIP engine's phase split (exorl_agent_update_phase) under data parallelism: two engines configured with
     world_size=2 each take half of a global batch; summing their gradient / statistic buffers between phases (what
@@ -248,13 +251,14 @@ def test_virtual_ranks_equal_single_rank(kind):
     ns = _synth.NoiseStream(4)
     for step in range(3):
         batch = _synth.synth_batch(6, step, B, O, A)
-        n1, n2 = ns.draw((B, A)), ns.draw((B, A))
+        n2rows = B * 10 if kind == 'crr' else B              # CRR's second draw is (B * num_value_samples, A)
+        n1, n2 = ns.draw((B, A)), ns.draw((n2rows, A))
         single.set_batch(*batch)
         single.update(0.2, n1, n2)
         for r, e in enumerate(ranks):
             sl = slice(r * B // 2, (r + 1) * B // 2)
             e.set_batch(*[x[sl] for x in batch])
-        sh = [(n1[:B // 2], n2[:B // 2]), (n1[B // 2:], n2[B // 2:])]
+        sh = [(n1[:B // 2], n2[:n2rows // 2]), (n1[B // 2:], n2[n2rows // 2:])]
         for e, (a, b) in zip(ranks, sh):
             e.update_phase(0, 0.2, a, b)
         if pc:

@@ -62,7 +62,7 @@ def test_rms_pbe_knn(gold):
 def _load_tiny(gold, kind):
     z = np.load(gold / f'tiny_{kind}.npz')
     O, A, H = 5, 3, 32
-    ash, csh = param_shapes(kind, O, A, H)
+    ash, csh = param_shapes(kind.partition('-')[0], O, A, H)
     actor = [z[f'init/actor/{k}'] for k, _ in ash]
     for (k, s), p in zip(ash, actor):
         assert tuple(p.shape) == tuple(s), (k, p.shape, s)
@@ -70,10 +70,12 @@ def _load_tiny(gold, kind):
     return z, ash, csh, actor, critic
 
 
-@pytest.mark.parametrize('kind', ['td3_bc', 'td3', 'bc', 'ddpg'])
+@pytest.mark.parametrize('kind', ['td3_bc', 'td3', 'bc', 'ddpg', 'crr', 'crr-exp', 'crr-identity'])
 def test_tiny_trajectory(gold, kind):
     z, ash, csh, actor, critic = _load_tiny(gold, kind)
-    ag = OracleAgent(kind, actor, critic)
+    base, _, wf = kind.partition('-')
+    ag = OracleAgent(base, actor, critic, **({'weight_func': wf} if wf else {}))
+    kind = base
     keys = [str(k) for k in z['metric_keys']]
     ni = 0
     for i in range(5):
@@ -100,7 +102,7 @@ def test_ddpg_skips_odd_steps(gold):
     assert ag.update(None, 1) == {}        # ddpg.py:302-303, no batch consumed
 
 
-@pytest.mark.parametrize('kind', ['td3_bc', 'bc'])
+@pytest.mark.parametrize('kind', ['td3_bc', 'bc', 'crr'])
 def test_full_size_trajectory(gold, kind):
     """BASELINE dims (H=1024). North-star tolerance: per-step losses to 1e-4 rtol vs the reference fp32 path."""
     g = json.load(open(gold / f'full_{kind}.json'))
@@ -116,7 +118,7 @@ def test_full_size_trajectory(gold, kind):
         if kind == 'bc':
             m = ag.update(batch, i)
         else:
-            m = ag.update(batch, i, noise.draw((B, A)), noise.draw((B, A)))
+            m = ag.update(batch, i, noise.draw((B, A)), noise.draw((10 * B if kind == 'crr' else B, A)))
         ref = g['fp32']['metrics'][i]
         for k, v in ref.items():
             assert abs(m[k] - v) <= 1e-4 * abs(v) + 1e-6, (kind, i, k, m[k], v)

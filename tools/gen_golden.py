@@ -176,13 +176,15 @@ def gen_utils(ref):
 
 
 # ----------------------------------------------------------------------------- agents (G3/G4)
-def make_agent(ref, kind, O, A, H, B, device='cpu', use_tb=True):
+def make_agent(ref, kind, O, A, H, B, device='cpu', use_tb=True, **kw):
     if kind == 'td3_bc':
         return ref.td3_bc.TD3BCAgent('td3_bc', (O,), (A,), device, 1e-4, H, 0.01, 0.2, 1, B, 0.3, use_tb, 2.5)
     if kind == 'td3':
         return ref.td3.TD3Agent('td3', (O,), (A,), device, 1e-4, H, 0.01, 0.2, 1, B, 0.3, use_tb)
     if kind == 'bc':
         return ref.bc.BCAgent('bc', (O,), (A,), device, 1e-4, H, B, 0.2, use_tb)
+    if kind == 'crr':
+        return ref.crr.CRRAgent('crr', (O,), (A,), device, 1e-4, H, 0.01, 10, kw.get('weight_func', 'indicator'), 0.2, 1, B, 0.3, use_tb)
     if kind == 'ddpg':
         return ref.ddpg.DDPGAgent('ddpg', True, 'states', (O,), (A,), device, 1e-4, 50, H, 0.01, 2000, 2,
                                   0.2, 3, B, 0.3, True, use_tb, False)
@@ -221,11 +223,15 @@ def checksums(agent):
     return cs
 
 
+TINY_KINDS = ('td3_bc', 'td3', 'bc', 'ddpg', 'crr', 'crr-exp', 'crr-identity')
+
+
 def gen_tiny(ref):
     O, A, H, B, N = 5, 3, 32, 8, 5
-    for kind in ('td3_bc', 'td3', 'bc', 'ddpg'):
+    for kind in TINY_KINDS:
         torch.manual_seed(21)
-        agent = make_agent(ref, kind, O, A, H, B)
+        base, _, wf = kind.partition('-')
+        agent = make_agent(ref, base, O, A, H, B, **({'weight_func': wf} if wf else {}))
         out = {}
         for nm, net in nets_of(agent):
             for k, v in net.state_dict().items():
@@ -242,7 +248,7 @@ def gen_tiny(ref):
                 return x
         rec = Rec()
         batches = [_synth.synth_batch(31, i, B, O, A) for i in range(N)]
-        metrics = run_agent(ref, agent, kind, N, lambda i: batches[i], rec, np.float32)
+        metrics = run_agent(ref, agent, base, N, lambda i: batches[i], rec, np.float32)
         for i, b in enumerate(batches):
             for j, t in enumerate(b):
                 out[f'batch/{i}/{j}'] = t
@@ -263,12 +269,15 @@ FULL = {  # kind: (O, A, H, B)  — BASELINE.json configs (walker / cheetah shap
     'td3': (17, 6, 1024, 1024),
     'bc': (24, 6, 1024, 256),
     'ddpg': (24, 6, 1024, 1024),
+    'crr': (24, 6, 1024, 1024),
 }
 
 
-def gen_full(ref, nsteps=10):
+def gen_full(ref, nsteps=10, only_kinds=None):
     torch.set_num_threads(1)
     for kind, (O, A, H, B) in FULL.items():
+        if only_kinds and kind not in only_kinds:
+            continue
         res = {'dims': [O, A, H, B], 'nsteps': nsteps, 'param_seed': 5, 'batch_seed': 9, 'noise_seed': 13}
         for tag, dtype, tdt in (('fp32', np.float32, torch.float32), ('fp64', np.float64, torch.float64)):
             agent = make_agent(ref, kind, O, A, H, B)
@@ -293,9 +302,16 @@ def gen_full(ref, nsteps=10):
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default=None)
+    ap.add_argument('--kinds', default=None, help='comma list: restrict tiny/full generation to these agent kinds')
     args = ap.parse_args()
     GOLD.mkdir(parents=True, exist_ok=True)
     ref = load_reference()
     todo = [args.only] if args.only else ['replay', 'utils', 'tiny', 'full']
+    kinds = args.kinds.split(',') if args.kinds else None
+    if kinds:
+        TINY_KINDS = tuple(k for k in TINY_KINDS if k.partition('-')[0] in kinds)
     for t in todo:
-        {'replay': gen_replay, 'utils': gen_utils, 'tiny': gen_tiny, 'full': gen_full}[t](ref)
+        if t == 'full':
+            gen_full(ref, only_kinds=kinds)
+        else:
+            {'replay': gen_replay, 'utils': gen_utils, 'tiny': gen_tiny}[t](ref)
