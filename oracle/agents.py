@@ -185,3 +185,123 @@ class OracleAgent:
         m.update(ma)
         nets.soft_update(self.critic, self.critic_target, self.tau)
         return m
+
+
+# ---------------------------------------------------------------------------------------------------
+# CQL (agents/offline_learning/cql.py:59-286): SAC-style tanh-Gaussian actor (2A outputs), TD loss + conservative
+# penalty over 3*n_samples re-evaluations of the critic, entropy-tuned actor.
+# ---------------------------------------------------------------------------------------------------
+def _softplus(x):
+    return np.logaddexp(F32(0), x).astype(F32)
+
+
+def squashed_log_prob(x, mu, std):
+    """TransformedDistribution(Normal(mu,std), TanhTransform).log_prob(tanh(x)) with x from the transform cache
+    (utils.py:152-196): Normal.log_prob(x) - 2 (log 2 - x - softplus(-2x)), per element."""
+    var = (std * std).astype(F32)
+    base = (-((x - mu) ** 2) / (F32(2) * var) - np.log(std) - F32(np.log(np.sqrt(2 * np.pi)))).astype(F32)
+    ladj = (F32(2.0) * (F32(np.log(2.0)) - x - _softplus(F32(-2.0) * x))).astype(F32)
+    return (base - ladj).astype(F32)
+
+
+def uniform_from_normal(z):
+    """The fixtures route Tensor.uniform_(-1,1) through the normal noise stream: u = -1 + 2 Phi(z) (tools/gen_golden.py)."""
+    from math import erf, sqrt
+    u = 0.5 * (1.0 + np.vectorize(erf)(z.astype(np.float64) / sqrt(2.0)))
+    return (-1.0 + 2.0 * u).astype(F32)
+
+
+class OracleCQL:
+    def __init__(self, actor_params, critic_params, lr=1e-4, tau=0.01, alpha=0.01, n_samples=3, world_size=1, allreduce=None):
+        self.actor = [np.array(p, F32) for p in actor_params]
+        self.critic = [np.array(p, F32) for p in critic_params]
+        self.critic_target = [p.copy() for p in self.critic]
+        self.actor_opt, self.critic_opt = Adam(self.actor, lr), Adam(self.critic, lr)
+        self.log_actor_alpha = [np.zeros(1, F32)]
+        self.actor_alpha_opt = Adam(self.log_actor_alpha, lr)
+        self.tau, self.alpha, self.n = tau, alpha, n_samples
+        self.world_size, self.allreduce = world_size, allreduce
+
+    def policy(self, obs):
+        raw, cache = ActorNet.fwd_raw(self.actor, obs)
+        A = raw.shape[1] // 2
+        mu = np.tanh(raw[:, :A]).astype(F32)
+        ls = raw[:, A:]
+        std = np.exp(np.clip(ls, F32(-10), F32(2))).astype(F32)
+        return mu, std, ls, cache
+
+    def update(self, batch, step, z_next, z_rand, z_cur, z_nxt, z_actor, rand_is_uniform=False):
+        obs, action, reward, discount, next_obs = [np.asarray(x, F32) for x in batch[:5]]
+        Bl, A = action.shape
+        B, n = Bl * self.world_size, self.n
+        m = dict(batch_reward=float(reward.mean(dtype=F32)))
+        # ---- critic (cql.py:152-232)
+        mu_n, std_n, _, _ = self.policy(next_obs)
+        mu_c, std_c, _, _ = self.policy(obs)
+        next_action = np.tanh(mu_n + std_n * z_next).astype(F32)
+        tq1, tq2, _ = TwinCritic.fwd(self.critic_target, next_obs, next_action)
+        y = (reward + discount * np.minimum(tq1, tq2)).astype(F32)
+        rand = z_rand if rand_is_uniform else uniform_from_normal(z_rand)
+        acts = np.concatenate([rand.reshape(n * Bl, A),
+                               np.tanh(mu_c[None] + std_c[None] * z_cur).astype(F32).reshape(n * Bl, A),
+                               np.tanh(mu_n[None] + std_n[None] * z_nxt).astype(F32).reshape(n * Bl, A),
+                               action], 0)
+        obs_all = np.concatenate([np.tile(obs, (3 * n, 1)), obs], 0)                 # repeat(n,1,1): sample-major rows
+        q1a, q2a, caches = TwinCritic.fwd(self.critic, obs_all, acts)
+        q1, q2 = q1a[3 * n * Bl:], q2a[3 * n * Bl:]
+        dqs, lse_sum = [], F32(0)
+        for qa, q in ((q1a, q1), (q2a, q2)):
+            cat = qa.reshape(3 * n + 1, Bl, 1)
+            mx = cat.max(0, keepdims=True)
+            ex = np.exp(cat - mx).astype(F32)
+            se = ex.sum(0, keepdims=True, dtype=F32)
+            lse_sum = lse_sum + (np.log(se) + mx).sum(dtype=F32) / F32(B)
+            w = (ex / se).astype(F32)                                                  # d logsumexp / d q
+            d = (F32(self.alpha) * w / F32(B)).astype(F32)
+            d[-1] += (F32(2) * (q - y) / F32(B) - F32(self.alpha) / F32(B)).astype(F32)
+            dqs.append(d.reshape(-1, 1))
+        e1, e2 = q1 - y, q2 - y
+        mse = ((e1 * e1).sum(dtype=F32) + (e2 * e2).sum(dtype=F32)) / F32(B)
+        penalty = lse_sum - (q1 + q2).sum(dtype=F32) / F32(B)
+        grads, _ = TwinCritic.bwd(self.critic, caches, dqs[0], dqs[1], need_dx=False)
+        if self.world_size > 1:
+            self.allreduce(grads)
+        self.critic_opt.step(self.critic, grads)
+        m.update(critic_target_q=float(y.mean(dtype=F32)), critic_q1=float(q1.mean(dtype=F32)), critic_q2=float(q2.mean(dtype=F32)),
+                 critic_loss=float(mse + F32(self.alpha) * penalty), critic_cql=float(penalty), critic_cql_logsum=float(lse_sum))
+        self.last_critic_grads = grads
+        # ---- actor (cql.py:234-263)
+        mu, std, ls, cache = self.policy(obs)
+        x = (mu + std * z_actor).astype(F32)
+        yact = np.tanh(x).astype(F32)
+        log_pi = squashed_log_prob(x, mu, std)
+        target_entropy = F32(-A)
+        s_lp = np.array([log_pi.sum(dtype=F32)], F32)
+        if self.world_size > 1:
+            self.allreduce([s_lp])
+        mean_lp = s_lp[0] / F32(B * A)
+        alpha_loss = -(self.log_actor_alpha[0][0] * (mean_lp + target_entropy))
+        self.actor_alpha_opt.step(self.log_actor_alpha, [np.array([-(mean_lp + target_entropy)], F32)])
+        alpha = np.exp(self.log_actor_alpha[0][0]).astype(F32)
+        q1p, q2p, cc = TwinCritic.fwd(self.critic, obs, yact)
+        w1, w2 = _min_grad(q1p, q2p)
+        dq = np.full_like(q1p, F32(-1.0) / F32(B))
+        _, dx = TwinCritic.bwd(self.critic, cc, (dq * w1).astype(F32), (dq * w2).astype(F32), need_dx=True)
+        dy = dx[:, obs.shape[1]:]
+        gx = (dy * (F32(1) - yact * yact)).astype(F32)                        # through y = tanh(x)
+        c = alpha / F32(B * A)
+        dmu = (gx + c * F32(2) * yact).astype(F32)                            # d log_pi / d mu = 2 tanh(x)
+        dstd = (gx * z_actor + c * (F32(-1) / std + F32(2) * yact * z_actor)).astype(F32)
+        draw_mu = (dmu * (F32(1) - mu * mu)).astype(F32)
+        inside = ((ls >= F32(-10)) & (ls <= F32(2))).astype(F32)              # clamp passes gradient on [min, max]
+        draw_ls = (dstd * std * inside).astype(F32)
+        grads = ActorNet.bwd_raw(self.actor, cache, np.concatenate([draw_mu, draw_ls], 1))
+        if self.world_size > 1:
+            self.allreduce(grads)
+        self.actor_opt.step(self.actor, grads)
+        qmin = np.minimum(q1p, q2p)
+        m.update(actor_loss=float(alpha * mean_lp - qmin.sum(dtype=F32) / F32(B)), actor_ent=float(-mean_lp),
+                 actor_alpha=float(alpha), actor_alpha_loss=float(alpha_loss))
+        self.last_actor_grads = grads
+        nets.soft_update(self.critic, self.critic_target, self.tau)
+        return m

@@ -106,6 +106,20 @@ class ActorNet:
         g_trunk, _ = Trunk.bwd(p[0:4], c1, dh, need_dx=False)
         return g_trunk + g_head
 
+    # raw head outputs, no final tanh (CQL's 2A-wide actor, cql.py:12-31)
+    @staticmethod
+    def fwd_raw(p, obs):
+        h, c1 = Trunk.fwd(p[0:4], obs)
+        pre, c2 = Head.fwd(p[4:8], h)
+        return pre, (c1, c2)
+
+    @staticmethod
+    def bwd_raw(p, cache, dpre):
+        c1, c2 = cache
+        g_head, dh = Head.bwd(p[4:8], c2, dpre)
+        g_trunk, _ = Trunk.bwd(p[0:4], c1, dh, need_dx=False)
+        return g_trunk + g_head
+
 
 class TwinCritic:
     """Offline Critic (td3_bc.py:33-56): two independent trunk+head nets on cat(obs, action).

@@ -122,3 +122,24 @@ def test_full_size_trajectory(gold, kind):
         ref = g['fp32']['metrics'][i]
         for k, v in ref.items():
             assert abs(m[k] - v) <= 1e-4 * abs(v) + 1e-6, (kind, i, k, m[k], v)
+
+
+def test_cql_tiny_trajectory(gold):
+    """Oracle CQL vs the reference's CQLAgent (tiny_cql.npz): all 11 metrics, final weights and log_actor_alpha."""
+    from oracle.agents import OracleCQL
+    z, ash, csh, actor, critic = _load_tiny(gold, 'cql')
+    ag = OracleCQL(actor, critic)
+    keys = [str(k) for k in z['metric_keys']]
+    ni = 0
+    for i in range(5):
+        batch = [z[f'batch/{i}/{j}'] for j in range(5)]
+        m = ag.update(batch, i, *[z[f'noise/{ni + k}'] for k in range(5)])
+        ni += 5
+        got = np.array([m[k] for k in keys])
+        np.testing.assert_allclose(got, z['metrics'][i], rtol=3e-5, atol=3e-6, err_msg=f'cql step {i} {keys}')
+    for (k, _), p in zip(ash, ag.actor):
+        np.testing.assert_allclose(p, z[f'final/actor/{k}'], rtol=1e-4, atol=2e-6, err_msg=k)
+    for (k, _), p, t in zip(csh, ag.critic, ag.critic_target):
+        np.testing.assert_allclose(p, z[f'final/critic/{k}'], rtol=1e-4, atol=2e-6, err_msg=k)
+        np.testing.assert_allclose(t, z[f'final/critic_target/{k}'], rtol=1e-4, atol=2e-6, err_msg=k)
+    np.testing.assert_allclose(ag.log_actor_alpha[0], z['final/log_actor_alpha'], rtol=1e-5, atol=1e-8)

@@ -183,6 +183,9 @@ def make_agent(ref, kind, O, A, H, B, device='cpu', use_tb=True, **kw):
         return ref.td3.TD3Agent('td3', (O,), (A,), device, 1e-4, H, 0.01, 0.2, 1, B, 0.3, use_tb)
     if kind == 'bc':
         return ref.bc.BCAgent('bc', (O,), (A,), device, 1e-4, H, B, 0.2, use_tb)
+    if kind == 'cql':
+        return ref.cql.CQLAgent('cql', (O,), (A,), device, 1e-4, H, 0.01, 1, B, use_tb, kw.get('alpha', 0.01), 3, 5.0,
+                                kw.get('use_critic_lagrange', False))
     if kind == 'crr':
         return ref.crr.CRRAgent('crr', (O,), (A,), device, 1e-4, H, 0.01, 10, kw.get('weight_func', 'indicator'), 0.2, 1, B, 0.3, use_tb)
     if kind == 'ddpg':
@@ -193,6 +196,7 @@ def make_agent(ref, kind, O, A, H, B, device='cpu', use_tb=True, **kw):
 
 def nets_of(agent):
     nets = [('actor', agent.actor)]
+    # (CQL's log_actor_alpha / log_critic_alpha scalars are stored separately by gen_tiny)
     if hasattr(agent, 'critic'):
         nets += [('critic', agent.critic), ('critic_target', agent.critic_target)]
     return nets
@@ -203,6 +207,25 @@ def run_agent(ref, agent, kind, nsteps, batch_fn, noise, dtype):
     U = ref.utils
     orig = U._standard_normal
     U._standard_normal = lambda shape, dtype, device: torch.from_numpy(noise.draw(shape)).to(dtype)
+    # CQL draws through three other doors (cql.py:159,170-176,238): torch.normal (Normal.sample), Tensor.uniform_ and
+    # torch.distributions.normal._standard_normal (Normal.rsample). Route them all to the same deterministic stream;
+    # uniform draws are U(-1,1) made from the stream's normals by the probability integral transform.
+    import math
+    import torch.distributions.normal as tdn
+    o_normal, o_uniform, o_sn = torch.normal, torch.Tensor.uniform_, tdn._standard_normal
+
+    def p_normal(mean, std, *a, **k):
+        z = torch.from_numpy(noise.draw(tuple(mean.shape))).to(mean.dtype)
+        return mean + std * z
+
+    def p_uniform(self, lo=0.0, hi=1.0, **k):
+        z = noise.draw(tuple(self.shape)).astype(np.float64)
+        u = 0.5 * (1.0 + np.vectorize(math.erf)(z / math.sqrt(2.0)))
+        self.copy_(torch.from_numpy(lo + (hi - lo) * u).to(self.dtype))
+        return self
+    if kind == 'cql':
+        torch.normal, torch.Tensor.uniform_ = p_normal, p_uniform
+        tdn._standard_normal = lambda shape, dtype, device: torch.from_numpy(noise.draw(shape)).to(dtype)
     metrics = []
     try:
         for i in range(nsteps):
@@ -212,6 +235,7 @@ def run_agent(ref, agent, kind, nsteps, batch_fn, noise, dtype):
             metrics.append({k: float(v) for k, v in m.items()})
     finally:
         U._standard_normal = orig
+        torch.normal, torch.Tensor.uniform_, tdn._standard_normal = o_normal, o_uniform, o_sn
     return metrics
 
 
@@ -223,7 +247,7 @@ def checksums(agent):
     return cs
 
 
-TINY_KINDS = ('td3_bc', 'td3', 'bc', 'ddpg', 'crr', 'crr-exp', 'crr-identity')
+TINY_KINDS = ('td3_bc', 'td3', 'bc', 'ddpg', 'crr', 'crr-exp', 'crr-identity', 'cql')
 
 
 def gen_tiny(ref):
@@ -260,6 +284,9 @@ def gen_tiny(ref):
         for nm, net in nets_of(agent):
             for k, v in net.state_dict().items():
                 out[f'final/{nm}/{k}'] = v.numpy().copy()
+        if base == 'cql':
+            out['final/log_actor_alpha'] = agent.log_actor_alpha.detach().numpy().copy()
+            out['final/log_critic_alpha'] = agent.log_critic_alpha.detach().numpy().copy()
         np.savez_compressed(GOLD / f'tiny_{kind}.npz', **out)
         print('tiny', kind, keys, out['metrics'][-1])
 
@@ -270,6 +297,7 @@ FULL = {  # kind: (O, A, H, B)  — BASELINE.json configs (walker / cheetah shap
     'bc': (24, 6, 1024, 256),
     'ddpg': (24, 6, 1024, 1024),
     'crr': (24, 6, 1024, 1024),
+    'cql': (78, 12, 1024, 1024),         # quadruped shapes, BASELINE.json configs[2]
 }
 
 
@@ -291,6 +319,9 @@ def gen_full(ref, nsteps=10, only_kinds=None):
                 agent.critic_target.load_state_dict(agent.critic.state_dict())
             for nm, net in nets_of(agent):
                 net.to(tdt)
+            if kind == 'cql' and tdt == torch.float64:
+                agent.log_actor_alpha = agent.log_actor_alpha.detach().double().requires_grad_(True)
+                agent.actor_alpha_opt = torch.optim.Adam([agent.log_actor_alpha], lr=1e-4)
             metrics = run_agent(ref, agent, kind, nsteps, lambda i: _synth.synth_batch(9, i, B, O, A),
                                 _synth.NoiseStream(13), dtype)
             res[tag] = {'metrics': metrics, 'checksums': checksums(agent)}
