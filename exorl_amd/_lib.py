@@ -12,7 +12,8 @@ P = C.POINTER
 
 # constants mirrored from include/exorl_hip.h
 SAMPLER_MT19937, SAMPLER_PHILOX, SAMPLER_GIVEN = 0, 1, 2
-AGENT_TD3_BC, AGENT_TD3, AGENT_BC, AGENT_DDPG, AGENT_CRR = 0, 1, 2, 3, 4
+AGENT_TD3_BC, AGENT_TD3, AGENT_BC, AGENT_DDPG, AGENT_CRR, AGENT_CQL = 0, 1, 2, 3, 4, 5
+M_CRITIC_CQL, M_CRITIC_CQL_LOGSUM, M_ACTOR_ALPHA, M_ACTOR_ALPHA_LOSS, M_ACTOR_ENT = 10, 11, 12, 13, 14
 CRR_WEIGHT = {'identity': 0, 'indicator': 1, 'exp': 2}
 PREC_F32, PREC_BF16 = 0, 1
 NET_ACTOR, NET_CRITIC, NET_CRITIC_TARGET = 0, 1, 2
@@ -36,7 +37,7 @@ class AgentCfg(C.Structure):
     _fields_ = [('kind', c_int32), ('obs_dim', c_int32), ('act_dim', c_int32), ('hidden_dim', c_int32),
                 ('batch', c_int32), ('precision', c_int32), ('world_size', c_int32), ('reserved', c_int32),
                 ('lr', c_float), ('tau', c_float), ('alpha', c_float), ('stddev_clip', c_float), ('seed', c_uint64),
-                ('num_value_samples', c_int32), ('weight_func', c_int32)]
+                ('num_value_samples', c_int32), ('weight_func', c_int32), ('n_samples', c_int32), ('reserved2', c_int32)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/exorl_hip.h
@@ -68,6 +69,7 @@ PROTOTYPES = {
     'exorl_agent_update': (C.c_int, [c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     'exorl_agent_update_phase': (C.c_int, [c_void_p, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
     'exorl_agent_stats_buffer': (C.c_int, [c_void_p, P(c_void_p), P(c_int64)]),
+    'exorl_agent_cql_alpha': (C.c_int, [c_void_p, c_void_p, c_int32]),
     'exorl_agent_act': (C.c_int, [c_void_p, c_void_p, c_int32, c_float, c_int32, c_void_p, c_void_p, c_void_p]),
     'exorl_agent_metrics': (C.c_int, [c_void_p, c_void_p, c_void_p]),
     'exorl_agent_set_metrics': (C.c_int, [c_void_p, c_int32]),

@@ -104,7 +104,7 @@ class _AgentBase:
             ws = torch.distributed.get_world_size()
         self.world_size = ws
         # initial weights first (CPU RNG order: actor, critic, critic_target — td3_bc.py:86-93)
-        actor0 = _mlp_init(obs_dim, hidden_dim, action_dim, 1, 1)
+        actor0 = _mlp_init(obs_dim, hidden_dim, 2 * action_dim if self.KIND == 'cql' else action_dim, 1, 1)
         critic0 = None
         if self.KIND != 'bc':
             nt = 1 if ddpg else 2
@@ -309,6 +309,80 @@ class CRRAgent(_AgentBase):
         self._step(replay_iter, stddev)
         if self.use_tb:
             metrics.update(self._metrics(_CRITIC_METRICS, stddev))
+        return metrics
+
+
+class CQLAgent(_AgentBase):
+    """agents/offline_learning/cql.py:59-286 (use_critic_lagrange=False, the shipped cql.yaml)."""
+    KIND = 'cql'
+
+    def __init__(self, name, obs_shape, action_shape, device, lr, hidden_dim, critic_target_tau, nstep, batch_size, use_tb, alpha,
+                 n_samples, target_cql_penalty, use_critic_lagrange, has_next_action=False, *, precision='fp32', seed=0):
+        if use_critic_lagrange:
+            raise NotImplementedError('exorl_amd CQLAgent: use_critic_lagrange=True (cql.py:203-214) is not built yet')
+        self.action_dim = action_shape[0]
+        self.hidden_dim = hidden_dim
+        self.lr = lr
+        self.device = device
+        self.critic_target_tau = critic_target_tau
+        self.use_tb = use_tb
+        self.use_critic_lagrange = use_critic_lagrange
+        self.target_cql_penalty = target_cql_penalty
+        self.alpha = alpha
+        self.n_samples = n_samples
+        self.target_entropy = -self.action_dim
+        self.stddev_schedule = '1.0'          # unused by CQL (state-dependent std); keeps the shared plumbing uniform
+        self._build(obs_shape[0], action_shape[0], hidden_dim, batch_size, lr, critic_target_tau, alpha, 0.0, device, precision, seed,
+                    n_samples=n_samples)
+        self.train()
+        self.critic_target.train()
+
+    @property
+    def log_actor_alpha(self):
+        return torch.tensor([self.engine.cql_alpha_state()[0]])
+
+    def act(self, obs, step, eval_mode):
+        return self._act(np.asarray(obs, np.float32), step, eval_mode)
+
+    def _noise(self, rows=None):
+        raise RuntimeError('CQL draws five noise tensors; see _run_update')
+
+    def _run_update(self, stddev):
+        B, A, n = self.engine.batch, self.action_dim, self.n_samples
+        if self.noise_hook is None:
+            nc = na = None
+        else:       # draw order cql.py:159,170-176,238; the hook returns N(0,1) except for the uniform(-1,1) random actions
+            z_next = self.noise_hook((B, A))
+            u_rand = self.noise_hook((n, B, A), 'uniform')
+            z_cur, z_nxt = self.noise_hook((n, B, A)), self.noise_hook((n, B, A))
+            nc = np.concatenate([np.asarray(x, np.float32).reshape(-1) for x in (z_next, u_rand, z_cur, z_nxt)])
+            na = np.asarray(self.noise_hook((B, A)), np.float32)
+        eng = self.engine
+        if self.world_size == 1:
+            eng.update(1.0, nc, na)
+            return
+        dist = torch.distributed
+        eng.update_phase(0, 1.0, nc, na)
+        dist.all_reduce(eng.flat(L.NET_CRITIC, L.T_GRAD))
+        eng.update_phase(1, 1.0, nc, na)
+        dist.all_reduce(eng.stats())              # sum of log_pi for the entropy temperature (cql.py:242-243)
+        eng.update_phase(2, 1.0, nc, na)
+        dist.all_reduce(eng.flat(L.NET_ACTOR, L.T_GRAD))
+        eng.update_phase(3, 1.0, nc, na)
+
+    def update(self, replay_iter, step):
+        metrics = dict()
+        self._step(replay_iter, 1.0)
+        if self.use_tb:
+            raw = self.engine.metrics_raw()
+            if self.world_size > 1:
+                t = torch.from_numpy(raw.copy()).to(self.engine.device)
+                torch.distributed.all_reduce(t)
+                raw = t.cpu().numpy()
+            for idx, name in _CRITIC_METRICS + [(L.M_CRITIC_CQL, 'critic_cql'), (L.M_CRITIC_CQL_LOGSUM, 'critic_cql_logsum'),
+                                                (L.M_ACTOR_ENT, 'actor_ent'), (L.M_ACTOR_ALPHA, 'actor_alpha'),
+                                                (L.M_ACTOR_ALPHA_LOSS, 'actor_alpha_loss')]:
+                metrics[name] = float(raw[idx])
         return metrics
 
 

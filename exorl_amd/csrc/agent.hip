@@ -147,8 +147,14 @@ static int net_backward(const NetDesc& d, const float* P, const NetShadow& sh, f
     const int64_t act = (int64_t)rows * H;
     const bool paired = d.n_trunks == d.n_heads;
     const bool bf = prec == EXORL_PREC_BF16;
-    EXORL_TRY(head_bwd(dout, P + d.W2, f.h2, bf ? nullptr : b.dz2, bf ? b.dz2b : nullptr, G ? pt.Ph : nullptr, rows, H, d.out_dim,
-                       d.n_heads, act, d.head_stride, G ? 1 : 0, s));
+    if (d.out_dim > 16) {
+        EXORL_REQUIRE(d.n_heads == 1, "net_backward: wide heads are single-net only");
+        EXORL_TRY(head_bwd_wide(dout, P + d.W2, f.h2, bf ? nullptr : b.dz2, bf ? b.dz2b : nullptr, G ? pt.Ph : nullptr, rows, H, d.out_dim,
+                                act, d.head_stride, G ? 1 : 0, s));
+    } else {
+        EXORL_TRY(head_bwd(dout, P + d.W2, f.h2, bf ? nullptr : b.dz2, bf ? b.dz2b : nullptr, G ? pt.Ph : nullptr, rows, H, d.out_dim,
+                           d.n_heads, act, d.head_stride, G ? 1 : 0, s));
+    }
     if (bf) {
         Gemm16Problem q[2];
         if (G) {
@@ -237,6 +243,8 @@ struct exorl_agent {
     FwdBufs fa{}, ft{}, fc{};    // actor (2B rows), target critic, critic
     BwdBufs bc{}, ba{};
     float *dq = nullptr, *da = nullptr, *dpre = nullptr;
+    float *x_all = nullptr, *dq_all = nullptr;     // CQL: (3n+1)B critic rows and their per-row loss gradients
+    CqlScalars* cql = nullptr;                      // CQL: log_actor_alpha + Adam moments + alpha (device)
     float *xc_rep = nullptr, *crr_w = nullptr;     // CRR: repeated (obs, sampled action) inputs; advantage weights
     FwdBufs fr{};                                   // CRR: critic forward on B*num_value_samples rows (no grad)
     NetShadow sh_actor{}, sh_critic{}, sh_target{};
@@ -266,6 +274,8 @@ namespace exorl {
 static void carve(exorl_agent* a, Carver& c) {
     const auto& cfg = a->cfg;
     const int64_t B = cfg.batch, O = cfg.obs_dim, A = cfg.act_dim, H = cfg.hidden_dim, W = O + A;
+    const int64_t AO = a->actor.out_dim;                                     // actor head width (2A for CQL)
+    const int64_t RC = cfg.kind == EXORL_AGENT_CQL ? (3 * cfg.n_samples + 1) * B : B;   // rows of the critic's gradient pass
     for (int w = 0; w < 4; ++w) a->flat[EXORL_NET_ACTOR][w] = c.take(a->actor.total);
     if (a->has_critic) {
         for (int w = 0; w < 4; ++w) a->flat[EXORL_NET_CRITIC][w] = c.take(a->critic.total);
@@ -275,26 +285,31 @@ static void carve(exorl_agent* a, Carver& c) {
     a->xa = c.take(2 * B * O);
     auto take_u16 = [&](int64_t n) { return reinterpret_cast<unsigned short*>(c.take((n + 1) / 2)); };
     const bool bf = cfg.precision == EXORL_PREC_BF16;
-    a->fa = FwdBufs{c.take(2 * B * H), c.take(2 * B * H), c.take(2 * B), c.take(2 * B * H), c.take(2 * B * A), bf ? take_u16(2 * B * H) : nullptr,
+    a->fa = FwdBufs{c.take(2 * B * H), c.take(2 * B * H), c.take(2 * B), c.take(2 * B * H), c.take(2 * B * AO), bf ? take_u16(2 * B * H) : nullptr,
                     bf ? take_u16(2 * B * H) : nullptr};
     a->ba = BwdBufs{c.take(B * H), c.take(B * H), bf ? take_u16(B * H) : nullptr};
     a->sh_actor = NetShadow{c.take(O * H), bf ? take_u16(H * H) : nullptr};
-    a->pa = Partials{c.take((int64_t)head_chunks(B) * ((A + 1) * H + 16)), c.take((int64_t)trunk_chunks(B) * 3 * H),
+    a->pa = Partials{c.take((int64_t)head_chunks(B) * ((AO + 1) * H + 32)), c.take((int64_t)trunk_chunks(B) * 3 * H),
                      c.take((int64_t)outer_chunks(B) * O * H)};
-    a->dpre = c.take(B * A);
+    a->dpre = c.take(B * AO);
     a->stats = c.take(4 + EXORL_N_METRICS);
     a->metrics = a->stats ? a->stats + 4 : nullptr;
     a->state = reinterpret_cast<StepState*>(c.take((sizeof(StepState) + 3) / 4));
     a->act_x = c.take(ACT_ROWS * O);
     a->act_noise = c.take(ACT_ROWS * A);
-    a->fact = FwdBufs{c.take(ACT_ROWS * H), nullptr, nullptr, c.take(ACT_ROWS * H), c.take(ACT_ROWS * A), bf ? take_u16(ACT_ROWS * H) : nullptr, nullptr};
+    a->fact = FwdBufs{c.take(ACT_ROWS * H), nullptr, nullptr, c.take(ACT_ROWS * H), c.take(ACT_ROWS * AO), bf ? take_u16(ACT_ROWS * H) : nullptr, nullptr};
     if (a->has_critic) {
         const int64_t nt = a->critic.n_trunks;
         a->xc_cur = c.take(B * W); a->xc_next = c.take(B * W); a->xc_pi = c.take(B * W);
         a->ft = FwdBufs{c.take(nt * B * H), nullptr, nullptr, c.take(2 * B * H), c.take(2 * B), bf ? take_u16(nt * B * H) : nullptr, nullptr};
-        a->fc = FwdBufs{c.take(nt * B * H), c.take(nt * B * H), c.take(nt * B), c.take(2 * B * H), c.take(2 * B), bf ? take_u16(nt * B * H) : nullptr,
-                        bf ? take_u16(nt * B * H) : nullptr};
-        a->bc = BwdBufs{c.take(2 * B * H), c.take(nt * B * H), bf ? take_u16(2 * B * H) : nullptr};
+        a->fc = FwdBufs{c.take(nt * RC * H), c.take(nt * RC * H), c.take(nt * RC), c.take(2 * RC * H), c.take(2 * RC), bf ? take_u16(nt * RC * H) : nullptr,
+                        bf ? take_u16(nt * RC * H) : nullptr};
+        a->bc = BwdBufs{c.take(2 * RC * H), c.take(nt * RC * H), bf ? take_u16(2 * RC * H) : nullptr};
+        if (cfg.kind == EXORL_AGENT_CQL) {
+            a->x_all = c.take(RC * W);
+            a->dq_all = c.take(2 * RC);
+            a->cql = reinterpret_cast<CqlScalars*>(c.take(16));
+        }
         a->dq = c.take(2 * B);
         a->da = c.take(nt * B * A);
         if (cfg.kind == EXORL_AGENT_CRR) {
@@ -305,14 +320,16 @@ static void carve(exorl_agent* a, Carver& c) {
         }
         a->sh_critic = NetShadow{c.take(nt * W * H), bf ? take_u16(2 * H * H) : nullptr};
         a->sh_target = NetShadow{c.take(nt * W * H), bf ? take_u16(2 * H * H) : nullptr};
-        a->pc = Partials{c.take(2 * (int64_t)head_chunks(B) * (2 * H + 16)), c.take(nt * (int64_t)trunk_chunks(B) * 3 * H),
-                         c.take(nt * (int64_t)outer_chunks(B) * W * H)};
+        a->pc = Partials{c.take(2 * (int64_t)head_chunks(RC) * (2 * H + 16)), c.take(nt * (int64_t)trunk_chunks(RC) * 3 * H),
+                         c.take(nt * (int64_t)outer_chunks(RC) * W * H)};
     }
 }
 
 static int describe(exorl_agent* a, const exorl_agent_cfg* cfg) {
     EXORL_REQUIRE(cfg, "agent: null cfg");
-    EXORL_REQUIRE(cfg->kind >= EXORL_AGENT_TD3_BC && cfg->kind <= EXORL_AGENT_CRR, "agent: unknown kind %d", cfg->kind);
+    EXORL_REQUIRE(cfg->kind >= EXORL_AGENT_TD3_BC && cfg->kind <= EXORL_AGENT_CQL, "agent: unknown kind %d", cfg->kind);
+    EXORL_REQUIRE(cfg->kind != EXORL_AGENT_CQL || (cfg->n_samples >= 1 && cfg->n_samples <= 16 && cfg->act_dim <= 16),
+                  "agent: CQL needs 1 <= n_samples <= 16 and action_dim <= 16 (got %d, %d)", cfg->n_samples, cfg->act_dim);
     EXORL_REQUIRE(cfg->kind != EXORL_AGENT_CRR || (cfg->num_value_samples >= 1 && cfg->num_value_samples <= 64 &&
                   cfg->weight_func >= EXORL_CRR_IDENTITY && cfg->weight_func <= EXORL_CRR_EXP),
                   "agent: CRR needs 1 <= num_value_samples <= 64 and a valid weight_func (got %d, %d)", cfg->num_value_samples, cfg->weight_func);
@@ -326,7 +343,7 @@ static int describe(exorl_agent* a, const exorl_agent_cfg* cfg) {
                   "agent: bf16 precision needs hidden_dim and batch to be multiples of 8 (got H=%d B=%d)", cfg->hidden_dim, cfg->batch);
     a->cfg = *cfg;
     a->has_critic = cfg->kind != EXORL_AGENT_BC;
-    a->actor = make_net(cfg->obs_dim, cfg->act_dim, cfg->hidden_dim, 1, 1);
+    a->actor = make_net(cfg->obs_dim, cfg->kind == EXORL_AGENT_CQL ? 2 * cfg->act_dim : cfg->act_dim, cfg->hidden_dim, 1, 1);
     if (a->has_critic)
         a->critic = make_net(cfg->obs_dim + cfg->act_dim, 1, cfg->hidden_dim, cfg->kind == EXORL_AGENT_DDPG ? 1 : 2, 2);
     a->inv_bg = 1.0f / ((float)cfg->batch * (float)cfg->world_size);
@@ -450,6 +467,70 @@ static int phase3(exorl_agent* a, hipStream_t s) {
                          &a->state->actor, nullptr, &a->spec_actor, s);
 }
 
+// ---- CQL (cql.py:152-263) ---------------------------------------------------------------------------
+static CqlNoise cql_noise(exorl_agent* a) {
+    const int64_t BA = (int64_t)a->cfg.batch * a->cfg.act_dim, n = a->cfg.n_samples;
+    const float* nc = a->noise_c;
+    CqlNoise z{};
+    z.z_next = nc; z.u_rand = nc ? nc + BA : nullptr; z.z_cur = nc ? nc + (1 + n) * BA : nullptr;
+    z.z_nxt = nc ? nc + (1 + 2 * n) * BA : nullptr; z.z_actor = a->noise_a;
+    z.seed = a->cfg.seed; z.counter_ptr = &a->state->noise_counter;
+    return z;
+}
+
+static int cql_phase0(exorl_agent* a, hipStream_t s) {
+    const auto& cfg = a->cfg;
+    const int B = cfg.batch, O = cfg.obs_dim, A = cfg.act_dim, W = O + A, n = cfg.n_samples, prec = cfg.precision;
+    const int R = (3 * n + 1) * B;
+    EXORL_TRY(prepare_inputs(a->obs, a->action, a->next_obs, a->xa, a->xc_cur, a->xc_next, a->xc_pi, B, O, A, 1, a->state,
+                             a->capturing ? 1 : 0, s));
+    a->actor_t += 1;
+    a->critic_t += 1;
+    const float* Pa = a->flat[EXORL_NET_ACTOR][EXORL_T_PARAM];
+    const float* Pc = a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM];
+    EXORL_TRY(net_forward(a->actor, Pa, a->sh_actor, a->xa, O, 2 * B, a->fa, true, false, prec, s));      // raw (mu | log_std) on [next_obs; obs]
+    EXORL_TRY(cql_build_inputs(a->obs, a->action, a->fa.out, cql_noise(a), a->xc_next, a->x_all, B, O, A, n, s));
+    EXORL_TRY(net_forward(a->critic, a->flat[EXORL_NET_CRITIC_TARGET][EXORL_T_PARAM], a->sh_target, a->xc_next, W, B, a->ft, false, false,
+                          prec, s));                                                                     // cql.py:160
+    EXORL_TRY(net_forward(a->critic, Pc, a->sh_critic, a->x_all, W, R, a->fc, true, false, prec, s));     // cql.py:166,179-184 in one pass
+    EXORL_TRY(cql_critic_dq(a->fc.out, a->ft.out, a->reward, a->discount, a->dq_all, a->metrics, B, n, cfg.alpha, a->inv_bg, s));
+    DoutSpec d{};
+    d.mode = EXORL_DOUT_BUFFER; d.buf = a->dq_all;
+    EXORL_TRY(net_backward(a->critic, Pc, a->sh_critic, a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD], a->pc, a->x_all, W, R, a->fc, d, a->bc,
+                           nullptr, 0, 0, prec, s, a->fk));
+    return 0;
+}
+
+static int cql_phase1(exorl_agent* a, hipStream_t s) {
+    const auto& cfg = a->cfg;
+    const int B = cfg.batch, O = cfg.obs_dim, A = cfg.act_dim, W = O + A, prec = cfg.precision;
+    EXORL_TRY(adam_step_dev(a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD],
+                            a->flat[EXORL_NET_CRITIC][EXORL_T_ADAM_M], a->flat[EXORL_NET_CRITIC][EXORL_T_ADAM_V], a->critic.total,
+                            &a->state->critic, a->flat[EXORL_NET_CRITIC_TARGET][EXORL_T_PARAM], &a->spec_critic, s));
+    EXORL_TRY(cql_actor_sample(a->fa.out + (int64_t)B * 2 * A, cql_noise(a), a->xc_pi, W, a->stats, B, O, A, s));    // cql.py:237-239
+    EXORL_TRY(net_forward(a->critic, a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->sh_critic, a->xc_pi, W, B, a->fc, true, false, prec, s));
+    return 0;
+}
+
+static int cql_phase2(exorl_agent* a, hipStream_t s) {
+    const auto& cfg = a->cfg;
+    const int B = cfg.batch, O = cfg.obs_dim, A = cfg.act_dim, W = O + A, H = cfg.hidden_dim, prec = cfg.precision;
+    EXORL_TRY(cql_alpha_step(a->cql, a->stats, &a->state->actor, a->metrics, B, A, a->inv_bg, a->fc.out, s));    // cql.py:241-247
+    DoutSpec dq{};
+    dq.mode = EXORL_DOUT_ACTOR_Q; dq.q = a->fc.out; dq.stats = a->stats; dq.inv_bg = a->inv_bg; dq.use_lambda = 0;
+    EXORL_TRY(net_backward(a->critic, a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->sh_critic, nullptr, a->pc, a->xc_pi, W, B, a->fc, dq,
+                           a->bc, a->da, O, A, prec, s, a->fk));
+    FwdBufs f{a->fa.h1 + (int64_t)B * H, a->fa.xhat + (int64_t)B * H, a->fa.rstd + B, a->fa.h2 + (int64_t)B * H,
+              a->fa.out + (int64_t)B * 2 * A, a->fa.h1b ? a->fa.h1b + (int64_t)B * H : nullptr,
+              a->fa.xhatb ? a->fa.xhatb + (int64_t)B * H : nullptr};
+    DoutSpec dm{};
+    dm.mode = EXORL_DOUT_CQL_ACTOR; dm.da = a->da; dm.da_nets = a->critic.n_trunks; dm.raw = f.out; dm.z = a->noise_a;
+    dm.alpha_ptr = &a->cql->alpha; dm.inv_bg = a->inv_bg; dm.seed = cfg.seed; dm.counter = 4; dm.counter_ptr = &a->state->noise_counter;
+    EXORL_TRY(net_backward(a->actor, a->flat[EXORL_NET_ACTOR][EXORL_T_PARAM], a->sh_actor, a->flat[EXORL_NET_ACTOR][EXORL_T_GRAD], a->pa,
+                           a->xa + (int64_t)B * O, O, B, f, dm, a->ba, nullptr, 0, 0, prec, s, a->fk));
+    return 0;
+}
+
 static int release_graph(exorl_agent* a) {
     if (a->graph_exec) { EXORL_CHECK_HIP(hipGraphExecDestroy(a->graph_exec)); a->graph_exec = nullptr; }
     if (a->graph) { EXORL_CHECK_HIP(hipGraphDestroy(a->graph)); a->graph = nullptr; }
@@ -499,6 +580,7 @@ int exorl_agent_create(const exorl_agent_cfg* cfg, void* workspace, size_t works
     st.lr = cfg->lr; st.b1 = 0.9f; st.b2 = 0.999f; st.eps = 1e-8f; st.tau = cfg->tau;      // torch.optim.Adam defaults
     st.has_critic = a->has_critic ? 1 : 0;
     st.b1t = st.b2t = st.b1t_c = st.b2t_c = 1.0;
+    if (a->cql) { CqlScalars sc{0.f, 0.f, 0.f, 1.0f}; (void)hipMemcpy(a->cql, &sc, sizeof(sc), hipMemcpyHostToDevice); }
     e = hipMemcpy(a->state, &st, sizeof(st), hipMemcpyHostToDevice);
     if (e != hipSuccess) { set_error("agent_create: state upload -> %s", hipGetErrorString(e)); if (a->owns_ws) (void)hipFree(a->ws); delete a; return 1; }
     *out = a;
@@ -590,9 +672,18 @@ int exorl_agent_set_batch(exorl_agent_t* a, const float* obs, const float* actio
 
 int exorl_agent_update_phase(exorl_agent_t* a, int32_t phase, float stddev, const float* noise_c, const float* noise_a, void* stream) {
     EXORL_REQUIRE(a, "agent_update_phase: null handle");
-    EXORL_REQUIRE(stddev > 0.f, "agent_update_phase: stddev must be > 0");
+    EXORL_REQUIRE(stddev > 0.f || a->cfg.kind == EXORL_AGENT_CQL, "agent_update_phase: stddev must be > 0");
     hipStream_t s = as_stream(stream);
     a->noise_a = noise_a;
+    if (a->cfg.kind == EXORL_AGENT_CQL) {
+        a->noise_c = noise_c;
+        switch (phase) {
+            case 0: return cql_phase0(a, s);
+            case 1: return cql_phase1(a, s);
+            case 2: return cql_phase2(a, s);
+            case 3: return phase3(a, s);
+        }
+    }
     switch (phase) {
         case 0: return phase0(a, stddev, noise_c, s);
         case 1: return phase1(a, stddev, noise_a, s);
@@ -622,9 +713,13 @@ int exorl_agent_act(exorl_agent_t* a, const float* obs, int32_t n, float stddev,
     const int O = a->cfg.obs_dim, A = a->cfg.act_dim;
     for (int r0 = 0; r0 < n; r0 += ACT_ROWS) {
         const int rows = n - r0 < ACT_ROWS ? n - r0 : ACT_ROWS;
-        EXORL_TRY(net_forward(a->actor, a->flat[EXORL_NET_ACTOR][EXORL_T_PARAM], a->sh_actor, obs + (int64_t)r0 * O, O, rows, a->fact, false, true,
+        EXORL_TRY(net_forward(a->actor, a->flat[EXORL_NET_ACTOR][EXORL_T_PARAM], a->sh_actor, obs + (int64_t)r0 * O, O, rows, a->fact, false,
+                              a->cfg.kind != EXORL_AGENT_CQL,
                               a->cfg.precision, s));
-        if (eval_mode) {
+        if (a->cfg.kind == EXORL_AGENT_CQL) {       // SquashedNormal: mean = tanh(loc), sample = tanh(loc + std z)  (cql.py:122-131)
+            EXORL_TRY(cql_act(a->fact.out, noise ? noise + (int64_t)r0 * A : nullptr, a->cfg.seed, (1ull << 63) | a->act_noise_counter++,
+                              eval_mode, out + (int64_t)r0 * A, rows, A, s));
+        } else if (eval_mode) {
             EXORL_CHECK_HIP(hipMemcpyAsync(out + (int64_t)r0 * A, a->fact.out, (size_t)rows * A * 4, hipMemcpyDeviceToDevice, s));
         } else {
             EXORL_REQUIRE(stddev > 0.f, "agent_act: stddev must be > 0 in sampling mode");
@@ -693,6 +788,19 @@ int exorl_agent_enable_graph(exorl_agent_t* a, exorl_replay_t* r, int32_t nstep,
     a->graph = g;
     EXORL_CHECK_HIP(hipGraphInstantiate(&a->graph_exec, g, nullptr, nullptr, 0));
     a->graph_replay = r;
+    return 0;
+}
+
+int exorl_agent_cql_alpha(exorl_agent_t* a, float* host, int32_t set) {
+    EXORL_REQUIRE(a && host && a->cql, "agent_cql_alpha: not a CQL agent / null argument");
+    if (set) {
+        CqlScalars sc{host[0], host[1], host[2], expf(host[0])};
+        EXORL_CHECK_HIP(hipMemcpy(a->cql, &sc, sizeof(sc), hipMemcpyHostToDevice));
+    } else {
+        CqlScalars sc;
+        EXORL_CHECK_HIP(hipMemcpy(&sc, a->cql, sizeof(sc), hipMemcpyDeviceToHost));
+        host[0] = sc.log_alpha; host[1] = sc.m; host[2] = sc.v;
+    }
     return 0;
 }
 

@@ -427,11 +427,12 @@ __global__ __launch_bounds__(256) void head_fwd4_kernel(const float* __restrict_
 
 int head_fwd4(const float* a, const float* W, const float* b, float* out, int rows, int H, int nout, int tanh_out,
               int nets, int64_t astride, int64_t pstride, int64_t ostride, hipStream_t s) {
-    EXORL_REQUIRE(nout >= 1 && nout <= 16 && H % 4 == 0 && H <= 1024, "head_fwd4: nout=%d H=%d unsupported", nout, H);
+    EXORL_REQUIRE(nout >= 1 && nout <= 32 && H % 4 == 0 && H <= 1024, "head_fwd4: nout=%d H=%d unsupported", nout, H);
     dim3 grid(cdiv(rows, 4), nets);
     if (nout == 1) hipLaunchKernelGGL((head_fwd4_kernel<1>), grid, dim3(256), 0, s, a, W, b, out, rows, H, nout, tanh_out, astride, pstride, ostride);
     else if (nout <= 8) hipLaunchKernelGGL((head_fwd4_kernel<8>), grid, dim3(256), 0, s, a, W, b, out, rows, H, nout, tanh_out, astride, pstride, ostride);
-    else hipLaunchKernelGGL((head_fwd4_kernel<16>), grid, dim3(256), 0, s, a, W, b, out, rows, H, nout, tanh_out, astride, pstride, ostride);
+    else if (nout <= 16) hipLaunchKernelGGL((head_fwd4_kernel<16>), grid, dim3(256), 0, s, a, W, b, out, rows, H, nout, tanh_out, astride, pstride, ostride);
+    else hipLaunchKernelGGL((head_fwd4_kernel<32>), grid, dim3(256), 0, s, a, W, b, out, rows, H, nout, tanh_out, astride, pstride, ostride);
     EXORL_LAUNCH_CHECK();
     return 0;
 }
@@ -442,9 +443,36 @@ int head_fwd4(const float* a, const float* W, const float* b, float* out, int ro
 // Thread = 4 consecutive columns (float4 streams), 8 rows per workgroup.
 // P layout per (net, chunk): [dW nout*H][db_hidden H][db_out 16]
 constexpr int HB_ROWS = 8;
+__device__ __forceinline__ float philox_normal_f(uint64_t seed, uint64_t counter, uint32_t elem) {
+    uint32_t c[4] = {elem, 0u, (uint32_t)counter, (uint32_t)(counter >> 32)};
+    Philox::gen(c, seed);
+    const float u1 = ((float)c[0] + 1.0f) * 2.3283064365386963e-10f;
+    const float u2 = (float)c[1] * 2.3283064365386963e-10f;
+    return sqrtf(-2.0f * __logf(u1)) * __cosf(6.283185307179586f * u2);
+}
+
 // d(loss)/d(head output) for row m, output j of net `net` (see DoutSpec)
 __device__ __forceinline__ float dout_value(const DoutSpec& d, int net, int m, int j, int rows, int nout) {
     if (d.mode == EXORL_DOUT_BUFFER) return d.buf[((int64_t)net * rows + m) * nout + j];
+    if (d.mode == EXORL_DOUT_CQL_ACTOR) {
+        // actor_loss = (alpha*log_pi - Q).mean() over (B,A), y = tanh(x), x = mu + std z  (cql.py:236-255). With
+        // g = dQterm/dy * (1-y^2), c = alpha/(Bg*A):  dL/dmu = g + 2 c y;  dL/dstd = g z + c (-1/std + 2 y z)
+        const int A = nout >> 1, jj = j < A ? j : j - A;
+        const float* rr = d.raw + (int64_t)m * nout;
+        const float mu = tanhf(rr[jj]);
+        const float ls = rr[A + jj];
+        const float sd = expf(fminf(fmaxf(ls, -10.0f), 2.0f));
+        const int e = m * A + jj;
+        const float z = d.z ? d.z[e] : philox_normal_f(d.seed, (d.counter_ptr ? *d.counter_ptr : 0ull) * 8 + d.counter, (uint32_t)e);
+        const float y = tanhf(mu + sd * z);
+        float dy = 0.f;
+        for (int t = 0; t < d.da_nets; ++t) dy += d.da[((int64_t)t * rows + m) * A + jj];
+        const float g = dy * (1.0f - y * y);
+        const float c = *d.alpha_ptr * d.inv_bg / (float)A;
+        if (j < A) return (g + 2.0f * c * y) * (1.0f - mu * mu);
+        const float inside = (ls >= -10.0f && ls <= 2.0f) ? 1.0f : 0.0f;
+        return (g * z + c * (-1.0f / sd + 2.0f * y * z)) * sd * inside;
+    }
     if (d.mode == EXORL_DOUT_TD) {
         const float y = d.reward[m] + d.discount[m] * fminf(d.tq[m], d.tq[rows + m]);
         return 2.0f * (d.q[net * rows + m] - y) * d.inv_bg;
@@ -547,6 +575,69 @@ int head_bwd(const DoutSpec& dspec, const float* W, const float* a, float* dz, u
     EXORL_LAUNCH_CHECK();
     return 0;
 }
+// 16 < nout <= 32 (CQL's 2A-wide actor head): one column per thread keeps the 2 x 32 per-output accumulators in registers.
+// Same partial layout as head_bwd_kernel, with 32 db_out slots.
+__global__ __launch_bounds__(256) void head_bwd_wide_kernel(const DoutSpec dspec, const float* __restrict__ W,
+                                                            const float* __restrict__ a, float* __restrict__ dz,
+                                                            unsigned short* __restrict__ dzb, float* __restrict__ P, int rows, int H,
+                                                            int nout, int64_t astride, int64_t pstride, int want_params) {
+    __shared__ float ds[HB_ROWS * 32];
+    const int net = blockIdx.z;
+    const int row0 = blockIdx.y * HB_ROWS;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    {
+        const int r = threadIdx.x >> 5, j = threadIdx.x & 31;        // 8 rows x 32 outputs = 256 threads
+        ds[threadIdx.x] = (row0 + r < rows && j < nout) ? dout_value(dspec, net, row0 + r, j, rows, nout) : 0.f;
+    }
+    __syncthreads();
+    const int64_t nh = (int64_t)(nout + 1) * H + 32;
+    float* Pn = P ? P + ((int64_t)net * gridDim.y + blockIdx.y) * nh : nullptr;
+    if (want_params && blockIdx.x == 0 && threadIdx.x < nout) {
+        float sj = 0.f;
+        for (int r = 0; r < HB_ROWS; ++r) sj += ds[r * 32 + threadIdx.x];
+        Pn[(int64_t)(nout + 1) * H + threadIdx.x] = sj;
+    }
+    if (c >= H) return;
+    float w[32], pw[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        w[j] = j < nout ? W[net * pstride + (int64_t)j * H + c] : 0.f;
+        pw[j] = 0.f;
+    }
+    float pb = 0.f;
+    const int nr = rows - row0 < HB_ROWS ? rows - row0 : HB_ROWS;
+    for (int r = 0; r < nr; ++r) {
+        const int64_t o = net * astride + (int64_t)(row0 + r) * H + c;
+        const float av = a[o];
+        float sacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const float d = ds[r * 32 + j];
+            sacc += d * w[j];
+            pw[j] += d * av;
+        }
+        const float v = av > 0.f ? sacc : 0.f;
+        if (dz) dz[o] = v;
+        if (dzb) dzb[o] = f2bf(v);
+        pb += v;
+    }
+    if (want_params) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j)
+            if (j < nout) Pn[(int64_t)j * H + c] = pw[j];
+        Pn[(int64_t)nout * H + c] = pb;
+    }
+}
+
+int head_bwd_wide(const DoutSpec& dspec, const float* W, const float* a, float* dz, unsigned short* dz_bf16, float* P, int rows, int H,
+                  int nout, int64_t astride, int64_t pstride, int want_params, hipStream_t s) {
+    EXORL_REQUIRE(nout > 16 && nout <= 32, "head_bwd_wide: nout=%d out of range", nout);
+    hipLaunchKernelGGL(head_bwd_wide_kernel, dim3(cdiv(H, 256), cdiv(rows, HB_ROWS), 1), dim3(256), 0, s, dspec, W, a, dz, dz_bf16, P, rows,
+                       H, nout, astride, pstride, want_params);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
 int head_chunks(int rows) { return cdiv(rows, HB_ROWS); }
 
 // ------------------------------------------------------------------------------------------------
@@ -568,7 +659,7 @@ __device__ __forceinline__ float chunk_sum(const float* __restrict__ p, int n, i
 
 __global__ __launch_bounds__(256) void finalize_grads_kernel(FinalizeArgs f) {
     const int H = f.H;
-    const int64_t nh = (int64_t)(f.nout + 1) * H + 16;       // head elements per net   (head_bwd_kernel)
+    const int64_t nh = (int64_t)(f.nout + 1) * H + (f.nout > 16 ? 32 : 16);   // head elements per net (head_bwd[_wide]_kernel)
     const int64_t nt = 3 * (int64_t)H;                       // LN/bias column sums      (ln_bwd_kernel)
     const int64_t nw = (int64_t)f.in_dim * H;                // first-layer weight grad  (outer_reduce_kernel)
     const int64_t total = f.n_heads * nh + f.n_trunks * (nt + nw);
@@ -605,7 +696,7 @@ __global__ __launch_bounds__(256) void finalize_grads_kernel(FinalizeArgs f) {
 }
 
 int finalize_grads(const FinalizeArgs& f, hipStream_t s) {
-    const int64_t total = f.n_heads * ((int64_t)(f.nout + 1) * f.H + 16) + f.n_trunks * (int64_t)(3 + f.in_dim) * f.H;
+    const int64_t total = f.n_heads * ((int64_t)(f.nout + 1) * f.H + (f.nout > 16 ? 32 : 16)) + f.n_trunks * (int64_t)(3 + f.in_dim) * f.H;
     hipLaunchKernelGGL(finalize_grads_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, f);
     EXORL_LAUNCH_CHECK();
     return 0;

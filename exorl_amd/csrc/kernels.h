@@ -60,6 +60,7 @@ int head_fwd4(const float* a, const float* W, const float* b, float* out, int ro
 #define EXORL_DOUT_BUFFER   0
 #define EXORL_DOUT_TD       1   /* 2 (q_net - (r + D min(tq1,tq2))) * inv_bg                    td3_bc.py:127-131 */
 #define EXORL_DOUT_ACTOR_Q  2   /* -lambda * inv_bg * [q_net is the min] (0.5 on ties)            td3_bc.py:152-155 */
+#define EXORL_DOUT_CQL_ACTOR 4  /* tanh-Gaussian actor, 2A outputs: reparameterised (alpha*log_pi - Q).mean()   cql.py:236-255 */
 #define EXORL_DOUT_ACTOR_MU 3   /* (sum_t da_t + bc term) * (1 - mu^2)  /  BC: -(a-mu)/std^2*inv_bg td3_bc.py:155, bc.py:83 */
 struct DoutSpec {
     int mode;
@@ -68,6 +69,9 @@ struct DoutSpec {
     const float* stats;      // ACTOR_Q: stats[0] = sum |Q| over the global batch
     const float *da, *mu, *a_data;             // ACTOR_MU: da (da_nets, rows, nout), mu / a_data (rows, nout)
     const float* w;          // ACTOR_MU, CRR: per-sample advantage weight (rows)
+    const float *raw, *z;    // CQL_ACTOR: actor head outputs (rows, 2A) [mu_raw | log_std_raw]; rsample noise (rows, A) or null
+    const float* alpha_ptr;  // CQL_ACTOR: exp(log_actor_alpha) after its optimiser step (device scalar)
+    uint64_t seed, counter; const uint64_t* counter_ptr;   // Philox identity of z when z == nullptr
     int da_nets;
     int kind;                // EXORL_AGENT_*
     int use_lambda;
@@ -166,6 +170,32 @@ int sample_actions2(const float* mu2, const float* noise_c, const float* noise_a
                     float stddev, float clip, float* dst_next, float* dst_pi, int64_t dst_ld, int B, int A, hipStream_t s);
 int sample_action(const float* mu, NoiseSpec noise, float stddev, float clip, int use_clip, float* dst, int64_t dst_ld,
                   int B, int A, float* logprob_sum, hipStream_t s);
+// ---- CQL (cql.py:152-263)
+struct CqlNoise {            // the five draws of one CQL update; null buffers -> Philox(seed, *counter_ptr + k)
+    const float *z_next, *u_rand, *z_cur, *z_nxt, *z_actor;
+    uint64_t seed;
+    const uint64_t* counter_ptr;
+};
+struct CqlScalars {          // device-resident entropy-temperature state (cql.py:96-101,241-247)
+    float log_alpha, m, v, alpha;
+};
+// raw2: actor head outputs on [next_obs; obs] (2B, 2A). Writes next_action into xc_next[:, O:] and the (3n+1)B critic
+// rows x_all = [obs | rand] (nB) ; [obs | pi(obs) samples] (nB) ; [obs | pi(next_obs) samples] (nB) ; [obs | a_data] (B)
+int cql_build_inputs(const float* obs, const float* action, const float* raw2, CqlNoise nz, float* xc_next, float* x_all, int B,
+                     int O, int A, int n, hipStream_t s);
+// per-row d(critic_loss)/dQ over the (3n+1)B rows of both nets + metrics (TD loss, logsumexp penalty)
+int cql_critic_dq(const float* q_all, const float* tq, const float* reward, const float* discount, float* dq_all, float* metrics,
+                  int B, int n, float cql_alpha, float inv_bg, hipStream_t s);
+// rsample of pi(obs): y = tanh(mu + std z) -> xc_pi[:, O:]; stats[0] = sum log_pi (per element, cql.py:239)
+int cql_actor_sample(const float* raw_obs, CqlNoise nz, float* xc_pi, int64_t ld, float* stats, int B, int O, int A, hipStream_t s);
+// scalar Adam step on log_actor_alpha from the (all-reduced) sum of log_pi; writes alpha = exp(log_alpha) and metrics
+int cql_alpha_step(CqlScalars* sc, const float* stats, const AdamConst* c_dev, float* metrics, int B, int A, float inv_bg, const float* q,
+                   hipStream_t s);
+// policy output for act(): tanh(mu) (eval) or tanh(mu + std z)
+int cql_act(const float* raw, const float* noise, uint64_t seed, uint64_t counter, int eval_mode, float* out, int rows, int A, hipStream_t s);
+int head_bwd_wide(const DoutSpec& dspec, const float* W, const float* a, float* dz, unsigned short* dz_bf16, float* P, int rows, int H,
+                  int nout, int64_t astride, int64_t pstride, int want_params, hipStream_t s);
+
 // CRR (crr.py:121-142): xc_rep[(b*n+i)] = [obs_b | TruncatedNormal(mu_b).sample(clip)] for i < n
 int repeat_sample(const float* obs, const float* mu, const float* noise, uint64_t seed, const uint64_t* counter_ptr, uint64_t counter,
                   float stddev, float clip, float* xc_rep, int B, int O, int A, int n, hipStream_t s);

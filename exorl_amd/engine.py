@@ -11,7 +11,7 @@ import torch
 
 from . import _lib as L
 
-KIND = {'td3_bc': L.AGENT_TD3_BC, 'td3': L.AGENT_TD3, 'bc': L.AGENT_BC, 'ddpg': L.AGENT_DDPG, 'crr': L.AGENT_CRR}
+KIND = {'td3_bc': L.AGENT_TD3_BC, 'td3': L.AGENT_TD3, 'bc': L.AGENT_BC, 'ddpg': L.AGENT_DDPG, 'crr': L.AGENT_CRR, 'cql': L.AGENT_CQL}
 PRECISION = {'fp32': L.PREC_F32, 'f32': L.PREC_F32, 'bf16': L.PREC_BF16}
 METRIC_KEYS = {L.M_BATCH_REWARD: 'batch_reward', L.M_CRITIC_TARGET_Q: 'critic_target_q', L.M_CRITIC_Q1: 'critic_q1',
                L.M_CRITIC_Q2: 'critic_q2', L.M_CRITIC_LOSS: 'critic_loss', L.M_ACTOR_LOSS: 'actor_loss',
@@ -29,13 +29,14 @@ def _require_gpu(device):
 
 class AgentEngine:
     def __init__(self, kind, obs_dim, act_dim, hidden_dim, batch, lr=1e-4, tau=0.01, alpha=2.5, stddev_clip=0.3,
-                 precision='fp32', world_size=1, seed=0, device='cuda', num_value_samples=10, weight_func='indicator'):
+                 precision='fp32', world_size=1, seed=0, device='cuda', num_value_samples=10, weight_func='indicator',
+                 n_samples=3):
         self.lib = L.load()
         self.device = _require_gpu(device)
         self.kind = kind
         self.cfg = L.AgentCfg(KIND[kind], obs_dim, act_dim, hidden_dim, batch, PRECISION[precision], world_size, 0,
                               lr, tau, alpha, stddev_clip if stddev_clip is not None else 0.0, seed, num_value_samples,
-                              L.CRR_WEIGHT[weight_func])
+                              L.CRR_WEIGHT[weight_func], n_samples, 0)
         self.obs_dim, self.act_dim, self.hidden_dim, self.batch = obs_dim, act_dim, hidden_dim, batch
         nbytes = self.lib.exorl_agent_workspace_bytes(C.byref(self.cfg))
         if nbytes == 0:
@@ -146,6 +147,15 @@ class AgentEngine:
 
     def set_metrics(self, enable):
         L.check(self.lib.exorl_agent_set_metrics(self.h, int(bool(enable))))
+
+    def cql_alpha_state(self):
+        host = np.zeros(3, np.float32)
+        L.check(self.lib.exorl_agent_cql_alpha(self.h, host.ctypes.data, 0))
+        return host            # log_actor_alpha, Adam m, Adam v
+
+    def set_cql_alpha_state(self, log_alpha, m=0.0, v=0.0):
+        host = np.array([log_alpha, m, v], np.float32)
+        L.check(self.lib.exorl_agent_cql_alpha(self.h, host.ctypes.data, 1))
 
     def metrics_raw(self):
         host = np.zeros(L.N_METRICS, np.float32)

@@ -105,6 +105,7 @@ typedef struct exorl_agent exorl_agent_t;
 #define EXORL_AGENT_BC     2
 #define EXORL_AGENT_DDPG   3   /* states; shared-trunk critic (ddpg.py:79-123) */
 #define EXORL_AGENT_CRR    4   /* agents/offline_learning/crr.py:59-219 */
+#define EXORL_AGENT_CQL    5   /* agents/offline_learning/cql.py:59-286 (use_critic_lagrange=False) */
 
 #define EXORL_CRR_IDENTITY  0   /* crr.py:132-142 adv_transform */
 #define EXORL_CRR_INDICATOR 1
@@ -133,6 +134,11 @@ typedef struct exorl_agent exorl_agent_t;
 #define EXORL_M_Q_ABS_SUM       7   /* local sum |Q| (DP scalar all-reduce operand) */
 #define EXORL_M_Q_SUM           8   /* local sum  Q  */
 #define EXORL_M_BC_SUM          9   /* local sum (mu-a)^2 */
+#define EXORL_M_CRITIC_CQL        10
+#define EXORL_M_CRITIC_CQL_LOGSUM 11
+#define EXORL_M_ACTOR_ALPHA       12
+#define EXORL_M_ACTOR_ALPHA_LOSS  13
+#define EXORL_M_ACTOR_ENT         14
 #define EXORL_N_METRICS        16
 
 typedef struct {
@@ -146,6 +152,8 @@ typedef struct {
     uint64_t seed;            /* Philox stream for action noise when no noise buffer is given */
     int32_t num_value_samples; /* CRR: actions sampled per state for V(s) (crr.yaml: 10) */
     int32_t weight_func;       /* CRR: EXORL_CRR_* */
+    int32_t n_samples;         /* CQL: action samples per source (cql.yaml: 3); `alpha` is then the CQL penalty weight */
+    int32_t reserved2;
 } exorl_agent_cfg;
 
 size_t exorl_agent_workspace_bytes(const exorl_agent_cfg* cfg);
@@ -172,7 +180,9 @@ int exorl_agent_set_batch(exorl_agent_t* a, const float* obs_dev, const float* a
                           void* stream);
 /* One gradient step on the batch currently in the batch slots.
  * noise_critic_dev / noise_actor_dev: (B,A) standard-normal draws (reference order; for CRR the second
- * draw is (B*num_value_samples, A), crr.py:125) or NULL for device Philox. Runs phases 0..3 back to back (world_size 1). */
+ * draw is (B*num_value_samples, A), crr.py:125) or NULL for device Philox.
+ * CQL (draw order cql.py:159,170-176,238): noise_critic_dev = [z_next (B,A) | u_rand (n,B,A) uniform(-1,1) | z_cur (n,B,A) |
+ * z_nxt (n,B,A)] back to back, noise_actor_dev = z_actor (B,A). Runs phases 0..3 back to back (world_size 1). */
 int exorl_agent_update(exorl_agent_t* a, float stddev, const float* noise_critic_dev,
                        const float* noise_actor_dev, void* stream);
 /* Data-parallel form: the caller all-reduces (sum) between phases:
@@ -184,6 +194,8 @@ int exorl_agent_update(exorl_agent_t* a, float stddev, const float* noise_critic
 int exorl_agent_update_phase(exorl_agent_t* a, int32_t phase, float stddev, const float* noise_critic_dev,
                              const float* noise_actor_dev, void* stream);
 int exorl_agent_stats_buffer(exorl_agent_t* a, void** ptr_dev, int64_t* numel);
+/* CQL: entropy temperature state (log_actor_alpha and its Adam moments), host <-> device. */
+int exorl_agent_cql_alpha(exorl_agent_t* a, float* log_alpha_host, int32_t set);
 /* Policy inference for n rows: out = mean (eval) or TruncatedNormal sample (clip=None). */
 int exorl_agent_act(exorl_agent_t* a, const float* obs_dev, int32_t n, float stddev, int32_t eval_mode,
                     const float* noise_dev, float* action_out_dev, void* stream);

@@ -21,6 +21,8 @@ def make(kind, O, A, H, B, use_tb=True, precision='fp32'):
     if kind.startswith('crr'):
         wf = kind.partition('-')[2] or 'indicator'
         return agents.CRRAgent('crr', (O,), (A,), 'cuda', 1e-4, H, 0.01, 10, wf, 0.2, 1, B, 0.3, use_tb, precision=precision)
+    if kind == 'cql':
+        return agents.CQLAgent('cql', (O,), (A,), 'cuda', 1e-4, H, 0.01, 1, B, use_tb, 0.01, 3, 5.0, False, precision=precision)
     if kind == 'bc':
         return agents.BCAgent('bc', (O,), (A,), 'cuda', 1e-4, H, B, 0.2, use_tb, precision=precision)
     return agents.DDPGAgent('ddpg', True, 'states', (O,), (A,), 'cuda', 1e-4, 50, H, 0.01, 2000, 2, 0.2, 3, B, 0.3, True,
@@ -280,3 +282,76 @@ def test_virtual_ranks_equal_single_rank(kind):
         p0, p1, ps = ranks[0].flat(net), ranks[1].flat(net), single.flat(net)
         assert torch.equal(p0, p1)                                       # replicas stay bit-identical
         np.testing.assert_allclose(p0.cpu().numpy(), ps.cpu().numpy(), rtol=2e-5, atol=2e-7)
+
+
+def _cql_hook(draws):
+    """noise_hook for CQLAgent from a list of standard-normal draws (the fixtures route uniform_ through the normal stream)."""
+    from oracle.agents import uniform_from_normal
+    it = iter(draws)
+
+    def hook(shape, kind='normal'):
+        z = next(it)
+        assert int(np.prod(z.shape)) == int(np.prod(shape)), (z.shape, shape)
+        return uniform_from_normal(z) if kind == 'uniform' else z
+    return hook
+
+
+def test_cql_tiny_trajectory_vs_reference(gold):
+    z = np.load(gold / 'tiny_cql.npz')
+    torch.manual_seed(21)
+    ag = make('cql', 5, 3, 32, 8)
+    for nm, net in nets_of(ag):
+        for k, v in net.state_dict().items():
+            np.testing.assert_allclose(v.cpu().numpy(), z[f'init/{nm}/{k}'], rtol=0, atol=2e-6, err_msg=f'{nm}.{k}')
+        net.load_state_dict({k: torch.from_numpy(z[f'init/{nm}/{k}']) for k in net.state_dict()})
+    ag.noise_hook = _cql_hook([z[f'noise/{i}'] for i in range(25)])
+    keys = [str(k) for k in z['metric_keys']]
+    for i in range(5):
+        m = ag.update(iter([tuple(z[f'batch/{i}/{j}'] for j in range(5))]), i)
+        assert sorted(m.keys()) == keys
+        np.testing.assert_allclose(np.array([m[k] for k in keys]), z['metrics'][i], rtol=1e-4, atol=3e-6, err_msg=f'cql step {i} {keys}')
+    for nm, net in nets_of(ag):
+        for k, v in net.state_dict().items():
+            np.testing.assert_allclose(v.cpu().numpy(), z[f'final/{nm}/{k}'], rtol=1e-4, atol=2e-6, err_msg=f'{nm}.{k}')
+    np.testing.assert_allclose(ag.log_actor_alpha.numpy(), z['final/log_actor_alpha'], rtol=1e-5, atol=1e-8)
+
+
+def test_cql_full_size_vs_reference_fp32(gold):
+    """BASELINE.json configs[2] shapes: CQL, quadruped (O=78, A=12), H=1024, B=1024, n_samples=3 -> critic on 10 B rows."""
+    g = json.load(open(gold / 'full_cql.json'))
+    O, A, H, B = g['dims']
+    ag = make('cql', O, A, H, B)
+    load_synth(ag, 'cql', O, A, H, g['param_seed'])
+    ns = _synth.NoiseStream(g['noise_seed'])
+    from oracle.agents import uniform_from_normal
+    ag.noise_hook = lambda shape, kind='normal': uniform_from_normal(ns.draw(shape)) if kind == 'uniform' else ns.draw(shape)
+    for i in range(g['nsteps']):
+        m = ag.update(iter([_synth.synth_batch(g['batch_seed'], i, B, O, A)]), i)
+        for k, v in g['fp32']['metrics'][i].items():
+            assert abs(m[k] - v) <= 1e-4 * abs(v) + 2e-6, ('cql', i, k, m[k], v, g['fp64']['metrics'][i][k])
+    for nm, net in nets_of(ag):
+        flat = torch.cat([p.double().reshape(-1) for p in net.parameters()])
+        s, s2, mx = g['fp32']['checksums'][nm]
+        assert abs(float((flat * flat).sum()) - s2) <= 1e-5 * s2, nm
+
+
+def test_cql_act_and_graph():
+    O, A, H, B = 24, 6, 128, 64
+    torch.manual_seed(2)
+    a1 = make('cql', O, A, H, B)
+    torch.manual_seed(2)
+    a2 = make('cql', O, A, H, B)
+    obs = np.random.RandomState(0).standard_normal(O).astype(np.float32)
+    act = a1.act(obs, 0, eval_mode=True)
+    assert act.shape == (A,) and np.all(np.abs(act) < 1)
+    a1.num_expl_steps = 0
+    assert a1.act(obs, 5, eval_mode=False).shape == (A,)
+    e1, it1 = _arena(3)
+    e2, it2 = _arena(3)
+    assert a1.enable_graph(it1)
+    it2.sample_into(a2.engine.batch_slots())
+    for s in range(3):
+        m1, m2 = a1.update(it1, s), a2.update(it2, s)
+        assert m1 == m2, (s, m1, m2)
+    for p, q in zip(a1.actor.parameters(), a2.actor.parameters()):
+        assert torch.equal(p, q)
