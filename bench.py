@@ -193,7 +193,11 @@ def main():
         big = fl >= 2.0 * 2 * B * H * H * 0.99           # the two-problem 1024^3 launches (fwd / dgrad / wgrad of Linear(H,H))
         ach = float(fl[big].mean() / (ms[big].mean() * 1e-3) / 1e12)
         peak = PEAK_TFLOPS[args.precision]
-        out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
+        traffic = None          # HBM-side bytes per launch from the committed rocprofv3 PMC passes (bf16 kernel only)
+        tf = ROOT / 'profiles' / 'r01_pmc_traffic_bf16.json'
+        if args.precision == 'bf16' and tf.exists():
+            traffic = json.load(open(tf))['traffic_bytes_per_launch']
+        out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic,
                            'kernel': ('gemm16g_kernel' if args.precision == 'bf16' else 'gemm_kernel') + ' (grouped 2x[1024x1024x1024], fwd/dgrad/wgrad of Linear(H,H))',
                            'launches': int(big.sum()), 'event_overhead_us': float(ovh.value * 1e3),
                            'avg_us': float(ms[big].mean() * 1e3), 'flop_per_launch': float(fl[big].mean()),

@@ -421,9 +421,9 @@ __global__ __launch_bounds__(256) void gemm16g_kernel(const Gemm16Batch gb) {
     const int h = lane >> 5;
     const int nk = K >> 6;                         // multiple of NSTG (checked by the launcher)
 
-    f32x16 acc;
+    f32x16 acc, acc2;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; }
 
     // ---- LDS-DMA source pointers: this wave's two 1-KB pieces per operand image (image rows 16*wave+8j + lane/8);
     // everything per-lane is computed once, the k-loop only adds a constant stride
@@ -491,8 +491,12 @@ __global__ __launch_bounds__(256) void gemm16g_kernel(const Gemm16Batch gb) {
             bfr[q] = frag(Bs, BT, boff[q]);
         }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q], bfr[q], acc, 0, 0, 0);
+        // two independent accumulation chains: PMC shows ~36 % of wave cycles as MFMA issue stalls (SQ_WAIT_INST_ANY)
+        // when all four MFMAs of a k-tile chain through one accumulator
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[0], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bfr[1], acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bfr[2], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[3], bfr[3], acc2, 0, 0, 0);
     };
 
     fill(std::integral_constant<int, 0>{});
@@ -505,6 +509,8 @@ __global__ __launch_bounds__(256) void gemm16g_kernel(const Gemm16Batch gb) {
         step(std::integral_constant<int, 3>{}, t + 3);
     }
 
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] += acc2[i];
     const int n = n0 + wn * 32 + (lane & 31);
     const float bias = P.bias ? P.bias[n] : 0.f;
     const bool relu = gb.relu != 0;
