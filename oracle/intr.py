@@ -1,0 +1,199 @@
+"""ORACLE (test infrastructure only — never imported by the product path).
+
+numpy fp32 restatement of the intrinsic-reward modules that sit in front of the DDPG update in the
+reference's unsupervised agents (states observations):
+  RND      /root/reference/agents/unsupervised_learning/rnd.py:13-60 (module), :79-108 (update_rnd, compute_intr_reward)
+  ICM      /root/reference/agents/unsupervised_learning/icm.py:12-45, :64-92
+  ICM-APT  /root/reference/agents/unsupervised_learning/icm_apt.py:13-57, :86-110 (PBE reward: utils.py:279-319)
+and of the update() that wires them into DDPG (rnd.py:110-159, icm.py:94-139, icm_apt.py:112-158).
+Pinned by tests/golden/tiny_{rnd,icm,icm_apt,icm_apt-kth}.npz (reference outputs).
+"""
+import numpy as np
+
+from . import nets
+from .knn import PBE, RMS
+from .nets import F32, Adam, linear_bwd, linear_fwd
+
+BN_EPS = F32(1e-5)           # nn.BatchNorm1d default
+
+
+def mlp_fwd(p, x, final_tanh=False):
+    """nn.Sequential(Linear, ReLU, Linear, ReLU, ..., Linear[, Tanh]); p = [W, b] * L."""
+    acts = [x]
+    n = len(p) // 2
+    for l in range(n):
+        z = linear_fwd(acts[-1], p[2 * l], p[2 * l + 1])
+        if l < n - 1:
+            z = np.maximum(z, F32(0))
+        elif final_tanh:
+            z = np.tanh(z).astype(F32)
+        acts.append(z)
+    return acts[-1], acts
+
+
+def mlp_bwd(p, acts, dout, final_tanh=False, need_dx=False):
+    n = len(p) // 2
+    grads = [None] * len(p)
+    d = dout
+    for l in range(n - 1, -1, -1):
+        a = acts[l + 1]
+        if l < n - 1:
+            d = (d * (a > 0)).astype(F32)
+        elif final_tanh:
+            d = (d * (F32(1) - a * a)).astype(F32)
+        dW, db, d = linear_bwd(acts[l], p[2 * l], d, need_dx or l > 0)
+        grads[2 * l], grads[2 * l + 1] = dW, db
+    return grads, d
+
+
+def l2_rows(x):
+    """torch.norm(x, dim=-1, p=2, keepdim=True) and its (sub)gradient factor x/||x|| (0 where the norm is 0)."""
+    n = np.sqrt((x * x).sum(-1, keepdims=True, dtype=F32)).astype(F32)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        g = np.where(n > 0, x / n, F32(0)).astype(F32)
+    return n, g
+
+
+RND_KEYS = [f'{n}.{i}.{w}' for n in ('predictor', 'target') for i in (1, 3, 5) for w in ('weight', 'bias')]
+ICM_KEYS = [f'{n}.{i}.{w}' for n in ('forward_net', 'backward_net') for i in (0, 2) for w in ('weight', 'bias')]
+APT_KEYS = ['trunk.0.weight', 'trunk.0.bias', 'trunk.1.weight', 'trunk.1.bias'] + ICM_KEYS
+
+
+def intr_param_shapes(kind, O, A, H, R):
+    """[(key, shape)] in the module's parameters() order."""
+    if kind == 'rnd':
+        one = [(H, O), (H,), (H, H), (H,), (R, H), (R,)]
+        return list(zip(RND_KEYS, one + one))
+    if kind == 'icm':
+        return list(zip(ICM_KEYS, [(H, O + A), (H,), (O, H), (O,), (H, 2 * O), (H,), (A, H), (A,)]))
+    return list(zip(APT_KEYS, [(R, O), (R,), (R,), (R,), (H, R + A), (H,), (R, H), (R,), (H, 2 * R), (H,), (A, H), (A,)]))
+
+
+class OracleRND:
+    """rnd.py: BatchNorm1d(affine=False, training) -> clamp(+-5) -> predictor / frozen target MLPs."""
+
+    def __init__(self, params, lr=1e-4, scale=1.0, clip_val=5.0):
+        self.p = [np.array(x, F32) for x in params]       # predictor (6) then target (6)
+        self.opt = Adam(self.p[:6], lr)                    # target grads are None -> Adam skips them (rnd.py:41-42,76)
+        self.scale, self.clip = scale, clip_val
+        self.rms = RMS()
+        O = self.p[0].shape[1]
+        self.running_mean, self.running_var, self.num_batches = np.zeros(O, F32), np.ones(O, F32), 0
+
+    def _norm(self, obs):
+        B = obs.shape[0]
+        mean = obs.mean(0, dtype=F32)
+        var = ((obs - mean) ** 2).mean(0, dtype=F32)                       # biased, normalisation
+        self.running_mean = (F32(0.9) * self.running_mean + F32(0.1) * mean).astype(F32)
+        self.running_var = (F32(0.9) * self.running_var + F32(0.1) * var * F32(B / max(B - 1, 1))).astype(F32)
+        self.num_batches += 1
+        x = ((obs - mean) / np.sqrt(var + BN_EPS)).astype(F32)
+        return np.clip(x, F32(-self.clip), F32(self.clip))
+
+    def errors(self, obs):
+        x = self._norm(obs)
+        pred, acts = mlp_fwd(self.p[:6], x)
+        targ, _ = mlp_fwd(self.p[6:], x)
+        diff = (targ - pred).astype(F32)
+        return (diff * diff).mean(-1, keepdims=True, dtype=F32), diff, acts
+
+    def update(self, obs):                                                 # rnd.py:79-96
+        err, diff, acts = self.errors(obs)
+        B, R = diff.shape
+        loss = err.mean(dtype=F32)
+        dpred = (F32(-2.0) * diff / F32(R) / F32(B)).astype(F32)
+        grads, _ = mlp_bwd(self.p[:6], acts, dpred)
+        self.opt.step(self.p[:6], grads)
+        self.last_grads = grads
+        return float(loss)
+
+    def reward(self, obs):                                                 # rnd.py:98-103
+        err, _, _ = self.errors(obs)
+        _, var = self.rms(err)
+        return (F32(self.scale) * err / (np.sqrt(var) + F32(1e-8))).astype(F32)
+
+
+class OracleICM:
+    """icm.py: forward model on [obs|action] -> next_obs, inverse model on [obs|next_obs] -> tanh action."""
+
+    def __init__(self, params, lr=1e-4, scale=1.0):
+        self.p = [np.array(x, F32) for x in params]       # forward_net (4) then backward_net (4)
+        self.opt = Adam(self.p, lr)
+        self.scale = scale
+
+    def errors(self, obs, action, next_obs):
+        nhat, fa = mlp_fwd(self.p[:4], np.concatenate([obs, action], -1))
+        ahat, ba = mlp_fwd(self.p[4:], np.concatenate([obs, next_obs], -1), final_tanh=True)
+        fe, fg = l2_rows((next_obs - nhat).astype(F32))
+        be, bg = l2_rows((action - ahat).astype(F32))
+        return fe, be, fg, bg, fa, ba
+
+    def update(self, obs, action, next_obs):                               # icm.py:64-84
+        fe, be, fg, bg, fa, ba = self.errors(obs, action, next_obs)
+        B = F32(obs.shape[0])
+        loss = fe.mean(dtype=F32) + be.mean(dtype=F32)
+        g1, _ = mlp_bwd(self.p[:4], fa, (-fg / B).astype(F32))
+        g2, _ = mlp_bwd(self.p[4:], ba, (-bg / B).astype(F32), final_tanh=True)
+        self.last_grads = g1 + g2
+        self.opt.step(self.p, self.last_grads)
+        return float(loss)
+
+    def reward(self, obs, action, next_obs):                               # icm.py:86-92
+        fe = self.errors(obs, action, next_obs)[0]
+        return np.log(fe * F32(self.scale) + F32(1.0)).astype(F32)
+
+
+class OracleICMAPT:
+    """icm_apt.py: ICM in the space of a Linear-LayerNorm-Tanh trunk; reward = particle entropy of the trunk output."""
+
+    def __init__(self, params, lr=1e-4, knn_rms=True, knn_k=12, knn_avg=True, knn_clip=0.0):
+        self.p = [np.array(x, F32) for x in params]       # trunk (4), forward_net (4), backward_net (4)
+        self.opt = Adam(self.p, lr)
+        self.pbe = PBE(RMS(), knn_clip, knn_k, knn_avg, knn_rms)
+
+    def update(self, obs, action, next_obs):                               # icm_apt.py:33-50,86-104
+        B = obs.shape[0]
+        rep, tc = nets.Trunk.fwd(self.p[:4], np.concatenate([obs, next_obs], 0))     # same weights on both
+        ro, rn = rep[:B], rep[B:]
+        nhat, fa = mlp_fwd(self.p[4:8], np.concatenate([ro, action], -1))
+        ahat, ba = mlp_fwd(self.p[8:], np.concatenate([ro, rn], -1), final_tanh=True)
+        fe, fg = l2_rows((rn - nhat).astype(F32))
+        be, bg = l2_rows((action - ahat).astype(F32))
+        loss = fe.mean(dtype=F32) + be.mean(dtype=F32)
+        R = ro.shape[1]
+        g1, dx1 = mlp_bwd(self.p[4:8], fa, (-fg / F32(B)).astype(F32), need_dx=True)
+        g2, dx2 = mlp_bwd(self.p[8:], ba, (-bg / F32(B)).astype(F32), final_tanh=True, need_dx=True)
+        d_ro = (dx1[:, :R] + dx2[:, :R]).astype(F32)
+        d_rn = (fg / F32(B) + dx2[:, R:]).astype(F32)      # next_obs rep is also the forward model's regression target
+        g0, _ = nets.Trunk.bwd(self.p[:4], tc, np.concatenate([d_ro, d_rn], 0), need_dx=False)
+        self.last_grads = g0 + g1 + g2
+        self.opt.step(self.p, self.last_grads)
+        return float(loss)
+
+    def reward(self, obs, action, next_obs):                               # icm_apt.py:106-110
+        rep, _ = nets.Trunk.fwd(self.p[:4], obs)
+        return self.pbe(rep).reshape(-1, 1)
+
+
+class OracleUnsupAgent:
+    """{RND,ICM,ICMAPT}Agent.update with reward_free=True: module step, intrinsic reward, then the DDPG update on it."""
+
+    def __init__(self, kind, ddpg, module):
+        self.kind, self.ddpg, self.module = kind, ddpg, module
+
+    def update(self, batch, step, noise_critic, noise_actor):
+        if step % self.ddpg.update_every_steps != 0:
+            return {}
+        obs, action, extr, discount, next_obs = [np.asarray(x, F32) for x in batch[:5]]
+        args = (obs,) if self.kind == 'rnd' else (obs, action, next_obs)
+        loss = self.module.update(*args)
+        intr = self.module.reward(*args)
+        self.last_intr = intr
+        m = self.ddpg.update((obs, action, intr, discount, next_obs), step, noise_critic, noise_actor)
+        m[{'rnd': 'rnd_loss'}.get(self.kind, 'icm_loss')] = loss
+        m['intr_reward'] = float(intr.mean(dtype=F32))
+        m['extr_reward'] = float(extr.mean(dtype=F32))
+        if self.kind == 'rnd':
+            m['pred_error_mean'] = float(self.module.rms.M[0])
+            m['pred_error_std'] = float(np.sqrt(self.module.rms.S[0]))
+        return m

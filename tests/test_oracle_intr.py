@@ -1,0 +1,56 @@
+"""Oracle restatement of the RND / ICM / ICM-APT agents vs the reference's own outputs (tests/golden/tiny_{rnd,icm,icm_apt*}.npz:
+5 update() calls of the reference agents on CPU, reward_free=True)."""
+import numpy as np
+import pytest
+
+from oracle.agents import OracleAgent, param_shapes
+from oracle.intr import OracleICM, OracleICMAPT, OracleRND, OracleUnsupAgent, intr_param_shapes
+
+O, A, H, R = 5, 3, 32, 16
+KINDS = ['rnd', 'icm', 'icm_apt', 'icm_apt-kth']
+
+
+def build_oracle(z, kind):
+    base = kind.partition('-')[0]
+    ash, csh = param_shapes('ddpg', O, A, H)
+    ddpg = OracleAgent('ddpg', [z[f'init/actor/{k}'] for k, _ in ash], [z[f'init/critic/{k}'] for k, _ in csh])
+    mod_name = 'rnd' if base == 'rnd' else 'icm'
+    ish = intr_param_shapes(base, O, A, H, R)
+    params = [z[f'init/{mod_name}/{k}'] for k, _ in ish]
+    for (k, s), p in zip(ish, params):
+        assert tuple(p.shape) == tuple(s), (k, p.shape, s)
+    if base == 'rnd':
+        mod = OracleRND(params)
+    elif base == 'icm':
+        mod = OracleICM(params)
+    else:
+        mod = OracleICMAPT(params, knn_k=3, **(dict(knn_avg=False, knn_clip=0.0005) if kind.endswith('kth') else {}))
+    return OracleUnsupAgent(base, ddpg, mod), ash, csh, ish, mod_name
+
+
+@pytest.mark.parametrize('kind', KINDS)
+def test_tiny_unsup_trajectory(gold, kind):
+    z = np.load(gold / f'tiny_{kind}.npz')
+    ag, ash, csh, ish, mod_name = build_oracle(z, kind)
+    keys = [str(k) for k in z['metric_keys']]
+    for i in range(5):
+        batch = [z[f'batch/{i}/{j}'] for j in range(5)]
+        assert ag.update(batch, 2 * i + 1, None, None) == {}
+        m = ag.update(batch, 2 * i, z[f'noise/{2 * i}'], z[f'noise/{2 * i + 1}'])
+        np.testing.assert_allclose(ag.last_intr, z['intr_reward'][i], rtol=2e-5, atol=2e-6, err_msg=f'{kind} intr step {i}')
+        got = np.array([m[k] for k in keys])
+        np.testing.assert_allclose(got, z['metrics'][i], rtol=5e-5, atol=2e-6, err_msg=f'{kind} step {i} {keys}')
+    for (k, _), p in zip(ish, ag.module.p):
+        np.testing.assert_allclose(p, z[f'final/{mod_name}/{k}'], rtol=1e-4, atol=2e-6, err_msg=k)
+    for (k, _), p in zip(ash, ag.ddpg.actor):
+        np.testing.assert_allclose(p, z[f'final/actor/{k}'], rtol=1e-4, atol=2e-6, err_msg=k)
+    for (k, _), p, t in zip(csh, ag.ddpg.critic, ag.ddpg.critic_target):
+        np.testing.assert_allclose(p, z[f'final/critic/{k}'], rtol=1e-4, atol=2e-6, err_msg=k)
+        np.testing.assert_allclose(t, z[f'final/critic_target/{k}'], rtol=1e-4, atol=2e-6, err_msg=k)
+    rms = ag.module.rms if kind == 'rnd' else getattr(ag.module, 'pbe', None) and ag.module.pbe.rms
+    if rms is not None and 'final/rms' in z:
+        np.testing.assert_allclose([rms.M[0], rms.S[0], rms.n], z['final/rms'], rtol=2e-5)
+    if kind == 'rnd':      # BatchNorm buffers (two forward passes per update: update_rnd + compute_intr_reward)
+        np.testing.assert_allclose(ag.module.running_mean, z['final/rnd/normalize_obs.running_mean'], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(ag.module.running_var, z['final/rnd/normalize_obs.running_var'], rtol=1e-5, atol=1e-6)
+        assert ag.module.num_batches == int(z['final/rnd/normalize_obs.num_batches_tracked'])

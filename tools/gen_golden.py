@@ -188,9 +188,19 @@ def make_agent(ref, kind, O, A, H, B, device='cpu', use_tb=True, **kw):
                                 kw.get('use_critic_lagrange', False))
     if kind == 'crr':
         return ref.crr.CRRAgent('crr', (O,), (A,), device, 1e-4, H, 0.01, 10, kw.get('weight_func', 'indicator'), 0.2, 1, B, 0.3, use_tb)
+    ddpg_kw = dict(name=kind, reward_free=True, obs_type='states', obs_shape=(O,), action_shape=(A,), device=device, lr=1e-4,
+                   feature_dim=50, hidden_dim=H, critic_target_tau=0.01, num_expl_steps=2000, update_every_steps=2,
+                   stddev_schedule=0.2, nstep=3, batch_size=B, stddev_clip=0.3, init_critic=True, use_tb=use_tb, use_wandb=False)
     if kind == 'ddpg':
-        return ref.ddpg.DDPGAgent('ddpg', True, 'states', (O,), (A,), device, 1e-4, 50, H, 0.01, 2000, 2,
-                                  0.2, 3, B, 0.3, True, use_tb, False)
+        return ref.ddpg.DDPGAgent(**ddpg_kw)
+    if kind == 'rnd':          # configs/agent/rnd.yaml: rnd_rep_dim 512, rnd_scale 1.0 (tiny: 16)
+        return ref.rnd.RNDAgent(rnd_rep_dim=kw.get('rep_dim', 16), update_encoder=True, rnd_scale=1.0, **ddpg_kw)
+    if kind == 'icm':          # configs/agent/icm.yaml: icm_scale 1.0
+        return ref.icm.ICMAgent(icm_scale=1.0, update_encoder=True, **ddpg_kw)
+    if kind == 'icm_apt':      # configs/agent/icm_apt.yaml: icm_rep_dim 512, knn_rms true, knn_k 12, knn_avg true, knn_clip 0.0
+        return ref.icm_apt.ICMAPTAgent(icm_scale=1.0, knn_rms=kw.get('knn_rms', True), knn_k=kw.get('knn_k', 3),
+                                       knn_avg=kw.get('knn_avg', True), knn_clip=kw.get('knn_clip', 0.0), update_encoder=True,
+                                       icm_rep_dim=kw.get('rep_dim', 16), **ddpg_kw)
     raise ValueError(kind)
 
 
@@ -199,6 +209,9 @@ def nets_of(agent):
     # (CQL's log_actor_alpha / log_critic_alpha scalars are stored separately by gen_tiny)
     if hasattr(agent, 'critic'):
         nets += [('critic', agent.critic), ('critic_target', agent.critic_target)]
+    for nm in ('rnd', 'icm'):            # intrinsic-reward modules of the DDPG-backbone agents
+        if hasattr(agent, nm):
+            nets.append((nm, getattr(agent, nm)))
     return nets
 
 
@@ -229,7 +242,7 @@ def run_agent(ref, agent, kind, nsteps, batch_fn, noise, dtype):
     metrics = []
     try:
         for i in range(nsteps):
-            step = 2 * i if kind == 'ddpg' else i           # ddpg.py:302 update_every_steps=2
+            step = 2 * i if kind in UNSUP else i           # ddpg.py:302 update_every_steps=2
             batch = tuple(x.astype(dtype) for x in batch_fn(i))
             m = agent.update(iter([batch]), step)
             metrics.append({k: float(v) for k, v in m.items()})
@@ -247,7 +260,8 @@ def checksums(agent):
     return cs
 
 
-TINY_KINDS = ('td3_bc', 'td3', 'bc', 'ddpg', 'crr', 'crr-exp', 'crr-identity', 'cql')
+UNSUP = ('ddpg', 'rnd', 'icm', 'icm_apt')
+TINY_KINDS = ('td3_bc', 'td3', 'bc', 'ddpg', 'crr', 'crr-exp', 'crr-identity', 'cql', 'rnd', 'icm', 'icm_apt', 'icm_apt-kth')
 
 
 def gen_tiny(ref):
@@ -255,8 +269,20 @@ def gen_tiny(ref):
     for kind in TINY_KINDS:
         torch.manual_seed(21)
         base, _, wf = kind.partition('-')
-        agent = make_agent(ref, base, O, A, H, B, **({'weight_func': wf} if wf else {}))
+        extra = {'weight_func': wf} if (wf and base == 'crr') else {}
+        if kind == 'icm_apt-kth':
+            extra = {'knn_avg': False, 'knn_clip': 0.0005}
+        agent = make_agent(ref, base, O, A, H, B, **extra)
         out = {}
+        intr_log = []
+        if hasattr(agent, 'compute_intr_reward'):        # record the intrinsic reward each step feeds to the critic
+            inner = agent.compute_intr_reward
+
+            def rec_intr(*a, **k):
+                r = inner(*a, **k)
+                intr_log.append(r.detach().numpy().copy())
+                return r
+            agent.compute_intr_reward = rec_intr
         for nm, net in nets_of(agent):
             for k, v in net.state_dict().items():
                 out[f'init/{nm}/{k}'] = v.numpy().copy()
@@ -284,6 +310,11 @@ def gen_tiny(ref):
         for nm, net in nets_of(agent):
             for k, v in net.state_dict().items():
                 out[f'final/{nm}/{k}'] = v.numpy().copy()
+        if intr_log:
+            out['intr_reward'] = np.stack(intr_log)
+        rms = getattr(agent, 'intrinsic_reward_rms', None) or getattr(getattr(agent, 'pbe', None), 'rms', None)
+        if rms is not None:
+            out['final/rms'] = np.array([float(rms.M), float(rms.S), float(rms.n)], np.float64)
         if base == 'cql':
             out['final/log_actor_alpha'] = agent.log_actor_alpha.detach().numpy().copy()
             out['final/log_critic_alpha'] = agent.log_critic_alpha.detach().numpy().copy()
