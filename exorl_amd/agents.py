@@ -4,6 +4,9 @@ libexorl_hip.so. Hydra drop-in: `agent._target_=exorl_amd.agents.TD3BCAgent` (se
 Reference classes mirrored (file:line in /root/reference):
   TD3BCAgent  agents/offline_learning/td3_bc.py:59-189      TD3Agent  agents/offline_learning/td3.py:59-186
   BCAgent     agents/offline_learning/bc.py:34-110           DDPGAgent agents/unsupervised_learning/ddpg.py:126-328 (states)
+  CRRAgent    agents/offline_learning/crr.py:59-219          CQLAgent  agents/offline_learning/cql.py:59-286
+  RNDAgent    agents/unsupervised_learning/rnd.py:63-159     ICMAgent  agents/unsupervised_learning/icm.py:48-139
+  ICMAPTAgent agents/unsupervised_learning/icm_apt.py:60-158
 
 Python here is orchestration only: it builds the initial weights with torch's CPU RNG in the reference's
 construction order (so a given torch.manual_seed yields the reference's initial parameters), hands batches
@@ -17,7 +20,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import utils
-from .engine import AgentEngine
+from .engine import AgentEngine, IntrEngine
 
 _OFFLINE_ACTOR_KEYS = ['policy.0.weight', 'policy.0.bias', 'policy.1.weight', 'policy.1.bias',
                        'policy.3.weight', 'policy.3.bias', 'policy.5.weight', 'policy.5.bias']
@@ -440,6 +443,7 @@ class DDPGAgent(_AgentBase):
         self.obs_dim = obs_shape[0] + meta_dim
         self.aug = self.encoder = _Identity()
         self.encoder_opt = None
+        self._precision = precision
         self._build(self.obs_dim, action_shape[0], hidden_dim, batch_size, lr, critic_target_tau, 0.0, stddev_clip, device,
                     precision, seed)
         self.train()
@@ -478,6 +482,158 @@ class DDPGAgent(_AgentBase):
         if self.use_tb or self.use_wandb:
             metrics.update(self._metrics(_CRITIC_METRICS + [(L.M_ACTOR_LOGPROB, 'actor_logprob')], stddev))
         return metrics
+
+
+def _seq_init(spec):
+    """Initial tensors of an nn.Sequential-style module: spec = [('lin', in, out) | ('ln', dim)]. Same RNG consumption as the
+    reference constructors: all Linears default-initialised at construction, then apply(utils.weight_init) in order."""
+    mods = [nn.Linear(s[1], s[2]) if s[0] == 'lin' else nn.LayerNorm(s[1]) for s in spec]
+    out = []
+    for m in mods:
+        if isinstance(m, nn.Linear):
+            nn.init.orthogonal_(m.weight.data)
+            m.bias.data.fill_(0.0)
+        out += [m.weight.data, m.bias.data]
+    return out
+
+
+_RND_KEYS = [f'{n}.{i}.{w}' for n in ('predictor', 'target') for i in (1, 3, 5) for w in ('weight', 'bias')]
+_ICM_KEYS = [f'{n}.{i}.{w}' for n in ('forward_net', 'backward_net') for i in (0, 2) for w in ('weight', 'bias')]
+_APT_KEYS = ['trunk.0.weight', 'trunk.0.bias', 'trunk.1.weight', 'trunk.1.bias'] + _ICM_KEYS
+
+
+class _RndView(NetView):
+    """agent.rnd: the parameters plus BatchNorm1d's buffers under the reference's state_dict keys (rnd.py:24-27)."""
+
+    def _bn(self):
+        O = self._engine.obs_dim
+        bn = self._engine.bn
+        return bn[:O], bn[O:2 * O], bn[2 * O:]
+
+    def state_dict(self):
+        mean, var, cnt = self._bn()
+        sd = OrderedDict([('normalize_obs.running_mean', mean.clone()), ('normalize_obs.running_var', var.clone()),
+                          ('normalize_obs.num_batches_tracked', cnt.clone().long().reshape(()))])
+        sd.update(super().state_dict())
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        sd = dict(sd)
+        mean, var, cnt = self._bn()
+        for k, dst in (('normalize_obs.running_mean', mean), ('normalize_obs.running_var', var), ('normalize_obs.num_batches_tracked', cnt)):
+            if k in sd:
+                dst.copy_(torch.as_tensor(sd.pop(k)).to(dst.device, torch.float32).reshape(dst.shape))
+            elif strict:
+                raise KeyError(f'state_dict mismatch: missing {k}')
+        super().load_state_dict(sd, strict)
+
+
+class _RmsView:
+    """Stands where the reference has a utils.RMS object (agent.intrinsic_reward_rms / agent.pbe.rms): .M, .S, .n."""
+
+    def __init__(self, engine):
+        self._engine = engine
+
+    M = property(lambda self: torch.tensor([self._engine.rms_state()[0]]))
+    S = property(lambda self: torch.tensor([self._engine.rms_state()[1]]))
+    n = property(lambda self: self._engine.rms_state()[2])
+
+
+class _IntrAgent(DDPGAgent):
+    """Shared update() of the reward-free agents (rnd.py:110-159, icm.py:94-139, icm_apt.py:112-158): module step and
+    intrinsic reward on the sampled batch (libexorl_hip: exorl_intr_update), then the DDPG update on that reward."""
+    LOSS_KEY = None
+
+    def _intr_step(self):
+        s = self._slots = self._slots or self.engine.batch_slots()
+        self.intr.update(s.obs, s.action, s.next_obs, s.reward, s.reward, True)
+
+    def enable_graph(self, replay_iter, step=0):
+        return False                     # the module step is launched eagerly in front of the DDPG chain
+
+    def update(self, replay_iter, step):
+        metrics = dict()
+        if step % self.update_every_steps != 0:
+            return metrics
+        if self.world_size != 1:
+            raise NotImplementedError('exorl_amd: the intrinsic-reward modules normalise over the batch (BatchNorm / RMS / kNN) and are '
+                                      'single-GPU this round; run data-parallel replicas instead')
+        stddev = self._stddev(step)
+        self._load_batch(replay_iter)
+        if self.reward_free:
+            self._intr_step()
+        self._run_update(stddev)
+        if self.use_tb or self.use_wandb:
+            metrics.update(self._metrics(_CRITIC_METRICS + [(L.M_ACTOR_LOGPROB, 'actor_logprob')], stddev))
+            if self.reward_free:
+                raw = self.intr.metrics_raw()
+                metrics[self.LOSS_KEY] = float(raw[L.IM_LOSS])
+                metrics['intr_reward'] = float(raw[L.IM_INTR_REWARD])
+                metrics['extr_reward'] = float(raw[L.IM_EXTR_REWARD])
+                if self.LOSS_KEY == 'rnd_loss':
+                    metrics['pred_error_mean'] = float(raw[L.IM_RMS_MEAN])
+                    metrics['pred_error_std'] = float(raw[L.IM_RMS_STD])
+            else:
+                metrics['extr_reward'] = metrics['batch_reward']
+        return metrics
+
+
+class RNDAgent(_IntrAgent):
+    """agents/unsupervised_learning/rnd.py:63-159 (configs/agent/rnd.yaml)."""
+    LOSS_KEY = 'rnd_loss'
+
+    def __init__(self, rnd_rep_dim, update_encoder, rnd_scale=1., **kwargs):
+        super().__init__(**kwargs)
+        self.rnd_scale = rnd_scale
+        self.update_encoder = update_encoder
+        O, H = self.obs_dim, self.hidden_dim
+        w = _seq_init([('lin', O, H), ('lin', H, H), ('lin', H, rnd_rep_dim)] * 2)      # predictor then target (rnd.py:28-43)
+        self.intr = IntrEngine('rnd', O, self.action_dim, H, self.engine.batch, rep_dim=rnd_rep_dim, lr=self.lr, scale=rnd_scale,
+                               precision=self._precision, device=self.device)
+        self.rnd = _RndView(self.intr, None, _RND_KEYS)
+        for p, t in zip(self.rnd.parameters(), w):
+            p.copy_(t.reshape(p.shape))
+        self.intrinsic_reward_rms = _RmsView(self.intr)
+
+
+class ICMAgent(_IntrAgent):
+    """agents/unsupervised_learning/icm.py:48-139 (configs/agent/icm.yaml)."""
+    LOSS_KEY = 'icm_loss'
+
+    def __init__(self, icm_scale, update_encoder, **kwargs):
+        super().__init__(**kwargs)
+        self.icm_scale = icm_scale
+        self.update_encoder = update_encoder
+        O, A, H = self.obs_dim, self.action_dim, self.hidden_dim
+        w = _seq_init([('lin', O + A, H), ('lin', H, O), ('lin', 2 * O, H), ('lin', H, A)])
+        self.intr = IntrEngine('icm', O, A, H, self.engine.batch, lr=self.lr, scale=icm_scale, precision=self._precision,
+                               device=self.device)
+        self.icm = NetView(self.intr, None, _ICM_KEYS)
+        for p, t in zip(self.icm.parameters(), w):
+            p.copy_(t.reshape(p.shape))
+
+
+class _PbeView:
+    def __init__(self, engine):
+        self.rms = _RmsView(engine)
+
+
+class ICMAPTAgent(_IntrAgent):
+    """agents/unsupervised_learning/icm_apt.py:60-158 (configs/agent/icm_apt.yaml)."""
+    LOSS_KEY = 'icm_loss'
+
+    def __init__(self, icm_scale, knn_rms, knn_k, knn_avg, knn_clip, update_encoder, icm_rep_dim, **kwargs):
+        super().__init__(**kwargs)
+        self.icm_scale = icm_scale
+        self.update_encoder = update_encoder
+        O, A, H, R = self.obs_dim, self.action_dim, self.hidden_dim, icm_rep_dim
+        w = _seq_init([('lin', O, R), ('ln', R), ('lin', R + A, H), ('lin', H, R), ('lin', 2 * R, H), ('lin', H, A)])
+        self.intr = IntrEngine('icm_apt', O, A, H, self.engine.batch, rep_dim=R, lr=self.lr, scale=icm_scale, knn_k=knn_k,
+                               knn_avg=knn_avg, knn_rms=knn_rms, knn_clip=knn_clip, precision=self._precision, device=self.device)
+        self.icm = NetView(self.intr, None, _APT_KEYS)
+        for p, t in zip(self.icm.parameters(), w):
+            p.copy_(t.reshape(p.shape))
+        self.pbe = _PbeView(self.intr)
 
 
 class _Identity:

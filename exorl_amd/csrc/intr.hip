@@ -1,0 +1,645 @@
+// Intrinsic-reward modules of the reward-free DDPG-backbone agents (states observations): one optimiser step of
+// the module on the sampled batch, then the intrinsic reward of that batch under the updated module, written
+// where the DDPG critic update reads its reward. Replaces (file:line in the reference repo):
+//   RND      agents/unsupervised_learning/rnd.py:13-60 (module), :79-108 (update_rnd, compute_intr_reward)
+//   ICM      agents/unsupervised_learning/icm.py:12-45, :64-92
+//   ICM-APT  agents/unsupervised_learning/icm_apt.py:13-57, :86-110; utils.PBE / utils.RMS utils/utils.py:257-319
+// The modules are plain Linear/ReLU stacks of arbitrary widths (obs_dim, hidden_dim, rep_dim), so the layers run on
+// the generic fp32-source grouped GEMM (gemm.hip) with small row/column kernels around it; what the reference's
+// autograd graph hides and this file exploits:
+//   * RND's target net is frozen and BatchNorm of the same batch is identical in the reward pass, so the target
+//     forward runs once per update instead of twice;
+//   * the L2-norm losses' gradients are formed in the same kernel that computes the errors (no separate loss pass);
+//   * APT's reward is a top-k over pairwise distances (knn.hip) instead of a (B,B,rep) broadcast temporary.
+#include <cmath>
+#include <vector>
+
+#include "kernels.h"
+
+namespace exorl {
+
+struct ITensor { int64_t off, rows, cols; };
+struct Lin { int in, out; int64_t W, b; };
+struct RmsState { float M, S; double n; };          // utils.RMS: running mean / variance / count (n starts at 1e-4)
+
+struct Mlp {                                         // Linear-ReLU-...-Linear; the last layer's output is raw
+    std::vector<Lin> L;
+    std::vector<float*> act, dact;                   // per layer: (rows, out) activations and their gradients
+};
+
+__device__ __forceinline__ float block_sum(float v, float* red) {      // all threads get the total; red: >= 17 floats
+    v = wave_sum(v);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < nw; ++i) s += red[i];
+        red[16] = s;
+    }
+    __syncthreads();
+    return red[16];
+}
+
+// nn.BatchNorm1d(affine=False) in training mode, then clamp(+-clip) (rnd.py:24-26,49-50): one block per feature.
+__global__ __launch_bounds__(256) void bn_clamp_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int rows, int O,
+                                                       float clip, float* __restrict__ running /* mean[O] var[O] count */) {
+    __shared__ float red[17];
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int r = threadIdx.x; r < rows; r += blockDim.x) s += x[(int64_t)r * ldx + c];
+    const float mean = block_sum(s, red) / (float)rows;
+    float q = 0.f;
+    for (int r = threadIdx.x; r < rows; r += blockDim.x) { const float d = x[(int64_t)r * ldx + c] - mean; q += d * d; }
+    const float var = block_sum(q, red) / (float)rows;
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    for (int r = threadIdx.x; r < rows; r += blockDim.x) {
+        const float v = (x[(int64_t)r * ldx + c] - mean) * rstd;
+        out[(int64_t)r * O + c] = fminf(fmaxf(v, -clip), clip);
+    }
+    if (threadIdx.x == 0) {                          // momentum 0.1; running_var takes the unbiased estimate
+        running[c] = 0.9f * running[c] + 0.1f * mean;
+        running[O + c] = 0.9f * running[O + c] + 0.1f * var * ((float)rows / (float)(rows > 1 ? rows - 1 : 1));
+        if (c == 0) running[2 * O] += 1.0f;
+    }
+}
+
+// dst[r] = [a[r, 0:ca] | b[r, 0:cb]]
+__global__ __launch_bounds__(256) void concat2_kernel(const float* __restrict__ a, int64_t lda, int ca, const float* __restrict__ b, int64_t ldb,
+                                                      int cb, float* __restrict__ dst, int rows) {
+    const int w = ca + cb;
+    const int64_t n = (int64_t)rows * w;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / w;
+        const int c = (int)(i - r * w);
+        dst[i] = c < ca ? a[r * lda + c] : b[r * ldb + (c - ca)];
+    }
+}
+
+__global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ d, const float* __restrict__ a, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        d[i] = a[i] > 0.f ? d[i] : 0.f;
+}
+
+// err[b] = mean_j (t - p)^2 (rnd.py:54-56); dpred = d(mean_b err)/dp = -2 (t - p) / R / B. One wave per row.
+__global__ __launch_bounds__(256) void rnd_err_kernel(const float* __restrict__ pred, const float* __restrict__ targ, float* __restrict__ err,
+                                                      float* __restrict__ dpred, int rows, int R) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float invR = 1.0f / (float)R, invB = 1.0f / (float)rows;
+    float s = 0.f;
+    for (int j = lane; j < R; j += 64) {
+        const float d = targ[(int64_t)row * R + j] - pred[(int64_t)row * R + j];
+        s += d * d;
+        if (dpred) dpred[(int64_t)row * R + j] = (-2.0f * d * invR) * invB;
+    }
+    s = wave_sum(s);
+    if (lane == 0) err[row] = s * invR;
+}
+
+// out[idx] (+)= sum(x) * scale — single block
+__global__ __launch_bounds__(1024) void mean_kernel(const float* __restrict__ x, int n, float scale, float* __restrict__ out, int accumulate) {
+    __shared__ float red[17];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += x[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) *out = (accumulate ? *out : 0.f) + s * scale;
+}
+
+// utils.RMS.__call__ (utils.py:264-276) on n values with batch mean `mean` and unbiased variance `var`; fp32 tensor math
+// with the Python-float scalars rounded to fp32 where torch does
+__device__ inline void rms_update(RmsState* st, float mean, float var, int bs) {
+    const float n = (float)st->n, nb = (float)(st->n + (double)bs), fbs = (float)bs;
+    const float delta = mean - st->M;
+    const float newM = st->M + delta * fbs / nb;
+    const float newS = (st->S * n + var * fbs + delta * delta * n * fbs / nb) / nb;
+    st->M = newM; st->S = newS; st->n += (double)bs;
+}
+
+// compute_intr_reward (rnd.py:98-103) + the update()'s reward bookkeeping (:131-137): single block
+__global__ __launch_bounds__(1024) void rnd_reward_kernel(const float* __restrict__ err, const float* extr, float* reward, int B, float scale,
+                                                          RmsState* st, float* __restrict__ metrics) {
+    __shared__ float red[17];
+    __shared__ float sh_S;
+    float s = 0.f, e = 0.f;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) { s += err[i]; e += extr ? extr[i] : 0.f; }
+    const float mean = block_sum(s, red) / (float)B;
+    e = block_sum(e, red);
+    float q = 0.f;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) { const float d = err[i] - mean; q += d * d; }
+    const float var = block_sum(q, red) / (float)(B > 1 ? B - 1 : 1);
+    if (threadIdx.x == 0) {
+        rms_update(st, mean, var, B);
+        sh_S = st->S;
+        metrics[EXORL_IM_EXTR_REWARD] = e / (float)B;
+        metrics[EXORL_IM_RMS_MEAN] = st->M;
+        metrics[EXORL_IM_RMS_STD] = sqrtf(st->S);
+    }
+    __syncthreads();
+    const float denom = sqrtf(sh_S) + 1e-8f;
+    float rs = 0.f;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        const float r = scale * err[i] / denom;
+        reward[i] = r;
+        rs += r;
+    }
+    rs = block_sum(rs, red);
+    if (threadIdx.x == 0) metrics[EXORL_IM_INTR_REWARD] = rs / (float)B;
+}
+
+// ICM errors (icm.py:28-45): fe = ||tgt - pred||_2, be = ||a - tanh(apre)||_2 per row, and the gradients of
+// mean(fe) + mean(be) w.r.t. pred / apre. One wave per row. apre == nullptr: forward error only (reward pass).
+__global__ __launch_bounds__(256) void icm_err_kernel(const float* __restrict__ pred, int D, const float* __restrict__ tgt, int64_t ldt,
+                                                      const float* __restrict__ apre, const float* __restrict__ action, int A,
+                                                      float* __restrict__ fe, float* __restrict__ be, float* __restrict__ dpred,
+                                                      float* __restrict__ dapre, int rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float invB = 1.0f / (float)rows;
+    float s = 0.f;
+    for (int j = lane; j < D; j += 64) { const float d = tgt[(int64_t)row * ldt + j] - pred[(int64_t)row * D + j]; s += d * d; }
+    const float nf = sqrtf(wave_sum(s));
+    if (lane == 0) fe[row] = nf;
+    if (dpred)
+        for (int j = lane; j < D; j += 64) {
+            const float d = tgt[(int64_t)row * ldt + j] - pred[(int64_t)row * D + j];
+            dpred[(int64_t)row * D + j] = nf > 0.f ? -(d / nf) * invB : 0.f;
+        }
+    if (!apre) return;
+    float ah = 0.f, d = 0.f;
+    if (lane < A) { ah = tanhf(apre[(int64_t)row * A + lane]); d = action[(int64_t)row * A + lane] - ah; }
+    const float nb = sqrtf(wave_sum(d * d));
+    if (lane == 0) be[row] = nb;
+    if (dapre && lane < A) dapre[(int64_t)row * A + lane] = nb > 0.f ? (-(d / nb) * invB) * (1.0f - ah * ah) : 0.f;
+}
+
+// reward = log(fe * scale + 1) (icm.py:86-92) + reward bookkeeping; single block
+__global__ __launch_bounds__(1024) void icm_reward_kernel(const float* __restrict__ fe, const float* extr, float* reward, int B, float scale,
+                                                          float* __restrict__ metrics) {
+    __shared__ float red[17];
+    float e = 0.f;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) e += extr ? extr[i] : 0.f;
+    e = block_sum(e, red);
+    float rs = 0.f;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        const float r = logf(fe[i] * scale + 1.0f);
+        reward[i] = r;
+        rs += r;
+    }
+    rs = block_sum(rs, red);
+    if (threadIdx.x == 0) { metrics[EXORL_IM_EXTR_REWARD] = e / (float)B; metrics[EXORL_IM_INTR_REWARD] = rs / (float)B; }
+}
+
+// utils.PBE.__call__ after the top-k (utils.py:301-319): topk (B,k) ascending; single block
+__global__ __launch_bounds__(1024) void pbe_reward_kernel(const float* __restrict__ topk, const float* extr, float* reward, int B, int k,
+                                                          int avg, int use_rms, float clip, RmsState* st, float* __restrict__ metrics) {
+    __shared__ float red[17];
+    __shared__ float sh_M;
+    const int n = avg ? B * k : B;
+    auto val = [&](int i) { return avg ? topk[i] : topk[(int64_t)i * k + (k - 1)]; };
+    float e = 0.f;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) e += extr ? extr[i] : 0.f;
+    e = block_sum(e, red);
+    float M = 1.0f;
+    if (use_rms) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) s += val(i);
+        const float mean = block_sum(s, red) / (float)n;
+        float q = 0.f;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) { const float d = val(i) - mean; q += d * d; }
+        const float var = block_sum(q, red) / (float)(n > 1 ? n - 1 : 1);
+        if (threadIdx.x == 0) { rms_update(st, mean, var, n); sh_M = st->M; }
+        __syncthreads();
+        M = sh_M;
+    }
+    float rs = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        float r;
+        if (avg) {
+            float acc = 0.f;
+            for (int j = 0; j < k; ++j) {
+                float v = topk[(int64_t)b * k + j];
+                if (use_rms) v = v / M;
+                if (clip >= 0.f) v = fmaxf(v - clip, 0.f);
+                acc += v;
+            }
+            r = acc / (float)k;
+        } else {
+            r = topk[(int64_t)b * k + (k - 1)];
+            if (use_rms) r = r / M;
+            if (clip >= 0.f) r = fmaxf(r - clip, 0.f);
+        }
+        r = logf(r + 1.0f);
+        reward[b] = r;
+        rs += r;
+    }
+    rs = block_sum(rs, red);
+    if (threadIdx.x == 0) {
+        metrics[EXORL_IM_EXTR_REWARD] = e / (float)B;
+        metrics[EXORL_IM_INTR_REWARD] = rs / (float)B;
+        metrics[EXORL_IM_RMS_MEAN] = st->M;
+        metrics[EXORL_IM_RMS_STD] = sqrtf(st->S);
+    }
+}
+
+// gradient reaching the trunk output of [obs; next_obs] (icm_apt.py:36-39): rows 0..B-1 from both nets' inputs,
+// rows B..2B-1 from the inverse model's input and from being the forward model's regression target (= -dnhat)
+__global__ __launch_bounds__(256) void apt_drep_kernel(const float* __restrict__ dxf, int64_t ldf, const float* __restrict__ dxb, int64_t ldb,
+                                                       const float* __restrict__ dnhat, float* __restrict__ drep, int B, int R) {
+    const int64_t n = (int64_t)B * R;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / R;
+        const int c = (int)(i - r * R);
+        drep[i] = dxf[r * ldf + c] + dxb[r * ldb + c];
+        drep[n + i] = dxb[r * ldb + R + c] - dnhat[i];
+    }
+}
+
+static int grid_for(int64_t n) { const int64_t b = (n + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
+
+static int mlp_forward(const Mlp& m, const float* P, const float* x, int rows, int prec, hipStream_t s) {
+    const int n = (int)m.L.size();
+    for (int l = 0; l < n; ++l) {
+        const Lin& L = m.L[l];
+        GemmProblem p{l ? m.act[l - 1] : x, P + L.W, m.act[l], P + L.b, rows, L.out, L.in, L.in, L.in, L.out};
+        EXORL_TRY(gemm_grouped(prec, 0, 0, &p, 1, l < n - 1, false, s));
+    }
+    return 0;
+}
+
+// dact[last] holds d(loss)/d(output); writes parameter gradients into G and, if dx, d(loss)/d(input) (rows, in0)
+static int mlp_backward(const Mlp& m, const float* P, float* G, const float* x, int rows, float* dx, int prec, hipStream_t s) {
+    const int n = (int)m.L.size();
+    for (int l = n - 1; l >= 0; --l) {
+        const Lin& L = m.L[l];
+        float* d = m.dact[l];
+        if (l < n - 1) {
+            const int64_t cnt = (int64_t)rows * L.out;
+            hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(cnt)), dim3(256), 0, s, d, m.act[l], cnt);
+            EXORL_LAUNCH_CHECK();
+        }
+        EXORL_TRY(colsum(d, G + L.b, rows, L.out, 1, 0, 0, s));
+        const float* in = l ? m.act[l - 1] : x;
+        GemmProblem w{d, in, G + L.W, nullptr, L.out, L.in, rows, L.out, L.in, L.in};          // dW[o][i] = sum_r d[r][o] in[r][i]
+        EXORL_TRY(gemm_grouped(prec, 1, 1, &w, 1, false, false, s));
+        float* dst = l ? m.dact[l - 1] : dx;
+        if (dst) {
+            GemmProblem g{d, P + L.W, dst, nullptr, rows, L.in, L.out, L.out, L.in, L.in};      // din[r][i] = sum_o d[r][o] W[o][i]
+            EXORL_TRY(gemm_grouped(prec, 0, 1, &g, 1, false, false, s));
+        }
+    }
+    return 0;
+}
+
+}  // namespace exorl
+
+using namespace exorl;
+
+struct exorl_intr {
+    exorl_intr_cfg cfg;
+    std::vector<ITensor> tensors;          // module.parameters() order
+    int64_t total = 0, trainable = 0;      // flat sizes (floats): all parameters / the prefix the optimiser steps
+    float* ws = nullptr;
+    bool owns_ws = false;
+    float* flat[4] = {nullptr, nullptr, nullptr, nullptr};
+    Mlp net[2];                            // RND: predictor, target; ICM(-APT): forward_net, backward_net
+    Lin trunk{};                           // APT: Linear(O, R) of the trunk; LayerNorm gain/beta offsets below
+    int64_t ln_g = 0, ln_b = 0;
+    float *xn = nullptr, *xf = nullptr, *xb = nullptr, *dxf = nullptr, *dxb = nullptr;
+    float *x2 = nullptr, *z = nullptr, *rep = nullptr, *xhat = nullptr, *rstd = nullptr, *drep = nullptr, *dz = nullptr, *topk = nullptr;
+    float *fe = nullptr, *be = nullptr, *metrics = nullptr, *bn = nullptr;
+    RmsState* rms = nullptr;
+    int64_t t = 0;                         // optimiser steps taken
+};
+
+namespace exorl {
+
+struct ICarver {
+    float* base; int64_t off = 0;
+    explicit ICarver(float* b) : base(b) {}
+    float* take(int64_t n) { float* p = base ? base + off : nullptr; off += round_up(n, 64); return p; }
+};
+
+static void describe_intr(exorl_intr* it) {
+    const auto& c = it->cfg;
+    const int O = c.obs_dim, A = c.act_dim, H = c.hidden_dim, R = c.rep_dim;
+    int64_t off = 0;
+    auto add = [&](int64_t rows, int64_t cols) { const int64_t o = off; it->tensors.push_back({o, rows, cols}); off += round_up(rows * cols, 4); return o; };
+    auto lin = [&](int in, int out) { Lin l{in, out, 0, 0}; l.W = add(out, in); l.b = add(out, 1); return l; };
+    it->tensors.clear();
+    it->net[0].L.clear(); it->net[1].L.clear();
+    if (c.kind == EXORL_INTR_RND) {
+        for (int n = 0; n < 2; ++n) {
+            it->net[n].L = {lin(O, H), lin(H, H), lin(H, R)};
+            if (n == 0) it->trainable = round_up(off, 64);
+            off = round_up(off, 64);
+        }
+    } else {
+        int in_f = O + A, in_b = 2 * O, out_f = O;
+        if (c.kind == EXORL_INTR_ICM_APT) {
+            it->trunk = lin(O, R);
+            it->ln_g = add(R, 1); it->ln_b = add(R, 1);
+            in_f = R + A; in_b = 2 * R; out_f = R;
+        }
+        it->net[0].L = {lin(in_f, H), lin(H, out_f)};
+        it->net[1].L = {lin(in_b, H), lin(H, A)};
+        it->trainable = round_up(off, 64);
+    }
+    it->total = round_up(off, 64);
+}
+
+static void carve_intr(exorl_intr* it, ICarver& c) {
+    const auto& g = it->cfg;
+    const int64_t B = g.batch, O = g.obs_dim, A = g.act_dim, R = g.rep_dim;
+    it->flat[EXORL_T_PARAM] = c.take(it->total);
+    for (int w = 1; w < 4; ++w) it->flat[w] = c.take(it->trainable);
+    for (int n = 0; n < 2; ++n) {
+        Mlp& m = it->net[n];
+        m.act.clear(); m.dact.clear();
+        for (const Lin& l : m.L) {
+            m.act.push_back(c.take(B * l.out));
+            m.dact.push_back((g.kind == EXORL_INTR_RND && n == 1) ? nullptr : c.take(B * l.out));
+        }
+    }
+    it->fe = c.take(B); it->be = c.take(B);
+    it->metrics = c.take(EXORL_N_INTR_METRICS);
+    it->rms = reinterpret_cast<RmsState*>(c.take(4));
+    if (g.kind == EXORL_INTR_RND) {
+        it->xn = c.take(B * O);
+        it->bn = c.take(2 * O + 1);
+    } else {
+        const int64_t in_f = it->net[0].L[0].in, in_b = it->net[1].L[0].in;
+        it->xf = c.take(B * in_f); it->xb = c.take(B * in_b);
+        if (g.kind == EXORL_INTR_ICM_APT) {
+            it->dxf = c.take(B * in_f); it->dxb = c.take(B * in_b);
+            it->x2 = c.take(2 * B * O); it->z = c.take(2 * B * R); it->rep = c.take(2 * B * R); it->xhat = c.take(2 * B * R);
+            it->rstd = c.take(2 * B); it->drep = c.take(2 * B * R); it->dz = c.take(2 * B * R);
+            it->topk = c.take(B * g.knn_k);
+        }
+    }
+    (void)A;
+}
+
+static int intr_reset_state(exorl_intr* it) {
+    const RmsState r0{0.f, 1.f, 1e-4};                    // utils.RMS.__init__ (utils.py:259-262)
+    EXORL_CHECK_HIP(hipMemcpy(it->rms, &r0, sizeof(r0), hipMemcpyHostToDevice));
+    if (it->bn) {                                         // BatchNorm1d buffers: running_mean 0, running_var 1, num_batches_tracked 0
+        std::vector<float> b(2 * it->cfg.obs_dim + 1, 0.f);
+        for (int i = 0; i < it->cfg.obs_dim; ++i) b[it->cfg.obs_dim + i] = 1.f;
+        EXORL_CHECK_HIP(hipMemcpy(it->bn, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+static int launch_mean(const float* x, int n, float scale, float* out, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, s, x, n, scale, out, accumulate);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
+static int intr_adam(exorl_intr* it, hipStream_t s) {
+    it->t += 1;
+    return adam_step(it->flat[EXORL_T_PARAM], it->flat[EXORL_T_GRAD], it->flat[EXORL_T_ADAM_M], it->flat[EXORL_T_ADAM_V], it->trainable,
+                     it->cfg.lr, 0.9f, 0.999f, 1e-8f, it->t, nullptr, 0.f, s);
+}
+
+// ---- RND -------------------------------------------------------------------------------------------
+static int rnd_forward(exorl_intr* it, const float* obs, bool with_target, float* dpred, hipStream_t s) {
+    const auto& c = it->cfg;
+    const int B = c.batch, O = c.obs_dim, R = c.rep_dim;
+    const float* P = it->flat[EXORL_T_PARAM];
+    hipLaunchKernelGGL(bn_clamp_kernel, dim3(O), dim3(256), 0, s, obs, (int64_t)O, it->xn, B, O, c.clip_val, it->bn);
+    EXORL_LAUNCH_CHECK();
+    EXORL_TRY(mlp_forward(it->net[0], P, it->xn, B, c.precision, s));
+    if (with_target) EXORL_TRY(mlp_forward(it->net[1], P, it->xn, B, c.precision, s));
+    hipLaunchKernelGGL(rnd_err_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->net[0].act[2], it->net[1].act[2], it->fe, dpred, B, R);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
+static int rnd_update(exorl_intr* it, const float* obs, const float* extr, float* reward, bool train, hipStream_t s) {
+    const auto& c = it->cfg;
+    const int B = c.batch;
+    if (train) {                                                                                     // rnd.py:79-96
+        EXORL_TRY(rnd_forward(it, obs, true, it->net[0].dact[2], s));
+        EXORL_TRY(launch_mean(it->fe, B, 1.0f / (float)B, it->metrics + EXORL_IM_LOSS, 0, s));
+        EXORL_TRY(mlp_backward(it->net[0], it->flat[EXORL_T_PARAM], it->flat[EXORL_T_GRAD], it->xn, B, nullptr, c.precision, s));
+        EXORL_TRY(intr_adam(it, s));
+    }
+    // compute_intr_reward (rnd.py:98-103): same batch -> same BatchNorm output and frozen target, only the predictor moved
+    EXORL_TRY(rnd_forward(it, obs, !train, nullptr, s));
+    hipLaunchKernelGGL(rnd_reward_kernel, dim3(1), dim3(1024), 0, s, it->fe, extr, reward, B, c.scale, it->rms, it->metrics);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- ICM / ICM-APT ---------------------------------------------------------------------------------
+static int launch_concat(const float* a, int64_t lda, int ca, const float* b, int64_t ldb, int cb, float* dst, int rows, hipStream_t s) {
+    hipLaunchKernelGGL(concat2_kernel, dim3(grid_for((int64_t)rows * (ca + cb))), dim3(256), 0, s, a, lda, ca, b, ldb, cb, dst, rows);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
+static int icm_errors(exorl_intr* it, const float* tgt, int64_t ldt, const float* action, bool grads, bool inverse, hipStream_t s) {
+    const auto& c = it->cfg;
+    const int D = it->net[0].L[1].out;
+    hipLaunchKernelGGL(icm_err_kernel, dim3(cdiv(c.batch, 4)), dim3(256), 0, s, it->net[0].act[1], D, tgt, ldt,
+                       inverse ? it->net[1].act[1] : nullptr, action, c.act_dim, it->fe, it->be, grads ? it->net[0].dact[1] : nullptr,
+                       grads ? it->net[1].dact[1] : nullptr, c.batch);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
+static int icm_update(exorl_intr* it, const float* obs, const float* action, const float* next_obs, const float* extr, float* reward,
+                      bool train, hipStream_t s) {
+    const auto& c = it->cfg;
+    const int B = c.batch, O = c.obs_dim, A = c.act_dim, prec = c.precision;
+    const float* P = it->flat[EXORL_T_PARAM];
+    float* G = it->flat[EXORL_T_GRAD];
+    EXORL_TRY(launch_concat(obs, O, O, action, A, A, it->xf, B, s));
+    if (train) {                                                                                     // icm.py:64-84
+        EXORL_TRY(launch_concat(obs, O, O, next_obs, O, O, it->xb, B, s));
+        EXORL_TRY(mlp_forward(it->net[0], P, it->xf, B, prec, s));
+        EXORL_TRY(mlp_forward(it->net[1], P, it->xb, B, prec, s));
+        EXORL_TRY(icm_errors(it, next_obs, O, action, true, true, s));
+        EXORL_TRY(launch_mean(it->fe, B, 1.0f / (float)B, it->metrics + EXORL_IM_LOSS, 0, s));
+        EXORL_TRY(launch_mean(it->be, B, 1.0f / (float)B, it->metrics + EXORL_IM_LOSS, 1, s));
+        EXORL_TRY(mlp_backward(it->net[0], P, G, it->xf, B, nullptr, prec, s));
+        EXORL_TRY(mlp_backward(it->net[1], P, G, it->xb, B, nullptr, prec, s));
+        EXORL_TRY(intr_adam(it, s));
+    }
+    EXORL_TRY(mlp_forward(it->net[0], P, it->xf, B, prec, s));                                       // icm.py:86-92
+    EXORL_TRY(icm_errors(it, next_obs, O, action, false, false, s));
+    hipLaunchKernelGGL(icm_reward_kernel, dim3(1), dim3(1024), 0, s, it->fe, extr, reward, B, c.scale, it->metrics);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
+static int apt_trunk(exorl_intr* it, const float* x, int rows, hipStream_t s) {        // Linear -> LayerNorm -> Tanh (icm_apt.py:21-22)
+    const auto& c = it->cfg;
+    const float* P = it->flat[EXORL_T_PARAM];
+    GemmProblem p{x, P + it->trunk.W, it->z, P + it->trunk.b, rows, c.rep_dim, c.obs_dim, c.obs_dim, c.obs_dim, c.rep_dim};
+    EXORL_TRY(gemm_grouped(c.precision, 0, 0, &p, 1, false, false, s));
+    return ln_tanh_fwd(it->z, P + it->ln_g, P + it->ln_b, it->rep, it->xhat, it->rstd, rows, c.rep_dim, 1, 0, 0, s);
+}
+
+static int apt_update(exorl_intr* it, const float* obs, const float* action, const float* next_obs, const float* extr, float* reward,
+                      bool train, hipStream_t s) {
+    const auto& c = it->cfg;
+    const int B = c.batch, O = c.obs_dim, A = c.act_dim, R = c.rep_dim, prec = c.precision;
+    const float* P = it->flat[EXORL_T_PARAM];
+    float* G = it->flat[EXORL_T_GRAD];
+    if (train) {                                                                                     // icm_apt.py:33-50,86-104
+        EXORL_CHECK_HIP(hipMemcpyAsync(it->x2, obs, sizeof(float) * B * O, hipMemcpyDeviceToDevice, s));
+        EXORL_CHECK_HIP(hipMemcpyAsync(it->x2 + (int64_t)B * O, next_obs, sizeof(float) * B * O, hipMemcpyDeviceToDevice, s));
+        EXORL_TRY(apt_trunk(it, it->x2, 2 * B, s));
+        const float* rn = it->rep + (int64_t)B * R;
+        EXORL_TRY(launch_concat(it->rep, R, R, action, A, A, it->xf, B, s));
+        EXORL_TRY(launch_concat(it->rep, R, R, rn, R, R, it->xb, B, s));
+        EXORL_TRY(mlp_forward(it->net[0], P, it->xf, B, prec, s));
+        EXORL_TRY(mlp_forward(it->net[1], P, it->xb, B, prec, s));
+        EXORL_TRY(icm_errors(it, rn, R, action, true, true, s));
+        EXORL_TRY(launch_mean(it->fe, B, 1.0f / (float)B, it->metrics + EXORL_IM_LOSS, 0, s));
+        EXORL_TRY(launch_mean(it->be, B, 1.0f / (float)B, it->metrics + EXORL_IM_LOSS, 1, s));
+        EXORL_TRY(mlp_backward(it->net[0], P, G, it->xf, B, it->dxf, prec, s));
+        EXORL_TRY(mlp_backward(it->net[1], P, G, it->xb, B, it->dxb, prec, s));
+        hipLaunchKernelGGL(apt_drep_kernel, dim3(grid_for((int64_t)B * R)), dim3(256), 0, s, it->dxf, (int64_t)(R + A), it->dxb,
+                           (int64_t)(2 * R), it->net[0].dact[1], it->drep, B, R);
+        EXORL_LAUNCH_CHECK();
+        EXORL_TRY(ln_param_grad(it->drep, it->rep, it->xhat, G + it->ln_g, G + it->ln_b, 2 * B, R, 1, 0, 0, s));
+        EXORL_TRY(ln_tanh_bwd(it->drep, it->rep, it->xhat, it->rstd, P + it->ln_g, it->dz, 2 * B, R, 1, 0, 0, s));
+        EXORL_TRY(colsum(it->dz, G + it->trunk.b, 2 * B, R, 1, 0, 0, s));
+        GemmProblem w{it->dz, it->x2, G + it->trunk.W, nullptr, R, O, 2 * B, R, O, O};
+        EXORL_TRY(gemm_grouped(prec, 1, 1, &w, 1, false, false, s));
+        EXORL_TRY(intr_adam(it, s));
+    }
+    EXORL_TRY(apt_trunk(it, obs, B, s));                                                             // icm_apt.py:106-110
+    EXORL_TRY(exorl_knn_topk(it->rep, B, it->rep, B, R, c.knn_k, it->topk, s));
+    hipLaunchKernelGGL(pbe_reward_kernel, dim3(1), dim3(1024), 0, s, it->topk, extr, reward, B, c.knn_k, c.knn_avg, c.knn_rms, c.knn_clip,
+                       it->rms, it->metrics);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace exorl
+
+extern "C" {
+
+static int check_intr_cfg(const exorl_intr_cfg* cfg) {
+    EXORL_REQUIRE(cfg, "intr: null cfg");
+    EXORL_REQUIRE(cfg->kind >= EXORL_INTR_RND && cfg->kind <= EXORL_INTR_ICM_APT, "intr: unknown kind %d", cfg->kind);
+    EXORL_REQUIRE(cfg->obs_dim > 0 && cfg->act_dim > 0 && cfg->act_dim <= 64 && cfg->hidden_dim > 0 && cfg->batch > 0,
+                  "intr: unsupported dims O=%d A=%d (<=64) H=%d B=%d", cfg->obs_dim, cfg->act_dim, cfg->hidden_dim, cfg->batch);
+    EXORL_REQUIRE(cfg->kind == EXORL_INTR_ICM || (cfg->rep_dim > 0 && (cfg->kind != EXORL_INTR_ICM_APT || cfg->rep_dim <= 1024)),
+                  "intr: rep_dim=%d out of range (ICM-APT trunk: <= 1024)", cfg->rep_dim);
+    EXORL_REQUIRE(cfg->kind != EXORL_INTR_ICM_APT || (cfg->knn_k >= 1 && cfg->knn_k <= 64 && cfg->knn_k <= cfg->batch && cfg->batch <= 4096),
+                  "intr: ICM-APT needs 1 <= knn_k <= min(64, batch) and batch <= 4096 (got k=%d B=%d)", cfg->knn_k, cfg->batch);
+    EXORL_REQUIRE(cfg->precision == EXORL_PREC_F32 || cfg->precision == EXORL_PREC_BF16, "intr: unknown precision %d", cfg->precision);
+    return 0;
+}
+
+size_t exorl_intr_workspace_bytes(const exorl_intr_cfg* cfg) {
+    if (check_intr_cfg(cfg) != 0) return 0;
+    exorl_intr tmp;
+    tmp.cfg = *cfg;
+    describe_intr(&tmp);
+    ICarver sizing(nullptr);
+    carve_intr(&tmp, sizing);
+    return (size_t)sizing.off * sizeof(float);
+}
+
+int exorl_intr_create(const exorl_intr_cfg* cfg, void* workspace, size_t workspace_bytes, exorl_intr_t** out) {
+    EXORL_REQUIRE(out, "intr_create: null argument");
+    EXORL_TRY(check_intr_cfg(cfg));
+    const size_t bytes = exorl_intr_workspace_bytes(cfg);
+    EXORL_REQUIRE(!workspace || (workspace_bytes >= bytes && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0),
+                  "intr_create: workspace of %zu bytes (need %zu, 256-byte aligned)", workspace_bytes, bytes);
+    auto* it = new exorl_intr();
+    it->cfg = *cfg;
+    describe_intr(it);
+    if (workspace) {
+        it->ws = static_cast<float*>(workspace);
+    } else {
+        if (hipMalloc(&it->ws, bytes) != hipSuccess) {
+            set_error("intr_create: hipMalloc(%zu) failed", bytes);
+            delete it;
+            return 1;
+        }
+        it->owns_ws = true;
+    }
+    ICarver c(it->ws);
+    carve_intr(it, c);
+    int rc = hipMemset(it->ws, 0, bytes) == hipSuccess ? 0 : 1;
+    if (rc != 0) set_error("intr_create: hipMemset failed");
+    if (rc == 0) rc = intr_reset_state(it);
+    if (rc != 0) { if (it->owns_ws) (void)hipFree(it->ws); delete it; return rc; }
+    *out = it;
+    return 0;
+}
+
+int exorl_intr_destroy(exorl_intr_t* it) {
+    if (!it) return 0;
+    (void)hipDeviceSynchronize();
+    if (it->owns_ws) (void)hipFree(it->ws);
+    delete it;
+    return 0;
+}
+
+int exorl_intr_num_tensors(exorl_intr_t* it, int32_t* n) {
+    EXORL_REQUIRE(it && n, "intr_num_tensors: null argument");
+    *n = (int32_t)it->tensors.size();
+    return 0;
+}
+
+int exorl_intr_tensor(exorl_intr_t* it, int32_t index, int32_t what, void** ptr, int64_t* rows, int64_t* cols) {
+    EXORL_REQUIRE(it && ptr && rows && cols, "intr_tensor: null argument");
+    EXORL_REQUIRE(index >= 0 && index < (int32_t)it->tensors.size(), "intr_tensor: index %d out of range", index);
+    EXORL_REQUIRE(what >= EXORL_T_PARAM && what <= EXORL_T_ADAM_V, "intr_tensor: unknown buffer %d", what);
+    const ITensor& t = it->tensors[index];
+    EXORL_REQUIRE(what == EXORL_T_PARAM || t.off < it->trainable, "intr_tensor: tensor %d is frozen (no gradient / optimiser state)", index);
+    *ptr = it->flat[what] + t.off; *rows = t.rows; *cols = t.cols;
+    return 0;
+}
+
+int exorl_intr_flat(exorl_intr_t* it, int32_t what, void** ptr, int64_t* numel) {
+    EXORL_REQUIRE(it && ptr && numel, "intr_flat: null argument");
+    EXORL_REQUIRE(what >= EXORL_T_PARAM && what <= EXORL_T_ADAM_V, "intr_flat: unknown buffer %d", what);
+    *ptr = it->flat[what];
+    *numel = what == EXORL_T_PARAM ? it->total : it->trainable;
+    return 0;
+}
+
+int exorl_intr_state(exorl_intr_t* it, void** rms_dev, void** bn_dev, int64_t* bn_numel) {
+    EXORL_REQUIRE(it && rms_dev && bn_dev && bn_numel, "intr_state: null argument");
+    *rms_dev = it->rms; *bn_dev = it->bn; *bn_numel = it->bn ? 2 * it->cfg.obs_dim + 1 : 0;
+    return 0;
+}
+
+int exorl_intr_update(exorl_intr_t* it, const float* obs, const float* action, const float* next_obs, const float* extr_reward,
+                      float* reward_out, int32_t train, void* stream) {
+    EXORL_REQUIRE(it && obs && reward_out, "intr_update: null argument");
+    EXORL_REQUIRE(it->cfg.kind == EXORL_INTR_RND || (action && next_obs), "intr_update: ICM needs action and next_obs");
+    hipStream_t s = as_stream(stream);
+    switch (it->cfg.kind) {
+        case EXORL_INTR_RND: return rnd_update(it, obs, extr_reward, reward_out, train != 0, s);
+        case EXORL_INTR_ICM: return icm_update(it, obs, action, next_obs, extr_reward, reward_out, train != 0, s);
+        default: return apt_update(it, obs, action, next_obs, extr_reward, reward_out, train != 0, s);
+    }
+}
+
+int exorl_intr_metrics(exorl_intr_t* it, float* host, void* stream) {
+    EXORL_REQUIRE(it && host, "intr_metrics: null argument");
+    EXORL_CHECK_HIP(hipMemcpyAsync(host, it->metrics, sizeof(float) * EXORL_N_INTR_METRICS, hipMemcpyDeviceToHost, as_stream(stream)));
+    EXORL_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
+    return 0;
+}
+
+int exorl_intr_opt_steps(exorl_intr_t* it, int64_t* steps, int32_t set) {
+    EXORL_REQUIRE(it && steps, "intr_opt_steps: null argument");
+    if (set) { EXORL_REQUIRE(*steps >= 0, "intr_opt_steps: negative step count"); it->t = *steps; }
+    else *steps = it->t;
+    return 0;
+}
+
+}  // extern "C"

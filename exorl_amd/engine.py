@@ -171,6 +171,88 @@ class AgentEngine:
         L.check(self.lib.exorl_agent_set_opt_steps(self.h, actor_steps, critic_steps))
 
 
+class IntrEngine:
+    """Intrinsic-reward module (exorl_intr_t): RND / ICM / ICM-APT. Parameters live in a torch-owned workspace so they
+    can be exposed as tensors (state_dict, snapshots)."""
+    KINDS = {'rnd': L.INTR_RND, 'icm': L.INTR_ICM, 'icm_apt': L.INTR_ICM_APT}
+
+    def __init__(self, kind, obs_dim, act_dim, hidden_dim, batch, rep_dim=0, lr=1e-4, scale=1.0, knn_k=12, knn_avg=True,
+                 knn_rms=True, knn_clip=0.0, clip_val=5.0, precision='fp32', device='cuda'):
+        self.lib = L.load()
+        self.device = _require_gpu(device)
+        self.kind, self.batch, self.obs_dim, self.act_dim = kind, batch, obs_dim, act_dim
+        self.cfg = L.IntrCfg(self.KINDS[kind], obs_dim, act_dim, hidden_dim, rep_dim, batch, PRECISION[precision], knn_k, int(bool(knn_avg)),
+                             int(bool(knn_rms)), (C.c_int32 * 2)(0, 0), lr, scale, knn_clip, clip_val)
+        nbytes = self.lib.exorl_intr_workspace_bytes(C.byref(self.cfg))
+        if nbytes == 0:
+            raise L.ExorlError(self.lib.exorl_last_error().decode())
+        with torch.cuda.device(self.device):
+            self.workspace = torch.zeros(nbytes + 256, dtype=torch.uint8, device=self.device)
+            base = self.workspace.data_ptr()
+            off = (-base) % 256
+            handle = C.c_void_p()
+            L.check(self.lib.exorl_intr_create(C.byref(self.cfg), base + off, nbytes, C.byref(handle)))
+        self.h = handle
+        self._f32 = self.workspace[off:off + nbytes].view(torch.float32)
+        rms, bn, nbn = C.c_void_p(), C.c_void_p(), C.c_int64()
+        L.check(self.lib.exorl_intr_state(self.h, C.byref(rms), C.byref(bn), C.byref(nbn)))
+        self._rms = self._view(rms.value, 4)                       # {float M, float S, double n}
+        self.bn = self._view(bn.value, nbn.value) if bn.value else None
+
+    def __del__(self):
+        h, self.h = getattr(self, 'h', None), None
+        if h:
+            self.lib.exorl_intr_destroy(h)
+
+    def _view(self, ptr, numel):
+        off = (ptr - self._f32.data_ptr()) // 4
+        return self._f32[off:off + numel]
+
+    def num_tensors(self, net=None):
+        n = C.c_int32()
+        L.check(self.lib.exorl_intr_num_tensors(self.h, C.byref(n)))
+        return n.value
+
+    def tensor(self, net, index, what=L.T_PARAM):
+        p, r, c = C.c_void_p(), C.c_int64(), C.c_int64()
+        L.check(self.lib.exorl_intr_tensor(self.h, index, what, C.byref(p), C.byref(r), C.byref(c)))
+        v = self._view(p.value, r.value * c.value)
+        return v.view(r.value, c.value) if c.value > 1 else v
+
+    def flat(self, what=L.T_PARAM):
+        p, n = C.c_void_p(), C.c_int64()
+        L.check(self.lib.exorl_intr_flat(self.h, what, C.byref(p), C.byref(n)))
+        return self._view(p.value, n.value)
+
+    def rms_state(self):
+        """(M, S, n) of the module's utils.RMS."""
+        raw = self._rms.cpu().numpy()
+        return float(raw[0]), float(raw[1]), float(raw[2:4].view(np.float64)[0])
+
+    def set_rms_state(self, M, S, n):
+        raw = np.zeros(4, np.float32)
+        raw[0], raw[1] = M, S
+        raw[2:4] = np.array([n], np.float64).view(np.float32)
+        self._rms.copy_(torch.from_numpy(raw))
+
+    def update(self, obs_ptr, action_ptr, next_obs_ptr, extr_ptr, reward_ptr, train=True):
+        L.check(self.lib.exorl_intr_update(self.h, obs_ptr, action_ptr, next_obs_ptr, extr_ptr, reward_ptr, int(bool(train)), L.current_stream()))
+
+    def metrics_raw(self):
+        host = np.zeros(L.N_INTR_METRICS, np.float32)
+        L.check(self.lib.exorl_intr_metrics(self.h, host.ctypes.data, L.current_stream()))
+        return host
+
+    def opt_steps(self):
+        n = C.c_int64()
+        L.check(self.lib.exorl_intr_opt_steps(self.h, C.byref(n), 0))
+        return n.value
+
+    def set_opt_steps(self, n):
+        v = C.c_int64(n)
+        L.check(self.lib.exorl_intr_opt_steps(self.h, C.byref(v), 1))
+
+
 class ReplayEngine:
     """HBM-resident episodic arena (exorl_replay_t)."""
 

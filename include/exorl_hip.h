@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EXORL_ABI_VERSION 2
+#define EXORL_ABI_VERSION 3
 
 const char* exorl_last_error(void);
 int exorl_abi_version(void);
@@ -243,6 +243,65 @@ int exorl_ln_tanh_fwd(const float* z_dev, const float* gain_dev, const float* be
 /* kNN particle-entropy building block: out[i][j] = j-th smallest L2 distance from src row i to the tgt rows (sorted). */
 int exorl_knn_topk(const float* src_dev, int32_t n_src, const float* tgt_dev, int32_t n_tgt, int32_t dim,
                    int32_t k, float* out_dev, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Intrinsic-reward modules of the reward-free DDPG-backbone agents (states observations).
+ * Replaces, per update() of the reference agent: the module's optimiser step and compute_intr_reward
+ *   RND      agents/unsupervised_learning/rnd.py:79-108   (module rnd.py:13-60)
+ *   ICM      agents/unsupervised_learning/icm.py:64-92    (module icm.py:12-45)
+ *   ICM-APT  agents/unsupervised_learning/icm_apt.py:86-110 (module icm_apt.py:13-57; utils.PBE/RMS utils/utils.py:257-319)
+ * The DDPG critic/actor update that follows is exorl_agent_update on the same batch with reward_out as its reward.
+ * ------------------------------------------------------------------------------------------- */
+#define EXORL_INTR_RND     0
+#define EXORL_INTR_ICM     1
+#define EXORL_INTR_ICM_APT 2
+
+typedef struct exorl_intr_cfg {
+    int32_t kind;         /* EXORL_INTR_* */
+    int32_t obs_dim, act_dim, hidden_dim;
+    int32_t rep_dim;      /* rnd_rep_dim / icm_rep_dim (unused by plain ICM) */
+    int32_t batch;
+    int32_t precision;    /* EXORL_PREC_* (MFMA operand type of the module's GEMMs) */
+    int32_t knn_k, knn_avg, knn_rms;   /* ICM-APT: utils.PBE arguments (configs/agent/icm_apt.yaml) */
+    int32_t reserved[2];
+    float lr;             /* Adam, betas (0.9, 0.999), eps 1e-8 */
+    float scale;          /* rnd_scale / icm_scale */
+    float knn_clip;
+    float clip_val;       /* RND: clamp of the BatchNorm-normalised observation (rnd.py:22, 5.0) */
+} exorl_intr_cfg;
+
+typedef struct exorl_intr exorl_intr_t;
+
+/* metric slots of exorl_intr_metrics */
+#define EXORL_IM_LOSS        0   /* rnd_loss / icm_loss */
+#define EXORL_IM_INTR_REWARD 1   /* mean intrinsic reward of the batch */
+#define EXORL_IM_EXTR_REWARD 2   /* mean of the extrinsic reward passed in (0 if none) */
+#define EXORL_IM_RMS_MEAN    3   /* running mean of the RMS (RND: pred_error_mean) */
+#define EXORL_IM_RMS_STD     4   /* sqrt of its running variance (RND: pred_error_std) */
+#define EXORL_N_INTR_METRICS 8
+
+/* workspace: device memory of exorl_intr_workspace_bytes(cfg) bytes, 256-byte aligned, owned by the caller (so that the
+ * parameters can be exposed as the caller's own tensors), or null to let the library allocate. */
+size_t exorl_intr_workspace_bytes(const exorl_intr_cfg* cfg);
+int exorl_intr_create(const exorl_intr_cfg* cfg, void* workspace, size_t workspace_bytes, exorl_intr_t** out);
+int exorl_intr_destroy(exorl_intr_t* m);
+/* Parameter tensors in the module's parameters() order (RND: predictor.{1,3,5}, target.{1,3,5}; ICM: forward_net.{0,2},
+ * backward_net.{0,2}; ICM-APT: trunk.0, trunk.1 (LayerNorm), forward_net, backward_net), each weight then bias.
+ * what = EXORL_T_*; RND's frozen target tensors have parameters only. */
+int exorl_intr_num_tensors(exorl_intr_t* m, int32_t* n);
+int exorl_intr_tensor(exorl_intr_t* m, int32_t index, int32_t what, void** ptr, int64_t* rows, int64_t* cols);
+int exorl_intr_flat(exorl_intr_t* m, int32_t what, void** ptr, int64_t* numel);
+/* Device state outside the parameters: rms = {float M, float S, double n} (utils.RMS); bn = running_mean[obs_dim],
+ * running_var[obs_dim], num_batches_tracked (as float) of RND's BatchNorm1d, or null. */
+int exorl_intr_state(exorl_intr_t* m, void** rms_dev, void** bn_dev, int64_t* bn_numel);
+/* train != 0: update_rnd / update_icm on (obs, action, next_obs) then compute_intr_reward under the updated module
+ * (rnd.py:121-124, icm.py:106-110, icm_apt.py:123-127); train == 0: compute_intr_reward only.
+ * reward_out (batch,) may alias extr_reward (the agent's reward slot); extr_reward may be null. All device pointers. */
+int exorl_intr_update(exorl_intr_t* m, const float* obs, const float* action, const float* next_obs, const float* extr_reward,
+                      float* reward_out, int32_t train, void* stream);
+int exorl_intr_metrics(exorl_intr_t* m, float* host_out /* EXORL_N_INTR_METRICS */, void* stream);
+/* optimiser step count of the module's Adam: set == 0 reads into *steps, else writes it (snapshot restore) */
+int exorl_intr_opt_steps(exorl_intr_t* m, int64_t* steps, int32_t set);
 
 #ifdef __cplusplus
 }

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert s in _lib.PROTOTYPES, f'{s} has no ctypes prototype'
     assert set(_lib.PROTOTYPES) == set(syms)
     lib.exorl_abi_version.restype = ctypes.c_int
-    assert lib.exorl_abi_version() == 2
+    assert lib.exorl_abi_version() == 3
 
 
 def test_product_fails_loudly_without_gpu():
@@ -57,6 +57,28 @@ def test_init_matches_reference_rng_order(gold, kind):
         ckeys = agents._DDPG_CRITIC_KEYS if kind == 'ddpg' else agents._OFFLINE_CRITIC_KEYS
         for k, w in zip(ckeys, critic0):
             np.testing.assert_array_equal(w.numpy(), z[f'init/critic/{k}'], err_msg=k)
+
+
+@pytest.mark.parametrize('kind', ['rnd', 'icm', 'icm_apt'])
+def test_intr_module_init_matches_reference_rng_order(gold, kind):
+    """The intrinsic-reward modules are constructed after the DDPG nets (rnd.py:64-71, icm.py:49-55, icm_apt.py:61-70)."""
+    from exorl_amd import agents
+    z = np.load(gold / f'tiny_{kind}.npz')
+    O, A, H, R = 5, 3, 32, 16
+    torch.manual_seed(21)
+    agents._mlp_init(O, H, A, 1, 1)
+    agents._mlp_init(O + A, H, 1, 1, 2)
+    agents._mlp_init(O + A, H, 1, 1, 2)
+    if kind == 'rnd':
+        w, keys, mod = agents._seq_init([('lin', O, H), ('lin', H, H), ('lin', H, R)] * 2), agents._RND_KEYS, 'rnd'
+    elif kind == 'icm':
+        w, keys, mod = agents._seq_init([('lin', O + A, H), ('lin', H, O), ('lin', 2 * O, H), ('lin', H, A)]), agents._ICM_KEYS, 'icm'
+    else:
+        w = agents._seq_init([('lin', O, R), ('ln', R), ('lin', R + A, H), ('lin', H, R), ('lin', 2 * R, H), ('lin', H, A)])
+        keys, mod = agents._APT_KEYS, 'icm'
+    assert len(w) == len(keys)
+    for k, t in zip(keys, w):
+        np.testing.assert_array_equal(t.numpy(), z[f'init/{mod}/{k}'], err_msg=k)
 
 
 def test_schedule_and_helpers(gold):
