@@ -6,12 +6,14 @@ Reference classes mirrored (file:line in /root/reference):
   BCAgent     agents/offline_learning/bc.py:34-110           DDPGAgent agents/unsupervised_learning/ddpg.py:126-328 (states)
   CRRAgent    agents/offline_learning/crr.py:59-219          CQLAgent  agents/offline_learning/cql.py:59-286
   RNDAgent    agents/unsupervised_learning/rnd.py:63-159     ICMAgent  agents/unsupervised_learning/icm.py:48-139
-  ICMAPTAgent agents/unsupervised_learning/icm_apt.py:60-158
+  ICMAPTAgent agents/unsupervised_learning/icm_apt.py:60-158 DisagreementAgent agents/unsupervised_learning/disagreement.py:50-136
+  DIAYNAgent  agents/unsupervised_learning/diayn.py:32-176
 
 Python here is orchestration only: it builds the initial weights with torch's CPU RNG in the reference's
 construction order (so a given torch.manual_seed yields the reference's initial parameters), hands batches
 to the engine and — under torch.distributed — all-reduces the flat gradient buffers between update phases.
 """
+import functools
 from collections import OrderedDict
 
 import numpy as np
@@ -98,6 +100,69 @@ class NetView:
 
 class _AgentBase:
     KIND = None
+
+    # -- pickling (pretrain.py:293-300 torch.save's the whole agent; finetune.py:222-252 loads it back) ---------------
+    def __init_subclass__(cls, **kw):
+        super().__init_subclass__(**kw)
+        orig = cls.__dict__.get('__init__')
+        if orig is None:
+            return
+
+        @functools.wraps(orig)
+        def init(self, *a, **k):
+            if not hasattr(self, '_ctor'):          # outermost constructor call: remember how this agent was built
+                self._ctor = (a, dict(k))
+            orig(self, *a, **k)
+        cls.__init__ = init
+
+    def _engines(self):
+        return [('agent', self.engine)] + ([('intr', self.intr)] if hasattr(self, 'intr') else [])
+
+    def __getstate__(self):
+        """Constructor arguments + every device buffer that defines the training state (parameters, Adam moments and step
+        counts, running statistics) as CPU tensors; host attributes that are plain data ride along."""
+        torch.cuda.synchronize()
+        eng = self.engine
+        st = {'ctor': self._ctor, 'flat': {}, 'opt_steps': eng.opt_steps(), 'training': getattr(self, 'training', True)}
+        nets = [L.NET_ACTOR] + ([L.NET_CRITIC, L.NET_CRITIC_TARGET] if eng.has_critic else [])
+        for net in nets:
+            whats = [L.T_PARAM] if net == L.NET_CRITIC_TARGET else [L.T_PARAM, L.T_ADAM_M, L.T_ADAM_V]
+            st['flat'][net] = {w: eng.flat(net, w).cpu() for w in whats}
+        if self.KIND == 'cql':
+            st['cql_alpha'] = eng.cql_alpha_state().tolist()
+        if hasattr(self, 'intr'):
+            it = self.intr
+            st['intr'] = {'flat': {w: it.flat(w).cpu() for w in (L.T_PARAM, L.T_ADAM_M, L.T_ADAM_V)}, 'rms': it.rms_state(),
+                          'bn': it.bn.cpu() if it.bn is not None else None, 'opt_steps': it.opt_steps()}
+        skip = {'engine', 'intr', 'actor', 'critic', 'critic_target', 'rnd', 'icm', 'pbe', 'intrinsic_reward_rms', 'disagreement', 'diayn', 'aug', 'encoder',
+                'noise_hook', '_slots', '_graph_iter', '_graph_stddev', '_ctor'}
+        st['attrs'] = {k: v for k, v in self.__dict__.items() if k not in skip and not k.startswith('_keep')}
+        return st
+
+    def __setstate__(self, st):
+        a, k = st['ctor']
+        rng = torch.get_rng_state()                 # construction draws initial weights; loading must not disturb the caller's stream
+        self._ctor = (a, dict(k))
+        type(self).__init__(self, *a, **k)
+        torch.set_rng_state(rng)
+        eng = self.engine
+        for net, bufs in st['flat'].items():
+            for w, t in bufs.items():
+                eng.flat(net, w).copy_(t)
+        eng.set_opt_steps(*st['opt_steps'])
+        if 'cql_alpha' in st:
+            eng.set_cql_alpha_state(*st['cql_alpha'])
+        eng.params_changed(sync_target=False)
+        if 'intr' in st:
+            it, si = self.intr, st['intr']
+            for w, t in si['flat'].items():
+                it.flat(w).copy_(t)
+            it.set_rms_state(*si['rms'])
+            if si['bn'] is not None:
+                it.bn.copy_(si['bn'])
+            it.set_opt_steps(si['opt_steps'])
+        self.__dict__.update(st['attrs'])
+        self.train(st['training'])
 
     def _build(self, obs_dim, action_dim, hidden_dim, batch_size, lr, tau, alpha, stddev_clip, device, precision, seed,
                **engine_kw):
@@ -570,6 +635,8 @@ class _IntrAgent(DDPGAgent):
                 metrics[self.LOSS_KEY] = float(raw[L.IM_LOSS])
                 metrics['intr_reward'] = float(raw[L.IM_INTR_REWARD])
                 metrics['extr_reward'] = float(raw[L.IM_EXTR_REWARD])
+                if self.LOSS_KEY == 'diayn_loss':
+                    metrics['diayn_acc'] = float(raw[L.IM_ACC])
                 if self.LOSS_KEY == 'rnd_loss':
                     metrics['pred_error_mean'] = float(raw[L.IM_RMS_MEAN])
                     metrics['pred_error_std'] = float(raw[L.IM_RMS_STD])
@@ -634,6 +701,99 @@ class ICMAPTAgent(_IntrAgent):
         for p, t in zip(self.icm.parameters(), w):
             p.copy_(t.reshape(p.shape))
         self.pbe = _PbeView(self.intr)
+
+
+_DIS_KEYS = [f'ensemble.{m}.{i}.{w}' for m in range(5) for i in (0, 2) for w in ('weight', 'bias')]
+_DIAYN_KEYS = [f'skill_pred_net.{i}.{w}' for i in (0, 2, 4) for w in ('weight', 'bias')]
+
+
+class DisagreementAgent(_IntrAgent):
+    """agents/unsupervised_learning/disagreement.py:50-136 (configs/agent/disagreement.yaml)."""
+    LOSS_KEY = 'disagreement_loss'
+
+    def __init__(self, update_encoder, **kwargs):
+        super().__init__(**kwargs)
+        self.update_encoder = update_encoder
+        O, A, H = self.obs_dim, self.action_dim, self.hidden_dim
+        # the ensemble keeps nn.Linear's default initialisation: Disagreement never applies utils.weight_init (disagreement.py:12-18)
+        w = []
+        for _ in range(5):
+            for m in (nn.Linear(O + A, H), nn.Linear(H, O)):
+                w += [m.weight.data, m.bias.data]
+        self.intr = IntrEngine('disagreement', O, A, H, self.engine.batch, lr=self.lr, n_models=5, precision=self._precision,
+                               device=self.device)
+        self.disagreement = NetView(self.intr, None, _DIS_KEYS)
+        for p, t in zip(self.disagreement.parameters(), w):
+            p.copy_(t.reshape(p.shape))
+
+
+class _Spec:
+    """Stand-in for dm_env.specs.Array as the replay storage reads it (name, shape, dtype)."""
+
+    def __init__(self, shape, dtype, name):
+        self.shape, self.dtype, self.name = tuple(shape), np.dtype(dtype), name
+
+
+class DIAYNAgent(_IntrAgent):
+    """agents/unsupervised_learning/diayn.py:32-176 (configs/agent/diayn.yaml): the skill rides in the batch as a 6th tensor and
+    is appended to obs / next_obs for the actor and critic; the discriminator sees the raw next_obs."""
+    LOSS_KEY = 'diayn_loss'
+
+    def __init__(self, update_skill_every_step, skill_dim, diayn_scale, update_encoder, **kwargs):
+        self.skill_dim = skill_dim
+        self.update_skill_every_step = update_skill_every_step
+        self.diayn_scale = diayn_scale
+        self.update_encoder = update_encoder
+        kwargs['meta_dim'] = self.skill_dim
+        self.skill_type = kwargs['skill_type']
+        super().__init__(**kwargs)
+        O, H = self.obs_dim - self.skill_dim, self.hidden_dim
+        w = _seq_init([('lin', O, H), ('lin', H, H), ('lin', H, skill_dim)])
+        self.intr = IntrEngine('diayn', O, self.action_dim, H, self.engine.batch, rep_dim=skill_dim, lr=self.lr, scale=diayn_scale,
+                               precision=self._precision, device=self.device)
+        self.diayn = NetView(self.intr, None, _DIAYN_KEYS)
+        for p, t in zip(self.diayn.parameters(), w):
+            p.copy_(t.reshape(p.shape))
+
+    def get_meta_specs(self):
+        return (_Spec((self.skill_dim,), np.float32, 'skill'),)
+
+    def init_meta(self):
+        if self.skill_type == 'uniform':
+            skill = np.random.uniform(0, 1, self.skill_dim).astype(np.float32)
+        else:
+            skill = np.zeros(self.skill_dim, dtype=np.float32)
+            skill[np.random.choice(self.skill_dim)] = 1.0
+        meta = OrderedDict()
+        meta['skill'] = skill
+        return meta
+
+    def update_meta(self, meta, global_step, time_step, finetune=False):
+        if global_step % self.update_skill_every_step == 0:
+            return self.init_meta()
+        return meta
+
+    def _views(self):
+        s = self._slots = self._slots or self.engine.batch_slots()
+        B, W = self.engine.batch, self.obs_dim
+        return s, self.engine._view(s.obs, B * W).view(B, W), self.engine._view(s.next_obs, B * W).view(B, W)
+
+    def _load_batch(self, replay_iter):
+        O, S = self.obs_dim - self.skill_dim, self.skill_dim
+        s, obs_v, next_v = self._views()
+        if hasattr(replay_iter, 'sample_into'):      # HBM sampler: obs and the skill (meta) columns land in the [obs | skill] rows
+            out = L.BatchOut(s.obs, s.obs_stride, s.action, s.action_stride, s.reward, s.discount, s.next_obs, s.next_obs_stride,
+                             s.obs + 4 * O, O + S)
+            replay_iter.sample_into(out, self.engine.batch)
+            next_v[:, O:].copy_(obs_v[:, O:])
+            return
+        obs, action, reward, discount, next_obs, skill = [torch.as_tensor(x).to(self.engine.device, torch.float32) for x in next(replay_iter)[:6]]
+        self.engine.set_batch(torch.cat([obs, skill], 1), action, reward, discount, torch.cat([next_obs, skill], 1))
+
+    def _intr_step(self):
+        O, W = self.obs_dim - self.skill_dim, self.obs_dim
+        s = self._slots
+        self.intr.update(s.obs, None, s.next_obs, s.reward, s.reward, True, skill=s.obs + 4 * O, obs_ld=W, next_obs_ld=W, skill_ld=W)
 
 
 class _Identity:

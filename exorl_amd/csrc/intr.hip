@@ -4,6 +4,8 @@
 //   RND      agents/unsupervised_learning/rnd.py:13-60 (module), :79-108 (update_rnd, compute_intr_reward)
 //   ICM      agents/unsupervised_learning/icm.py:12-45, :64-92
 //   ICM-APT  agents/unsupervised_learning/icm_apt.py:13-57, :86-110; utils.PBE / utils.RMS utils/utils.py:257-319
+//   Disagreement agents/unsupervised_learning/disagreement.py:11-47, :64-90
+//   DIAYN    agents/unsupervised_learning/diayn.py:15-29, :78-127
 // The modules are plain Linear/ReLU stacks of arbitrary widths (obs_dim, hidden_dim, rep_dim), so the layers run on
 // the generic fp32-source grouped GEMM (gemm.hip) with small row/column kernels around it; what the reference's
 // autograd graph hides and this file exploits:
@@ -153,10 +155,9 @@ __global__ __launch_bounds__(1024) void rnd_reward_kernel(const float* __restric
 __global__ __launch_bounds__(256) void icm_err_kernel(const float* __restrict__ pred, int D, const float* __restrict__ tgt, int64_t ldt,
                                                       const float* __restrict__ apre, const float* __restrict__ action, int A,
                                                       float* __restrict__ fe, float* __restrict__ be, float* __restrict__ dpred,
-                                                      float* __restrict__ dapre, int rows) {
+                                                      float* __restrict__ dapre, int rows, float invB) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
-    const float invB = 1.0f / (float)rows;
     float s = 0.f;
     for (int j = lane; j < D; j += 64) { const float d = tgt[(int64_t)row * ldt + j] - pred[(int64_t)row * D + j]; s += d * d; }
     const float nf = sqrtf(wave_sum(s));
@@ -256,20 +257,74 @@ __global__ __launch_bounds__(256) void apt_drep_kernel(const float* __restrict__
     }
 }
 
+// Disagreement reward (disagreement.py:35-47): unbiased variance over the ensemble's predictions, mean over features
+struct PredSet { const float* p[EXORL_MAX_ENSEMBLE]; };
+__global__ __launch_bounds__(256) void disagreement_reward_kernel(PredSet ps, int n, float* __restrict__ reward, int rows, int D) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float acc = 0.f;
+    for (int j = lane; j < D; j += 64) {
+        float mean = 0.f;
+        for (int m = 0; m < n; ++m) mean += ps.p[m][(int64_t)row * D + j];
+        mean /= (float)n;
+        float q = 0.f;
+        for (int m = 0; m < n; ++m) { const float d = ps.p[m][(int64_t)row * D + j] - mean; q += d * d; }
+        acc += q / (float)(n > 1 ? n - 1 : 1);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) reward[row] = acc / (float)D;
+}
+
+// DIAYN (diayn.py:94-127): z = argmax(skill), log-softmax of the discriminator logits; nll = -lsm[z], hit = [argmax lsm == z],
+// dlogits = (softmax - onehot(z)) / B (CrossEntropyLoss, mean), reward = (lsm[z] - log(1/S)) * scale. One wave per row.
+__global__ __launch_bounds__(256) void diayn_kernel(const float* __restrict__ logits, const float* __restrict__ skill, int64_t lds_, int S,
+                                                    float* __restrict__ nll, float* __restrict__ hit, float* __restrict__ dlogits,
+                                                    float* reward, float scale, int rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float mx = -INFINITY, smx = -INFINITY;
+    int amx = 0x7fffffff, asx = 0x7fffffff;
+    for (int j = lane; j < S; j += 64) {
+        const float v = logits[(int64_t)row * S + j], k = skill[(int64_t)row * lds_ + j];
+        if (v > mx) { mx = v; amx = j; }
+        if (k > smx) { smx = k; asx = j; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {            // first-occurrence arg-max, as torch.argmax / torch.max
+        const float ov = __shfl_xor(mx, off, 64), ok = __shfl_xor(smx, off, 64);
+        const int oi = __shfl_xor(amx, off, 64), oj = __shfl_xor(asx, off, 64);
+        if (ov > mx || (ov == mx && oi < amx)) { mx = ov; amx = oi; }
+        if (ok > smx || (ok == smx && oj < asx)) { smx = ok; asx = oj; }
+    }
+    float se = 0.f;
+    for (int j = lane; j < S; j += 64) se += expf(logits[(int64_t)row * S + j] - mx);
+    const float lse = mx + logf(wave_sum(se));
+    const float lz = logits[(int64_t)row * S + asx] - lse;
+    if (lane == 0) {
+        if (nll) { nll[row] = -lz; hit[row] = amx == asx ? 1.f : 0.f; }
+        if (reward) reward[row] = (lz - logf(1.0f / (float)S)) * scale;
+    }
+    if (dlogits) {
+        const float invB = 1.0f / (float)rows;
+        for (int j = lane; j < S; j += 64)
+            dlogits[(int64_t)row * S + j] = (expf(logits[(int64_t)row * S + j] - lse) - (j == asx ? 1.f : 0.f)) * invB;
+    }
+}
+
 static int grid_for(int64_t n) { const int64_t b = (n + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
 
-static int mlp_forward(const Mlp& m, const float* P, const float* x, int rows, int prec, hipStream_t s) {
+static int mlp_forward(const Mlp& m, const float* P, const float* x, int64_t ldx, int rows, int prec, hipStream_t s) {
     const int n = (int)m.L.size();
     for (int l = 0; l < n; ++l) {
         const Lin& L = m.L[l];
-        GemmProblem p{l ? m.act[l - 1] : x, P + L.W, m.act[l], P + L.b, rows, L.out, L.in, L.in, L.in, L.out};
+        GemmProblem p{l ? m.act[l - 1] : x, P + L.W, m.act[l], P + L.b, rows, L.out, L.in, l ? (int64_t)L.in : ldx, L.in, L.out};
         EXORL_TRY(gemm_grouped(prec, 0, 0, &p, 1, l < n - 1, false, s));
     }
     return 0;
 }
 
 // dact[last] holds d(loss)/d(output); writes parameter gradients into G and, if dx, d(loss)/d(input) (rows, in0)
-static int mlp_backward(const Mlp& m, const float* P, float* G, const float* x, int rows, float* dx, int prec, hipStream_t s) {
+static int mlp_backward(const Mlp& m, const float* P, float* G, const float* x, int64_t ldx, int rows, float* dx, int prec, hipStream_t s) {
     const int n = (int)m.L.size();
     for (int l = n - 1; l >= 0; --l) {
         const Lin& L = m.L[l];
@@ -281,7 +336,7 @@ static int mlp_backward(const Mlp& m, const float* P, float* G, const float* x, 
         }
         EXORL_TRY(colsum(d, G + L.b, rows, L.out, 1, 0, 0, s));
         const float* in = l ? m.act[l - 1] : x;
-        GemmProblem w{d, in, G + L.W, nullptr, L.out, L.in, rows, L.out, L.in, L.in};          // dW[o][i] = sum_r d[r][o] in[r][i]
+        GemmProblem w{d, in, G + L.W, nullptr, L.out, L.in, rows, L.out, l ? (int64_t)L.in : ldx, L.in};          // dW[o][i] = sum_r d[r][o] in[r][i]
         EXORL_TRY(gemm_grouped(prec, 1, 1, &w, 1, false, false, s));
         float* dst = l ? m.dact[l - 1] : dx;
         if (dst) {
@@ -303,7 +358,8 @@ struct exorl_intr {
     float* ws = nullptr;
     bool owns_ws = false;
     float* flat[4] = {nullptr, nullptr, nullptr, nullptr};
-    Mlp net[2];                            // RND: predictor, target; ICM(-APT): forward_net, backward_net
+    Mlp net[EXORL_MAX_ENSEMBLE];           // RND: predictor, target; ICM(-APT): forward_net, backward_net; Disagreement: the ensemble; DIAYN: [0]
+    int n_nets = 0;
     Lin trunk{};                           // APT: Linear(O, R) of the trunk; LayerNorm gain/beta offsets below
     int64_t ln_g = 0, ln_b = 0;
     float *xn = nullptr, *xf = nullptr, *xb = nullptr, *dxf = nullptr, *dxb = nullptr;
@@ -321,6 +377,8 @@ struct ICarver {
     float* take(int64_t n) { float* p = base ? base + off : nullptr; off += round_up(n, 64); return p; }
 };
 
+static int n_models_of(const exorl_intr_cfg& c) { return c.n_models > 0 ? c.n_models : 5; }     // disagreement.py:12 default
+
 static void describe_intr(exorl_intr* it) {
     const auto& c = it->cfg;
     const int O = c.obs_dim, A = c.act_dim, H = c.hidden_dim, R = c.rep_dim;
@@ -328,13 +386,22 @@ static void describe_intr(exorl_intr* it) {
     auto add = [&](int64_t rows, int64_t cols) { const int64_t o = off; it->tensors.push_back({o, rows, cols}); off += round_up(rows * cols, 4); return o; };
     auto lin = [&](int in, int out) { Lin l{in, out, 0, 0}; l.W = add(out, in); l.b = add(out, 1); return l; };
     it->tensors.clear();
-    it->net[0].L.clear(); it->net[1].L.clear();
+    for (auto& n : it->net) n.L.clear();
+    it->n_nets = 2;
     if (c.kind == EXORL_INTR_RND) {
         for (int n = 0; n < 2; ++n) {
             it->net[n].L = {lin(O, H), lin(H, H), lin(H, R)};
             if (n == 0) it->trainable = round_up(off, 64);
             off = round_up(off, 64);
         }
+    } else if (c.kind == EXORL_INTR_DISAGREEMENT) {
+        it->n_nets = n_models_of(c);
+        for (int n = 0; n < it->n_nets; ++n) it->net[n].L = {lin(O + A, H), lin(H, O)};
+        it->trainable = round_up(off, 64);
+    } else if (c.kind == EXORL_INTR_DIAYN) {
+        it->n_nets = 1;
+        it->net[0].L = {lin(O, H), lin(H, H), lin(H, R)};             // R = skill_dim
+        it->trainable = round_up(off, 64);
     } else {
         int in_f = O + A, in_b = 2 * O, out_f = O;
         if (c.kind == EXORL_INTR_ICM_APT) {
@@ -351,10 +418,10 @@ static void describe_intr(exorl_intr* it) {
 
 static void carve_intr(exorl_intr* it, ICarver& c) {
     const auto& g = it->cfg;
-    const int64_t B = g.batch, O = g.obs_dim, A = g.act_dim, R = g.rep_dim;
+    const int64_t B = g.batch, O = g.obs_dim, R = g.rep_dim;
     it->flat[EXORL_T_PARAM] = c.take(it->total);
     for (int w = 1; w < 4; ++w) it->flat[w] = c.take(it->trainable);
-    for (int n = 0; n < 2; ++n) {
+    for (int n = 0; n < it->n_nets; ++n) {
         Mlp& m = it->net[n];
         m.act.clear(); m.dact.clear();
         for (const Lin& l : m.L) {
@@ -362,13 +429,15 @@ static void carve_intr(exorl_intr* it, ICarver& c) {
             m.dact.push_back((g.kind == EXORL_INTR_RND && n == 1) ? nullptr : c.take(B * l.out));
         }
     }
-    it->fe = c.take(B); it->be = c.take(B);
+    it->fe = c.take(B * (g.kind == EXORL_INTR_DISAGREEMENT ? it->n_nets : 1)); it->be = c.take(B);
     it->metrics = c.take(EXORL_N_INTR_METRICS);
     it->rms = reinterpret_cast<RmsState*>(c.take(4));
     if (g.kind == EXORL_INTR_RND) {
         it->xn = c.take(B * O);
         it->bn = c.take(2 * O + 1);
-    } else {
+    } else if (g.kind == EXORL_INTR_DISAGREEMENT) {
+        it->xf = c.take(B * it->net[0].L[0].in);
+    } else if (g.kind != EXORL_INTR_DIAYN) {
         const int64_t in_f = it->net[0].L[0].in, in_b = it->net[1].L[0].in;
         it->xf = c.take(B * in_f); it->xb = c.take(B * in_b);
         if (g.kind == EXORL_INTR_ICM_APT) {
@@ -378,7 +447,6 @@ static void carve_intr(exorl_intr* it, ICarver& c) {
             it->topk = c.take(B * g.knn_k);
         }
     }
-    (void)A;
 }
 
 static int intr_reset_state(exorl_intr* it) {
@@ -404,106 +472,105 @@ static int intr_adam(exorl_intr* it, hipStream_t s) {
                      it->cfg.lr, 0.9f, 0.999f, 1e-8f, it->t, nullptr, 0.f, s);
 }
 
-// ---- RND -------------------------------------------------------------------------------------------
-static int rnd_forward(exorl_intr* it, const float* obs, bool with_target, float* dpred, hipStream_t s) {
-    const auto& c = it->cfg;
-    const int B = c.batch, O = c.obs_dim, R = c.rep_dim;
-    const float* P = it->flat[EXORL_T_PARAM];
-    hipLaunchKernelGGL(bn_clamp_kernel, dim3(O), dim3(256), 0, s, obs, (int64_t)O, it->xn, B, O, c.clip_val, it->bn);
-    EXORL_LAUNCH_CHECK();
-    EXORL_TRY(mlp_forward(it->net[0], P, it->xn, B, c.precision, s));
-    if (with_target) EXORL_TRY(mlp_forward(it->net[1], P, it->xn, B, c.precision, s));
-    hipLaunchKernelGGL(rnd_err_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->net[0].act[2], it->net[1].act[2], it->fe, dpred, B, R);
-    EXORL_LAUNCH_CHECK();
-    return 0;
-}
-
-static int rnd_update(exorl_intr* it, const float* obs, const float* extr, float* reward, bool train, hipStream_t s) {
-    const auto& c = it->cfg;
-    const int B = c.batch;
-    if (train) {                                                                                     // rnd.py:79-96
-        EXORL_TRY(rnd_forward(it, obs, true, it->net[0].dact[2], s));
-        EXORL_TRY(launch_mean(it->fe, B, 1.0f / (float)B, it->metrics + EXORL_IM_LOSS, 0, s));
-        EXORL_TRY(mlp_backward(it->net[0], it->flat[EXORL_T_PARAM], it->flat[EXORL_T_GRAD], it->xn, B, nullptr, c.precision, s));
-        EXORL_TRY(intr_adam(it, s));
-    }
-    // compute_intr_reward (rnd.py:98-103): same batch -> same BatchNorm output and frozen target, only the predictor moved
-    EXORL_TRY(rnd_forward(it, obs, !train, nullptr, s));
-    hipLaunchKernelGGL(rnd_reward_kernel, dim3(1), dim3(1024), 0, s, it->fe, extr, reward, B, c.scale, it->rms, it->metrics);
-    EXORL_LAUNCH_CHECK();
-    return 0;
-}
-
-// ---- ICM / ICM-APT ---------------------------------------------------------------------------------
 static int launch_concat(const float* a, int64_t lda, int ca, const float* b, int64_t ldb, int cb, float* dst, int rows, hipStream_t s) {
     hipLaunchKernelGGL(concat2_kernel, dim3(grid_for((int64_t)rows * (ca + cb))), dim3(256), 0, s, a, lda, ca, b, ldb, cb, dst, rows);
     EXORL_LAUNCH_CHECK();
     return 0;
 }
 
-static int icm_errors(exorl_intr* it, const float* tgt, int64_t ldt, const float* action, bool grads, bool inverse, hipStream_t s) {
+// ---- RND -------------------------------------------------------------------------------------------
+static int rnd_forward(exorl_intr* it, const exorl_intr_batch& b, bool with_target, float* dpred, hipStream_t s) {
     const auto& c = it->cfg;
-    const int D = it->net[0].L[1].out;
-    hipLaunchKernelGGL(icm_err_kernel, dim3(cdiv(c.batch, 4)), dim3(256), 0, s, it->net[0].act[1], D, tgt, ldt,
-                       inverse ? it->net[1].act[1] : nullptr, action, c.act_dim, it->fe, it->be, grads ? it->net[0].dact[1] : nullptr,
-                       grads ? it->net[1].dact[1] : nullptr, c.batch);
+    const int B = c.batch, O = c.obs_dim, R = c.rep_dim;
+    const float* P = it->flat[EXORL_T_PARAM];
+    hipLaunchKernelGGL(bn_clamp_kernel, dim3(O), dim3(256), 0, s, b.obs, b.obs_ld, it->xn, B, O, c.clip_val, it->bn);
+    EXORL_LAUNCH_CHECK();
+    EXORL_TRY(mlp_forward(it->net[0], P, it->xn, O, B, c.precision, s));
+    if (with_target) EXORL_TRY(mlp_forward(it->net[1], P, it->xn, O, B, c.precision, s));
+    hipLaunchKernelGGL(rnd_err_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->net[0].act[2], it->net[1].act[2], it->fe, dpred, B, R);
     EXORL_LAUNCH_CHECK();
     return 0;
 }
 
-static int icm_update(exorl_intr* it, const float* obs, const float* action, const float* next_obs, const float* extr, float* reward,
-                      bool train, hipStream_t s) {
+static int rnd_update(exorl_intr* it, const exorl_intr_batch& b, bool train, hipStream_t s) {
+    const auto& c = it->cfg;
+    const int B = c.batch;
+    if (train) {                                                                                     // rnd.py:79-96
+        EXORL_TRY(rnd_forward(it, b, true, it->net[0].dact[2], s));
+        EXORL_TRY(launch_mean(it->fe, B, 1.0f / (float)B, it->metrics + EXORL_IM_LOSS, 0, s));
+        EXORL_TRY(mlp_backward(it->net[0], it->flat[EXORL_T_PARAM], it->flat[EXORL_T_GRAD], it->xn, c.obs_dim, B, nullptr, c.precision, s));
+        EXORL_TRY(intr_adam(it, s));
+    }
+    // compute_intr_reward (rnd.py:98-103): same batch -> same BatchNorm output and frozen target, only the predictor moved
+    EXORL_TRY(rnd_forward(it, b, !train, nullptr, s));
+    hipLaunchKernelGGL(rnd_reward_kernel, dim3(1), dim3(1024), 0, s, it->fe, b.extr_reward, b.reward_out, B, c.scale, it->rms, it->metrics);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- ICM / ICM-APT ---------------------------------------------------------------------------------
+static int icm_errors(exorl_intr* it, const float* tgt, int64_t ldt, const float* action, int64_t lda, bool grads, bool inverse, hipStream_t s) {
+    const auto& c = it->cfg;
+    const int D = it->net[0].L[1].out;
+    EXORL_REQUIRE(!inverse || lda == c.act_dim, "intr: ICM needs a dense action matrix (ld == action_dim)");
+    hipLaunchKernelGGL(icm_err_kernel, dim3(cdiv(c.batch, 4)), dim3(256), 0, s, it->net[0].act[1], D, tgt, ldt,
+                       inverse ? it->net[1].act[1] : nullptr, action, c.act_dim, it->fe, it->be, grads ? it->net[0].dact[1] : nullptr,
+                       grads ? it->net[1].dact[1] : nullptr, c.batch, 1.0f / (float)c.batch);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
+static int icm_update(exorl_intr* it, const exorl_intr_batch& b, bool train, hipStream_t s) {
     const auto& c = it->cfg;
     const int B = c.batch, O = c.obs_dim, A = c.act_dim, prec = c.precision;
     const float* P = it->flat[EXORL_T_PARAM];
     float* G = it->flat[EXORL_T_GRAD];
-    EXORL_TRY(launch_concat(obs, O, O, action, A, A, it->xf, B, s));
+    EXORL_TRY(launch_concat(b.obs, b.obs_ld, O, b.action, b.action_ld, A, it->xf, B, s));
     if (train) {                                                                                     // icm.py:64-84
-        EXORL_TRY(launch_concat(obs, O, O, next_obs, O, O, it->xb, B, s));
-        EXORL_TRY(mlp_forward(it->net[0], P, it->xf, B, prec, s));
-        EXORL_TRY(mlp_forward(it->net[1], P, it->xb, B, prec, s));
-        EXORL_TRY(icm_errors(it, next_obs, O, action, true, true, s));
+        EXORL_TRY(launch_concat(b.obs, b.obs_ld, O, b.next_obs, b.next_obs_ld, O, it->xb, B, s));
+        EXORL_TRY(mlp_forward(it->net[0], P, it->xf, O + A, B, prec, s));
+        EXORL_TRY(mlp_forward(it->net[1], P, it->xb, 2 * O, B, prec, s));
+        EXORL_TRY(icm_errors(it, b.next_obs, b.next_obs_ld, b.action, b.action_ld, true, true, s));
         EXORL_TRY(launch_mean(it->fe, B, 1.0f / (float)B, it->metrics + EXORL_IM_LOSS, 0, s));
         EXORL_TRY(launch_mean(it->be, B, 1.0f / (float)B, it->metrics + EXORL_IM_LOSS, 1, s));
-        EXORL_TRY(mlp_backward(it->net[0], P, G, it->xf, B, nullptr, prec, s));
-        EXORL_TRY(mlp_backward(it->net[1], P, G, it->xb, B, nullptr, prec, s));
+        EXORL_TRY(mlp_backward(it->net[0], P, G, it->xf, O + A, B, nullptr, prec, s));
+        EXORL_TRY(mlp_backward(it->net[1], P, G, it->xb, 2 * O, B, nullptr, prec, s));
         EXORL_TRY(intr_adam(it, s));
     }
-    EXORL_TRY(mlp_forward(it->net[0], P, it->xf, B, prec, s));                                       // icm.py:86-92
-    EXORL_TRY(icm_errors(it, next_obs, O, action, false, false, s));
-    hipLaunchKernelGGL(icm_reward_kernel, dim3(1), dim3(1024), 0, s, it->fe, extr, reward, B, c.scale, it->metrics);
+    EXORL_TRY(mlp_forward(it->net[0], P, it->xf, O + A, B, prec, s));                                // icm.py:86-92
+    EXORL_TRY(icm_errors(it, b.next_obs, b.next_obs_ld, b.action, b.action_ld, false, false, s));
+    hipLaunchKernelGGL(icm_reward_kernel, dim3(1), dim3(1024), 0, s, it->fe, b.extr_reward, b.reward_out, B, c.scale, it->metrics);
     EXORL_LAUNCH_CHECK();
     return 0;
 }
 
-static int apt_trunk(exorl_intr* it, const float* x, int rows, hipStream_t s) {        // Linear -> LayerNorm -> Tanh (icm_apt.py:21-22)
+static int apt_trunk(exorl_intr* it, const float* x, int64_t ldx, int rows, hipStream_t s) {    // Linear -> LayerNorm -> Tanh (icm_apt.py:21-22)
     const auto& c = it->cfg;
     const float* P = it->flat[EXORL_T_PARAM];
-    GemmProblem p{x, P + it->trunk.W, it->z, P + it->trunk.b, rows, c.rep_dim, c.obs_dim, c.obs_dim, c.obs_dim, c.rep_dim};
+    GemmProblem p{x, P + it->trunk.W, it->z, P + it->trunk.b, rows, c.rep_dim, c.obs_dim, ldx, c.obs_dim, c.rep_dim};
     EXORL_TRY(gemm_grouped(c.precision, 0, 0, &p, 1, false, false, s));
     return ln_tanh_fwd(it->z, P + it->ln_g, P + it->ln_b, it->rep, it->xhat, it->rstd, rows, c.rep_dim, 1, 0, 0, s);
 }
 
-static int apt_update(exorl_intr* it, const float* obs, const float* action, const float* next_obs, const float* extr, float* reward,
-                      bool train, hipStream_t s) {
+static int apt_update(exorl_intr* it, const exorl_intr_batch& b, bool train, hipStream_t s) {
     const auto& c = it->cfg;
     const int B = c.batch, O = c.obs_dim, A = c.act_dim, R = c.rep_dim, prec = c.precision;
     const float* P = it->flat[EXORL_T_PARAM];
     float* G = it->flat[EXORL_T_GRAD];
     if (train) {                                                                                     // icm_apt.py:33-50,86-104
-        EXORL_CHECK_HIP(hipMemcpyAsync(it->x2, obs, sizeof(float) * B * O, hipMemcpyDeviceToDevice, s));
-        EXORL_CHECK_HIP(hipMemcpyAsync(it->x2 + (int64_t)B * O, next_obs, sizeof(float) * B * O, hipMemcpyDeviceToDevice, s));
-        EXORL_TRY(apt_trunk(it, it->x2, 2 * B, s));
+        EXORL_TRY(launch_concat(b.obs, b.obs_ld, O, nullptr, 0, 0, it->x2, B, s));                   // x2 = [obs; next_obs] stacked by rows
+        EXORL_TRY(launch_concat(b.next_obs, b.next_obs_ld, O, nullptr, 0, 0, it->x2 + (int64_t)B * O, B, s));
+        EXORL_TRY(apt_trunk(it, it->x2, O, 2 * B, s));
         const float* rn = it->rep + (int64_t)B * R;
-        EXORL_TRY(launch_concat(it->rep, R, R, action, A, A, it->xf, B, s));
+        EXORL_TRY(launch_concat(it->rep, R, R, b.action, b.action_ld, A, it->xf, B, s));
         EXORL_TRY(launch_concat(it->rep, R, R, rn, R, R, it->xb, B, s));
-        EXORL_TRY(mlp_forward(it->net[0], P, it->xf, B, prec, s));
-        EXORL_TRY(mlp_forward(it->net[1], P, it->xb, B, prec, s));
-        EXORL_TRY(icm_errors(it, rn, R, action, true, true, s));
+        EXORL_TRY(mlp_forward(it->net[0], P, it->xf, R + A, B, prec, s));
+        EXORL_TRY(mlp_forward(it->net[1], P, it->xb, 2 * R, B, prec, s));
+        EXORL_TRY(icm_errors(it, rn, R, b.action, b.action_ld, true, true, s));
         EXORL_TRY(launch_mean(it->fe, B, 1.0f / (float)B, it->metrics + EXORL_IM_LOSS, 0, s));
         EXORL_TRY(launch_mean(it->be, B, 1.0f / (float)B, it->metrics + EXORL_IM_LOSS, 1, s));
-        EXORL_TRY(mlp_backward(it->net[0], P, G, it->xf, B, it->dxf, prec, s));
-        EXORL_TRY(mlp_backward(it->net[1], P, G, it->xb, B, it->dxb, prec, s));
+        EXORL_TRY(mlp_backward(it->net[0], P, G, it->xf, R + A, B, it->dxf, prec, s));
+        EXORL_TRY(mlp_backward(it->net[1], P, G, it->xb, 2 * R, B, it->dxb, prec, s));
         hipLaunchKernelGGL(apt_drep_kernel, dim3(grid_for((int64_t)B * R)), dim3(256), 0, s, it->dxf, (int64_t)(R + A), it->dxb,
                            (int64_t)(2 * R), it->net[0].dact[1], it->drep, B, R);
         EXORL_LAUNCH_CHECK();
@@ -514,12 +581,65 @@ static int apt_update(exorl_intr* it, const float* obs, const float* action, con
         EXORL_TRY(gemm_grouped(prec, 1, 1, &w, 1, false, false, s));
         EXORL_TRY(intr_adam(it, s));
     }
-    EXORL_TRY(apt_trunk(it, obs, B, s));                                                             // icm_apt.py:106-110
+    EXORL_TRY(apt_trunk(it, b.obs, b.obs_ld, B, s));                                                 // icm_apt.py:106-110
     EXORL_TRY(exorl_knn_topk(it->rep, B, it->rep, B, R, c.knn_k, it->topk, s));
-    hipLaunchKernelGGL(pbe_reward_kernel, dim3(1), dim3(1024), 0, s, it->topk, extr, reward, B, c.knn_k, c.knn_avg, c.knn_rms, c.knn_clip,
-                       it->rms, it->metrics);
+    hipLaunchKernelGGL(pbe_reward_kernel, dim3(1), dim3(1024), 0, s, it->topk, b.extr_reward, b.reward_out, B, c.knn_k, c.knn_avg, c.knn_rms,
+                       c.knn_clip, it->rms, it->metrics);
     EXORL_LAUNCH_CHECK();
     return 0;
+}
+
+// ---- Disagreement ----------------------------------------------------------------------------------
+static int disagreement_update(exorl_intr* it, const exorl_intr_batch& b, bool train, hipStream_t s) {
+    const auto& c = it->cfg;
+    const int B = c.batch, O = c.obs_dim, A = c.act_dim, prec = c.precision, n = it->n_nets;
+    const float* P = it->flat[EXORL_T_PARAM];
+    float* G = it->flat[EXORL_T_GRAD];
+    EXORL_TRY(launch_concat(b.obs, b.obs_ld, O, b.action, b.action_ld, A, it->xf, B, s));
+    if (train) {                                                                                     // disagreement.py:19-33,64-80
+        for (int m = 0; m < n; ++m) {
+            EXORL_TRY(mlp_forward(it->net[m], P, it->xf, O + A, B, prec, s));
+            hipLaunchKernelGGL(icm_err_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->net[m].act[1], O, b.next_obs, b.next_obs_ld, nullptr, nullptr,
+                               A, it->fe + (int64_t)m * B, nullptr, it->net[m].dact[1], nullptr, B, 1.0f / ((float)B * (float)n));
+            EXORL_LAUNCH_CHECK();
+            EXORL_TRY(mlp_backward(it->net[m], P, G, it->xf, O + A, B, nullptr, prec, s));
+        }
+        EXORL_TRY(launch_mean(it->fe, B * n, 1.0f / ((float)B * (float)n), it->metrics + EXORL_IM_LOSS, 0, s));
+        EXORL_TRY(intr_adam(it, s));
+    }
+    PredSet ps{};
+    for (int m = 0; m < n; ++m) {                                                                    // disagreement.py:35-47
+        EXORL_TRY(mlp_forward(it->net[m], P, it->xf, O + A, B, prec, s));
+        ps.p[m] = it->net[m].act[1];
+    }
+    if (b.extr_reward) EXORL_TRY(launch_mean(b.extr_reward, B, 1.0f / (float)B, it->metrics + EXORL_IM_EXTR_REWARD, 0, s));
+    hipLaunchKernelGGL(disagreement_reward_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, ps, n, b.reward_out, B, O);
+    EXORL_LAUNCH_CHECK();
+    return launch_mean(b.reward_out, B, 1.0f / (float)B, it->metrics + EXORL_IM_INTR_REWARD, 0, s);
+}
+
+// ---- DIAYN -----------------------------------------------------------------------------------------
+static int diayn_update(exorl_intr* it, const exorl_intr_batch& b, bool train, hipStream_t s) {
+    const auto& c = it->cfg;
+    const int B = c.batch, O = c.obs_dim, S = c.rep_dim, prec = c.precision;
+    const float* P = it->flat[EXORL_T_PARAM];
+    if (train) {                                                                                     // diayn.py:78-92,107-127
+        EXORL_TRY(mlp_forward(it->net[0], P, b.next_obs, b.next_obs_ld, B, prec, s));
+        hipLaunchKernelGGL(diayn_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->net[0].act[2], b.skill, b.skill_ld, S, it->fe, it->be,
+                           it->net[0].dact[2], (float*)nullptr, c.scale, B);
+        EXORL_LAUNCH_CHECK();
+        EXORL_TRY(launch_mean(it->fe, B, 1.0f / (float)B, it->metrics + EXORL_IM_LOSS, 0, s));
+        EXORL_TRY(launch_mean(it->be, B, 1.0f / (float)B, it->metrics + EXORL_IM_ACC, 0, s));
+        EXORL_TRY(mlp_backward(it->net[0], P, it->flat[EXORL_T_GRAD], b.next_obs, b.next_obs_ld, B, nullptr, prec, s));
+        EXORL_TRY(intr_adam(it, s));
+    }
+    EXORL_TRY(mlp_forward(it->net[0], P, b.next_obs, b.next_obs_ld, B, prec, s));                    // diayn.py:94-105
+    if (b.extr_reward) EXORL_TRY(launch_mean(b.extr_reward, B, 1.0f / (float)B, it->metrics + EXORL_IM_EXTR_REWARD, 0, s));
+    hipLaunchKernelGGL(diayn_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->net[0].act[2], b.skill, b.skill_ld, S, (float*)nullptr,
+                       (float*)nullptr, (float*)nullptr, b.reward_out, c.scale, B);
+    EXORL_LAUNCH_CHECK();
+    (void)O;
+    return launch_mean(b.reward_out, B, 1.0f / (float)B, it->metrics + EXORL_IM_INTR_REWARD, 0, s);
 }
 
 }  // namespace exorl
@@ -528,10 +648,11 @@ extern "C" {
 
 static int check_intr_cfg(const exorl_intr_cfg* cfg) {
     EXORL_REQUIRE(cfg, "intr: null cfg");
-    EXORL_REQUIRE(cfg->kind >= EXORL_INTR_RND && cfg->kind <= EXORL_INTR_ICM_APT, "intr: unknown kind %d", cfg->kind);
+    EXORL_REQUIRE(cfg->kind >= EXORL_INTR_RND && cfg->kind <= EXORL_INTR_DIAYN, "intr: unknown kind %d", cfg->kind);
+    EXORL_REQUIRE(cfg->n_models >= 0 && cfg->n_models <= EXORL_MAX_ENSEMBLE, "intr: n_models=%d out of range (<= %d)", cfg->n_models, EXORL_MAX_ENSEMBLE);
     EXORL_REQUIRE(cfg->obs_dim > 0 && cfg->act_dim > 0 && cfg->act_dim <= 64 && cfg->hidden_dim > 0 && cfg->batch > 0,
                   "intr: unsupported dims O=%d A=%d (<=64) H=%d B=%d", cfg->obs_dim, cfg->act_dim, cfg->hidden_dim, cfg->batch);
-    EXORL_REQUIRE(cfg->kind == EXORL_INTR_ICM || (cfg->rep_dim > 0 && (cfg->kind != EXORL_INTR_ICM_APT || cfg->rep_dim <= 1024)),
+    EXORL_REQUIRE(cfg->kind == EXORL_INTR_ICM || cfg->kind == EXORL_INTR_DISAGREEMENT || (cfg->rep_dim > 0 && (cfg->kind != EXORL_INTR_ICM_APT || cfg->rep_dim <= 1024)),
                   "intr: rep_dim=%d out of range (ICM-APT trunk: <= 1024)", cfg->rep_dim);
     EXORL_REQUIRE(cfg->kind != EXORL_INTR_ICM_APT || (cfg->knn_k >= 1 && cfg->knn_k <= 64 && cfg->knn_k <= cfg->batch && cfg->batch <= 4096),
                   "intr: ICM-APT needs 1 <= knn_k <= min(64, batch) and batch <= 4096 (got k=%d B=%d)", cfg->knn_k, cfg->batch);
@@ -616,15 +737,21 @@ int exorl_intr_state(exorl_intr_t* it, void** rms_dev, void** bn_dev, int64_t* b
     return 0;
 }
 
-int exorl_intr_update(exorl_intr_t* it, const float* obs, const float* action, const float* next_obs, const float* extr_reward,
-                      float* reward_out, int32_t train, void* stream) {
-    EXORL_REQUIRE(it && obs && reward_out, "intr_update: null argument");
-    EXORL_REQUIRE(it->cfg.kind == EXORL_INTR_RND || (action && next_obs), "intr_update: ICM needs action and next_obs");
+int exorl_intr_update(exorl_intr_t* it, const exorl_intr_batch* b, int32_t train, void* stream) {
+    EXORL_REQUIRE(it && b && b->obs && b->reward_out, "intr_update: null argument");
+    const int k = it->cfg.kind;
+    EXORL_REQUIRE(k == EXORL_INTR_RND || b->next_obs, "intr_update: this module needs next_obs");
+    EXORL_REQUIRE(k == EXORL_INTR_RND || k == EXORL_INTR_DIAYN || b->action, "intr_update: this module needs action");
+    EXORL_REQUIRE(k != EXORL_INTR_DIAYN || b->skill, "intr_update: DIAYN needs the skill matrix");
+    EXORL_REQUIRE(b->obs_ld >= it->cfg.obs_dim && (!b->next_obs || b->next_obs_ld >= it->cfg.obs_dim) && (!b->action || b->action_ld >= it->cfg.act_dim) &&
+                  (!b->skill || b->skill_ld >= it->cfg.rep_dim), "intr_update: a leading dimension is smaller than its row width");
     hipStream_t s = as_stream(stream);
-    switch (it->cfg.kind) {
-        case EXORL_INTR_RND: return rnd_update(it, obs, extr_reward, reward_out, train != 0, s);
-        case EXORL_INTR_ICM: return icm_update(it, obs, action, next_obs, extr_reward, reward_out, train != 0, s);
-        default: return apt_update(it, obs, action, next_obs, extr_reward, reward_out, train != 0, s);
+    switch (k) {
+        case EXORL_INTR_RND: return rnd_update(it, *b, train != 0, s);
+        case EXORL_INTR_ICM: return icm_update(it, *b, train != 0, s);
+        case EXORL_INTR_ICM_APT: return apt_update(it, *b, train != 0, s);
+        case EXORL_INTR_DISAGREEMENT: return disagreement_update(it, *b, train != 0, s);
+        default: return diayn_update(it, *b, train != 0, s);
     }
 }
 

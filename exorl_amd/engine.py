@@ -174,15 +174,15 @@ class AgentEngine:
 class IntrEngine:
     """Intrinsic-reward module (exorl_intr_t): RND / ICM / ICM-APT. Parameters live in a torch-owned workspace so they
     can be exposed as tensors (state_dict, snapshots)."""
-    KINDS = {'rnd': L.INTR_RND, 'icm': L.INTR_ICM, 'icm_apt': L.INTR_ICM_APT}
+    KINDS = {'rnd': L.INTR_RND, 'icm': L.INTR_ICM, 'icm_apt': L.INTR_ICM_APT, 'disagreement': L.INTR_DISAGREEMENT, 'diayn': L.INTR_DIAYN}
 
     def __init__(self, kind, obs_dim, act_dim, hidden_dim, batch, rep_dim=0, lr=1e-4, scale=1.0, knn_k=12, knn_avg=True,
-                 knn_rms=True, knn_clip=0.0, clip_val=5.0, precision='fp32', device='cuda'):
+                 knn_rms=True, knn_clip=0.0, clip_val=5.0, n_models=0, precision='fp32', device='cuda'):
         self.lib = L.load()
         self.device = _require_gpu(device)
         self.kind, self.batch, self.obs_dim, self.act_dim = kind, batch, obs_dim, act_dim
         self.cfg = L.IntrCfg(self.KINDS[kind], obs_dim, act_dim, hidden_dim, rep_dim, batch, PRECISION[precision], knn_k, int(bool(knn_avg)),
-                             int(bool(knn_rms)), (C.c_int32 * 2)(0, 0), lr, scale, knn_clip, clip_val)
+                             int(bool(knn_rms)), n_models, 0, lr, scale, knn_clip, clip_val)
         nbytes = self.lib.exorl_intr_workspace_bytes(C.byref(self.cfg))
         if nbytes == 0:
             raise L.ExorlError(self.lib.exorl_last_error().decode())
@@ -235,8 +235,12 @@ class IntrEngine:
         raw[2:4] = np.array([n], np.float64).view(np.float32)
         self._rms.copy_(torch.from_numpy(raw))
 
-    def update(self, obs_ptr, action_ptr, next_obs_ptr, extr_ptr, reward_ptr, train=True):
-        L.check(self.lib.exorl_intr_update(self.h, obs_ptr, action_ptr, next_obs_ptr, extr_ptr, reward_ptr, int(bool(train)), L.current_stream()))
+    def update(self, obs, action, next_obs, extr_reward, reward_out, train=True, skill=None, obs_ld=None, action_ld=None,
+               next_obs_ld=None, skill_ld=0):
+        """Device pointers (ints) + row strides in floats; see exorl_intr_batch."""
+        b = L.IntrBatch(obs, obs_ld or self.obs_dim, action, action_ld or self.act_dim, next_obs, next_obs_ld or self.obs_dim,
+                        skill, skill_ld, extr_reward, reward_out)
+        L.check(self.lib.exorl_intr_update(self.h, C.byref(b), int(bool(train)), L.current_stream()))
 
     def metrics_raw(self):
         host = np.zeros(L.N_INTR_METRICS, np.float32)

@@ -255,15 +255,19 @@ int exorl_knn_topk(const float* src_dev, int32_t n_src, const float* tgt_dev, in
 #define EXORL_INTR_RND     0
 #define EXORL_INTR_ICM     1
 #define EXORL_INTR_ICM_APT 2
+#define EXORL_INTR_DISAGREEMENT 3   /* agents/unsupervised_learning/disagreement.py:11-90 */
+#define EXORL_INTR_DIAYN   4        /* agents/unsupervised_learning/diayn.py:15-127 */
+#define EXORL_MAX_ENSEMBLE 8
 
 typedef struct exorl_intr_cfg {
     int32_t kind;         /* EXORL_INTR_* */
     int32_t obs_dim, act_dim, hidden_dim;
-    int32_t rep_dim;      /* rnd_rep_dim / icm_rep_dim (unused by plain ICM) */
+    int32_t rep_dim;      /* rnd_rep_dim / icm_rep_dim / DIAYN skill_dim (unused by plain ICM and Disagreement) */
     int32_t batch;
     int32_t precision;    /* EXORL_PREC_* (MFMA operand type of the module's GEMMs) */
     int32_t knn_k, knn_avg, knn_rms;   /* ICM-APT: utils.PBE arguments (configs/agent/icm_apt.yaml) */
-    int32_t reserved[2];
+    int32_t n_models;     /* Disagreement ensemble size (0 -> 5, disagreement.py:12) */
+    int32_t reserved;
     float lr;             /* Adam, betas (0.9, 0.999), eps 1e-8 */
     float scale;          /* rnd_scale / icm_scale */
     float knn_clip;
@@ -278,6 +282,7 @@ typedef struct exorl_intr exorl_intr_t;
 #define EXORL_IM_EXTR_REWARD 2   /* mean of the extrinsic reward passed in (0 if none) */
 #define EXORL_IM_RMS_MEAN    3   /* running mean of the RMS (RND: pred_error_mean) */
 #define EXORL_IM_RMS_STD     4   /* sqrt of its running variance (RND: pred_error_std) */
+#define EXORL_IM_ACC         5   /* DIAYN: discriminator accuracy (diayn_acc) */
 #define EXORL_N_INTR_METRICS 8
 
 /* workspace: device memory of exorl_intr_workspace_bytes(cfg) bytes, 256-byte aligned, owned by the caller (so that the
@@ -286,7 +291,8 @@ size_t exorl_intr_workspace_bytes(const exorl_intr_cfg* cfg);
 int exorl_intr_create(const exorl_intr_cfg* cfg, void* workspace, size_t workspace_bytes, exorl_intr_t** out);
 int exorl_intr_destroy(exorl_intr_t* m);
 /* Parameter tensors in the module's parameters() order (RND: predictor.{1,3,5}, target.{1,3,5}; ICM: forward_net.{0,2},
- * backward_net.{0,2}; ICM-APT: trunk.0, trunk.1 (LayerNorm), forward_net, backward_net), each weight then bias.
+ * backward_net.{0,2}; ICM-APT: trunk.0, trunk.1 (LayerNorm), forward_net, backward_net; Disagreement: ensemble.{m}.{0,2};
+ * DIAYN: skill_pred_net.{0,2,4}), each weight then bias.
  * what = EXORL_T_*; RND's frozen target tensors have parameters only. */
 int exorl_intr_num_tensors(exorl_intr_t* m, int32_t* n);
 int exorl_intr_tensor(exorl_intr_t* m, int32_t index, int32_t what, void** ptr, int64_t* rows, int64_t* cols);
@@ -294,11 +300,21 @@ int exorl_intr_flat(exorl_intr_t* m, int32_t what, void** ptr, int64_t* numel);
 /* Device state outside the parameters: rms = {float M, float S, double n} (utils.RMS); bn = running_mean[obs_dim],
  * running_var[obs_dim], num_batches_tracked (as float) of RND's BatchNorm1d, or null. */
 int exorl_intr_state(exorl_intr_t* m, void** rms_dev, void** bn_dev, int64_t* bn_numel);
-/* train != 0: update_rnd / update_icm on (obs, action, next_obs) then compute_intr_reward under the updated module
- * (rnd.py:121-124, icm.py:106-110, icm_apt.py:123-127); train == 0: compute_intr_reward only.
- * reward_out (batch,) may alias extr_reward (the agent's reward slot); extr_reward may be null. All device pointers. */
-int exorl_intr_update(exorl_intr_t* m, const float* obs, const float* action, const float* next_obs, const float* extr_reward,
-                      float* reward_out, int32_t train, void* stream);
+/* One sampled batch as device pointers with row strides in floats (so that columns of a wider matrix can be passed in place:
+ * DIAYN's skill lives in the last columns of the agent's [obs | skill] rows). action / next_obs / skill / extr_reward may be
+ * null where the module does not read them; reward_out (batch,) may alias extr_reward (the agent's reward slot). */
+typedef struct exorl_intr_batch {
+    const float* obs;      int64_t obs_ld;
+    const float* action;   int64_t action_ld;
+    const float* next_obs; int64_t next_obs_ld;
+    const float* skill;    int64_t skill_ld;
+    const float* extr_reward;
+    float* reward_out;
+} exorl_intr_batch;
+/* train != 0: the module's optimiser step (update_rnd / update_icm / update_disagreement / update_diayn) then
+ * compute_intr_reward under the updated module (rnd.py:121-124, icm.py:106-110, icm_apt.py:123-127, disagreement.py:106-112,
+ * diayn.py:143-147); train == 0: compute_intr_reward only. */
+int exorl_intr_update(exorl_intr_t* m, const exorl_intr_batch* batch, int32_t train, void* stream);
 int exorl_intr_metrics(exorl_intr_t* m, float* host_out /* EXORL_N_INTR_METRICS */, void* stream);
 /* optimiser step count of the module's Adam: set == 0 reads into *steps, else writes it (snapshot restore) */
 int exorl_intr_opt_steps(exorl_intr_t* m, int64_t* steps, int32_t set);

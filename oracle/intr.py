@@ -5,8 +5,11 @@ reference's unsupervised agents (states observations):
   RND      /root/reference/agents/unsupervised_learning/rnd.py:13-60 (module), :79-108 (update_rnd, compute_intr_reward)
   ICM      /root/reference/agents/unsupervised_learning/icm.py:12-45, :64-92
   ICM-APT  /root/reference/agents/unsupervised_learning/icm_apt.py:13-57, :86-110 (PBE reward: utils.py:279-319)
-and of the update() that wires them into DDPG (rnd.py:110-159, icm.py:94-139, icm_apt.py:112-158).
-Pinned by tests/golden/tiny_{rnd,icm,icm_apt,icm_apt-kth}.npz (reference outputs).
+  Disagreement /root/reference/agents/unsupervised_learning/disagreement.py:11-47, :64-90
+  DIAYN    /root/reference/agents/unsupervised_learning/diayn.py:15-29, :78-127
+and of the update() that wires them into DDPG (rnd.py:110-159, icm.py:94-139, icm_apt.py:112-158,
+disagreement.py:92-136, diayn.py:129-176).
+Pinned by tests/golden/tiny_{rnd,icm,icm_apt,icm_apt-kth,disagreement,diayn}.npz (reference outputs).
 """
 import numpy as np
 
@@ -59,8 +62,16 @@ ICM_KEYS = [f'{n}.{i}.{w}' for n in ('forward_net', 'backward_net') for i in (0,
 APT_KEYS = ['trunk.0.weight', 'trunk.0.bias', 'trunk.1.weight', 'trunk.1.bias'] + ICM_KEYS
 
 
+DIS_KEYS = [f'ensemble.{m}.{i}.{w}' for m in range(5) for i in (0, 2) for w in ('weight', 'bias')]
+DIAYN_KEYS = [f'skill_pred_net.{i}.{w}' for i in (0, 2, 4) for w in ('weight', 'bias')]
+
+
 def intr_param_shapes(kind, O, A, H, R):
-    """[(key, shape)] in the module's parameters() order."""
+    """[(key, shape)] in the module's parameters() order. R: rep_dim (RND / ICM-APT) or skill_dim (DIAYN)."""
+    if kind == 'disagreement':
+        return list(zip(DIS_KEYS, [(H, O + A), (H,), (O, H), (O,)] * 5))
+    if kind == 'diayn':
+        return list(zip(DIAYN_KEYS, [(H, O), (H,), (H, H), (H,), (R, H), (R,)]))
     if kind == 'rnd':
         one = [(H, O), (H,), (H, H), (H,), (R, H), (R,)]
         return list(zip(RND_KEYS, one + one))
@@ -175,6 +186,70 @@ class OracleICMAPT:
         return self.pbe(rep).reshape(-1, 1)
 
 
+class OracleDisagreement:
+    """disagreement.py: ensemble of 5 forward models; loss = mean L2 error over (B, 5); reward = variance of the predictions."""
+
+    def __init__(self, params, lr=1e-4, n_models=5):
+        self.p = [np.array(x, F32) for x in params]
+        self.opt = Adam(self.p, lr)
+        self.n = n_models
+
+    def update(self, obs, action, next_obs):                               # disagreement.py:19-33,64-80
+        x = np.concatenate([obs, action], -1)
+        B = obs.shape[0]
+        grads, loss = [], F32(0)
+        for m in range(self.n):
+            p = self.p[4 * m:4 * m + 4]
+            nhat, acts = mlp_fwd(p, x)
+            e, g = l2_rows((next_obs - nhat).astype(F32))
+            loss = loss + e.sum(dtype=F32)
+            gm, _ = mlp_bwd(p, acts, (-g / F32(B * self.n)).astype(F32))
+            grads += gm
+        self.last_grads = grads
+        self.opt.step(self.p, grads)
+        return float(loss / F32(B * self.n))
+
+    def reward(self, obs, action, next_obs):                               # disagreement.py:35-47,82-85
+        x = np.concatenate([obs, action], -1)
+        preds = np.stack([mlp_fwd(self.p[4 * m:4 * m + 4], x)[0] for m in range(self.n)], 0)
+        return preds.var(0, ddof=1, dtype=F32).mean(-1, dtype=F32).astype(F32).reshape(-1, 1)
+
+
+class OracleDIAYN:
+    """diayn.py: skill discriminator on next_obs; cross-entropy loss; reward = log q(z|s') - log(1/skill_dim)."""
+
+    def __init__(self, params, lr=1e-4, scale=1.0):
+        self.p = [np.array(x, F32) for x in params]
+        self.opt = Adam(self.p, lr)
+        self.scale = scale
+
+    def _logits(self, next_obs):
+        d, acts = mlp_fwd(self.p, next_obs)
+        mx = d.max(-1, keepdims=True)
+        lse = (mx + np.log(np.exp(d - mx).sum(-1, keepdims=True, dtype=F32))).astype(F32)
+        return d, (d - lse).astype(F32), acts
+
+    def update(self, skill, next_obs):                                     # diayn.py:78-92,107-127
+        B = next_obs.shape[0]
+        z = skill.argmax(1)
+        d, lsm, acts = self._logits(next_obs)
+        loss = -lsm[np.arange(B), z].mean(dtype=F32)
+        self.acc = float((lsm.argmax(1) == z).sum() / B)
+        dd = np.exp(lsm).astype(F32)
+        dd[np.arange(B), z] -= F32(1)
+        grads, _ = mlp_bwd(self.p, acts, (dd / F32(B)).astype(F32))
+        self.last_grads = grads
+        self.opt.step(self.p, grads)
+        return float(loss)
+
+    def reward(self, skill, next_obs):                                     # diayn.py:94-105
+        B, S = skill.shape
+        _, lsm, _ = self._logits(next_obs)
+        import math
+        r = (lsm[np.arange(B), skill.argmax(1)] - F32(math.log(1 / S))).astype(F32).reshape(-1, 1)
+        return (r * F32(self.scale)).astype(F32)
+
+
 class OracleUnsupAgent:
     """{RND,ICM,ICMAPT}Agent.update with reward_free=True: module step, intrinsic reward, then the DDPG update on it."""
 
@@ -186,11 +261,18 @@ class OracleUnsupAgent:
             return {}
         obs, action, extr, discount, next_obs = [np.asarray(x, F32) for x in batch[:5]]
         args = (obs,) if self.kind == 'rnd' else (obs, action, next_obs)
+        if self.kind == 'diayn':
+            skill = np.asarray(batch[5], F32)
+            args = (skill, next_obs)
         loss = self.module.update(*args)
         intr = self.module.reward(*args)
         self.last_intr = intr
+        if self.kind == 'diayn':          # the actor/critic see [obs | skill] (diayn.py:162-164)
+            obs, next_obs = np.concatenate([obs, skill], 1), np.concatenate([next_obs, skill], 1)
         m = self.ddpg.update((obs, action, intr, discount, next_obs), step, noise_critic, noise_actor)
-        m[{'rnd': 'rnd_loss'}.get(self.kind, 'icm_loss')] = loss
+        m[{'rnd': 'rnd_loss', 'disagreement': 'disagreement_loss', 'diayn': 'diayn_loss'}.get(self.kind, 'icm_loss')] = loss
+        if self.kind == 'diayn':
+            m['diayn_acc'] = self.module.acc
         m['intr_reward'] = float(intr.mean(dtype=F32))
         m['extr_reward'] = float(extr.mean(dtype=F32))
         if self.kind == 'rnd':

@@ -7,7 +7,7 @@ import torch
 
 import _synth
 from oracle.agents import OracleAgent, param_shapes
-from oracle.intr import OracleICM, OracleICMAPT, OracleRND, OracleUnsupAgent, intr_param_shapes
+from oracle.intr import OracleDIAYN, OracleDisagreement, OracleICM, OracleICMAPT, OracleRND, OracleUnsupAgent, intr_param_shapes
 
 pytestmark = pytest.mark.gpu
 
@@ -27,6 +27,10 @@ def make(kind, O, A, H, B, R, use_tb=True, precision='fp32', **kw):
         return agents.RNDAgent(rnd_rep_dim=R, update_encoder=True, rnd_scale=1.0, **d)
     if base == 'icm':
         return agents.ICMAgent(icm_scale=1.0, update_encoder=True, **d)
+    if base == 'disagreement':
+        return agents.DisagreementAgent(update_encoder=True, **d)
+    if base == 'diayn':
+        return agents.DIAYNAgent(update_skill_every_step=50, skill_dim=R, diayn_scale=1.0, update_encoder=True, skill_type='uniform', **d)
     apt = dict(knn_rms=True, knn_k=3, knn_avg=True, knn_clip=0.0)
     if kind.endswith('kth'):
         apt.update(knn_avg=False, knn_clip=0.0005)
@@ -34,16 +38,22 @@ def make(kind, O, A, H, B, R, use_tb=True, precision='fp32', **kw):
     return agents.ICMAPTAgent(icm_scale=1.0, update_encoder=True, icm_rep_dim=R, **apt, **d)
 
 
+def module_of(ag):
+    for nm in ('rnd', 'icm', 'disagreement', 'diayn'):
+        if hasattr(ag, nm):
+            return nm, getattr(ag, nm)
+
+
 def nets_of(ag):
-    mod = ('rnd', ag.rnd) if hasattr(ag, 'rnd') else ('icm', ag.icm)
+    mod = module_of(ag)
     return [('actor', ag.actor), ('critic', ag.critic), ('critic_target', ag.critic_target), mod]
 
 
-@pytest.mark.parametrize('kind', ['rnd', 'icm', 'icm_apt', 'icm_apt-kth'])
+@pytest.mark.parametrize('kind', ['rnd', 'icm', 'icm_apt', 'icm_apt-kth', 'disagreement', 'diayn'])
 def test_tiny_trajectory_vs_reference(gold, kind):
     z = np.load(gold / f'tiny_{kind}.npz')
     torch.manual_seed(21)
-    ag = make(kind, 5, 3, 32, 8, 16)
+    ag = make(kind, 5, 3, 32, 8, 4 if kind == 'diayn' else 16)
     for nm, net in nets_of(ag):
         sd = net.state_dict()
         for k, v in sd.items():
@@ -53,7 +63,7 @@ def test_tiny_trajectory_vs_reference(gold, kind):
     ag.noise_hook = lambda shape: next(noise)
     keys = [str(k) for k in z['metric_keys']]
     for i in range(5):
-        batch = tuple(z[f'batch/{i}/{j}'] for j in range(5))
+        batch = tuple(z[f'batch/{i}/{j}'] for j in range(6 if kind == 'diayn' else 5))
         assert ag.update(iter([]), 2 * i + 1) == {}
         m = ag.update(iter([batch]), 2 * i)
         assert sorted(m.keys()) == keys
@@ -73,14 +83,14 @@ def build_pair(kind, O, A, H, B, R, precision='fp32', **kw):
     """exorl_amd agent and oracle agent with the same synthetic parameters."""
     base = kind.partition('-')[0]
     ag = make(kind, O, A, H, B, R, precision=precision, **kw)
-    ash, csh = param_shapes('ddpg', O, A, H)
+    ash, csh = param_shapes('ddpg', O + (R if base == 'diayn' else 0), A, H)
     pa, pc = _synth.synth_params(ash, 3), _synth.synth_params(csh, 4)
     ag.actor.load_state_dict({k: torch.from_numpy(v) for k, v in pa.items()})
     ag.critic.load_state_dict({k: torch.from_numpy(v) for k, v in pc.items()})
     ag.critic_target.load_state_dict(ag.critic.state_dict())
     ish = intr_param_shapes(base, O, A, H, R)
     pi = _synth.synth_params(ish, 5)
-    mod = ag.rnd if base == 'rnd' else ag.icm
+    mod = module_of(ag)[1]
     sd = {k: torch.from_numpy(v) for k, v in pi.items()}
     if base == 'rnd':
         sd.update({k: v for k, v in mod.state_dict().items() if k.startswith('normalize_obs')})
@@ -90,6 +100,10 @@ def build_pair(kind, O, A, H, B, R, precision='fp32', **kw):
         om = OracleRND(list(pi.values()))
     elif base == 'icm':
         om = OracleICM(list(pi.values()))
+    elif base == 'disagreement':
+        om = OracleDisagreement(list(pi.values()))
+    elif base == 'diayn':
+        om = OracleDIAYN(list(pi.values()))
     else:
         o = dict(knn_rms=True, knn_k=3, knn_avg=True, knn_clip=0.0)
         o.update(kw)
@@ -104,6 +118,9 @@ def build_pair(kind, O, A, H, B, R, precision='fp32', **kw):
     ('icm_apt', (17, 6, 256, 512, 128), dict(knn_k=5, knn_avg=False, knn_clip=0.0005)),
     ('rnd', (9, 2, 136, 100, 40), {}),                                       # unaligned widths -> scalar-load GEMM path
     ('icm', (9, 2, 136, 100, 0), {}),
+    ('disagreement', (24, 6, 1024, 1024, 0), {}),                            # configs/agent/disagreement.yaml widths
+    ('diayn', (24, 6, 1024, 1024, 16), {}),                                  # configs/agent/diayn.yaml: skill_dim 16
+    ('diayn', (9, 2, 136, 100, 5), {}),
 ])
 def test_shipped_widths_vs_oracle(kind, dims, kw):
     O, A, H, B, R = dims
@@ -113,13 +130,15 @@ def test_shipped_widths_vs_oracle(kind, dims, kw):
     ns2 = _synth.NoiseStream(11)
     for i in range(3):
         batch = _synth.synth_batch(17, i, B, O, A)
+        if kind == 'diayn':
+            batch = batch + (np.eye(R, dtype=np.float32)[np.random.RandomState(i).randint(0, R, B)],)
         m = ag.update(iter([batch]), 2 * i)
         mo = orc.update(batch, 2 * i, ns2.draw((B, A)), ns2.draw((B, A)))
         intr = ag.engine._view(ag.engine.batch_slots().reward, B).cpu().numpy().reshape(-1, 1)
         np.testing.assert_allclose(intr, orc.last_intr, rtol=2e-4, atol=1e-5, err_msg=f'{kind} intr reward step {i}')
         for k, v in mo.items():
             assert abs(m[k] - v) <= 1e-4 * abs(v) + 2e-6, (kind, i, k, m[k], v)
-    mod = ag.rnd if kind == 'rnd' else ag.icm
+    mod = module_of(ag)[1]
     for (k, _), p, want in zip(ish, mod.parameters(), orc.module.p):
         got = p.cpu().numpy().reshape(want.shape)
         # Adam moves every element by ~lr per step whatever its gradient's size, so an element whose gradient is rounding
@@ -169,3 +188,86 @@ def test_bf16_mode_tracks_fp32():
         res[prec] = m
     for k, v in res['fp32'].items():
         assert abs(res['bf16'][k] - v) <= 3e-2 * abs(v) + 3e-2, (k, res['bf16'][k], v)
+
+
+@pytest.mark.parametrize('kind', ['td3_bc', 'cql', 'rnd', 'icm_apt'])
+def test_pickle_roundtrip_continues_bit_identically(kind):
+    """pretrain.py:293-300 / finetune.py:222-252 torch.save and torch.load the whole agent object: a restored agent must
+    continue the run exactly (parameters, Adam moments and step counts, running statistics)."""
+    import io
+    import pickle
+    O, A, H, B, R = 17, 6, 128, 64, 32
+    if kind in ('rnd', 'icm_apt'):
+        ag = make(kind, O, A, H, B, R)
+    else:
+        from test_gpu_agent import make as make_offline
+        ag = make_offline(kind, O, A, H, B)
+    upd = (lambda a, i: a.update(iter([_synth.synth_batch(23, i, B, O, A)]), 2 * i))
+
+    def hook(agent, seed):
+        ns = _synth.NoiseStream(seed)
+        if kind == 'cql':
+            agent.noise_hook = lambda shape, dist='normal': (ns.draw(shape) if dist == 'normal' else np.tanh(ns.draw(shape)))
+        else:
+            agent.noise_hook = ns.draw
+    hook(ag, 1)
+    for i in range(3):
+        upd(ag, i)
+    buf = io.BytesIO()
+    torch.save({'agent': ag, '_global_step': 3}, buf)            # what pretrain.py:297-300 does
+    buf.seek(0)
+    payload = torch.load(buf, weights_only=False)                 # our own file (finetune.py:250)
+    ag2 = payload['agent']
+    assert type(ag2) is type(ag) and payload['_global_step'] == 3
+    ag3 = pickle.loads(pickle.dumps(ag))
+    for a in (ag, ag2, ag3):
+        hook(a, 2)
+        for i in range(3, 5):
+            m = upd(a, i)
+    nets = [ag.actor] + ([ag.critic, ag.critic_target] if hasattr(ag, 'critic') else [])
+    for other in (ag2, ag3):
+        onets = [other.actor] + ([other.critic, other.critic_target] if hasattr(other, 'critic') else [])
+        for n1, n2 in zip(nets, onets):
+            for (k, p), q in zip(n1.named_parameters(), n2.parameters()):
+                assert torch.equal(p, q), (kind, k)
+        if hasattr(ag, 'intr'):
+            assert torch.equal(ag.intr.flat(), other.intr.flat())
+            assert ag.intr.rms_state() == other.intr.rms_state() and ag.intr.opt_steps() == other.intr.opt_steps() == 5
+        assert ag.engine.opt_steps() == other.engine.opt_steps()
+        assert other.use_tb == ag.use_tb and other.hidden_dim == ag.hidden_dim
+
+
+def test_diayn_zero_copy_sampler_path_matches_iterator_path():
+    """DIAYN with the HBM sampler: obs and the stored skill land directly in the agent's [obs | skill] rows; the result must
+    equal feeding the same sampled batch through the plain iterator path."""
+    from exorl_amd.engine import ReplayEngine
+    from exorl_amd.replay_buffer import ArenaIterator
+    O, A, H, B, S = 11, 3, 64, 32, 4
+    rs = np.random.RandomState(0)
+    eng = ReplayEngine((O,), np.float32, A, S, 4096, 16, 'cuda')
+    slots = []
+    for e in range(6):
+        rows = 20 + e
+        ep = dict(observation=rs.standard_normal((rows, O)).astype(np.float32), action=rs.uniform(-1, 1, (rows, A)).astype(np.float32),
+                  reward=rs.uniform(0, 1, (rows, 1)).astype(np.float32), discount=np.ones((rows, 1), np.float32),
+                  skill=np.eye(S, dtype=np.float32)[rs.randint(0, S, rows)])
+        slots.append(eng.append_episode(ep, ('skill',)))
+    eng.set_order(slots)
+    agents = []
+    for path in ('zero_copy', 'iterator'):
+        torch.manual_seed(3)
+        ag = make('diayn', O, A, H, B, S)
+        ag.noise_hook = _synth.NoiseStream(9).draw
+        eng.seed_philox(5)
+        it = ArenaIterator(eng, B, 3, 0.99, 'philox')
+        for i in range(3):
+            if path == 'zero_copy':
+                m = ag.update(it, 2 * i)
+            else:
+                m = ag.update(iter([tuple(t.cpu().numpy() for t in next(it))]), 2 * i)
+        agents.append((ag, m))
+    (a0, m0), (a1, m1) = agents
+    assert m0 == m1
+    for p, q in zip(a0.actor.parameters() + a0.critic.parameters() + a0.diayn.parameters(),
+                    a1.actor.parameters() + a1.critic.parameters() + a1.diayn.parameters()):
+        assert torch.equal(p, q)

@@ -4,18 +4,20 @@ import numpy as np
 import pytest
 
 from oracle.agents import OracleAgent, param_shapes
-from oracle.intr import OracleICM, OracleICMAPT, OracleRND, OracleUnsupAgent, intr_param_shapes
+from oracle.intr import OracleDIAYN, OracleDisagreement, OracleICM, OracleICMAPT, OracleRND, OracleUnsupAgent, intr_param_shapes
 
 O, A, H, R = 5, 3, 32, 16
-KINDS = ['rnd', 'icm', 'icm_apt', 'icm_apt-kth']
+KINDS = ['rnd', 'icm', 'icm_apt', 'icm_apt-kth', 'disagreement', 'diayn']
+MODULE = {'rnd': 'rnd', 'disagreement': 'disagreement', 'diayn': 'diayn'}
 
 
 def build_oracle(z, kind):
     base = kind.partition('-')[0]
-    ash, csh = param_shapes('ddpg', O, A, H)
+    S = 4 if base == 'diayn' else 0
+    ash, csh = param_shapes('ddpg', O + S, A, H)
     ddpg = OracleAgent('ddpg', [z[f'init/actor/{k}'] for k, _ in ash], [z[f'init/critic/{k}'] for k, _ in csh])
-    mod_name = 'rnd' if base == 'rnd' else 'icm'
-    ish = intr_param_shapes(base, O, A, H, R)
+    mod_name = MODULE.get(base, 'icm')
+    ish = intr_param_shapes(base, O, A, H, S or R)
     params = [z[f'init/{mod_name}/{k}'] for k, _ in ish]
     for (k, s), p in zip(ish, params):
         assert tuple(p.shape) == tuple(s), (k, p.shape, s)
@@ -23,6 +25,10 @@ def build_oracle(z, kind):
         mod = OracleRND(params)
     elif base == 'icm':
         mod = OracleICM(params)
+    elif base == 'disagreement':
+        mod = OracleDisagreement(params)
+    elif base == 'diayn':
+        mod = OracleDIAYN(params)
     else:
         mod = OracleICMAPT(params, knn_k=3, **(dict(knn_avg=False, knn_clip=0.0005) if kind.endswith('kth') else {}))
     return OracleUnsupAgent(base, ddpg, mod), ash, csh, ish, mod_name
@@ -34,7 +40,7 @@ def test_tiny_unsup_trajectory(gold, kind):
     ag, ash, csh, ish, mod_name = build_oracle(z, kind)
     keys = [str(k) for k in z['metric_keys']]
     for i in range(5):
-        batch = [z[f'batch/{i}/{j}'] for j in range(5)]
+        batch = [z[f'batch/{i}/{j}'] for j in range(6 if kind == 'diayn' else 5)]
         assert ag.update(batch, 2 * i + 1, None, None) == {}
         m = ag.update(batch, 2 * i, z[f'noise/{2 * i}'], z[f'noise/{2 * i + 1}'])
         np.testing.assert_allclose(ag.last_intr, z['intr_reward'][i], rtol=2e-5, atol=2e-6, err_msg=f'{kind} intr step {i}')

@@ -197,6 +197,11 @@ def make_agent(ref, kind, O, A, H, B, device='cpu', use_tb=True, **kw):
         return ref.rnd.RNDAgent(rnd_rep_dim=kw.get('rep_dim', 16), update_encoder=True, rnd_scale=1.0, **ddpg_kw)
     if kind == 'icm':          # configs/agent/icm.yaml: icm_scale 1.0
         return ref.icm.ICMAgent(icm_scale=1.0, update_encoder=True, **ddpg_kw)
+    if kind == 'disagreement':
+        return ref.disagreement.DisagreementAgent(update_encoder=True, **ddpg_kw)
+    if kind == 'diayn':        # configs/agent/diayn.yaml: skill_dim 16, diayn_scale 1.0, update_skill_every_step 50 (tiny: 4 skills)
+        return ref.diayn.DIAYNAgent(update_skill_every_step=50, skill_dim=kw.get('skill_dim', 4), diayn_scale=1.0,
+                                    update_encoder=True, skill_type='uniform', **ddpg_kw)
     if kind == 'icm_apt':      # configs/agent/icm_apt.yaml: icm_rep_dim 512, knn_rms true, knn_k 12, knn_avg true, knn_clip 0.0
         return ref.icm_apt.ICMAPTAgent(icm_scale=1.0, knn_rms=kw.get('knn_rms', True), knn_k=kw.get('knn_k', 3),
                                        knn_avg=kw.get('knn_avg', True), knn_clip=kw.get('knn_clip', 0.0), update_encoder=True,
@@ -209,7 +214,7 @@ def nets_of(agent):
     # (CQL's log_actor_alpha / log_critic_alpha scalars are stored separately by gen_tiny)
     if hasattr(agent, 'critic'):
         nets += [('critic', agent.critic), ('critic_target', agent.critic_target)]
-    for nm in ('rnd', 'icm'):            # intrinsic-reward modules of the DDPG-backbone agents
+    for nm in ('rnd', 'icm', 'disagreement', 'diayn'):            # intrinsic-reward modules of the DDPG-backbone agents
         if hasattr(agent, nm):
             nets.append((nm, getattr(agent, nm)))
     return nets
@@ -260,8 +265,8 @@ def checksums(agent):
     return cs
 
 
-UNSUP = ('ddpg', 'rnd', 'icm', 'icm_apt')
-TINY_KINDS = ('td3_bc', 'td3', 'bc', 'ddpg', 'crr', 'crr-exp', 'crr-identity', 'cql', 'rnd', 'icm', 'icm_apt', 'icm_apt-kth')
+UNSUP = ('ddpg', 'rnd', 'icm', 'icm_apt', 'disagreement', 'diayn')
+TINY_KINDS = ('td3_bc', 'td3', 'bc', 'ddpg', 'crr', 'crr-exp', 'crr-identity', 'cql', 'rnd', 'icm', 'icm_apt', 'icm_apt-kth', 'disagreement', 'diayn')
 
 
 def gen_tiny(ref):
@@ -298,6 +303,9 @@ def gen_tiny(ref):
                 return x
         rec = Rec()
         batches = [_synth.synth_batch(31, i, B, O, A) for i in range(N)]
+        if base == 'diayn':          # 6th batch element: the one-hot skill the replay buffer stores as meta (diayn.py:123-125)
+            rsk = np.random.RandomState(41)
+            batches = [b + (np.eye(4, dtype=np.float32)[rsk.randint(0, 4, B)],) for b in batches]
         metrics = run_agent(ref, agent, base, N, lambda i: batches[i], rec, np.float32)
         for i, b in enumerate(batches):
             for j, t in enumerate(b):

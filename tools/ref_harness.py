@@ -50,7 +50,7 @@ def load_reference():
     pkg = types.ModuleType('refunsup')
     pkg.__path__ = [f'{REF}/agents/unsupervised_learning']
     sys.modules['refunsup'] = pkg
-    for n in ('ddpg', 'proto', 'rnd', 'icm', 'icm_apt'):
+    for n in ('ddpg', 'proto', 'rnd', 'icm', 'icm_apt', 'disagreement', 'diayn', 'aps', 'smm'):
         setattr(ref, n, importlib.import_module(f'refunsup.{n}'))
     return ref
 
