@@ -364,8 +364,10 @@ static NoiseSpec act_noise_spec(exorl_agent* a, const float* buf) {
 static int push_opt_steps(exorl_agent* a) {
     long long t[2] = {a->actor_t, a->critic_t};
     EXORL_CHECK_HIP(hipMemcpy(&a->state->t_actor, t, sizeof(t), hipMemcpyHostToDevice));
-    const double p[4] = {std::pow(0.9, (double)a->actor_t), 0.0, std::pow(0.9, (double)a->critic_t), std::pow(0.999, (double)a->critic_t)};
-    const double p2 = std::pow(0.999, (double)a->actor_t);
+    // beta^t as the device forms it (a running product, one multiply per step) so that a restored agent continues bit-identically
+    auto prod = [](double b, long long t) { double r = 1.0; for (long long i = 0; i < t; ++i) r *= b; return r; };
+    const double p[4] = {prod(0.9, a->actor_t), 0.0, prod(0.9, a->critic_t), prod(0.999, a->critic_t)};
+    const double p2 = prod(0.999, a->actor_t);
     EXORL_CHECK_HIP(hipMemcpy(&a->state->b1t, p, sizeof(p), hipMemcpyHostToDevice));
     EXORL_CHECK_HIP(hipMemcpy(&a->state->b2t, &p2, sizeof(p2), hipMemcpyHostToDevice));
     return 0;
@@ -577,7 +579,7 @@ int exorl_agent_create(const exorl_agent_cfg* cfg, void* workspace, size_t works
     a->spec_actor = shadow_spec(a->actor, a->sh_actor, nullptr);
     if (a->has_critic) a->spec_critic = shadow_spec(a->critic, a->sh_critic, &a->sh_target);
     StepState st{};
-    st.lr = cfg->lr; st.b1 = 0.9f; st.b2 = 0.999f; st.eps = 1e-8f; st.tau = cfg->tau;      // torch.optim.Adam defaults
+    st.lr = dec7(cfg->lr); st.b1 = 0.9; st.b2 = 0.999; st.eps = 1e-8; st.tau = dec7(cfg->tau);      // torch.optim.Adam defaults
     st.has_critic = a->has_critic ? 1 : 0;
     st.b1t = st.b2t = st.b1t_c = st.b2t_c = 1.0;
     if (a->cql) { CqlScalars sc{0.f, 0.f, 0.f, 1.0f}; (void)hipMemcpy(a->cql, &sc, sizeof(sc), hipMemcpyHostToDevice); }

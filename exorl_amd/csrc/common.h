@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -38,6 +39,13 @@ void set_error(const char* fmt, ...);
 
 #define EXORL_LAUNCH_CHECK() EXORL_CHECK_HIP(hipGetLastError())
 
+// The ABI carries hyper-parameters as fp32, the reference holds them as Python floats (doubles): 0.9f is 0.89999998, not 0.9.
+// Recover the short decimal the caller meant (7 significant digits identify an fp32 value's intended literal).
+inline double dec7(float x) {
+    char buf[40];
+    snprintf(buf, sizeof(buf), "%.7g", (double)x);
+    return strtod(buf, nullptr);
+}
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 inline int cdiv(int64_t a, int64_t b) { return static_cast<int>((a + b - 1) / b); }

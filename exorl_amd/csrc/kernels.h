@@ -124,24 +124,24 @@ struct StepState {
     double b1t, b2t_actor_unused, b1t_c, b2t_c;   // running beta^t products: [actor b1^t, (pad), critic b1^t, critic b2^t]
     double b2t;                  // actor b2^t
     AdamConst actor, critic;
-    float lr, b1, b2, eps, tau;
+    double lr, b1, b2, eps, tau;  // the Python-float hyper-parameters torch.optim.Adam holds (dec7() of the fp32 ABI values)
     int has_critic;
 };
 int step_begin(StepState* st, int advance_replay, hipStream_t s);
 
-__device__ inline void fill_adam_const(AdamConst& c, double b1t, double b2t, float lr, float b1, float b2, float eps, float tau) {
+__host__ __device__ inline void fill_adam_const(AdamConst& c, double b1t, double b2t, double lr, double b1, double b2, double eps, double tau) {
     // double-precision scalar math, as torch's _single_tensor_adam does in Python floats; beta^t comes from a running
     // product kept in the step state (one multiply per step instead of two software pow() calls on the critical path)
     const double bc1 = 1.0 - b1t;
     const double bc2 = 1.0 - b2t;
-    c.one_minus_b1 = (float)(1.0 - (double)b1);
-    c.b2 = b2;
-    c.one_minus_b2 = (float)(1.0 - (double)b2);
+    c.one_minus_b1 = (float)(1.0 - b1);
+    c.b2 = (float)b2;
+    c.one_minus_b2 = (float)(1.0 - b2);
     c.bc2_sqrt = (float)sqrt(bc2);
-    c.eps = eps;
-    c.neg_step_size = (float)(-((double)lr / bc1));
-    c.tau = tau;
-    c.one_minus_tau = (float)(1.0 - (double)tau);
+    c.eps = (float)eps;
+    c.neg_step_size = (float)(-(lr / bc1));
+    c.tau = (float)tau;
+    c.one_minus_tau = (float)(1.0 - tau);
 }
 
 // One thread: advance the counters and pre-compute both optimisers' scalars for this step.
@@ -149,13 +149,13 @@ __device__ inline void step_begin_device(StepState* st, int advance_replay) {
     if (advance_replay) st->replay_counter += 1;
     st->noise_counter += 2;
     st->t_actor += 1;
-    st->b1t *= (double)st->b1;
-    st->b2t *= (double)st->b2;
-    fill_adam_const(st->actor, st->b1t, st->b2t, st->lr, st->b1, st->b2, st->eps, 0.f);
+    st->b1t *= st->b1;
+    st->b2t *= st->b2;
+    fill_adam_const(st->actor, st->b1t, st->b2t, st->lr, st->b1, st->b2, st->eps, 0.0);
     if (st->has_critic) {
         st->t_critic += 1;
-        st->b1t_c *= (double)st->b1;
-        st->b2t_c *= (double)st->b2;
+        st->b1t_c *= st->b1;
+        st->b2t_c *= st->b2;
         fill_adam_const(st->critic, st->b1t_c, st->b2t_c, st->lr, st->b1, st->b2, st->eps, st->tau);
     }
 }

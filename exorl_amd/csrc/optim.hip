@@ -107,17 +107,9 @@ int adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr,
     EXORL_REQUIRE(n % 4 == 0, "adam_step: n=%lld must be a multiple of 4 (flat buffers are padded)", (long long)n);
     EXORL_REQUIRE(t >= 1, "adam_step: step count t=%lld must be >= 1", (long long)t);
     // Python-double scalar math of torch's _single_tensor_adam, then cast to fp32 like the tensor ops do
-    const double bc1 = 1.0 - pow((double)b1, (double)t);
-    const double bc2 = 1.0 - pow((double)b2, (double)t);
+    const double b1d = dec7(b1), b2d = dec7(b2);
     AdamConst c;
-    c.one_minus_b1 = (float)(1.0 - (double)b1);
-    c.b2 = b2;
-    c.one_minus_b2 = (float)(1.0 - (double)b2);
-    c.bc2_sqrt = (float)sqrt(bc2);
-    c.eps = eps;
-    c.neg_step_size = (float)(-((double)lr / bc1));
-    c.tau = tau;
-    c.one_minus_tau = (float)(1.0 - (double)tau);
+    fill_adam_const(c, pow(b1d, (double)t), pow(b2d, (double)t), dec7(lr), b1d, b2d, dec7(eps), dec7(tau));
     const int64_t n4 = n / 4;
     int blocks = cdiv(n4, 256);
     if (blocks > 2048) blocks = 2048;
@@ -159,7 +151,7 @@ __global__ __launch_bounds__(256) void soft_update_kernel(const float* __restric
 int soft_update(const float* p, float* target, int64_t n, float tau, hipStream_t s) {
     int blocks = cdiv(n, 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(soft_update_kernel, dim3(blocks), dim3(256), 0, s, p, target, n, tau, (float)(1.0 - (double)tau));
+    hipLaunchKernelGGL(soft_update_kernel, dim3(blocks), dim3(256), 0, s, p, target, n, (float)dec7(tau), (float)(1.0 - dec7(tau)));
     EXORL_LAUNCH_CHECK();
     return 0;
 }
