@@ -162,7 +162,7 @@ def test_shipped_widths_vs_oracle(kind, dims, kw):
         # fall on different sides: that changes one hidden unit's row of dW for one sample (seen: 30 of 7680 elements)
         big = B * H >= 1 << 19
         assert_mostly_close(got.reshape(want.shape), want, 2e-4, 1e-8 + (1e-2 if big else 2e-4) * np.abs(want).max(),
-                            0.1 * np.abs(want).max(), frac=0.35 if big else 1e-2, err_msg=f'grad {ish[i][0]}')
+                            0.1 * np.abs(want).max(), frac=1e-2, err_msg=f'grad {ish[i][0]}')
 
 
 def test_reward_only_and_state_roundtrip():
