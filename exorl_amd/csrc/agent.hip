@@ -93,7 +93,7 @@ struct Fork {
 
 struct FwdBufs { float *h1, *xhat, *rstd, *h2, *out; unsigned short *h1b, *xhatb; };
 struct BwdBufs { float *dz2, *dh1; unsigned short* dz2b; };
-struct NetShadow { float* w0t; unsigned short* w1b; };     // W0 transposed per trunk; W1 as bf16 per head
+struct NetShadow { float* w0t; unsigned short* w1b; unsigned short* w0b; };   // W0 transposed per trunk; W1 as bf16 per head; W0 as K-padded bf16
 struct Partials { float *Ph, *Pt, *Pw; };                  // per-chunk partial gradients (fused.hip)
 
 static ShadowSpec shadow_spec(const NetDesc& d, const NetShadow& sh, const NetShadow* target) {
@@ -101,21 +101,26 @@ static ShadowSpec shadow_spec(const NetDesc& d, const NetShadow& sh, const NetSh
     s.n_trunks = d.n_trunks; s.n_heads = d.n_heads; s.in_dim = d.in_dim; s.H = d.H;
     for (int t = 0; t < d.n_trunks; ++t) s.w0_off[t] = d.W0 + t * d.trunk_stride;
     for (int i = 0; i < d.n_heads; ++i) s.w1_off[i] = d.W1 + i * d.head_stride;
-    s.w0t = sh.w0t; s.w1b = sh.w1b;
+    s.w0t = sh.w0t; s.w1b = sh.w1b; s.w0b = sh.w0b;
     s.t_w0t = target ? target->w0t : nullptr;
     s.t_w1b = target ? target->w1b : nullptr;
+    s.t_w0b = target ? target->w0b : nullptr;
     return s;
 }
 
 static int net_forward(const NetDesc& d, const float* P, const NetShadow& sh, const float* x, int64_t ldx, int rows,
-                       const FwdBufs& f, bool save, bool tanh_out, int prec, hipStream_t s) {
+                       const FwdBufs& f, bool save, bool tanh_out, int prec, hipStream_t s, const SampleSpec* sample = nullptr) {
     const int H = d.H;
     const int64_t act = (int64_t)rows * H;
     const bool bf = prec == EXORL_PREC_BF16;
     // fast mode keeps the trunk activations as bf16 only (MFMA operand + LN backward input): 4 B/elem written instead of 10
-    EXORL_TRY(trunk_fwd(x, ldx, sh.w0t, P + d.b0, P + d.g, P + d.beta, bf ? nullptr : f.h1, (save && !bf) ? f.xhat : nullptr,
-                        save ? f.rstd : nullptr, bf ? f.h1b : nullptr, (bf && save) ? f.xhatb : nullptr, rows, d.in_dim, H,
-                        d.n_trunks, act, d.trunk_stride, (int64_t)d.in_dim * H, s));
+    if (bf && sh.w0b && trunk_fwd16_supported(H))
+        EXORL_TRY(trunk_fwd16(x, ldx, sh.w0b, P + d.b0, P + d.g, P + d.beta, save ? f.rstd : nullptr, f.h1b, save ? f.xhatb : nullptr, rows,
+                              d.in_dim, H, d.n_trunks, act, d.trunk_stride, s));
+    else
+        EXORL_TRY(trunk_fwd(x, ldx, sh.w0t, P + d.b0, P + d.g, P + d.beta, bf ? nullptr : f.h1, (save && !bf) ? f.xhat : nullptr,
+                            save ? f.rstd : nullptr, bf ? f.h1b : nullptr, (bf && save) ? f.xhatb : nullptr, rows, d.in_dim, H,
+                            d.n_trunks, act, d.trunk_stride, (int64_t)d.in_dim * H, s));
     if (bf) {
         Gemm16Problem q[2];
         for (int i = 0; i < d.n_heads; ++i)
@@ -131,7 +136,7 @@ static int net_forward(const NetDesc& d, const float* P, const NetShadow& sh, co
     }
     if (H % 4 == 0)
         EXORL_TRY(head_fwd4(f.h2, P + d.W2, P + d.b2, f.out, rows, H, d.out_dim, tanh_out ? 1 : 0, d.n_heads, act, d.head_stride,
-                            (int64_t)rows * d.out_dim, s));
+                            (int64_t)rows * d.out_dim, s, sample));
     else
         EXORL_TRY(head_fwd(f.h2, P + d.W2, P + d.b2, f.out, rows, H, d.out_dim, tanh_out ? 1 : 0, d.n_heads, act, d.head_stride,
                            (int64_t)rows * d.out_dim, s));
@@ -156,21 +161,42 @@ static int net_backward(const NetDesc& d, const float* P, const NetShadow& sh, f
                            d.n_heads, act, d.head_stride, G ? 1 : 0, s));
     }
     if (bf) {
-        Gemm16Problem q[2];
-        if (G) {
-            for (int i = 0; i < d.n_heads; ++i)      // dW1_i[n][k] = sum_m dz2_i[m][n] h1[m][k]
-                q[i] = Gemm16Problem{b.dz2b + i * act, f.h1b + (paired ? i : 0) * act, G + d.W1 + i * d.head_stride, nullptr,
-                                     H, H, rows, H, H, H};
-            EXORL_TRY(fk.fork(s));                 // wgrad only feeds the optimiser: off the dgrad -> LN-backward chain
-            EXORL_TRY(gemm16_grouped(1, 1, q, d.n_heads, false, false, fk.side(s)));
-        }
-        for (int i = 0; i < d.n_heads; ++i)          // dh1[m][k] = sum_n dz2_i[m][n] W1_i[n][k]
-            q[i] = Gemm16Problem{b.dz2b + i * act, sh.w1b + (int64_t)i * H * H, b.dh1 + (paired ? i : 0) * act, nullptr,
-                                 rows, H, H, H, H, H};
-        if (paired) {
-            EXORL_TRY(gemm16_grouped(0, 1, q, d.n_heads, false, false, s));
+        Gemm16Problem q[4];
+        int at[4];
+        int nq = 0;
+        if (G && !fk.on) {                           // wgrad + dgrad in one launch (independent readers of dz2)
+            for (int i = 0; i < d.n_heads; ++i) {    // dW1_i[n][k] = sum_m dz2_i[m][n] h1[m][k]
+                at[nq] = 1;
+                q[nq++] = Gemm16Problem{b.dz2b + i * act, f.h1b + (paired ? i : 0) * act, G + d.W1 + i * d.head_stride, nullptr,
+                                        H, H, rows, H, H, H};
+            }
+            const int nd = paired ? d.n_heads : 1;   // shared trunk: the heads' dgrads add into one dh1 -> only the first joins
+            for (int i = 0; i < nd; ++i) {           // dh1[m][k] = sum_n dz2_i[m][n] W1_i[n][k]
+                at[nq] = 0;
+                q[nq++] = Gemm16Problem{b.dz2b + i * act, sh.w1b + (int64_t)i * H * H, b.dh1 + (paired ? i : 0) * act, nullptr,
+                                        rows, H, H, H, H, H};
+            }
+            EXORL_TRY(gemm16_grouped_mixed(at, q, nq, s));
+            for (int i = nd; i < d.n_heads; ++i) {
+                Gemm16Problem r{b.dz2b + i * act, sh.w1b + (int64_t)i * H * H, b.dh1, nullptr, rows, H, H, H, H, H};
+                EXORL_TRY(gemm16_grouped(0, 1, &r, 1, false, true, s));
+            }
         } else {
-            for (int i = 0; i < d.n_heads; ++i) EXORL_TRY(gemm16_grouped(0, 1, q + i, 1, false, i > 0, s));
+            if (G) {
+                for (int i = 0; i < d.n_heads; ++i)
+                    q[i] = Gemm16Problem{b.dz2b + i * act, f.h1b + (paired ? i : 0) * act, G + d.W1 + i * d.head_stride, nullptr,
+                                         H, H, rows, H, H, H};
+                EXORL_TRY(fk.fork(s));                 // wgrad only feeds the optimiser: off the dgrad -> LN-backward chain
+                EXORL_TRY(gemm16_grouped(1, 1, q, d.n_heads, false, false, fk.side(s)));
+            }
+            for (int i = 0; i < d.n_heads; ++i)
+                q[i] = Gemm16Problem{b.dz2b + i * act, sh.w1b + (int64_t)i * H * H, b.dh1 + (paired ? i : 0) * act, nullptr,
+                                     rows, H, H, H, H, H};
+            if (paired) {
+                EXORL_TRY(gemm16_grouped(0, 1, q, d.n_heads, false, false, s));
+            } else {
+                for (int i = 0; i < d.n_heads; ++i) EXORL_TRY(gemm16_grouped(0, 1, q + i, 1, false, i > 0, s));
+            }
         }
     } else {
         GemmProblem p[2];
@@ -266,6 +292,7 @@ struct exorl_agent {
     bool capturing = false;
     Fork fk{};                   // parallel-branch plumbing (active while capturing)
     bool parallel_branches = false;  // measured slower than one chain on MI355X (2987 vs 3259 steps/s): opt-in
+    bool staged_by_sampler = false;  // captured step: the sampler's gather kernel writes the staged inputs and runs step_begin
     bool want_metrics = true;    // the (B,1)-sized metric reductions are skipped when the caller never reads them (use_tb=False)
 };
 
@@ -288,7 +315,7 @@ static void carve(exorl_agent* a, Carver& c) {
     a->fa = FwdBufs{c.take(2 * B * H), c.take(2 * B * H), c.take(2 * B), c.take(2 * B * H), c.take(2 * B * AO), bf ? take_u16(2 * B * H) : nullptr,
                     bf ? take_u16(2 * B * H) : nullptr};
     a->ba = BwdBufs{c.take(B * H), c.take(B * H), bf ? take_u16(B * H) : nullptr};
-    a->sh_actor = NetShadow{c.take(O * H), bf ? take_u16(H * H) : nullptr};
+    a->sh_actor = NetShadow{c.take(O * H), bf ? take_u16(H * H) : nullptr, bf ? take_u16(H * round_up(O, 32)) : nullptr};
     a->pa = Partials{c.take((int64_t)head_chunks(B) * ((AO + 1) * H + 32)), c.take((int64_t)trunk_chunks(B) * 3 * H),
                      c.take((int64_t)outer_chunks(B) * O * H)};
     a->dpre = c.take(B * AO);
@@ -318,8 +345,8 @@ static void carve(exorl_agent* a, Carver& c) {
             a->crr_w = c.take(B);
             a->fr = FwdBufs{bf ? nullptr : c.take(nt * R * H), nullptr, nullptr, c.take(2 * R * H), c.take(2 * R), bf ? take_u16(nt * R * H) : nullptr, nullptr};
         }
-        a->sh_critic = NetShadow{c.take(nt * W * H), bf ? take_u16(2 * H * H) : nullptr};
-        a->sh_target = NetShadow{c.take(nt * W * H), bf ? take_u16(2 * H * H) : nullptr};
+        a->sh_critic = NetShadow{c.take(nt * W * H), bf ? take_u16(2 * H * H) : nullptr, bf ? take_u16(nt * H * round_up(W, 32)) : nullptr};
+        a->sh_target = NetShadow{c.take(nt * W * H), bf ? take_u16(2 * H * H) : nullptr, bf ? take_u16(nt * H * round_up(W, 32)) : nullptr};
         a->pc = Partials{c.take(2 * (int64_t)head_chunks(RC) * (2 * H + 16)), c.take(nt * (int64_t)trunk_chunks(RC) * 3 * H),
                          c.take(nt * (int64_t)outer_chunks(RC) * W * H)};
     }
@@ -378,8 +405,9 @@ static int phase0(exorl_agent* a, float stddev, const float* noise_c, hipStream_
     const auto& cfg = a->cfg;
     const int B = cfg.batch, O = cfg.obs_dim, A = cfg.act_dim, W = O + A, prec = cfg.precision;
     // stages the inputs and (thread 0) advances the device-side step state: counters, Adam scalars of this step
-    EXORL_TRY(prepare_inputs(a->obs, a->action, a->next_obs, a->xa, a->xc_cur, a->xc_next, a->xc_pi, B, O, A, a->has_critic, a->state,
-                             a->capturing ? 1 : 0, s));
+    if (!a->staged_by_sampler)
+        EXORL_TRY(prepare_inputs(a->obs, a->action, a->next_obs, a->xa, a->xc_cur, a->xc_next, a->xc_pi, B, O, A, a->has_critic, a->state,
+                                 a->capturing ? 1 : 0, s));
     a->actor_t += 1;
     if (a->has_critic) a->critic_t += 1;
     if (!a->has_critic) return 0;
@@ -387,12 +415,16 @@ static int phase0(exorl_agent* a, float stddev, const float* noise_c, hipStream_
     const float* Pc = a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM];
     const float* Pt = a->flat[EXORL_NET_CRITIC_TARGET][EXORL_T_PARAM];
     // actor on [next_obs; obs] in one pass (td3_bc.py:124 and :149 use the same weights)
-    EXORL_TRY(net_forward(a->actor, Pa, a->sh_actor, a->xa, O, 2 * B, a->fa, true, true, prec, s));
     // next_action = dist.sample(clip) (td3_bc.py:125) and the actor-step sample pi(obs) (:151, it does not depend on the
-    // critic update) straight into the two critic input buffers
+    // critic update) straight into the two critic input buffers, as the epilogue of the actor head
     a->noise_c = noise_c;
-    EXORL_TRY(sample_actions2(a->fa.out, noise_c, cfg.kind == EXORL_AGENT_CRR ? nullptr : a->noise_a, cfg.seed,
-                              &a->state->noise_counter, stddev, cfg.stddev_clip, a->xc_next + O, a->xc_pi + O, W, B, A, s));
+    const bool fused_sample = cfg.hidden_dim % 4 == 0 && A > 1;
+    SampleSpec sp{noise_c, cfg.kind == EXORL_AGENT_CRR ? nullptr : a->noise_a, cfg.seed, &a->state->noise_counter, stddev, cfg.stddev_clip,
+                  a->xc_next + O, a->xc_pi + O, W, B};
+    EXORL_TRY(net_forward(a->actor, Pa, a->sh_actor, a->xa, O, 2 * B, a->fa, true, true, prec, s, fused_sample ? &sp : nullptr));
+    if (!fused_sample)
+        EXORL_TRY(sample_actions2(a->fa.out, noise_c, cfg.kind == EXORL_AGENT_CRR ? nullptr : a->noise_a, cfg.seed,
+                                  &a->state->noise_counter, stddev, cfg.stddev_clip, a->xc_next + O, a->xc_pi + O, W, B, A, s));
     EXORL_TRY(a->fk.fork(s));                   // target critic (td3_bc.py:126) and critic (td3_bc.py:130) forwards are independent
     EXORL_TRY(net_forward(a->critic, Pt, a->sh_target, a->xc_next, W, B, a->ft, false, false, prec, a->fk.side(s)));
     EXORL_TRY(net_forward(a->critic, Pc, a->sh_critic, a->xc_cur, W, B, a->fc, true, false, prec, s));
@@ -466,7 +498,7 @@ static int phase2(exorl_agent* a, float stddev, hipStream_t s) {
 static int phase3(exorl_agent* a, hipStream_t s) {
     return adam_step_dev(a->flat[EXORL_NET_ACTOR][EXORL_T_PARAM], a->flat[EXORL_NET_ACTOR][EXORL_T_GRAD],
                          a->flat[EXORL_NET_ACTOR][EXORL_T_ADAM_M], a->flat[EXORL_NET_ACTOR][EXORL_T_ADAM_V], a->actor.total,
-                         &a->state->actor, nullptr, &a->spec_actor, s);
+                         &a->state->actor, nullptr, &a->spec_actor, s, a->staged_by_sampler ? &a->state->replay_counter : nullptr);
 }
 
 // ---- CQL (cql.py:152-263) ---------------------------------------------------------------------------
@@ -484,8 +516,9 @@ static int cql_phase0(exorl_agent* a, hipStream_t s) {
     const auto& cfg = a->cfg;
     const int B = cfg.batch, O = cfg.obs_dim, A = cfg.act_dim, W = O + A, n = cfg.n_samples, prec = cfg.precision;
     const int R = (3 * n + 1) * B;
-    EXORL_TRY(prepare_inputs(a->obs, a->action, a->next_obs, a->xa, a->xc_cur, a->xc_next, a->xc_pi, B, O, A, 1, a->state,
-                             a->capturing ? 1 : 0, s));
+    if (!a->staged_by_sampler)
+        EXORL_TRY(prepare_inputs(a->obs, a->action, a->next_obs, a->xa, a->xc_cur, a->xc_next, a->xc_pi, B, O, A, 1, a->state,
+                                 a->capturing ? 1 : 0, s));
     a->actor_t += 1;
     a->critic_t += 1;
     const float* Pa = a->flat[EXORL_NET_ACTOR][EXORL_T_PARAM];
@@ -776,9 +809,14 @@ int exorl_agent_enable_graph(exorl_agent_t* a, exorl_replay_t* r, int32_t nstep,
     EXORL_CHECK_HIP(hipStreamBeginCapture(a->capture_stream, hipStreamCaptureModeThreadLocal));
     a->capturing = true;
     a->fk.on = a->parallel_branches;
+    // fp32 state observations: the gather kernel writes the networks' staged inputs itself and runs step_begin (one kernel
+    // boundary less per step); the replay counter is then advanced by the step's last kernel (the actor's optimiser pass)
+    StageOut stage{a->xa, a->xc_cur, a->xc_next, a->xc_pi, a->cfg.obs_dim, a->cfg.act_dim, a->cfg.batch, a->has_critic ? 1 : 0, a->state};
+    a->staged_by_sampler = replay_obs_bytes(r) == a->cfg.obs_dim * 4;
     int rc = replay_sample_impl(r, a->cfg.batch, nstep, gamma, EXORL_SAMPLER_PHILOX, nullptr, &slots, nullptr, a->capture_stream,
-                                &a->state->replay_counter);
+                                &a->state->replay_counter, a->staged_by_sampler ? &stage : nullptr);
     for (int p = 0; p < 4 && rc == 0; ++p) rc = exorl_agent_update_phase(a, p, stddev, nullptr, nullptr, a->capture_stream);
+    a->staged_by_sampler = false;
     a->capturing = false;
     a->fk.on = false;
     hipGraph_t g = nullptr;

@@ -160,6 +160,124 @@ __global__ __launch_bounds__(512) void trunk_fwd_kernel(const float* __restrict_
     if (rstd && lane == 0) rstd[net * (int64_t)rows + row] = rs;
 }
 
+// ------------------------------------------------------------------------------------------------
+// trunk forward on the matrix cores (bf16 fast mode): z^T = W0 x^T as v_mfma_f32_16x16x32_bf16 tiles, then LayerNorm + tanh
+// in registers. The wave-per-row kernel above re-stages the whole first-layer weight (120 KB) through LDS for every 8 rows and
+// spends its time waiting on that; here a workgroup owns 16 rows, each of its 8 waves a 1/8 slab of the H columns, and the
+// weight fragments go L2 -> registers directly (16 B per lane per tile, from a bf16 shadow W0b[H][Kp] kept by the optimiser).
+//   A (16x32) = W0b rows: lane l holds W0b[col0 + (l&15)][8(l>>4) .. +7]        B (32x16) = x^T: lane l holds x[row0 + (l&15)][8(l>>4) .. +7]
+//   C lane l, reg i = z[row0 + (l&15)][col0 + 4(l>>4) + i]  ->  4 consecutive columns of one row per lane (8-byte bf16 stores)
+// LayerNorm statistics: lane-local over its T*4 columns, 2 shuffles across the 4 lanes of a row, 8 wave partials through LDS.
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4_t;
+
+template <int T>     // T = H / 128 column tiles per wave
+__global__ __launch_bounds__(512) void trunk_fwd16_kernel(const float* __restrict__ x, int64_t ldx, const unsigned short* __restrict__ W0b,
+                                                          const float* __restrict__ b0, const float* __restrict__ gain,
+                                                          const float* __restrict__ beta, float* __restrict__ rstd,
+                                                          unsigned short* __restrict__ hb, unsigned short* __restrict__ xhb, int rows,
+                                                          int in_dim, int Kp, int64_t astride, int64_t pstride, int64_t wstride) {
+    constexpr int H = T * 128;
+    __shared__ float red[2][8][16];
+    const int net = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rn = lane & 15, kq = lane >> 4;                 // batch row within the tile / k-group (and column quad of C)
+    const int row = blockIdx.x * 16 + rn;
+    const bool live = row < rows;
+    const unsigned short* Wb = W0b + net * wstride;
+    const int col0 = wave * (H / 8);
+    f32x4_t acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < Kp; k0 += 32) {
+        bf16x8_t bx;
+        const int kb = k0 + 8 * kq;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bx[j] = (__bf16)((live && kb + j < in_dim) ? x[(int64_t)row * ldx + kb + j] : 0.f);
+        bf16x8_t aw[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+            aw[t] = *reinterpret_cast<const bf16x8_t*>(Wb + (int64_t)(col0 + t * 16 + rn) * Kp + kb);
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[t], bx, acc[t], 0, 0, 0);
+    }
+    // + bias; row statistics
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const float4 b = *reinterpret_cast<const float4*>(b0 + net * pstride + col0 + t * 16 + 4 * kq);
+        acc[t][0] += b.x; acc[t][1] += b.y; acc[t][2] += b.z; acc[t][3] += b.w;
+        s += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
+    }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (kq == 0) red[0][wave][rn] = s;
+    __syncthreads();
+    float mean = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) mean += red[0][w][rn];
+    mean *= 1.0f / (float)H;
+    float s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc[t][i] -= mean; s2 += acc[t][i] * acc[t][i]; }
+    }
+    s2 += __shfl_xor(s2, 16, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (kq == 0) red[1][wave][rn] = s2;
+    __syncthreads();
+    float var = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) var += red[1][w][rn];
+    const float rs = 1.0f / sqrtf(var * (1.0f / (float)H) + LN_EPS2);
+    if (!live) return;
+    const int64_t o = net * astride + (int64_t)row * H;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int c = col0 + t * 16 + 4 * kq;
+        const float4 g = *reinterpret_cast<const float4*>(gain + net * pstride + c);
+        const float4 be = *reinterpret_cast<const float4*>(beta + net * pstride + c);
+        const float xh[4] = {acc[t][0] * rs, acc[t][1] * rs, acc[t][2] * rs, acc[t][3] * rs};
+        ushort4 q;
+        q.x = f2bf(tanh_fast(xh[0] * g.x + be.x)); q.y = f2bf(tanh_fast(xh[1] * g.y + be.y));
+        q.z = f2bf(tanh_fast(xh[2] * g.z + be.z)); q.w = f2bf(tanh_fast(xh[3] * g.w + be.w));
+        *reinterpret_cast<ushort4*>(hb + o + c) = q;
+        if (xhb) {
+            ushort4 u;
+            u.x = f2bf(xh[0]); u.y = f2bf(xh[1]); u.z = f2bf(xh[2]); u.w = f2bf(xh[3]);
+            *reinterpret_cast<ushort4*>(xhb + o + c) = u;
+        }
+    }
+    if (rstd && wave == 0 && kq == 0) rstd[net * (int64_t)rows + row] = rs;
+}
+
+bool trunk_fwd16_supported(int H) { return H >= 128 && H <= 1024 && H % 128 == 0; }
+
+int trunk_fwd16(const float* x, int64_t ldx, const unsigned short* W0b, const float* b0, const float* gain, const float* beta, float* rstd,
+                unsigned short* h_bf16, unsigned short* xhat_bf16, int rows, int in_dim, int H, int nets, int64_t astride, int64_t pstride,
+                hipStream_t s) {
+    EXORL_REQUIRE(trunk_fwd16_supported(H) && in_dim >= 1 && in_dim <= MAX_IN && h_bf16, "trunk_fwd16: unsupported H=%d in=%d", H, in_dim);
+    const int Kp = (int)round_up(in_dim, 32);
+    const dim3 grid(cdiv(rows, 16), nets);
+    const int64_t wstride = (int64_t)H * Kp;
+#define EXORL_TF16(T) hipLaunchKernelGGL((trunk_fwd16_kernel<T>), grid, dim3(512), 0, s, x, ldx, W0b, b0, gain, beta, rstd, h_bf16, xhat_bf16, \
+                                         rows, in_dim, Kp, astride, pstride, wstride)
+    switch (H / 128) {
+        case 1: EXORL_TF16(1); break;
+        case 2: EXORL_TF16(2); break;
+        case 3: EXORL_TF16(3); break;
+        case 4: EXORL_TF16(4); break;
+        case 5: EXORL_TF16(5); break;
+        case 6: EXORL_TF16(6); break;
+        case 7: EXORL_TF16(7); break;
+        default: EXORL_TF16(8); break;
+    }
+#undef EXORL_TF16
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
 int trunk_fwd(const float* x, int64_t ldx, const float* W0T, const float* b0, const float* gain, const float* beta,
               float* h, float* xhat, float* rstd, unsigned short* h_bf16, unsigned short* xhat_bf16, int rows, int in_dim,
               int H, int nets, int64_t astride, int64_t pstride, int64_t tstride, hipStream_t s) {
@@ -373,11 +491,19 @@ __device__ __forceinline__ float wave_sum8(const float (&v)[8], int lane) {
 
 // ------------------------------------------------------------------------------------------------
 // head forward v2: out[m][j] = b[j] + sum_c a[m][c] W[j][c]; one wave per row, float4 streams (H % 4 == 0)
+__device__ __forceinline__ float philox_normal_f(uint64_t seed, uint64_t counter, uint32_t elem) {
+    uint32_t c[4] = {elem, 0u, (uint32_t)counter, (uint32_t)(counter >> 32)};
+    Philox::gen(c, seed);
+    const float u1 = ((float)c[0] + 1.0f) * 2.3283064365386963e-10f;
+    const float u2 = (float)c[1] * 2.3283064365386963e-10f;
+    return sqrtf(-2.0f * __logf(u1)) * __cosf(6.283185307179586f * u2);
+}
+
 template <int NO>
 __global__ __launch_bounds__(256) void head_fwd4_kernel(const float* __restrict__ a, const float* __restrict__ W,
                                                         const float* __restrict__ b, float* __restrict__ out, int rows,
                                                         int H, int nout, int tanh_out, int64_t astride, int64_t pstride,
-                                                        int64_t ostride) {
+                                                        int64_t ostride, SampleSpec sp) {
     const int net = blockIdx.y;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -420,19 +546,29 @@ __global__ __launch_bounds__(256) void head_fwd4_kernel(const float* __restrict_
                 v += b ? b[net * pstride + j] : 0.f;
                 if (tanh_out) v = tanhf(v);
                 out[net * ostride + (int64_t)row * nout + j] = v;
+                if (sp.dst_next) {                   // TruncatedNormal(mu, std).sample(clip) (utils.py:139-149)
+                    const int half = row >= sp.B, m = half ? row - sp.B : row, e = m * nout + j;
+                    const float* nb = half ? sp.noise_a : sp.noise_c;
+                    const float z = nb ? nb[e] : philox_normal_f(sp.seed, (uint64_t)half + (sp.counter_ptr ? *sp.counter_ptr : 0ull), (uint32_t)e);
+                    const float eps = fminf(fmaxf(z * sp.stddev, -sp.clip), sp.clip);
+                    const float x = fminf(fmaxf(v + eps, -1.0f + 1e-6f), 1.0f - 1e-6f);
+                    (half ? sp.dst_pi : sp.dst_next)[(int64_t)m * sp.dst_ld + j] = x;
+                }
             }
         }
     }
 }
 
 int head_fwd4(const float* a, const float* W, const float* b, float* out, int rows, int H, int nout, int tanh_out,
-              int nets, int64_t astride, int64_t pstride, int64_t ostride, hipStream_t s) {
+              int nets, int64_t astride, int64_t pstride, int64_t ostride, hipStream_t s, const SampleSpec* sample) {
     EXORL_REQUIRE(nout >= 1 && nout <= 32 && H % 4 == 0 && H <= 1024, "head_fwd4: nout=%d H=%d unsupported", nout, H);
+    EXORL_REQUIRE(!sample || (nout > 1 && nets == 1 && tanh_out && rows == 2 * sample->B), "head_fwd4: sampling epilogue needs the stacked actor head");
+    const SampleSpec sp = sample ? *sample : SampleSpec{};
     dim3 grid(cdiv(rows, 4), nets);
-    if (nout == 1) hipLaunchKernelGGL((head_fwd4_kernel<1>), grid, dim3(256), 0, s, a, W, b, out, rows, H, nout, tanh_out, astride, pstride, ostride);
-    else if (nout <= 8) hipLaunchKernelGGL((head_fwd4_kernel<8>), grid, dim3(256), 0, s, a, W, b, out, rows, H, nout, tanh_out, astride, pstride, ostride);
-    else if (nout <= 16) hipLaunchKernelGGL((head_fwd4_kernel<16>), grid, dim3(256), 0, s, a, W, b, out, rows, H, nout, tanh_out, astride, pstride, ostride);
-    else hipLaunchKernelGGL((head_fwd4_kernel<32>), grid, dim3(256), 0, s, a, W, b, out, rows, H, nout, tanh_out, astride, pstride, ostride);
+    if (nout == 1) hipLaunchKernelGGL((head_fwd4_kernel<1>), grid, dim3(256), 0, s, a, W, b, out, rows, H, nout, tanh_out, astride, pstride, ostride, sp);
+    else if (nout <= 8) hipLaunchKernelGGL((head_fwd4_kernel<8>), grid, dim3(256), 0, s, a, W, b, out, rows, H, nout, tanh_out, astride, pstride, ostride, sp);
+    else if (nout <= 16) hipLaunchKernelGGL((head_fwd4_kernel<16>), grid, dim3(256), 0, s, a, W, b, out, rows, H, nout, tanh_out, astride, pstride, ostride, sp);
+    else hipLaunchKernelGGL((head_fwd4_kernel<32>), grid, dim3(256), 0, s, a, W, b, out, rows, H, nout, tanh_out, astride, pstride, ostride, sp);
     EXORL_LAUNCH_CHECK();
     return 0;
 }
@@ -443,14 +579,6 @@ int head_fwd4(const float* a, const float* W, const float* b, float* out, int ro
 // Thread = 4 consecutive columns (float4 streams), 8 rows per workgroup.
 // P layout per (net, chunk): [dW nout*H][db_hidden H][db_out 16]
 constexpr int HB_ROWS = 8;
-__device__ __forceinline__ float philox_normal_f(uint64_t seed, uint64_t counter, uint32_t elem) {
-    uint32_t c[4] = {elem, 0u, (uint32_t)counter, (uint32_t)(counter >> 32)};
-    Philox::gen(c, seed);
-    const float u1 = ((float)c[0] + 1.0f) * 2.3283064365386963e-10f;
-    const float u2 = (float)c[1] * 2.3283064365386963e-10f;
-    return sqrtf(-2.0f * __logf(u1)) * __cosf(6.283185307179586f * u2);
-}
-
 // d(loss)/d(head output) for row m, output j of net `net` (see DoutSpec)
 __device__ __forceinline__ float dout_value(const DoutSpec& d, int net, int m, int j, int rows, int nout) {
     if (d.mode == EXORL_DOUT_BUFFER) return d.buf[((int64_t)net * rows + m) * nout + j];

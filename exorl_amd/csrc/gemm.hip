@@ -261,6 +261,7 @@ struct Gemm16Batch {
     int relu;
     int accumulate;
     int swizzle;      // 1: XCD-aware tile order (blocks that share an XCD take neighbouring tiles)
+    int a_t[4];       // mixed-layout launch (gemm16g_mixed_kernel): problem i reads A as a k image (layout 1)
 };
 static int g_gemm16_variant = -1;    // experiment switch (exorl_gemm_tune): -1 = default heuristics
 
@@ -399,11 +400,13 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const Gemm16Batch gb) {
 typedef short v4s16 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 
+constexpr int G16G_NSTG = 4;
+constexpr int G16G_IMG = 64 * ROWB;                // 8 KB per operand image
+
 template <bool AT, bool BT>
-__global__ __launch_bounds__(256) void gemm16g_kernel(const Gemm16Batch gb) {
-    constexpr int NSTG = 4;
-    constexpr int IMG = 64 * ROWB;                 // 8 KB per operand image
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NSTG * 2 * IMG];
+__device__ __forceinline__ void gemm16g_body(const Gemm16Batch& gb, unsigned char* smem) {
+    constexpr int NSTG = G16G_NSTG;
+    constexpr int IMG = G16G_IMG;
 
     const Gemm16Problem& P = gb.p[blockIdx.z];
     const int M = P.M, N = P.N, K = P.K;
@@ -533,6 +536,21 @@ __global__ __launch_bounds__(256) void gemm16g_kernel(const Gemm16Batch gb) {
     }
 }
 
+template <bool AT, bool BT>
+__global__ __launch_bounds__(256) void gemm16g_kernel(const Gemm16Batch gb) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G16G_NSTG * 2 * G16G_IMG];
+    gemm16g_body<AT, BT>(gb, smem);
+}
+
+// One launch for the wgrad and dgrad GEMMs of a Linear(H,H) backward: both read dZ (wgrad as a k image, dgrad as a row image)
+// and are independent, so 2 x 512 tiles fill the 256 CUs four deep instead of two launches two deep, and one kernel boundary
+// (~4.5 us of drain + cache write-back + ramp on this part) disappears. B is a k image in both.
+__global__ __launch_bounds__(256) void gemm16g_mixed_kernel(const Gemm16Batch gb) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G16G_NSTG * 2 * G16G_IMG];
+    if (gb.a_t[blockIdx.z]) gemm16g_body<true, true>(gb, smem);
+    else gemm16g_body<false, true>(gb, smem);
+}
+
 template <int AL, int BL>
 static int launch16(const Gemm16Batch& gb, int count, int tiles64, int tiles128, hipStream_t s) {
     const bool prof = g_prof.on && g_prof.used < PROF_MAX_LAUNCHES;
@@ -581,6 +599,51 @@ static int launch16(const Gemm16Batch& gb, int count, int tiles64, int tiles128,
         if (big) EXORL_G16(128, 2, true); else EXORL_G16(64, 2, true);
     }
 #undef EXORL_G16
+    EXORL_LAUNCH_CHECK();
+    if (prof) {
+        EXORL_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s));
+        g_prof.used += 1;
+    }
+    return 0;
+}
+
+// probs[i] with a_layouts[i] in {0,1}, b_layout 1 for all, no bias/relu/accumulate. Falls back to one launch per layout when a
+// problem does not meet the LDS-DMA kernel's tiling rules.
+int gemm16_grouped_mixed(const int* a_layouts, const Gemm16Problem* probs, int count, hipStream_t s) {
+    EXORL_REQUIRE(count >= 1 && count <= 4, "gemm16_grouped_mixed: count %d out of range", count);
+    Gemm16Batch gb;
+    memset(&gb, 0, sizeof(gb));
+    bool ok = g_gemm16_variant < 0 || !(g_gemm16_variant & 128);
+    int t64 = 0;
+    double flops = 0;
+    for (int i = 0; i < count; ++i) {
+        const Gemm16Problem& p = probs[i];
+        gb.p[i] = p;
+        gb.a_t[i] = a_layouts[i] != 0;
+        ok = ok && p.M > 0 && p.M % 64 == 0 && p.N % 64 == 0 && p.K % 256 == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && !p.bias &&
+             reinterpret_cast<uintptr_t>(p.A) % 16 == 0 && reinterpret_cast<uintptr_t>(p.B) % 16 == 0;
+        const int a64 = cdiv(p.M, 64) * cdiv(p.N, 64);
+        t64 = a64 > t64 ? a64 : t64;
+        flops += 2.0 * p.M * (double)p.N * p.K;
+    }
+    if (!ok) {
+        for (int i = 0; i < count; ++i) EXORL_TRY(gemm16_grouped(a_layouts[i], 1, probs + i, 1, false, false, s));
+        return 0;
+    }
+    gb.swizzle = (g_gemm16_variant >= 0 && (g_gemm16_variant & 8)) ? 0 : 1;
+    const bool prof = g_prof.on && g_prof.used < PROF_MAX_LAUNCHES;
+    if (prof) {
+        if (g_prof.ev.size() < 2 * (g_prof.used + 1)) {
+            hipEvent_t a, b;
+            EXORL_CHECK_HIP(hipEventCreate(&a));
+            EXORL_CHECK_HIP(hipEventCreate(&b));
+            g_prof.ev.push_back(a);
+            g_prof.ev.push_back(b);
+        }
+        g_prof.flops.push_back(flops);
+        EXORL_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.used], s));
+    }
+    hipLaunchKernelGGL(gemm16g_mixed_kernel, dim3(t64, 1, count), dim3(256), 0, s, gb);
     EXORL_LAUNCH_CHECK();
     if (prof) {
         EXORL_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s));

@@ -25,6 +25,8 @@ struct Gemm16Problem {
 };
 // operands stored as bf16 in memory (fast mode); same layout conventions as gemm_grouped
 int gemm16_grouped(int a_layout, int b_layout, const Gemm16Problem* probs, int count, bool relu, bool accumulate, hipStream_t s);
+// wgrad (a_layout 1) and dgrad (a_layout 0) problems of one backward pass in a single launch; b_layout 1, plain store
+int gemm16_grouped_mixed(const int* a_layouts, const Gemm16Problem* probs, int count, hipStream_t s);
 
 // ---- row-wise / column-wise layer kernels (rowops.hip). `nets` independent nets are processed by one
 // launch (blockIdx.y); a* strides are in floats between nets for activations, p* for parameters.
@@ -46,6 +48,11 @@ int head_bwd_params(const float* dout, const float* a, const float* dz, float* d
 int trunk_fwd(const float* x, int64_t ldx, const float* W0T, const float* b0, const float* gain, const float* beta,
               float* h, float* xhat, float* rstd, unsigned short* h_bf16, unsigned short* xhat_bf16, int rows, int in_dim,
               int H, int nets, int64_t astride, int64_t pstride, int64_t tstride, hipStream_t s);
+// MFMA variant for the bf16 fast mode (H % 128 == 0): W0b = bf16 shadow [nets][H][round_up(in_dim, 32)], zero padded
+bool trunk_fwd16_supported(int H);
+int trunk_fwd16(const float* x, int64_t ldx, const unsigned short* W0b, const float* b0, const float* gain, const float* beta, float* rstd,
+                unsigned short* h_bf16, unsigned short* xhat_bf16, int rows, int in_dim, int H, int nets, int64_t astride, int64_t pstride,
+                hipStream_t s);
 int ln_bwd(float* dh, const float* h, const float* xhat, const unsigned short* h_bf16, const unsigned short* xhat_bf16,
            const float* rstd, const float* gain, float* P, int rows, int H, int nets, int64_t astride, int64_t pstride,
            int want_params, hipStream_t s);
@@ -53,8 +60,20 @@ int trunk_chunks(int rows);
 int outer_reduce(const float* u, int64_t ldu, int J, const float* v, float* P, int rows, int H, int nets, int64_t vstride,
                  hipStream_t s);
 int outer_chunks(int rows);
+// Optional epilogue of the actor head on the stacked [next_obs; obs] batch: the two TruncatedNormal draws of a DDPG-family
+// step (rows < B -> next_action into dst_next, rows >= B -> pi(obs) sample into dst_pi), td3_bc.py:125,151 — saves the
+// separate sampling kernel. noise_* null -> Philox(seed, *counter_ptr + half).
+struct SampleSpec {
+    const float *noise_c, *noise_a;
+    uint64_t seed;
+    const uint64_t* counter_ptr;
+    float stddev, clip;
+    float *dst_next, *dst_pi;
+    int64_t dst_ld;
+    int B;
+};
 int head_fwd4(const float* a, const float* W, const float* b, float* out, int rows, int H, int nout, int tanh_out,
-              int nets, int64_t astride, int64_t pstride, int64_t ostride, hipStream_t s);
+              int nets, int64_t astride, int64_t pstride, int64_t ostride, hipStream_t s, const SampleSpec* sample = nullptr);
 // Where head_bwd takes d(loss)/d(head output) from: a buffer, or computed on the fly from the loss definition so that
 // the (B,1)/(B,A)-sized loss kernels need not sit between the forward and the backward pass.
 #define EXORL_DOUT_BUFFER   0
@@ -98,8 +117,10 @@ struct ShadowSpec {
     int64_t w0_off[2], w1_off[2];      // flat offsets of W0 (per trunk) and W1 (per head)
     float* w0t;                        // [n_trunks][in][H]
     unsigned short* w1b;               // [n_heads][H][H] bf16, or nullptr
+    unsigned short* w0b;               // [n_trunks][H][round_up(in, 32)] bf16 (zero padded), or nullptr
     float* t_w0t;                      // same for the Polyak target (nullptr if none)
     unsigned short* t_w1b;
+    unsigned short* t_w0b;
 };
 int refresh_shadows(const float* p, int64_t n, const ShadowSpec& sh, bool target, hipStream_t s);
 
@@ -214,13 +235,23 @@ int adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr,
               int64_t t, float* target, float tau, hipStream_t s);
 int soft_update(const float* p, float* target, int64_t n, float tau, hipStream_t s);
 // Adam with the scalars read from device memory (StepState), for graph-replayable steps.
+// bump != nullptr: block 0 also increments *bump (the replay counter of a captured step: nothing later in the step reads it)
 int adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const AdamConst* c_dev, float* target,
-                  const ShadowSpec* shadows, hipStream_t s);
+                  const ShadowSpec* shadows, hipStream_t s, uint64_t* bump = nullptr);
 
 // ---- replay (replay.hip) internal entry points used by the agent's graph capture
+// Optional fan-out of the sampled rows into the agent's staged network inputs (what prepare_inputs would do in a second
+// kernel): xa = [next_obs ; obs], xc_cur = [obs | action], xc_next[:, :O] = next_obs, xc_pi[:, :O] = obs. fp32 state
+// observations only. st != nullptr: thread 0 also runs step_begin_device(st, 0).
+struct StageOut {
+    float *xa, *xc_cur, *xc_next, *xc_pi;
+    int O, A, B, has_critic;
+    StepState* st;
+};
 int replay_sample_impl(exorl_replay* r, int32_t batch, int32_t nstep, float gamma, int32_t sampler,
                        const int32_t* pairs_host, const exorl_batch_out* out, int32_t* pairs_out_host, hipStream_t s,
-                       const uint64_t* dev_counter);
+                       const uint64_t* dev_counter, const StageOut* stage = nullptr);
+int replay_obs_bytes(exorl_replay* r);
 uint64_t replay_philox_counter(exorl_replay* r);
 void replay_advance_philox(exorl_replay* r, uint64_t n);
 

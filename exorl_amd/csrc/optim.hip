@@ -32,7 +32,7 @@ __device__ __forceinline__ unsigned short to_bf16(float x) {
 
 // Writes the derived copies (ShadowSpec) of the 4 parameters at flat index 4*i4.
 __device__ __forceinline__ void write_shadows(int64_t i4, const float4& pv, const ShadowSpec& sh, float* w0t,
-                                              unsigned short* w1b) {
+                                              unsigned short* w1b, unsigned short* w0b) {
     const int64_t idx = 4 * i4;
     const int64_t hh = (int64_t)sh.H * sh.H, w0n = (int64_t)sh.H * sh.in_dim;
     for (int t = 0; t < sh.n_heads; ++t) {
@@ -49,7 +49,13 @@ __device__ __forceinline__ void write_shadows(int64_t i4, const float4& pv, cons
             const float e[4] = {pv.x, pv.y, pv.z, pv.w};
             for (int q = 0; q < 4; ++q) {
                 const int64_t l = idx + q - sh.w0_off[t];
-                if (l >= 0 && l < w0n) w0t[t * w0n + (l % sh.in_dim) * sh.H + l / sh.in_dim] = e[q];
+                if (l >= 0 && l < w0n) {
+                    w0t[t * w0n + (l % sh.in_dim) * sh.H + l / sh.in_dim] = e[q];
+                    if (w0b) {
+                        const int64_t Kp = (sh.in_dim + 31) / 32 * 32;
+                        w0b[t * (int64_t)sh.H * Kp + (l / sh.in_dim) * Kp + l % sh.in_dim] = to_bf16(e[q]);
+                    }
+                }
             }
             return;
         }
@@ -59,7 +65,8 @@ __device__ __forceinline__ void write_shadows(int64_t i4, const float4& pv, cons
 __global__ __launch_bounds__(256) void refresh_shadows_kernel(const float* __restrict__ p, int64_t n4, ShadowSpec sh,
                                                               int target) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
-        write_shadows(i, reinterpret_cast<const float4*>(p)[i], sh, target ? sh.t_w0t : sh.w0t, target ? sh.t_w1b : sh.w1b);
+        write_shadows(i, reinterpret_cast<const float4*>(p)[i], sh, target ? sh.t_w0t : sh.w0t, target ? sh.t_w1b : sh.w1b,
+                      target ? sh.t_w0b : sh.w0b);
 }
 
 int refresh_shadows(const float* p, int64_t n, const ShadowSpec& sh, bool target, hipStream_t s) {
@@ -75,8 +82,10 @@ template <bool DEV>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    float* __restrict__ target, int64_t n4, AdamConst cv,
-                                                   const AdamConst* __restrict__ cp, ShadowSpec sh, int has_shadows) {
+                                                   const AdamConst* __restrict__ cp, ShadowSpec sh, int has_shadows,
+                                                   unsigned long long* bump) {
     const AdamConst c = DEV ? *cp : cv;
+    if (bump && blockIdx.x == 0 && threadIdx.x == 0) *bump += 1ull;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         float4 pv = reinterpret_cast<float4*>(p)[i];
         const float4 gv = reinterpret_cast<const float4*>(g)[i];
@@ -96,9 +105,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
             tv.z = polyak(pv.z, tv.z, c.tau, c.one_minus_tau);
             tv.w = polyak(pv.w, tv.w, c.tau, c.one_minus_tau);
             reinterpret_cast<float4*>(target)[i] = tv;
-            if (has_shadows) write_shadows(i, tv, sh, sh.t_w0t, sh.t_w1b);
+            if (has_shadows) write_shadows(i, tv, sh, sh.t_w0t, sh.t_w1b, sh.t_w0b);
         }
-        if (has_shadows) write_shadows(i, pv, sh, sh.w0t, sh.w1b);
+        if (has_shadows) write_shadows(i, pv, sh, sh.w0t, sh.w1b, sh.w0b);
     }
 }
 
@@ -114,20 +123,20 @@ int adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr,
     int blocks = cdiv(n4, 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL((adam_kernel<false>), dim3(blocks), dim3(256), 0, s, p, g, m, v, target, n4, c, (const AdamConst*)nullptr,
-                       ShadowSpec{}, 0);
+                       ShadowSpec{}, 0, (unsigned long long*)nullptr);
     EXORL_LAUNCH_CHECK();
     return 0;
 }
 
 int adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const AdamConst* c_dev, float* target,
-                  const ShadowSpec* shadows, hipStream_t s) {
+                  const ShadowSpec* shadows, hipStream_t s, uint64_t* bump) {
     EXORL_REQUIRE(n % 4 == 0, "adam_step_dev: n must be a multiple of 4");
     const int64_t n4 = n / 4;
     int blocks = cdiv(n4, 256);
     if (blocks > 2048) blocks = 2048;
     AdamConst dummy{};
     hipLaunchKernelGGL((adam_kernel<true>), dim3(blocks), dim3(256), 0, s, p, g, m, v, target, n4, dummy, c_dev,
-                       shadows ? *shadows : ShadowSpec{}, shadows ? 1 : 0);
+                       shadows ? *shadows : ShadowSpec{}, shadows ? 1 : 0, reinterpret_cast<unsigned long long*>(bump));
     EXORL_LAUNCH_CHECK();
     return 0;
 }

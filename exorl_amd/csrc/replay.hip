@@ -140,8 +140,9 @@ __global__ __launch_bounds__(256) void gather_nstep_kernel(ReplayView v, const i
                                                            int32_t* pairs_out, exorl_batch_out out,
                                                            int batch, int nstep, float gamma, int sampler,
                                                            uint64_t seed, uint64_t counter_val,
-                                                           const uint64_t* counter_ptr, int vec16) {
+                                                           const uint64_t* counter_ptr, int vec16, StageOut stage) {
 #pragma clang fp contract(off)
+    if (stage.st && blockIdx.x == 0 && threadIdx.x == 0) step_begin_device(stage.st, 0);   // noise counter, Adam scalars of this step
     const uint64_t counter = counter_ptr ? *counter_ptr : counter_val;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -167,6 +168,23 @@ __global__ __launch_bounds__(256) void gather_nstep_kernel(ReplayView v, const i
     if (out.meta)
         for (int j = lane; j < v.meta_dim; j += 64)
             out.meta[(int64_t)b * out.meta_stride + j] = v.meta[(row - 1) * v.meta_dim + j];
+    if (stage.xa) {                                  // the agent's staged network inputs, straight from the arena rows
+        const int O = stage.O, A = stage.A, W = O + A;
+        const float* so = reinterpret_cast<const float*>(v.obs + (row - 1) * v.obs_bytes);
+        const float* sn = reinterpret_cast<const float*>(v.obs + (row + nstep - 1) * v.obs_bytes);
+        for (int j = lane; j < O; j += 64) {
+            const float o = so[j], no = sn[j];
+            stage.xa[(int64_t)b * O + j] = no;
+            stage.xa[(int64_t)(stage.B + b) * O + j] = o;
+            if (stage.has_critic) {
+                stage.xc_cur[(int64_t)b * W + j] = o;
+                stage.xc_next[(int64_t)b * W + j] = no;
+                stage.xc_pi[(int64_t)b * W + j] = o;
+            }
+        }
+        if (stage.has_critic)
+            for (int j = lane; j < A; j += 64) stage.xc_cur[(int64_t)b * W + O + j] = v.act[row * v.act_dim + j];
+    }
     if (lane == 0) {
         float R = 0.0f, D = 1.0f;
         for (int i = 0; i < nstep; ++i) {
@@ -372,8 +390,10 @@ namespace exorl {
 // still advanced so eager sampling continues the stream afterwards.
 int replay_sample_impl(exorl_replay* r, int32_t batch, int32_t nstep, float gamma, int32_t sampler,
                        const int32_t* pairs_host, const exorl_batch_out* out, int32_t* pairs_out_host, hipStream_t s,
-                       const uint64_t* dev_counter) {
+                       const uint64_t* dev_counter, const StageOut* stage) {
     EXORL_REQUIRE(r && out, "replay_sample: null argument");
+    EXORL_REQUIRE(!stage || (r->cfg.obs_bytes == stage->O * 4 && r->cfg.act_dim == stage->A && stage->B == batch),
+                  "replay_sample: staged outputs need fp32 state observations of the agent's dimensions");
     EXORL_REQUIRE(batch > 0 && nstep >= 1, "replay_sample: batch=%d nstep=%d", batch, nstep);
     EXORL_REQUIRE(out->obs && out->action && out->reward && out->discount && out->next_obs, "replay_sample: null output");
     EXORL_REQUIRE((r->cfg.meta_dim > 0) || out->meta == nullptr, "replay_sample: meta output without meta columns");
@@ -421,13 +441,14 @@ int replay_sample_impl(exorl_replay* r, int32_t batch, int32_t nstep, float gamm
     const int vec16 = (r->cfg.obs_bytes % 16 == 0) && (out->obs_stride % 16 == 0) && (out->next_obs_stride % 16 == 0) &&
                       ((uintptr_t)out->obs % 16 == 0) && ((uintptr_t)out->next_obs % 16 == 0);
     hipLaunchKernelGGL(gather_nstep_kernel, dim3(cdiv(batch, 4)), dim3(256), 0, s, v, r->d_pairs, r->d_pairs, *out, batch, nstep,
-                       gamma, sampler, r->philox_seed, r->philox_counter, dev_counter, vec16);
+                       gamma, sampler, r->philox_seed, r->philox_counter, dev_counter, vec16, stage ? *stage : StageOut{});
     EXORL_LAUNCH_CHECK();
     if (sampler == EXORL_SAMPLER_PHILOX) r->philox_counter += 1;
     return 0;
 }
 
 uint64_t replay_philox_counter(exorl_replay* r) { return r->philox_counter; }
+int replay_obs_bytes(exorl_replay* r) { return r->cfg.obs_bytes; }
 void replay_advance_philox(exorl_replay* r, uint64_t n) { r->philox_counter += n; }
 }  // namespace exorl
 
