@@ -143,6 +143,43 @@ static int net_forward(const NetDesc& d, const float* P, const NetShadow& sh, co
     return 0;
 }
 
+// The critic on (obs, a_data) and its Polyak target on (next_obs, next_action) in shared launches (bf16 mode): the two forward
+// chains are independent, same shapes, different weights -> 3 launches instead of 6, each filling the chip twice as deep.
+static bool forward2_supported(const NetDesc& d, int prec, const NetShadow& sa, const NetShadow& sb) {
+    return prec == EXORL_PREC_BF16 && sa.w0b && sb.w0b && trunk_fwd16_supported(d.H) && d.out_dim == 1 && d.n_heads == 2 && d.H % 4 == 0;
+}
+static int net_forward2(const NetDesc& d, const float* Pa, const NetShadow& sa, const float* xa, const FwdBufs& fa, bool save_a,
+                        const float* Pb, const NetShadow& sb, const float* xb, const FwdBufs& fb, bool save_b, int64_t ldx, int rows,
+                        hipStream_t s) {
+    const int H = d.H;
+    const int64_t act = (int64_t)rows * H, wst = (int64_t)H * round_up(d.in_dim, 32);
+    const float* P[2] = {Pa, Pb};
+    const NetShadow* sh[2] = {&sa, &sb};
+    const float* x[2] = {xa, xb};
+    const FwdBufs* f[2] = {&fa, &fb};
+    const bool save[2] = {save_a, save_b};
+    TrunkBatch tb{};
+    int nt = 0;
+    for (int k = 0; k < 2; ++k)
+        for (int t = 0; t < d.n_trunks; ++t)
+            tb.it[nt++] = TrunkItem{x[k], sh[k]->w0b + t * wst, P[k] + d.b0 + t * d.trunk_stride, P[k] + d.g + t * d.trunk_stride,
+                                    P[k] + d.beta + t * d.trunk_stride, save[k] ? f[k]->rstd + (int64_t)t * rows : nullptr,
+                                    f[k]->h1b + t * act, save[k] ? f[k]->xhatb + t * act : nullptr};
+    EXORL_TRY(trunk_fwd16_batch(tb, nt, ldx, rows, d.in_dim, H, s));
+    Gemm16Problem q[4];
+    HeadBatch hb{};
+    int nq = 0;
+    for (int k = 0; k < 2; ++k)
+        for (int i = 0; i < d.n_heads; ++i) {
+            q[nq] = Gemm16Problem{f[k]->h1b + (d.n_trunks == d.n_heads ? i : 0) * act, sh[k]->w1b + (int64_t)i * H * H, f[k]->h2 + i * act,
+                                  P[k] + d.b1 + i * d.head_stride, rows, H, H, H, H, H};
+            hb.it[nq] = HeadItem{f[k]->h2 + i * act, P[k] + d.W2 + i * d.head_stride, P[k] + d.b2 + i * d.head_stride, f[k]->out + (int64_t)i * rows};
+            ++nq;
+        }
+    EXORL_TRY(gemm16_grouped(0, 0, q, nq, true, false, s));
+    return head_fwd1_batch(hb, nq, rows, H, s);
+}
+
 // G == nullptr: dgrad only (no parameter gradients). dx (n_trunks x rows x dx_cols, one slab per trunk — the
 // consumer adds them) receives d/dx[:, col0:col0+dx_cols].
 static int net_backward(const NetDesc& d, const float* P, const NetShadow& sh, float* G, const Partials& pt, const float* x,
@@ -425,10 +462,14 @@ static int phase0(exorl_agent* a, float stddev, const float* noise_c, hipStream_
     if (!fused_sample)
         EXORL_TRY(sample_actions2(a->fa.out, noise_c, cfg.kind == EXORL_AGENT_CRR ? nullptr : a->noise_a, cfg.seed,
                                   &a->state->noise_counter, stddev, cfg.stddev_clip, a->xc_next + O, a->xc_pi + O, W, B, A, s));
-    EXORL_TRY(a->fk.fork(s));                   // target critic (td3_bc.py:126) and critic (td3_bc.py:130) forwards are independent
-    EXORL_TRY(net_forward(a->critic, Pt, a->sh_target, a->xc_next, W, B, a->ft, false, false, prec, a->fk.side(s)));
-    EXORL_TRY(net_forward(a->critic, Pc, a->sh_critic, a->xc_cur, W, B, a->fc, true, false, prec, s));
-    EXORL_TRY(a->fk.join(s));
+    if (!a->fk.on && forward2_supported(a->critic, prec, a->sh_target, a->sh_critic)) {
+        EXORL_TRY(net_forward2(a->critic, Pt, a->sh_target, a->xc_next, a->ft, false, Pc, a->sh_critic, a->xc_cur, a->fc, true, W, B, s));
+    } else {
+        EXORL_TRY(a->fk.fork(s));               // target critic (td3_bc.py:126) and critic (td3_bc.py:130) forwards are independent
+        EXORL_TRY(net_forward(a->critic, Pt, a->sh_target, a->xc_next, W, B, a->ft, false, false, prec, a->fk.side(s)));
+        EXORL_TRY(net_forward(a->critic, Pc, a->sh_critic, a->xc_cur, W, B, a->fc, true, false, prec, s));
+        EXORL_TRY(a->fk.join(s));
+    }
     if (a->want_metrics)
         EXORL_TRY(critic_loss(a->fc.out, a->ft.out, a->reward, a->discount, a->dq, a->metrics, B, a->inv_bg, s));   // :133-137
     DoutSpec td{};                              // d(2 x MSE)/dQ computed where it is consumed (:127-131)

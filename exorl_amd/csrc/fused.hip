@@ -172,14 +172,20 @@ typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
 typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4_t;
 
 template <int T>     // T = H / 128 column tiles per wave
-__global__ __launch_bounds__(512) void trunk_fwd16_kernel(const float* __restrict__ x, int64_t ldx, const unsigned short* __restrict__ W0b,
-                                                          const float* __restrict__ b0, const float* __restrict__ gain,
-                                                          const float* __restrict__ beta, float* __restrict__ rstd,
-                                                          unsigned short* __restrict__ hb, unsigned short* __restrict__ xhb, int rows,
-                                                          int in_dim, int Kp, int64_t astride, int64_t pstride, int64_t wstride) {
+__global__ __launch_bounds__(512) void trunk_fwd16_kernel(const TrunkBatch tb, int64_t ldx, int rows, int in_dim, int Kp) {
     constexpr int H = T * 128;
     __shared__ float red[2][8][16];
-    const int net = blockIdx.y;
+    const TrunkItem& it = tb.it[blockIdx.y];
+    const float* __restrict__ x = it.x;
+    const float* __restrict__ b0 = it.b0;
+    const float* __restrict__ gain = it.gain;
+    const float* __restrict__ beta = it.beta;
+    float* __restrict__ rstd = it.rstd;
+    unsigned short* __restrict__ hb = it.hb;
+    unsigned short* __restrict__ xhb = it.xhb;
+    const unsigned short* __restrict__ W0b = it.W0b;
+    constexpr int net = 0;
+    constexpr int64_t astride = 0, pstride = 0, wstride = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rn = lane & 15, kq = lane >> 4;                 // batch row within the tile / k-group (and column quad of C)
     const int row = blockIdx.x * 16 + rn;
@@ -254,15 +260,12 @@ __global__ __launch_bounds__(512) void trunk_fwd16_kernel(const float* __restric
 
 bool trunk_fwd16_supported(int H) { return H >= 128 && H <= 1024 && H % 128 == 0; }
 
-int trunk_fwd16(const float* x, int64_t ldx, const unsigned short* W0b, const float* b0, const float* gain, const float* beta, float* rstd,
-                unsigned short* h_bf16, unsigned short* xhat_bf16, int rows, int in_dim, int H, int nets, int64_t astride, int64_t pstride,
-                hipStream_t s) {
-    EXORL_REQUIRE(trunk_fwd16_supported(H) && in_dim >= 1 && in_dim <= MAX_IN && h_bf16, "trunk_fwd16: unsupported H=%d in=%d", H, in_dim);
+int trunk_fwd16_batch(const TrunkBatch& tb, int count, int64_t ldx, int rows, int in_dim, int H, hipStream_t s) {
+    EXORL_REQUIRE(trunk_fwd16_supported(H) && in_dim >= 1 && in_dim <= MAX_IN && count >= 1 && count <= 4, "trunk_fwd16: unsupported H=%d in=%d n=%d",
+                  H, in_dim, count);
     const int Kp = (int)round_up(in_dim, 32);
-    const dim3 grid(cdiv(rows, 16), nets);
-    const int64_t wstride = (int64_t)H * Kp;
-#define EXORL_TF16(T) hipLaunchKernelGGL((trunk_fwd16_kernel<T>), grid, dim3(512), 0, s, x, ldx, W0b, b0, gain, beta, rstd, h_bf16, xhat_bf16, \
-                                         rows, in_dim, Kp, astride, pstride, wstride)
+    const dim3 grid(cdiv(rows, 16), count);
+#define EXORL_TF16(T) hipLaunchKernelGGL((trunk_fwd16_kernel<T>), grid, dim3(512), 0, s, tb, ldx, rows, in_dim, Kp)
     switch (H / 128) {
         case 1: EXORL_TF16(1); break;
         case 2: EXORL_TF16(2); break;
@@ -276,6 +279,18 @@ int trunk_fwd16(const float* x, int64_t ldx, const unsigned short* W0b, const fl
 #undef EXORL_TF16
     EXORL_LAUNCH_CHECK();
     return 0;
+}
+
+int trunk_fwd16(const float* x, int64_t ldx, const unsigned short* W0b, const float* b0, const float* gain, const float* beta, float* rstd,
+                unsigned short* h_bf16, unsigned short* xhat_bf16, int rows, int in_dim, int H, int nets, int64_t astride, int64_t pstride,
+                hipStream_t s) {
+    EXORL_REQUIRE(h_bf16 && nets >= 1 && nets <= 4, "trunk_fwd16: bad arguments");
+    TrunkBatch tb{};
+    const int64_t wstride = (int64_t)H * round_up(in_dim, 32);
+    for (int n = 0; n < nets; ++n)
+        tb.it[n] = TrunkItem{x, W0b + n * wstride, b0 + n * pstride, gain + n * pstride, beta + n * pstride, rstd ? rstd + (int64_t)n * rows : nullptr,
+                             h_bf16 + n * astride, xhat_bf16 ? xhat_bf16 + n * astride : nullptr};
+    return trunk_fwd16_batch(tb, nets, ldx, rows, in_dim, H, s);
 }
 
 int trunk_fwd(const float* x, int64_t ldx, const float* W0T, const float* b0, const float* gain, const float* beta,
@@ -557,6 +572,36 @@ __global__ __launch_bounds__(256) void head_fwd4_kernel(const float* __restrict_
             }
         }
     }
+}
+
+// scalar heads of several nets in one launch (critic Q1,Q2 and target Q1,Q2): per-net pointers instead of strides
+__global__ __launch_bounds__(256) void head_fwd1_batch_kernel(const HeadBatch hb, int rows, int H) {
+    const HeadItem& it = hb.it[blockIdx.y];
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float4* ar = reinterpret_cast<const float4*>(it.a + (int64_t)row * H);
+    const int H4 = H >> 2;
+    float4 avs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) avs[i] = lane + 64 * i < H4 ? ar[lane + 64 * i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c4 = lane + 64 * i;
+        if (c4 >= H4) break;
+        const float4 wv = reinterpret_cast<const float4*>(it.W)[c4];
+        acc += avs[i].x * wv.x + avs[i].y * wv.y + avs[i].z * wv.z + avs[i].w * wv.w;
+    }
+    const float v = wave_sum(acc) + it.b[0];
+    if (lane == 0) it.out[row] = v;
+}
+
+int head_fwd1_batch(const HeadBatch& hb, int count, int rows, int H, hipStream_t s) {
+    EXORL_REQUIRE(count >= 1 && count <= 4 && H % 4 == 0 && H <= 1024, "head_fwd1_batch: count=%d H=%d unsupported", count, H);
+    hipLaunchKernelGGL(head_fwd1_batch_kernel, dim3(cdiv(rows, 4), count), dim3(256), 0, s, hb, rows, H);
+    EXORL_LAUNCH_CHECK();
+    return 0;
 }
 
 int head_fwd4(const float* a, const float* W, const float* b, float* out, int rows, int H, int nout, int tanh_out,

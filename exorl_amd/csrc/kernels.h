@@ -48,6 +48,14 @@ int head_bwd_params(const float* dout, const float* a, const float* dz, float* d
 int trunk_fwd(const float* x, int64_t ldx, const float* W0T, const float* b0, const float* gain, const float* beta,
               float* h, float* xhat, float* rstd, unsigned short* h_bf16, unsigned short* xhat_bf16, int rows, int in_dim,
               int H, int nets, int64_t astride, int64_t pstride, int64_t tstride, hipStream_t s);
+// per-net operands of one trunk / scalar head, so that nets whose parameters live in different buffers (critic and its Polyak
+// target) share a launch
+struct TrunkItem { const float* x; const unsigned short* W0b; const float *b0, *gain, *beta; float* rstd; unsigned short *hb, *xhb; };
+struct TrunkBatch { TrunkItem it[4]; };
+int trunk_fwd16_batch(const TrunkBatch& tb, int count, int64_t ldx, int rows, int in_dim, int H, hipStream_t s);
+struct HeadItem { const float* a; const float* W; const float* b; float* out; };
+struct HeadBatch { HeadItem it[4]; };
+int head_fwd1_batch(const HeadBatch& hb, int count, int rows, int H, hipStream_t s);
 // MFMA variant for the bf16 fast mode (H % 128 == 0): W0b = bf16 shadow [nets][H][round_up(in_dim, 32)], zero padded
 bool trunk_fwd16_supported(int H);
 int trunk_fwd16(const float* x, int64_t ldx, const unsigned short* W0b, const float* b0, const float* gain, const float* beta, float* rstd,
