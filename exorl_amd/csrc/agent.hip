@@ -184,7 +184,7 @@ static int net_forward2(const NetDesc& d, const float* Pa, const NetShadow& sa, 
 // consumer adds them) receives d/dx[:, col0:col0+dx_cols].
 static int net_backward(const NetDesc& d, const float* P, const NetShadow& sh, float* G, const Partials& pt, const float* x,
                         int64_t ldx, int rows, const FwdBufs& f, const DoutSpec& dout, const BwdBufs& b, float* dx, int dx_col0,
-                        int dx_cols, int prec, hipStream_t s, const Fork& fk) {
+                        int dx_cols, int prec, hipStream_t s, const Fork& fk, FinalizeArgs* defer = nullptr) {
     const int H = d.H;
     const int64_t act = (int64_t)rows * H;
     const bool paired = d.n_trunks == d.n_heads;
@@ -253,9 +253,11 @@ static int net_backward(const NetDesc& d, const float* P, const NetShadow& sh, f
             for (int i = 0; i < d.n_heads; ++i) EXORL_TRY(gemm_grouped(prec, 0, 1, p + i, 1, false, i > 0, s));
         }
     }
+    const bool dx_fused = dx && !G;              // dgrad-only pass: d/d(input columns) in the LayerNorm-backward kernel itself
     EXORL_TRY(ln_bwd(b.dh1, f.h1, f.xhat, bf ? f.h1b : nullptr, bf ? f.xhatb : nullptr, f.rstd, P + d.g, pt.Pt, rows, H, d.n_trunks,
-                     act, d.trunk_stride, G ? 1 : 0, s));
-    if (dx)       // dx[m][j] = sum_c dz0[m][c] W0[c][col0+j]: a row-dot against rows col0.. of the transposed shadow
+                     act, d.trunk_stride, G ? 1 : 0, s, dx_fused ? sh.w0t + (int64_t)dx_col0 * H : nullptr, (int64_t)d.in_dim * H,
+                     dx_fused ? dx : nullptr, dx_cols));
+    if (dx && !dx_fused)       // dx[m][j] = sum_c dz0[m][c] W0[c][col0+j]: a row-dot against rows col0.. of the transposed shadow
         EXORL_TRY(head_fwd4(b.dh1, sh.w0t + (int64_t)dx_col0 * H, nullptr, dx, rows, H, dx_cols, 0, d.n_trunks, act,
                             (int64_t)d.in_dim * H, (int64_t)rows * dx_cols, s));
     if (G) {
@@ -268,7 +270,8 @@ static int net_backward(const NetDesc& d, const float* P, const NetShadow& sh, f
         fa.Pw = pt.Pw; fa.w_chunks = outer_chunks(rows);
         fa.gW0 = d.W0; fa.gb0 = d.b0; fa.gg = d.g; fa.gbeta = d.beta;
         fa.H = H; fa.nout = d.out_dim; fa.in_dim = d.in_dim; fa.G = G;
-        EXORL_TRY(finalize_grads(fa, s));
+        if (defer) *defer = fa;                    // the optimiser launch sums the partials itself (finalize_adam)
+        else EXORL_TRY(finalize_grads(fa, s));
     }
     return 0;
 }
@@ -329,6 +332,8 @@ struct exorl_agent {
     bool capturing = false;
     Fork fk{};                   // parallel-branch plumbing (active while capturing)
     bool parallel_branches = false;  // measured slower than one chain on MI355X (2987 vs 3259 steps/s): opt-in
+    bool fuse_opt = false;           // whole-step call on one GPU: partial-gradient reduction happens inside the optimiser launch
+    FinalizeArgs pend_c{}, pend_a{};
     bool staged_by_sampler = false;  // captured step: the sampler's gather kernel writes the staged inputs and runs step_begin
     bool want_metrics = true;    // the (B,1)-sized metric reductions are skipped when the caller never reads them (use_tb=False)
 };
@@ -437,6 +442,21 @@ static int push_opt_steps(exorl_agent* a) {
     return 0;
 }
 
+static int opt_step(exorl_agent* a, int net, const NetDesc& d, const FinalizeArgs& pend, const AdamConst* c, float* target, const ShadowSpec& spec,
+                    uint64_t* bump, hipStream_t s) {
+    float** f = a->flat[net];
+    if (a->fuse_opt) {
+        FusedAdamArgs fa{f[EXORL_T_PARAM], f[EXORL_T_GRAD], f[EXORL_T_ADAM_M], f[EXORL_T_ADAM_V], target, c, d.n_heads,
+                         {d.W1, d.W1 + d.head_stride}, reinterpret_cast<unsigned long long*>(bump)};
+        return finalize_adam(pend, fa, spec, s);
+    }
+    return adam_step_dev(f[EXORL_T_PARAM], f[EXORL_T_GRAD], f[EXORL_T_ADAM_M], f[EXORL_T_ADAM_V], d.total, c, target, &spec, s, bump);
+}
+static int opt_step_critic(exorl_agent* a, hipStream_t s) {
+    return opt_step(a, EXORL_NET_CRITIC, a->critic, a->pend_c, &a->state->critic, a->flat[EXORL_NET_CRITIC_TARGET][EXORL_T_PARAM], a->spec_critic,
+                    nullptr, s);
+}
+
 // -- phase 0: everything up to the critic gradients -------------------------------------------------
 static int phase0(exorl_agent* a, float stddev, const float* noise_c, hipStream_t s) {
     const auto& cfg = a->cfg;
@@ -475,7 +495,7 @@ static int phase0(exorl_agent* a, float stddev, const float* noise_c, hipStream_
     DoutSpec td{};                              // d(2 x MSE)/dQ computed where it is consumed (:127-131)
     td.mode = EXORL_DOUT_TD; td.q = a->fc.out; td.tq = a->ft.out; td.reward = a->reward; td.discount = a->discount; td.inv_bg = a->inv_bg;
     EXORL_TRY(net_backward(a->critic, Pc, a->sh_critic, a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD], a->pc, a->xc_cur, W, B, a->fc, td,
-                           a->bc, nullptr, 0, 0, prec, s, a->fk));                                                     // :141
+                           a->bc, nullptr, 0, 0, prec, s, a->fk, a->fuse_opt ? &a->pend_c : nullptr));                           // :141
     return 0;
 }
 
@@ -484,9 +504,7 @@ static int phase1(exorl_agent* a, float stddev, const float* noise_a, hipStream_
     if (!a->has_critic) return 0;
     const auto& cfg = a->cfg;
     const int B = cfg.batch, O = cfg.obs_dim, A = cfg.act_dim, W = O + A, prec = cfg.precision;
-    EXORL_TRY(adam_step_dev(a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD],
-                            a->flat[EXORL_NET_CRITIC][EXORL_T_ADAM_M], a->flat[EXORL_NET_CRITIC][EXORL_T_ADAM_V], a->critic.total,
-                            &a->state->critic, a->flat[EXORL_NET_CRITIC_TARGET][EXORL_T_PARAM], &a->spec_critic, s));
+    EXORL_TRY(opt_step_critic(a, s));
     if (cfg.kind == EXORL_AGENT_CRR) {          // crr.py:170-179 with the updated critic, no gradients
         const int n = cfg.num_value_samples;
         const float* Pc = a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM];
@@ -532,14 +550,13 @@ static int phase2(exorl_agent* a, float stddev, hipStream_t s) {
     dm.mode = EXORL_DOUT_ACTOR_MU; dm.da = a->da; dm.da_nets = a->has_critic ? a->critic.n_trunks : 0; dm.mu = f.out; dm.a_data = a->action;
     dm.kind = cfg.kind; dm.inv_bg = a->inv_bg; dm.stddev = stddev; dm.w = a->crr_w;
     EXORL_TRY(net_backward(a->actor, Pa, a->sh_actor, a->flat[EXORL_NET_ACTOR][EXORL_T_GRAD], a->pa, a->xa + (int64_t)B * O, O, B, f,
-                           dm, a->ba, nullptr, 0, 0, prec, s, a->fk));
+                           dm, a->ba, nullptr, 0, 0, prec, s, a->fk, a->fuse_opt ? &a->pend_a : nullptr));
     return 0;
 }
 
 static int phase3(exorl_agent* a, hipStream_t s) {
-    return adam_step_dev(a->flat[EXORL_NET_ACTOR][EXORL_T_PARAM], a->flat[EXORL_NET_ACTOR][EXORL_T_GRAD],
-                         a->flat[EXORL_NET_ACTOR][EXORL_T_ADAM_M], a->flat[EXORL_NET_ACTOR][EXORL_T_ADAM_V], a->actor.total,
-                         &a->state->actor, nullptr, &a->spec_actor, s, a->staged_by_sampler ? &a->state->replay_counter : nullptr);
+    return opt_step(a, EXORL_NET_ACTOR, a->actor, a->pend_a, &a->state->actor, nullptr, a->spec_actor,
+                    a->staged_by_sampler ? &a->state->replay_counter : nullptr, s);
 }
 
 // ---- CQL (cql.py:152-263) ---------------------------------------------------------------------------
@@ -573,16 +590,14 @@ static int cql_phase0(exorl_agent* a, hipStream_t s) {
     DoutSpec d{};
     d.mode = EXORL_DOUT_BUFFER; d.buf = a->dq_all;
     EXORL_TRY(net_backward(a->critic, Pc, a->sh_critic, a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD], a->pc, a->x_all, W, R, a->fc, d, a->bc,
-                           nullptr, 0, 0, prec, s, a->fk));
+                           nullptr, 0, 0, prec, s, a->fk, a->fuse_opt ? &a->pend_c : nullptr));
     return 0;
 }
 
 static int cql_phase1(exorl_agent* a, hipStream_t s) {
     const auto& cfg = a->cfg;
     const int B = cfg.batch, O = cfg.obs_dim, A = cfg.act_dim, W = O + A, prec = cfg.precision;
-    EXORL_TRY(adam_step_dev(a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD],
-                            a->flat[EXORL_NET_CRITIC][EXORL_T_ADAM_M], a->flat[EXORL_NET_CRITIC][EXORL_T_ADAM_V], a->critic.total,
-                            &a->state->critic, a->flat[EXORL_NET_CRITIC_TARGET][EXORL_T_PARAM], &a->spec_critic, s));
+    EXORL_TRY(opt_step_critic(a, s));
     EXORL_TRY(cql_actor_sample(a->fa.out + (int64_t)B * 2 * A, cql_noise(a), a->xc_pi, W, a->stats, B, O, A, s));    // cql.py:237-239
     EXORL_TRY(net_forward(a->critic, a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->sh_critic, a->xc_pi, W, B, a->fc, true, false, prec, s));
     return 0;
@@ -603,7 +618,7 @@ static int cql_phase2(exorl_agent* a, hipStream_t s) {
     dm.mode = EXORL_DOUT_CQL_ACTOR; dm.da = a->da; dm.da_nets = a->critic.n_trunks; dm.raw = f.out; dm.z = a->noise_a;
     dm.alpha_ptr = &a->cql->alpha; dm.inv_bg = a->inv_bg; dm.seed = cfg.seed; dm.counter = 4; dm.counter_ptr = &a->state->noise_counter;
     EXORL_TRY(net_backward(a->actor, a->flat[EXORL_NET_ACTOR][EXORL_T_PARAM], a->sh_actor, a->flat[EXORL_NET_ACTOR][EXORL_T_GRAD], a->pa,
-                           a->xa + (int64_t)B * O, O, B, f, dm, a->ba, nullptr, 0, 0, prec, s, a->fk));
+                           a->xa + (int64_t)B * O, O, B, f, dm, a->ba, nullptr, 0, 0, prec, s, a->fk, a->fuse_opt ? &a->pend_a : nullptr));
     return 0;
 }
 
@@ -771,8 +786,13 @@ int exorl_agent_update_phase(exorl_agent_t* a, int32_t phase, float stddev, cons
 }
 
 int exorl_agent_update(exorl_agent_t* a, float stddev, const float* noise_c, const float* noise_a, void* stream) {
-    for (int p = 0; p < 4; ++p) EXORL_TRY(exorl_agent_update_phase(a, p, stddev, noise_c, noise_a, stream));
-    return 0;
+    EXORL_REQUIRE(a, "agent_update: null handle");
+    // nothing is exchanged between the phases of a whole-step call: the optimiser launches reduce the gradient partials themselves
+    a->fuse_opt = a->cfg.world_size == 1 && !a->fk.on;
+    int rc = 0;
+    for (int p = 0; p < 4 && rc == 0; ++p) rc = exorl_agent_update_phase(a, p, stddev, noise_c, noise_a, stream);
+    a->fuse_opt = false;
+    return rc;
 }
 
 int exorl_agent_stats_buffer(exorl_agent_t* a, void** ptr, int64_t* numel) {
@@ -856,7 +876,9 @@ int exorl_agent_enable_graph(exorl_agent_t* a, exorl_replay_t* r, int32_t nstep,
     a->staged_by_sampler = replay_obs_bytes(r) == a->cfg.obs_dim * 4;
     int rc = replay_sample_impl(r, a->cfg.batch, nstep, gamma, EXORL_SAMPLER_PHILOX, nullptr, &slots, nullptr, a->capture_stream,
                                 &a->state->replay_counter, a->staged_by_sampler ? &stage : nullptr);
+    a->fuse_opt = !a->fk.on;
     for (int p = 0; p < 4 && rc == 0; ++p) rc = exorl_agent_update_phase(a, p, stddev, nullptr, nullptr, a->capture_stream);
+    a->fuse_opt = false;
     a->staged_by_sampler = false;
     a->capturing = false;
     a->fk.on = false;

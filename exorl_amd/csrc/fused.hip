@@ -325,13 +325,37 @@ __device__ __forceinline__ float4 bf4_to_f4(ushort4 q) {
                        __uint_as_float((unsigned)q.z << 16), __uint_as_float((unsigned)q.w << 16));
 }
 
+__device__ __forceinline__ float wave_sum8(const float (&v)[8], int lane) {
+    float a[4], b[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float keep = (lane & 1) ? v[2 * j + 1] : v[2 * j];
+        const float send = (lane & 1) ? v[2 * j] : v[2 * j + 1];
+        a[j] = keep + __shfl_xor(send, 1, 64);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float keep = (lane & 2) ? a[2 * j + 1] : a[2 * j];
+        const float send = (lane & 2) ? a[2 * j] : a[2 * j + 1];
+        b[j] = keep + __shfl_xor(send, 2, 64);
+    }
+    float r = ((lane & 4) ? b[1] : b[0]) + __shfl_xor((lane & 4) ? b[0] : b[1], 4, 64);
+    r += __shfl_xor(r, 8, 64);
+    r += __shfl_xor(r, 16, 64);
+    r += __shfl_xor(r, 32, 64);
+    return r;
+}
+
 // B16: h and xhat are read from their bf16 copies (fast mode keeps no fp32 copies of the trunk activations)
+// dx != nullptr (dgrad-only pass): dx[net][row][j] = sum_c dz[row][c] W0T[j][c], j < dx_cols — the d/d(action) the actor
+// step needs (td3_bc.py:152-155) formed from the dz row while it is still in registers; dz itself is then not stored.
 template <bool PARAMS, bool B16>
 __global__ __launch_bounds__(512) void ln_bwd_kernel(float* dh, const float* __restrict__ h, const float* __restrict__ xhat,
                                                      const unsigned short* __restrict__ hb, const unsigned short* __restrict__ xhb,
                                                      const float* __restrict__ rstd, const float* __restrict__ gain,
                                                      float* __restrict__ P, int rows, int H, int64_t astride,
-                                                     int64_t pstride) {
+                                                     int64_t pstride, const float* __restrict__ w0t, int64_t tstride,
+                                                     float* __restrict__ dx, int dx_cols) {
     __shared__ __attribute__((aligned(16))) float red[PARAMS ? 8 * 1024 : 4];
     const int net = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -377,15 +401,43 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(float* dh, const float* __r
         }
         const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
         const float rs = rstd[net * (int64_t)rows + row];
+        float4 dzv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c4 = lane + 64 * i;
+            dzv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (c4 < H4) {
                 float4 v;
                 v.x = rs * (d[i].x - m1 - xh[i].x * m2); v.y = rs * (d[i].y - m1 - xh[i].y * m2);
                 v.z = rs * (d[i].z - m1 - xh[i].z * m2); v.w = rs * (d[i].w - m1 - xh[i].w * m2);
-                reinterpret_cast<float4*>(dh + o)[c4] = v;
+                if (PARAMS || !dx) reinterpret_cast<float4*>(dh + o)[c4] = v;
+                dzv[i] = v;
                 if constexpr (PARAMS) { pb0[i].x += v.x; pb0[i].y += v.y; pb0[i].z += v.z; pb0[i].w += v.w; }
+            }
+        }
+        if constexpr (!PARAMS) {
+            if (dx) {
+                for (int j0 = 0; j0 < dx_cols; j0 += 8) {
+                    float part[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        part[j] = 0.f;
+                        if (j0 + j < dx_cols) {
+                            const float4* wr = reinterpret_cast<const float4*>(w0t + net * tstride + (int64_t)(j0 + j) * H);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int c4 = lane + 64 * i;
+                                if (c4 < H4) {
+                                    const float4 wv = wr[c4];
+                                    part[j] += dzv[i].x * wv.x + dzv[i].y * wv.y + dzv[i].z * wv.z + dzv[i].w * wv.w;
+                                }
+                            }
+                        }
+                    }
+                    const float tot = wave_sum8(part, lane);
+                    const int j = j0 + (lane & 7);
+                    if (lane < 8 && j < dx_cols) dx[((int64_t)net * rows + row) * dx_cols + j] = tot;
+                }
             }
         }
     }
@@ -412,11 +464,12 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(float* dh, const float* __r
 
 int ln_bwd(float* dh, const float* h, const float* xhat, const unsigned short* h_bf16, const unsigned short* xhat_bf16,
            const float* rstd, const float* gain, float* P, int rows, int H, int nets, int64_t astride, int64_t pstride,
-           int want_params, hipStream_t s) {
+           int want_params, hipStream_t s, const float* w0t, int64_t tstride, float* dx, int dx_cols) {
     EXORL_REQUIRE(H >= 4 && H <= 1024 && H % 4 == 0, "ln_bwd: unsupported H=%d", H);
+    EXORL_REQUIRE(!dx || (!want_params && w0t && dx_cols >= 1), "ln_bwd: the dx epilogue belongs to the dgrad-only pass");
     const dim3 grid(cdiv(rows, TB_ROWS), nets);
     const bool b16 = h_bf16 && xhat_bf16;
-#define EXORL_LNB(PA, BB) hipLaunchKernelGGL((ln_bwd_kernel<PA, BB>), grid, dim3(512), 0, s, dh, h, xhat, h_bf16, xhat_bf16, rstd, gain, P, rows, H, astride, pstride)
+#define EXORL_LNB(PA, BB) hipLaunchKernelGGL((ln_bwd_kernel<PA, BB>), grid, dim3(512), 0, s, dh, h, xhat, h_bf16, xhat_bf16, rstd, gain, P, rows, H, astride, pstride, w0t, tstride, dx, dx_cols)
     if (want_params) { if (b16) EXORL_LNB(true, true); else EXORL_LNB(true, false); }
     else             { if (b16) EXORL_LNB(false, true); else EXORL_LNB(false, false); }
 #undef EXORL_LNB
@@ -483,27 +536,6 @@ int outer_chunks(int rows) { return cdiv(rows, OR_ROWS); }
 // Sums 8 per-lane values over the wave with 10 cross-lane exchanges instead of 48: three butterfly steps that each
 // halve the number of live values (lane l ends up owning value index l & 7), then three plain steps over the remaining
 // 8-lane groups. Returns the wave total of value (lane & 7) in every lane.
-__device__ __forceinline__ float wave_sum8(const float (&v)[8], int lane) {
-    float a[4], b[2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float keep = (lane & 1) ? v[2 * j + 1] : v[2 * j];
-        const float send = (lane & 1) ? v[2 * j] : v[2 * j + 1];
-        a[j] = keep + __shfl_xor(send, 1, 64);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const float keep = (lane & 2) ? a[2 * j + 1] : a[2 * j];
-        const float send = (lane & 2) ? a[2 * j] : a[2 * j + 1];
-        b[j] = keep + __shfl_xor(send, 2, 64);
-    }
-    float r = ((lane & 4) ? b[1] : b[0]) + __shfl_xor((lane & 4) ? b[0] : b[1], 4, 64);
-    r += __shfl_xor(r, 8, 64);
-    r += __shfl_xor(r, 16, 64);
-    r += __shfl_xor(r, 32, 64);
-    return r;
-}
-
 // ------------------------------------------------------------------------------------------------
 // head forward v2: out[m][j] = b[j] + sum_c a[m][c] W[j][c]; one wave per row, float4 streams (H % 4 == 0)
 __device__ __forceinline__ float philox_normal_f(uint64_t seed, uint64_t counter, uint32_t elem) {
@@ -866,6 +898,107 @@ __global__ __launch_bounds__(256) void finalize_grads_kernel(FinalizeArgs f) {
             }
         }
     }
+}
+
+// ---- finalize + optimiser step in one launch (see FusedAdamArgs) ---------------------------------------------------
+__device__ __forceinline__ void step_small(const FusedAdamArgs& a, const AdamConst& c, int64_t gi, float grad, float& pnew, float& tnew) {
+    a.g[gi] = grad;
+    float p = a.p[gi], m = a.m[gi], v = a.v[gi];
+    adam_elem(p, grad, m, v, c);
+    a.p[gi] = p; a.m[gi] = m; a.v[gi] = v;
+    pnew = p; tnew = 0.f;
+    if (a.target) {
+        tnew = polyak(p, a.target[gi], c.tau, c.one_minus_tau);
+        a.target[gi] = tnew;
+    }
+}
+
+__global__ __launch_bounds__(256) void finalize_adam_kernel(FinalizeArgs f, FusedAdamArgs a, ShadowSpec sh, int nb_fin) {
+    const AdamConst c = *a.c;
+    if (a.bump && blockIdx.x == 0 && threadIdx.x == 0) *a.bump += 1ull;
+    const int H = f.H;
+    if ((int)blockIdx.x >= nb_fin) {             // H x H weights: float4 streams, gradient straight from the wgrad GEMM
+        const int64_t hh4 = (int64_t)H * H / 4, n4 = a.n_heads * hh4;
+        for (int64_t i = (int64_t)(blockIdx.x - nb_fin) * blockDim.x + threadIdx.x; i < n4; i += (int64_t)(gridDim.x - nb_fin) * blockDim.x) {
+            const int t = (int)(i / hh4);
+            const int64_t e4 = i % hh4, gi4 = a.w1_off[t] / 4 + e4;
+            float4 pv = reinterpret_cast<float4*>(a.p)[gi4];
+            const float4 gv = reinterpret_cast<const float4*>(a.g)[gi4];
+            float4 mv = reinterpret_cast<float4*>(a.m)[gi4];
+            float4 vv = reinterpret_cast<float4*>(a.v)[gi4];
+            adam_elem(pv.x, gv.x, mv.x, vv.x, c); adam_elem(pv.y, gv.y, mv.y, vv.y, c);
+            adam_elem(pv.z, gv.z, mv.z, vv.z, c); adam_elem(pv.w, gv.w, mv.w, vv.w, c);
+            reinterpret_cast<float4*>(a.p)[gi4] = pv;
+            reinterpret_cast<float4*>(a.m)[gi4] = mv;
+            reinterpret_cast<float4*>(a.v)[gi4] = vv;
+            if (sh.w1b) {
+                ushort4 q; q.x = f2bf(pv.x); q.y = f2bf(pv.y); q.z = f2bf(pv.z); q.w = f2bf(pv.w);
+                reinterpret_cast<ushort4*>(sh.w1b + (int64_t)t * H * H)[e4] = q;
+            }
+            if (a.target) {
+                float4 tv = reinterpret_cast<float4*>(a.target)[gi4];
+                tv.x = polyak(pv.x, tv.x, c.tau, c.one_minus_tau); tv.y = polyak(pv.y, tv.y, c.tau, c.one_minus_tau);
+                tv.z = polyak(pv.z, tv.z, c.tau, c.one_minus_tau); tv.w = polyak(pv.w, tv.w, c.tau, c.one_minus_tau);
+                reinterpret_cast<float4*>(a.target)[gi4] = tv;
+                if (sh.t_w1b) {
+                    ushort4 q; q.x = f2bf(tv.x); q.y = f2bf(tv.y); q.z = f2bf(tv.z); q.w = f2bf(tv.w);
+                    reinterpret_cast<ushort4*>(sh.t_w1b + (int64_t)t * H * H)[e4] = q;
+                }
+            }
+        }
+        return;
+    }
+    const int64_t nh = (int64_t)(f.nout + 1) * H + (f.nout > 16 ? 32 : 16);
+    const int64_t nt = 3 * (int64_t)H;
+    const int64_t nw = (int64_t)f.in_dim * H;
+    const int64_t total = f.n_heads * nh + f.n_trunks * (nt + nw);
+    const int64_t Kp = (f.in_dim + 31) / 32 * 32;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)nb_fin * blockDim.x) {
+        float pn, tn;
+        if (i < f.n_heads * nh) {
+            const int net = (int)(i / nh);
+            const int64_t e = i % nh;
+            const int64_t j = e / H;
+            if (j > f.nout && e - (int64_t)(f.nout + 1) * H >= f.nout) continue;
+            const float sacc = chunk_sum(f.Ph + (int64_t)net * f.head_chunks * nh + e, f.head_chunks, nh);
+            const int64_t base = net * f.head_stride;
+            const int64_t gi = base + (j < f.nout ? f.gW2 + e : (j == f.nout ? f.gb1 + (e - (int64_t)f.nout * H) : f.gb2 + (e - (int64_t)(f.nout + 1) * H)));
+            step_small(a, c, gi, sacc, pn, tn);
+        } else {
+            const int64_t ii = i - f.n_heads * nh;
+            const int net = (int)(ii / (nt + nw));
+            const int64_t e = ii % (nt + nw);
+            const int64_t base = net * f.trunk_stride;
+            if (e < nt) {
+                const float sacc = chunk_sum(f.Pt + (int64_t)net * f.trunk_chunks * nt + e, f.trunk_chunks, nt);
+                const int seg = (int)(e / H), cc = (int)(e % H);
+                step_small(a, c, base + (seg == 0 ? f.gg : (seg == 1 ? f.gbeta : f.gb0)) + cc, sacc, pn, tn);
+            } else {
+                const int64_t ew = e - nt;
+                const float sacc = chunk_sum(f.Pw + (int64_t)net * f.w_chunks * nw + ew, f.w_chunks, nw);
+                const int k = (int)(ew / H), cc = (int)(ew % H);
+                step_small(a, c, base + f.gW0 + (int64_t)cc * f.in_dim + k, sacc, pn, tn);
+                // derived copies of the first-layer weight (ShadowSpec): transposed fp32 and K-padded bf16
+                sh.w0t[net * nw + (int64_t)k * H + cc] = pn;
+                if (sh.w0b) sh.w0b[(int64_t)net * H * Kp + (int64_t)cc * Kp + k] = f2bf(pn);
+                if (a.target && sh.t_w0t) {
+                    sh.t_w0t[net * nw + (int64_t)k * H + cc] = tn;
+                    if (sh.t_w0b) sh.t_w0b[(int64_t)net * H * Kp + (int64_t)cc * Kp + k] = f2bf(tn);
+                }
+            }
+        }
+    }
+}
+
+int finalize_adam(const FinalizeArgs& f, const FusedAdamArgs& a, const ShadowSpec& sh, hipStream_t s) {
+    EXORL_REQUIRE(f.H % 2 == 0 && a.n_heads >= 1 && a.n_heads <= 2, "finalize_adam: unsupported geometry");
+    const int64_t total = f.n_heads * ((int64_t)(f.nout + 1) * f.H + (f.nout > 16 ? 32 : 16)) + f.n_trunks * (int64_t)(3 + f.in_dim) * f.H;
+    const int nb_fin = cdiv(total, 256);
+    int nb_w1 = cdiv((int64_t)a.n_heads * f.H * f.H / 4, 256);
+    if (nb_w1 > 1024) nb_w1 = 1024;
+    hipLaunchKernelGGL(finalize_adam_kernel, dim3(nb_fin + nb_w1), dim3(256), 0, s, f, a, sh, nb_fin);
+    EXORL_LAUNCH_CHECK();
+    return 0;
 }
 
 int finalize_grads(const FinalizeArgs& f, hipStream_t s) {

@@ -63,7 +63,7 @@ int trunk_fwd16(const float* x, int64_t ldx, const unsigned short* W0b, const fl
                 hipStream_t s);
 int ln_bwd(float* dh, const float* h, const float* xhat, const unsigned short* h_bf16, const unsigned short* xhat_bf16,
            const float* rstd, const float* gain, float* P, int rows, int H, int nets, int64_t astride, int64_t pstride,
-           int want_params, hipStream_t s);
+           int want_params, hipStream_t s, const float* w0t = nullptr, int64_t tstride = 0, float* dx = nullptr, int dx_cols = 0);
 int trunk_chunks(int rows);
 int outer_reduce(const float* u, int64_t ldu, int J, const float* v, float* P, int rows, int H, int nets, int64_t vstride,
                  hipStream_t s);
@@ -118,6 +118,26 @@ struct FinalizeArgs {
 };
 int finalize_grads(const FinalizeArgs& f, hipStream_t s);
 
+// Products and sums are rounded separately (no FMA contraction): the op order of torch's CPU kernels.
+__device__ __forceinline__ float polyak(float p, float t, float tau, float one_minus_tau) {
+#pragma clang fp contract(off)
+    const float a = tau * p;
+    const float b = one_minus_tau * t;
+    return a + b;
+}
+struct AdamConst;
+// One launch for "sum the per-workgroup gradient partials" and the optimiser step (single-GPU steps: nothing has to be
+// exchanged between the two): the first blocks reduce the partials of every tensor except the H x H weights and step those
+// elements in place (Adam, Polyak target, derived copies), the remaining blocks stream the H x H weights' Adam update.
+struct FusedAdamArgs {
+    float *p, *g, *m, *v, *target;
+    const AdamConst* c;                // device
+    int n_heads; int64_t w1_off[2];    // flat offsets of the H x H weights
+    unsigned long long* bump;
+};
+struct ShadowSpec;
+int finalize_adam(const FinalizeArgs& f, const FusedAdamArgs& a, const ShadowSpec& sh, hipStream_t s);
+
 // Derived copies of a net's weights that the kernels read: W0T[in][H] per trunk (coalesced first-layer reads)
 // and, in bf16 mode, W1 as bf16 per head (MFMA operand). Kept current by the Adam kernel itself.
 struct ShadowSpec {
@@ -143,6 +163,15 @@ struct NoiseSpec {           // where TruncatedNormal noise comes from
 struct AdamConst {           // fp32 scalars of one torch.optim.Adam step (bias corrections folded in)
     float one_minus_b1, b2, one_minus_b2, bc2_sqrt, eps, neg_step_size, tau, one_minus_tau;
 };
+
+__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const AdamConst& c) {
+#pragma clang fp contract(off)
+    // exp_avg.lerp_(g, 1-b1); exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2); p.addcdiv_(m, sqrt(v)/bc2_sqrt + eps, -lr/bc1)
+    m = m + c.one_minus_b1 * (g - m);
+    v = v * c.b2 + (c.one_minus_b2 * g) * g;
+    const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
+    p = p + (c.neg_step_size * m) / denom;
+}
 
 // Device-resident per-agent step state: everything that changes from one update() to the next, so the whole
 // step can be captured once in a hipGraph and replayed with no host-side argument patching.

@@ -7,23 +7,6 @@
 
 namespace exorl {
 
-// Products and sums are rounded separately (no FMA contraction): the op order of torch's CPU kernels.
-__device__ __forceinline__ float polyak(float p, float t, float tau, float one_minus_tau) {
-#pragma clang fp contract(off)
-    const float a = tau * p;
-    const float b = one_minus_tau * t;
-    return a + b;
-}
-
-__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const AdamConst& c) {
-#pragma clang fp contract(off)
-    // exp_avg.lerp_(g, 1-b1); exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2); p.addcdiv_(m, sqrt(v)/bc2_sqrt + eps, -lr/bc1)
-    m = m + c.one_minus_b1 * (g - m);
-    v = v * c.b2 + (c.one_minus_b2 * g) * g;
-    const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
-    p = p + (c.neg_step_size * m) / denom;
-}
-
 typedef __bf16 bf16s_t;
 __device__ __forceinline__ unsigned short to_bf16(float x) {
     bf16s_t b = (bf16s_t)x;
