@@ -109,7 +109,8 @@ static ShadowSpec shadow_spec(const NetDesc& d, const NetShadow& sh, const NetSh
 }
 
 static int net_forward(const NetDesc& d, const float* P, const NetShadow& sh, const float* x, int64_t ldx, int rows,
-                       const FwdBufs& f, bool save, bool tanh_out, int prec, hipStream_t s, const SampleSpec* sample = nullptr) {
+                       const FwdBufs& f, bool save, bool tanh_out, int prec, hipStream_t s, const SampleSpec* sample = nullptr,
+                       bool no_head = false) {
     const int H = d.H;
     const int64_t act = (int64_t)rows * H;
     const bool bf = prec == EXORL_PREC_BF16;
@@ -134,6 +135,7 @@ static int net_forward(const NetDesc& d, const float* P, const NetShadow& sh, co
                                P + d.b1 + i * d.head_stride, rows, H, H, H, H, H};
         EXORL_TRY(gemm_grouped(prec, 0, 0, p, d.n_heads, true, false, s));
     }
+    if (no_head) return 0;                       // the caller runs the fused head forward+backward (qhead)
     if (H % 4 == 0)
         EXORL_TRY(head_fwd4(f.h2, P + d.W2, P + d.b2, f.out, rows, H, d.out_dim, tanh_out ? 1 : 0, d.n_heads, act, d.head_stride,
                             (int64_t)rows * d.out_dim, s, sample));
@@ -150,7 +152,7 @@ static bool forward2_supported(const NetDesc& d, int prec, const NetShadow& sa, 
 }
 static int net_forward2(const NetDesc& d, const float* Pa, const NetShadow& sa, const float* xa, const FwdBufs& fa, bool save_a,
                         const float* Pb, const NetShadow& sb, const float* xb, const FwdBufs& fb, bool save_b, int64_t ldx, int rows,
-                        hipStream_t s) {
+                        hipStream_t s, bool no_head = false) {
     const int H = d.H;
     const int64_t act = (int64_t)rows * H, wst = (int64_t)H * round_up(d.in_dim, 32);
     const float* P[2] = {Pa, Pb};
@@ -177,6 +179,7 @@ static int net_forward2(const NetDesc& d, const float* Pa, const NetShadow& sa, 
             ++nq;
         }
     EXORL_TRY(gemm16_grouped(0, 0, q, nq, true, false, s));
+    if (no_head) return 0;
     return head_fwd1_batch(hb, nq, rows, H, s);
 }
 
@@ -184,12 +187,14 @@ static int net_forward2(const NetDesc& d, const float* Pa, const NetShadow& sa, 
 // consumer adds them) receives d/dx[:, col0:col0+dx_cols].
 static int net_backward(const NetDesc& d, const float* P, const NetShadow& sh, float* G, const Partials& pt, const float* x,
                         int64_t ldx, int rows, const FwdBufs& f, const DoutSpec& dout, const BwdBufs& b, float* dx, int dx_col0,
-                        int dx_cols, int prec, hipStream_t s, const Fork& fk, FinalizeArgs* defer = nullptr) {
+                        int dx_cols, int prec, hipStream_t s, const Fork& fk, FinalizeArgs* defer = nullptr, bool have_dz2 = false) {
     const int H = d.H;
     const int64_t act = (int64_t)rows * H;
     const bool paired = d.n_trunks == d.n_heads;
     const bool bf = prec == EXORL_PREC_BF16;
-    if (d.out_dim > 16) {
+    if (have_dz2) {
+        // dz2 and the head partials were produced by qhead
+    } else if (d.out_dim > 16) {
         EXORL_REQUIRE(d.n_heads == 1, "net_backward: wide heads are single-net only");
         EXORL_TRY(head_bwd_wide(dout, P + d.W2, f.h2, bf ? nullptr : b.dz2, bf ? b.dz2b : nullptr, G ? pt.Ph : nullptr, rows, H, d.out_dim,
                                 act, d.head_stride, G ? 1 : 0, s));
@@ -264,7 +269,7 @@ static int net_backward(const NetDesc& d, const float* P, const NetShadow& sh, f
         EXORL_TRY(outer_reduce(x, ldx, d.in_dim, b.dh1, pt.Pw, rows, H, d.n_trunks, act, s));
         EXORL_TRY(fk.join(s));                     // wgrad branch done before the gradients are finalised
         FinalizeArgs fa{};
-        fa.Ph = pt.Ph; fa.head_chunks = head_chunks(rows); fa.n_heads = d.n_heads; fa.head_stride = d.head_stride;
+        fa.Ph = pt.Ph; fa.head_chunks = have_dz2 ? qhead_chunks(rows) : head_chunks(rows); fa.n_heads = d.n_heads; fa.head_stride = d.head_stride;
         fa.gW2 = d.W2; fa.gb1 = d.b1; fa.gb2 = d.b2;
         fa.Pt = pt.Pt; fa.trunk_chunks = trunk_chunks(rows); fa.n_trunks = d.n_trunks; fa.trunk_stride = d.trunk_stride;
         fa.Pw = pt.Pw; fa.w_chunks = outer_chunks(rows);
@@ -308,7 +313,7 @@ struct exorl_agent {
     float *xa = nullptr, *xc_cur = nullptr, *xc_next = nullptr, *xc_pi = nullptr;
     FwdBufs fa{}, ft{}, fc{};    // actor (2B rows), target critic, critic
     BwdBufs bc{}, ba{};
-    float *dq = nullptr, *da = nullptr, *dpre = nullptr;
+    float *dq = nullptr, *da = nullptr, *dpre = nullptr, *abs_part = nullptr;
     float *x_all = nullptr, *dq_all = nullptr;     // CQL: (3n+1)B critic rows and their per-row loss gradients
     CqlScalars* cql = nullptr;                      // CQL: log_actor_alpha + Adam moments + alpha (device)
     float *xc_rep = nullptr, *crr_w = nullptr;     // CRR: repeated (obs, sampled action) inputs; advantage weights
@@ -380,6 +385,7 @@ static void carve(exorl_agent* a, Carver& c) {
             a->cql = reinterpret_cast<CqlScalars*>(c.take(16));
         }
         a->dq = c.take(2 * B);
+        a->abs_part = c.take(2 * (int64_t)qhead_chunks(B));
         a->da = c.take(nt * B * A);
         if (cfg.kind == EXORL_AGENT_CRR) {
             const int64_t R = B * cfg.num_value_samples;
@@ -389,7 +395,7 @@ static void carve(exorl_agent* a, Carver& c) {
         }
         a->sh_critic = NetShadow{c.take(nt * W * H), bf ? take_u16(2 * H * H) : nullptr, bf ? take_u16(nt * H * round_up(W, 32)) : nullptr};
         a->sh_target = NetShadow{c.take(nt * W * H), bf ? take_u16(2 * H * H) : nullptr, bf ? take_u16(nt * H * round_up(W, 32)) : nullptr};
-        a->pc = Partials{c.take(2 * (int64_t)head_chunks(RC) * (2 * H + 16)), c.take(nt * (int64_t)trunk_chunks(RC) * 3 * H),
+        a->pc = Partials{c.take(2 * (int64_t)qhead_chunks(RC) * (2 * H + 16)), c.take(nt * (int64_t)trunk_chunks(RC) * 3 * H),
                          c.take(nt * (int64_t)outer_chunks(RC) * W * H)};
     }
 }
@@ -457,6 +463,31 @@ static int opt_step_critic(exorl_agent* a, hipStream_t s) {
                     nullptr, s);
 }
 
+// fused scalar-head path: whole-step call on one GPU, nobody reads the metrics, twin scalar heads
+static bool qfuse(const exorl_agent* a) {
+    return a->fuse_opt && !a->want_metrics && a->has_critic && a->critic.n_heads == 2 && a->critic.out_dim == 1 && a->cfg.hidden_dim % 4 == 0 &&
+           (a->cfg.kind == EXORL_AGENT_TD3_BC || a->cfg.kind == EXORL_AGENT_TD3 || a->cfg.kind == EXORL_AGENT_DDPG);
+}
+static int run_qhead(exorl_agent* a, int mode, hipStream_t s) {
+    const NetDesc& d = a->critic;
+    const int B = a->cfg.batch, H = d.H;
+    const int64_t act = (int64_t)B * H;
+    const float* Pc = a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM];
+    const float* Pt = a->flat[EXORL_NET_CRITIC_TARGET][EXORL_T_PARAM];
+    const bool bf = a->cfg.precision == EXORL_PREC_BF16;
+    QHeadArgs q{};
+    for (int i = 0; i < 2; ++i) {
+        q.a[i] = a->fc.h2 + i * act; q.W[i] = Pc + d.W2 + i * d.head_stride; q.b[i] = Pc + d.b2 + i * d.head_stride;
+        q.a[2 + i] = a->ft.h2 + i * act; q.W[2 + i] = Pt + d.W2 + i * d.head_stride; q.b[2 + i] = Pt + d.b2 + i * d.head_stride;
+    }
+    q.q = a->fc.out; q.tq = a->ft.out; q.reward = a->reward; q.discount = a->discount;
+    q.dz = bf ? nullptr : a->bc.dz2; q.dzb = bf ? a->bc.dz2b : nullptr; q.act = act;
+    q.P = mode == 0 ? a->pc.Ph : nullptr;
+    q.abs_part = a->abs_part;
+    q.rows = B; q.H = H; q.mode = mode; q.inv_bg = a->inv_bg;
+    return qhead(q, s);
+}
+
 // -- phase 0: everything up to the critic gradients -------------------------------------------------
 static int phase0(exorl_agent* a, float stddev, const float* noise_c, hipStream_t s) {
     const auto& cfg = a->cfg;
@@ -482,20 +513,22 @@ static int phase0(exorl_agent* a, float stddev, const float* noise_c, hipStream_
     if (!fused_sample)
         EXORL_TRY(sample_actions2(a->fa.out, noise_c, cfg.kind == EXORL_AGENT_CRR ? nullptr : a->noise_a, cfg.seed,
                                   &a->state->noise_counter, stddev, cfg.stddev_clip, a->xc_next + O, a->xc_pi + O, W, B, A, s));
+    const bool qf = qfuse(a);
     if (!a->fk.on && forward2_supported(a->critic, prec, a->sh_target, a->sh_critic)) {
-        EXORL_TRY(net_forward2(a->critic, Pt, a->sh_target, a->xc_next, a->ft, false, Pc, a->sh_critic, a->xc_cur, a->fc, true, W, B, s));
+        EXORL_TRY(net_forward2(a->critic, Pt, a->sh_target, a->xc_next, a->ft, false, Pc, a->sh_critic, a->xc_cur, a->fc, true, W, B, s, qf));
     } else {
         EXORL_TRY(a->fk.fork(s));               // target critic (td3_bc.py:126) and critic (td3_bc.py:130) forwards are independent
-        EXORL_TRY(net_forward(a->critic, Pt, a->sh_target, a->xc_next, W, B, a->ft, false, false, prec, a->fk.side(s)));
-        EXORL_TRY(net_forward(a->critic, Pc, a->sh_critic, a->xc_cur, W, B, a->fc, true, false, prec, s));
+        EXORL_TRY(net_forward(a->critic, Pt, a->sh_target, a->xc_next, W, B, a->ft, false, false, prec, a->fk.side(s), nullptr, qf));
+        EXORL_TRY(net_forward(a->critic, Pc, a->sh_critic, a->xc_cur, W, B, a->fc, true, false, prec, s, nullptr, qf));
         EXORL_TRY(a->fk.join(s));
     }
+    if (qf) EXORL_TRY(run_qhead(a, 0, s));       // Q, Q', TD gradient, dz2 and head partials in one kernel
     if (a->want_metrics)
         EXORL_TRY(critic_loss(a->fc.out, a->ft.out, a->reward, a->discount, a->dq, a->metrics, B, a->inv_bg, s));   // :133-137
     DoutSpec td{};                              // d(2 x MSE)/dQ computed where it is consumed (:127-131)
     td.mode = EXORL_DOUT_TD; td.q = a->fc.out; td.tq = a->ft.out; td.reward = a->reward; td.discount = a->discount; td.inv_bg = a->inv_bg;
     EXORL_TRY(net_backward(a->critic, Pc, a->sh_critic, a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD], a->pc, a->xc_cur, W, B, a->fc, td,
-                           a->bc, nullptr, 0, 0, prec, s, a->fk, a->fuse_opt ? &a->pend_c : nullptr));                           // :141
+                           a->bc, nullptr, 0, 0, prec, s, a->fk, a->fuse_opt ? &a->pend_c : nullptr, qf));                       // :141
     return 0;
 }
 
@@ -519,8 +552,10 @@ static int phase1(exorl_agent* a, float stddev, const float* noise_a, hipStream_
     if (cfg.kind == EXORL_AGENT_DDPG && a->want_metrics)
         EXORL_TRY(sample_action(a->fa.out + (int64_t)B * A, noise_spec(a, noise_a, 1), stddev, cfg.stddev_clip, 1, a->xc_pi + O, W, B, A,
                                 a->metrics + EXORL_M_ACTOR_LOGPROB, s));
-    EXORL_TRY(net_forward(a->critic, a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->sh_critic, a->xc_pi, W, B, a->fc, true, false, prec, s));
-    EXORL_TRY(actor_stats(a->fc.out, a->stats, B, s));
+    const bool qf = qfuse(a);
+    EXORL_TRY(net_forward(a->critic, a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->sh_critic, a->xc_pi, W, B, a->fc, true, false, prec, s,
+                          nullptr, qf));
+    if (!qf) EXORL_TRY(actor_stats(a->fc.out, a->stats, B, s));
     return 0;
 }
 
@@ -533,8 +568,10 @@ static int phase2(exorl_agent* a, float stddev, hipStream_t s) {
         DoutSpec dq{};                          // -lambda/Bg routed to the smaller Q (td3_bc.py:152-155)
         dq.mode = EXORL_DOUT_ACTOR_Q; dq.q = a->fc.out; dq.stats = a->stats; dq.inv_bg = a->inv_bg; dq.alpha = cfg.alpha;
         dq.use_lambda = cfg.kind == EXORL_AGENT_TD3_BC;
+        const bool qf = qfuse(a);
+        if (qf) EXORL_TRY(run_qhead(a, 1, s));   // Q(s, pi(s)), its min-routing gradient (lambda applied later), dz2, sum|Q| partials
         EXORL_TRY(net_backward(a->critic, a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->sh_critic, nullptr, a->pc, a->xc_pi, W, B, a->fc,
-                               dq, a->bc, a->da, O, A, prec, s, a->fk));
+                               dq, a->bc, a->da, O, A, prec, s, a->fk, nullptr, qf));
     }
     // the obs half (rows B..2B) of the stacked actor forward
     FwdBufs f{a->fa.h1 + (int64_t)B * H, a->fa.xhat + (int64_t)B * H, a->fa.rstd + B, a->fa.h2 + (int64_t)B * H,
@@ -549,6 +586,9 @@ static int phase2(exorl_agent* a, float stddev, hipStream_t s) {
     DoutSpec dm{};
     dm.mode = EXORL_DOUT_ACTOR_MU; dm.da = a->da; dm.da_nets = a->has_critic ? a->critic.n_trunks : 0; dm.mu = f.out; dm.a_data = a->action;
     dm.kind = cfg.kind; dm.inv_bg = a->inv_bg; dm.stddev = stddev; dm.w = a->crr_w;
+    if (qfuse(a)) {                             // lambda = alpha / mean|Q| from the per-chunk sums qhead left behind
+        dm.lam_parts = a->abs_part; dm.lam_chunks = qhead_chunks(B); dm.use_lambda = cfg.kind == EXORL_AGENT_TD3_BC; dm.alpha = cfg.alpha;
+    }
     EXORL_TRY(net_backward(a->actor, Pa, a->sh_actor, a->flat[EXORL_NET_ACTOR][EXORL_T_GRAD], a->pa, a->xa + (int64_t)B * O, O, B, f,
                            dm, a->ba, nullptr, 0, 0, prec, s, a->fk, a->fuse_opt ? &a->pend_a : nullptr));
     return 0;

@@ -657,7 +657,7 @@ int head_fwd4(const float* a, const float* W, const float* b, float* out, int ro
 // P layout per (net, chunk): [dW nout*H][db_hidden H][db_out 16]
 constexpr int HB_ROWS = 8;
 // d(loss)/d(head output) for row m, output j of net `net` (see DoutSpec)
-__device__ __forceinline__ float dout_value(const DoutSpec& d, int net, int m, int j, int rows, int nout) {
+__device__ __forceinline__ float dout_value(const DoutSpec& d, int net, int m, int j, int rows, int nout, float lam = 1.0f) {
     if (d.mode == EXORL_DOUT_BUFFER) return d.buf[((int64_t)net * rows + m) * nout + j];
     if (d.mode == EXORL_DOUT_CQL_ACTOR) {
         // actor_loss = (alpha*log_pi - Q).mean() over (B,A), y = tanh(x), x = mu + std z  (cql.py:236-255). With
@@ -699,6 +699,7 @@ __device__ __forceinline__ float dout_value(const DoutSpec& d, int net, int m, i
     } else {
         dmu = 0.f;
         for (int t = 0; t < d.da_nets; ++t) dmu += d.da[((int64_t)t * rows + m) * nout + j];
+        dmu *= lam;
         if (d.kind == EXORL_AGENT_TD3_BC) dmu += 2.0f * d.inv_bg / (float)nout * (mv - d.a_data[i]);
     }
     return dmu * (1.0f - mv * mv);
@@ -710,13 +711,25 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const DoutSpec dspec, con
                                                        unsigned short* __restrict__ dzb, float* __restrict__ P, int rows,
                                                        int H, int nout, int64_t astride, int64_t pstride, int want_params) {
     __shared__ float ds[HB_ROWS * 16];
+    __shared__ float lam_s[5];
     const int net = blockIdx.y;
     const int row0 = blockIdx.x * HB_ROWS;
     const int c4 = threadIdx.x;
     const int H4 = H >> 2;
+    float lam = 1.0f;
+    if (dspec.mode == EXORL_DOUT_ACTOR_MU && dspec.lam_parts && dspec.use_lambda) {     // lambda = alpha / mean |min(Q1,Q2)| (td3_bc.py:154)
+        float sabs = 0.f;
+        for (int i = threadIdx.x; i < dspec.lam_chunks; i += blockDim.x) sabs += dspec.lam_parts[2 * i];
+        sabs = wave_sum(sabs);
+        if ((threadIdx.x & 63) == 0) lam_s[threadIdx.x >> 6] = sabs;
+        __syncthreads();
+        if (threadIdx.x == 0) lam_s[4] = dspec.alpha / (((lam_s[0] + lam_s[1]) + (lam_s[2] + lam_s[3])) * dspec.inv_bg);
+        __syncthreads();
+        lam = lam_s[4];
+    }
     if (threadIdx.x < HB_ROWS * 16) {
         const int r = threadIdx.x >> 4, j = threadIdx.x & 15;
-        ds[threadIdx.x] = (row0 + r < rows && j < nout) ? dout_value(dspec, net, row0 + r, j, rows, nout) : 0.f;
+        ds[threadIdx.x] = (row0 + r < rows && j < nout) ? dout_value(dspec, net, row0 + r, j, rows, nout, lam) : 0.f;
     }
     __syncthreads();
     const int64_t nh = (int64_t)(nout + 1) * H + 16;
@@ -844,6 +857,123 @@ int head_bwd_wide(const DoutSpec& dspec, const float* W, const float* a, float* 
 }
 
 int head_chunks(int rows) { return cdiv(rows, HB_ROWS); }
+
+// ------------------------------------------------------------------------------------------------
+constexpr int QH_ROWS = 4;      // rows per workgroup: 256 workgroups at B = 1024 (8 rows left half the CUs idle and cost 17.6 us)
+// scalar critic heads forward + backward (see QHeadArgs). One workgroup per chunk of QH_ROWS rows, thread = 4 consecutive
+// columns of both critic nets; the h2 rows read for the dot products stay in registers for the dz2 pass.
+__global__ __launch_bounds__(256) void qhead_kernel(const QHeadArgs g) {
+    __shared__ float part[4][4 * QH_ROWS];      // [wave][net * QH_ROWS + r]
+    __shared__ float dq[2 * QH_ROWS];
+    const int row0 = blockIdx.x * QH_ROWS;
+    const int c4 = threadIdx.x, H = g.H, H4 = H >> 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nr = g.rows - row0 < QH_ROWS ? g.rows - row0 : QH_ROWS;
+    const int nn = g.mode == 0 ? 4 : 2;
+    const bool on = c4 < H4;
+    float4 avs[2][QH_ROWS];
+    float4 w[2];
+    float dots[4 * QH_ROWS];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        if (n >= nn) {
+#pragma unroll
+            for (int r = 0; r < QH_ROWS; ++r) dots[n * QH_ROWS + r] = 0.f;
+            continue;
+        }
+        const float4 wv = on ? reinterpret_cast<const float4*>(g.W[n])[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < 2) w[n] = wv;
+        float4 t[QH_ROWS];
+#pragma unroll
+        for (int r = 0; r < QH_ROWS; ++r)
+            t[r] = (on && r < nr) ? reinterpret_cast<const float4*>(g.a[n] + (int64_t)(row0 + r) * H)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < QH_ROWS; ++r) {
+            dots[n * QH_ROWS + r] = (t[r].x * wv.x + t[r].y * wv.y) + (t[r].z * wv.z + t[r].w * wv.w);
+            if (n < 2) avs[n][r] = t[r];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4 * QH_ROWS; ++i) {
+        const float v = wave_sum(dots[i]);
+        if (lane == 0) part[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 * QH_ROWS) {             // thread i owns (net, row) = (i / QH_ROWS, i % QH_ROWS)
+        const int n = threadIdx.x / QH_ROWS, r = threadIdx.x % QH_ROWS;
+        if (n < nn && r < nr) {
+            const float v = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x])) + g.b[n][0];
+            part[0][threadIdx.x] = v;
+            (n < 2 ? g.q : g.tq)[(int64_t)(n & 1) * g.rows + row0 + r] = v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * QH_ROWS) {
+        const int n = threadIdx.x / QH_ROWS, r = threadIdx.x % QH_ROWS;
+        float d = 0.f;
+        if (r < nr) {
+            const float q1 = part[0][r], q2 = part[0][QH_ROWS + r];
+            if (g.mode == 0) {
+                const float y = g.reward[row0 + r] + g.discount[row0 + r] * fminf(part[0][2 * QH_ROWS + r], part[0][3 * QH_ROWS + r]);
+                d = 2.0f * ((n == 0 ? q1 : q2) - y) * g.inv_bg;
+            } else {
+                const float w1 = q1 < q2 ? 1.0f : (q1 == q2 ? 0.5f : 0.0f);
+                d = -g.inv_bg * (n == 0 ? w1 : 1.0f - w1);
+            }
+        }
+        dq[threadIdx.x] = d;
+    }
+    if (g.mode == 1 && threadIdx.x == 0) {
+        float sa = 0.f, sm = 0.f;
+        for (int r = 0; r < nr; ++r) { const float m = fminf(part[0][r], part[0][QH_ROWS + r]); sa += fabsf(m); sm += m; }
+        g.abs_part[2 * blockIdx.x] = sa;
+        g.abs_part[2 * blockIdx.x + 1] = sm;
+    }
+    __syncthreads();
+    const int64_t nh = 2 * (int64_t)H + 16;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        float* Pn = g.P ? g.P + ((int64_t)n * gridDim.x + blockIdx.x) * nh : nullptr;
+        if (Pn && threadIdx.x == 0) {
+            float sj = 0.f;
+            for (int r = 0; r < QH_ROWS; ++r) sj += dq[n * QH_ROWS + r];
+            Pn[2 * (int64_t)H] = sj;
+        }
+        if (!on) continue;
+        float4 pw = make_float4(0.f, 0.f, 0.f, 0.f), pb = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < QH_ROWS; ++r) {
+            if (r >= nr) break;
+            const float d = dq[n * QH_ROWS + r];
+            const float4 av = avs[n][r];
+            pw.x += d * av.x; pw.y += d * av.y; pw.z += d * av.z; pw.w += d * av.w;
+            float4 v;
+            v.x = av.x > 0.f ? d * w[n].x : 0.f; v.y = av.y > 0.f ? d * w[n].y : 0.f;
+            v.z = av.z > 0.f ? d * w[n].z : 0.f; v.w = av.w > 0.f ? d * w[n].w : 0.f;
+            const int64_t o = n * g.act + (int64_t)(row0 + r) * H;
+            if (g.dz) reinterpret_cast<float4*>(g.dz + o)[c4] = v;
+            if (g.dzb) {
+                ushort4 u;
+                u.x = f2bf(v.x); u.y = f2bf(v.y); u.z = f2bf(v.z); u.w = f2bf(v.w);
+                reinterpret_cast<ushort4*>(g.dzb + o)[c4] = u;
+            }
+            pb.x += v.x; pb.y += v.y; pb.z += v.z; pb.w += v.w;
+        }
+        if (Pn) {
+            reinterpret_cast<float4*>(Pn)[c4] = pw;
+            reinterpret_cast<float4*>(Pn + H)[c4] = pb;
+        }
+    }
+}
+
+int qhead_chunks(int rows) { return cdiv(rows, QH_ROWS); }
+
+int qhead(const QHeadArgs& q, hipStream_t s) {
+    EXORL_REQUIRE(q.H % 4 == 0 && q.H <= 1024 && q.rows > 0 && (q.mode == 0 || q.mode == 1), "qhead: unsupported H=%d rows=%d", q.H, q.rows);
+    hipLaunchKernelGGL(qhead_kernel, dim3(cdiv(q.rows, QH_ROWS)), dim3(256), 0, s, q);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
 
 // ------------------------------------------------------------------------------------------------
 // finalize: sums the per-chunk partials in chunk order and scatters into the flat gradient buffer.

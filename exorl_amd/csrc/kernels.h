@@ -99,6 +99,8 @@ struct DoutSpec {
     const float *raw, *z;    // CQL_ACTOR: actor head outputs (rows, 2A) [mu_raw | log_std_raw]; rsample noise (rows, A) or null
     const float* alpha_ptr;  // CQL_ACTOR: exp(log_actor_alpha) after its optimiser step (device scalar)
     uint64_t seed, counter; const uint64_t* counter_ptr;   // Philox identity of z when z == nullptr
+    const float* lam_parts;  // ACTOR_MU after qhead(ACTOR): per-chunk [sum |min Q|, sum min Q]; lambda = alpha / mean|Q| is applied here
+    int lam_chunks;          //   (the critic backward is linear in its output gradient, so it ran with lambda = 1)
     int da_nets;
     int kind;                // EXORL_AGENT_*
     int use_lambda;
@@ -107,6 +109,24 @@ struct DoutSpec {
 int head_bwd(const DoutSpec& dspec, const float* W, const float* a, float* dz, unsigned short* dz_bf16, float* P, int rows,
              int H, int nout, int nets, int64_t astride, int64_t pstride, int want_params, hipStream_t s);
 int head_chunks(int rows);
+// Scalar critic heads, forward and backward in one kernel (single-GPU whole-step path, no metrics): Q1,Q2 (and the target's
+// Q1',Q2') row dots, the loss gradient at the head output, dz2 = dQ * W2 * [h2 > 0] and the per-chunk parameter partials.
+//   mode 0 (critic step, td3_bc.py:126-131): dQ_n = 2 (Q_n - (r + D min(Q1',Q2'))) * inv_bg
+//   mode 1 (actor step, td3_bc.py:152-155):  dQ_n = -inv_bg * [Q_n is the min] (0.5 on ties); per-chunk sum|min Q|, sum min Q -> abs_part
+struct QHeadArgs {
+    const float* a[4];       // h2 rows of critic net 0, 1 and (mode 0) target net 0, 1
+    const float* W[4];
+    const float* b[4];
+    float *q, *tq;           // (2, rows) outputs
+    const float *reward, *discount;
+    float* dz; unsigned short* dzb; int64_t act;
+    float* P;                // head partials [net][chunk][(1+1)H + 16] or null
+    float* abs_part;         // [chunk][2]
+    int rows, H, mode;
+    float inv_bg;
+};
+int qhead(const QHeadArgs& q, hipStream_t s);
+int qhead_chunks(int rows);     // partial rows qhead writes per net (finer than head_chunks)
 struct FinalizeArgs {
     const float* Ph; int head_chunks; int n_heads; int64_t head_stride;    // head partials; stride between heads in G
     int64_t gW2, gb1, gb2;                                                 // offsets of head 0's tensors in G

@@ -355,3 +355,30 @@ def test_cql_act_and_graph():
         assert m1 == m2, (s, m1, m2)
     for p, q in zip(a1.actor.parameters(), a2.actor.parameters()):
         assert torch.equal(p, q)
+
+
+@pytest.mark.parametrize('kind,precision', [('td3_bc', 'fp32'), ('td3', 'fp32'), ('ddpg', 'fp32'), ('td3_bc', 'bf16')])
+def test_no_metrics_fast_path_matches_metrics_path(kind, precision):
+    """use_tb=False takes the fused scalar-head kernels (Q forward + loss gradient + dz2 in one launch, lambda applied after
+    the critic's linear backward) — same arithmetic as the metric-producing path up to rounding; also through the captured graph."""
+    O, A, H, B = 24, 6, 256, 64
+    agents_ = []
+    for use_tb, graph in ((True, False), (False, False), (False, True)):
+        torch.manual_seed(3)
+        ag = make(kind, O, A, H, B, use_tb=use_tb, precision=precision)
+        e, it = _arena(9)
+        if graph:
+            assert ag.enable_graph(it)
+        else:
+            it.sample_into(ag.engine.batch_slots())
+        for s in ([0, 2, 4] if kind == 'ddpg' else [0, 1, 2]):
+            ag.update(it, s)
+        agents_.append(ag)
+    ref, fast, fast_graph = agents_
+    for (n1, net1), (_, net2), (_, net3) in zip(nets_of(ref), nets_of(fast), nets_of(fast_graph)):
+        for p, q, r in zip(net1.parameters(), net2.parameters(), net3.parameters()):
+            assert torch.equal(q, r), n1                                    # graph replay == eager launches of the fast path
+            d = (p - q).abs()
+            tol = 2e-6 + 1e-5 * p.abs() if precision == 'fp32' else 2e-3 + 0 * p
+            # Adam moves an element whose gradient is rounding noise by +-lr per step either way: allow a few such elements
+            assert float((d > tol).float().mean()) <= 5e-3 and float(d.max()) <= 6.5e-4, (kind, n1, float(d.max()))
