@@ -262,7 +262,38 @@ struct Gemm16Batch {
     int accumulate;
     int swizzle;      // 1: XCD-aware tile order (blocks that share an XCD take neighbouring tiles)
     int a_t[4];       // mixed-layout launch (gemm16g_mixed_kernel): problem i reads A as a k image (layout 1)
+    int xcd_map;      // 1: 1-D grid, workgroup id -> (problem, tile) so that each XCD owns a compact block of one problem's output
+    int count;
 };
+
+// Workgroups are dealt to the 8 XCDs round-robin by linear id and every XCD has its own L2, so what an XCD's tiles touch is
+// fetched once per XCD over the fabric. With tile order following the id, an XCD ends up needing every problem's whole B
+// operand (PMC: 39 MB of fabric reads for a launch whose operands total 12 MB). This mapping gives XCD x = id & 7 the problem
+// x / (8/count) and, inside it, one block of an (sm x sn) split of the output, walked row-major by id >> 3: per XCD only a
+// 1/sm slice of A and a 1/sn slice of B of ONE problem.
+struct XcdTile { int p, tm, tn; bool ok; };
+__device__ __forceinline__ XcdTile xcd_tile(int id, int count, int tiles_m, int tiles_n) {
+    const int X = 8 / count;                       // XCDs per problem (count in {1, 2, 4})
+    const int sm = X == 8 ? 4 : 2, sn = X == 2 ? 1 : 2;
+    const int xcd = id & 7, slot = id >> 3;
+    const int xq = xcd % X;
+    const int bm = tiles_m / sm, bn = tiles_n / sn;
+    XcdTile t;
+    t.p = xcd / X;
+    t.tm = (xq / sn) * bm + slot / bn;
+    t.tn = (xq % sn) * bn + slot % bn;
+    t.ok = slot < bm * bn;
+    return t;
+}
+static bool xcd_map_ok(const Gemm16Batch& gb, int count, int tile) {
+    if (!(count == 1 || count == 2 || count == 4)) return false;
+    const int X = 8 / count, sm = X == 8 ? 4 : 2, sn = X == 2 ? 1 : 2;
+    for (int i = 0; i < count; ++i) {
+        if (gb.p[i].M != gb.p[0].M || gb.p[i].N != gb.p[0].N) return false;
+        if ((gb.p[i].M / tile) % sm != 0 || (gb.p[i].N / tile) % sn != 0) return false;
+    }
+    return true;
+}
 static int g_gemm16_variant = -1;    // experiment switch (exorl_gemm_tune): -1 = default heuristics
 
 template <int AL, int BL, int BM, int NS, bool GUARD>
@@ -408,15 +439,21 @@ __device__ __forceinline__ void gemm16g_body(const Gemm16Batch& gb, unsigned cha
     constexpr int NSTG = G16G_NSTG;
     constexpr int IMG = G16G_IMG;
 
-    const Gemm16Problem& P = gb.p[blockIdx.z];
-    const int M = P.M, N = P.N, K = P.K;
-    const int tiles_n = N >> 6, tiles_m = M >> 6;
-    const int ntiles = tiles_n * tiles_m;
-    if ((int)blockIdx.x >= ntiles) return;
-    int tile = blockIdx.x;
-    if (gb.swizzle && (ntiles & 7) == 0) tile = (tile & 7) * (ntiles >> 3) + (tile >> 3);
-    const int m0 = (tile / tiles_n) << 6;
-    const int n0 = (tile % tiles_n) << 6;
+    int pidx = blockIdx.z, m0, n0;
+    if (gb.xcd_map) {
+        const XcdTile xt = xcd_tile(blockIdx.x, gb.count, gb.p[0].M >> 6, gb.p[0].N >> 6);
+        if (!xt.ok) return;
+        pidx = xt.p; m0 = xt.tm << 6; n0 = xt.tn << 6;
+    } else {
+        const int tiles_n = gb.p[pidx].N >> 6, ntiles = tiles_n * (gb.p[pidx].M >> 6);
+        if ((int)blockIdx.x >= ntiles) return;
+        int tile = blockIdx.x;
+        if (gb.swizzle && (ntiles & 7) == 0) tile = (tile & 7) * (ntiles >> 3) + (tile >> 3);
+        m0 = (tile / tiles_n) << 6;
+        n0 = (tile % tiles_n) << 6;
+    }
+    const Gemm16Problem& P = gb.p[pidx];
+    const int K = P.K;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -536,6 +573,190 @@ __device__ __forceinline__ void gemm16g_body(const Gemm16Batch& gb, unsigned cha
     }
 }
 
+// ---- 128 x 128 workgroup tile (4 waves, each 64 x 64 = 2 x 2 MFMA sub-tiles) ------------------------------------------
+// The 64 x 64 kernel above re-reads every operand byte from LDS for 32 x 32 of output per wave: 8 KB of ds_read per 4 MFMAs,
+// twice what the CU's 128 B/clk LDS port can feed while the MFMAs run (PMC: the pipe is LDS-bound). A 64 x 64 wave tile reuses
+// each fragment twice (16 KB per 16 MFMAs: LDS and MFMA time balance) and halves the L2->LDS bytes per FLOP. An operand tile is
+// two of the 64-row images of the kernel above side by side (same swizzles, same fragment reads); 4 stages x 32 KB = 128 KB of
+// LDS, one workgroup per CU.
+constexpr int G16H_STAGE = 4 * G16G_IMG;           // A0 A1 B0 B1
+
+template <bool AT, bool BT, int NSTG>
+__device__ __forceinline__ void gemm16h_body(const Gemm16Batch& gb, unsigned char* smem) {
+    constexpr int IMG = G16G_IMG;
+    const Gemm16Problem& P = gb.p[blockIdx.z];
+    const int M = P.M, N = P.N, K = P.K;
+    const int tiles_n = N >> 7, tiles_m = M >> 7;
+    const int ntiles = tiles_n * tiles_m;
+    if ((int)blockIdx.x >= ntiles) return;
+    int tile = blockIdx.x;
+    if (gb.swizzle && (ntiles & 7) == 0) tile = (tile & 7) * (ntiles >> 3) + (tile >> 3);
+    const int m0 = (tile / tiles_n) << 7;
+    const int n0 = (tile % tiles_n) << 7;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5;
+    const int nk = K >> 6;                         // multiple of NSTG (checked by the launcher)
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    // DMA source pointers: for each of the 4 images this wave's two 1-KB pieces (image rows 16*wave + 8j + lane/8)
+    const unsigned short* src[8];
+    int64_t kstep[2];
+#pragma unroll
+    for (int img = 0; img < 2; ++img)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int rr = 16 * wave + 8 * j + (lane >> 3), p = lane & 7;
+            const int ma = m0 + 64 * img, nb = n0 + 64 * img;
+            if constexpr (!AT) src[2 * img + j] = P.A + (int64_t)(ma + rr) * P.lda + 8 * (p ^ ((rr >> 1) & 7));
+            else               src[2 * img + j] = P.A + (int64_t)rr * P.lda + ma + 8 * (p ^ (4 * ((rr >> 1) & 1)));
+            if constexpr (!BT) src[4 + 2 * img + j] = P.B + (int64_t)(nb + rr) * P.ldb + 8 * (p ^ ((rr >> 1) & 7));
+            else               src[4 + 2 * img + j] = P.B + (int64_t)rr * P.ldb + nb + 8 * (p ^ (4 * ((rr >> 1) & 1)));
+        }
+    kstep[0] = AT ? 64 * P.lda : 64;
+    kstep[1] = BT ? 64 * P.ldb : 64;
+    const int piece = 16 * wave * ROWB;
+
+    const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    auto tr_off = [&](int rbase) {
+        const int c = rbase + 16 * (g & 1) + 4 * pp;
+        return (8 * (g >> 1) + qq) * ROWB + (((c >> 3) ^ (4 * ((qq >> 1) & 1))) << 4) + ((c & 7) << 1);
+    };
+    int aoff[2][4], boff[2][4];                    // [sub-tile][q]: fragment offsets inside this wave's A / B image
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            aoff[t][q] = AT ? tr_off(t * 32) + q * 16 * ROWB : lds_off(t * 32 + (lane & 31), 2 * q + h);
+            boff[t][q] = BT ? tr_off(t * 32) + q * 16 * ROWB : lds_off(t * 32 + (lane & 31), 2 * q + h);
+        }
+
+    auto fill = [&](auto sc) {
+        constexpr int st = decltype(sc)::value;
+        unsigned char* base = smem + st * G16H_STAGE + piece;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {              // images A0 A1 B0 B1
+            __builtin_amdgcn_global_load_lds((const void*)src[2 * i], (lds_void*)(base + i * IMG), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)src[2 * i + 1], (lds_void*)(base + i * IMG + 8 * ROWB), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { src[i] += kstep[0]; src[4 + i] += kstep[1]; }
+    };
+    auto frag = [&](const unsigned char* img, bool tr, int off) -> bf16x8 {
+        if (!tr) return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(img + off));
+        const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(img + off));
+        const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(img + off + 4 * ROWB));
+        typedef short v8s16 __attribute__((ext_vector_type(8)));
+        const v8s16 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    auto step = [&](auto sc, int t) {
+        constexpr int st = decltype(sc)::value;
+        // tile t has landed once at most the fills of the two younger tiles remain outstanding (8 DMA pieces per tile per wave)
+        const int younger = nk - 1 - t;            // NSTG - 2 younger tiles may still be in flight
+        if (NSTG >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (NSTG >= 3 && younger >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + NSTG - 1 < nk) fill(std::integral_constant<int, (st + NSTG - 1) % NSTG>{});
+        const unsigned char* As = smem + st * G16H_STAGE + wm * IMG;
+        const unsigned char* Bs = smem + st * G16H_STAGE + (2 + wn) * IMG;
+        bf16x8 af[2][4], bfr[2][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {              // q-major: the first MFMAs only wait for the first reads
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                af[u][q] = frag(As, AT, aoff[u][q]);
+                bfr[u][q] = frag(Bs, BT, boff[u][q]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][q], bfr[0][q], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][q], bfr[1][q], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][q], bfr[0][q], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][q], bfr[1][q], acc[1][1], 0, 0, 0);
+        }
+    };
+
+    fill(std::integral_constant<int, 0>{});
+    if constexpr (NSTG >= 3) fill(std::integral_constant<int, 1>{});
+    if constexpr (NSTG >= 4) fill(std::integral_constant<int, 2>{});
+    for (int t = 0; t < nk; t += NSTG) {
+        step(std::integral_constant<int, 0>{}, t);
+        step(std::integral_constant<int, 1>{}, t + 1);
+        if constexpr (NSTG >= 4) {
+            step(std::integral_constant<int, 2>{}, t + 2);
+            step(std::integral_constant<int, 3>{}, t + 3);
+        }
+    }
+
+    const bool relu = gb.relu != 0;
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            const int n = n0 + wn * 64 + tb * 32 + (lane & 31);
+            const float bias = P.bias ? P.bias[n] : 0.f;
+            float* crow = P.C + (int64_t)(m0 + wm * 64 + ta * 32 + 4 * h) * P.ldc + n;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float* dst = crow + (int64_t)((r & 3) + 8 * (r >> 2)) * P.ldc;
+                float v = acc[ta][tb][r] + bias;
+                if (relu) v = fmaxf(v, 0.f);
+                *dst = gb.accumulate ? v + *dst : v;
+            }
+        }
+}
+
+template <bool AT, bool BT, int NSTG>
+__global__ __launch_bounds__(256) void gemm16h_kernel(const Gemm16Batch gb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
+    gemm16h_body<AT, BT, NSTG>(gb, smem_h);
+}
+
+template <int NSTG>
+__global__ __launch_bounds__(256) void gemm16h_mixed_kernel(const Gemm16Batch gb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
+    if (gb.a_t[blockIdx.z]) gemm16h_body<true, true, NSTG>(gb, smem_h);
+    else gemm16h_body<false, true, NSTG>(gb, smem_h);
+}
+
+constexpr size_t G16H_LDS = (size_t)G16G_NSTG * G16H_STAGE;      // 128 KB at 4 stages; 64 KB at 2 (two workgroups per CU)
+static int g16h_stages() { return (g_gemm16_variant >= 0 && (g_gemm16_variant & 512)) ? 2 : 4; }
+template <int NSTG>
+static int g16h_enable_n() {          // > 64 KB of dynamic LDS needs the opt-in, once per kernel
+    static bool done = false;
+    if (done) return 0;
+    const int lds = NSTG * G16H_STAGE;
+    EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm16h_kernel<false, false, NSTG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm16h_kernel<false, true, NSTG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm16h_kernel<true, true, NSTG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm16h_mixed_kernel<NSTG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    done = true;
+    return 0;
+}
+static int g16h_enable() { return g16h_stages() == 2 ? g16h_enable_n<2>() : g16h_enable_n<4>(); }
+static bool g16h_fits(const Gemm16Batch& gb, int count) {
+    // measured slower than the 64 x 64 tiles on the 1024-wide layers (15-17 us vs 9-12 us per problem: one workgroup per CU leaves
+    // the k-tile chain wait -> barrier -> DMA issue -> LDS reads -> MFMA exposed): opt-in through tuning bit 1024
+    if (g_gemm16_variant < 0 || !(g_gemm16_variant & 1024)) return false;
+    for (int i = 0; i < count; ++i)
+        if (gb.p[i].M % 128 != 0 || gb.p[i].N % 128 != 0) return false;
+    return true;
+}
+
 template <bool AT, bool BT>
 __global__ __launch_bounds__(256) void gemm16g_kernel(const Gemm16Batch gb) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[G16G_NSTG * 2 * G16G_IMG];
@@ -547,7 +768,8 @@ __global__ __launch_bounds__(256) void gemm16g_kernel(const Gemm16Batch gb) {
 // (~4.5 us of drain + cache write-back + ramp on this part) disappears. B is a k image in both.
 __global__ __launch_bounds__(256) void gemm16g_mixed_kernel(const Gemm16Batch gb) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[G16G_NSTG * 2 * G16G_IMG];
-    if (gb.a_t[blockIdx.z]) gemm16g_body<true, true>(gb, smem);
+    const int p = gb.xcd_map ? (int)(blockIdx.x & 7) / (8 / gb.count) : (int)blockIdx.z;
+    if (gb.a_t[p]) gemm16g_body<true, true>(gb, smem);
     else gemm16g_body<false, true>(gb, smem);
 }
 
@@ -582,7 +804,18 @@ static int launch16(const Gemm16Batch& gb, int count, int tiles64, int tiles128,
         exact64 = exact64 && gb.p[i].M % 64 == 0 && gb.p[i].N % 64 == 0 && gb.p[i].K % 256 == 0 && gb.p[i].lda % 8 == 0 &&
                   gb.p[i].ldb % 8 == 0 && reinterpret_cast<uintptr_t>(gb.p[i].A) % 16 == 0 && reinterpret_cast<uintptr_t>(gb.p[i].B) % 16 == 0;
     if (exact64 && !(var & 128)) {         // LDS-DMA pipeline (bit 128 of the tuning variant forces the register-staged kernels)
-        hipLaunchKernelGGL((gemm16g_kernel<AL != 0, BL != 0>), dim3(tiles64, 1, count), dim3(256), 0, s, g2);
+        if (g16h_fits(g2, count)) {
+            EXORL_TRY(g16h_enable());
+            int t128 = 0;
+            for (int i = 0; i < count; ++i) { const int t = (gb.p[i].M >> 7) * (gb.p[i].N >> 7); t128 = t > t128 ? t : t128; }
+            if (g16h_stages() == 2) hipLaunchKernelGGL((gemm16h_kernel<AL != 0, BL != 0, 2>), dim3(t128, 1, count), dim3(256), 2 * G16H_STAGE, s, g2);
+            else hipLaunchKernelGGL((gemm16h_kernel<AL != 0, BL != 0, 4>), dim3(t128, 1, count), dim3(256), G16H_LDS, s, g2);
+        } else {
+            g2.count = count;
+            g2.xcd_map = ((var & 2048) && xcd_map_ok(g2, count, 64)) ? 1 : 0;     // measured: no gain over id order (12.8 vs 12.5 us) -> opt-in
+            if (g2.xcd_map) hipLaunchKernelGGL((gemm16g_kernel<AL != 0, BL != 0>), dim3(tiles64 * count, 1, 1), dim3(256), 0, s, g2);
+            else hipLaunchKernelGGL((gemm16g_kernel<AL != 0, BL != 0>), dim3(tiles64, 1, count), dim3(256), 0, s, g2);
+        }
         EXORL_LAUNCH_CHECK();
         if (prof) {
             EXORL_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s));
@@ -643,7 +876,18 @@ int gemm16_grouped_mixed(const int* a_layouts, const Gemm16Problem* probs, int c
         g_prof.flops.push_back(flops);
         EXORL_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.used], s));
     }
-    hipLaunchKernelGGL(gemm16g_mixed_kernel, dim3(t64, 1, count), dim3(256), 0, s, gb);
+    if (g16h_fits(gb, count)) {
+        EXORL_TRY(g16h_enable());
+        int t128 = 0;
+        for (int i = 0; i < count; ++i) { const int t = (gb.p[i].M >> 7) * (gb.p[i].N >> 7); t128 = t > t128 ? t : t128; }
+        if (g16h_stages() == 2) hipLaunchKernelGGL(gemm16h_mixed_kernel<2>, dim3(t128, 1, count), dim3(256), 2 * G16H_STAGE, s, gb);
+        else hipLaunchKernelGGL(gemm16h_mixed_kernel<4>, dim3(t128, 1, count), dim3(256), G16H_LDS, s, gb);
+    } else {
+        gb.count = count;
+        gb.xcd_map = (g_gemm16_variant >= 0 && (g_gemm16_variant & 2048) && xcd_map_ok(gb, count, 64)) ? 1 : 0;
+        if (gb.xcd_map) hipLaunchKernelGGL(gemm16g_mixed_kernel, dim3(t64 * count, 1, 1), dim3(256), 0, s, gb);
+        else hipLaunchKernelGGL(gemm16g_mixed_kernel, dim3(t64, 1, count), dim3(256), 0, s, gb);
+    }
     EXORL_LAUNCH_CHECK();
     if (prof) {
         EXORL_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s));

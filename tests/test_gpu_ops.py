@@ -56,7 +56,8 @@ def test_gemm(lib, prec, al, bl, M, N, K):
 
 
 @pytest.mark.parametrize('al,bl', [(0, 0), (0, 1), (1, 1)])
-@pytest.mark.parametrize('M,N,K', [(64, 64, 64), (128, 64, 32), (1024, 1024, 1024), (2048, 1024, 1024), (96, 200, 72), (8, 32, 8)])
+@pytest.mark.parametrize('M,N,K', [(64, 64, 64), (128, 64, 32), (1024, 1024, 1024), (2048, 1024, 1024), (96, 200, 72), (8, 32, 8),
+                                   (256, 384, 512), (128, 128, 256), (192, 128, 256)])
 def test_gemm_bf16_operands(lib, al, bl, M, N, K):
     """Fast-mode kernel: operands already bf16 in memory; exact up to fp32 accumulation order."""
     from exorl_amd import _lib as L
