@@ -60,3 +60,34 @@ def test_tiny_unsup_trajectory(gold, kind):
         np.testing.assert_allclose(ag.module.running_mean, z['final/rnd/normalize_obs.running_mean'], rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(ag.module.running_var, z['final/rnd/normalize_obs.running_var'], rtol=1e-5, atol=1e-6)
         assert ag.module.num_batches == int(z['final/rnd/normalize_obs.num_batches_tracked'])
+
+
+def test_tiny_proto_trajectory(gold):
+    from oracle.proto import OracleProto, OracleProtoAgent, proto_param_shapes, uniform_from_normal, sinkhorn_knopp
+    z = np.load(gold / 'tiny_proto.npz')
+    ash, csh = param_shapes('ddpg', O, A, H)
+    ddpg = OracleAgent('ddpg', [z[f'init/actor/{k}'] for k, _ in ash], [z[f'init/critic/{k}'] for k, _ in csh])
+    psh = proto_param_shapes(O, 8, 16, 6)
+    params = [z['init/' + k.replace('predictor.', 'predictor/').replace('projector.', 'projector/').replace('protos.', 'protos/')] for k, _ in psh]
+    for (k, s), p in zip(psh, params):
+        assert tuple(p.shape) == tuple(s), (k, p.shape, s)
+    ag = OracleProtoAgent(ddpg, OracleProto(params, queue_size=24))
+    keys = [str(k) for k in z['metric_keys']]
+    for i in range(5):
+        batch = [z[f'batch/{i}/{j}'] for j in range(5)]
+        assert ag.update(batch, 2 * i + 1, None, None, None) == {}
+        m = ag.update(batch, 2 * i, uniform_from_normal(z[f'noise/{3 * i}']), z[f'noise/{3 * i + 1}'], z[f'noise/{3 * i + 2}'])
+        np.testing.assert_allclose(ag.last_intr, z['intr_reward'][i], rtol=2e-5, atol=2e-6, err_msg=f'intr step {i}')
+        got = np.array([m[k] for k in keys])
+        np.testing.assert_allclose(got, z['metrics'][i], rtol=5e-5, atol=2e-6, err_msg=f'step {i} {keys}')
+    fin = {'predictor.weight': 'predictor/weight', 'predictor.bias': 'predictor/bias', 'projector.trunk.0.weight': 'projector/trunk.0.weight',
+           'projector.trunk.0.bias': 'projector/trunk.0.bias', 'projector.trunk.2.weight': 'projector/trunk.2.weight',
+           'projector.trunk.2.bias': 'projector/trunk.2.bias', 'protos.weight': 'protos/weight'}
+    for (k, _), p in zip(psh, ag.module.p):
+        np.testing.assert_allclose(p, z['final/' + fin[k]], rtol=1e-4, atol=2e-6, err_msg=k)
+    np.testing.assert_allclose(ag.module.pt[0], z['final/predictor_target/weight'], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(ag.module.queue, z['final/queue'], rtol=1e-5, atol=1e-6)
+    assert ag.module.queue_ptr == int(z['final/queue_ptr'])
+    # sinkhorn: every sample's assignment sums to 1, prototypes are used equally up to the last column normalisation
+    q = sinkhorn_knopp(np.random.RandomState(0).standard_normal((32, 6)).astype(np.float32) * 3)
+    np.testing.assert_allclose(q.sum(1), 1.0, rtol=1e-5)

@@ -197,6 +197,10 @@ def make_agent(ref, kind, O, A, H, B, device='cpu', use_tb=True, **kw):
         return ref.rnd.RNDAgent(rnd_rep_dim=kw.get('rep_dim', 16), update_encoder=True, rnd_scale=1.0, **ddpg_kw)
     if kind == 'icm':          # configs/agent/icm.yaml: icm_scale 1.0
         return ref.icm.ICMAgent(icm_scale=1.0, update_encoder=True, **ddpg_kw)
+    if kind == 'proto':        # configs/agent/proto.yaml: pred_dim 128, proj_dim 512, queue 2048, 512 protos, tau 0.1, topk 3 (tiny: 8/16/24/6)
+        return ref.proto.ProtoAgent(pred_dim=kw.get('pred_dim', 8), proj_dim=kw.get('proj_dim', 16), queue_size=kw.get('queue_size', 24),
+                                    num_protos=kw.get('num_protos', 6), tau=0.1, encoder_target_tau=0.05, topk=3, update_encoder=True,
+                                    **ddpg_kw)
     if kind == 'disagreement':
         return ref.disagreement.DisagreementAgent(update_encoder=True, **ddpg_kw)
     if kind == 'diayn':        # configs/agent/diayn.yaml: skill_dim 16, diayn_scale 1.0, update_skill_every_step 50 (tiny: 4 skills)
@@ -214,7 +218,7 @@ def nets_of(agent):
     # (CQL's log_actor_alpha / log_critic_alpha scalars are stored separately by gen_tiny)
     if hasattr(agent, 'critic'):
         nets += [('critic', agent.critic), ('critic_target', agent.critic_target)]
-    for nm in ('rnd', 'icm', 'disagreement', 'diayn'):            # intrinsic-reward modules of the DDPG-backbone agents
+    for nm in ('rnd', 'icm', 'disagreement', 'diayn', 'predictor', 'predictor_target', 'projector', 'protos'):            # intrinsic-reward modules of the DDPG-backbone agents
         if hasattr(agent, nm):
             nets.append((nm, getattr(agent, nm)))
     return nets
@@ -241,6 +245,18 @@ def run_agent(ref, agent, kind, nsteps, batch_fn, noise, dtype):
         u = 0.5 * (1.0 + np.vectorize(math.erf)(z / math.sqrt(2.0)))
         self.copy_(torch.from_numpy(lo + (hi - lo) * u).to(self.dtype))
         return self
+    import torch.distributions as pyd
+    o_cat = pyd.Categorical.sample
+
+    def p_cat(self, sample_shape=torch.Size()):
+        # Categorical(prob).sample() (proto.py:103) by inverse CDF on uniforms made from the deterministic stream
+        z = noise.draw((self.probs.shape[0],)).astype(np.float64)
+        u = 0.5 * (1.0 + np.vectorize(math.erf)(z / math.sqrt(2.0)))
+        cdf = torch.cumsum(self.probs.double(), dim=1).numpy()
+        idx = [min(int(np.searchsorted(cdf[i], u[i] * cdf[i, -1], side='right')), cdf.shape[1] - 1) for i in range(len(u))]
+        return torch.tensor(idx, dtype=torch.long)
+    if kind == 'proto':
+        pyd.Categorical.sample = p_cat
     if kind == 'cql':
         torch.normal, torch.Tensor.uniform_ = p_normal, p_uniform
         tdn._standard_normal = lambda shape, dtype, device: torch.from_numpy(noise.draw(shape)).to(dtype)
@@ -254,6 +270,7 @@ def run_agent(ref, agent, kind, nsteps, batch_fn, noise, dtype):
     finally:
         U._standard_normal = orig
         torch.normal, torch.Tensor.uniform_, tdn._standard_normal = o_normal, o_uniform, o_sn
+        pyd.Categorical.sample = o_cat
     return metrics
 
 
@@ -265,8 +282,8 @@ def checksums(agent):
     return cs
 
 
-UNSUP = ('ddpg', 'rnd', 'icm', 'icm_apt', 'disagreement', 'diayn')
-TINY_KINDS = ('td3_bc', 'td3', 'bc', 'ddpg', 'crr', 'crr-exp', 'crr-identity', 'cql', 'rnd', 'icm', 'icm_apt', 'icm_apt-kth', 'disagreement', 'diayn')
+UNSUP = ('ddpg', 'rnd', 'icm', 'icm_apt', 'disagreement', 'diayn', 'proto')
+TINY_KINDS = ('td3_bc', 'td3', 'bc', 'ddpg', 'crr', 'crr-exp', 'crr-identity', 'cql', 'rnd', 'icm', 'icm_apt', 'icm_apt-kth', 'disagreement', 'diayn', 'proto')
 
 
 def gen_tiny(ref):
@@ -320,6 +337,9 @@ def gen_tiny(ref):
                 out[f'final/{nm}/{k}'] = v.numpy().copy()
         if intr_log:
             out['intr_reward'] = np.stack(intr_log)
+        if base == 'proto':
+            out['final/queue'] = agent.queue.numpy().copy()
+            out['final/queue_ptr'] = np.array(agent.queue_ptr)
         rms = getattr(agent, 'intrinsic_reward_rms', None) or getattr(getattr(agent, 'pbe', None), 'rms', None)
         if rms is not None:
             out['final/rms'] = np.array([float(rms.M), float(rms.S), float(rms.n)], np.float64)
