@@ -20,7 +20,7 @@ NET_ACTOR, NET_CRITIC, NET_CRITIC_TARGET = 0, 1, 2
 T_PARAM, T_GRAD, T_ADAM_M, T_ADAM_V = 0, 1, 2, 3
 M_BATCH_REWARD, M_CRITIC_TARGET_Q, M_CRITIC_Q1, M_CRITIC_Q2, M_CRITIC_LOSS, M_ACTOR_LOSS, M_ACTOR_LOGPROB = range(7)
 N_METRICS = 16
-INTR_RND, INTR_ICM, INTR_ICM_APT, INTR_DISAGREEMENT, INTR_DIAYN = 0, 1, 2, 3, 4
+INTR_RND, INTR_ICM, INTR_ICM_APT, INTR_DISAGREEMENT, INTR_DIAYN, INTR_PROTO = 0, 1, 2, 3, 4, 5
 IM_LOSS, IM_INTR_REWARD, IM_EXTR_REWARD, IM_RMS_MEAN, IM_RMS_STD, IM_ACC = range(6)
 N_INTR_METRICS = 8
 
@@ -46,12 +46,13 @@ class AgentCfg(C.Structure):
 class IntrCfg(C.Structure):
     _fields_ = [('kind', c_int32), ('obs_dim', c_int32), ('act_dim', c_int32), ('hidden_dim', c_int32), ('rep_dim', c_int32),
                 ('batch', c_int32), ('precision', c_int32), ('knn_k', c_int32), ('knn_avg', c_int32), ('knn_rms', c_int32),
-                ('n_models', c_int32), ('reserved', c_int32), ('lr', c_float), ('scale', c_float), ('knn_clip', c_float), ('clip_val', c_float)]
+                ('n_models', c_int32), ('reserved', c_int32), ('lr', c_float), ('scale', c_float), ('knn_clip', c_float), ('clip_val', c_float),
+                ('num_protos', c_int32), ('queue_size', c_int32), ('tau', c_float), ('target_tau', c_float)]
 
 
 class IntrBatch(C.Structure):
     _fields_ = [('obs', c_void_p), ('obs_ld', c_int64), ('action', c_void_p), ('action_ld', c_int64), ('next_obs', c_void_p),
-                ('next_obs_ld', c_int64), ('skill', c_void_p), ('skill_ld', c_int64), ('extr_reward', c_void_p), ('reward_out', c_void_p)]
+                ('next_obs_ld', c_int64), ('skill', c_void_p), ('skill_ld', c_int64), ('extr_reward', c_void_p), ('reward_out', c_void_p), ('cat_uniform', c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/exorl_hip.h
@@ -63,6 +64,7 @@ PROTOTYPES = {
     'exorl_intr_tensor': (C.c_int, [c_void_p, c_int32, c_int32, P(c_void_p), P(c_int64), P(c_int64)]),
     'exorl_intr_flat': (C.c_int, [c_void_p, c_int32, P(c_void_p), P(c_int64)]),
     'exorl_intr_state': (C.c_int, [c_void_p, P(c_void_p), P(c_void_p), P(c_int64)]),
+    'exorl_intr_queue': (C.c_int, [c_void_p, P(c_void_p), P(c_int64), P(c_int64), P(c_int64), c_int32]),
     'exorl_intr_update': (C.c_int, [c_void_p, P(IntrBatch), c_int32, c_void_p]),
     'exorl_intr_metrics': (C.c_int, [c_void_p, c_void_p, c_void_p]),
     'exorl_intr_opt_steps': (C.c_int, [c_void_p, P(c_int64), c_int32]),

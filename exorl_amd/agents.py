@@ -7,7 +7,7 @@ Reference classes mirrored (file:line in /root/reference):
   CRRAgent    agents/offline_learning/crr.py:59-219          CQLAgent  agents/offline_learning/cql.py:59-286
   RNDAgent    agents/unsupervised_learning/rnd.py:63-159     ICMAgent  agents/unsupervised_learning/icm.py:48-139
   ICMAPTAgent agents/unsupervised_learning/icm_apt.py:60-158 DisagreementAgent agents/unsupervised_learning/disagreement.py:50-136
-  DIAYNAgent  agents/unsupervised_learning/diayn.py:32-176
+  DIAYNAgent  agents/unsupervised_learning/diayn.py:32-176     ProtoAgent agents/unsupervised_learning/proto.py:46-207 (states)
 
 Python here is orchestration only: it builds the initial weights with torch's CPU RNG in the reference's
 construction order (so a given torch.manual_seed yields the reference's initial parameters), hands batches
@@ -133,8 +133,10 @@ class _AgentBase:
         if hasattr(self, 'intr'):
             it = self.intr
             st['intr'] = {'flat': {w: it.flat(w).cpu() for w in (L.T_PARAM, L.T_ADAM_M, L.T_ADAM_V)}, 'rms': it.rms_state(),
-                          'bn': it.bn.cpu() if it.bn is not None else None, 'opt_steps': it.opt_steps()}
-        skip = {'engine', 'intr', 'actor', 'critic', 'critic_target', 'rnd', 'icm', 'pbe', 'intrinsic_reward_rms', 'disagreement', 'diayn', 'aug', 'encoder',
+                          'bn': it.bn.cpu() if it.bn is not None else None, 'opt_steps': it.opt_steps(),
+                          'queue': (it.queue.cpu(), it.queue_ptr()) if it.queue is not None else None}
+        skip = {'engine', 'intr', 'actor', 'critic', 'critic_target', 'rnd', 'icm', 'pbe', 'intrinsic_reward_rms', 'disagreement', 'diayn',
+                'predictor', 'predictor_target', 'projector', 'protos', 'queue', 'encoder_target', 'cat_hook', 'aug', 'encoder',
                 'noise_hook', '_slots', '_graph_iter', '_graph_stddev', '_ctor'}
         st['attrs'] = {k: v for k, v in self.__dict__.items() if k not in skip and not k.startswith('_keep')}
         return st
@@ -161,6 +163,9 @@ class _AgentBase:
             if si['bn'] is not None:
                 it.bn.copy_(si['bn'])
             it.set_opt_steps(si['opt_steps'])
+            if si.get('queue') is not None:
+                it.queue.copy_(si['queue'][0])
+                it.queue_ptr(si['queue'][1])
         self.__dict__.update(st['attrs'])
         self.train(st['training'])
 
@@ -794,6 +799,85 @@ class DIAYNAgent(_IntrAgent):
         O, W = self.obs_dim - self.skill_dim, self.obs_dim
         s = self._slots
         self.intr.update(s.obs, None, s.next_obs, s.reward, s.reward, True, skill=s.obs + 4 * O, obs_ld=W, next_obs_ld=W, skill_ld=W)
+
+
+class _TensorsView(NetView):
+    """A NetView over a subset of an engine's tensors (agent.predictor / .projector / .protos / .predictor_target)."""
+
+    def __init__(self, engine, indices, keys):
+        self._engine, self._net, self._keys, self._on_change = engine, None, list(keys), None
+        self.training = True
+        self._idx = list(indices)
+        self._params = [engine.tensor(None, i, L.T_PARAM) for i in self._idx]
+
+    def grads(self):
+        return [self._engine.tensor(None, i, L.T_GRAD) for i in self._idx]
+
+
+def _proto_init(O, pred_dim, proj_dim, num_protos):
+    """proto.py:55-67: predictor (Linear + weight_init), projector (Projector applies weight_init itself, then the agent applies it
+    again), protos (bias-free Linear + weight_init) — the same RNG consumption, tensor by tensor."""
+    def orth(m):
+        nn.init.orthogonal_(m.weight.data)
+        if m.bias is not None:
+            m.bias.data.fill_(0.0)
+    pred = nn.Linear(O, pred_dim)
+    orth(pred)
+    p0, p2 = nn.Linear(pred_dim, proj_dim), nn.Linear(proj_dim, pred_dim)
+    for _ in range(2):
+        orth(p0)
+        orth(p2)
+    protos = nn.Linear(pred_dim, num_protos, bias=False)
+    orth(protos)
+    return [pred.weight.data, pred.bias.data, p0.weight.data, p0.bias.data, p2.weight.data, p2.bias.data, protos.weight.data]
+
+
+class ProtoAgent(_IntrAgent):
+    """agents/unsupervised_learning/proto.py:46-207 (configs/agent/proto.yaml) on state observations: the encoder is the identity,
+    so encoder_target and the encoder's share of proto_opt vanish; the intrinsic reward is computed on next_obs (proto.py:175-177)."""
+    LOSS_KEY = 'repr_loss'
+
+    def __init__(self, pred_dim, proj_dim, queue_size, num_protos, tau, encoder_target_tau, topk, update_encoder, **kwargs):
+        super().__init__(**kwargs)
+        self.tau = tau
+        self.encoder_target_tau = encoder_target_tau
+        self.topk = topk
+        self.num_protos = num_protos
+        self.update_encoder = update_encoder
+        self.encoder_target = _Identity()
+        O = self.obs_dim
+        w = _proto_init(O, pred_dim, proj_dim, num_protos)
+        self.intr = IntrEngine('proto', O, self.action_dim, proj_dim, self.engine.batch, rep_dim=pred_dim, lr=self.lr, knn_k=topk,
+                               num_protos=num_protos, queue_size=queue_size, tau=tau, target_tau=encoder_target_tau,
+                               precision=self._precision, device=self.device)
+        self.predictor = _TensorsView(self.intr, [0, 1], ['weight', 'bias'])
+        self.projector = _TensorsView(self.intr, [2, 3, 4, 5], ['trunk.0.weight', 'trunk.0.bias', 'trunk.2.weight', 'trunk.2.bias'])
+        self.protos = _TensorsView(self.intr, [6], ['weight'])
+        self.predictor_target = _TensorsView(self.intr, [7, 8], ['weight', 'bias'])
+        for view, ts in ((self.predictor, w[0:2]), (self.projector, w[2:6]), (self.protos, w[6:7]), (self.predictor_target, w[0:2])):
+            for p, t in zip(view.parameters(), ts):
+                p.copy_(t.reshape(p.shape))
+        self.queue = self.intr.queue
+        self.cat_hook = None            # tests: callable(num_protos) -> uniforms standing in for Categorical(prob).sample()
+
+    queue_ptr = property(lambda self: self.intr.queue_ptr(), lambda self, v: self.intr.queue_ptr(v))
+
+    def init_from(self, other):         # proto.py:87-96
+        utils.hard_update_params(other.actor, self.actor)
+        utils.hard_update_params(other.predictor, self.predictor)
+        utils.hard_update_params(other.projector, self.projector)
+        utils.hard_update_params(other.protos, self.protos)
+        if self.init_critic:
+            utils.hard_update_params(other.critic, self.critic)
+        self.params_changed()
+
+    def _intr_step(self):
+        s = self._slots = self._slots or self.engine.batch_slots()
+        u = None
+        if self.cat_hook is not None:
+            u = torch.as_tensor(np.asarray(self.cat_hook(self.num_protos), np.float32), device=self.engine.device)
+        self.intr.update(s.obs, None, s.next_obs, s.reward, s.reward, True, cat_uniform=u.data_ptr() if u is not None else None)
+        self._keep_u = u
 
 
 class _Identity:

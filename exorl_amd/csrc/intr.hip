@@ -6,6 +6,7 @@
 //   ICM-APT  agents/unsupervised_learning/icm_apt.py:13-57, :86-110; utils.PBE / utils.RMS utils/utils.py:257-319
 //   Disagreement agents/unsupervised_learning/disagreement.py:11-47, :64-90
 //   DIAYN    agents/unsupervised_learning/diayn.py:15-29, :78-127
+//   Proto    agents/unsupervised_learning/proto.py:14-157 (sinkhorn_knopp, prototypes, candidate queue, kNN reward)
 // The modules are plain Linear/ReLU stacks of arbitrary widths (obs_dim, hidden_dim, rep_dim), so the layers run on
 // the generic fp32-source grouped GEMM (gemm.hip) with small row/column kernels around it; what the reference's
 // autograd graph hides and this file exploits:
@@ -311,6 +312,133 @@ __global__ __launch_bounds__(256) void diayn_kernel(const float* __restrict__ lo
     }
 }
 
+// ---- Proto (proto.py) -------------------------------------------------------------------------------
+// F.normalize(x, dim=1): y = x / max(||x||, 1e-12), one wave per row; in place allowed; nrm optional
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* x, float* y, float* __restrict__ nrm, int rows, int D) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int j = lane; j < D; j += 64) { const float v = x[(int64_t)row * D + j]; s += v * v; }
+    const float n = fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+    for (int j = lane; j < D; j += 64) y[(int64_t)row * D + j] = x[(int64_t)row * D + j] / n;
+    if (nrm && lane == 0) nrm[row] = n;
+}
+// dx = (dy - y (y . dy)) / ||x||
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ nrm,
+                                                         float* __restrict__ dx, int rows, int D) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int j = lane; j < D; j += 64) s += y[(int64_t)row * D + j] * dy[(int64_t)row * D + j];
+    s = wave_sum(s);
+    const float n = nrm[row];
+    for (int j = lane; j < D; j += 64) dx[(int64_t)row * D + j] = (dy[(int64_t)row * D + j] - y[(int64_t)row * D + j] * s) / n;
+}
+// Sinkhorn-Knopp on S = scores / tau in the (B, P) layout of the scores (the reference works on the transpose):
+//   stage 0: scal[0] = max S                      stage 1: E = exp(S/tau - max/tau), scal[1] = sum E        (single block each)
+__global__ __launch_bounds__(1024) void sk_max_kernel(const float* __restrict__ S, int64_t n, float* __restrict__ scal) {
+    __shared__ float red[17];
+    float m = -INFINITY;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, S[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) { float r = red[0]; for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = fmaxf(r, red[i]); scal[0] = r; }
+}
+__global__ __launch_bounds__(1024) void sk_exp_kernel(const float* __restrict__ S, float* __restrict__ E, int64_t n, float inv_tau,
+                                                      float* __restrict__ scal) {
+    __shared__ float red[17];
+    const float mx = scal[0] * inv_tau;
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { const float e = expf(S[i] * inv_tau - mx); E[i] = e; s += e; }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) scal[1] = s;
+}
+// one Sinkhorn half-iteration pair, wave per row b: E[b,p] *= colscale_p, then the row is rescaled to sum `target`
+// (1/B inside the loop, 1 for the final normalisation). first != 0: colscale_p = 1/total (the Q /= Q.sum() of proto.py:18).
+__global__ __launch_bounds__(256) void sk_row_kernel(float* __restrict__ E, const float* __restrict__ colsum, const float* __restrict__ scal,
+                                                     int rows, int P, int first, float rP, float target) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int j = lane; j < P; j += 64) {
+        const float v = E[(int64_t)row * P + j] * (first ? 1.0f / scal[1] : rP / colsum[j]);
+        E[(int64_t)row * P + j] = v;
+        s += v;
+    }
+    if (first) return;
+    s = wave_sum(s);
+    for (int j = lane; j < P; j += 64) E[(int64_t)row * P + j] = E[(int64_t)row * P + j] * (target / s);
+}
+// loss_b = -sum_p q log_softmax(scores/tau); dscores = (softmax * sum_p q - q) / (B tau). One wave per row.
+__global__ __launch_bounds__(256) void proto_loss_kernel(const float* __restrict__ scores, const float* __restrict__ q, float* __restrict__ dscores,
+                                                         float* __restrict__ loss_row, int rows, int P, float inv_tau) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float mx = -INFINITY, qs = 0.f;
+    for (int j = lane; j < P; j += 64) { mx = fmaxf(mx, scores[(int64_t)row * P + j] * inv_tau); qs += q[(int64_t)row * P + j]; }
+    mx = wave_max(mx); qs = wave_sum(qs);
+    float se = 0.f;
+    for (int j = lane; j < P; j += 64) se += expf(scores[(int64_t)row * P + j] * inv_tau - mx);
+    const float lse = mx + logf(wave_sum(se));
+    float l = 0.f;
+    const float sc = inv_tau / (float)rows;
+    for (int j = lane; j < P; j += 64) {
+        const float lp = scores[(int64_t)row * P + j] * inv_tau - lse, qq = q[(int64_t)row * P + j];
+        l -= qq * lp;
+        dscores[(int64_t)row * P + j] = (expf(lp) * qs - qq) * sc;
+    }
+    l = wave_sum(l);
+    if (lane == 0) loss_row[row] = l;
+}
+// Categorical(softmax over the batch of scores[:, p]).sample() by inverse CDF (proto.py:109-112), one workgroup per prototype;
+// the chosen z row goes straight into the candidate queue (proto.py:115-117)
+__global__ __launch_bounds__(256) void proto_candidates_kernel(const float* __restrict__ scores, const float* __restrict__ z,
+                                                               const float* __restrict__ u_in, uint64_t seed, uint64_t counter,
+                                                               float* __restrict__ queue, int64_t qrow0, int B, int P, int D,
+                                                               int* __restrict__ cand_out) {
+    extern __shared__ float pr[];               // B probabilities (unnormalised), then prefix sums
+    __shared__ float red[17];
+    __shared__ int pick;
+    const int p = blockIdx.x;
+    float mx = -INFINITY;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) mx = fmaxf(mx, scores[(int64_t)b * P + p]);
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    for (int b = threadIdx.x; b < B; b += blockDim.x) pr[b] = expf(scores[(int64_t)b * P + p] - mx);
+    __syncthreads();
+    if (threadIdx.x == 0) {                     // serial prefix in double, as the oracle / torch.multinomial's cumulative table
+        double acc = 0.0;
+        for (int b = 0; b < B; ++b) acc += (double)pr[b];
+        float u;
+        if (u_in) u = u_in[p];
+        else { uint32_t c[4] = {(uint32_t)p, 7u, (uint32_t)counter, (uint32_t)(counter >> 32)}; Philox::gen(c, seed); u = (float)c[0] * 2.3283064365386963e-10f; }
+        const double thr = (double)u * acc;
+        double run = 0.0;
+        int k = B - 1;
+        for (int b = 0; b < B; ++b) { run += (double)pr[b]; if (run > thr) { k = b; break; } }
+        pick = k;
+        if (cand_out) cand_out[p] = k;
+    }
+    __syncthreads();
+    const int k = pick;
+    for (int j = threadIdx.x; j < D; j += blockDim.x) queue[(qrow0 + p) * D + j] = z[(int64_t)k * D + j];
+}
+// reward = topk-th smallest distance (proto.py:119-124) + reward bookkeeping; single block
+__global__ __launch_bounds__(1024) void kth_reward_kernel(const float* __restrict__ topk, const float* extr, float* reward, int B, int k,
+                                                          float* __restrict__ metrics) {
+    __shared__ float red[17];
+    float e = 0.f;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) e += extr ? extr[i] : 0.f;
+    e = block_sum(e, red);
+    float rs = 0.f;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) { const float r = topk[(int64_t)i * k + (k - 1)]; reward[i] = r; rs += r; }
+    rs = block_sum(rs, red);
+    if (threadIdx.x == 0) { metrics[EXORL_IM_EXTR_REWARD] = e / (float)B; metrics[EXORL_IM_INTR_REWARD] = rs / (float)B; }
+}
+
 static int grid_for(int64_t n) { const int64_t b = (n + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
 
 static int mlp_forward(const Mlp& m, const float* P, const float* x, int64_t ldx, int rows, int prec, hipStream_t s) {
@@ -366,6 +494,13 @@ struct exorl_intr {
     float *x2 = nullptr, *z = nullptr, *rep = nullptr, *xhat = nullptr, *rstd = nullptr, *drep = nullptr, *dz = nullptr, *topk = nullptr;
     float *fe = nullptr, *be = nullptr, *metrics = nullptr, *bn = nullptr;
     RmsState* rms = nullptr;
+    // Proto: predictor (Linear) in front of net[0] = projector; prototypes C; frozen predictor_target; candidate queue
+    Lin pred{}, pred_t{};
+    int64_t protos = 0;
+    float *z1 = nullptr, *dz1 = nullptr, *sn = nullptr, *nrm = nullptr, *tn = nullptr, *scores_s = nullptr, *scores_t = nullptr,
+          *dscores = nullptr, *dsn = nullptr, *colsum_p = nullptr, *scal = nullptr, *queue = nullptr;
+    int64_t queue_ptr = 0;
+    uint64_t cat_counter = 0;
     int64_t t = 0;                         // optimiser steps taken
 };
 
@@ -402,6 +537,14 @@ static void describe_intr(exorl_intr* it) {
         it->n_nets = 1;
         it->net[0].L = {lin(O, H), lin(H, H), lin(H, R)};             // R = skill_dim
         it->trainable = round_up(off, 64);
+    } else if (c.kind == EXORL_INTR_PROTO) {                          // R = pred_dim, H = proj_dim
+        it->n_nets = 1;
+        it->pred = lin(O, R);
+        it->net[0].L = {lin(R, H), lin(H, R)};
+        it->protos = add(c.num_protos, R);
+        it->trainable = round_up(off, 64);
+        off = it->trainable;
+        it->pred_t = lin(O, R);                                       // predictor_target: same padded layout as predictor
     } else {
         int in_f = O + A, in_b = 2 * O, out_f = O;
         if (c.kind == EXORL_INTR_ICM_APT) {
@@ -435,6 +578,13 @@ static void carve_intr(exorl_intr* it, ICarver& c) {
     if (g.kind == EXORL_INTR_RND) {
         it->xn = c.take(B * O);
         it->bn = c.take(2 * O + 1);
+    } else if (g.kind == EXORL_INTR_PROTO) {
+        const int64_t P = g.num_protos;
+        it->z1 = c.take(B * R); it->dz1 = c.take(B * R); it->sn = c.take(B * R); it->nrm = c.take(B); it->tn = c.take(B * R);
+        it->scores_s = c.take(B * P); it->scores_t = c.take(B * P); it->dscores = c.take(B * P); it->dsn = c.take(B * R);
+        it->colsum_p = c.take(P); it->scal = c.take(4);
+        it->queue = c.take((int64_t)g.queue_size * R);
+        it->topk = c.take(B * g.knn_k);
     } else if (g.kind == EXORL_INTR_DISAGREEMENT) {
         it->xf = c.take(B * it->net[0].L[0].in);
     } else if (g.kind != EXORL_INTR_DIAYN) {
@@ -642,13 +792,90 @@ static int diayn_update(exorl_intr* it, const exorl_intr_batch& b, bool train, h
     return launch_mean(b.reward_out, B, 1.0f / (float)B, it->metrics + EXORL_IM_INTR_REWARD, 0, s);
 }
 
+// ---- Proto ------------------------------------------------------------------------------------------
+static int launch_l2norm(const float* x, float* y, float* nrm, int rows, int D, hipStream_t s) {
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, y, nrm, rows, D);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
+static int proto_update(exorl_intr* it, const exorl_intr_batch& b, bool train, hipStream_t s) {
+    const auto& c = it->cfg;
+    const int B = c.batch, O = c.obs_dim, D = c.rep_dim, P = c.num_protos, prec = c.precision;
+    float* Pm = it->flat[EXORL_T_PARAM];
+    float* G = it->flat[EXORL_T_GRAD];
+    float* C = Pm + it->protos;
+    const float inv_tau = 1.0f / c.tau;
+    if (train) {                                                                                     // proto.py:126-157
+        EXORL_TRY(launch_l2norm(C, C, nullptr, P, D, s));                                            // normalize_protos
+        GemmProblem p1{b.obs, Pm + it->pred.W, it->z1, Pm + it->pred.b, B, D, O, b.obs_ld, O, D};
+        EXORL_TRY(gemm_grouped(prec, 0, 0, &p1, 1, false, false, s));
+        EXORL_TRY(mlp_forward(it->net[0], Pm, it->z1, D, B, prec, s));
+        EXORL_TRY(launch_l2norm(it->net[0].act[1], it->sn, it->nrm, B, D, s));
+        GemmProblem ps{it->sn, C, it->scores_s, nullptr, B, P, D, D, D, P};
+        EXORL_TRY(gemm_grouped(prec, 0, 0, &ps, 1, false, false, s));
+        // target branch (no gradient): predictor_target on next_obs, Sinkhorn assignment
+        GemmProblem pt{b.next_obs, Pm + it->pred_t.W, it->tn, Pm + it->pred_t.b, B, D, O, b.next_obs_ld, O, D};
+        EXORL_TRY(gemm_grouped(prec, 0, 0, &pt, 1, false, false, s));
+        EXORL_TRY(launch_l2norm(it->tn, it->tn, nullptr, B, D, s));
+        GemmProblem pq{it->tn, C, it->scores_t, nullptr, B, P, D, D, D, P};
+        EXORL_TRY(gemm_grouped(prec, 0, 0, &pq, 1, false, false, s));
+        const int64_t n = (int64_t)B * P;
+        hipLaunchKernelGGL(sk_max_kernel, dim3(1), dim3(1024), 0, s, it->scores_t, n, it->scal);
+        hipLaunchKernelGGL(sk_exp_kernel, dim3(1), dim3(1024), 0, s, it->scores_t, it->scores_t, n, inv_tau, it->scal);
+        hipLaunchKernelGGL(sk_row_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->scores_t, it->colsum_p, it->scal, B, P, 1, 0.f, 0.f);
+        EXORL_LAUNCH_CHECK();
+        for (int iter = 0; iter < 3; ++iter) {     // u = r / Q.sum(1); Q *= u; Q *= c / Q.sum(0)   (+ the final Q / Q.sum(0) folded into the last pass)
+            EXORL_TRY(colsum(it->scores_t, it->colsum_p, B, P, 1, 0, 0, s));
+            hipLaunchKernelGGL(sk_row_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->scores_t, it->colsum_p, it->scal, B, P, 0, 1.0f / (float)P,
+                               iter == 2 ? 1.0f : 1.0f / (float)B);
+            EXORL_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(proto_loss_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->scores_s, it->scores_t, it->dscores, it->fe, B, P, inv_tau);
+        EXORL_LAUNCH_CHECK();
+        EXORL_TRY(launch_mean(it->fe, B, 1.0f / (float)B, it->metrics + EXORL_IM_LOSS, 0, s));
+        GemmProblem gc{it->dscores, it->sn, G + it->protos, nullptr, P, D, B, P, D, D};              // dC = dscores^T sn
+        EXORL_TRY(gemm_grouped(prec, 1, 1, &gc, 1, false, false, s));
+        GemmProblem gs{it->dscores, C, it->dsn, nullptr, B, D, P, P, D, D};                          // dsn = dscores C
+        EXORL_TRY(gemm_grouped(prec, 0, 1, &gs, 1, false, false, s));
+        hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->dsn, it->sn, it->nrm, it->net[0].dact[1], B, D);
+        EXORL_LAUNCH_CHECK();
+        EXORL_TRY(mlp_backward(it->net[0], Pm, G, it->z1, D, B, it->dz1, prec, s));
+        EXORL_TRY(colsum(it->dz1, G + it->pred.b, B, D, 1, 0, 0, s));
+        GemmProblem gw{it->dz1, b.obs, G + it->pred.W, nullptr, D, O, B, D, b.obs_ld, O};
+        EXORL_TRY(gemm_grouped(prec, 1, 1, &gw, 1, false, false, s));
+        EXORL_TRY(intr_adam(it, s));
+    }
+    // compute_intr_reward(next_obs) (proto.py:103-124)
+    EXORL_TRY(launch_l2norm(C, C, nullptr, P, D, s));
+    GemmProblem pz{b.next_obs, Pm + it->pred.W, it->sn, Pm + it->pred.b, B, D, O, b.next_obs_ld, O, D};
+    EXORL_TRY(gemm_grouped(prec, 0, 0, &pz, 1, false, false, s));
+    EXORL_TRY(launch_l2norm(it->sn, it->sn, nullptr, B, D, s));
+    GemmProblem pc{it->sn, C, it->scores_s, nullptr, B, P, D, D, D, P};
+    EXORL_TRY(gemm_grouped(prec, 0, 0, &pc, 1, false, false, s));
+    hipLaunchKernelGGL(proto_candidates_kernel, dim3(P), dim3(256), (size_t)B * sizeof(float), s, it->scores_s, it->sn, b.cat_uniform,
+                       0x70726f746full, it->cat_counter++, it->queue, it->queue_ptr, B, P, D, (int*)nullptr);
+    EXORL_LAUNCH_CHECK();
+    it->queue_ptr = (it->queue_ptr + P) % c.queue_size;
+    EXORL_TRY(exorl_knn_topk(it->sn, B, it->queue, c.queue_size, D, c.knn_k, it->topk, s));
+    hipLaunchKernelGGL(kth_reward_kernel, dim3(1), dim3(1024), 0, s, it->topk, b.extr_reward, b.reward_out, B, c.knn_k, it->metrics);
+    EXORL_LAUNCH_CHECK();
+    if (train)                                     // utils.soft_update_params(predictor, predictor_target, encoder_target_tau) (proto.py:202-203)
+        EXORL_TRY(soft_update(Pm + it->pred.W, Pm + it->pred_t.W, it->pred_t.b + round_up(c.rep_dim, 4) - it->pred_t.W, c.target_tau, s));
+    return 0;
+}
+
 }  // namespace exorl
 
 extern "C" {
 
 static int check_intr_cfg(const exorl_intr_cfg* cfg) {
     EXORL_REQUIRE(cfg, "intr: null cfg");
-    EXORL_REQUIRE(cfg->kind >= EXORL_INTR_RND && cfg->kind <= EXORL_INTR_DIAYN, "intr: unknown kind %d", cfg->kind);
+    EXORL_REQUIRE(cfg->kind >= EXORL_INTR_RND && cfg->kind <= EXORL_INTR_PROTO, "intr: unknown kind %d", cfg->kind);
+    EXORL_REQUIRE(cfg->kind != EXORL_INTR_PROTO || (cfg->num_protos >= 1 && cfg->queue_size >= cfg->num_protos && cfg->queue_size % cfg->num_protos == 0 &&
+                  cfg->queue_size <= 4096 && cfg->knn_k >= 1 && cfg->knn_k <= 64 && cfg->knn_k <= cfg->queue_size && cfg->tau > 0.f && cfg->batch <= 8192),
+                  "intr: Proto needs num_protos >= 1, queue_size a multiple of num_protos and <= 4096, 1 <= topk <= 64, tau > 0 (got %d, %d, %d, %g)",
+                  cfg->num_protos, cfg->queue_size, cfg->knn_k, (double)cfg->tau);
     EXORL_REQUIRE(cfg->n_models >= 0 && cfg->n_models <= EXORL_MAX_ENSEMBLE, "intr: n_models=%d out of range (<= %d)", cfg->n_models, EXORL_MAX_ENSEMBLE);
     EXORL_REQUIRE(cfg->obs_dim > 0 && cfg->act_dim > 0 && cfg->act_dim <= 64 && cfg->hidden_dim > 0 && cfg->batch > 0,
                   "intr: unsupported dims O=%d A=%d (<=64) H=%d B=%d", cfg->obs_dim, cfg->act_dim, cfg->hidden_dim, cfg->batch);
@@ -741,18 +968,31 @@ int exorl_intr_update(exorl_intr_t* it, const exorl_intr_batch* b, int32_t train
     EXORL_REQUIRE(it && b && b->obs && b->reward_out, "intr_update: null argument");
     const int k = it->cfg.kind;
     EXORL_REQUIRE(k == EXORL_INTR_RND || b->next_obs, "intr_update: this module needs next_obs");
-    EXORL_REQUIRE(k == EXORL_INTR_RND || k == EXORL_INTR_DIAYN || b->action, "intr_update: this module needs action");
+    EXORL_REQUIRE(k == EXORL_INTR_RND || k == EXORL_INTR_DIAYN || k == EXORL_INTR_PROTO || b->action, "intr_update: this module needs action");
     EXORL_REQUIRE(k != EXORL_INTR_DIAYN || b->skill, "intr_update: DIAYN needs the skill matrix");
     EXORL_REQUIRE(b->obs_ld >= it->cfg.obs_dim && (!b->next_obs || b->next_obs_ld >= it->cfg.obs_dim) && (!b->action || b->action_ld >= it->cfg.act_dim) &&
-                  (!b->skill || b->skill_ld >= it->cfg.rep_dim), "intr_update: a leading dimension is smaller than its row width");
+                  (!b->skill || k != EXORL_INTR_DIAYN || b->skill_ld >= it->cfg.rep_dim), "intr_update: a leading dimension is smaller than its row width");
     hipStream_t s = as_stream(stream);
     switch (k) {
         case EXORL_INTR_RND: return rnd_update(it, *b, train != 0, s);
         case EXORL_INTR_ICM: return icm_update(it, *b, train != 0, s);
         case EXORL_INTR_ICM_APT: return apt_update(it, *b, train != 0, s);
         case EXORL_INTR_DISAGREEMENT: return disagreement_update(it, *b, train != 0, s);
+        case EXORL_INTR_PROTO: return proto_update(it, *b, train != 0, s);
         default: return diayn_update(it, *b, train != 0, s);
     }
+}
+
+int exorl_intr_queue(exorl_intr_t* it, void** queue_dev, int64_t* rows, int64_t* cols, int64_t* ptr_inout, int32_t set) {
+    EXORL_REQUIRE(it && queue_dev && rows && cols && ptr_inout && it->queue, "intr_queue: not a Proto module / null argument");
+    *queue_dev = it->queue; *rows = it->cfg.queue_size; *cols = it->cfg.rep_dim;
+    if (set) {
+        EXORL_REQUIRE(*ptr_inout >= 0 && *ptr_inout < it->cfg.queue_size && *ptr_inout % it->cfg.num_protos == 0, "intr_queue: bad write pointer");
+        it->queue_ptr = *ptr_inout;
+    } else {
+        *ptr_inout = it->queue_ptr;
+    }
+    return 0;
 }
 
 int exorl_intr_metrics(exorl_intr_t* it, float* host, void* stream) {

@@ -174,15 +174,17 @@ class AgentEngine:
 class IntrEngine:
     """Intrinsic-reward module (exorl_intr_t): RND / ICM / ICM-APT. Parameters live in a torch-owned workspace so they
     can be exposed as tensors (state_dict, snapshots)."""
-    KINDS = {'rnd': L.INTR_RND, 'icm': L.INTR_ICM, 'icm_apt': L.INTR_ICM_APT, 'disagreement': L.INTR_DISAGREEMENT, 'diayn': L.INTR_DIAYN}
+    KINDS = {'rnd': L.INTR_RND, 'icm': L.INTR_ICM, 'icm_apt': L.INTR_ICM_APT, 'disagreement': L.INTR_DISAGREEMENT, 'diayn': L.INTR_DIAYN,
+             'proto': L.INTR_PROTO}
 
     def __init__(self, kind, obs_dim, act_dim, hidden_dim, batch, rep_dim=0, lr=1e-4, scale=1.0, knn_k=12, knn_avg=True,
-                 knn_rms=True, knn_clip=0.0, clip_val=5.0, n_models=0, precision='fp32', device='cuda'):
+                 knn_rms=True, knn_clip=0.0, clip_val=5.0, n_models=0, num_protos=0, queue_size=0, tau=0.1, target_tau=0.05, precision='fp32',
+                 device='cuda'):
         self.lib = L.load()
         self.device = _require_gpu(device)
         self.kind, self.batch, self.obs_dim, self.act_dim = kind, batch, obs_dim, act_dim
         self.cfg = L.IntrCfg(self.KINDS[kind], obs_dim, act_dim, hidden_dim, rep_dim, batch, PRECISION[precision], knn_k, int(bool(knn_avg)),
-                             int(bool(knn_rms)), n_models, 0, lr, scale, knn_clip, clip_val)
+                             int(bool(knn_rms)), n_models, 0, lr, scale, knn_clip, clip_val, num_protos, queue_size, tau, target_tau)
         nbytes = self.lib.exorl_intr_workspace_bytes(C.byref(self.cfg))
         if nbytes == 0:
             raise L.ExorlError(self.lib.exorl_last_error().decode())
@@ -198,6 +200,17 @@ class IntrEngine:
         L.check(self.lib.exorl_intr_state(self.h, C.byref(rms), C.byref(bn), C.byref(nbn)))
         self._rms = self._view(rms.value, 4)                       # {float M, float S, double n}
         self.bn = self._view(bn.value, nbn.value) if bn.value else None
+        self.queue = None
+        if kind == 'proto':
+            q, r, c, ptr = C.c_void_p(), C.c_int64(), C.c_int64(), C.c_int64()
+            L.check(self.lib.exorl_intr_queue(self.h, C.byref(q), C.byref(r), C.byref(c), C.byref(ptr), 0))
+            self.queue = self._view(q.value, r.value * c.value).view(r.value, c.value)
+
+    def queue_ptr(self, set_to=None):
+        q, r, c = C.c_void_p(), C.c_int64(), C.c_int64()
+        ptr = C.c_int64(0 if set_to is None else int(set_to))
+        L.check(self.lib.exorl_intr_queue(self.h, C.byref(q), C.byref(r), C.byref(c), C.byref(ptr), int(set_to is not None)))
+        return ptr.value
 
     def __del__(self):
         h, self.h = getattr(self, 'h', None), None
@@ -236,10 +249,10 @@ class IntrEngine:
         self._rms.copy_(torch.from_numpy(raw))
 
     def update(self, obs, action, next_obs, extr_reward, reward_out, train=True, skill=None, obs_ld=None, action_ld=None,
-               next_obs_ld=None, skill_ld=0):
+               next_obs_ld=None, skill_ld=0, cat_uniform=None):
         """Device pointers (ints) + row strides in floats; see exorl_intr_batch."""
         b = L.IntrBatch(obs, obs_ld or self.obs_dim, action, action_ld or self.act_dim, next_obs, next_obs_ld or self.obs_dim,
-                        skill, skill_ld, extr_reward, reward_out)
+                        skill, skill_ld, extr_reward, reward_out, cat_uniform)
         L.check(self.lib.exorl_intr_update(self.h, C.byref(b), int(bool(train)), L.current_stream()))
 
     def metrics_raw(self):

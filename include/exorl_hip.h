@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EXORL_ABI_VERSION 3
+#define EXORL_ABI_VERSION 4
 
 const char* exorl_last_error(void);
 int exorl_abi_version(void);
@@ -257,6 +257,7 @@ int exorl_knn_topk(const float* src_dev, int32_t n_src, const float* tgt_dev, in
 #define EXORL_INTR_ICM_APT 2
 #define EXORL_INTR_DISAGREEMENT 3   /* agents/unsupervised_learning/disagreement.py:11-90 */
 #define EXORL_INTR_DIAYN   4        /* agents/unsupervised_learning/diayn.py:15-127 */
+#define EXORL_INTR_PROTO   5        /* agents/unsupervised_learning/proto.py:14-207 (state observations) */
 #define EXORL_MAX_ENSEMBLE 8
 
 typedef struct exorl_intr_cfg {
@@ -272,6 +273,10 @@ typedef struct exorl_intr_cfg {
     float scale;          /* rnd_scale / icm_scale */
     float knn_clip;
     float clip_val;       /* RND: clamp of the BatchNorm-normalised observation (rnd.py:22, 5.0) */
+    /* Proto (configs/agent/proto.yaml): rep_dim = pred_dim, hidden_dim = proj_dim, knn_k = topk */
+    int32_t num_protos, queue_size;
+    float tau;            /* softmax / Sinkhorn temperature */
+    float target_tau;     /* encoder_target_tau: Polyak rate of predictor_target */
 } exorl_intr_cfg;
 
 typedef struct exorl_intr exorl_intr_t;
@@ -292,7 +297,8 @@ int exorl_intr_create(const exorl_intr_cfg* cfg, void* workspace, size_t workspa
 int exorl_intr_destroy(exorl_intr_t* m);
 /* Parameter tensors in the module's parameters() order (RND: predictor.{1,3,5}, target.{1,3,5}; ICM: forward_net.{0,2},
  * backward_net.{0,2}; ICM-APT: trunk.0, trunk.1 (LayerNorm), forward_net, backward_net; Disagreement: ensemble.{m}.{0,2};
- * DIAYN: skill_pred_net.{0,2,4}), each weight then bias.
+ * DIAYN: skill_pred_net.{0,2,4}; Proto: predictor, projector.trunk.{0,2}, protos (no bias), then the frozen predictor_target),
+ * each weight then bias.
  * what = EXORL_T_*; RND's frozen target tensors have parameters only. */
 int exorl_intr_num_tensors(exorl_intr_t* m, int32_t* n);
 int exorl_intr_tensor(exorl_intr_t* m, int32_t index, int32_t what, void** ptr, int64_t* rows, int64_t* cols);
@@ -300,6 +306,8 @@ int exorl_intr_flat(exorl_intr_t* m, int32_t what, void** ptr, int64_t* numel);
 /* Device state outside the parameters: rms = {float M, float S, double n} (utils.RMS); bn = running_mean[obs_dim],
  * running_var[obs_dim], num_batches_tracked (as float) of RND's BatchNorm1d, or null. */
 int exorl_intr_state(exorl_intr_t* m, void** rms_dev, void** bn_dev, int64_t* bn_numel);
+/* Proto's candidate queue (queue_size x pred_dim, device) and its write pointer (get: set == 0; restore: set != 0). */
+int exorl_intr_queue(exorl_intr_t* m, void** queue_dev, int64_t* rows, int64_t* cols, int64_t* ptr_inout, int32_t set);
 /* One sampled batch as device pointers with row strides in floats (so that columns of a wider matrix can be passed in place:
  * DIAYN's skill lives in the last columns of the agent's [obs | skill] rows). action / next_obs / skill / extr_reward may be
  * null where the module does not read them; reward_out (batch,) may alias extr_reward (the agent's reward slot). */
@@ -310,6 +318,7 @@ typedef struct exorl_intr_batch {
     const float* skill;    int64_t skill_ld;
     const float* extr_reward;
     float* reward_out;
+    const float* cat_uniform;   /* Proto: num_protos uniforms in [0,1) for Categorical(prob).sample() (proto.py:112), or null -> Philox */
 } exorl_intr_batch;
 /* train != 0: the module's optimiser step (update_rnd / update_icm / update_disagreement / update_diayn) then
  * compute_intr_reward under the updated module (rnd.py:121-124, icm.py:106-110, icm_apt.py:123-127, disagreement.py:106-112,

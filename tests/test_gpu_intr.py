@@ -283,3 +283,87 @@ def test_diayn_zero_copy_sampler_path_matches_iterator_path():
     for p, q in zip(a0.actor.parameters() + a0.critic.parameters() + a0.diayn.parameters(),
                     a1.actor.parameters() + a1.critic.parameters() + a1.diayn.parameters()):
         assert torch.equal(p, q)
+
+
+# ---------------------------------------------------------------------------------------------------- Proto (states)
+def make_proto(O, A, H, B, pred, proj, protos, queue, use_tb=True, precision='fp32'):
+    from exorl_amd import agents
+    return agents.ProtoAgent(pred_dim=pred, proj_dim=proj, queue_size=queue, num_protos=protos, tau=0.1, encoder_target_tau=0.05, topk=3,
+                             update_encoder=True, **ddpg_kw('proto', O, A, H, B, use_tb, precision))
+
+
+PROTO_VIEWS = ['predictor', 'predictor_target', 'projector', 'protos']
+
+
+def test_proto_tiny_trajectory_vs_reference(gold):
+    from oracle.proto import uniform_from_normal
+    z = np.load(gold / 'tiny_proto.npz')
+    torch.manual_seed(21)
+    ag = make_proto(5, 3, 32, 8, 8, 16, 6, 24)
+    nets = [('actor', ag.actor), ('critic', ag.critic), ('critic_target', ag.critic_target)] + [(n, getattr(ag, n)) for n in PROTO_VIEWS]
+    for nm, net in nets:
+        sd = net.state_dict()
+        for k, v in sd.items():
+            np.testing.assert_allclose(v.cpu().numpy(), z[f'init/{nm}/{k}'], rtol=0, atol=2e-6, err_msg=f'{nm}.{k}')
+        net.load_state_dict({k: torch.from_numpy(z[f'init/{nm}/{k}']) for k in sd})
+    stream = iter([z[f'noise/{i}'] for i in range(15)])
+    ag.cat_hook = lambda n: uniform_from_normal(next(stream))
+    ag.noise_hook = lambda shape: next(stream)
+    keys = [str(k) for k in z['metric_keys']]
+    for i in range(5):
+        batch = tuple(z[f'batch/{i}/{j}'] for j in range(5))
+        assert ag.update(iter([]), 2 * i + 1) == {}
+        m = ag.update(iter([batch]), 2 * i)
+        assert sorted(m.keys()) == keys
+        intr = ag.engine._view(ag.engine.batch_slots().reward, 8).cpu().numpy().reshape(-1, 1)
+        np.testing.assert_allclose(intr, z['intr_reward'][i], rtol=1e-4, atol=2e-6, err_msg=f'intr reward step {i}')
+        got = np.array([m[k] for k in keys])
+        np.testing.assert_allclose(got, z['metrics'][i], rtol=1e-4, atol=2e-6, err_msg=f'step {i} {keys}')
+    for nm, net in nets:
+        for k, v in net.state_dict().items():
+            np.testing.assert_allclose(v.cpu().numpy(), z[f'final/{nm}/{k}'], rtol=1e-4, atol=2e-6, err_msg=f'{nm}.{k}')
+    np.testing.assert_allclose(ag.queue.cpu().numpy(), z['final/queue'], rtol=1e-5, atol=1e-6)
+    assert ag.queue_ptr == int(z['final/queue_ptr'])
+
+
+@pytest.mark.parametrize('dims', [(24, 6, 1024, 1024, 128, 512, 512, 2048),      # configs/agent/proto.yaml widths, walker states
+                                  (9, 2, 72, 100, 20, 36, 10, 40)])
+def test_proto_shipped_widths_vs_oracle(dims):
+    from oracle.proto import OracleProto, OracleProtoAgent, proto_param_shapes
+    O, A, H, B, pred, proj, protos, queue = dims
+    ag = make_proto(O, A, H, B, pred, proj, protos, queue)
+    ash, csh = param_shapes('ddpg', O, A, H)
+    pa, pc = _synth.synth_params(ash, 3), _synth.synth_params(csh, 4)
+    ag.actor.load_state_dict({k: torch.from_numpy(v) for k, v in pa.items()})
+    ag.critic.load_state_dict({k: torch.from_numpy(v) for k, v in pc.items()})
+    ag.critic_target.load_state_dict(ag.critic.state_dict())
+    psh = proto_param_shapes(O, pred, proj, protos)
+    pp = list(_synth.synth_params(psh, 5).values())
+    for view, ts in ((ag.predictor, pp[0:2]), (ag.projector, pp[2:6]), (ag.protos, pp[6:7]), (ag.predictor_target, pp[0:2])):
+        for p, t in zip(view.parameters(), ts):
+            p.copy_(torch.from_numpy(t).reshape(p.shape))
+    orc = OracleProtoAgent(OracleAgent('ddpg', list(pa.values()), list(pc.values())), OracleProto(pp, queue_size=queue))
+    rs = np.random.RandomState(2)
+    ns, ns2 = _synth.NoiseStream(11), _synth.NoiseStream(11)
+    ag.noise_hook = ns.draw
+    us = []
+    ag.cat_hook = lambda n: us[-1]
+    for i in range(3):
+        us.append(rs.uniform(0, 1, protos))
+        batch = _synth.synth_batch(17, i, B, O, A)
+        m = ag.update(iter([batch]), 2 * i)
+        mo = orc.update(batch, 2 * i, us[-1], ns2.draw((B, A)), ns2.draw((B, A)))
+        intr = ag.engine._view(ag.engine.batch_slots().reward, B).cpu().numpy().reshape(-1, 1)
+        assert_mostly_close(intr, orc.last_intr, 2e-4, 2e-5, 0.05 * np.abs(orc.last_intr).max() + 0.05, 2e-2, f'proto intr reward step {i}')
+        for k, v in mo.items():
+            assert abs(m[k] - v) <= 2e-4 * abs(v) + 2e-6, (i, k, m[k], v)
+    views = [ag.predictor, ag.projector, ag.protos]
+    got = [p for v in views for p in v.parameters()]
+    for (k, _), p, want in zip(psh, got, orc.module.p):
+        assert_mostly_close(p.cpu().numpy().reshape(want.shape), want, 1e-4, 2e-6, 2 * 1e-4 * 3, err_msg=k)
+    grads = [g for v in views for g in v.grads()]
+    for (k, _), g, want in zip(psh, grads, orc.module.last_grads):
+        assert_mostly_close(g.cpu().numpy().reshape(want.shape), want, 5e-4, 1e-8 + 1e-3 * np.abs(want).max(), 0.1 * np.abs(want).max(),
+                            frac=2e-2, err_msg=f'grad {k}')
+    np.testing.assert_allclose(ag.predictor_target.parameters()[0].cpu().numpy(), orc.module.pt[0], rtol=1e-4, atol=2e-6)
+    assert ag.queue_ptr == orc.module.queue_ptr

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert s in _lib.PROTOTYPES, f'{s} has no ctypes prototype'
     assert set(_lib.PROTOTYPES) == set(syms)
     lib.exorl_abi_version.restype = ctypes.c_int
-    assert lib.exorl_abi_version() == 3
+    assert lib.exorl_abi_version() == 4
 
 
 def test_product_fails_loudly_without_gpu():
@@ -79,6 +79,22 @@ def test_intr_module_init_matches_reference_rng_order(gold, kind):
     assert len(w) == len(keys)
     for k, t in zip(keys, w):
         np.testing.assert_array_equal(t.numpy(), z[f'init/{mod}/{k}'], err_msg=k)
+
+
+def test_proto_init_matches_reference_rng_order(gold):
+    """proto.py:55-67 draws: predictor, projector (weight_init applied twice), protos — after the DDPG nets."""
+    from exorl_amd import agents
+    z = np.load(gold / 'tiny_proto.npz')
+    O, A, H = 5, 3, 32
+    torch.manual_seed(21)
+    agents._mlp_init(O, H, A, 1, 1)
+    agents._mlp_init(O + A, H, 1, 1, 2)
+    agents._mlp_init(O + A, H, 1, 1, 2)
+    w = agents._proto_init(O, 8, 16, 6)
+    keys = ['predictor/weight', 'predictor/bias', 'projector/trunk.0.weight', 'projector/trunk.0.bias', 'projector/trunk.2.weight',
+            'projector/trunk.2.bias', 'protos/weight']
+    for k, t in zip(keys, w):
+        np.testing.assert_array_equal(t.numpy(), z[f'init/{k}'], err_msg=k)
 
 
 def test_schedule_and_helpers(gold):
