@@ -40,7 +40,8 @@ class AgentCfg(C.Structure):
     _fields_ = [('kind', c_int32), ('obs_dim', c_int32), ('act_dim', c_int32), ('hidden_dim', c_int32),
                 ('batch', c_int32), ('precision', c_int32), ('world_size', c_int32), ('reserved', c_int32),
                 ('lr', c_float), ('tau', c_float), ('alpha', c_float), ('stddev_clip', c_float), ('seed', c_uint64),
-                ('num_value_samples', c_int32), ('weight_func', c_int32), ('n_samples', c_int32), ('reserved2', c_int32)]
+                ('num_value_samples', c_int32), ('weight_func', c_int32), ('n_samples', c_int32), ('use_critic_lagrange', c_int32),
+                ('target_cql_penalty', c_float), ('reserved3', c_int32)]
 
 
 class IntrCfg(C.Structure):

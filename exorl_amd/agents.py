@@ -386,13 +386,11 @@ class CRRAgent(_AgentBase):
 
 
 class CQLAgent(_AgentBase):
-    """agents/offline_learning/cql.py:59-286 (use_critic_lagrange=False, the shipped cql.yaml)."""
+    """agents/offline_learning/cql.py:59-286 (both the shipped cql.yaml and use_critic_lagrange=True; the latter single-GPU)."""
     KIND = 'cql'
 
     def __init__(self, name, obs_shape, action_shape, device, lr, hidden_dim, critic_target_tau, nstep, batch_size, use_tb, alpha,
                  n_samples, target_cql_penalty, use_critic_lagrange, has_next_action=False, *, precision='fp32', seed=0):
-        if use_critic_lagrange:
-            raise NotImplementedError('exorl_amd CQLAgent: use_critic_lagrange=True (cql.py:203-214) is not built yet')
         self.action_dim = action_shape[0]
         self.hidden_dim = hidden_dim
         self.lr = lr
@@ -406,13 +404,17 @@ class CQLAgent(_AgentBase):
         self.target_entropy = -self.action_dim
         self.stddev_schedule = '1.0'          # unused by CQL (state-dependent std); keeps the shared plumbing uniform
         self._build(obs_shape[0], action_shape[0], hidden_dim, batch_size, lr, critic_target_tau, alpha, 0.0, device, precision, seed,
-                    n_samples=n_samples)
+                    n_samples=n_samples, use_critic_lagrange=use_critic_lagrange, target_cql_penalty=target_cql_penalty)
         self.train()
         self.critic_target.train()
 
     @property
     def log_actor_alpha(self):
         return torch.tensor([self.engine.cql_alpha_state()[0]])
+
+    @property
+    def log_critic_alpha(self):
+        return torch.tensor([self.engine.cql_alpha_state()[3]])
 
     def act(self, obs, step, eval_mode):
         return self._act(np.asarray(obs, np.float32), step, eval_mode)

@@ -405,6 +405,8 @@ static int describe(exorl_agent* a, const exorl_agent_cfg* cfg) {
     EXORL_REQUIRE(cfg->kind >= EXORL_AGENT_TD3_BC && cfg->kind <= EXORL_AGENT_CQL, "agent: unknown kind %d", cfg->kind);
     EXORL_REQUIRE(cfg->kind != EXORL_AGENT_CQL || (cfg->n_samples >= 1 && cfg->n_samples <= 16 && cfg->act_dim <= 16),
                   "agent: CQL needs 1 <= n_samples <= 16 and action_dim <= 16 (got %d, %d)", cfg->n_samples, cfg->act_dim);
+    EXORL_REQUIRE(!cfg->use_critic_lagrange || (cfg->kind == EXORL_AGENT_CQL && cfg->world_size == 1),
+                  "agent: use_critic_lagrange is a single-GPU CQL option (the penalty is a batch-global scalar that steers its own multiplier)");
     EXORL_REQUIRE(cfg->kind != EXORL_AGENT_CRR || (cfg->num_value_samples >= 1 && cfg->num_value_samples <= 64 &&
                   cfg->weight_func >= EXORL_CRR_IDENTITY && cfg->weight_func <= EXORL_CRR_EXP),
                   "agent: CRR needs 1 <= num_value_samples <= 64 and a valid weight_func (got %d, %d)", cfg->num_value_samples, cfg->weight_func);
@@ -626,7 +628,8 @@ static int cql_phase0(exorl_agent* a, hipStream_t s) {
     EXORL_TRY(net_forward(a->critic, a->flat[EXORL_NET_CRITIC_TARGET][EXORL_T_PARAM], a->sh_target, a->xc_next, W, B, a->ft, false, false,
                           prec, s));                                                                     // cql.py:160
     EXORL_TRY(net_forward(a->critic, Pc, a->sh_critic, a->x_all, W, R, a->fc, true, false, prec, s));     // cql.py:166,179-184 in one pass
-    EXORL_TRY(cql_critic_dq(a->fc.out, a->ft.out, a->reward, a->discount, a->dq_all, a->metrics, B, n, cfg.alpha, a->inv_bg, s));
+    EXORL_TRY(cql_critic_dq(a->fc.out, a->ft.out, a->reward, a->discount, a->dq_all, a->metrics, B, n, cfg.alpha, a->inv_bg, s,
+                            cfg.use_critic_lagrange ? a->cql + 1 : nullptr, &a->state->critic, cfg.target_cql_penalty));
     DoutSpec d{};
     d.mode = EXORL_DOUT_BUFFER; d.buf = a->dq_all;
     EXORL_TRY(net_backward(a->critic, Pc, a->sh_critic, a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD], a->pc, a->x_all, W, R, a->fc, d, a->bc,
@@ -936,13 +939,17 @@ int exorl_agent_enable_graph(exorl_agent_t* a, exorl_replay_t* r, int32_t nstep,
 
 int exorl_agent_cql_alpha(exorl_agent_t* a, float* host, int32_t set) {
     EXORL_REQUIRE(a && host && a->cql, "agent_cql_alpha: not a CQL agent / null argument");
-    if (set) {
-        CqlScalars sc{host[0], host[1], host[2], expf(host[0])};
-        EXORL_CHECK_HIP(hipMemcpy(a->cql, &sc, sizeof(sc), hipMemcpyHostToDevice));
-    } else {
-        CqlScalars sc;
-        EXORL_CHECK_HIP(hipMemcpy(&sc, a->cql, sizeof(sc), hipMemcpyDeviceToHost));
-        host[0] = sc.log_alpha; host[1] = sc.m; host[2] = sc.v;
+    const int nsc = a->cfg.use_critic_lagrange ? 2 : 1;      // [1] = log_critic_alpha (cql.py:103-105)
+    for (int i = 0; i < nsc; ++i) {
+        float* h = host + 3 * i;
+        if (set) {
+            CqlScalars sc{h[0], h[1], h[2], expf(h[0])};
+            EXORL_CHECK_HIP(hipMemcpy(a->cql + i, &sc, sizeof(sc), hipMemcpyHostToDevice));
+        } else {
+            CqlScalars sc;
+            EXORL_CHECK_HIP(hipMemcpy(&sc, a->cql + i, sizeof(sc), hipMemcpyDeviceToHost));
+            h[0] = sc.log_alpha; h[1] = sc.m; h[2] = sc.v;
+        }
     }
     return 0;
 }

@@ -101,15 +101,64 @@ __device__ __forceinline__ void block_sum_c(float (&v)[NV], float (*sm)[16]) {
 __global__ __launch_bounds__(1024) void cql_critic_dq_kernel(const float* __restrict__ q_all, const float* __restrict__ tq,
                                                              const float* __restrict__ reward, const float* __restrict__ discount,
                                                              float* __restrict__ dq_all, float* __restrict__ metrics, int B, int n,
-                                                             float cql_alpha, float inv_bg) {
+                                                             float cql_alpha_in, float inv_bg, CqlScalars* lag,
+                                                             const AdamConst* __restrict__ cp, float target_penalty) {
+#pragma clang fp contract(off)
     __shared__ float sm[7][16];
+    __shared__ float sh_alpha;
     const int K = 3 * n;                     // re-evaluated rows per sample; the data row is the (K+1)-th entry
     const int64_t R = (int64_t)(K + 1) * B;
+    // pass 1: the batch scalars (the penalty decides the Lagrange multiplier before any gradient can be formed)
     float v[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // r, y, q1, q2, mse, lse, (q1+q2)
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         const float r = reward[b];
         const float y = r + discount[b] * fminf(tq[b], tq[B + b]);
         v[0] += r; v[1] += y;
+        for (int net = 0; net < 2; ++net) {
+            const float* q = q_all + net * R;
+            const float qd = q[(int64_t)K * B + b];
+            float mx = qd;
+            for (int k = 0; k < K; ++k) mx = fmaxf(mx, q[(int64_t)k * B + b]);
+            float se = expf(qd - mx);
+            for (int k = 0; k < K; ++k) se += expf(q[(int64_t)k * B + b] - mx);
+            const float e = qd - y;
+            v[2 + net] += qd;
+            v[4] += e * e;
+            v[5] += logf(se) + mx;
+            v[6] += qd;
+        }
+    }
+    block_sum_c<7>(v, sm);
+    if (threadIdx.x == 0) {
+        const float lse = v[5] * inv_bg, pen = lse - v[6] * inv_bg;
+        float alpha = cql_alpha_in;
+        if (lag) {                           // alpha_loss = -0.5 * clamp(exp(log_alpha), 0, 1e6) * (penalty - target); Adam; re-read
+            const AdamConst c = *cp;
+            const float ea = expf(lag->log_alpha);
+            const float g = (ea >= 0.0f && ea <= 1000000.0f) ? -0.5f * (pen - target_penalty) * ea : 0.0f;
+            float m = lag->m, vv = lag->v, p = lag->log_alpha;
+            m = m + c.one_minus_b1 * (g - m);
+            vv = vv * c.b2 + (c.one_minus_b2 * g) * g;
+            const float denom = sqrtf(vv) / c.bc2_sqrt + c.eps;
+            p = p + (c.neg_step_size * m) / denom;
+            lag->m = m; lag->v = vv; lag->log_alpha = p;
+            alpha = fminf(fmaxf(expf(p), 0.0f), 1000000.0f);
+            lag->alpha = alpha;
+        }
+        sh_alpha = alpha;
+        metrics[EXORL_M_BATCH_REWARD] = v[0] * inv_bg;
+        metrics[EXORL_M_CRITIC_TARGET_Q] = v[1] * inv_bg;
+        metrics[EXORL_M_CRITIC_Q1] = v[2] * inv_bg;
+        metrics[EXORL_M_CRITIC_Q2] = v[3] * inv_bg;
+        metrics[EXORL_M_CRITIC_CQL_LOGSUM] = lse;
+        metrics[EXORL_M_CRITIC_CQL] = pen;
+        metrics[EXORL_M_CRITIC_LOSS] = v[4] * inv_bg + alpha * pen;
+    }
+    __syncthreads();
+    const float cql_alpha = sh_alpha;
+    // pass 2: per-row gradients
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float y = reward[b] + discount[b] * fminf(tq[b], tq[B + b]);
         for (int net = 0; net < 2; ++net) {
             const float* q = q_all + net * R;
             float* dq = dq_all + net * R;
@@ -122,28 +171,14 @@ __global__ __launch_bounds__(1024) void cql_critic_dq_kernel(const float* __rest
             for (int k = 0; k < K; ++k) dq[(int64_t)k * B + b] = cql_alpha * expf(q[(int64_t)k * B + b] - mx) * inv * inv_bg;
             const float e = qd - y;
             dq[(int64_t)K * B + b] = cql_alpha * expf(qd - mx) * inv * inv_bg + 2.0f * e * inv_bg - cql_alpha * inv_bg;
-            v[2 + net] += qd;
-            v[4] += e * e;
-            v[5] += logf(se) + mx;
-            v[6] += qd;
         }
-    }
-    block_sum_c<7>(v, sm);
-    if (threadIdx.x == 0) {
-        const float lse = v[5] * inv_bg, pen = lse - v[6] * inv_bg;
-        metrics[EXORL_M_BATCH_REWARD] = v[0] * inv_bg;
-        metrics[EXORL_M_CRITIC_TARGET_Q] = v[1] * inv_bg;
-        metrics[EXORL_M_CRITIC_Q1] = v[2] * inv_bg;
-        metrics[EXORL_M_CRITIC_Q2] = v[3] * inv_bg;
-        metrics[EXORL_M_CRITIC_CQL_LOGSUM] = lse;
-        metrics[EXORL_M_CRITIC_CQL] = pen;
-        metrics[EXORL_M_CRITIC_LOSS] = v[4] * inv_bg + cql_alpha * pen;
     }
 }
 
 int cql_critic_dq(const float* q_all, const float* tq, const float* reward, const float* discount, float* dq_all, float* metrics,
-                  int B, int n, float cql_alpha, float inv_bg, hipStream_t s) {
-    hipLaunchKernelGGL(cql_critic_dq_kernel, dim3(1), dim3(1024), 0, s, q_all, tq, reward, discount, dq_all, metrics, B, n, cql_alpha, inv_bg);
+                  int B, int n, float cql_alpha, float inv_bg, hipStream_t s, CqlScalars* lag, const AdamConst* c_dev, float target_penalty) {
+    hipLaunchKernelGGL(cql_critic_dq_kernel, dim3(1), dim3(1024), 0, s, q_all, tq, reward, discount, dq_all, metrics, B, n, cql_alpha, inv_bg,
+                       lag, c_dev, target_penalty);
     EXORL_LAUNCH_CHECK();
     return 0;
 }

@@ -30,13 +30,13 @@ def _require_gpu(device):
 class AgentEngine:
     def __init__(self, kind, obs_dim, act_dim, hidden_dim, batch, lr=1e-4, tau=0.01, alpha=2.5, stddev_clip=0.3,
                  precision='fp32', world_size=1, seed=0, device='cuda', num_value_samples=10, weight_func='indicator',
-                 n_samples=3):
+                 n_samples=3, use_critic_lagrange=False, target_cql_penalty=5.0):
         self.lib = L.load()
         self.device = _require_gpu(device)
         self.kind = kind
         self.cfg = L.AgentCfg(KIND[kind], obs_dim, act_dim, hidden_dim, batch, PRECISION[precision], world_size, 0,
                               lr, tau, alpha, stddev_clip if stddev_clip is not None else 0.0, seed, num_value_samples,
-                              L.CRR_WEIGHT[weight_func], n_samples, 0)
+                              L.CRR_WEIGHT[weight_func], n_samples, int(bool(use_critic_lagrange)), target_cql_penalty, 0)
         self.obs_dim, self.act_dim, self.hidden_dim, self.batch = obs_dim, act_dim, hidden_dim, batch
         nbytes = self.lib.exorl_agent_workspace_bytes(C.byref(self.cfg))
         if nbytes == 0:
@@ -149,12 +149,12 @@ class AgentEngine:
         L.check(self.lib.exorl_agent_set_metrics(self.h, int(bool(enable))))
 
     def cql_alpha_state(self):
-        host = np.zeros(3, np.float32)
+        host = np.zeros(6, np.float32)
         L.check(self.lib.exorl_agent_cql_alpha(self.h, host.ctypes.data, 0))
-        return host            # log_actor_alpha, Adam m, Adam v
+        return host            # log_actor_alpha, Adam m, Adam v [, log_critic_alpha, m, v with use_critic_lagrange]
 
-    def set_cql_alpha_state(self, log_alpha, m=0.0, v=0.0):
-        host = np.array([log_alpha, m, v], np.float32)
+    def set_cql_alpha_state(self, log_alpha, m=0.0, v=0.0, log_critic_alpha=0.0, cm=0.0, cv=0.0):
+        host = np.array([log_alpha, m, v, log_critic_alpha, cm, cv], np.float32)
         L.check(self.lib.exorl_agent_cql_alpha(self.h, host.ctypes.data, 1))
 
     def metrics_raw(self):

@@ -153,7 +153,9 @@ typedef struct {
     int32_t num_value_samples; /* CRR: actions sampled per state for V(s) (crr.yaml: 10) */
     int32_t weight_func;       /* CRR: EXORL_CRR_* */
     int32_t n_samples;         /* CQL: action samples per source (cql.yaml: 3); `alpha` is then the CQL penalty weight */
-    int32_t reserved2;
+    int32_t use_critic_lagrange; /* CQL: learn the penalty weight (cql.py:201-213); single-GPU only */
+    float   target_cql_penalty;  /* CQL Lagrange target (cql.yaml: 5.0) */
+    int32_t reserved3;
 } exorl_agent_cfg;
 
 size_t exorl_agent_workspace_bytes(const exorl_agent_cfg* cfg);
@@ -194,7 +196,8 @@ int exorl_agent_update(exorl_agent_t* a, float stddev, const float* noise_critic
 int exorl_agent_update_phase(exorl_agent_t* a, int32_t phase, float stddev, const float* noise_critic_dev,
                              const float* noise_actor_dev, void* stream);
 int exorl_agent_stats_buffer(exorl_agent_t* a, void** ptr_dev, int64_t* numel);
-/* CQL: entropy temperature state (log_actor_alpha and its Adam moments), host <-> device. */
+/* CQL: entropy temperature state (log_actor_alpha and its Adam moments), host <-> device: host[0..2]; with
+ * use_critic_lagrange also host[3..5] = log_critic_alpha and its Adam moments (pass a 6-float array). */
 int exorl_agent_cql_alpha(exorl_agent_t* a, float* log_alpha_host, int32_t set);
 /* Policy inference for n rows: out = mean (eval) or TruncatedNormal sample (clip=None). */
 int exorl_agent_act(exorl_agent_t* a, const float* obs_dev, int32_t n, float stddev, int32_t eval_mode,

@@ -212,7 +212,8 @@ def uniform_from_normal(z):
 
 
 class OracleCQL:
-    def __init__(self, actor_params, critic_params, lr=1e-4, tau=0.01, alpha=0.01, n_samples=3, world_size=1, allreduce=None):
+    def __init__(self, actor_params, critic_params, lr=1e-4, tau=0.01, alpha=0.01, n_samples=3, world_size=1, allreduce=None,
+                 use_critic_lagrange=False, target_cql_penalty=5.0):
         self.actor = [np.array(p, F32) for p in actor_params]
         self.critic = [np.array(p, F32) for p in critic_params]
         self.critic_target = [p.copy() for p in self.critic]
@@ -221,6 +222,9 @@ class OracleCQL:
         self.actor_alpha_opt = Adam(self.log_actor_alpha, lr)
         self.tau, self.alpha, self.n = tau, alpha, n_samples
         self.world_size, self.allreduce = world_size, allreduce
+        self.use_critic_lagrange, self.target_cql_penalty = use_critic_lagrange, target_cql_penalty
+        self.log_critic_alpha = [np.zeros(1, F32)]                 # cql.py:103-105,111-112
+        self.critic_alpha_opt = Adam(self.log_critic_alpha, lr)
 
     def policy(self, obs):
         raw, cache = ActorNet.fwd_raw(self.actor, obs)
@@ -249,26 +253,35 @@ class OracleCQL:
         obs_all = np.concatenate([np.tile(obs, (3 * n, 1)), obs], 0)                 # repeat(n,1,1): sample-major rows
         q1a, q2a, caches = TwinCritic.fwd(self.critic, obs_all, acts)
         q1, q2 = q1a[3 * n * Bl:], q2a[3 * n * Bl:]
-        dqs, lse_sum = [], F32(0)
-        for qa, q in ((q1a, q1), (q2a, q2)):
+        ws, lse_sum = [], F32(0)
+        for qa in (q1a, q2a):
             cat = qa.reshape(3 * n + 1, Bl, 1)
             mx = cat.max(0, keepdims=True)
             ex = np.exp(cat - mx).astype(F32)
             se = ex.sum(0, keepdims=True, dtype=F32)
             lse_sum = lse_sum + (np.log(se) + mx).sum(dtype=F32) / F32(B)
-            w = (ex / se).astype(F32)                                                  # d logsumexp / d q
-            d = (F32(self.alpha) * w / F32(B)).astype(F32)
-            d[-1] += (F32(2) * (q - y) / F32(B) - F32(self.alpha) / F32(B)).astype(F32)
+            ws.append((ex / se).astype(F32))                                           # d logsumexp / d q
+        penalty = lse_sum - (q1 + q2).sum(dtype=F32) / F32(B)
+        alpha_c = F32(self.alpha)
+        if self.use_critic_lagrange:                                                   # cql.py:201-213 (single process only)
+            ea = np.exp(self.log_critic_alpha[0]).astype(F32)
+            inside = (ea >= 0.0) & (ea <= 1000000.0)                                   # torch.clamp passes the gradient on [min, max]
+            g = np.where(inside, F32(-0.5) * (penalty - F32(self.target_cql_penalty)) * ea, F32(0)).astype(F32)
+            self.critic_alpha_opt.step(self.log_critic_alpha, [g])
+            alpha_c = np.clip(np.exp(self.log_critic_alpha[0]).astype(F32), F32(0), F32(1000000.0))[0]
+        dqs = []
+        for w, q in zip(ws, (q1, q2)):
+            d = (alpha_c * w / F32(B)).astype(F32)
+            d[-1] += (F32(2) * (q - y) / F32(B) - alpha_c / F32(B)).astype(F32)
             dqs.append(d.reshape(-1, 1))
         e1, e2 = q1 - y, q2 - y
         mse = ((e1 * e1).sum(dtype=F32) + (e2 * e2).sum(dtype=F32)) / F32(B)
-        penalty = lse_sum - (q1 + q2).sum(dtype=F32) / F32(B)
         grads, _ = TwinCritic.bwd(self.critic, caches, dqs[0], dqs[1], need_dx=False)
         if self.world_size > 1:
             self.allreduce(grads)
         self.critic_opt.step(self.critic, grads)
         m.update(critic_target_q=float(y.mean(dtype=F32)), critic_q1=float(q1.mean(dtype=F32)), critic_q2=float(q2.mean(dtype=F32)),
-                 critic_loss=float(mse + F32(self.alpha) * penalty), critic_cql=float(penalty), critic_cql_logsum=float(lse_sum))
+                 critic_loss=float(mse + alpha_c * penalty), critic_cql=float(penalty), critic_cql_logsum=float(lse_sum))
         self.last_critic_grads = grads
         # ---- actor (cql.py:234-263)
         mu, std, ls, cache = self.policy(obs)

@@ -296,10 +296,15 @@ def _cql_hook(draws):
     return hook
 
 
-def test_cql_tiny_trajectory_vs_reference(gold):
-    z = np.load(gold / 'tiny_cql.npz')
+@pytest.mark.parametrize('variant', ['cql', 'cql-lagrange'])
+def test_cql_tiny_trajectory_vs_reference(gold, variant):
+    z = np.load(gold / f'tiny_{variant}.npz')
     torch.manual_seed(21)
-    ag = make('cql', 5, 3, 32, 8)
+    if variant == 'cql':
+        ag = make('cql', 5, 3, 32, 8)
+    else:           # use_critic_lagrange=True, target_cql_penalty 5.0 (cql.py:201-213)
+        from exorl_amd import agents
+        ag = agents.CQLAgent('cql', (5,), (3,), 'cuda', 1e-4, 32, 0.01, 1, 8, True, 0.01, 3, 5.0, True)
     for nm, net in nets_of(ag):
         for k, v in net.state_dict().items():
             np.testing.assert_allclose(v.cpu().numpy(), z[f'init/{nm}/{k}'], rtol=0, atol=2e-6, err_msg=f'{nm}.{k}')
@@ -314,6 +319,8 @@ def test_cql_tiny_trajectory_vs_reference(gold):
         for k, v in net.state_dict().items():
             np.testing.assert_allclose(v.cpu().numpy(), z[f'final/{nm}/{k}'], rtol=1e-4, atol=2e-6, err_msg=f'{nm}.{k}')
     np.testing.assert_allclose(ag.log_actor_alpha.numpy(), z['final/log_actor_alpha'], rtol=1e-5, atol=1e-8)
+    if variant == 'cql-lagrange':
+        np.testing.assert_allclose(ag.log_critic_alpha.numpy(), z['final/log_critic_alpha'], rtol=1e-5, atol=1e-8)
 
 
 def test_cql_full_size_vs_reference_fp32(gold):

@@ -124,11 +124,13 @@ def test_full_size_trajectory(gold, kind):
             assert abs(m[k] - v) <= 1e-4 * abs(v) + 1e-6, (kind, i, k, m[k], v)
 
 
-def test_cql_tiny_trajectory(gold):
-    """Oracle CQL vs the reference's CQLAgent (tiny_cql.npz): all 11 metrics, final weights and log_actor_alpha."""
+@pytest.mark.parametrize('variant', ['cql', 'cql-lagrange'])
+def test_cql_tiny_trajectory(gold, variant):
+    """Oracle CQL vs the reference's CQLAgent (tiny_cql.npz, and use_critic_lagrange=True in tiny_cql-lagrange.npz): all 11
+    metrics, final weights, log_actor_alpha and log_critic_alpha."""
     from oracle.agents import OracleCQL
-    z, ash, csh, actor, critic = _load_tiny(gold, 'cql')
-    ag = OracleCQL(actor, critic)
+    z, ash, csh, actor, critic = _load_tiny(gold, variant)
+    ag = OracleCQL(actor, critic, use_critic_lagrange=variant.endswith('lagrange'))
     keys = [str(k) for k in z['metric_keys']]
     ni = 0
     for i in range(5):
@@ -143,3 +145,4 @@ def test_cql_tiny_trajectory(gold):
         np.testing.assert_allclose(p, z[f'final/critic/{k}'], rtol=1e-4, atol=2e-6, err_msg=k)
         np.testing.assert_allclose(t, z[f'final/critic_target/{k}'], rtol=1e-4, atol=2e-6, err_msg=k)
     np.testing.assert_allclose(ag.log_actor_alpha[0], z['final/log_actor_alpha'], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(ag.log_critic_alpha[0], z['final/log_critic_alpha'], rtol=1e-5, atol=1e-8)

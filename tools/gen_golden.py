@@ -282,8 +282,9 @@ def checksums(agent):
     return cs
 
 
+TINY_CQL_LAGRANGE = 'cql-lagrange'
 UNSUP = ('ddpg', 'rnd', 'icm', 'icm_apt', 'disagreement', 'diayn', 'proto')
-TINY_KINDS = ('td3_bc', 'td3', 'bc', 'ddpg', 'crr', 'crr-exp', 'crr-identity', 'cql', 'rnd', 'icm', 'icm_apt', 'icm_apt-kth', 'disagreement', 'diayn', 'proto')
+TINY_KINDS = ('td3_bc', 'td3', 'bc', 'ddpg', 'crr', 'crr-exp', 'crr-identity', 'cql', 'rnd', 'icm', 'icm_apt', 'icm_apt-kth', 'disagreement', 'diayn', 'proto', 'cql-lagrange')
 
 
 def gen_tiny(ref):
@@ -294,6 +295,8 @@ def gen_tiny(ref):
         extra = {'weight_func': wf} if (wf and base == 'crr') else {}
         if kind == 'icm_apt-kth':
             extra = {'knn_avg': False, 'knn_clip': 0.0005}
+        if kind == TINY_CQL_LAGRANGE:
+            extra = {'use_critic_lagrange': True}
         agent = make_agent(ref, base, O, A, H, B, **extra)
         out = {}
         intr_log = []
