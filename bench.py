@@ -198,7 +198,8 @@ def main():
         if args.precision == 'bf16' and tf.exists():
             traffic = json.load(open(tf))['traffic_bytes_per_launch']
         out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic,
-                           'kernel': ('gemm16g_kernel' if args.precision == 'bf16' else 'gemm_kernel') + ' (grouped 2x[1024x1024x1024], fwd/dgrad/wgrad of Linear(H,H))',
+                           'kernel': ('gemm16g_kernel / gemm16g_mixed_kernel (grouped 2-4 x [1024x1024x1024]: fwd, dgrad, wgrad+dgrad of Linear(H,H))'
+                                      if args.precision == 'bf16' else 'gemm_kernel (grouped 2x[1024x1024x1024], fwd/dgrad/wgrad of Linear(H,H))'),
                            'launches': int(big.sum()), 'event_overhead_us': float(ovh.value * 1e3),
                            'avg_us': float(ms[big].mean() * 1e3), 'flop_per_launch': float(fl[big].mean()),
                            'all_gemm_us_per_step': float(ms.sum() * 1e3 / nprof), 'gemm_launches_per_step': n.value / nprof}

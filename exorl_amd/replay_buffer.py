@@ -159,8 +159,9 @@ class DeviceReplayLoader:
     """What make_replay_loader returns: iterable whose iterator yields device-resident minibatches."""
 
     def __init__(self, storage, max_size, batch_size, num_workers, save_snapshot, nstep, discount, fetch_every=1000,
-                 device='cuda', sampler='mt19937', seed=None, worker_ids=None, max_episodes=None, capacity_rows=None):
+                 device='cuda', sampler='mt19937', seed=None, worker_ids=None, max_episodes=None, capacity_rows=None, static=False):
         self.storage = storage
+        self.static = static                # the directory will not change (offline datasets): load once, never re-scan
         self.num_workers = max(1, num_workers)
         self.max_size = max_size // self.num_workers          # replay_buffer.py:262
         self.batch_size = batch_size
@@ -187,6 +188,24 @@ class DeviceReplayIterator:
         self.shards = [_Shard(loader, w) for w in loader.worker_ids]
         self.turn = 0
         self._seeded = False
+        # what agent.enable_graph reads; .engine is only set for a static single-shard dataset (see static_engine)
+        self.sampler, self.nstep, self.discount, self.batch_size = loader.sampler, loader.nstep, loader.discount, loader.batch_size
+
+    @property
+    def engine(self):
+        """The HBM arena, when sampling from it can be captured into the agent's hipGraph: a static directory held by one
+        shard with the Philox sampler (no host-side re-scan or MT19937 draws between steps). None otherwise."""
+        ld = self.loader
+        if not (ld.static and len(self.shards) == 1 and ld.sampler == L.SAMPLER_PHILOX):
+            return None
+        shard = self.shards[0]
+        if shard.engine is None:
+            shard.try_fetch()
+            if shard.engine is None:
+                raise IndexError('replay buffer is empty (random.choice on an empty list, replay_buffer.py:169)')
+            self._seed(shard)
+        shard.since_fetch = -(1 << 62)      # the captured graph samples without passing through the fetch counter
+        return shard.engine
 
     def __iter__(self):
         return self
@@ -304,4 +323,5 @@ class _DirStorage:
 def make_offline_replay_loader(env, replay_dir, max_size, batch_size, num_workers, discount, **kw):
     """replay_buffer.py:246-258 (OfflineReplayBuffer semantics: nstep=1, files kept on disk). Reward
     re-labelling through MuJoCo physics (relabel_episode, :31-42) is the caller's concern and out of scope."""
+    kw.setdefault('static', True)
     return DeviceReplayLoader(_DirStorage(replay_dir), max_size, batch_size, num_workers, True, 1, discount, **kw)
