@@ -12,7 +12,7 @@ P = C.POINTER
 
 # constants mirrored from include/exorl_hip.h
 SAMPLER_MT19937, SAMPLER_PHILOX, SAMPLER_GIVEN = 0, 1, 2
-AGENT_TD3_BC, AGENT_TD3, AGENT_BC, AGENT_DDPG, AGENT_CRR, AGENT_CQL = 0, 1, 2, 3, 4, 5
+AGENT_TD3_BC, AGENT_TD3, AGENT_BC, AGENT_DDPG, AGENT_CRR, AGENT_CQL, AGENT_APS = 0, 1, 2, 3, 4, 5, 6
 M_CRITIC_CQL, M_CRITIC_CQL_LOGSUM, M_ACTOR_ALPHA, M_ACTOR_ALPHA_LOSS, M_ACTOR_ENT = 10, 11, 12, 13, 14
 CRR_WEIGHT = {'identity': 0, 'indicator': 1, 'exp': 2}
 PREC_F32, PREC_BF16 = 0, 1
@@ -20,8 +20,8 @@ NET_ACTOR, NET_CRITIC, NET_CRITIC_TARGET = 0, 1, 2
 T_PARAM, T_GRAD, T_ADAM_M, T_ADAM_V = 0, 1, 2, 3
 M_BATCH_REWARD, M_CRITIC_TARGET_Q, M_CRITIC_Q1, M_CRITIC_Q2, M_CRITIC_LOSS, M_ACTOR_LOSS, M_ACTOR_LOGPROB = range(7)
 N_METRICS = 16
-INTR_RND, INTR_ICM, INTR_ICM_APT, INTR_DISAGREEMENT, INTR_DIAYN, INTR_PROTO = 0, 1, 2, 3, 4, 5
-IM_LOSS, IM_INTR_REWARD, IM_EXTR_REWARD, IM_RMS_MEAN, IM_RMS_STD, IM_ACC = range(6)
+INTR_RND, INTR_ICM, INTR_ICM_APT, INTR_DISAGREEMENT, INTR_DIAYN, INTR_PROTO, INTR_APS = 0, 1, 2, 3, 4, 5, 6
+IM_LOSS, IM_INTR_REWARD, IM_EXTR_REWARD, IM_RMS_MEAN, IM_RMS_STD, IM_ACC, IM_ENT_REWARD, IM_SF_REWARD = range(8)
 N_INTR_METRICS = 8
 
 
@@ -38,7 +38,7 @@ class BatchOut(C.Structure):
 
 class AgentCfg(C.Structure):
     _fields_ = [('kind', c_int32), ('obs_dim', c_int32), ('act_dim', c_int32), ('hidden_dim', c_int32),
-                ('batch', c_int32), ('precision', c_int32), ('world_size', c_int32), ('reserved', c_int32),
+                ('batch', c_int32), ('precision', c_int32), ('world_size', c_int32), ('sf_dim', c_int32),
                 ('lr', c_float), ('tau', c_float), ('alpha', c_float), ('stddev_clip', c_float), ('seed', c_uint64),
                 ('num_value_samples', c_int32), ('weight_func', c_int32), ('n_samples', c_int32), ('use_critic_lagrange', c_int32),
                 ('target_cql_penalty', c_float), ('reserved3', c_int32)]

@@ -8,6 +8,7 @@ Reference classes mirrored (file:line in /root/reference):
   RNDAgent    agents/unsupervised_learning/rnd.py:63-159     ICMAgent  agents/unsupervised_learning/icm.py:48-139
   ICMAPTAgent agents/unsupervised_learning/icm_apt.py:60-158 DisagreementAgent agents/unsupervised_learning/disagreement.py:50-136
   DIAYNAgent  agents/unsupervised_learning/diayn.py:32-176     ProtoAgent agents/unsupervised_learning/proto.py:46-207 (states)
+  APSAgent    agents/unsupervised_learning/aps.py:82-320
 
 Python here is orchestration only: it builds the initial weights with torch's CPU RNG in the reference's
 construction order (so a given torch.manual_seed yields the reference's initial parameters), hands batches
@@ -136,7 +137,7 @@ class _AgentBase:
                           'bn': it.bn.cpu() if it.bn is not None else None, 'opt_steps': it.opt_steps(),
                           'queue': (it.queue.cpu(), it.queue_ptr()) if it.queue is not None else None}
         skip = {'engine', 'intr', 'actor', 'critic', 'critic_target', 'rnd', 'icm', 'pbe', 'intrinsic_reward_rms', 'disagreement', 'diayn',
-                'predictor', 'predictor_target', 'projector', 'protos', 'queue', 'encoder_target', 'cat_hook', 'aug', 'encoder',
+                'predictor', 'predictor_target', 'projector', 'protos', 'queue', 'encoder_target', 'cat_hook', 'aps', 'aug', 'encoder',
                 'noise_hook', '_slots', '_graph_iter', '_graph_stddev', '_ctor'}
         st['attrs'] = {k: v for k, v in self.__dict__.items() if k not in skip and not k.startswith('_keep')}
         return st
@@ -171,7 +172,7 @@ class _AgentBase:
 
     def _build(self, obs_dim, action_dim, hidden_dim, batch_size, lr, tau, alpha, stddev_clip, device, precision, seed,
                **engine_kw):
-        ddpg = self.KIND == 'ddpg'
+        ddpg = self.KIND in ('ddpg', 'aps')
         ws = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             ws = torch.distributed.get_world_size()
@@ -183,6 +184,9 @@ class _AgentBase:
             nt = 1 if ddpg else 2
             critic0 = _mlp_init(obs_dim + action_dim, hidden_dim, 1, nt, 2)
             _mlp_init(obs_dim + action_dim, hidden_dim, 1, nt, 2)       # critic_target's draws, overwritten by the copy
+            if self.KIND == 'aps':      # APSAgent builds DDPG's scalar critics first, then replaces both with CriticSF (aps.py:94-104)
+                critic0 = _mlp_init(obs_dim + action_dim, hidden_dim, engine_kw['sf_dim'], 1, 2)
+                _mlp_init(obs_dim + action_dim, hidden_dim, engine_kw['sf_dim'], 1, 2)
         self.engine = AgentEngine(self.KIND, obs_dim, action_dim, hidden_dim, batch_size, lr=lr, tau=tau, alpha=alpha,
                                   stddev_clip=stddev_clip, precision=precision, world_size=ws, seed=seed, device=device,
                                   **engine_kw)
@@ -517,9 +521,12 @@ class DDPGAgent(_AgentBase):
         self.encoder_opt = None
         self._precision = precision
         self._build(self.obs_dim, action_shape[0], hidden_dim, batch_size, lr, critic_target_tau, 0.0, stddev_clip, device,
-                    precision, seed)
+                    precision, seed, **self._engine_kw())
         self.train()
         self.critic_target.train()
+
+    def _engine_kw(self):
+        return {}
 
     def train(self, training=True):
         super().train(training)
@@ -644,6 +651,9 @@ class _IntrAgent(DDPGAgent):
                 metrics['extr_reward'] = float(raw[L.IM_EXTR_REWARD])
                 if self.LOSS_KEY == 'diayn_loss':
                     metrics['diayn_acc'] = float(raw[L.IM_ACC])
+                if self.LOSS_KEY == 'aps_loss':
+                    metrics['intr_ent_reward'] = float(raw[L.IM_ENT_REWARD])
+                    metrics['intr_sf_reward'] = float(raw[L.IM_SF_REWARD])
                 if self.LOSS_KEY == 'rnd_loss':
                     metrics['pred_error_mean'] = float(raw[L.IM_RMS_MEAN])
                     metrics['pred_error_std'] = float(raw[L.IM_RMS_STD])
@@ -741,13 +751,42 @@ class _Spec:
         self.shape, self.dtype, self.name = tuple(shape), np.dtype(dtype), name
 
 
-class DIAYNAgent(_IntrAgent):
+class _MetaObsMixin:
+    """Agents whose batch carries a 6th tensor (DIAYN's skill, APS's task) that is appended to obs / next_obs for the actor and
+    critic (diayn.py:162-164, aps.py:236-238) while the module sees the raw observation: the agent's batch slots hold
+    [obs | meta] rows, the module gets strided views of them."""
+    _meta_dim = 0
+
+    def _views(self):
+        s = self._slots = self._slots or self.engine.batch_slots()
+        B, W = self.engine.batch, self.obs_dim
+        return s, self.engine._view(s.obs, B * W).view(B, W), self.engine._view(s.next_obs, B * W).view(B, W)
+
+    def _load_batch(self, replay_iter):
+        O, S = self.obs_dim - self._meta_dim, self._meta_dim
+        s, obs_v, next_v = self._views()
+        if hasattr(replay_iter, 'sample_into'):      # HBM sampler: obs and the meta columns land in the [obs | meta] rows
+            out = L.BatchOut(s.obs, s.obs_stride, s.action, s.action_stride, s.reward, s.discount, s.next_obs, s.next_obs_stride,
+                             s.obs + 4 * O, O + S)
+            replay_iter.sample_into(out, self.engine.batch)
+            next_v[:, O:].copy_(obs_v[:, O:])
+            return
+        obs, action, reward, discount, next_obs, meta = [torch.as_tensor(x).to(self.engine.device, torch.float32) for x in next(replay_iter)[:6]]
+        self.engine.set_batch(torch.cat([obs, meta], 1), action, reward, discount, torch.cat([next_obs, meta], 1))
+
+    def _intr_step(self):
+        O, W = self.obs_dim - self._meta_dim, self.obs_dim
+        s = self._slots
+        self.intr.update(s.obs, None, s.next_obs, s.reward, s.reward, True, skill=s.obs + 4 * O, obs_ld=W, next_obs_ld=W, skill_ld=W)
+
+
+class DIAYNAgent(_MetaObsMixin, _IntrAgent):
     """agents/unsupervised_learning/diayn.py:32-176 (configs/agent/diayn.yaml): the skill rides in the batch as a 6th tensor and
     is appended to obs / next_obs for the actor and critic; the discriminator sees the raw next_obs."""
     LOSS_KEY = 'diayn_loss'
 
     def __init__(self, update_skill_every_step, skill_dim, diayn_scale, update_encoder, **kwargs):
-        self.skill_dim = skill_dim
+        self.skill_dim = self._meta_dim = skill_dim
         self.update_skill_every_step = update_skill_every_step
         self.diayn_scale = diayn_scale
         self.update_encoder = update_encoder
@@ -780,27 +819,82 @@ class DIAYNAgent(_IntrAgent):
             return self.init_meta()
         return meta
 
-    def _views(self):
-        s = self._slots = self._slots or self.engine.batch_slots()
-        B, W = self.engine.batch, self.obs_dim
-        return s, self.engine._view(s.obs, B * W).view(B, W), self.engine._view(s.next_obs, B * W).view(B, W)
 
-    def _load_batch(self, replay_iter):
-        O, S = self.obs_dim - self.skill_dim, self.skill_dim
-        s, obs_v, next_v = self._views()
-        if hasattr(replay_iter, 'sample_into'):      # HBM sampler: obs and the skill (meta) columns land in the [obs | skill] rows
-            out = L.BatchOut(s.obs, s.obs_stride, s.action, s.action_stride, s.reward, s.discount, s.next_obs, s.next_obs_stride,
-                             s.obs + 4 * O, O + S)
-            replay_iter.sample_into(out, self.engine.batch)
-            next_v[:, O:].copy_(obs_v[:, O:])
-            return
-        obs, action, reward, discount, next_obs, skill = [torch.as_tensor(x).to(self.engine.device, torch.float32) for x in next(replay_iter)[:6]]
-        self.engine.set_batch(torch.cat([obs, skill], 1), action, reward, discount, torch.cat([next_obs, skill], 1))
+_APS_KEYS = [f'state_feat_net.{i}.{w}' for i in (0, 2, 4) for w in ('weight', 'bias')]
 
-    def _intr_step(self):
-        O, W = self.obs_dim - self.skill_dim, self.obs_dim
-        s = self._slots
-        self.intr.update(s.obs, None, s.next_obs, s.reward, s.reward, True, skill=s.obs + 4 * O, obs_ld=W, next_obs_ld=W, skill_ld=W)
+
+class APSAgent(_MetaObsMixin, _IntrAgent):
+    """agents/unsupervised_learning/aps.py:82-320 (configs/agent/aps.yaml): DDPG whose critic emits sf_dim successor features per
+    head, Q = task . features (CriticSF, aps.py:12-60); the task vector rides in the batch and in the trailing columns of obs."""
+    KIND = 'aps'
+    LOSS_KEY = 'aps_loss'
+
+    def __init__(self, update_task_every_step, sf_dim, knn_rms, knn_k, knn_avg, knn_clip, num_init_steps, lstsq_batch_size, update_encoder,
+                 **kwargs):
+        self.sf_dim = self._meta_dim = sf_dim
+        self.update_task_every_step = update_task_every_step
+        self.num_init_steps = num_init_steps
+        self.lstsq_batch_size = lstsq_batch_size
+        self.update_encoder = update_encoder
+        kwargs['meta_dim'] = self.sf_dim
+        super().__init__(**kwargs)
+        O, H = self.obs_dim - self.sf_dim, self.hidden_dim
+        w = _seq_init([('lin', O, H), ('lin', H, H), ('lin', H, sf_dim)])
+        self.intr = IntrEngine('aps', O, self.action_dim, H, self.engine.batch, rep_dim=sf_dim, lr=self.lr, knn_k=knn_k, knn_avg=knn_avg,
+                               knn_rms=knn_rms, knn_clip=knn_clip, precision=self._precision, device=self.device)
+        self.aps = NetView(self.intr, None, _APS_KEYS)
+        for p, t in zip(self.aps.parameters(), w):
+            p.copy_(t.reshape(p.shape))
+        self.pbe = _PbeView(self.intr)
+
+    def _engine_kw(self):
+        return {'sf_dim': self.sf_dim}
+
+    def get_meta_specs(self):
+        return (_Spec((self.sf_dim,), np.float32, 'task'),)
+
+    def init_meta(self):
+        if self.solved_meta is not None:
+            return self.solved_meta
+        task = torch.randn(self.sf_dim)
+        task = task / torch.norm(task)
+        meta = OrderedDict()
+        meta['task'] = task.cpu().numpy()
+        return meta
+
+    def update_meta(self, meta, global_step, time_step, finetune=False):
+        if global_step % self.update_task_every_step == 0:
+            return self.init_meta()
+        return meta
+
+    @torch.no_grad()
+    def regress_meta(self, replay_iter, step):
+        """aps.py:247-266: least-squares task from (reward, phi(obs)) pairs at the start of fine-tuning. Host-side, once per run;
+        the features come from the module's forward pass (reward-only call on zero tasks), the solve is torch.linalg.lstsq."""
+        obs, reward = [], []
+        n = 0
+        while n < self.lstsq_batch_size:
+            batch = next(replay_iter)
+            o, r = torch.as_tensor(batch[0]).to(self.device, torch.float32), torch.as_tensor(batch[2]).to(self.device, torch.float32)
+            obs.append(o)
+            reward.append(r.reshape(-1, 1))
+            n += o.shape[0]
+        obs, reward = torch.cat(obs, 0), torch.cat(reward, 0)
+        rep = self._features(obs)
+        task = torch.linalg.lstsq(reward, rep)[0][:rep.size(1), :][0]
+        task = task / torch.norm(task)
+        meta = OrderedDict()
+        meta['task'] = task.cpu().numpy()
+        self.solved_meta = meta
+        return meta
+
+    def _features(self, obs):
+        """F.normalize(state_feat_net(obs)) for arbitrary row counts: three Linear layers on the module's own parameter views
+        (inference outside the update path; torch GEMMs are plumbing here, not the hot path)."""
+        p = self.aps.parameters()
+        h = torch.relu(obs @ p[0].t() + p[1])
+        h = torch.relu(h @ p[2].t() + p[3])
+        return torch.nn.functional.normalize(h @ p[4].t() + p[5], dim=-1)
 
 
 class _TensorsView(NetView):

@@ -314,6 +314,7 @@ struct exorl_agent {
     FwdBufs fa{}, ft{}, fc{};    // actor (2B rows), target critic, critic
     BwdBufs bc{}, ba{};
     float *dq = nullptr, *da = nullptr, *dpre = nullptr, *abs_part = nullptr;
+    float *sfq = nullptr, *sftq = nullptr;           // APS: scalar Q = task . successor features of critic / target (2, B)
     float *x_all = nullptr, *dq_all = nullptr;     // CQL: (3n+1)B critic rows and their per-row loss gradients
     CqlScalars* cql = nullptr;                      // CQL: log_actor_alpha + Adam moments + alpha (device)
     float *xc_rep = nullptr, *crr_w = nullptr;     // CRR: repeated (obs, sampled action) inputs; advantage weights
@@ -375,8 +376,9 @@ static void carve(exorl_agent* a, Carver& c) {
     if (a->has_critic) {
         const int64_t nt = a->critic.n_trunks;
         a->xc_cur = c.take(B * W); a->xc_next = c.take(B * W); a->xc_pi = c.take(B * W);
-        a->ft = FwdBufs{c.take(nt * B * H), nullptr, nullptr, c.take(2 * B * H), c.take(2 * B), bf ? take_u16(nt * B * H) : nullptr, nullptr};
-        a->fc = FwdBufs{c.take(nt * RC * H), c.take(nt * RC * H), c.take(nt * RC), c.take(2 * RC * H), c.take(2 * RC), bf ? take_u16(nt * RC * H) : nullptr,
+        const int64_t od = a->critic.out_dim;
+        a->ft = FwdBufs{c.take(nt * B * H), nullptr, nullptr, c.take(2 * B * H), c.take(2 * B * od), bf ? take_u16(nt * B * H) : nullptr, nullptr};
+        a->fc = FwdBufs{c.take(nt * RC * H), c.take(nt * RC * H), c.take(nt * RC), c.take(2 * RC * H), c.take(2 * RC * od), bf ? take_u16(nt * RC * H) : nullptr,
                         bf ? take_u16(nt * RC * H) : nullptr};
         a->bc = BwdBufs{c.take(2 * RC * H), c.take(nt * RC * H), bf ? take_u16(2 * RC * H) : nullptr};
         if (cfg.kind == EXORL_AGENT_CQL) {
@@ -385,6 +387,7 @@ static void carve(exorl_agent* a, Carver& c) {
             a->cql = reinterpret_cast<CqlScalars*>(c.take(16));
         }
         a->dq = c.take(2 * B);
+        if (cfg.kind == EXORL_AGENT_APS) { a->sfq = c.take(2 * B); a->sftq = c.take(2 * B); }
         a->abs_part = c.take(2 * (int64_t)qhead_chunks(B));
         a->da = c.take(nt * B * A);
         if (cfg.kind == EXORL_AGENT_CRR) {
@@ -395,14 +398,16 @@ static void carve(exorl_agent* a, Carver& c) {
         }
         a->sh_critic = NetShadow{c.take(nt * W * H), bf ? take_u16(2 * H * H) : nullptr, bf ? take_u16(nt * H * round_up(W, 32)) : nullptr};
         a->sh_target = NetShadow{c.take(nt * W * H), bf ? take_u16(2 * H * H) : nullptr, bf ? take_u16(nt * H * round_up(W, 32)) : nullptr};
-        a->pc = Partials{c.take(2 * (int64_t)qhead_chunks(RC) * (2 * H + 16)), c.take(nt * (int64_t)trunk_chunks(RC) * 3 * H),
+        a->pc = Partials{c.take(2 * (int64_t)qhead_chunks(RC) * ((od + 1) * H + 32)), c.take(nt * (int64_t)trunk_chunks(RC) * 3 * H),
                          c.take(nt * (int64_t)outer_chunks(RC) * W * H)};
     }
 }
 
 static int describe(exorl_agent* a, const exorl_agent_cfg* cfg) {
     EXORL_REQUIRE(cfg, "agent: null cfg");
-    EXORL_REQUIRE(cfg->kind >= EXORL_AGENT_TD3_BC && cfg->kind <= EXORL_AGENT_CQL, "agent: unknown kind %d", cfg->kind);
+    EXORL_REQUIRE(cfg->kind >= EXORL_AGENT_TD3_BC && cfg->kind <= EXORL_AGENT_APS, "agent: unknown kind %d", cfg->kind);
+    EXORL_REQUIRE(cfg->kind != EXORL_AGENT_APS || (cfg->sf_dim >= 1 && cfg->sf_dim <= 16 && cfg->sf_dim < cfg->obs_dim),
+                  "agent: APS needs 1 <= sf_dim <= 16 and obs_dim = observation + sf_dim (got sf_dim=%d obs_dim=%d)", cfg->sf_dim, cfg->obs_dim);
     EXORL_REQUIRE(cfg->kind != EXORL_AGENT_CQL || (cfg->n_samples >= 1 && cfg->n_samples <= 16 && cfg->act_dim <= 16),
                   "agent: CQL needs 1 <= n_samples <= 16 and action_dim <= 16 (got %d, %d)", cfg->n_samples, cfg->act_dim);
     EXORL_REQUIRE(!cfg->use_critic_lagrange || (cfg->kind == EXORL_AGENT_CQL && cfg->world_size == 1),
@@ -422,7 +427,8 @@ static int describe(exorl_agent* a, const exorl_agent_cfg* cfg) {
     a->has_critic = cfg->kind != EXORL_AGENT_BC;
     a->actor = make_net(cfg->obs_dim, cfg->kind == EXORL_AGENT_CQL ? 2 * cfg->act_dim : cfg->act_dim, cfg->hidden_dim, 1, 1);
     if (a->has_critic)
-        a->critic = make_net(cfg->obs_dim + cfg->act_dim, 1, cfg->hidden_dim, cfg->kind == EXORL_AGENT_DDPG ? 1 : 2, 2);
+        a->critic = make_net(cfg->obs_dim + cfg->act_dim, cfg->kind == EXORL_AGENT_APS ? cfg->sf_dim : 1, cfg->hidden_dim,
+                             (cfg->kind == EXORL_AGENT_DDPG || cfg->kind == EXORL_AGENT_APS) ? 1 : 2, 2);
     a->inv_bg = 1.0f / ((float)cfg->batch * (float)cfg->world_size);
     return 0;
 }
@@ -525,10 +531,19 @@ static int phase0(exorl_agent* a, float stddev, const float* noise_c, hipStream_
         EXORL_TRY(a->fk.join(s));
     }
     if (qf) EXORL_TRY(run_qhead(a, 0, s));       // Q, Q', TD gradient, dz2 and head partials in one kernel
+    const bool aps = cfg.kind == EXORL_AGENT_APS;
+    const float* task = aps ? a->obs + (O - cfg.sf_dim) : nullptr;          // obs rows are [observation | task] (aps.py:236-238)
+    const float *qv = a->fc.out, *tqv = a->ft.out;
+    if (aps) {                                  // Q = task . successor features (aps.py:55-58)
+        EXORL_TRY(sf_q(a->ft.out, task, O, a->sftq, B, cfg.sf_dim, 2, s));
+        EXORL_TRY(sf_q(a->fc.out, task, O, a->sfq, B, cfg.sf_dim, 2, s));
+        qv = a->sfq; tqv = a->sftq;
+    }
     if (a->want_metrics)
-        EXORL_TRY(critic_loss(a->fc.out, a->ft.out, a->reward, a->discount, a->dq, a->metrics, B, a->inv_bg, s));   // :133-137
+        EXORL_TRY(critic_loss(qv, tqv, a->reward, a->discount, a->dq, a->metrics, B, a->inv_bg, s));   // :133-137
     DoutSpec td{};                              // d(2 x MSE)/dQ computed where it is consumed (:127-131)
-    td.mode = EXORL_DOUT_TD; td.q = a->fc.out; td.tq = a->ft.out; td.reward = a->reward; td.discount = a->discount; td.inv_bg = a->inv_bg;
+    td.mode = EXORL_DOUT_TD; td.q = qv; td.tq = tqv; td.reward = a->reward; td.discount = a->discount; td.inv_bg = a->inv_bg;
+    td.task = task; td.task_ld = O;
     EXORL_TRY(net_backward(a->critic, Pc, a->sh_critic, a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD], a->pc, a->xc_cur, W, B, a->fc, td,
                            a->bc, nullptr, 0, 0, prec, s, a->fk, a->fuse_opt ? &a->pend_c : nullptr, qf));                       // :141
     return 0;
@@ -551,13 +566,18 @@ static int phase1(exorl_agent* a, float stddev, const float* noise_a, hipStream_
         return 0;
     }
     // pi(obs) sample already sits in xc_pi (phase 0); DDPG logs its log-prob (ddpg.py:276,289)
-    if (cfg.kind == EXORL_AGENT_DDPG && a->want_metrics)
+    if ((cfg.kind == EXORL_AGENT_DDPG || cfg.kind == EXORL_AGENT_APS) && a->want_metrics)
         EXORL_TRY(sample_action(a->fa.out + (int64_t)B * A, noise_spec(a, noise_a, 1), stddev, cfg.stddev_clip, 1, a->xc_pi + O, W, B, A,
                                 a->metrics + EXORL_M_ACTOR_LOGPROB, s));
     const bool qf = qfuse(a);
     EXORL_TRY(net_forward(a->critic, a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->sh_critic, a->xc_pi, W, B, a->fc, true, false, prec, s,
                           nullptr, qf));
-    if (!qf) EXORL_TRY(actor_stats(a->fc.out, a->stats, B, s));
+    if (cfg.kind == EXORL_AGENT_APS) {
+        EXORL_TRY(sf_q(a->fc.out, a->obs + (O - cfg.sf_dim), O, a->sfq, B, cfg.sf_dim, 2, s));
+        EXORL_TRY(actor_stats(a->sfq, a->stats, B, s));
+    } else if (!qf) {
+        EXORL_TRY(actor_stats(a->fc.out, a->stats, B, s));
+    }
     return 0;
 }
 
@@ -569,6 +589,7 @@ static int phase2(exorl_agent* a, float stddev, hipStream_t s) {
     if (a->has_critic && cfg.kind != EXORL_AGENT_CRR) {
         DoutSpec dq{};                          // -lambda/Bg routed to the smaller Q (td3_bc.py:152-155)
         dq.mode = EXORL_DOUT_ACTOR_Q; dq.q = a->fc.out; dq.stats = a->stats; dq.inv_bg = a->inv_bg; dq.alpha = cfg.alpha;
+        if (cfg.kind == EXORL_AGENT_APS) { dq.q = a->sfq; dq.task = a->obs + (O - cfg.sf_dim); dq.task_ld = O; }
         dq.use_lambda = cfg.kind == EXORL_AGENT_TD3_BC;
         const bool qf = qfuse(a);
         if (qf) EXORL_TRY(run_qhead(a, 1, s));   // Q(s, pi(s)), its min-routing gradient (lambda applied later), dz2, sum|Q| partials

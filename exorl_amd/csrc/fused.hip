@@ -680,13 +680,15 @@ __device__ __forceinline__ float dout_value(const DoutSpec& d, int net, int m, i
     }
     if (d.mode == EXORL_DOUT_TD) {
         const float y = d.reward[m] + d.discount[m] * fminf(d.tq[m], d.tq[rows + m]);
-        return 2.0f * (d.q[net * rows + m] - y) * d.inv_bg;
+        const float g = 2.0f * (d.q[net * rows + m] - y) * d.inv_bg;
+        return d.task ? g * d.task[(int64_t)m * d.task_ld + j] : g;
     }
     if (d.mode == EXORL_DOUT_ACTOR_Q) {
         const float lambda = d.use_lambda ? d.alpha / (d.stats[0] * d.inv_bg) : 1.0f;
         const float q1 = d.q[m], q2 = d.q[rows + m];
         const float w1 = q1 < q2 ? 1.0f : (q1 == q2 ? 0.5f : 0.0f);      // torch.min backward: ties split evenly
-        return -lambda * d.inv_bg * (net == 0 ? w1 : 1.0f - w1);
+        const float g = -lambda * d.inv_bg * (net == 0 ? w1 : 1.0f - w1);
+        return d.task ? g * d.task[(int64_t)m * d.task_ld + j] : g;
     }
     // EXORL_DOUT_ACTOR_MU: gradient at the actor's pre-tanh output
     const int i = m * nout + j;

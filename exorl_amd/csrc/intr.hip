@@ -6,6 +6,7 @@
 //   ICM-APT  agents/unsupervised_learning/icm_apt.py:13-57, :86-110; utils.PBE / utils.RMS utils/utils.py:257-319
 //   Disagreement agents/unsupervised_learning/disagreement.py:11-47, :64-90
 //   DIAYN    agents/unsupervised_learning/diayn.py:15-29, :78-127
+//   APS      agents/unsupervised_learning/aps.py:63-79, :147-175 (successor-feature net; PBE + task . phi reward)
 //   Proto    agents/unsupervised_learning/proto.py:14-157 (sinkhorn_knopp, prototypes, candidate queue, kNN reward)
 // The modules are plain Linear/ReLU stacks of arbitrary widths (obs_dim, hidden_dim, rep_dim), so the layers run on
 // the generic fp32-source grouped GEMM (gemm.hip) with small row/column kernels around it; what the reference's
@@ -439,6 +440,43 @@ __global__ __launch_bounds__(1024) void kth_reward_kernel(const float* __restric
     if (threadIdx.x == 0) { metrics[EXORL_IM_EXTR_REWARD] = e / (float)B; metrics[EXORL_IM_INTR_REWARD] = rs / (float)B; }
 }
 
+// ---- APS (aps.py:147-175) ---------------------------------------------------------------------------
+// loss_b = -task . fn with fn = F.normalize(f); df = (dfn - fn (fn . dfn)) / max(||f||, 1e-12), dfn = -task / B. One wave per row.
+__global__ __launch_bounds__(256) void aps_loss_kernel(const float* __restrict__ f, const float* __restrict__ task, int64_t ldt,
+                                                       float* __restrict__ df, float* __restrict__ loss_row, int rows, int D) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s = 0.f, tf = 0.f;
+    for (int j = lane; j < D; j += 64) { const float v = f[(int64_t)row * D + j]; s += v * v; tf += v * task[(int64_t)row * ldt + j]; }
+    const float n = fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+    const float tfn = wave_sum(tf) / n;                 // task . fn
+    const float invB = 1.0f / (float)rows;
+    for (int j = lane; j < D; j += 64) {
+        const float fn = f[(int64_t)row * D + j] / n, dfn = -task[(int64_t)row * ldt + j] * invB;
+        df[(int64_t)row * D + j] = (dfn - fn * (-tfn * invB)) / n;
+    }
+    if (lane == 0) loss_row[row] = -tfn;
+}
+// reward += task . rep / ||rep|| (aps.py:164-168), metrics split into the two parts; single block
+__global__ __launch_bounds__(1024) void aps_sf_reward_kernel(const float* __restrict__ rep, const float* __restrict__ task, int64_t ldt,
+                                                             float* reward, int B, int D, float* __restrict__ metrics) {
+    __shared__ float red[17];
+    float ss = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        float n2 = 0.f, tr = 0.f;
+        for (int j = 0; j < D; ++j) { const float v = rep[(int64_t)b * D + j]; n2 += v * v; tr += v * task[(int64_t)b * ldt + j]; }
+        const float sf = tr / sqrtf(n2);
+        reward[b] += sf;
+        ss += sf;
+    }
+    ss = block_sum(ss, red);
+    if (threadIdx.x == 0) {
+        metrics[EXORL_IM_ENT_REWARD] = metrics[EXORL_IM_INTR_REWARD];
+        metrics[EXORL_IM_SF_REWARD] = ss / (float)B;
+        metrics[EXORL_IM_INTR_REWARD] += ss / (float)B;
+    }
+}
+
 static int grid_for(int64_t n) { const int64_t b = (n + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
 
 static int mlp_forward(const Mlp& m, const float* P, const float* x, int64_t ldx, int rows, int prec, hipStream_t s) {
@@ -533,7 +571,7 @@ static void describe_intr(exorl_intr* it) {
         it->n_nets = n_models_of(c);
         for (int n = 0; n < it->n_nets; ++n) it->net[n].L = {lin(O + A, H), lin(H, O)};
         it->trainable = round_up(off, 64);
-    } else if (c.kind == EXORL_INTR_DIAYN) {
+    } else if (c.kind == EXORL_INTR_DIAYN || c.kind == EXORL_INTR_APS) {
         it->n_nets = 1;
         it->net[0].L = {lin(O, H), lin(H, H), lin(H, R)};             // R = skill_dim
         it->trainable = round_up(off, 64);
@@ -578,6 +616,8 @@ static void carve_intr(exorl_intr* it, ICarver& c) {
     if (g.kind == EXORL_INTR_RND) {
         it->xn = c.take(B * O);
         it->bn = c.take(2 * O + 1);
+    } else if (g.kind == EXORL_INTR_APS) {
+        it->topk = c.take(B * g.knn_k);
     } else if (g.kind == EXORL_INTR_PROTO) {
         const int64_t P = g.num_protos;
         it->z1 = c.take(B * R); it->dz1 = c.take(B * R); it->sn = c.take(B * R); it->nrm = c.take(B); it->tn = c.take(B * R);
@@ -792,6 +832,29 @@ static int diayn_update(exorl_intr* it, const exorl_intr_batch& b, bool train, h
     return launch_mean(b.reward_out, B, 1.0f / (float)B, it->metrics + EXORL_IM_INTR_REWARD, 0, s);
 }
 
+// ---- APS -------------------------------------------------------------------------------------------
+static int aps_update(exorl_intr* it, const exorl_intr_batch& b, bool train, hipStream_t s) {
+    const auto& c = it->cfg;
+    const int B = c.batch, D = c.rep_dim, prec = c.precision;
+    const float* P = it->flat[EXORL_T_PARAM];
+    if (train) {                                                                                     // aps.py:147-159,170-175
+        EXORL_TRY(mlp_forward(it->net[0], P, b.next_obs, b.next_obs_ld, B, prec, s));
+        hipLaunchKernelGGL(aps_loss_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->net[0].act[2], b.skill, b.skill_ld, it->net[0].dact[2], it->fe, B, D);
+        EXORL_LAUNCH_CHECK();
+        EXORL_TRY(launch_mean(it->fe, B, 1.0f / (float)B, it->metrics + EXORL_IM_LOSS, 0, s));
+        EXORL_TRY(mlp_backward(it->net[0], P, it->flat[EXORL_T_GRAD], b.next_obs, b.next_obs_ld, B, nullptr, prec, s));
+        EXORL_TRY(intr_adam(it, s));
+    }
+    EXORL_TRY(mlp_forward(it->net[0], P, b.next_obs, b.next_obs_ld, B, prec, s));                    // aps.py:161-168
+    const float* rep = it->net[0].act[2];
+    EXORL_TRY(exorl_knn_topk(rep, B, rep, B, D, c.knn_k, it->topk, s));
+    hipLaunchKernelGGL(pbe_reward_kernel, dim3(1), dim3(1024), 0, s, it->topk, b.extr_reward, b.reward_out, B, c.knn_k, c.knn_avg, c.knn_rms,
+                       c.knn_clip, it->rms, it->metrics);
+    hipLaunchKernelGGL(aps_sf_reward_kernel, dim3(1), dim3(1024), 0, s, rep, b.skill, b.skill_ld, b.reward_out, B, D, it->metrics);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- Proto ------------------------------------------------------------------------------------------
 static int launch_l2norm(const float* x, float* y, float* nrm, int rows, int D, hipStream_t s) {
     hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, y, nrm, rows, D);
@@ -871,7 +934,9 @@ extern "C" {
 
 static int check_intr_cfg(const exorl_intr_cfg* cfg) {
     EXORL_REQUIRE(cfg, "intr: null cfg");
-    EXORL_REQUIRE(cfg->kind >= EXORL_INTR_RND && cfg->kind <= EXORL_INTR_PROTO, "intr: unknown kind %d", cfg->kind);
+    EXORL_REQUIRE(cfg->kind >= EXORL_INTR_RND && cfg->kind <= EXORL_INTR_APS, "intr: unknown kind %d", cfg->kind);
+    EXORL_REQUIRE(cfg->kind != EXORL_INTR_APS || (cfg->knn_k >= 1 && cfg->knn_k <= 64 && cfg->knn_k <= cfg->batch && cfg->batch <= 4096),
+                  "intr: APS needs 1 <= knn_k <= min(64, batch) and batch <= 4096 (got k=%d B=%d)", cfg->knn_k, cfg->batch);
     EXORL_REQUIRE(cfg->kind != EXORL_INTR_PROTO || (cfg->num_protos >= 1 && cfg->queue_size >= cfg->num_protos && cfg->queue_size % cfg->num_protos == 0 &&
                   cfg->queue_size <= 4096 && cfg->knn_k >= 1 && cfg->knn_k <= 64 && cfg->knn_k <= cfg->queue_size && cfg->tau > 0.f && cfg->batch <= 8192),
                   "intr: Proto needs num_protos >= 1, queue_size a multiple of num_protos and <= 4096, 1 <= topk <= 64, tau > 0 (got %d, %d, %d, %g)",
@@ -968,10 +1033,10 @@ int exorl_intr_update(exorl_intr_t* it, const exorl_intr_batch* b, int32_t train
     EXORL_REQUIRE(it && b && b->obs && b->reward_out, "intr_update: null argument");
     const int k = it->cfg.kind;
     EXORL_REQUIRE(k == EXORL_INTR_RND || b->next_obs, "intr_update: this module needs next_obs");
-    EXORL_REQUIRE(k == EXORL_INTR_RND || k == EXORL_INTR_DIAYN || k == EXORL_INTR_PROTO || b->action, "intr_update: this module needs action");
-    EXORL_REQUIRE(k != EXORL_INTR_DIAYN || b->skill, "intr_update: DIAYN needs the skill matrix");
+    EXORL_REQUIRE(k == EXORL_INTR_RND || k == EXORL_INTR_DIAYN || k == EXORL_INTR_PROTO || k == EXORL_INTR_APS || b->action, "intr_update: this module needs action");
+    EXORL_REQUIRE((k != EXORL_INTR_DIAYN && k != EXORL_INTR_APS) || b->skill, "intr_update: DIAYN / APS need the skill / task matrix");
     EXORL_REQUIRE(b->obs_ld >= it->cfg.obs_dim && (!b->next_obs || b->next_obs_ld >= it->cfg.obs_dim) && (!b->action || b->action_ld >= it->cfg.act_dim) &&
-                  (!b->skill || k != EXORL_INTR_DIAYN || b->skill_ld >= it->cfg.rep_dim), "intr_update: a leading dimension is smaller than its row width");
+                  (!b->skill || (k != EXORL_INTR_DIAYN && k != EXORL_INTR_APS) || b->skill_ld >= it->cfg.rep_dim), "intr_update: a leading dimension is smaller than its row width");
     hipStream_t s = as_stream(stream);
     switch (k) {
         case EXORL_INTR_RND: return rnd_update(it, *b, train != 0, s);
@@ -979,6 +1044,7 @@ int exorl_intr_update(exorl_intr_t* it, const exorl_intr_batch* b, int32_t train
         case EXORL_INTR_ICM_APT: return apt_update(it, *b, train != 0, s);
         case EXORL_INTR_DISAGREEMENT: return disagreement_update(it, *b, train != 0, s);
         case EXORL_INTR_PROTO: return proto_update(it, *b, train != 0, s);
+        case EXORL_INTR_APS: return aps_update(it, *b, train != 0, s);
         default: return diayn_update(it, *b, train != 0, s);
     }
 }

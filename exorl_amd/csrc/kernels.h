@@ -99,6 +99,8 @@ struct DoutSpec {
     const float *raw, *z;    // CQL_ACTOR: actor head outputs (rows, 2A) [mu_raw | log_std_raw]; rsample noise (rows, A) or null
     const float* alpha_ptr;  // CQL_ACTOR: exp(log_actor_alpha) after its optimiser step (device scalar)
     uint64_t seed, counter; const uint64_t* counter_ptr;   // Philox identity of z when z == nullptr
+    const float* task;       // TD / ACTOR_Q with a successor-feature critic (aps.py:50-58): dQ/d(feature j) = task[m][j]
+    int64_t task_ld;
     const float* lam_parts;  // ACTOR_MU after qhead(ACTOR): per-chunk [sum |min Q|, sum min Q]; lambda = alpha / mean|Q| is applied here
     int lam_chunks;          //   (the critic backward is linear in its output gradient, so it ran with lambda = 1)
     int da_nets;
@@ -284,6 +286,8 @@ int crr_weights(const float* q_rep, const float* q_data, float* w, int B, int n,
 int critic_loss(const float* q, const float* tq, const float* reward, const float* discount, float* dq,
                 float* metrics, int B, float inv_bg, hipStream_t s);
 int actor_stats(const float* q, float* stats, int B, hipStream_t s);
+// successor-feature critic: q[net][m] = sum_j task[m][j] * feat[net][m][j]   (aps.py:55-58)
+int sf_q(const float* feat, const float* task, int64_t task_ld, float* q, int B, int sf, int nets, hipStream_t s);
 int actor_dq(const float* q, const float* stats, float* dq, int B, float inv_bg, float alpha, int use_lambda,
              hipStream_t s);
 int actor_dmu(const float* da, int64_t da_ld, int da_nets, int64_t da_net_stride, const float* mu, const float* a_data, const float* reward, const float* w, float* dpre, float* stats,

@@ -235,6 +235,22 @@ __global__ __launch_bounds__(1024) void actor_stats_kernel(const float* __restri
     }
 }
 
+__global__ __launch_bounds__(256) void sf_q_kernel(const float* __restrict__ feat, const float* __restrict__ task, int64_t task_ld,
+                                                   float* __restrict__ q, int B, int sf, int nets) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nets * B; i += gridDim.x * blockDim.x) {
+        const int m = i % B;
+        float acc = 0.f;
+        for (int j = 0; j < sf; ++j) acc += task[(int64_t)m * task_ld + j] * feat[(int64_t)i * sf + j];
+        q[i] = acc;
+    }
+}
+
+int sf_q(const float* feat, const float* task, int64_t task_ld, float* q, int B, int sf, int nets, hipStream_t s) {
+    hipLaunchKernelGGL(sf_q_kernel, dim3(cdiv(nets * B, 256)), dim3(256), 0, s, feat, task, task_ld, q, B, sf, nets);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
 int actor_stats(const float* q, float* stats, int B, hipStream_t s) {
     // metrics block directly follows the 4-float stats block (agent.hip lays them out that way)
     hipLaunchKernelGGL(actor_stats_kernel, dim3(1), dim3(1024), 0, s, q, stats, stats + 4, B);

@@ -11,7 +11,8 @@ import torch
 
 from . import _lib as L
 
-KIND = {'td3_bc': L.AGENT_TD3_BC, 'td3': L.AGENT_TD3, 'bc': L.AGENT_BC, 'ddpg': L.AGENT_DDPG, 'crr': L.AGENT_CRR, 'cql': L.AGENT_CQL}
+KIND = {'td3_bc': L.AGENT_TD3_BC, 'td3': L.AGENT_TD3, 'bc': L.AGENT_BC, 'ddpg': L.AGENT_DDPG, 'crr': L.AGENT_CRR, 'cql': L.AGENT_CQL,
+        'aps': L.AGENT_APS}
 PRECISION = {'fp32': L.PREC_F32, 'f32': L.PREC_F32, 'bf16': L.PREC_BF16}
 METRIC_KEYS = {L.M_BATCH_REWARD: 'batch_reward', L.M_CRITIC_TARGET_Q: 'critic_target_q', L.M_CRITIC_Q1: 'critic_q1',
                L.M_CRITIC_Q2: 'critic_q2', L.M_CRITIC_LOSS: 'critic_loss', L.M_ACTOR_LOSS: 'actor_loss',
@@ -30,11 +31,11 @@ def _require_gpu(device):
 class AgentEngine:
     def __init__(self, kind, obs_dim, act_dim, hidden_dim, batch, lr=1e-4, tau=0.01, alpha=2.5, stddev_clip=0.3,
                  precision='fp32', world_size=1, seed=0, device='cuda', num_value_samples=10, weight_func='indicator',
-                 n_samples=3, use_critic_lagrange=False, target_cql_penalty=5.0):
+                 n_samples=3, use_critic_lagrange=False, target_cql_penalty=5.0, sf_dim=0):
         self.lib = L.load()
         self.device = _require_gpu(device)
         self.kind = kind
-        self.cfg = L.AgentCfg(KIND[kind], obs_dim, act_dim, hidden_dim, batch, PRECISION[precision], world_size, 0,
+        self.cfg = L.AgentCfg(KIND[kind], obs_dim, act_dim, hidden_dim, batch, PRECISION[precision], world_size, sf_dim,
                               lr, tau, alpha, stddev_clip if stddev_clip is not None else 0.0, seed, num_value_samples,
                               L.CRR_WEIGHT[weight_func], n_samples, int(bool(use_critic_lagrange)), target_cql_penalty, 0)
         self.obs_dim, self.act_dim, self.hidden_dim, self.batch = obs_dim, act_dim, hidden_dim, batch
@@ -175,7 +176,7 @@ class IntrEngine:
     """Intrinsic-reward module (exorl_intr_t): RND / ICM / ICM-APT. Parameters live in a torch-owned workspace so they
     can be exposed as tensors (state_dict, snapshots)."""
     KINDS = {'rnd': L.INTR_RND, 'icm': L.INTR_ICM, 'icm_apt': L.INTR_ICM_APT, 'disagreement': L.INTR_DISAGREEMENT, 'diayn': L.INTR_DIAYN,
-             'proto': L.INTR_PROTO}
+             'proto': L.INTR_PROTO, 'aps': L.INTR_APS}
 
     def __init__(self, kind, obs_dim, act_dim, hidden_dim, batch, rep_dim=0, lr=1e-4, scale=1.0, knn_k=12, knn_avg=True,
                  knn_rms=True, knn_clip=0.0, clip_val=5.0, n_models=0, num_protos=0, queue_size=0, tau=0.1, target_tau=0.05, precision='fp32',

@@ -105,7 +105,9 @@ typedef struct exorl_agent exorl_agent_t;
 #define EXORL_AGENT_BC     2
 #define EXORL_AGENT_DDPG   3   /* states; shared-trunk critic (ddpg.py:79-123) */
 #define EXORL_AGENT_CRR    4   /* agents/offline_learning/crr.py:59-219 */
-#define EXORL_AGENT_CQL    5   /* agents/offline_learning/cql.py:59-286 (use_critic_lagrange=False) */
+#define EXORL_AGENT_CQL    5   /* agents/offline_learning/cql.py:59-286 */
+#define EXORL_AGENT_APS    6   /* agents/unsupervised_learning/aps.py:12-60,268-320: DDPG with the successor-feature critic
+                                  (heads emit sf_dim features, Q = task . features; the task is the last sf_dim columns of obs) */
 
 #define EXORL_CRR_IDENTITY  0   /* crr.py:132-142 adv_transform */
 #define EXORL_CRR_INDICATOR 1
@@ -147,7 +149,7 @@ typedef struct {
     int32_t batch;            /* rows per update on THIS rank */
     int32_t precision;        /* EXORL_PREC_* */
     int32_t world_size;       /* data-parallel ranks; losses are means over batch*world_size */
-    int32_t reserved;
+    int32_t sf_dim;           /* APS: successor-feature width (aps.yaml: 10); obs_dim includes it */
     float   lr, tau, alpha, stddev_clip;
     uint64_t seed;            /* Philox stream for action noise when no noise buffer is given */
     int32_t num_value_samples; /* CRR: actions sampled per state for V(s) (crr.yaml: 10) */
@@ -261,12 +263,13 @@ int exorl_knn_topk(const float* src_dev, int32_t n_src, const float* tgt_dev, in
 #define EXORL_INTR_DISAGREEMENT 3   /* agents/unsupervised_learning/disagreement.py:11-90 */
 #define EXORL_INTR_DIAYN   4        /* agents/unsupervised_learning/diayn.py:15-127 */
 #define EXORL_INTR_PROTO   5        /* agents/unsupervised_learning/proto.py:14-207 (state observations) */
+#define EXORL_INTR_APS     6        /* agents/unsupervised_learning/aps.py:63-79,147-175 (the task rides in `skill`) */
 #define EXORL_MAX_ENSEMBLE 8
 
 typedef struct exorl_intr_cfg {
     int32_t kind;         /* EXORL_INTR_* */
     int32_t obs_dim, act_dim, hidden_dim;
-    int32_t rep_dim;      /* rnd_rep_dim / icm_rep_dim / DIAYN skill_dim (unused by plain ICM and Disagreement) */
+    int32_t rep_dim;      /* rnd_rep_dim / icm_rep_dim / DIAYN skill_dim / APS sf_dim (unused by plain ICM and Disagreement) */
     int32_t batch;
     int32_t precision;    /* EXORL_PREC_* (MFMA operand type of the module's GEMMs) */
     int32_t knn_k, knn_avg, knn_rms;   /* ICM-APT: utils.PBE arguments (configs/agent/icm_apt.yaml) */
@@ -291,6 +294,8 @@ typedef struct exorl_intr exorl_intr_t;
 #define EXORL_IM_RMS_MEAN    3   /* running mean of the RMS (RND: pred_error_mean) */
 #define EXORL_IM_RMS_STD     4   /* sqrt of its running variance (RND: pred_error_std) */
 #define EXORL_IM_ACC         5   /* DIAYN: discriminator accuracy (diayn_acc) */
+#define EXORL_IM_ENT_REWARD  6   /* APS: mean particle-entropy part of the reward (intr_ent_reward) */
+#define EXORL_IM_SF_REWARD   7   /* APS: mean successor-feature part (intr_sf_reward) */
 #define EXORL_N_INTR_METRICS 8
 
 /* workspace: device memory of exorl_intr_workspace_bytes(cfg) bytes, 256-byte aligned, owned by the caller (so that the
@@ -300,7 +305,7 @@ int exorl_intr_create(const exorl_intr_cfg* cfg, void* workspace, size_t workspa
 int exorl_intr_destroy(exorl_intr_t* m);
 /* Parameter tensors in the module's parameters() order (RND: predictor.{1,3,5}, target.{1,3,5}; ICM: forward_net.{0,2},
  * backward_net.{0,2}; ICM-APT: trunk.0, trunk.1 (LayerNorm), forward_net, backward_net; Disagreement: ensemble.{m}.{0,2};
- * DIAYN: skill_pred_net.{0,2,4}; Proto: predictor, projector.trunk.{0,2}, protos (no bias), then the frozen predictor_target),
+ * DIAYN: skill_pred_net.{0,2,4}; APS: state_feat_net.{0,2,4}; Proto: predictor, projector.trunk.{0,2}, protos (no bias), then the frozen predictor_target),
  * each weight then bias.
  * what = EXORL_T_*; RND's frozen target tensors have parameters only. */
 int exorl_intr_num_tensors(exorl_intr_t* m, int32_t* n);

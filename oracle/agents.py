@@ -21,18 +21,19 @@ CRITIC_KEYS_DDPG = (['trunk.0.weight', 'trunk.0.bias', 'trunk.1.weight', 'trunk.
                     [f'{q}.{i}.{w}' for q in ('Q1', 'Q2') for i in (0, 2) for w in ('weight', 'bias')])
 
 
-def param_shapes(kind, O, A, H):
-    """(actor [(key, shape)], critic [(key, shape)] or None) in the reference's parameter order."""
+def param_shapes(kind, O, A, H, sf_dim=None):
+    """(actor [(key, shape)], critic [(key, shape)] or None) in the reference's parameter order.
+    sf_dim: APS's CriticSF (aps.py:12-60) — the DDPG critic with sf_dim-wide heads; O then includes the task."""
     tr = lambda i: [(H, i), (H,), (H,), (H,)]
     hd = lambda o: [(H, H), (H,), (o, H), (o,)]
-    ddpg = kind == 'ddpg'
+    ddpg = kind in ('ddpg', 'aps')
     actor = list(zip(ACTOR_KEYS_DDPG if ddpg else ACTOR_KEYS_OFFLINE, tr(O) + hd(A)))
     if kind == 'bc':
         return actor, None
     if kind == 'cql':
         actor = list(zip(ACTOR_KEYS_OFFLINE, tr(O) + hd(2 * A)))
     if ddpg:
-        critic = list(zip(CRITIC_KEYS_DDPG, tr(O + A) + hd(1) + hd(1)))
+        critic = list(zip(CRITIC_KEYS_DDPG, tr(O + A) + hd(sf_dim or 1) + hd(sf_dim or 1)))
     else:
         critic = list(zip(CRITIC_KEYS_OFFLINE, tr(O + A) + hd(1) + tr(O + A) + hd(1)))
     return actor, critic
@@ -44,12 +45,31 @@ def _min_grad(q1, q2):
     return w1, (F32(1) - w1)
 
 
+def make_sf_critic(sf_dim):
+    """CriticSF (aps.py:12-60) as a drop-in for SharedTrunkCritic: heads emit sf_dim successor features, Q = task . features with
+    the task in the last sf_dim columns of obs (the agent feeds cat(obs, task), aps.py:236-238)."""
+    class SFCritic:
+        @staticmethod
+        def fwd(p, obs, action):
+            o1, o2, c = SharedTrunkCritic.fwd(p, obs, action)
+            task = obs[:, -sf_dim:]
+            q1 = (task * o1).sum(1, keepdims=True, dtype=F32)
+            q2 = (task * o2).sum(1, keepdims=True, dtype=F32)
+            return q1, q2, (c, task)
+
+        @staticmethod
+        def bwd(p, caches, dq1, dq2, need_dx, need_dw=True):
+            c, task = caches
+            return SharedTrunkCritic.bwd(p, c, (dq1 * task).astype(F32), (dq2 * task).astype(F32), need_dx, need_dw)
+    return SFCritic
+
+
 class OracleAgent:
-    """kind in {'td3_bc','td3','bc','ddpg','crr'}; params are lists of float32 arrays (reference order)."""
+    """kind in {'td3_bc','td3','bc','ddpg','crr','aps'}; params are lists of float32 arrays (reference order)."""
 
     def __init__(self, kind, actor_params, critic_params=None, lr=1e-4, tau=0.01, stddev_schedule='0.2',
                  stddev_clip=0.3, alpha=2.5, update_every_steps=2, world_size=1, allreduce=None,
-                 num_value_samples=10, weight_func='indicator'):
+                 num_value_samples=10, weight_func='indicator', sf_dim=None):
         """world_size > 1: this instance is one data-parallel rank holding a shard of the global batch; `allreduce`
         (list of float32 arrays -> summed in place across ranks) is called at the three points where the reference's
         single-process update needs a batch-global quantity: critic grads, sum|Q| (td3_bc.py:154),
@@ -60,6 +80,8 @@ class OracleAgent:
         self.actor = [np.array(p, F32) for p in actor_params]
         self.actor_opt = Adam(self.actor, lr)
         self.C = SharedTrunkCritic if kind == 'ddpg' else TwinCritic
+        if kind == 'aps':                       # aps.py:268-320: DDPG's update_critic / update_actor with the task-conditioned critic
+            self.C = make_sf_critic(sf_dim)
         if kind != 'bc':
             self.critic = [np.array(p, F32) for p in critic_params]
             self.critic_target = [p.copy() for p in self.critic]      # td3_bc.py:93
@@ -114,7 +136,7 @@ class OracleAgent:
         self.actor_opt.step(self.actor, grads)
         m['actor_loss'] = float(loss)
         m['actor_ent'] = float(nets.normal_entropy(std) * A)
-        if self.kind == 'ddpg':
+        if self.kind in ('ddpg', 'aps'):
             lp = np.array([nets.normal_log_prob(a, mu, std).sum(dtype=F32) / F32(B)], F32)
             if self.world_size > 1:
                 self.allreduce([lp])
@@ -164,7 +186,7 @@ class OracleAgent:
 
     # td3_bc.py:168-189 / bc.py:97-110 / ddpg.py:298-328
     def update(self, batch, step, noise_critic=None, noise_actor=None):
-        if self.kind == 'ddpg' and step % self.update_every_steps != 0:
+        if self.kind in ('ddpg', 'aps') and step % self.update_every_steps != 0:
             return {}
         obs, action, reward, discount, next_obs = [np.asarray(x, F32) for x in batch[:5]]
         std = nets.schedule(self.sched, step)

@@ -64,6 +64,7 @@ APT_KEYS = ['trunk.0.weight', 'trunk.0.bias', 'trunk.1.weight', 'trunk.1.bias'] 
 
 DIS_KEYS = [f'ensemble.{m}.{i}.{w}' for m in range(5) for i in (0, 2) for w in ('weight', 'bias')]
 DIAYN_KEYS = [f'skill_pred_net.{i}.{w}' for i in (0, 2, 4) for w in ('weight', 'bias')]
+APS_KEYS = [f'state_feat_net.{i}.{w}' for i in (0, 2, 4) for w in ('weight', 'bias')]
 
 
 def intr_param_shapes(kind, O, A, H, R):
@@ -72,6 +73,8 @@ def intr_param_shapes(kind, O, A, H, R):
         return list(zip(DIS_KEYS, [(H, O + A), (H,), (O, H), (O,)] * 5))
     if kind == 'diayn':
         return list(zip(DIAYN_KEYS, [(H, O), (H,), (H, H), (H,), (R, H), (R,)]))
+    if kind == 'aps':           # R = sf_dim
+        return list(zip(APS_KEYS, [(H, O), (H,), (H, H), (H,), (R, H), (R,)]))
     if kind == 'rnd':
         one = [(H, O), (H,), (H, H), (H,), (R, H), (R,)]
         return list(zip(RND_KEYS, one + one))
@@ -250,6 +253,36 @@ class OracleDIAYN:
         return (r * F32(self.scale)).astype(F32)
 
 
+class OracleAPS:
+    """aps.py:63-79,147-175: successor-feature net; loss = -mean(task . normalize(phi(s'))); reward = PBE(phi(s')) + task . phi/||phi||."""
+
+    def __init__(self, params, lr=1e-4, knn_rms=True, knn_k=12, knn_avg=True, knn_clip=0.0001):
+        self.p = [np.array(x, F32) for x in params]
+        self.opt = Adam(self.p, lr)
+        self.pbe = PBE(RMS(), knn_clip, knn_k, knn_avg, knn_rms)
+
+    def update(self, task, next_obs):
+        B = next_obs.shape[0]
+        f, acts = mlp_fwd(self.p, next_obs)
+        n = np.maximum(np.sqrt((f * f).sum(1, keepdims=True, dtype=F32)), F32(1e-12)).astype(F32)      # F.normalize
+        fn = (f / n).astype(F32)
+        loss = -(task * fn).sum(1, dtype=F32).mean(dtype=F32)
+        dfn = (-task / F32(B)).astype(F32)
+        df = ((dfn - fn * (fn * dfn).sum(1, keepdims=True, dtype=F32)) / n).astype(F32)
+        grads, _ = mlp_bwd(self.p, acts, df)
+        self.last_grads = grads
+        self.opt.step(self.p, grads)
+        return float(loss)
+
+    def reward(self, task, next_obs):
+        rep, _ = mlp_fwd(self.p, next_obs)
+        ent = self.pbe(rep).reshape(-1, 1)
+        repn = (rep / np.sqrt((rep * rep).sum(1, keepdims=True, dtype=F32))).astype(F32)      # torch.norm, no eps (aps.py:166)
+        sf = (task * repn).sum(1, keepdims=True, dtype=F32)
+        self.last_ent, self.last_sf = ent, sf
+        return (ent + sf).astype(F32)
+
+
 class OracleUnsupAgent:
     """{RND,ICM,ICMAPT}Agent.update with reward_free=True: module step, intrinsic reward, then the DDPG update on it."""
 
@@ -261,16 +294,19 @@ class OracleUnsupAgent:
             return {}
         obs, action, extr, discount, next_obs = [np.asarray(x, F32) for x in batch[:5]]
         args = (obs,) if self.kind == 'rnd' else (obs, action, next_obs)
-        if self.kind == 'diayn':
+        if self.kind in ('diayn', 'aps'):
             skill = np.asarray(batch[5], F32)
             args = (skill, next_obs)
         loss = self.module.update(*args)
         intr = self.module.reward(*args)
         self.last_intr = intr
-        if self.kind == 'diayn':          # the actor/critic see [obs | skill] (diayn.py:162-164)
+        if self.kind in ('diayn', 'aps'):  # the actor/critic see [obs | skill] (diayn.py:162-164) / [obs | task] (aps.py:236-238)
             obs, next_obs = np.concatenate([obs, skill], 1), np.concatenate([next_obs, skill], 1)
         m = self.ddpg.update((obs, action, intr, discount, next_obs), step, noise_critic, noise_actor)
-        m[{'rnd': 'rnd_loss', 'disagreement': 'disagreement_loss', 'diayn': 'diayn_loss'}.get(self.kind, 'icm_loss')] = loss
+        m[{'rnd': 'rnd_loss', 'disagreement': 'disagreement_loss', 'diayn': 'diayn_loss', 'aps': 'aps_loss'}.get(self.kind, 'icm_loss')] = loss
+        if self.kind == 'aps':
+            m['intr_ent_reward'] = float(self.module.last_ent.mean(dtype=F32))
+            m['intr_sf_reward'] = float(self.module.last_sf.mean(dtype=F32))
         if self.kind == 'diayn':
             m['diayn_acc'] = self.module.acc
         m['intr_reward'] = float(intr.mean(dtype=F32))

@@ -81,6 +81,26 @@ def test_intr_module_init_matches_reference_rng_order(gold, kind):
         np.testing.assert_array_equal(t.numpy(), z[f'init/{mod}/{k}'], err_msg=k)
 
 
+def test_aps_init_matches_reference_rng_order(gold):
+    """APSAgent.__init__ (aps.py:82-119): DDPG nets (scalar critics, then discarded), CriticSF x2, then the APS module."""
+    from exorl_amd import agents
+    z = np.load(gold / 'tiny_aps.npz')
+    O, A, H, S = 5, 3, 32, 4
+    torch.manual_seed(21)
+    actor0 = agents._mlp_init(O + S, H, A, 1, 1)
+    for _ in range(2):
+        agents._mlp_init(O + S + A, H, 1, 1, 2)
+    critic0 = agents._mlp_init(O + S + A, H, S, 1, 2)
+    agents._mlp_init(O + S + A, H, S, 1, 2)
+    w = agents._seq_init([('lin', O, H), ('lin', H, H), ('lin', H, S)])
+    for k, t in zip(agents._DDPG_ACTOR_KEYS, actor0):
+        np.testing.assert_array_equal(t.numpy(), z[f'init/actor/{k}'], err_msg=k)
+    for k, t in zip(agents._DDPG_CRITIC_KEYS, critic0):
+        np.testing.assert_array_equal(t.numpy(), z[f'init/critic/{k}'], err_msg=k)
+    for k, t in zip(agents._APS_KEYS, w):
+        np.testing.assert_array_equal(t.numpy(), z[f'init/aps/{k}'], err_msg=k)
+
+
 def test_proto_init_matches_reference_rng_order(gold):
     """proto.py:55-67 draws: predictor, projector (weight_init applied twice), protos — after the DDPG nets."""
     from exorl_amd import agents

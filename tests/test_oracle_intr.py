@@ -4,18 +4,19 @@ import numpy as np
 import pytest
 
 from oracle.agents import OracleAgent, param_shapes
-from oracle.intr import OracleDIAYN, OracleDisagreement, OracleICM, OracleICMAPT, OracleRND, OracleUnsupAgent, intr_param_shapes
+from oracle.intr import OracleAPS, OracleDIAYN, OracleDisagreement, OracleICM, OracleICMAPT, OracleRND, OracleUnsupAgent, intr_param_shapes
 
 O, A, H, R = 5, 3, 32, 16
-KINDS = ['rnd', 'icm', 'icm_apt', 'icm_apt-kth', 'disagreement', 'diayn']
-MODULE = {'rnd': 'rnd', 'disagreement': 'disagreement', 'diayn': 'diayn'}
+KINDS = ['rnd', 'icm', 'icm_apt', 'icm_apt-kth', 'disagreement', 'diayn', 'aps']
+MODULE = {'rnd': 'rnd', 'disagreement': 'disagreement', 'diayn': 'diayn', 'aps': 'aps'}
 
 
 def build_oracle(z, kind):
     base = kind.partition('-')[0]
-    S = 4 if base == 'diayn' else 0
-    ash, csh = param_shapes('ddpg', O + S, A, H)
-    ddpg = OracleAgent('ddpg', [z[f'init/actor/{k}'] for k, _ in ash], [z[f'init/critic/{k}'] for k, _ in csh])
+    S = 4 if base in ('diayn', 'aps') else 0
+    ash, csh = param_shapes('aps' if base == 'aps' else 'ddpg', O + S, A, H, sf_dim=4 if base == 'aps' else None)
+    ddpg = OracleAgent('aps' if base == 'aps' else 'ddpg', [z[f'init/actor/{k}'] for k, _ in ash], [z[f'init/critic/{k}'] for k, _ in csh],
+                       sf_dim=4 if base == 'aps' else None)
     mod_name = MODULE.get(base, 'icm')
     ish = intr_param_shapes(base, O, A, H, S or R)
     params = [z[f'init/{mod_name}/{k}'] for k, _ in ish]
@@ -29,6 +30,8 @@ def build_oracle(z, kind):
         mod = OracleDisagreement(params)
     elif base == 'diayn':
         mod = OracleDIAYN(params)
+    elif base == 'aps':
+        mod = OracleAPS(params, knn_k=3)
     else:
         mod = OracleICMAPT(params, knn_k=3, **(dict(knn_avg=False, knn_clip=0.0005) if kind.endswith('kth') else {}))
     return OracleUnsupAgent(base, ddpg, mod), ash, csh, ish, mod_name
@@ -40,7 +43,7 @@ def test_tiny_unsup_trajectory(gold, kind):
     ag, ash, csh, ish, mod_name = build_oracle(z, kind)
     keys = [str(k) for k in z['metric_keys']]
     for i in range(5):
-        batch = [z[f'batch/{i}/{j}'] for j in range(6 if kind == 'diayn' else 5)]
+        batch = [z[f'batch/{i}/{j}'] for j in range(6 if kind in ('diayn', 'aps') else 5)]
         assert ag.update(batch, 2 * i + 1, None, None) == {}
         m = ag.update(batch, 2 * i, z[f'noise/{2 * i}'], z[f'noise/{2 * i + 1}'])
         np.testing.assert_allclose(ag.last_intr, z['intr_reward'][i], rtol=2e-5, atol=2e-6, err_msg=f'{kind} intr step {i}')

@@ -201,6 +201,9 @@ def make_agent(ref, kind, O, A, H, B, device='cpu', use_tb=True, **kw):
         return ref.proto.ProtoAgent(pred_dim=kw.get('pred_dim', 8), proj_dim=kw.get('proj_dim', 16), queue_size=kw.get('queue_size', 24),
                                     num_protos=kw.get('num_protos', 6), tau=0.1, encoder_target_tau=0.05, topk=3, update_encoder=True,
                                     **ddpg_kw)
+    if kind == 'aps':          # configs/agent/aps.yaml: sf_dim 10, knn_k 12, knn_avg true, knn_rms true, knn_clip 0.0001 (tiny: 4 / 3)
+        return ref.aps.APSAgent(update_task_every_step=5, sf_dim=kw.get('sf_dim', 4), knn_rms=True, knn_k=kw.get('knn_k', 3), knn_avg=True,
+                                knn_clip=0.0001, num_init_steps=4096, lstsq_batch_size=4096, update_encoder=True, **ddpg_kw)
     if kind == 'disagreement':
         return ref.disagreement.DisagreementAgent(update_encoder=True, **ddpg_kw)
     if kind == 'diayn':        # configs/agent/diayn.yaml: skill_dim 16, diayn_scale 1.0, update_skill_every_step 50 (tiny: 4 skills)
@@ -218,7 +221,7 @@ def nets_of(agent):
     # (CQL's log_actor_alpha / log_critic_alpha scalars are stored separately by gen_tiny)
     if hasattr(agent, 'critic'):
         nets += [('critic', agent.critic), ('critic_target', agent.critic_target)]
-    for nm in ('rnd', 'icm', 'disagreement', 'diayn', 'predictor', 'predictor_target', 'projector', 'protos'):            # intrinsic-reward modules of the DDPG-backbone agents
+    for nm in ('rnd', 'icm', 'disagreement', 'diayn', 'aps', 'smm', 'predictor', 'predictor_target', 'projector', 'protos'):            # intrinsic-reward modules of the DDPG-backbone agents
         if hasattr(agent, nm):
             nets.append((nm, getattr(agent, nm)))
     return nets
@@ -283,8 +286,8 @@ def checksums(agent):
 
 
 TINY_CQL_LAGRANGE = 'cql-lagrange'
-UNSUP = ('ddpg', 'rnd', 'icm', 'icm_apt', 'disagreement', 'diayn', 'proto')
-TINY_KINDS = ('td3_bc', 'td3', 'bc', 'ddpg', 'crr', 'crr-exp', 'crr-identity', 'cql', 'rnd', 'icm', 'icm_apt', 'icm_apt-kth', 'disagreement', 'diayn', 'proto', 'cql-lagrange')
+UNSUP = ('ddpg', 'rnd', 'icm', 'icm_apt', 'disagreement', 'diayn', 'proto', 'aps', 'smm')
+TINY_KINDS = ('td3_bc', 'td3', 'bc', 'ddpg', 'crr', 'crr-exp', 'crr-identity', 'cql', 'rnd', 'icm', 'icm_apt', 'icm_apt-kth', 'disagreement', 'diayn', 'proto', 'cql-lagrange', 'aps')
 
 
 def gen_tiny(ref):
@@ -305,7 +308,10 @@ def gen_tiny(ref):
 
             def rec_intr(*a, **k):
                 r = inner(*a, **k)
-                intr_log.append(r.detach().numpy().copy())
+                if isinstance(r, tuple):         # APS: (entropy reward, successor-feature reward) — the critic sees their sum
+                    intr_log.append(sum(x.detach() for x in r).numpy().copy())
+                else:
+                    intr_log.append(r.detach().numpy().copy())
                 return r
             agent.compute_intr_reward = rec_intr
         for nm, net in nets_of(agent):
@@ -326,6 +332,10 @@ def gen_tiny(ref):
         if base == 'diayn':          # 6th batch element: the one-hot skill the replay buffer stores as meta (diayn.py:123-125)
             rsk = np.random.RandomState(41)
             batches = [b + (np.eye(4, dtype=np.float32)[rsk.randint(0, 4, B)],) for b in batches]
+        if base == 'aps':            # 6th batch element: the task vector w, unit norm (aps.py:139-146)
+            rsk = np.random.RandomState(43)
+            ts = [rsk.standard_normal((B, 4)).astype(np.float32) for _ in batches]
+            batches = [b + ((t / np.linalg.norm(t, axis=1, keepdims=True)).astype(np.float32),) for b, t in zip(batches, ts)]
         metrics = run_agent(ref, agent, base, N, lambda i: batches[i], rec, np.float32)
         for i, b in enumerate(batches):
             for j, t in enumerate(b):
@@ -343,6 +353,8 @@ def gen_tiny(ref):
         if base == 'proto':
             out['final/queue'] = agent.queue.numpy().copy()
             out['final/queue_ptr'] = np.array(agent.queue_ptr)
+        if intr_log and isinstance(intr_log[0], tuple):       # APS returns (entropy reward, successor-feature reward)
+            pass
         rms = getattr(agent, 'intrinsic_reward_rms', None) or getattr(getattr(agent, 'pbe', None), 'rms', None)
         if rms is not None:
             out['final/rms'] = np.array([float(rms.M), float(rms.S), float(rms.n)], np.float64)
