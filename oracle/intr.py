@@ -315,3 +315,110 @@ class OracleUnsupAgent:
             m['pred_error_mean'] = float(self.module.rms.M[0])
             m['pred_error_std'] = float(np.sqrt(self.module.rms.S[0]))
         return m
+
+
+# ---------------------------------------------------------------------------------------------------
+# SMM (agents/unsupervised_learning/smm.py): VAE density model of [obs | z], skill discriminator, reward from their losses.
+# ---------------------------------------------------------------------------------------------------
+SMM_KEYS = ([f'z_pred_net.{i}.{w}' for i in (0, 2, 4) for w in ('weight', 'bias')] +
+            [f'vae.{n}.{w}' for n in ('enc.0', 'enc.2', 'enc_mu', 'enc_logvar', 'dec.0', 'dec.2', 'dec.4') for w in ('weight', 'bias')])
+
+
+def smm_param_shapes(O, Z, H, code_dim=128, vae_hidden=150):
+    W = O + Z
+    zp = [(H, O), (H,), (H, H), (H,), (Z, H), (Z,)]
+    vae = [(vae_hidden, W), (vae_hidden,), (vae_hidden, vae_hidden), (vae_hidden,), (code_dim, vae_hidden), (code_dim,),
+           (code_dim, vae_hidden), (code_dim,), (vae_hidden, code_dim), (vae_hidden,), (vae_hidden, vae_hidden), (vae_hidden,), (W, vae_hidden), (W,)]
+    return list(zip(SMM_KEYS, zp + vae))
+
+
+class OracleSMM:
+    """smm.py:27-70 (VAE), :89-112 (SMM), :173-200 (update_vae / update_pred), :217-246 (reward)."""
+
+    def __init__(self, params, sp_lr=1e-3, vae_lr=1e-2, vae_beta=0.5, state_ent_coef=1.0, latent_ent_coef=1.0, latent_cond_ent_coef=1.0,
+                 goal=(150.0, 75.0)):
+        self.p = [np.array(x, F32) for x in params]
+        self.zp, self.vae = self.p[:6], self.p[6:]
+        self.zp_opt, self.vae_opt = Adam(self.zp, sp_lr), Adam(self.vae, vae_lr)
+        self.beta, self.coefs, self.goal = vae_beta, (state_ent_coef, latent_ent_coef, latent_cond_ent_coef), goal
+
+    def update_vae(self, x, eps):
+        v = self.vae
+        B, W = x.shape
+        h2, acts = mlp_fwd(v[0:4] + [np.eye(v[2].shape[0], dtype=F32), np.zeros(v[2].shape[0], F32)], x)     # enc = Linear-ReLU-Linear-ReLU
+        h1 = acts[1]
+        h2 = acts[2]
+        mu, lv = linear_fwd(h2, v[4], v[5]), linear_fwd(h2, v[6], v[7])
+        std = np.exp(F32(0.5) * lv).astype(F32)
+        code = (eps * std + mu).astype(F32)
+        out, dacts = mlp_fwd(v[8:14], code)
+        diff = (x - out).astype(F32)
+        sq = (diff * diff).astype(F32)
+        kle = (F32(-0.5) * (F32(1) + lv - mu * mu - np.exp(lv)).sum(1, dtype=F32)).mean(dtype=F32)
+        loss = F32(self.beta) * kle + sq.mean(dtype=F32)
+        h_s_z = sq.sum(1, keepdims=True, dtype=F32)
+        dout = (F32(-2.0) * diff / F32(B * W)).astype(F32)
+        gdec, dcode = mlp_bwd(v[8:14], dacts, dout, need_dx=True)
+        dmu = (dcode + F32(self.beta) * mu / F32(B)).astype(F32)
+        dlv = (dcode * eps * F32(0.5) * std + F32(self.beta) * F32(-0.5) * (F32(1) - np.exp(lv)) / F32(B)).astype(F32)
+        gWmu, gbmu, dh_mu = linear_bwd(h2, v[4], dmu)
+        gWlv, gblv, dh_lv = linear_bwd(h2, v[6], dlv)
+        dh2 = ((dh_mu + dh_lv) * (h2 > 0)).astype(F32)
+        gW2, gb2, dh1 = linear_bwd(h1, v[2], dh2)
+        dh1 = (dh1 * (h1 > 0)).astype(F32)
+        gW1, gb1, _ = linear_bwd(x, v[0], dh1, need_dx=False)
+        self.last_vae_grads = [gW1, gb1, gW2, gb2, gWmu, gbmu, gWlv, gblv] + gdec
+        self.vae_opt.step(self.vae, self.last_vae_grads)
+        return float(loss), h_s_z
+
+    def update_pred(self, obs, z):
+        B = obs.shape[0]
+        logits, acts = mlp_fwd(self.zp, obs)
+        lab = z.argmax(1)
+        m = logits.max(1, keepdims=True)
+        lsm = (logits - (m + np.log(np.exp(logits - m).sum(1, keepdims=True, dtype=F32)))).astype(F32)
+        h_z_s = (-lsm[np.arange(B), lab]).reshape(-1, 1).astype(F32)
+        dd = np.exp(lsm).astype(F32)
+        dd[np.arange(B), lab] -= F32(1)
+        grads, _ = mlp_bwd(self.zp, acts, (dd / F32(B)).astype(F32))
+        self.last_pred_grads = grads
+        self.zp_opt.step(self.zp, grads)
+        return float(h_z_s.mean(dtype=F32)), h_z_s
+
+    def log_p_star(self, obs):
+        d = np.sqrt(((obs[:, 0] - F32(self.goal[0])) ** 2 + (obs[:, 1] - F32(self.goal[1])) ** 2).astype(F32)).astype(F32)
+        return np.log(np.where(d > 1.0, F32(1) / d, F32(1)).astype(F32)).astype(F32)
+
+
+class OracleSMMAgent:
+    """SMMAgent.update, reward_free=True, states (smm.py:217-281).
+
+    The reference adds the 1-D `log_p_star` (B,) to (B,1) terms, so its reward — and with it the TD target — is a (B,B) matrix:
+    mse_loss(Q (B,1), target (B,B)) then averages over all pairs. Per sample that is the TD loss against
+    reward_i = rest_i + mean_j log_p_star_j, plus the constant var_j(log_p_star_j) per critic in the loss VALUE. The oracle (and the
+    HIP path) implement exactly that, bug-compatible and tested against the reference's own trajectory."""
+
+    def __init__(self, ddpg, smm):
+        self.ddpg, self.module = ddpg, smm
+
+    def update(self, batch, step, eps, noise_critic, noise_actor):
+        if step % self.ddpg.update_every_steps != 0:
+            return {}
+        obs, action, extr, discount, next_obs, z = [np.asarray(x, F32) for x in batch[:6]]
+        sm = self.module
+        loss_vae, h_s_z = sm.update_vae(np.concatenate([obs, z], 1), eps)
+        loss_pred, h_z_s = sm.update_pred(obs, z)
+        sec, lec, lcec = sm.coefs
+        lps = sm.log_p_star(obs)
+        h_z = F32(np.log(z.shape[1]))
+        rest = (F32(sec) * h_s_z + F32(lec) * h_z + F32(lcec) * h_z_s).astype(F32)
+        lps_mean = lps.mean(dtype=F32)
+        reward = (rest + lps_mean).astype(F32)
+        self.last_intr = reward
+        m = self.ddpg.update((np.concatenate([obs, z], 1), action, reward, discount, np.concatenate([next_obs, z], 1)), step, noise_critic,
+                             noise_actor)
+        m['critic_loss'] = m['critic_loss'] + 2.0 * float(((lps - lps_mean) ** 2).mean(dtype=F32))
+        m.update(intr_reward=float(reward.mean(dtype=F32)), log_p_star=float(lps_mean), pred_log_ratios=float((F32(sec) * h_s_z).mean(dtype=F32)),
+                 latent_ent_coef=float(F32(lec) * h_z), latent_cond_ent_coef=float((F32(lcec) * h_z_s).mean(dtype=F32)), loss_vae=loss_vae,
+                 loss_pred=loss_pred, extr_reward=float(extr.mean(dtype=F32)))
+        return m

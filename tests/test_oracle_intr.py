@@ -94,3 +94,35 @@ def test_tiny_proto_trajectory(gold):
     # sinkhorn: every sample's assignment sums to 1, prototypes are used equally up to the last column normalisation
     q = sinkhorn_knopp(np.random.RandomState(0).standard_normal((32, 6)).astype(np.float32) * 3)
     np.testing.assert_allclose(q.sum(1), 1.0, rtol=1e-5)
+
+
+def test_tiny_smm_trajectory(gold):
+    """SMM incl. the reference's (B,B) reward broadcast (see OracleSMMAgent)."""
+    from oracle.intr import OracleSMM, OracleSMMAgent, smm_param_shapes
+    z = np.load(gold / 'tiny_smm.npz')
+    Z = 4
+    ash, csh = param_shapes('ddpg', O + Z, A, H)
+    ddpg = OracleAgent('ddpg', [z[f'init/actor/{k}'] for k, _ in ash], [z[f'init/critic/{k}'] for k, _ in csh])
+    ssh = smm_param_shapes(O, Z, H)
+    params = [z[f'init/smm/{k}'] for k, _ in ssh]
+    for (k, s), p in zip(ssh, params):
+        assert tuple(p.shape) == tuple(s), (k, p.shape, s)
+    ag = OracleSMMAgent(ddpg, OracleSMM(params))
+    keys = [str(k) for k in z['metric_keys']]
+    for i in range(5):
+        batch = [z[f'batch/{i}/{j}'] for j in range(6)]
+        assert ag.update(batch, 2 * i + 1, None, None, None) == {}
+        m = ag.update(batch, 2 * i, z[f'noise/{3 * i}'], z[f'noise/{3 * i + 1}'], z[f'noise/{3 * i + 2}'])
+        got = np.array([m[k] for k in keys])
+        np.testing.assert_allclose(got, z['metrics'][i], rtol=5e-5, atol=2e-6, err_msg=f'step {i} {keys}')
+    for (k, _), p in zip(ssh, ag.module.p):
+        # vae_lr = 1e-2: Adam's normalised step turns last-bit gradient differences into ~1e-5 parameter differences
+        want = z[f'final/smm/{k}']
+        bad = np.abs(p - want) > 2e-6 + 1e-4 * np.abs(want)
+        assert bad.mean() <= 1e-3, (k, bad.mean())
+        np.testing.assert_allclose(p, want, rtol=2e-3, atol=2e-4, err_msg=k)
+    for (k, _), p in zip(ash, ag.ddpg.actor):
+        np.testing.assert_allclose(p, z[f'final/actor/{k}'], rtol=1e-4, atol=2e-6, err_msg=k)
+    for (k, _), p, t in zip(csh, ag.ddpg.critic, ag.ddpg.critic_target):
+        np.testing.assert_allclose(p, z[f'final/critic/{k}'], rtol=1e-4, atol=2e-6, err_msg=k)
+        np.testing.assert_allclose(t, z[f'final/critic_target/{k}'], rtol=1e-4, atol=2e-6, err_msg=k)

@@ -201,6 +201,9 @@ def make_agent(ref, kind, O, A, H, B, device='cpu', use_tb=True, **kw):
         return ref.proto.ProtoAgent(pred_dim=kw.get('pred_dim', 8), proj_dim=kw.get('proj_dim', 16), queue_size=kw.get('queue_size', 24),
                                     num_protos=kw.get('num_protos', 6), tau=0.1, encoder_target_tau=0.05, topk=3, update_encoder=True,
                                     **ddpg_kw)
+    if kind == 'smm':          # configs/agent/smm.yaml: z_dim = skill_dim (4), sp_lr 1e-3, vae_lr 1e-2, vae_beta 0.5; coefficients pretrain.yaml
+        return ref.smm.SMMAgent(z_dim=4, sp_lr=1e-3, vae_lr=1e-2, vae_beta=0.5, state_ent_coef=1.0, latent_ent_coef=1.0,
+                                latent_cond_ent_coef=1.0, update_encoder=True, **ddpg_kw)
     if kind == 'aps':          # configs/agent/aps.yaml: sf_dim 10, knn_k 12, knn_avg true, knn_rms true, knn_clip 0.0001 (tiny: 4 / 3)
         return ref.aps.APSAgent(update_task_every_step=5, sf_dim=kw.get('sf_dim', 4), knn_rms=True, knn_k=kw.get('knn_k', 3), knn_avg=True,
                                 knn_clip=0.0001, num_init_steps=4096, lstsq_batch_size=4096, update_encoder=True, **ddpg_kw)
@@ -260,6 +263,9 @@ def run_agent(ref, agent, kind, nsteps, batch_fn, noise, dtype):
         return torch.tensor(idx, dtype=torch.long)
     if kind == 'proto':
         pyd.Categorical.sample = p_cat
+    o_randn = torch.randn
+    if kind == 'smm':            # VAE.loss draws epsilon with torch.randn (smm.py:62)
+        torch.randn = lambda *shape, **k: torch.from_numpy(noise.draw(tuple(shape[0]) if isinstance(shape[0], (list, tuple)) else shape))
     if kind == 'cql':
         torch.normal, torch.Tensor.uniform_ = p_normal, p_uniform
         tdn._standard_normal = lambda shape, dtype, device: torch.from_numpy(noise.draw(shape)).to(dtype)
@@ -274,6 +280,7 @@ def run_agent(ref, agent, kind, nsteps, batch_fn, noise, dtype):
         U._standard_normal = orig
         torch.normal, torch.Tensor.uniform_, tdn._standard_normal = o_normal, o_uniform, o_sn
         pyd.Categorical.sample = o_cat
+        torch.randn = o_randn
     return metrics
 
 
@@ -287,7 +294,7 @@ def checksums(agent):
 
 TINY_CQL_LAGRANGE = 'cql-lagrange'
 UNSUP = ('ddpg', 'rnd', 'icm', 'icm_apt', 'disagreement', 'diayn', 'proto', 'aps', 'smm')
-TINY_KINDS = ('td3_bc', 'td3', 'bc', 'ddpg', 'crr', 'crr-exp', 'crr-identity', 'cql', 'rnd', 'icm', 'icm_apt', 'icm_apt-kth', 'disagreement', 'diayn', 'proto', 'cql-lagrange', 'aps')
+TINY_KINDS = ('td3_bc', 'td3', 'bc', 'ddpg', 'crr', 'crr-exp', 'crr-identity', 'cql', 'rnd', 'icm', 'icm_apt', 'icm_apt-kth', 'disagreement', 'diayn', 'proto', 'cql-lagrange', 'aps', 'smm')
 
 
 def gen_tiny(ref):
@@ -329,6 +336,9 @@ def gen_tiny(ref):
                 return x
         rec = Rec()
         batches = [_synth.synth_batch(31, i, B, O, A) for i in range(N)]
+        if base == 'smm':            # 6th batch element: one-hot z (smm.py:148-152)
+            rsk = np.random.RandomState(47)
+            batches = [b + (np.eye(4, dtype=np.float32)[rsk.randint(0, 4, B)],) for b in batches]
         if base == 'diayn':          # 6th batch element: the one-hot skill the replay buffer stores as meta (diayn.py:123-125)
             rsk = np.random.RandomState(41)
             batches = [b + (np.eye(4, dtype=np.float32)[rsk.randint(0, 4, B)],) for b in batches]
