@@ -20,7 +20,7 @@ NET_ACTOR, NET_CRITIC, NET_CRITIC_TARGET = 0, 1, 2
 T_PARAM, T_GRAD, T_ADAM_M, T_ADAM_V = 0, 1, 2, 3
 M_BATCH_REWARD, M_CRITIC_TARGET_Q, M_CRITIC_Q1, M_CRITIC_Q2, M_CRITIC_LOSS, M_ACTOR_LOSS, M_ACTOR_LOGPROB = range(7)
 N_METRICS = 16
-INTR_RND, INTR_ICM, INTR_ICM_APT, INTR_DISAGREEMENT, INTR_DIAYN, INTR_PROTO, INTR_APS = 0, 1, 2, 3, 4, 5, 6
+INTR_RND, INTR_ICM, INTR_ICM_APT, INTR_DISAGREEMENT, INTR_DIAYN, INTR_PROTO, INTR_APS, INTR_SMM = 0, 1, 2, 3, 4, 5, 6, 7
 IM_LOSS, IM_INTR_REWARD, IM_EXTR_REWARD, IM_RMS_MEAN, IM_RMS_STD, IM_ACC, IM_ENT_REWARD, IM_SF_REWARD = range(8)
 N_INTR_METRICS = 8
 
@@ -48,7 +48,9 @@ class IntrCfg(C.Structure):
     _fields_ = [('kind', c_int32), ('obs_dim', c_int32), ('act_dim', c_int32), ('hidden_dim', c_int32), ('rep_dim', c_int32),
                 ('batch', c_int32), ('precision', c_int32), ('knn_k', c_int32), ('knn_avg', c_int32), ('knn_rms', c_int32),
                 ('n_models', c_int32), ('reserved', c_int32), ('lr', c_float), ('scale', c_float), ('knn_clip', c_float), ('clip_val', c_float),
-                ('num_protos', c_int32), ('queue_size', c_int32), ('tau', c_float), ('target_tau', c_float)]
+                ('num_protos', c_int32), ('queue_size', c_int32), ('tau', c_float), ('target_tau', c_float),
+                ('sp_lr', c_float), ('vae_lr', c_float), ('vae_beta', c_float), ('state_ent_coef', c_float), ('latent_ent_coef', c_float),
+                ('latent_cond_ent_coef', c_float), ('goal_x', c_float), ('goal_y', c_float)]
 
 
 class IntrBatch(C.Structure):

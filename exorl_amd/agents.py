@@ -8,7 +8,7 @@ Reference classes mirrored (file:line in /root/reference):
   RNDAgent    agents/unsupervised_learning/rnd.py:63-159     ICMAgent  agents/unsupervised_learning/icm.py:48-139
   ICMAPTAgent agents/unsupervised_learning/icm_apt.py:60-158 DisagreementAgent agents/unsupervised_learning/disagreement.py:50-136
   DIAYNAgent  agents/unsupervised_learning/diayn.py:32-176     ProtoAgent agents/unsupervised_learning/proto.py:46-207 (states)
-  APSAgent    agents/unsupervised_learning/aps.py:82-320
+  APSAgent    agents/unsupervised_learning/aps.py:82-320       SMMAgent   agents/unsupervised_learning/smm.py:115-281 (states)
 
 Python here is orchestration only: it builds the initial weights with torch's CPU RNG in the reference's
 construction order (so a given torch.manual_seed yields the reference's initial parameters), hands batches
@@ -137,7 +137,7 @@ class _AgentBase:
                           'bn': it.bn.cpu() if it.bn is not None else None, 'opt_steps': it.opt_steps(),
                           'queue': (it.queue.cpu(), it.queue_ptr()) if it.queue is not None else None}
         skip = {'engine', 'intr', 'actor', 'critic', 'critic_target', 'rnd', 'icm', 'pbe', 'intrinsic_reward_rms', 'disagreement', 'diayn',
-                'predictor', 'predictor_target', 'projector', 'protos', 'queue', 'encoder_target', 'cat_hook', 'aps', 'aug', 'encoder',
+                'predictor', 'predictor_target', 'projector', 'protos', 'queue', 'encoder_target', 'cat_hook', 'aps', 'smm', 'eps_hook', 'aug', 'encoder',
                 'noise_hook', '_slots', '_graph_iter', '_graph_stddev', '_ctor'}
         st['attrs'] = {k: v for k, v in self.__dict__.items() if k not in skip and not k.startswith('_keep')}
         return st
@@ -895,6 +895,121 @@ class APSAgent(_MetaObsMixin, _IntrAgent):
         h = torch.relu(obs @ p[0].t() + p[1])
         h = torch.relu(h @ p[2].t() + p[3])
         return torch.nn.functional.normalize(h @ p[4].t() + p[5], dim=-1)
+
+
+_SMM_KEYS = ([f'z_pred_net.{i}.{w}' for i in (0, 2, 4) for w in ('weight', 'bias')] +
+             [f'vae.{n}.{w}' for n in ('enc.0', 'enc.2', 'enc_mu', 'enc_logvar', 'dec.0', 'dec.2', 'dec.4') for w in ('weight', 'bias')])
+
+
+def _smm_init(O, Z, H, code_dim=128, vae_hidden=150):
+    """SMM.__init__ (smm.py:89-104): z_pred_net, then VAE (which applies weight_init to itself), then weight_init over everything —
+    the VAE's Linear layers are re-drawn a second time."""
+    def orth(ms):
+        for m in ms:
+            nn.init.orthogonal_(m.weight.data)
+            m.bias.data.fill_(0.0)
+    W = O + Z
+    zp = [nn.Linear(O, H), nn.Linear(H, H), nn.Linear(H, Z)]
+    vae = [nn.Linear(W, vae_hidden), nn.Linear(vae_hidden, vae_hidden), nn.Linear(vae_hidden, code_dim), nn.Linear(vae_hidden, code_dim),
+           nn.Linear(code_dim, vae_hidden), nn.Linear(vae_hidden, vae_hidden), nn.Linear(vae_hidden, W)]
+    orth(vae)
+    orth(zp)
+    orth(vae)
+    return [t for m in zp + vae for t in (m.weight.data, m.bias.data)]
+
+
+class SMMAgent(_MetaObsMixin, _IntrAgent):
+    """agents/unsupervised_learning/smm.py:115-281 (configs/agent/smm.yaml) on state observations.
+
+    Bug-compatible with the reference in one documented place: smm.py adds the 1-D `log_p_star` (B,) to (B,1) terms, so its reward and
+    TD target are (B,B) matrices and `mse_loss` averages over all pairs. Per sample that is the TD loss against
+    rest_i + mean_j log_p_star_j, plus var_j(log_p_star_j) in each critic's loss value; the module writes exactly that reward and
+    `critic_loss` carries the variance term (tests/golden/tiny_smm.npz reproduces the reference's numbers)."""
+    LOSS_KEY = 'loss_vae'
+
+    def __init__(self, z_dim, sp_lr, vae_lr, vae_beta, state_ent_coef, latent_ent_coef, latent_cond_ent_coef, update_encoder, **kwargs):
+        self.z_dim = self._meta_dim = z_dim
+        self.state_ent_coef = state_ent_coef
+        self.latent_ent_coef = latent_ent_coef
+        self.latent_cond_ent_coef = latent_cond_ent_coef
+        self.update_encoder = update_encoder
+        kwargs['meta_dim'] = self.z_dim
+        super().__init__(**kwargs)
+        O, H = self.obs_dim - z_dim, self.hidden_dim
+        self.goal = (150, 75)
+        w = _smm_init(O, z_dim, H)
+        self.intr = IntrEngine('smm', O, self.action_dim, H, self.engine.batch, rep_dim=z_dim, sp_lr=sp_lr, vae_lr=vae_lr, vae_beta=vae_beta,
+                               state_ent_coef=state_ent_coef, latent_ent_coef=latent_ent_coef, latent_cond_ent_coef=latent_cond_ent_coef,
+                               goal=self.goal, precision=self._precision, device=self.device)
+        self.smm = NetView(self.intr, None, _SMM_KEYS)
+        for p, t in zip(self.smm.parameters(), w):
+            p.copy_(t.reshape(p.shape))
+        self.ft_returns = np.zeros(z_dim, dtype=np.float32)
+        self.ft_not_finished = [True for _ in range(z_dim)]
+        self.eps_hook = None            # tests: callable(shape) -> the VAE's epsilon (torch.randn in smm.py:62)
+
+    def get_meta_specs(self):
+        return (_Spec((self.z_dim,), np.float32, 'z'),)
+
+    def init_meta(self):
+        z = np.zeros(self.z_dim, dtype=np.float32)
+        z[np.random.choice(self.z_dim)] = 1.0
+        meta = OrderedDict()
+        meta['z'] = z
+        return meta
+
+    def update_meta(self, meta, global_step, time_step, finetune=False):
+        if self.reward_free:                             # smm.py:154-160 (sic: the fine-tuning rule is keyed on reward_free)
+            return self.update_meta_ft(meta, global_step, time_step)
+        if time_step.last():
+            return self.init_meta()
+        return meta
+
+    def update_meta_ft(self, meta, global_step, time_step):
+        z_ind = meta['z'].argmax()
+        if any(self.ft_not_finished):
+            self.ft_returns[z_ind] += time_step.reward
+            if time_step.last():
+                if not any(self.ft_not_finished):
+                    new_z_ind = self.ft_returns.argmax()
+                else:
+                    self.ft_not_finished[z_ind] = False
+                    not_tried_z = sum(self.ft_not_finished)
+                    for i in range(self.z_dim):
+                        if self.ft_not_finished[i]:
+                            if np.random.random() < 1 / not_tried_z:
+                                new_z_ind = i
+                                break
+                            not_tried_z -= 1
+                new_z = np.zeros(self.z_dim, dtype=np.float32)
+                new_z[new_z_ind] = 1.0
+                meta['z'] = new_z
+        return meta
+
+    def _intr_step(self):
+        O, W = self.obs_dim - self._meta_dim, self.obs_dim
+        s = self._slots
+        e = None
+        if self.eps_hook is not None:
+            e = torch.as_tensor(np.asarray(self.eps_hook((self.engine.batch, 128)), np.float32), device=self.engine.device).contiguous()
+        self.intr.update(s.obs, None, None, s.reward, s.reward, True, skill=s.obs + 4 * O, obs_ld=W, skill_ld=W,
+                         cat_uniform=e.data_ptr() if e is not None else None)
+        self._keep_eps = e
+
+    def update(self, replay_iter, step):
+        if step % self.update_every_steps != 0:
+            return dict()
+        metrics = super().update(replay_iter, step)
+        if self.reward_free:                             # smm.py:249-258: these are reported whatever use_tb says
+            raw = self.intr.metrics_raw()
+            for k in ('icm_loss', 'loss_vae'):
+                metrics.pop(k, None)
+            metrics.update(intr_reward=float(raw[1]), log_p_star=float(raw[3]), pred_log_ratios=float(raw[4]),
+                           latent_ent_coef=float(np.float32(self.latent_ent_coef) * np.float32(np.log(self.z_dim))),
+                           latent_cond_ent_coef=float(raw[6]), loss_vae=float(raw[0]), loss_pred=float(raw[5]))
+            if 'critic_loss' in metrics:
+                metrics['critic_loss'] += 2.0 * float(raw[7])
+        return metrics
 
 
 class _TensorsView(NetView):

@@ -7,6 +7,7 @@
 //   Disagreement agents/unsupervised_learning/disagreement.py:11-47, :64-90
 //   DIAYN    agents/unsupervised_learning/diayn.py:15-29, :78-127
 //   APS      agents/unsupervised_learning/aps.py:63-79, :147-175 (successor-feature net; PBE + task . phi reward)
+//   SMM      agents/unsupervised_learning/smm.py:27-112 (VAE, discriminator), :173-246 (updates, reward)
 //   Proto    agents/unsupervised_learning/proto.py:14-157 (sinkhorn_knopp, prototypes, candidate queue, kNN reward)
 // The modules are plain Linear/ReLU stacks of arbitrary widths (obs_dim, hidden_dim, rep_dim), so the layers run on
 // the generic fp32-source grouped GEMM (gemm.hip) with small row/column kernels around it; what the reference's
@@ -26,8 +27,9 @@ struct ITensor { int64_t off, rows, cols; };
 struct Lin { int in, out; int64_t W, b; };
 struct RmsState { float M, S; double n; };          // utils.RMS: running mean / variance / count (n starts at 1e-4)
 
-struct Mlp {                                         // Linear-ReLU-...-Linear; the last layer's output is raw
+struct Mlp {                                         // Linear-ReLU-...-Linear; the last layer's output is raw unless relu_last
     std::vector<Lin> L;
+    bool relu_last = false;
     std::vector<float*> act, dact;                   // per layer: (rows, out) activations and their gradients
 };
 
@@ -477,6 +479,92 @@ __global__ __launch_bounds__(1024) void aps_sf_reward_kernel(const float* __rest
     }
 }
 
+// ---- SMM (smm.py) -----------------------------------------------------------------------------------
+constexpr int SMM_VAE_HIDDEN = 150, SMM_CODE_DIM = 128;      // smm.py:38-45,98-101: fixed by the reference
+__device__ __forceinline__ float philox_normal_i(uint64_t seed, uint64_t counter, uint32_t elem) {
+    uint32_t c[4] = {elem, 11u, (uint32_t)counter, (uint32_t)(counter >> 32)};
+    Philox::gen(c, seed);
+    const float u1 = ((float)c[0] + 1.0f) * 2.3283064365386963e-10f, u2 = (float)c[1] * 2.3283064365386963e-10f;
+    return sqrtf(-2.0f * __logf(u1)) * __cosf(6.283185307179586f * u2);
+}
+// code = eps * exp(0.5 logvar) + mu (smm.py:54-58); eps kept for the backward pass
+__global__ __launch_bounds__(256) void vae_code_kernel(const float* __restrict__ mu, const float* __restrict__ lv, const float* __restrict__ eps_in,
+                                                       uint64_t seed, uint64_t counter, float* __restrict__ eps, float* __restrict__ code, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float e = eps_in ? eps_in[i] : philox_normal_i(seed, counter, (uint32_t)i);
+        eps[i] = e;
+        code[i] = e * expf(0.5f * lv[i]) + mu[i];
+    }
+}
+// per row: h_s_z = sum_j (x - out)^2 (smm.py:66-70), d(mean squared error)/d out
+__global__ __launch_bounds__(256) void vae_out_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ out, float* __restrict__ dout,
+                                                      float* __restrict__ hsz, int rows, int W) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float sc = -2.0f / ((float)rows * (float)W);
+    float s = 0.f;
+    for (int j = lane; j < W; j += 64) {
+        const float d = x[(int64_t)row * ldx + j] - out[(int64_t)row * W + j];
+        s += d * d;
+        dout[(int64_t)row * W + j] = sc * d;
+    }
+    s = wave_sum(s);
+    if (lane == 0) hsz[row] = s;
+}
+// gradients at (mu, logvar) of beta * KL + reconstruction, given d/d code; kle_row = -0.5 sum (1 + lv - mu^2 - e^lv)
+__global__ __launch_bounds__(256) void vae_latent_kernel(const float* __restrict__ dcode, const float* __restrict__ mu, const float* __restrict__ lv,
+                                                         const float* __restrict__ eps, float* __restrict__ dmu, float* __restrict__ dlv,
+                                                         float* __restrict__ kle_row, int rows, int C, float beta) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float invB = 1.0f / (float)rows;
+    float k = 0.f;
+    for (int j = lane; j < C; j += 64) {
+        const int64_t i = (int64_t)row * C + j;
+        const float m = mu[i], l = lv[i], el = expf(l), sd = expf(0.5f * l), dc = dcode[i];
+        dmu[i] = dc + beta * m * invB;
+        dlv[i] = dc * eps[i] * 0.5f * sd + beta * -0.5f * (1.0f - el) * invB;
+        k += 1.0f + l - m * m - el;
+    }
+    k = wave_sum(k);
+    if (lane == 0) kle_row[row] = -0.5f * k;
+}
+// reward and bookkeeping (smm.py:229-258); single block. The reference's 1-D log_p_star broadcasts its reward to (B,B): per
+// sample that is rest_i + mean_j log_p_star_j for the TD gradient, plus var_j(log_p_star_j) in each critic's loss value.
+__global__ __launch_bounds__(1024) void smm_reward_kernel(const float* __restrict__ obs, int64_t ld, const float* __restrict__ hsz,
+                                                          const float* __restrict__ hzs, const float* extr, float* reward, int B, int Z,
+                                                          float sec, float lec, float lcec, float gx, float gy, float* __restrict__ metrics) {
+    __shared__ float red[17];
+    float e = 0.f, sl = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        e += extr ? extr[b] : 0.f;
+        const float dx = obs[(int64_t)b * ld] - gx, dy = obs[(int64_t)b * ld + 1] - gy;
+        const float dist = sqrtf(dx * dx + dy * dy);
+        sl += logf(dist > 1.0f ? 1.0f / dist : 1.0f);
+        s1 += sec * hsz[b];
+        s2 += lcec * hzs[b];
+    }
+    e = block_sum(e, red);
+    const float lm = block_sum(sl, red) / (float)B;
+    s1 = block_sum(s1, red); s2 = block_sum(s2, red);
+    float var = 0.f, rs = 0.f;
+    const float hz = lec * logf((float)Z);
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float dx = obs[(int64_t)b * ld] - gx, dy = obs[(int64_t)b * ld + 1] - gy;
+        const float dist = sqrtf(dx * dx + dy * dy);
+        const float l = logf(dist > 1.0f ? 1.0f / dist : 1.0f) - lm;
+        var += l * l;
+        const float r = lm + sec * hsz[b] + hz + lcec * hzs[b];
+        reward[b] = r;
+        rs += r;
+    }
+    var = block_sum(var, red); rs = block_sum(rs, red);
+    if (threadIdx.x == 0) {
+        metrics[1] = rs / (float)B; metrics[2] = e / (float)B; metrics[3] = lm; metrics[4] = s1 / (float)B; metrics[6] = s2 / (float)B;
+        metrics[7] = var / (float)B;
+    }
+}
+
 static int grid_for(int64_t n) { const int64_t b = (n + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
 
 static int mlp_forward(const Mlp& m, const float* P, const float* x, int64_t ldx, int rows, int prec, hipStream_t s) {
@@ -484,7 +572,7 @@ static int mlp_forward(const Mlp& m, const float* P, const float* x, int64_t ldx
     for (int l = 0; l < n; ++l) {
         const Lin& L = m.L[l];
         GemmProblem p{l ? m.act[l - 1] : x, P + L.W, m.act[l], P + L.b, rows, L.out, L.in, l ? (int64_t)L.in : ldx, L.in, L.out};
-        EXORL_TRY(gemm_grouped(prec, 0, 0, &p, 1, l < n - 1, false, s));
+        EXORL_TRY(gemm_grouped(prec, 0, 0, &p, 1, l < n - 1 || m.relu_last, false, s));
     }
     return 0;
 }
@@ -495,7 +583,7 @@ static int mlp_backward(const Mlp& m, const float* P, float* G, const float* x, 
     for (int l = n - 1; l >= 0; --l) {
         const Lin& L = m.L[l];
         float* d = m.dact[l];
-        if (l < n - 1) {
+        if (l < n - 1 || m.relu_last) {
             const int64_t cnt = (int64_t)rows * L.out;
             hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(cnt)), dim3(256), 0, s, d, m.act[l], cnt);
             EXORL_LAUNCH_CHECK();
@@ -539,6 +627,10 @@ struct exorl_intr {
           *dscores = nullptr, *dsn = nullptr, *colsum_p = nullptr, *scal = nullptr, *queue = nullptr;
     int64_t queue_ptr = 0;
     uint64_t cat_counter = 0;
+    // SMM: net[0] = z_pred_net, net[1] = vae.enc (ReLU after both layers), net[2] = vae.dec; the two heads; sub-range of the vae
+    Lin enc_mu{}, enc_lv{};
+    int64_t vae_off = 0;
+    float *mu = nullptr, *lv = nullptr, *eps = nullptr, *code = nullptr, *dcode = nullptr, *dmu = nullptr, *dlv = nullptr, *hsz = nullptr, *hzs = nullptr;
     int64_t t = 0;                         // optimiser steps taken
 };
 
@@ -574,6 +666,18 @@ static void describe_intr(exorl_intr* it) {
     } else if (c.kind == EXORL_INTR_DIAYN || c.kind == EXORL_INTR_APS) {
         it->n_nets = 1;
         it->net[0].L = {lin(O, H), lin(H, H), lin(H, R)};             // R = skill_dim
+        it->trainable = round_up(off, 64);
+    } else if (c.kind == EXORL_INTR_SMM) {                            // R = z_dim
+        const int W = O + R, V = SMM_VAE_HIDDEN, C = SMM_CODE_DIM;
+        it->n_nets = 3;
+        it->net[0].L = {lin(O, H), lin(H, H), lin(H, R)};
+        off = round_up(off, 64);
+        it->vae_off = off;
+        it->net[1].L = {lin(W, V), lin(V, V)};
+        it->net[1].relu_last = true;
+        it->enc_mu = lin(V, C);
+        it->enc_lv = lin(V, C);
+        it->net[2].L = {lin(C, V), lin(V, V), lin(V, W)};
         it->trainable = round_up(off, 64);
     } else if (c.kind == EXORL_INTR_PROTO) {                          // R = pred_dim, H = proj_dim
         it->n_nets = 1;
@@ -618,6 +722,10 @@ static void carve_intr(exorl_intr* it, ICarver& c) {
         it->bn = c.take(2 * O + 1);
     } else if (g.kind == EXORL_INTR_APS) {
         it->topk = c.take(B * g.knn_k);
+    } else if (g.kind == EXORL_INTR_SMM) {
+        const int64_t C = SMM_CODE_DIM;
+        it->mu = c.take(B * C); it->lv = c.take(B * C); it->eps = c.take(B * C); it->code = c.take(B * C); it->dcode = c.take(B * C);
+        it->dmu = c.take(B * C); it->dlv = c.take(B * C); it->hsz = c.take(B); it->hzs = c.take(B);
     } else if (g.kind == EXORL_INTR_PROTO) {
         const int64_t P = g.num_protos;
         it->z1 = c.take(B * R); it->dz1 = c.take(B * R); it->sn = c.take(B * R); it->nrm = c.take(B); it->tn = c.take(B * R);
@@ -832,6 +940,60 @@ static int diayn_update(exorl_intr* it, const exorl_intr_batch& b, bool train, h
     return launch_mean(b.reward_out, B, 1.0f / (float)B, it->metrics + EXORL_IM_INTR_REWARD, 0, s);
 }
 
+// ---- SMM --------------------------------------------------------------------------------------------
+static int adam_range(exorl_intr* it, int64_t off, int64_t n, float lr, hipStream_t s) {
+    return adam_step(it->flat[EXORL_T_PARAM] + off, it->flat[EXORL_T_GRAD] + off, it->flat[EXORL_T_ADAM_M] + off, it->flat[EXORL_T_ADAM_V] + off, n,
+                     lr, 0.9f, 0.999f, 1e-8f, it->t, nullptr, 0.f, s);
+}
+
+static int smm_update(exorl_intr* it, const exorl_intr_batch& b, bool train, hipStream_t s) {
+    const auto& c = it->cfg;
+    const int B = c.batch, O = c.obs_dim, Z = c.rep_dim, W = O + Z, V = SMM_VAE_HIDDEN, C = SMM_CODE_DIM, prec = c.precision;
+    EXORL_REQUIRE(b.obs_ld >= W, "intr_update: SMM reads [obs | z] rows (obs_ld >= obs_dim + z_dim)");
+    EXORL_REQUIRE(train, "intr_update: SMM's reward is defined by the losses of its own update step (smm.py:226-241); train must be set");
+    const float* P = it->flat[EXORL_T_PARAM];
+    float* G = it->flat[EXORL_T_GRAD];
+    Mlp &zp = it->net[0], &enc = it->net[1], &dec = it->net[2];
+    it->t += 1;
+    // ---- update_vae (smm.py:173-185, VAE.loss :61-70) on obs_z
+    EXORL_TRY(mlp_forward(enc, P, b.obs, b.obs_ld, B, prec, s));
+    GemmProblem hd[2] = {{enc.act[1], P + it->enc_mu.W, it->mu, P + it->enc_mu.b, B, C, V, V, V, C},
+                         {enc.act[1], P + it->enc_lv.W, it->lv, P + it->enc_lv.b, B, C, V, V, V, C}};
+    EXORL_TRY(gemm_grouped(prec, 0, 0, hd, 2, false, false, s));
+    hipLaunchKernelGGL(vae_code_kernel, dim3(grid_for((int64_t)B * C)), dim3(256), 0, s, it->mu, it->lv, b.cat_uniform, 0x736d6dull, it->cat_counter++,
+                       it->eps, it->code, (int64_t)B * C);
+    EXORL_LAUNCH_CHECK();
+    EXORL_TRY(mlp_forward(dec, P, it->code, C, B, prec, s));
+    hipLaunchKernelGGL(vae_out_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, b.obs, b.obs_ld, dec.act[2], dec.dact[2], it->hsz, B, W);
+    EXORL_LAUNCH_CHECK();
+    EXORL_TRY(mlp_backward(dec, P, G, it->code, C, B, it->dcode, prec, s));
+    hipLaunchKernelGGL(vae_latent_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->dcode, it->mu, it->lv, it->eps, it->dmu, it->dlv, it->fe, B, C, c.vae_beta);
+    EXORL_LAUNCH_CHECK();
+    EXORL_TRY(launch_mean(it->fe, B, c.vae_beta / (float)B, it->metrics + EXORL_IM_LOSS, 0, s));            // beta * kle
+    EXORL_TRY(launch_mean(it->hsz, B, 1.0f / ((float)B * (float)W), it->metrics + EXORL_IM_LOSS, 1, s));    // + mse.mean()
+    EXORL_TRY(colsum(it->dmu, G + it->enc_mu.b, B, C, 1, 0, 0, s));
+    EXORL_TRY(colsum(it->dlv, G + it->enc_lv.b, B, C, 1, 0, 0, s));
+    GemmProblem wg[2] = {{it->dmu, enc.act[1], G + it->enc_mu.W, nullptr, C, V, B, C, V, V}, {it->dlv, enc.act[1], G + it->enc_lv.W, nullptr, C, V, B, C, V, V}};
+    EXORL_TRY(gemm_grouped(prec, 1, 1, wg, 2, false, false, s));
+    GemmProblem d1{it->dmu, P + it->enc_mu.W, enc.dact[1], nullptr, B, V, C, C, V, V}, d2{it->dlv, P + it->enc_lv.W, enc.dact[1], nullptr, B, V, C, C, V, V};
+    EXORL_TRY(gemm_grouped(prec, 0, 1, &d1, 1, false, false, s));
+    EXORL_TRY(gemm_grouped(prec, 0, 1, &d2, 1, false, true, s));
+    EXORL_TRY(mlp_backward(enc, P, G, b.obs, b.obs_ld, B, nullptr, prec, s));
+    EXORL_TRY(adam_range(it, it->vae_off, it->trainable - it->vae_off, c.vae_lr, s));
+    // ---- update_pred (smm.py:187-200): skill discriminator on the raw observation columns
+    EXORL_TRY(mlp_forward(zp, P, b.obs, b.obs_ld, B, prec, s));
+    hipLaunchKernelGGL(diayn_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, zp.act[2], b.skill, b.skill_ld, Z, it->hzs, it->be, zp.dact[2], (float*)nullptr, 1.0f, B);
+    EXORL_LAUNCH_CHECK();
+    EXORL_TRY(launch_mean(it->hzs, B, 1.0f / (float)B, it->metrics + 5, 0, s));
+    EXORL_TRY(mlp_backward(zp, P, G, b.obs, b.obs_ld, B, nullptr, prec, s));
+    EXORL_TRY(adam_range(it, 0, it->vae_off, c.sp_lr, s));
+    // ---- reward (smm.py:229-246)
+    hipLaunchKernelGGL(smm_reward_kernel, dim3(1), dim3(1024), 0, s, b.obs, b.obs_ld, it->hsz, it->hzs, b.extr_reward, b.reward_out, B, Z,
+                       c.state_ent_coef, c.latent_ent_coef, c.latent_cond_ent_coef, c.goal_x, c.goal_y, it->metrics);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- APS -------------------------------------------------------------------------------------------
 static int aps_update(exorl_intr* it, const exorl_intr_batch& b, bool train, hipStream_t s) {
     const auto& c = it->cfg;
@@ -934,7 +1096,9 @@ extern "C" {
 
 static int check_intr_cfg(const exorl_intr_cfg* cfg) {
     EXORL_REQUIRE(cfg, "intr: null cfg");
-    EXORL_REQUIRE(cfg->kind >= EXORL_INTR_RND && cfg->kind <= EXORL_INTR_APS, "intr: unknown kind %d", cfg->kind);
+    EXORL_REQUIRE(cfg->kind >= EXORL_INTR_RND && cfg->kind <= EXORL_INTR_SMM, "intr: unknown kind %d", cfg->kind);
+    EXORL_REQUIRE(cfg->kind != EXORL_INTR_SMM || (cfg->rep_dim >= 1 && cfg->rep_dim <= 1024 && cfg->obs_dim >= 2 && cfg->sp_lr > 0.f && cfg->vae_lr > 0.f),
+                  "intr: SMM needs z_dim in [1, 1024], obs_dim >= 2 (p* reads obs[:, :2]) and positive sp_lr / vae_lr");
     EXORL_REQUIRE(cfg->kind != EXORL_INTR_APS || (cfg->knn_k >= 1 && cfg->knn_k <= 64 && cfg->knn_k <= cfg->batch && cfg->batch <= 4096),
                   "intr: APS needs 1 <= knn_k <= min(64, batch) and batch <= 4096 (got k=%d B=%d)", cfg->knn_k, cfg->batch);
     EXORL_REQUIRE(cfg->kind != EXORL_INTR_PROTO || (cfg->num_protos >= 1 && cfg->queue_size >= cfg->num_protos && cfg->queue_size % cfg->num_protos == 0 &&
@@ -1032,11 +1196,11 @@ int exorl_intr_state(exorl_intr_t* it, void** rms_dev, void** bn_dev, int64_t* b
 int exorl_intr_update(exorl_intr_t* it, const exorl_intr_batch* b, int32_t train, void* stream) {
     EXORL_REQUIRE(it && b && b->obs && b->reward_out, "intr_update: null argument");
     const int k = it->cfg.kind;
-    EXORL_REQUIRE(k == EXORL_INTR_RND || b->next_obs, "intr_update: this module needs next_obs");
-    EXORL_REQUIRE(k == EXORL_INTR_RND || k == EXORL_INTR_DIAYN || k == EXORL_INTR_PROTO || k == EXORL_INTR_APS || b->action, "intr_update: this module needs action");
-    EXORL_REQUIRE((k != EXORL_INTR_DIAYN && k != EXORL_INTR_APS) || b->skill, "intr_update: DIAYN / APS need the skill / task matrix");
+    EXORL_REQUIRE(k == EXORL_INTR_RND || k == EXORL_INTR_SMM || b->next_obs, "intr_update: this module needs next_obs");
+    EXORL_REQUIRE(k == EXORL_INTR_RND || k == EXORL_INTR_DIAYN || k == EXORL_INTR_PROTO || k == EXORL_INTR_APS || k == EXORL_INTR_SMM || b->action, "intr_update: this module needs action");
+    EXORL_REQUIRE((k != EXORL_INTR_DIAYN && k != EXORL_INTR_APS && k != EXORL_INTR_SMM) || b->skill, "intr_update: DIAYN / APS / SMM need the skill / task matrix");
     EXORL_REQUIRE(b->obs_ld >= it->cfg.obs_dim && (!b->next_obs || b->next_obs_ld >= it->cfg.obs_dim) && (!b->action || b->action_ld >= it->cfg.act_dim) &&
-                  (!b->skill || (k != EXORL_INTR_DIAYN && k != EXORL_INTR_APS) || b->skill_ld >= it->cfg.rep_dim), "intr_update: a leading dimension is smaller than its row width");
+                  (!b->skill || (k != EXORL_INTR_DIAYN && k != EXORL_INTR_APS && k != EXORL_INTR_SMM) || b->skill_ld >= it->cfg.rep_dim), "intr_update: a leading dimension is smaller than its row width");
     hipStream_t s = as_stream(stream);
     switch (k) {
         case EXORL_INTR_RND: return rnd_update(it, *b, train != 0, s);
@@ -1045,6 +1209,7 @@ int exorl_intr_update(exorl_intr_t* it, const exorl_intr_batch* b, int32_t train
         case EXORL_INTR_DISAGREEMENT: return disagreement_update(it, *b, train != 0, s);
         case EXORL_INTR_PROTO: return proto_update(it, *b, train != 0, s);
         case EXORL_INTR_APS: return aps_update(it, *b, train != 0, s);
+        case EXORL_INTR_SMM: return smm_update(it, *b, train != 0, s);
         default: return diayn_update(it, *b, train != 0, s);
     }
 }

@@ -176,16 +176,18 @@ class IntrEngine:
     """Intrinsic-reward module (exorl_intr_t): RND / ICM / ICM-APT. Parameters live in a torch-owned workspace so they
     can be exposed as tensors (state_dict, snapshots)."""
     KINDS = {'rnd': L.INTR_RND, 'icm': L.INTR_ICM, 'icm_apt': L.INTR_ICM_APT, 'disagreement': L.INTR_DISAGREEMENT, 'diayn': L.INTR_DIAYN,
-             'proto': L.INTR_PROTO, 'aps': L.INTR_APS}
+             'proto': L.INTR_PROTO, 'aps': L.INTR_APS, 'smm': L.INTR_SMM}
 
     def __init__(self, kind, obs_dim, act_dim, hidden_dim, batch, rep_dim=0, lr=1e-4, scale=1.0, knn_k=12, knn_avg=True,
-                 knn_rms=True, knn_clip=0.0, clip_val=5.0, n_models=0, num_protos=0, queue_size=0, tau=0.1, target_tau=0.05, precision='fp32',
+                 knn_rms=True, knn_clip=0.0, clip_val=5.0, n_models=0, num_protos=0, queue_size=0, tau=0.1, target_tau=0.05, sp_lr=1e-3, vae_lr=1e-2,
+                 vae_beta=0.5, state_ent_coef=1.0, latent_ent_coef=1.0, latent_cond_ent_coef=1.0, goal=(150.0, 75.0), precision='fp32',
                  device='cuda'):
         self.lib = L.load()
         self.device = _require_gpu(device)
         self.kind, self.batch, self.obs_dim, self.act_dim = kind, batch, obs_dim, act_dim
         self.cfg = L.IntrCfg(self.KINDS[kind], obs_dim, act_dim, hidden_dim, rep_dim, batch, PRECISION[precision], knn_k, int(bool(knn_avg)),
-                             int(bool(knn_rms)), n_models, 0, lr, scale, knn_clip, clip_val, num_protos, queue_size, tau, target_tau)
+                             int(bool(knn_rms)), n_models, 0, lr, scale, knn_clip, clip_val, num_protos, queue_size, tau, target_tau,
+                             sp_lr, vae_lr, vae_beta, state_ent_coef, latent_ent_coef, latent_cond_ent_coef, goal[0], goal[1])
         nbytes = self.lib.exorl_intr_workspace_bytes(C.byref(self.cfg))
         if nbytes == 0:
             raise L.ExorlError(self.lib.exorl_last_error().decode())

@@ -264,6 +264,7 @@ int exorl_knn_topk(const float* src_dev, int32_t n_src, const float* tgt_dev, in
 #define EXORL_INTR_DIAYN   4        /* agents/unsupervised_learning/diayn.py:15-127 */
 #define EXORL_INTR_PROTO   5        /* agents/unsupervised_learning/proto.py:14-207 (state observations) */
 #define EXORL_INTR_APS     6        /* agents/unsupervised_learning/aps.py:63-79,147-175 (the task rides in `skill`) */
+#define EXORL_INTR_SMM     7        /* agents/unsupervised_learning/smm.py:27-112,173-246 (states; obs rows are [obs | z], z also in `skill`) */
 #define EXORL_MAX_ENSEMBLE 8
 
 typedef struct exorl_intr_cfg {
@@ -283,6 +284,10 @@ typedef struct exorl_intr_cfg {
     int32_t num_protos, queue_size;
     float tau;            /* softmax / Sinkhorn temperature */
     float target_tau;     /* encoder_target_tau: Polyak rate of predictor_target */
+    /* SMM (configs/agent/smm.yaml, pretrain.yaml): rep_dim = z_dim; lr is unused, the two optimisers have their own rates */
+    float sp_lr, vae_lr, vae_beta;
+    float state_ent_coef, latent_ent_coef, latent_cond_ent_coef;
+    float goal_x, goal_y; /* smm.py:139 self.goal = (150, 75): p*(s) is 1/dist of obs[:, :2] to it beyond distance 1 */
 } exorl_intr_cfg;
 
 typedef struct exorl_intr exorl_intr_t;
@@ -296,6 +301,8 @@ typedef struct exorl_intr exorl_intr_t;
 #define EXORL_IM_ACC         5   /* DIAYN: discriminator accuracy (diayn_acc) */
 #define EXORL_IM_ENT_REWARD  6   /* APS: mean particle-entropy part of the reward (intr_ent_reward) */
 #define EXORL_IM_SF_REWARD   7   /* APS: mean successor-feature part (intr_sf_reward) */
+/* SMM reuses the slots: 0 loss_vae, 1 intr_reward, 2 extr_reward, 3 log_p_star (batch mean), 4 pred_log_ratios, 5 loss_pred,
+ * 6 latent_cond_ent_coef term, 7 var_j(log_p_star_j) — the constant the reference's (B,B) reward broadcast adds to each critic's loss */
 #define EXORL_N_INTR_METRICS 8
 
 /* workspace: device memory of exorl_intr_workspace_bytes(cfg) bytes, 256-byte aligned, owned by the caller (so that the
@@ -305,7 +312,8 @@ int exorl_intr_create(const exorl_intr_cfg* cfg, void* workspace, size_t workspa
 int exorl_intr_destroy(exorl_intr_t* m);
 /* Parameter tensors in the module's parameters() order (RND: predictor.{1,3,5}, target.{1,3,5}; ICM: forward_net.{0,2},
  * backward_net.{0,2}; ICM-APT: trunk.0, trunk.1 (LayerNorm), forward_net, backward_net; Disagreement: ensemble.{m}.{0,2};
- * DIAYN: skill_pred_net.{0,2,4}; APS: state_feat_net.{0,2,4}; Proto: predictor, projector.trunk.{0,2}, protos (no bias), then the frozen predictor_target),
+ * DIAYN: skill_pred_net.{0,2,4}; APS: state_feat_net.{0,2,4}; SMM: z_pred_net.{0,2,4}, vae.enc.{0,2}, vae.enc_mu, vae.enc_logvar,
+ * vae.dec.{0,2,4}; Proto: predictor, projector.trunk.{0,2}, protos (no bias), then the frozen predictor_target),
  * each weight then bias.
  * what = EXORL_T_*; RND's frozen target tensors have parameters only. */
 int exorl_intr_num_tensors(exorl_intr_t* m, int32_t* n);
@@ -326,7 +334,8 @@ typedef struct exorl_intr_batch {
     const float* skill;    int64_t skill_ld;
     const float* extr_reward;
     float* reward_out;
-    const float* cat_uniform;   /* Proto: num_protos uniforms in [0,1) for Categorical(prob).sample() (proto.py:112), or null -> Philox */
+    const float* cat_uniform;   /* Proto: num_protos uniforms in [0,1) for Categorical(prob).sample() (proto.py:112); SMM: the VAE's
+                                   epsilon, (batch, 128) standard normals (smm.py:62); null -> Philox */
 } exorl_intr_batch;
 /* train != 0: the module's optimiser step (update_rnd / update_icm / update_disagreement / update_diayn) then
  * compute_intr_reward under the updated module (rnd.py:121-124, icm.py:106-110, icm_apt.py:123-127, disagreement.py:106-112,
