@@ -397,8 +397,8 @@ def test_smm_tiny_trajectory_vs_reference(gold):
     nets = [('actor', ag.actor), ('critic', ag.critic), ('critic_target', ag.critic_target), ('smm', ag.smm)]
     for nm, net in nets:
         sd = net.state_dict()
-        for k, v in sd.items():
-            np.testing.assert_allclose(v.cpu().numpy(), z[f'init/{nm}/{k}'], rtol=0, atol=2e-6, err_msg=f'{nm}.{k}')
+        for k, v in sd.items():      # same RNG draws; the 150x150 QR differs in the last bits across host CPUs
+            np.testing.assert_allclose(v.cpu().numpy(), z[f'init/{nm}/{k}'], rtol=0, atol=1e-5, err_msg=f'{nm}.{k}')
         net.load_state_dict({k: torch.from_numpy(z[f'init/{nm}/{k}']) for k in sd})
     stream = iter([z[f'noise/{i}'] for i in range(15)])
     ag.eps_hook = lambda shape: next(stream)
