@@ -1,0 +1,121 @@
+"""ORACLE (test infrastructure only — never imported by the product path).
+
+numpy fp32 restatement of the pixel front end of the DDPG-backbone agents:
+  utils.RandomShiftsAug   /root/reference/utils/utils.py:222-254  (replicate pad 4, integer shift through F.grid_sample)
+  ddpg.Encoder            /root/reference/agents/unsupervised_learning/ddpg.py:12-39 (obs/255 - 0.5, 4 x [Conv3x3 + ReLU], flatten)
+Third-party arithmetic restated: torch.linspace (fp32 CPU: symmetric start/end formula), F.grid_sample bilinear with
+align_corners=False and zero padding (unnormalise ((g + 1) * size - 1) / 2, four taps nw/ne/sw/se), nn.Conv2d cross-correlation.
+Pinned by tests/golden/pixels_g5.npz (reference outputs).
+"""
+import numpy as np
+
+F32 = np.float32
+
+
+def _linspace_f32(start, end, steps):
+    """torch.linspace(start, end, steps, dtype=float32) on CPU: step = (end - start)/(steps - 1) in fp32, first half counted from
+    start, second half from end."""
+    start, end = F32(start), F32(end)
+    step = F32((end - start) / F32(steps - 1))
+    half = steps // 2
+    out = np.empty(steps, F32)
+    for i in range(steps):
+        out[i] = F32(start + step * F32(i)) if i < half else F32(end - step * F32(steps - i - 1))
+    return out
+
+
+def random_shifts_aug(x, shifts, pad=4):
+    """x: (n, c, h, h) uint8 or float; shifts: (n, 2) integers in [0, 2 pad] = (x shift, y shift). Returns float32 (n, c, h, h)."""
+    x = np.asarray(x).astype(F32)
+    n, c, h, w = x.shape
+    P = h + 2 * pad
+    xp = np.pad(x, ((0, 0), (0, 0), (pad, pad), (pad, pad)), mode='edge')
+    eps = 1.0 / P
+    ar = _linspace_f32(-1.0 + eps, 1.0 - eps, P)[:h]
+    out = np.zeros((n, c, h, w), F32)
+    for b in range(n):
+        sh = (np.asarray(shifts[b], F32) * F32(2.0 / P)).astype(F32)
+        gx = (ar + sh[0]).astype(F32)                        # along the width
+        gy = (ar + sh[1]).astype(F32)                        # along the height
+        # grid_sampler_unnormalize, align_corners=False. In exact arithmetic ix = j + shift; in fp32 it lands within ~1e-5 of the
+        # integer, so the bilinear tap mixes in ~1e-5 of a neighbouring pixel: outputs deviate from a pure integer shift by up to
+        # ~2e-3 (pixel units), and two fp32 evaluation orders of this line differ from each other by as much.
+        ix = (((gx + F32(1)) * F32(P) - F32(1)) / F32(2)).astype(F32)
+        iy = (((gy + F32(1)) * F32(P) - F32(1)) / F32(2)).astype(F32)
+        x0, y0 = np.floor(ix).astype(np.int64), np.floor(iy).astype(np.int64)
+        wx1, wy1 = (ix - x0).astype(F32), (iy - y0).astype(F32)
+        wx0, wy0 = (F32(1) - wx1).astype(F32), (F32(1) - wy1).astype(F32)
+
+        def tap(yy, xx):
+            ok = ((yy >= 0) & (yy < P))[:, None] & ((xx >= 0) & (xx < P))[None, :]
+            v = xp[b][:, np.clip(yy, 0, P - 1)][:, :, np.clip(xx, 0, P - 1)]
+            return np.where(ok[None], v, F32(0))
+        out[b] = (tap(y0, x0) * (wy0[:, None] * wx0[None, :]) + tap(y0, x0 + 1) * (wy0[:, None] * wx1[None, :]) +
+                  tap(y0 + 1, x0) * (wy1[:, None] * wx0[None, :]) + tap(y0 + 1, x0 + 1) * (wy1[:, None] * wx1[None, :])).astype(F32)
+    return out
+
+
+def _im2col(x, k, stride):
+    n, c, h, w = x.shape
+    oh, ow = (h - k) // stride + 1, (w - k) // stride + 1
+    cols = np.empty((n, oh, ow, c, k, k), x.dtype)
+    for ky in range(k):
+        for kx in range(k):
+            cols[:, :, :, :, ky, kx] = x[:, :, ky:ky + stride * oh:stride, kx:kx + stride * ow:stride].transpose(0, 2, 3, 1)
+    return cols.reshape(n * oh * ow, c * k * k), oh, ow
+
+
+def conv_fwd(x, W, b, stride):
+    """nn.Conv2d(ci, co, 3, stride): cross-correlation, no padding. x (n, ci, h, w) -> (n, co, oh, ow)."""
+    n = x.shape[0]
+    co, ci, k, _ = W.shape
+    cols, oh, ow = _im2col(x, k, stride)
+    y = (cols @ W.reshape(co, -1).T + b).astype(F32)
+    return y.reshape(n, oh, ow, co).transpose(0, 3, 1, 2).copy(), cols
+
+
+def conv_bwd(x_shape, cols, W, dy, stride, need_dx=True):
+    n, ci, h, w = x_shape
+    co, _, k, _ = W.shape
+    oh, ow = dy.shape[2], dy.shape[3]
+    d2 = dy.transpose(0, 2, 3, 1).reshape(-1, co)
+    dW = (d2.T @ cols).reshape(W.shape).astype(F32)
+    db = d2.sum(0).astype(F32)
+    dx = None
+    if need_dx:
+        dcols = (d2 @ W.reshape(co, -1)).astype(F32).reshape(n, oh, ow, ci, k, k)
+        dx = np.zeros(x_shape, F32)
+        for ky in range(k):
+            for kx in range(k):
+                dx[:, :, ky:ky + stride * oh:stride, kx:kx + stride * ow:stride] += dcols[:, :, :, :, ky, kx].transpose(0, 3, 1, 2)
+    return dW, db, dx
+
+
+STRIDES = (2, 1, 1, 1)
+
+
+def encoder_fwd(p, obs):
+    """p = [W0, b0, W1, b1, W2, b2, W3, b3] (convnet.{0,2,4,6}); obs (n, c, 84, 84) pixel values. Returns (n, 39200) and a cache."""
+    a = (np.asarray(obs).astype(F32) / F32(255.0) - F32(0.5)).astype(F32)
+    cache = []
+    for l in range(4):
+        y, cols = conv_fwd(a, p[2 * l], p[2 * l + 1], STRIDES[l])
+        a_out = np.maximum(y, F32(0))
+        cache.append((a.shape, cols, a_out))
+        a = a_out
+    return a.reshape(a.shape[0], -1), cache
+
+
+def encoder_bwd(p, cache, dh, need_dx=False):
+    n = dh.shape[0]
+    d = dh.reshape(cache[-1][2].shape).astype(F32)
+    grads = [None] * 8
+    dx = None
+    for l in range(3, -1, -1):
+        x_shape, cols, a_out = cache[l]
+        d = (d * (a_out > 0)).astype(F32)
+        dW, db, d = conv_bwd(x_shape, cols, p[2 * l], d, STRIDES[l], need_dx=(l > 0 or need_dx))
+        grads[2 * l], grads[2 * l + 1] = dW, db
+    if need_dx:
+        dx = (d / F32(255.0)).astype(F32)
+    return grads, dx

@@ -175,6 +175,45 @@ def gen_utils(ref):
     print('utils g2 keys', len(out))
 
 
+# ----------------------------------------------------------------------------- pixels (G5: K14 encoder, K15 augmentation)
+def gen_pixels(ref):
+    """utils.RandomShiftsAug (utils.py:222-254) with explicit shifts, and ddpg.Encoder (ddpg.py:12-39) forward + backward."""
+    U = ref.utils
+    out = {}
+    rs = np.random.RandomState(3)
+    for tag, (n, c, h) in dict(small=(3, 2, 12), full=(2, 3, 84)).items():
+        x = rs.randint(0, 256, (n, c, h, h)).astype(np.uint8)
+        shifts = rs.randint(0, 9, (n, 1, 1, 2))
+        shifts[0, 0, 0] = (0, 8)                                   # extremes of the range
+        o_randint = torch.randint
+        torch.randint = lambda lo, hi, size, device=None, dtype=None: torch.from_numpy(shifts.copy()).to(dtype)
+        try:
+            y = U.RandomShiftsAug(pad=4)(torch.from_numpy(x))
+        finally:
+            torch.randint = o_randint
+        out[f'aug_{tag}_x'], out[f'aug_{tag}_shift'], out[f'aug_{tag}_y'] = x, shifts.reshape(n, 2).astype(np.int32), y.numpy()
+    for tag, (n, c) in dict(c3=(2, 3), c9=(2, 9)).items():
+        torch.manual_seed(17)
+        enc = ref.ddpg.Encoder((c, 84, 84))
+        x = rs.randint(0, 256, (n, c, 84, 84)).astype(np.uint8)
+        xt = torch.from_numpy(x).float().requires_grad_(True)
+        hfeat = enc(xt)
+        dh = torch.from_numpy(np.random.RandomState(7).standard_normal(tuple(hfeat.shape)).astype(np.float32))
+        (hfeat * dh).sum().backward()
+        out[f'enc_{tag}_x'] = x
+        for k, v in enc.state_dict().items():
+            out[f'enc_{tag}_param/{k}'] = v.numpy().copy()
+        for k, p in enc.named_parameters():
+            out[f'enc_{tag}_grad/{k}'] = p.grad.numpy().copy()
+        # the full feature map is 39200 floats per image: keep a strided sample + checksums (fixture size), all of dx for one image channel
+        hf = hfeat.detach().numpy()
+        out[f'enc_{tag}_h_sample'] = hf[:, ::97].copy()
+        out[f'enc_{tag}_h_sums'] = np.array([hf.astype(np.float64).sum(), (hf.astype(np.float64) ** 2).sum()])
+        out[f'enc_{tag}_dx0'] = xt.grad.numpy()[0, 0].copy()
+    np.savez_compressed(GOLD / 'pixels_g5.npz', **out)
+    print('pixels g5 keys', len(out))
+
+
 # ----------------------------------------------------------------------------- agents (G3/G4)
 def make_agent(ref, kind, O, A, H, B, device='cpu', use_tb=True, **kw):
     if kind == 'td3_bc':
@@ -421,7 +460,7 @@ if __name__ == '__main__':
     args = ap.parse_args()
     GOLD.mkdir(parents=True, exist_ok=True)
     ref = load_reference()
-    todo = [args.only] if args.only else ['replay', 'utils', 'tiny', 'full']
+    todo = [args.only] if args.only else ['replay', 'utils', 'tiny', 'full', 'pixels']
     kinds = args.kinds.split(',') if args.kinds else None
     if kinds:
         TINY_KINDS = tuple(k for k in TINY_KINDS if k.partition('-')[0] in kinds)
@@ -429,4 +468,4 @@ if __name__ == '__main__':
         if t == 'full':
             gen_full(ref, only_kinds=kinds)
         else:
-            {'replay': gen_replay, 'utils': gen_utils, 'tiny': gen_tiny}[t](ref)
+            {'replay': gen_replay, 'utils': gen_utils, 'tiny': gen_tiny, 'pixels': gen_pixels}[t](ref)
