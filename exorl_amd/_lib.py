@@ -60,6 +60,12 @@ class IntrBatch(C.Structure):
 
 # name -> (restype, argtypes); every symbol declared in include/exorl_hip.h
 PROTOTYPES = {
+    'exorl_aug_shift': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_uint64, c_uint64, c_void_p, c_void_p]),
+    'exorl_encoder_param_floats': (c_int64, [c_int32, c_int32]),
+    'exorl_encoder_out_dim': (c_int64, [c_int32]),
+    'exorl_encoder_workspace_floats': (c_int64, [c_int32, c_int32, c_int32]),
+    'exorl_encoder_forward': (C.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, P(c_void_p), c_void_p]),
+    'exorl_encoder_backward': (C.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     'exorl_intr_workspace_bytes': (c_size_t, [P(IntrCfg)]),
     'exorl_intr_create': (C.c_int, [P(IntrCfg), c_void_p, c_size_t, P(c_void_p)]),
     'exorl_intr_destroy': (C.c_int, [c_void_p]),

@@ -1,0 +1,324 @@
+// Pixel front end of the DDPG-backbone agents. Replaces (file:line in the reference repo):
+//   utils.RandomShiftsAug   utils/utils.py:222-254   replicate pad 4 + random integer shift through F.grid_sample
+//   ddpg.Encoder            agents/unsupervised_learning/ddpg.py:12-39   obs/255 - 0.5, 4 x [Conv2d 3x3 (stride 2,1,1,1) + ReLU], flatten
+// Direct fp32 convolutions in the reference's NCHW layout (the flatten order feeds Linear(39200, feature_dim) unchanged):
+//   forward / dgrad  one workgroup = one image x a 16x16 output tile x all 32 output channels; the input tile of every input
+//                    channel and the layer's weights sit in LDS, a thread owns one output pixel and 32 accumulators
+//   wgrad            one workgroup = one image, thread = (co, ci) pair with its 9 taps in registers; per-image partials, summed in
+//                    image order by the column-sum kernel (deterministic, no atomics)
+// The ReLU mask of layer l is applied where d(a_l) is produced (dgrad epilogue), so no separate masking pass touches the maps.
+// First correct version (round 1): fp32 VALU; an MFMA implicit-GEMM form is the next step for these layers.
+#include "kernels.h"
+
+namespace exorl {
+
+constexpr int CONV_CO = 32;          // every layer of the encoder has 32 output channels (ddpg.py:27-31)
+constexpr int CONV_TILE = 16;
+
+// ---- RandomShiftsAug: out[n][c][i][j] = bilinear tap of the replicate-padded image at (i + sy, j + sx) ---------------------------
+__device__ __forceinline__ float lin_f32(float start, float end, float step, int i, int steps) {      // torch.linspace, fp32 CPU
+    return i < steps / 2 ? start + step * (float)i : end - step * (float)(steps - i - 1);
+}
+__global__ __launch_bounds__(256) void aug_shift_kernel(const unsigned char* __restrict__ x, const int* __restrict__ shifts, uint64_t seed,
+                                                        uint64_t counter, float* __restrict__ out, int n, int c, int h, int pad) {
+#pragma clang fp contract(off)
+    const int P = h + 2 * pad;
+    const float eps = (float)(1.0 / P), start = -1.0f + eps, end = 1.0f - eps, step = (end - start) / (float)(P - 1);
+    const float unit = (float)(2.0 / P);
+    const int64_t total = (int64_t)n * c * h * h;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(idx % h), i = (int)((idx / h) % h), ch = (int)((idx / ((int64_t)h * h)) % c), b = (int)(idx / ((int64_t)h * h * c));
+        int sx, sy;
+        if (shifts) { sx = shifts[2 * b]; sy = shifts[2 * b + 1]; }
+        else {      // torch.randint(0, 2 pad + 1, (n,1,1,2)): one Philox draw per image
+            uint32_t r[4] = {(uint32_t)b, 13u, (uint32_t)counter, (uint32_t)(counter >> 32)};
+            Philox::gen(r, seed);
+            sx = (int)(((uint64_t)r[0] * (uint64_t)(2 * pad + 1)) >> 32);
+            sy = (int)(((uint64_t)r[1] * (uint64_t)(2 * pad + 1)) >> 32);
+        }
+        const float gx = lin_f32(start, end, step, j, P) + (float)sx * unit;
+        const float gy = lin_f32(start, end, step, i, P) + (float)sy * unit;
+        const float ix = ((gx + 1.0f) * (float)P - 1.0f) / 2.0f, iy = ((gy + 1.0f) * (float)P - 1.0f) / 2.0f;
+        const float fx = floorf(ix), fy = floorf(iy);
+        const int x0 = (int)fx, y0 = (int)fy;
+        const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+        const unsigned char* img = x + ((int64_t)b * c + ch) * h * h;
+        auto tap = [&](int yy, int xx) -> float {
+            if (yy < 0 || yy >= P || xx < 0 || xx >= P) return 0.f;      // padding_mode='zeros' outside the padded image
+            const int sy2 = min(max(yy - pad, 0), h - 1), sx2 = min(max(xx - pad, 0), h - 1);
+            return (float)img[sy2 * h + sx2];
+        };
+        out[idx] = tap(y0, x0) * (wy0 * wx0) + tap(y0, x0 + 1) * (wy0 * wx1) + tap(y0 + 1, x0) * (wy1 * wx0) + tap(y0 + 1, x0 + 1) * (wy1 * wx1);
+    }
+}
+
+// ---- weight shadows: Wf[ci][tap][co] for the forward pass, Wb[co][tap flipped][ci] for dgrad -----------------------------------
+__global__ void conv_weight_shadow_kernel(const float* __restrict__ W, float* __restrict__ Wf, float* __restrict__ Wb, int ci_n) {
+    const int total = CONV_CO * ci_n * 9;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int tap = i % 9, ci = (i / 9) % ci_n, co = i / (9 * ci_n);
+        const float w = W[i];                                    // torch layout [co][ci][ky][kx]
+        Wf[(ci * 9 + tap) * CONV_CO + co] = w;
+        if (Wb) Wb[(co * 9 + (8 - tap)) * ci_n + ci] = w;        // dx = full correlation of dy with the flipped kernel
+    }
+}
+
+// ---- forward conv / dgrad: out[n][co][y][x] = bias[co] + sum_{ci,ky,kx} Wt[ci][tap][co] * in[n][ci][y*s + ky - pad][x*s + kx - pad] ----
+// in_scale: in = in / 255 - 0.5 (Encoder.forward, ddpg.py:36). relu: ReLU epilogue. mask: out *= (mask > 0) (dgrad through the ReLU of
+// the layer below). Zero padding `pad` (0 forward, 2 for dgrad). co_n <= 32 output channels, ci_n input channels.
+__global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ in, const float* __restrict__ Wt, const float* __restrict__ bias,
+                                                      const float* __restrict__ mask, float* __restrict__ out, int ci_n, int co_n, int ih, int iw,
+                                                      int oh, int ow, int stride, int pad, int in_scale, int relu) {
+    extern __shared__ float lds[];
+    const int tin = (CONV_TILE - 1) * stride + 3;                 // input tile edge
+    float* wl = lds;                                              // [ci][9][co_n]
+    float* tile = lds + ci_n * 9 * co_n;                          // [ci][tin][tin]
+    const int tiles_x = (ow + CONV_TILE - 1) / CONV_TILE;
+    const int ty0 = (blockIdx.x / tiles_x) * CONV_TILE, tx0 = (blockIdx.x % tiles_x) * CONV_TILE;
+    const int n = blockIdx.y;
+    for (int i = threadIdx.x; i < ci_n * 9 * co_n; i += 256) wl[i] = Wt[i];
+    const int iy0 = ty0 * stride - pad, ix0 = tx0 * stride - pad;
+    const float* inn = in + (int64_t)n * ci_n * ih * iw;
+    for (int i = threadIdx.x; i < ci_n * tin * tin; i += 256) {
+        const int xx = i % tin, yy = (i / tin) % tin, ci = i / (tin * tin);
+        const int gy = iy0 + yy, gx = ix0 + xx;
+        float v = 0.f;
+        if (gy >= 0 && gy < ih && gx >= 0 && gx < iw) {
+            v = inn[((int64_t)ci * ih + gy) * iw + gx];
+            if (in_scale) v = v / 255.0f - 0.5f;
+        }
+        tile[i] = v;
+    }
+    __syncthreads();
+    const int ly = threadIdx.x / CONV_TILE, lx = threadIdx.x % CONV_TILE;
+    const int oy = ty0 + ly, ox = tx0 + lx;
+    float acc[CONV_CO];
+#pragma unroll
+    for (int co = 0; co < CONV_CO; ++co) acc[co] = 0.f;
+    for (int ci = 0; ci < ci_n; ++ci) {
+        const float* t = tile + ci * tin * tin + (ly * stride) * tin + lx * stride;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float v = t[ky * tin + kx];
+                const float* w = wl + (ci * 9 + ky * 3 + kx) * co_n;
+#pragma unroll
+                for (int co = 0; co < CONV_CO; ++co)
+                    if (co < co_n) acc[co] += v * w[co];
+            }
+    }
+    if (oy >= oh || ox >= ow) return;
+    float* o = out + (int64_t)n * co_n * oh * ow + (int64_t)oy * ow + ox;
+    const float* mk = mask ? mask + (int64_t)n * co_n * oh * ow + (int64_t)oy * ow + ox : nullptr;
+#pragma unroll
+    for (int co = 0; co < CONV_CO; ++co) {
+        if (co >= co_n) break;
+        float v = acc[co] + (bias ? bias[co] : 0.f);
+        if (relu) v = fmaxf(v, 0.f);
+        if (mk) v = mk[(int64_t)co * oh * ow] > 0.f ? v : 0.f;
+        o[(int64_t)co * oh * ow] = v;
+    }
+}
+
+static int conv3x3(const float* in, const float* Wt, const float* bias, const float* mask, float* out, int n, int ci_n, int co_n, int ih, int iw,
+                   int oh, int ow, int stride, int pad, int in_scale, int relu, hipStream_t s) {
+    const int tin = (CONV_TILE - 1) * stride + 3;
+    const size_t lds = ((size_t)ci_n * 9 * co_n + (size_t)ci_n * tin * tin) * sizeof(float);
+    EXORL_REQUIRE(lds <= 160 * 1024 && co_n <= CONV_CO, "conv3x3: tile does not fit LDS (ci=%d stride=%d) or co=%d > 32", ci_n, stride, co_n);
+    static bool attr = false;
+    if (!attr) {
+        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(conv3x3_kernel, dim3(cdiv(oh, CONV_TILE) * cdiv(ow, CONV_TILE), n), dim3(256), lds, s, in, Wt, bias, mask, out, ci_n, co_n,
+                       ih, iw, oh, ow, stride, pad, in_scale, relu);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- wgrad: P[n][co][ci][tap] = sum_{y,x} dy[n][co][y][x] * in[n][ci][y*s + ky][x*s + kx];  Pb[n][co] = sum dy -------------------------
+constexpr int WG_ROWS = 6;            // output rows per LDS tile
+__global__ __launch_bounds__(1024) void conv_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ in, float* __restrict__ P,
+                                                          float* __restrict__ Pb, int ci_n, int ih, int iw, int oh, int ow, int stride,
+                                                          int in_scale) {
+    extern __shared__ float lds[];
+    const int n = blockIdx.x;
+    const int co = threadIdx.x >> 5, ci = threadIdx.x & 31;
+    const int in_rows = (WG_ROWS - 1) * stride + 3;
+    float* dyt = lds;                                   // [WG_ROWS * ow][32 co]
+    float* it = lds + WG_ROWS * ow * CONV_CO;           // [in_rows * iw][ci_n]
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    float bsum = 0.f;
+    const float* dyn = dy + (int64_t)n * CONV_CO * oh * ow;
+    const float* inn = in + (int64_t)n * ci_n * ih * iw;
+    for (int r0 = 0; r0 < oh; r0 += WG_ROWS) {
+        const int nr = oh - r0 < WG_ROWS ? oh - r0 : WG_ROWS;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nr * ow * CONV_CO; i += 1024) {
+            const int p = i % (nr * ow), c2 = i / (nr * ow);                  // coalesced over pixels of one channel
+            dyt[p * CONV_CO + c2] = dyn[(int64_t)c2 * oh * ow + (int64_t)r0 * ow + p];
+        }
+        const int iy0 = r0 * stride, rows_in = (nr - 1) * stride + 3;
+        for (int i = threadIdx.x; i < rows_in * iw * ci_n; i += 1024) {
+            const int p = i % (rows_in * iw), c2 = i / (rows_in * iw);
+            float v = inn[(int64_t)c2 * ih * iw + (int64_t)iy0 * iw + p];
+            if (in_scale) v = v / 255.0f - 0.5f;
+            it[p * ci_n + c2] = v;
+        }
+        __syncthreads();
+        if (ci < ci_n) {
+            for (int y = 0; y < nr; ++y)
+                for (int x = 0; x < ow; ++x) {
+                    const float d = dyt[(y * ow + x) * CONV_CO + co];
+                    const float* ip = it + ((y * stride) * iw + x * stride) * ci_n + ci;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] += d * ip[(ky * iw + kx) * ci_n];
+                    if (ci == 0) bsum += d;
+                }
+        }
+    }
+    (void)in_rows;
+    if (ci < ci_n) {
+        float* Pn = P + ((int64_t)n * CONV_CO + co) * ci_n * 9 + ci * 9;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) Pn[t] = acc[t];
+        if (ci == 0) Pb[(int64_t)n * CONV_CO + co] = bsum;
+    }
+}
+
+// d *= (a > 0): ReLU mask of the top activation against the gradient that arrives from the trunk's Linear
+__global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ d, const float* __restrict__ a, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = a[i] > 0.f ? d[i] : 0.f;
+}
+
+// ---- encoder geometry -------------------------------------------------------------------------------------------------
+struct EncGeom {
+    int c_in, hw;                 // input channels, image edge (84 or 64)
+    int edge[5];                  // spatial edge of the input and of the 4 activations
+    int64_t w_off[4], b_off[4];   // flat parameter offsets (torch order convnet.{0,2,4,6}.{weight,bias}, each padded to 4 floats)
+    int64_t total;
+};
+static EncGeom enc_geom(int c_in, int hw) {
+    EncGeom g{};
+    g.c_in = c_in; g.hw = hw;
+    g.edge[0] = hw;
+    g.edge[1] = (hw - 3) / 2 + 1;
+    for (int l = 2; l <= 4; ++l) g.edge[l] = g.edge[l - 1] - 2;
+    int64_t off = 0;
+    for (int l = 0; l < 4; ++l) {
+        const int ci = l == 0 ? c_in : CONV_CO;
+        g.w_off[l] = off; off += round_up((int64_t)CONV_CO * ci * 9, 4);
+        g.b_off[l] = off; off += round_up(CONV_CO, 4);
+    }
+    g.total = round_up(off, 64);
+    return g;
+}
+
+}  // namespace exorl
+
+using namespace exorl;
+
+extern "C" {
+
+int exorl_aug_shift(const unsigned char* x_dev, int32_t n, int32_t c, int32_t h, int32_t pad, const int32_t* shifts_dev, uint64_t seed,
+                    uint64_t counter, float* out_dev, void* stream) {
+    EXORL_REQUIRE(x_dev && out_dev && n > 0 && c > 0 && h > 1 && pad >= 0, "aug_shift: bad arguments");
+    const int64_t total = (int64_t)n * c * h * h;
+    const int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(aug_shift_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, as_stream(stream), x_dev, shifts_dev, seed,
+                       counter, out_dev, n, c, h, pad);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
+int64_t exorl_encoder_param_floats(int32_t c_in, int32_t hw) { return enc_geom(c_in, hw).total; }
+int64_t exorl_encoder_out_dim(int32_t hw) { const EncGeom g = enc_geom(3, hw); return (int64_t)CONV_CO * g.edge[4] * g.edge[4]; }
+
+// floats of scratch for n images: 4 activation maps, 3 gradient maps (ping-pong would do with 2; kept simple), weight shadows, wgrad partials
+int64_t exorl_encoder_workspace_floats(int32_t n, int32_t c_in, int32_t hw) {
+    const EncGeom g = enc_geom(c_in, hw);
+    int64_t f = 0;
+    for (int l = 1; l <= 4; ++l) f += round_up((int64_t)n * CONV_CO * g.edge[l] * g.edge[l], 64);          // activations
+    for (int l = 1; l <= 3; ++l) f += round_up((int64_t)n * CONV_CO * g.edge[l] * g.edge[l], 64);          // d(activations) 1..3
+    f += 2 * 4 * round_up((int64_t)CONV_CO * CONV_CO * 9, 64);                                             // Wf, Wb per layer
+    f += round_up((int64_t)n * CONV_CO * CONV_CO * 9, 64) + round_up((int64_t)n * CONV_CO, 64);           // wgrad partials
+    return f;
+}
+
+struct EncWs { float* act[5]; float* dact[4]; float* wf[4]; float* wb[4]; float *P, *Pb; };
+static EncWs enc_carve(const EncGeom& g, int n, float* ws) {
+    EncWs w{};
+    int64_t off = 0;
+    auto take = [&](int64_t c) { float* p = ws + off; off += round_up(c, 64); return p; };
+    for (int l = 1; l <= 4; ++l) w.act[l] = take((int64_t)n * CONV_CO * g.edge[l] * g.edge[l]);
+    for (int l = 1; l <= 3; ++l) w.dact[l] = take((int64_t)n * CONV_CO * g.edge[l] * g.edge[l]);
+    for (int l = 0; l < 4; ++l) { w.wf[l] = take((int64_t)CONV_CO * CONV_CO * 9); w.wb[l] = take((int64_t)CONV_CO * CONV_CO * 9); }
+    w.P = take((int64_t)n * CONV_CO * CONV_CO * 9);
+    w.Pb = take((int64_t)n * CONV_CO);
+    return w;
+}
+
+// Encoder.forward (ddpg.py:35-39): x (n, c_in, hw, hw) fp32 pixel values (0..255, e.g. the augmentation's output);
+// the flattened features (n, 32*e*e) are ws_dev's 4th activation map: *h_out_dev points at them.
+int exorl_encoder_forward(const float* params_dev, int32_t c_in, int32_t hw, const float* x_dev, int32_t n, float* ws_dev, float** h_out_dev,
+                          void* stream) {
+    EXORL_REQUIRE(params_dev && x_dev && ws_dev && n > 0 && c_in > 0 && c_in <= 16 && hw >= 16, "encoder_forward: bad arguments");
+    hipStream_t s = as_stream(stream);
+    const EncGeom g = enc_geom(c_in, hw);
+    const EncWs w = enc_carve(g, n, ws_dev);
+    const float* in = x_dev;
+    for (int l = 0; l < 4; ++l) {
+        const int ci = l == 0 ? c_in : CONV_CO;
+        hipLaunchKernelGGL(conv_weight_shadow_kernel, dim3(cdiv(CONV_CO * ci * 9, 256)), dim3(256), 0, s, params_dev + g.w_off[l], w.wf[l],
+                           l > 0 ? w.wb[l] : nullptr, ci);
+        EXORL_LAUNCH_CHECK();
+        EXORL_TRY(conv3x3(in, w.wf[l], params_dev + g.b_off[l], nullptr, w.act[l + 1], n, ci, CONV_CO, g.edge[l], g.edge[l], g.edge[l + 1],
+                          g.edge[l + 1], l == 0 ? 2 : 1, 0, l == 0 ? 1 : 0, 1, s));
+        in = w.act[l + 1];
+    }
+    if (h_out_dev) *h_out_dev = w.act[4];
+    return 0;
+}
+
+// Backward through the encoder after exorl_encoder_forward on the same x / ws: dh (n, 32*e*e) is overwritten (ReLU mask);
+// parameter gradients are written to grads_dev in the parameters' flat layout. No d/d(pixels).
+int exorl_encoder_backward(const float* params_dev, int32_t c_in, int32_t hw, const float* x_dev, int32_t n, float* ws_dev, float* dh_dev,
+                           float* grads_dev, void* stream) {
+    EXORL_REQUIRE(params_dev && x_dev && ws_dev && dh_dev && grads_dev && n > 0, "encoder_backward: bad arguments");
+    hipStream_t s = as_stream(stream);
+    const EncGeom g = enc_geom(c_in, hw);
+    const EncWs w = enc_carve(g, n, ws_dev);
+    const int64_t top = (int64_t)n * CONV_CO * g.edge[4] * g.edge[4];
+    hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((top + 255) / 256 > 4096 ? 4096 : (top + 255) / 256)), dim3(256), 0, s, dh_dev, w.act[4], top);
+    EXORL_LAUNCH_CHECK();
+    float* d = dh_dev;                                            // d(a_{l+1}), already masked
+    for (int l = 3; l >= 0; --l) {
+        const int ci = l == 0 ? c_in : CONV_CO, stride = l == 0 ? 2 : 1;
+        const float* in = l == 0 ? x_dev : w.act[l];
+        const int oh = g.edge[l + 1], ih = g.edge[l];
+        const int in_rows = (WG_ROWS - 1) * stride + 3;
+        const size_t lds = ((size_t)WG_ROWS * oh * CONV_CO + (size_t)in_rows * ih * ci) * sizeof(float);
+        EXORL_REQUIRE(lds <= 160 * 1024, "encoder_backward: wgrad tile does not fit LDS");
+        static bool attr = false;
+        if (!attr) {
+            EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr = true;
+        }
+        hipLaunchKernelGGL(conv_wgrad_kernel, dim3(n), dim3(1024), lds, s, d, in, w.P, w.Pb, ci, ih, ih, oh, oh, stride, l == 0 ? 1 : 0);
+        EXORL_LAUNCH_CHECK();
+        EXORL_TRY(colsum(w.P, grads_dev + g.w_off[l], n, CONV_CO * ci * 9, 1, 0, 0, s));
+        EXORL_TRY(colsum(w.Pb, grads_dev + g.b_off[l], n, CONV_CO, 1, 0, 0, s));
+        if (l > 0) {              // d(a_l) = full correlation of d(a_{l+1}) with the flipped kernel, masked by a_l > 0
+            EXORL_TRY(conv3x3(d, w.wb[l], nullptr, w.act[l], w.dact[l], n, CONV_CO, CONV_CO, oh, oh, ih, ih, 1, 2, 0, 0, s));
+            d = w.dact[l];
+        }
+    }
+    return 0;
+}
+
+}  // extern "C"

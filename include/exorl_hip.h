@@ -345,6 +345,26 @@ int exorl_intr_metrics(exorl_intr_t* m, float* host_out /* EXORL_N_INTR_METRICS 
 /* optimiser step count of the module's Adam: set == 0 reads into *steps, else writes it (snapshot restore) */
 int exorl_intr_opt_steps(exorl_intr_t* m, int64_t* steps, int32_t set);
 
+/* ---------------------------------------------------------------------------------------------
+ * Pixel front end (building blocks; the pixel actor/critic heads are not wired into exorl_agent_* yet).
+ *   utils.RandomShiftsAug  utils/utils.py:222-254      ddpg.Encoder  agents/unsupervised_learning/ddpg.py:12-39
+ * ------------------------------------------------------------------------------------------- */
+/* out (n, c, h, h) fp32 pixel values = RandomShiftsAug(pad)(x) for x (n, c, h, h) uint8. shifts_dev: (n, 2) int32 (x shift, y shift)
+ * in [0, 2 pad] — what torch.randint draws at utils.py:244-248 — or null for Philox(seed, counter). */
+int exorl_aug_shift(const unsigned char* x_dev, int32_t n, int32_t c, int32_t h, int32_t pad, const int32_t* shifts_dev, uint64_t seed,
+                    uint64_t counter, float* out_dev, void* stream);
+/* Encoder parameters live in one flat fp32 buffer in torch order convnet.{0,2,4,6}.{weight,bias} (each tensor padded to 4 floats). */
+int64_t exorl_encoder_param_floats(int32_t c_in, int32_t hw);
+int64_t exorl_encoder_out_dim(int32_t hw);                         /* repr_dim: 32*35*35 for 84x84, 32*25*25 for 64x64 */
+int64_t exorl_encoder_workspace_floats(int32_t n, int32_t c_in, int32_t hw);
+/* Encoder.forward on x (n, c_in, hw, hw) fp32 pixel values; *h_out_dev = the flattened features (n, repr_dim) inside ws_dev. */
+int exorl_encoder_forward(const float* params_dev, int32_t c_in, int32_t hw, const float* x_dev, int32_t n, float* ws_dev, float** h_out_dev,
+                          void* stream);
+/* Backward after exorl_encoder_forward with the same x / ws: dh_dev (n, repr_dim) is overwritten; parameter gradients go to
+ * grads_dev (flat layout of the parameters). */
+int exorl_encoder_backward(const float* params_dev, int32_t c_in, int32_t hw, const float* x_dev, int32_t n, float* ws_dev, float* dh_dev,
+                           float* grads_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,116 @@
+"""GPU parity of the pixel front end through the C ABI: RandomShiftsAug and the conv encoder (forward + backward) against the
+reference's own outputs (tests/golden/pixels_g5.npz) and against the oracle at batch size."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pixels
+
+pytestmark = pytest.mark.gpu
+
+ENC_KEYS = [f'convnet.{i}.{w}' for i in (0, 2, 4, 6) for w in ('weight', 'bias')]
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from exorl_amd import _lib as L
+    return L.load()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def flat_params(lib, plist, c_in, hw=84):
+    """torch-order tensors -> the library's flat layout (each tensor padded to 4 floats)."""
+    n = lib.exorl_encoder_param_floats(c_in, hw)
+    flat = np.zeros(n, np.float32)
+    off, offs = 0, []
+    for p in plist:
+        flat[off:off + p.size] = p.reshape(-1)
+        offs.append(off)
+        off += (p.size + 3) // 4 * 4
+    return flat, offs
+
+
+def run_encoder(lib, plist, x, dh=None):
+    from exorl_amd import _lib as L
+    n, c_in, hw, _ = x.shape
+    flat, offs = flat_params(lib, plist, c_in, hw)
+    P = dev(flat)
+    X = dev(x.astype(np.float32))
+    ws = torch.zeros(lib.exorl_encoder_workspace_floats(n, c_in, hw), device='cuda')
+    hp = C.c_void_p()
+    L.check(lib.exorl_encoder_forward(P.data_ptr(), c_in, hw, X.data_ptr(), n, ws.data_ptr(), C.byref(hp), None))
+    D = lib.exorl_encoder_out_dim(hw)
+    off = (hp.value - ws.data_ptr()) // 4
+    h = ws[off:off + n * D].view(n, D).clone()
+    grads = None
+    if dh is not None:
+        G = torch.zeros_like(P)
+        DH = dev(dh.astype(np.float32))
+        L.check(lib.exorl_encoder_backward(P.data_ptr(), c_in, hw, X.data_ptr(), n, ws.data_ptr(), DH.data_ptr(), G.data_ptr(), None))
+        g = G.cpu().numpy()
+        grads = [g[o:o + p.size].reshape(p.shape) for o, p in zip(offs, plist)]
+    torch.cuda.synchronize()
+    return h.cpu().numpy(), grads
+
+
+@pytest.mark.parametrize('tag', ['small', 'full'])
+def test_aug_vs_reference(lib, gold, tag):
+    from exorl_amd import _lib as L
+    z = np.load(gold / 'pixels_g5.npz')
+    x, sh, want = z[f'aug_{tag}_x'], z[f'aug_{tag}_shift'], z[f'aug_{tag}_y']
+    n, c, h, _ = x.shape
+    X, S = dev(x), dev(sh.astype(np.int32))
+    out = torch.empty(n, c, h, h, device='cuda')
+    L.check(lib.exorl_aug_shift(X.data_ptr(), n, c, h, 4, S.data_ptr(), 0, 0, out.data_ptr(), None))
+    got = out.cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=3e-3)          # pixel units; see oracle/pixels.py on the grid's fp32 rounding
+    assert (np.abs(got - want) > 1e-3).mean() < 5e-3
+    np.testing.assert_allclose(got, pixels.random_shifts_aug(x, sh), rtol=0, atol=3e-3)
+    # Philox shifts: every image is an integer shift in [0, 8]^2 of its replicate-padded self
+    L.check(lib.exorl_aug_shift(X.data_ptr(), n, c, h, 4, None, 5, 9, out.data_ptr(), None))
+    got = out.cpu().numpy()
+    xp = np.pad(x.astype(np.float32), ((0, 0), (0, 0), (4, 4), (4, 4)), mode='edge')
+    for b in range(n):
+        errs = [np.abs(got[b] - xp[b][:, sy:sy + h, sx:sx + h]).max() for sy in range(9) for sx in range(9)]
+        assert min(errs) < 2e-2
+
+
+@pytest.mark.parametrize('tag', ['c3', 'c9'])
+def test_encoder_vs_reference(lib, gold, tag):
+    z = np.load(gold / 'pixels_g5.npz')
+    p = [z[f'enc_{tag}_param/{k}'] for k in ENC_KEYS]
+    x = z[f'enc_{tag}_x']
+    dh = np.random.RandomState(7).standard_normal((2, 39200)).astype(np.float32)
+    h, grads = run_encoder(lib, p, x, dh)
+    np.testing.assert_allclose(h[:, ::97], z[f'enc_{tag}_h_sample'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose([h.astype(np.float64).sum(), (h.astype(np.float64) ** 2).sum()], z[f'enc_{tag}_h_sums'], rtol=1e-5)
+    for k, g in zip(ENC_KEYS, grads):
+        want = z[f'enc_{tag}_grad/{k}']
+        np.testing.assert_allclose(g, want, rtol=2e-4, atol=2e-5 * np.abs(want).max(), err_msg=k)
+
+
+def test_encoder_batch_vs_oracle(lib):
+    """A batch that spans several workgroups per layer and ragged output tiles (64x64 images: edges 31, 29, 27, 25)."""
+    rs = np.random.RandomState(0)
+    for (n, c, hw) in ((5, 3, 64), (3, 9, 84)):
+        p = []
+        for l in range(4):
+            ci = c if l == 0 else 32
+            p += [(rs.standard_normal((32, ci, 3, 3)) / np.sqrt(ci * 9)).astype(np.float32), (0.1 * rs.standard_normal(32)).astype(np.float32)]
+        x = rs.randint(0, 256, (n, c, hw, hw)).astype(np.uint8)
+        ho, cache = pixels.encoder_fwd(p, x) if hw == 84 else _fwd_any(p, x)
+        dh = rs.standard_normal(ho.shape).astype(np.float32)
+        go, _ = pixels.encoder_bwd(p, cache, dh)
+        h, g = run_encoder(lib, p, x, dh)
+        np.testing.assert_allclose(h, ho, rtol=1e-4, atol=1e-5)
+        for i, (a, b) in enumerate(zip(g, go)):
+            np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-5 * np.abs(b).max(), err_msg=f'grad {i}')
+
+
+def _fwd_any(p, x):
+    return pixels.encoder_fwd(p, x)
