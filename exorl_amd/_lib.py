@@ -58,8 +58,26 @@ class IntrBatch(C.Structure):
                 ('next_obs_ld', c_int64), ('skill', c_void_p), ('skill_ld', c_int64), ('extr_reward', c_void_p), ('reward_out', c_void_p), ('cat_uniform', c_void_p)]
 
 
+class PixelCfg(C.Structure):
+    _fields_ = [('c_in', c_int32), ('hw', c_int32), ('act_dim', c_int32), ('feature_dim', c_int32), ('hidden_dim', c_int32), ('batch', c_int32),
+                ('precision', c_int32), ('reserved', c_int32), ('lr', c_float), ('tau', c_float), ('stddev_clip', c_float), ('reserved2', c_float),
+                ('seed', c_uint64)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/exorl_hip.h
 PROTOTYPES = {
+    'exorl_u8_to_f32': (C.c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    'exorl_pixel_agent_workspace_bytes': (c_size_t, [P(PixelCfg)]),
+    'exorl_pixel_agent_create': (C.c_int, [P(PixelCfg), c_void_p, c_size_t, P(c_void_p)]),
+    'exorl_pixel_agent_destroy': (C.c_int, [c_void_p]),
+    'exorl_pixel_agent_num_tensors': (C.c_int, [c_void_p, c_int32, P(c_int32)]),
+    'exorl_pixel_agent_tensor': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, P(c_void_p), P(c_int64), P(c_int64)]),
+    'exorl_pixel_agent_sync_target': (C.c_int, [c_void_p, c_void_p]),
+    'exorl_pixel_agent_batch_slots': (C.c_int, [c_void_p, P(BatchOut)]),
+    'exorl_pixel_agent_set_batch': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'exorl_pixel_agent_update': (C.c_int, [c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'exorl_pixel_agent_metrics': (C.c_int, [c_void_p, c_void_p, c_void_p]),
+    'exorl_pixel_agent_act': (C.c_int, [c_void_p, c_void_p, c_float, c_int32, c_void_p, c_void_p, c_void_p]),
     'exorl_aug_shift': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_uint64, c_uint64, c_void_p, c_void_p]),
     'exorl_encoder_param_floats': (c_int64, [c_int32, c_int32]),
     'exorl_encoder_out_dim': (c_int64, [c_int32]),

@@ -7,7 +7,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / 'csrc'
 LIB = HERE / 'libexorl_hip.so'
-SOURCES = ['api.cpp', 'gemm.hip', 'rowops.hip', 'fused.hip', 'loss.hip', 'cql.hip', 'optim.hip', 'replay.hip', 'agent.hip', 'knn.hip', 'intr.hip', 'pixels.hip']
+SOURCES = ['api.cpp', 'gemm.hip', 'rowops.hip', 'fused.hip', 'loss.hip', 'cql.hip', 'optim.hip', 'replay.hip', 'agent.hip', 'knn.hip', 'intr.hip', 'pixels.hip', 'pixel_agent.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
 

@@ -24,14 +24,7 @@
 namespace exorl {
 
 struct ITensor { int64_t off, rows, cols; };
-struct Lin { int in, out; int64_t W, b; };
 struct RmsState { float M, S; double n; };          // utils.RMS: running mean / variance / count (n starts at 1e-4)
-
-struct Mlp {                                         // Linear-ReLU-...-Linear; the last layer's output is raw unless relu_last
-    std::vector<Lin> L;
-    bool relu_last = false;
-    std::vector<float*> act, dact;                   // per layer: (rows, out) activations and their gradients
-};
 
 __device__ __forceinline__ float block_sum(float v, float* red) {      // all threads get the total; red: >= 17 floats
     v = wave_sum(v);
@@ -567,7 +560,7 @@ __global__ __launch_bounds__(1024) void smm_reward_kernel(const float* __restric
 
 static int grid_for(int64_t n) { const int64_t b = (n + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
 
-static int mlp_forward(const Mlp& m, const float* P, const float* x, int64_t ldx, int rows, int prec, hipStream_t s) {
+int mlp_forward(const Mlp& m, const float* P, const float* x, int64_t ldx, int rows, int prec, hipStream_t s) {
     const int n = (int)m.L.size();
     for (int l = 0; l < n; ++l) {
         const Lin& L = m.L[l];
@@ -578,7 +571,7 @@ static int mlp_forward(const Mlp& m, const float* P, const float* x, int64_t ldx
 }
 
 // dact[last] holds d(loss)/d(output); writes parameter gradients into G and, if dx, d(loss)/d(input) (rows, in0)
-static int mlp_backward(const Mlp& m, const float* P, float* G, const float* x, int64_t ldx, int rows, float* dx, int prec, hipStream_t s) {
+int mlp_backward(const Mlp& m, const float* P, float* G, const float* x, int64_t ldx, int rows, float* dx, int prec, hipStream_t s) {
     const int n = (int)m.L.size();
     for (int l = n - 1; l >= 0; --l) {
         const Lin& L = m.L[l];
@@ -770,7 +763,7 @@ static int intr_adam(exorl_intr* it, hipStream_t s) {
                      it->cfg.lr, 0.9f, 0.999f, 1e-8f, it->t, nullptr, 0.f, s);
 }
 
-static int launch_concat(const float* a, int64_t lda, int ca, const float* b, int64_t ldb, int cb, float* dst, int rows, hipStream_t s) {
+int launch_concat(const float* a, int64_t lda, int ca, const float* b, int64_t ldb, int cb, float* dst, int rows, hipStream_t s) {
     hipLaunchKernelGGL(concat2_kernel, dim3(grid_for((int64_t)rows * (ca + cb))), dim3(256), 0, s, a, lda, ca, b, ldb, cb, dst, rows);
     EXORL_LAUNCH_CHECK();
     return 0;

@@ -1,5 +1,7 @@
 // Internal C++ interface between the kernel translation units of libexorl_hip.so.
 #pragma once
+#include <vector>
+
 #include "common.h"
 
 namespace exorl {
@@ -301,6 +303,18 @@ int soft_update(const float* p, float* target, int64_t n, float tau, hipStream_t
 // bump != nullptr: block 0 also increments *bump (the replay counter of a captured step: nothing later in the step reads it)
 int adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const AdamConst* c_dev, float* target,
                   const ShadowSpec* shadows, hipStream_t s, uint64_t* bump = nullptr);
+
+// ---- plain Linear/ReLU stacks on the generic grouped GEMM (intr.hip); shared by the intrinsic modules and the pixel agent
+struct Lin { int in, out; int64_t W, b; };           // offsets into a flat parameter buffer, torch layout W[out][in]
+struct Mlp {                                         // Linear-ReLU-...-Linear; the last layer's output is raw unless relu_last
+    std::vector<Lin> L;
+    bool relu_last = false;
+    std::vector<float*> act, dact;                   // per layer: (rows, out) activations and their gradients
+};
+int mlp_forward(const Mlp& m, const float* P, const float* x, int64_t ldx, int rows, int prec, hipStream_t s);
+// dact[last] holds d(loss)/d(output); writes parameter gradients into G and, if dx, d(loss)/d(input) (rows, in0)
+int mlp_backward(const Mlp& m, const float* P, float* G, const float* x, int64_t ldx, int rows, float* dx, int prec, hipStream_t s);
+int launch_concat(const float* a, int64_t lda, int ca, const float* b, int64_t ldb, int cb, float* dst, int rows, hipStream_t s);
 
 // ---- replay (replay.hip) internal entry points used by the agent's graph capture
 // Optional fan-out of the sampled rows into the agent's staged network inputs (what prepare_inputs would do in a second

@@ -1,0 +1,408 @@
+// DDPG on pixel observations: augmentation, conv encoder, the pixel Actor / Critic and their update.
+// Replaces (file:line in the reference repo, agents/unsupervised_learning/ddpg.py):
+//   Actor (obs_type == 'pixels')   :42-76   trunk Linear(repr, feature_dim)+LN+Tanh, policy Linear-ReLU-Linear-ReLU-Linear, tanh
+//   Critic (obs_type == 'pixels')  :79-123  trunk on the encoding, action concatenated AFTER the trunk, Q1/Q2 three-layer heads
+//   aug_and_encode :213-215, update_critic :240-268 (encoder_opt steps with critic_opt), update_actor :270-292, update :298-328, act :221-238
+// Built from the blocks of the other translation units: pixels.hip (RandomShiftsAug, conv encoder forward/backward), the generic
+// grouped GEMM + Linear/ReLU stack helpers (intr.hip), LayerNorm/tanh row kernels (rowops.hip), loss/sampling kernels (loss.hip),
+// Adam/Polyak (optim.hip). The one shape the generic GEMM handles badly is the trunk's Linear(39200, 50): 16 row tiles of a
+// K = 39200 reduction would occupy 16 CUs, so it runs as a 16-way split-K (4 grouped launches) + a fixed-order reduce.
+#include <vector>
+
+#include "kernels.h"
+
+namespace exorl {
+
+struct PTensor { int64_t off, rows, cols; };
+struct PNet {                       // trunk Linear(D, F) + LayerNorm(F) + Tanh, then n_heads three-layer heads on F (+A)
+    int D = 0, F = 0, H = 0, head_in = 0, out = 0, n_heads = 0;
+    Lin trunk{};
+    int64_t g = 0, beta = 0;
+    Mlp head[2];
+    int64_t total = 0;
+    std::vector<PTensor> tensors;
+};
+
+static PNet make_pnet(int D, int F, int H, int head_in, int out, int n_heads) {
+    PNet n;
+    n.D = D; n.F = F; n.H = H; n.head_in = head_in; n.out = out; n.n_heads = n_heads;
+    int64_t off = 0;
+    auto add = [&](int64_t r, int64_t c) { const int64_t o = off; n.tensors.push_back({o, r, c}); off += round_up(r * c, 4); return o; };
+    auto lin = [&](int in, int o2) { Lin l{in, o2, 0, 0}; l.W = add(o2, in); l.b = add(o2, 1); return l; };
+    n.trunk = lin(D, F);
+    n.g = add(F, 1); n.beta = add(F, 1);
+    for (int i = 0; i < n_heads; ++i) n.head[i].L = {lin(head_in, H), lin(H, H), lin(H, out)};
+    n.total = round_up(off, 64);
+    return n;
+}
+
+constexpr int SPLITK = 16;
+
+// z[m][f] = bias[f] + sum_s P[s][m][f]
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ P, const float* __restrict__ bias, float* __restrict__ z,
+                                                            int64_t n, int F, int splits) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float acc = bias[i % F];
+        for (int s = 0; s < splits; ++s) acc += P[(int64_t)s * n + i];
+        z[i] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void tanh_kernel(float* __restrict__ x, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] = tanhf(x[i]);
+}
+// dst[m][j] = a[m*lda + c0 + j] + b[m*ldb + c0 + j]
+__global__ __launch_bounds__(256) void add_cols_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b, int64_t ldb, int c0,
+                                                       int nc, float* __restrict__ dst, int rows) {
+    const int64_t n = (int64_t)rows * nc;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / nc;
+        const int j = (int)(i - m * nc);
+        dst[i] = a[m * lda + c0 + j] + b[m * ldb + c0 + j];
+    }
+}
+// straight-through sample (utils.py:135-138) then tanh: dpre = da * (1 - mu^2)
+__global__ __launch_bounds__(256) void dpre_kernel(const float* __restrict__ da, const float* __restrict__ mu, float* __restrict__ dpre, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dpre[i] = da[i] * (1.0f - mu[i] * mu[i]);
+}
+
+static int grid1(int64_t n) { const int64_t b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
+
+}  // namespace exorl
+
+using namespace exorl;
+
+struct TrunkAct { float *z, *h, *xhat, *rstd; };
+
+struct exorl_pixel_agent {
+    exorl_pixel_cfg cfg;
+    int R = 0;                                   // repr_dim
+    PNet actor, critic;
+    int64_t enc_total = 0;
+    float* ws = nullptr;
+    // flat[net][what]; nets: 0 encoder, 1 actor, 2 critic, 3 critic_target (params only)
+    float* flat[4][4] = {{nullptr}};
+    unsigned char *obs = nullptr, *next_obs = nullptr;
+    float *action = nullptr, *reward = nullptr, *discount = nullptr;
+    float *aug_o = nullptr, *aug_n = nullptr, *enc_ws_o = nullptr, *enc_ws_n = nullptr, *feat_o = nullptr, *feat_n = nullptr;
+    float* splitk = nullptr;
+    TrunkAct ta_n{}, ta_o{}, tt{}, tc{};         // actor on next_obs / obs, target critic, critic
+    float *xq_t = nullptr, *xq_c = nullptr, *dxq[2] = {nullptr, nullptr};
+    float *q = nullptr, *tq = nullptr, *dq = nullptr, *mu_n = nullptr, *mu_o = nullptr, *dmu = nullptr, *dh = nullptr, *dz = nullptr, *dfeat = nullptr;
+    float *stats = nullptr, *metrics = nullptr;
+    int32_t* shifts = nullptr;
+    float* act_ws = nullptr;                     // B = 1 inference scratch
+    int64_t t = 0;
+    uint64_t noise_counter = 0, aug_counter = 0, act_counter = 0;
+};
+
+namespace exorl {
+
+struct PCarver {
+    float* base; int64_t off = 0;
+    explicit PCarver(float* b) : base(b) {}
+    float* take(int64_t n) { float* p = base ? base + off : nullptr; off += round_up(n, 64); return p; }
+};
+
+static void take_mlp(Mlp& m, PCarver& c, int64_t rows, float* last_act, float* last_dact) {
+    m.act.clear(); m.dact.clear();
+    for (size_t l = 0; l < m.L.size(); ++l) {
+        const bool last = l + 1 == m.L.size();
+        m.act.push_back(last && last_act ? last_act : c.take(rows * m.L[l].out));
+        m.dact.push_back(last && last_dact ? last_dact : c.take(rows * m.L[l].out));
+    }
+}
+
+static void pcarve(exorl_pixel_agent* a, PCarver& c) {
+    const auto& g = a->cfg;
+    const int64_t B = g.batch, A = g.act_dim, F = g.feature_dim, R = a->R, img = (int64_t)g.c_in * g.hw * g.hw;
+    a->flat[0][0] = c.take(a->enc_total);
+    for (int w = 1; w < 4; ++w) a->flat[0][w] = c.take(a->enc_total);
+    for (int w = 0; w < 4; ++w) a->flat[1][w] = c.take(a->actor.total);
+    for (int w = 0; w < 4; ++w) a->flat[2][w] = c.take(a->critic.total);
+    a->flat[3][0] = c.take(a->critic.total);
+    a->obs = reinterpret_cast<unsigned char*>(c.take((B * img + 3) / 4));
+    a->next_obs = reinterpret_cast<unsigned char*>(c.take((B * img + 3) / 4));
+    a->action = c.take(B * A); a->reward = c.take(B); a->discount = c.take(B);
+    a->aug_o = c.take(B * img); a->aug_n = c.take(B * img);
+    const int64_t ews = exorl_encoder_workspace_floats((int32_t)B, g.c_in, g.hw);
+    a->enc_ws_o = c.take(ews); a->enc_ws_n = c.take(ews);
+    a->splitk = c.take((int64_t)SPLITK * B * F);
+    for (TrunkAct* t : {&a->ta_n, &a->ta_o, &a->tt, &a->tc}) { t->z = c.take(B * F); t->h = c.take(B * F); t->xhat = c.take(B * F); t->rstd = c.take(B); }
+    a->xq_t = c.take(B * (F + A)); a->xq_c = c.take(B * (F + A));
+    a->dxq[0] = c.take(B * (F + A)); a->dxq[1] = c.take(B * (F + A));
+    a->q = c.take(2 * B); a->tq = c.take(2 * B); a->dq = c.take(2 * B);
+    a->mu_n = c.take(B * A); a->mu_o = c.take(B * A); a->dmu = c.take(B * A);
+    a->dh = c.take(B * F); a->dz = c.take(B * F); a->dfeat = c.take(B * R);
+    a->stats = c.take(4 + EXORL_N_METRICS);
+    a->metrics = a->stats ? a->stats + 4 : nullptr;
+    a->shifts = reinterpret_cast<int32_t*>(c.take(4 * B));
+    // actor policy: outputs land in mu_* (policy on next_obs shares the Mlp buffers: it is consumed before the obs pass runs)
+    take_mlp(a->actor.head[0], c, B, nullptr, nullptr);
+    // critic heads: outputs are the halves of q (B each); gradients at the outputs are the halves of dq
+    for (int i = 0; i < 2; ++i) take_mlp(a->critic.head[i], c, B, a->q ? a->q + i * B : nullptr, a->dq ? a->dq + i * B : nullptr);
+    a->act_ws = c.take(exorl_encoder_workspace_floats(1, g.c_in, g.hw) + img + 4 * F + 2 * 1024 + 64);
+}
+
+// z = x W0^T + b0 (split-K), then LayerNorm + tanh
+static int trunk_forward(exorl_pixel_agent* a, const PNet& n, const float* P, const float* x, int rows, const TrunkAct& t, int prec, hipStream_t s) {
+    const int D = n.D, F = n.F;
+    int kc = (int)round_up(cdiv(D, SPLITK), 4);
+    for (int s0 = 0; s0 < SPLITK; s0 += 4) {
+        GemmProblem p[4];
+        int cnt = 0;
+        for (int i = 0; i < 4; ++i) {
+            const int k0 = (s0 + i) * kc;
+            if (k0 >= D) break;
+            const int k = D - k0 < kc ? D - k0 : kc;
+            p[cnt++] = GemmProblem{x + k0, P + n.trunk.W + k0, a->splitk + (int64_t)(s0 + i) * rows * F, nullptr, rows, F, k, D, D, F};
+        }
+        if (cnt) EXORL_TRY(gemm_grouped(prec, 0, 0, p, cnt, false, false, s));
+    }
+    const int splits = cdiv(D, kc);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid1((int64_t)rows * F)), dim3(256), 0, s, a->splitk, P + n.trunk.b, t.z, (int64_t)rows * F, F, splits);
+    EXORL_LAUNCH_CHECK();
+    return ln_tanh_fwd(t.z, P + n.g, P + n.beta, t.h, t.xhat, t.rstd, rows, F, 1, 0, 0, s);
+}
+
+// dh (rows, F) at the trunk output -> parameter grads (W0, b0, gain, beta) and optionally d/d(input) (rows, D)
+static int trunk_backward(exorl_pixel_agent* a, const PNet& n, const float* P, float* G, const float* x, int rows, const TrunkAct& t, const float* dh,
+                          float* dx, int prec, hipStream_t s) {
+    const int D = n.D, F = n.F;
+    EXORL_TRY(ln_param_grad(dh, t.h, t.xhat, G + n.g, G + n.beta, rows, F, 1, 0, 0, s));
+    EXORL_TRY(ln_tanh_bwd(dh, t.h, t.xhat, t.rstd, P + n.g, a->dz, rows, F, 1, 0, 0, s));
+    EXORL_TRY(colsum(a->dz, G + n.trunk.b, rows, F, 1, 0, 0, s));
+    GemmProblem w{a->dz, x, G + n.trunk.W, nullptr, F, D, rows, F, D, D};
+    EXORL_TRY(gemm_grouped(prec, 1, 1, &w, 1, false, false, s));
+    if (dx) {
+        GemmProblem g{a->dz, P + n.trunk.W, dx, nullptr, rows, D, F, F, D, D};
+        EXORL_TRY(gemm_grouped(prec, 0, 1, &g, 1, false, false, s));
+    }
+    return 0;
+}
+
+static int padam(exorl_pixel_agent* a, int net, int64_t n, float* target, hipStream_t s) {
+    return adam_step(a->flat[net][0], a->flat[net][1], a->flat[net][2], a->flat[net][3], n, a->cfg.lr, 0.9f, 0.999f, 1e-8f, a->t, target,
+                     target ? a->cfg.tau : 0.f, s);
+}
+
+}  // namespace exorl
+
+extern "C" {
+
+static int check_pcfg(const exorl_pixel_cfg* c) {
+    EXORL_REQUIRE(c, "pixel_agent: null cfg");
+    EXORL_REQUIRE(c->c_in >= 1 && c->c_in <= 16 && (c->hw == 84 || c->hw == 64), "pixel_agent: obs_shape (%d, %d, %d) unsupported (84x84 or 64x64, <= 16 channels)",
+                  c->c_in, c->hw, c->hw);
+    EXORL_REQUIRE(c->act_dim >= 1 && c->act_dim <= 64 && c->feature_dim >= 1 && c->feature_dim <= 1024 && c->hidden_dim >= 1 && c->batch >= 1,
+                  "pixel_agent: unsupported dims A=%d feature_dim=%d H=%d B=%d", c->act_dim, c->feature_dim, c->hidden_dim, c->batch);
+    EXORL_REQUIRE(c->precision == EXORL_PREC_F32 || c->precision == EXORL_PREC_BF16, "pixel_agent: unknown precision %d", c->precision);
+    return 0;
+}
+
+static void pdescribe(exorl_pixel_agent* a) {
+    const auto& c = a->cfg;
+    a->R = (int)exorl_encoder_out_dim(c.hw);
+    a->enc_total = exorl_encoder_param_floats(c.c_in, c.hw);
+    a->actor = make_pnet(a->R, c.feature_dim, c.hidden_dim, c.feature_dim, c.act_dim, 1);
+    a->critic = make_pnet(a->R, c.feature_dim, c.hidden_dim, c.feature_dim + c.act_dim, 1, 2);
+}
+
+size_t exorl_pixel_agent_workspace_bytes(const exorl_pixel_cfg* cfg) {
+    if (check_pcfg(cfg) != 0) return 0;
+    exorl_pixel_agent tmp;
+    tmp.cfg = *cfg;
+    pdescribe(&tmp);
+    PCarver c(nullptr);
+    pcarve(&tmp, c);
+    return (size_t)c.off * sizeof(float);
+}
+
+int exorl_pixel_agent_create(const exorl_pixel_cfg* cfg, void* workspace, size_t workspace_bytes, exorl_pixel_agent_t** out) {
+    EXORL_REQUIRE(out && workspace, "pixel_agent_create: null argument (the workspace is caller-owned)");
+    EXORL_TRY(check_pcfg(cfg));
+    const size_t bytes = exorl_pixel_agent_workspace_bytes(cfg);
+    EXORL_REQUIRE(workspace_bytes >= bytes && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "pixel_agent_create: workspace of %zu bytes (need %zu, 256-byte aligned)",
+                  workspace_bytes, bytes);
+    auto* a = new exorl_pixel_agent();
+    a->cfg = *cfg;
+    pdescribe(a);
+    a->ws = static_cast<float*>(workspace);
+    PCarver c(a->ws);
+    pcarve(a, c);
+    if (hipMemset(a->ws, 0, bytes) != hipSuccess) { set_error("pixel_agent_create: hipMemset failed"); delete a; return 1; }
+    *out = a;
+    return 0;
+}
+
+int exorl_pixel_agent_destroy(exorl_pixel_agent_t* a) {
+    if (!a) return 0;
+    (void)hipDeviceSynchronize();
+    delete a;
+    return 0;
+}
+
+// nets: 0 encoder (convnet.{0,2,4,6}.{weight,bias}; weights reported as (32, ci*9)), 1 actor, 2 critic, 3 critic_target
+int exorl_pixel_agent_num_tensors(exorl_pixel_agent_t* a, int32_t net, int32_t* n) {
+    EXORL_REQUIRE(a && n && net >= 0 && net <= 3, "pixel_agent_num_tensors: bad arguments");
+    *n = net == 0 ? 8 : (int32_t)(net == 1 ? a->actor.tensors.size() : a->critic.tensors.size());
+    return 0;
+}
+
+int exorl_pixel_agent_tensor(exorl_pixel_agent_t* a, int32_t net, int32_t index, int32_t what, void** ptr, int64_t* rows, int64_t* cols) {
+    EXORL_REQUIRE(a && ptr && rows && cols && net >= 0 && net <= 3 && what >= 0 && what <= 3 && (net != 3 || what == 0), "pixel_agent_tensor: bad arguments");
+    if (net == 0) {
+        EXORL_REQUIRE(index >= 0 && index < 8, "pixel_agent_tensor: encoder tensor %d out of range", index);
+        int64_t off = 0;
+        for (int l = 0; l < 4; ++l) {
+            const int64_t ci = l == 0 ? a->cfg.c_in : 32;
+            if (index == 2 * l) { *ptr = a->flat[0][what] + off; *rows = 32; *cols = ci * 9; return 0; }
+            off += round_up(32 * ci * 9, 4);
+            if (index == 2 * l + 1) { *ptr = a->flat[0][what] + off; *rows = 32; *cols = 1; return 0; }
+            off += 32;
+        }
+    }
+    const PNet& n = net == 1 ? a->actor : a->critic;
+    EXORL_REQUIRE(index >= 0 && index < (int32_t)n.tensors.size(), "pixel_agent_tensor: index %d out of range", index);
+    *ptr = a->flat[net][what] + n.tensors[index].off; *rows = n.tensors[index].rows; *cols = n.tensors[index].cols;
+    return 0;
+}
+
+int exorl_pixel_agent_sync_target(exorl_pixel_agent_t* a, void* stream) {
+    EXORL_REQUIRE(a, "pixel_agent_sync_target: null handle");
+    EXORL_CHECK_HIP(hipMemcpyAsync(a->flat[3][0], a->flat[2][0], a->critic.total * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)));
+    return 0;
+}
+
+int exorl_pixel_agent_set_batch(exorl_pixel_agent_t* a, const unsigned char* obs, const float* action, const float* reward, const float* discount,
+                                const unsigned char* next_obs, void* stream) {
+    EXORL_REQUIRE(a && obs && action && reward && discount && next_obs, "pixel_agent_set_batch: null argument");
+    hipStream_t s = as_stream(stream);
+    const size_t B = a->cfg.batch, img = (size_t)a->cfg.c_in * a->cfg.hw * a->cfg.hw;
+    EXORL_CHECK_HIP(hipMemcpyAsync(a->obs, obs, B * img, hipMemcpyDeviceToDevice, s));
+    EXORL_CHECK_HIP(hipMemcpyAsync(a->next_obs, next_obs, B * img, hipMemcpyDeviceToDevice, s));
+    EXORL_CHECK_HIP(hipMemcpyAsync(a->action, action, B * a->cfg.act_dim * 4, hipMemcpyDeviceToDevice, s));
+    EXORL_CHECK_HIP(hipMemcpyAsync(a->reward, reward, B * 4, hipMemcpyDeviceToDevice, s));
+    EXORL_CHECK_HIP(hipMemcpyAsync(a->discount, discount, B * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int exorl_pixel_agent_batch_slots(exorl_pixel_agent_t* a, exorl_batch_out* out) {
+    EXORL_REQUIRE(a && out, "pixel_agent_batch_slots: null argument");
+    const int64_t img = (int64_t)a->cfg.c_in * a->cfg.hw * a->cfg.hw;
+    out->obs = a->obs; out->obs_stride = img;
+    out->action = a->action; out->action_stride = a->cfg.act_dim;
+    out->reward = a->reward; out->discount = a->discount;
+    out->next_obs = a->next_obs; out->next_obs_stride = img;
+    out->meta = nullptr; out->meta_stride = 0;
+    return 0;
+}
+
+// One DDPG update on the batch in the slots. shifts_*: (B,2) int32 augmentation shifts (utils.py:244-248) or null -> Philox;
+// noise_*: (B,A) standard normals for the two TruncatedNormal draws (critic target first, actor second) or null -> Philox.
+int exorl_pixel_agent_update(exorl_pixel_agent_t* a, float stddev, const int32_t* shifts_obs, const int32_t* shifts_next, const float* noise_c,
+                             const float* noise_a, void* stream) {
+    EXORL_REQUIRE(a && stddev > 0.f, "pixel_agent_update: bad arguments");
+    hipStream_t s = as_stream(stream);
+    const auto& c = a->cfg;
+    const int B = c.batch, A = c.act_dim, F = c.feature_dim, R = a->R, FA = F + A, prec = c.precision;
+    const float inv_b = 1.0f / (float)B;
+    float *Pe = a->flat[0][0], *Pa = a->flat[1][0], *Pc = a->flat[2][0], *Pt = a->flat[3][0];
+    float *Ge = a->flat[0][1], *Ga = a->flat[1][1], *Gc = a->flat[2][1];
+    a->t += 1;
+    // ---- aug_and_encode (ddpg.py:213-215, 312-315)
+    EXORL_TRY(exorl_aug_shift(a->obs, B, c.c_in, c.hw, 4, shifts_obs, c.seed, 2 * a->aug_counter, a->aug_o, s));
+    EXORL_TRY(exorl_aug_shift(a->next_obs, B, c.c_in, c.hw, 4, shifts_next, c.seed, 2 * a->aug_counter + 1, a->aug_n, s));
+    a->aug_counter += 1;
+    EXORL_TRY(exorl_encoder_forward(Pe, c.c_in, c.hw, a->aug_o, B, a->enc_ws_o, &a->feat_o, s));
+    EXORL_TRY(exorl_encoder_forward(Pe, c.c_in, c.hw, a->aug_n, B, a->enc_ws_n, &a->feat_n, s));
+    // ---- update_critic (ddpg.py:240-268)
+    EXORL_TRY(trunk_forward(a, a->actor, Pa, a->feat_n, B, a->ta_n, prec, s));
+    Mlp& pol = a->actor.head[0];
+    EXORL_TRY(mlp_forward(pol, Pa, a->ta_n.h, F, B, prec, s));
+    EXORL_CHECK_HIP(hipMemcpyAsync(a->mu_n, pol.act[2], sizeof(float) * B * A, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(tanh_kernel, dim3(grid1((int64_t)B * A)), dim3(256), 0, s, a->mu_n, (int64_t)B * A);
+    EXORL_LAUNCH_CHECK();
+    EXORL_TRY(trunk_forward(a, a->critic, Pt, a->feat_n, B, a->tt, prec, s));
+    EXORL_TRY(launch_concat(a->tt.h, F, F, a->mu_n, A, A, a->xq_t, B, s));           // action columns overwritten by the sample below
+    NoiseSpec nc{noise_c, c.seed, 2 * a->noise_counter, nullptr};
+    EXORL_TRY(sample_action(a->mu_n, nc, stddev, c.stddev_clip, 1, a->xq_t + F, FA, B, A, nullptr, s));
+    // the target's Q heads reuse the critic's Mlp buffers (outputs to q), then are copied to tq
+    for (int i = 0; i < 2; ++i) EXORL_TRY(mlp_forward(a->critic.head[i], Pt, a->xq_t, FA, B, prec, s));
+    EXORL_CHECK_HIP(hipMemcpyAsync(a->tq, a->q, sizeof(float) * 2 * B, hipMemcpyDeviceToDevice, s));
+    EXORL_TRY(trunk_forward(a, a->critic, Pc, a->feat_o, B, a->tc, prec, s));
+    EXORL_TRY(launch_concat(a->tc.h, F, F, a->action, A, A, a->xq_c, B, s));
+    for (int i = 0; i < 2; ++i) EXORL_TRY(mlp_forward(a->critic.head[i], Pc, a->xq_c, FA, B, prec, s));
+    EXORL_TRY(critic_loss(a->q, a->tq, a->reward, a->discount, a->dq, a->metrics, B, inv_b, s));
+    for (int i = 0; i < 2; ++i) EXORL_TRY(mlp_backward(a->critic.head[i], Pc, Gc, a->xq_c, FA, B, a->dxq[i], prec, s));
+    hipLaunchKernelGGL(add_cols_kernel, dim3(grid1((int64_t)B * F)), dim3(256), 0, s, a->dxq[0], (int64_t)FA, a->dxq[1], (int64_t)FA, 0, F, a->dh, B);
+    EXORL_LAUNCH_CHECK();
+    EXORL_TRY(trunk_backward(a, a->critic, Pc, Gc, a->feat_o, B, a->tc, a->dh, a->dfeat, prec, s));
+    EXORL_TRY(exorl_encoder_backward(Pe, c.c_in, c.hw, a->aug_o, B, a->enc_ws_o, a->dfeat, Ge, s));
+    EXORL_TRY(padam(a, 2, a->critic.total, nullptr, s));
+    EXORL_TRY(padam(a, 0, a->enc_total, nullptr, s));
+    // ---- update_actor (ddpg.py:270-292) on obs.detach(): the encoding computed above, the critic just updated
+    EXORL_TRY(trunk_forward(a, a->actor, Pa, a->feat_o, B, a->ta_o, prec, s));
+    EXORL_TRY(mlp_forward(pol, Pa, a->ta_o.h, F, B, prec, s));
+    EXORL_CHECK_HIP(hipMemcpyAsync(a->mu_o, pol.act[2], sizeof(float) * B * A, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(tanh_kernel, dim3(grid1((int64_t)B * A)), dim3(256), 0, s, a->mu_o, (int64_t)B * A);
+    EXORL_LAUNCH_CHECK();
+    EXORL_TRY(trunk_forward(a, a->critic, Pc, a->feat_o, B, a->tc, prec, s));
+    EXORL_TRY(launch_concat(a->tc.h, F, F, a->mu_o, A, A, a->xq_c, B, s));
+    NoiseSpec na{noise_a, c.seed, 2 * a->noise_counter + 1, nullptr};
+    EXORL_TRY(sample_action(a->mu_o, na, stddev, c.stddev_clip, 1, a->xq_c + F, FA, B, A, a->metrics + EXORL_M_ACTOR_LOGPROB, s));
+    a->noise_counter += 1;
+    for (int i = 0; i < 2; ++i) EXORL_TRY(mlp_forward(a->critic.head[i], Pc, a->xq_c, FA, B, prec, s));
+    EXORL_TRY(actor_stats(a->q, a->stats, B, s));
+    EXORL_TRY(actor_dq(a->q, a->stats, a->dq, B, inv_b, 0.f, 0, s));
+    for (int i = 0; i < 2; ++i) EXORL_TRY(mlp_backward(a->critic.head[i], Pc, Gc, a->xq_c, FA, B, a->dxq[i], prec, s));     // Gc: scratch now
+    hipLaunchKernelGGL(add_cols_kernel, dim3(grid1((int64_t)B * A)), dim3(256), 0, s, a->dxq[0], (int64_t)FA, a->dxq[1], (int64_t)FA, F, A, a->dmu, B);
+    hipLaunchKernelGGL(dpre_kernel, dim3(grid1((int64_t)B * A)), dim3(256), 0, s, a->dmu, a->mu_o, pol.dact[2], (int64_t)B * A);
+    EXORL_LAUNCH_CHECK();
+    EXORL_TRY(mlp_backward(pol, Pa, Ga, a->ta_o.h, F, B, a->dh, prec, s));
+    EXORL_TRY(trunk_backward(a, a->actor, Pa, Ga, a->feat_o, B, a->ta_o, a->dh, nullptr, prec, s));
+    EXORL_TRY(padam(a, 1, a->actor.total, nullptr, s));
+    // ---- soft update (ddpg.py:326-327)
+    return soft_update(Pc, Pt, a->critic.total, c.tau, s);
+}
+
+// actor_loss = -mean(min Q) is stats[1] / B (actor_stats); the rest comes from critic_loss / sample_action
+int exorl_pixel_agent_metrics(exorl_pixel_agent_t* a, float* host, void* stream) {
+    EXORL_REQUIRE(a && host, "pixel_agent_metrics: null argument");
+    float buf[4 + EXORL_N_METRICS];
+    EXORL_CHECK_HIP(hipMemcpyAsync(buf, a->stats, sizeof(buf), hipMemcpyDeviceToHost, as_stream(stream)));
+    EXORL_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
+    for (int i = 0; i < EXORL_N_METRICS; ++i) host[i] = buf[4 + i];
+    host[EXORL_M_ACTOR_LOSS] = -buf[1] / (float)a->cfg.batch;
+    return 0;
+}
+
+// act (ddpg.py:221-238) for one uint8 image (no augmentation): mean action (eval) or TruncatedNormal sample without clip
+int exorl_pixel_agent_act(exorl_pixel_agent_t* a, const unsigned char* obs_dev, float stddev, int32_t eval_mode, const float* noise_dev,
+                          float* action_out_dev, void* stream) {
+    EXORL_REQUIRE(a && obs_dev && action_out_dev, "pixel_agent_act: null argument");
+    hipStream_t s = as_stream(stream);
+    const auto& c = a->cfg;
+    const int A = c.act_dim, F = c.feature_dim, prec = c.precision;
+    const int64_t img = (int64_t)c.c_in * c.hw * c.hw;
+    float* ws = a->act_ws;
+    float* x = ws; ws += round_up(img, 64);
+    float* ews = ws;
+    EXORL_TRY(exorl_u8_to_f32(obs_dev, img, x, s));           // act() sees the raw frame: no augmentation (ddpg.py:223-224)
+    float* feat = nullptr;
+    EXORL_TRY(exorl_encoder_forward(a->flat[0][0], c.c_in, c.hw, x, 1, ews, &feat, s));
+    // B = 1 reuses the batch-sized trunk / policy buffers (act() is never called inside update())
+    EXORL_TRY(trunk_forward(a, a->actor, a->flat[1][0], feat, 1, a->ta_n, prec, s));
+    Mlp& pol = a->actor.head[0];
+    EXORL_TRY(mlp_forward(pol, a->flat[1][0], a->ta_n.h, F, 1, prec, s));
+    EXORL_CHECK_HIP(hipMemcpyAsync(a->mu_n, pol.act[2], sizeof(float) * A, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(tanh_kernel, dim3(1), dim3(256), 0, s, a->mu_n, (int64_t)A);
+    EXORL_LAUNCH_CHECK();
+    if (eval_mode) {
+        EXORL_CHECK_HIP(hipMemcpyAsync(action_out_dev, a->mu_n, sizeof(float) * A, hipMemcpyDeviceToDevice, s));
+        return 0;
+    }
+    NoiseSpec nz{noise_dev, c.seed, (1ull << 63) | a->act_counter++, nullptr};
+    return sample_action(a->mu_n, nz, stddev, 0.f, 0, action_out_dev, A, 1, A, nullptr, s);
+}
+
+}  // extern "C"

@@ -236,6 +236,17 @@ int exorl_aug_shift(const unsigned char* x_dev, int32_t n, int32_t c, int32_t h,
     return 0;
 }
 
+__global__ __launch_bounds__(256) void u8_to_f32_kernel(const unsigned char* __restrict__ x, float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (float)x[i];
+}
+int exorl_u8_to_f32(const unsigned char* x_dev, int64_t n, float* out_dev, void* stream) {
+    EXORL_REQUIRE(x_dev && out_dev && n > 0, "u8_to_f32: bad arguments");
+    const int64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(u8_to_f32_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, as_stream(stream), x_dev, out_dev, n);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
 int64_t exorl_encoder_param_floats(int32_t c_in, int32_t hw) { return enc_geom(c_in, hw).total; }
 int64_t exorl_encoder_out_dim(int32_t hw) { const EncGeom g = enc_geom(3, hw); return (int64_t)CONV_CO * g.edge[4] * g.edge[4]; }
 

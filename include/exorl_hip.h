@@ -364,6 +364,43 @@ int exorl_encoder_forward(const float* params_dev, int32_t c_in, int32_t hw, con
  * grads_dev (flat layout of the parameters). */
 int exorl_encoder_backward(const float* params_dev, int32_t c_in, int32_t hw, const float* x_dev, int32_t n, float* ws_dev, float* dh_dev,
                            float* grads_dev, void* stream);
+int exorl_u8_to_f32(const unsigned char* x_dev, int64_t n, float* out_dev, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * DDPG on pixel observations (agents/unsupervised_learning/ddpg.py with obs_type == 'pixels'): augmentation + encoder +
+ * pixel Actor (:42-76) / Critic (:79-123) and update (:240-328; the encoder steps with the critic's loss). meta_dim = 0.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct exorl_pixel_cfg {
+    int32_t c_in, hw;          /* obs_shape = (c_in, hw, hw), hw in {84, 64}, uint8 */
+    int32_t act_dim, feature_dim, hidden_dim, batch;
+    int32_t precision;         /* EXORL_PREC_* for the Linear layers' GEMMs; the convolutions are fp32 */
+    int32_t reserved;
+    float lr, tau, stddev_clip, reserved2;
+    uint64_t seed;
+} exorl_pixel_cfg;
+typedef struct exorl_pixel_agent exorl_pixel_agent_t;
+#define EXORL_PNET_ENCODER 0
+#define EXORL_PNET_ACTOR   1
+#define EXORL_PNET_CRITIC  2
+#define EXORL_PNET_CRITIC_TARGET 3
+size_t exorl_pixel_agent_workspace_bytes(const exorl_pixel_cfg* cfg);
+int exorl_pixel_agent_create(const exorl_pixel_cfg* cfg, void* workspace_dev, size_t workspace_bytes, exorl_pixel_agent_t** out);
+int exorl_pixel_agent_destroy(exorl_pixel_agent_t* a);
+/* tensors in parameters() order: encoder convnet.{0,2,4,6}.{weight,bias} (weights as (32, ci*9)); actor trunk.0, trunk.1,
+ * policy.{0,2,4}; critic trunk.0, trunk.1, Q1.{0,2,4}, Q2.{0,2,4}. what = EXORL_T_*; the target has parameters only. */
+int exorl_pixel_agent_num_tensors(exorl_pixel_agent_t* a, int32_t net, int32_t* n);
+int exorl_pixel_agent_tensor(exorl_pixel_agent_t* a, int32_t net, int32_t index, int32_t what, void** ptr_dev, int64_t* rows, int64_t* cols);
+int exorl_pixel_agent_sync_target(exorl_pixel_agent_t* a, void* stream);       /* critic_target.load_state_dict(critic.state_dict()) */
+int exorl_pixel_agent_batch_slots(exorl_pixel_agent_t* a, exorl_batch_out* out);   /* uint8 obs / next_obs rows for the HBM sampler */
+int exorl_pixel_agent_set_batch(exorl_pixel_agent_t* a, const unsigned char* obs_dev, const float* action_dev, const float* reward_dev,
+                                const float* discount_dev, const unsigned char* next_obs_dev, void* stream);
+/* One update() on the batch in the slots. shifts_*: (batch, 2) int32 RandomShiftsAug draws for obs / next_obs or null -> Philox;
+ * noise_*: (batch, act_dim) standard normals for the TruncatedNormal draws (critic target first, actor second) or null. */
+int exorl_pixel_agent_update(exorl_pixel_agent_t* a, float stddev, const int32_t* shifts_obs_dev, const int32_t* shifts_next_dev,
+                             const float* noise_critic_dev, const float* noise_actor_dev, void* stream);
+int exorl_pixel_agent_metrics(exorl_pixel_agent_t* a, float* host_out /* EXORL_N_METRICS */, void* stream);
+int exorl_pixel_agent_act(exorl_pixel_agent_t* a, const unsigned char* obs_dev, float stddev, int32_t eval_mode, const float* noise_dev,
+                          float* action_out_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -119,3 +119,100 @@ def encoder_bwd(p, cache, dh, need_dx=False):
     if need_dx:
         dx = (d / F32(255.0)).astype(F32)
     return grads, dx
+
+
+# ---------------------------------------------------------------------------------------------------
+# DDPG on pixels (agents/unsupervised_learning/ddpg.py, obs_type == 'pixels')
+# ---------------------------------------------------------------------------------------------------
+ENC_KEYS = [f'convnet.{i}.{w}' for i in (0, 2, 4, 6) for w in ('weight', 'bias')]
+PIX_ACTOR_KEYS = ['trunk.0.weight', 'trunk.0.bias', 'trunk.1.weight', 'trunk.1.bias'] + [f'policy.{i}.{w}' for i in (0, 2, 4) for w in ('weight', 'bias')]
+PIX_CRITIC_KEYS = (['trunk.0.weight', 'trunk.0.bias', 'trunk.1.weight', 'trunk.1.bias'] +
+                   [f'{q}.{i}.{w}' for q in ('Q1', 'Q2') for i in (0, 2, 4) for w in ('weight', 'bias')])
+
+
+def pixel_param_shapes(c_in, A, F, H, R=39200):
+    enc = []
+    for l in range(4):
+        enc += [(32, c_in if l == 0 else 32, 3, 3), (32,)]
+    tr = [(F, R), (F,), (F,), (F,)]
+    actor = tr + [(H, F), (H,), (H, H), (H,), (A, H), (A,)]
+    q = [(H, F + A), (H,), (H, H), (H,), (1, H), (1,)]
+    return list(zip(ENC_KEYS, enc)), list(zip(PIX_ACTOR_KEYS, actor)), list(zip(PIX_CRITIC_KEYS, tr + q + q))
+
+
+class OraclePixelDDPG:
+    """ddpg.py:126-328 with obs_type='pixels', meta_dim=0: aug_and_encode, update_critic (the encoder steps on the critic loss),
+    update_actor on the detached encoding, soft update."""
+
+    def __init__(self, enc, actor, critic, lr=1e-4, tau=0.01, stddev=0.2, clip=0.3, update_every_steps=2):
+        from . import nets
+        from .intr import mlp_bwd, mlp_fwd
+        self.nets, self.mlp_fwd, self.mlp_bwd = nets, mlp_fwd, mlp_bwd
+        self.enc = [np.array(p, F32) for p in enc]
+        self.actor = [np.array(p, F32) for p in actor]
+        self.critic = [np.array(p, F32) for p in critic]
+        self.critic_target = [p.copy() for p in self.critic]
+        self.enc_opt, self.actor_opt, self.critic_opt = nets.Adam(self.enc, lr), nets.Adam(self.actor, lr), nets.Adam(self.critic, lr)
+        self.tau, self.std, self.clip, self.every = tau, stddev, clip, update_every_steps
+
+    def _actor(self, feat):
+        h, c1 = self.nets.Trunk.fwd(self.actor[0:4], feat)
+        pre, acts = self.mlp_fwd(self.actor[4:10], h)
+        return np.tanh(pre).astype(F32), (c1, acts)
+
+    def _critic(self, p, feat, action):
+        h, c1 = self.nets.Trunk.fwd(p[0:4], feat)
+        x = np.concatenate([h, action], 1)
+        q1, a1 = self.mlp_fwd(p[4:10], x)
+        q2, a2 = self.mlp_fwd(p[10:16], x)
+        return q1, q2, (c1, a1, a2)
+
+    def _critic_bwd(self, p, cache, dq1, dq2, need_dfeat):
+        c1, a1, a2 = cache
+        F = p[0].shape[0]
+        g1, dx1 = self.mlp_bwd(p[4:10], a1, dq1, need_dx=True)
+        g2, dx2 = self.mlp_bwd(p[10:16], a2, dq2, need_dx=True)
+        dx = (dx1 + dx2).astype(F32)
+        gt, dfeat = self.nets.Trunk.bwd(p[0:4], c1, dx[:, :F], need_dfeat)
+        return gt + g1 + g2, dfeat, dx[:, F:]
+
+    def update(self, batch, step, shifts_obs, shifts_next, noise_c, noise_a):
+        if step % self.every != 0:
+            return {}
+        obs, action, reward, discount, next_obs = batch[:5]
+        action, reward, discount = [np.asarray(x, F32) for x in (action, reward, discount)]
+        B = obs.shape[0]
+        fo, ecache = encoder_fwd(self.enc, random_shifts_aug(obs, shifts_obs))
+        fn, _ = encoder_fwd(self.enc, random_shifts_aug(next_obs, shifts_next))
+        nets = self.nets
+        # update_critic (ddpg.py:240-268)
+        mu_n, _ = self._actor(fn)
+        na = nets.truncated_normal_sample(mu_n, noise_c, self.std, self.clip)
+        tq1, tq2, _ = self._critic(self.critic_target, fn, na)
+        y = (reward + discount * np.minimum(tq1, tq2)).astype(F32)
+        q1, q2, cc = self._critic(self.critic, fo, action)
+        e1, e2 = (q1 - y).astype(F32), (q2 - y).astype(F32)
+        m = dict(batch_reward=float(reward.mean(dtype=F32)), critic_target_q=float(y.mean(dtype=F32)), critic_q1=float(q1.mean(dtype=F32)),
+                 critic_q2=float(q2.mean(dtype=F32)), critic_loss=float(((e1 * e1).sum(dtype=F32) + (e2 * e2).sum(dtype=F32)) / F32(B)))
+        gc, dfeat, _ = self._critic_bwd(self.critic, cc, (F32(2) * e1 / F32(B)).astype(F32), (F32(2) * e2 / F32(B)).astype(F32), True)
+        ge, _ = encoder_bwd(self.enc, ecache, dfeat)
+        self.last_critic_grads, self.last_enc_grads = gc, ge
+        self.critic_opt.step(self.critic, gc)
+        self.enc_opt.step(self.enc, ge)
+        # update_actor (ddpg.py:270-292) on obs.detach()
+        mu, (c1, acts) = self._actor(fo)
+        a = nets.truncated_normal_sample(mu, noise_a, self.std, self.clip)
+        q1, q2, cc = self._critic(self.critic, fo, a)
+        w1 = np.where(q1 < q2, F32(1), np.where(q1 == q2, F32(0.5), F32(0)))
+        dq = F32(-1.0) / F32(B)
+        _, _, da = self._critic_bwd(self.critic, cc, (dq * w1).astype(F32), (dq * (F32(1) - w1)).astype(F32), False)
+        dpre = (da * (F32(1) - mu * mu)).astype(F32)
+        gp, dh = self.mlp_bwd(self.actor[4:10], acts, dpre, need_dx=True)
+        gt, _ = nets.Trunk.bwd(self.actor[0:4], c1, dh, False)
+        self.last_actor_grads = gt + gp
+        self.actor_opt.step(self.actor, self.last_actor_grads)
+        A = mu.shape[1]
+        m.update(actor_loss=float(-np.minimum(q1, q2).mean(dtype=F32)), actor_ent=float(nets.normal_entropy(self.std) * A),
+                 actor_logprob=float(nets.normal_log_prob(a, mu, self.std).sum(dtype=F32) / F32(B)))
+        nets.soft_update(self.critic, self.critic_target, self.tau)
+        return m

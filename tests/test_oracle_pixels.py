@@ -35,3 +35,28 @@ def test_encoder_forward_backward(gold, tag):
         want = z[f'enc_{tag}_grad/{k}']
         np.testing.assert_allclose(g, want, rtol=2e-4, atol=2e-5 * np.abs(want).max(), err_msg=k)
     np.testing.assert_allclose(dx[0, 0], z[f'enc_{tag}_dx0'], rtol=2e-4, atol=1e-6 * max(1.0, np.abs(z[f'enc_{tag}_dx0']).max()))
+
+
+def test_pixel_ddpg_trajectory(gold):
+    """Oracle DDPG-on-pixels vs 3 update() calls of the reference agent (tests/golden/pixel_ddpg.npz)."""
+    import _synth
+    z = np.load(gold / 'pixel_ddpg.npz')
+    C, HW, A, F, H, B, N = [int(v) for v in z['dims']]
+    esh, ash, csh = pixels.pixel_param_shapes(C, A, F, H)
+    enc = list(_synth.synth_params(esh, 50).values())
+    actor = list(_synth.synth_params(ash, 51).values())
+    critic = list(_synth.synth_params(csh, 52).values())
+    ag = pixels.OraclePixelDDPG(enc, actor, critic)
+    noise = _synth.NoiseStream(21)
+    keys = [str(k) for k in z['metric_keys']]
+    for i in range(N):
+        batch = (z[f'batch/{i}/obs'], z[f'batch/{i}/action'], z[f'batch/{i}/reward'], z[f'batch/{i}/discount'], z[f'batch/{i}/next_obs'])
+        m = ag.update(batch, 2 * i, z['shifts'][2 * i], z['shifts'][2 * i + 1], noise.draw((B, A)), noise.draw((B, A)))
+        got = np.array([m[k] for k in keys])
+        np.testing.assert_allclose(got, z['metrics'][i], rtol=1e-4, atol=2e-6, err_msg=f'step {i} {keys}')
+    for nm, ks, ps in (('encoder', esh, ag.enc), ('actor', ash, ag.actor), ('critic', csh, ag.critic), ('critic_target', csh, ag.critic_target)):
+        for (k, _), p in zip(ks, ps):
+            if f'final/{nm}/{k}' in z.files:
+                np.testing.assert_allclose(p, z[f'final/{nm}/{k}'], rtol=1e-4, atol=2e-6, err_msg=f'{nm}.{k}')
+            else:
+                np.testing.assert_allclose(p.reshape(-1)[::997], z[f'final_sample/{nm}/{k}'], rtol=1e-4, atol=2e-6, err_msg=f'{nm}.{k}')

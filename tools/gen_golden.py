@@ -214,6 +214,58 @@ def gen_pixels(ref):
     print('pixels g5 keys', len(out))
 
 
+def gen_pixel_ddpg(ref):
+    """DDPGAgent with obs_type='pixels' (ddpg.py:126-328): 3 update() calls, B=4, (3,84,84) uint8 frames. Weights come from
+    _synth.synth_params seeds (the 39200-wide trunks are too big to store); augmentation shifts and action noise are recorded."""
+    U = ref.utils
+    C, HW, A, F, H, B, N = 3, 84, 3, 16, 32, 4, 3
+    torch.manual_seed(5)
+    agent = ref.ddpg.DDPGAgent('ddpg', True, 'pixels', (C, HW, HW), (A,), 'cpu', 1e-4, F, H, 0.01, 2000, 2, 0.2, 3, B, 0.3, True, True, False)
+    out = {'dims': np.array([C, HW, A, F, H, B, N])}
+    for i, (nm, net) in enumerate((('encoder', agent.encoder), ('actor', agent.actor), ('critic', agent.critic))):
+        shapes = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+        params = _synth.synth_params(shapes, 50 + i)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+        out[f'keys/{nm}'] = np.array([k for k, _ in shapes])
+    agent.critic_target.load_state_dict(agent.critic.state_dict())
+    rs = np.random.RandomState(8)
+    shifts, noise = [], _synth.NoiseStream(21)
+    o_sn, o_randint = U._standard_normal, torch.randint
+
+    def p_randint(lo, hi, size, device=None, dtype=None):
+        sh = rs.randint(lo, hi, tuple(size))
+        shifts.append(sh.reshape(-1, 2).astype(np.int32))
+        return torch.from_numpy(sh).to(dtype)
+    U._standard_normal = lambda shape, dtype, device: torch.from_numpy(noise.draw(shape)).to(dtype)
+    torch.randint = p_randint
+    metrics = []
+    try:
+        for i in range(N):
+            b = _synth.synth_batch(61, i, B, 4, A)
+            obs = rs.randint(0, 256, (B, C, HW, HW)).astype(np.uint8)
+            nobs = rs.randint(0, 256, (B, C, HW, HW)).astype(np.uint8)
+            out[f'batch/{i}/obs'], out[f'batch/{i}/next_obs'] = obs, nobs
+            out[f'batch/{i}/action'], out[f'batch/{i}/reward'], out[f'batch/{i}/discount'] = b[1], b[2], b[3]
+            m = agent.update(iter([(obs, b[1], b[2], b[3], nobs)]), 2 * i)
+            metrics.append({k: float(v) for k, v in m.items()})
+    finally:
+        U._standard_normal, torch.randint = o_sn, o_randint
+    out['shifts'] = np.stack(shifts)                      # [2 * step + (0 obs | 1 next_obs)]
+    keys = sorted(metrics[0].keys())
+    out['metric_keys'] = np.array(keys)
+    out['metrics'] = np.array([[m[k] for k in keys] for m in metrics], np.float64)
+    for nm, net in (('encoder', agent.encoder), ('actor', agent.actor), ('critic', agent.critic), ('critic_target', agent.critic_target)):
+        for k, v in net.state_dict().items():
+            v = v.numpy()
+            if v.size <= 20000:
+                out[f'final/{nm}/{k}'] = v.copy()
+            else:                                         # trunk.0.weight (F x 39200): strided sample + checksums
+                out[f'final_sample/{nm}/{k}'] = v.reshape(-1)[::997].copy()
+                out[f'final_sums/{nm}/{k}'] = np.array([v.astype(np.float64).sum(), (v.astype(np.float64) ** 2).sum()])
+    np.savez_compressed(GOLD / 'pixel_ddpg.npz', **out)
+    print('pixel ddpg', keys, out['metrics'][-1])
+
+
 # ----------------------------------------------------------------------------- agents (G3/G4)
 def make_agent(ref, kind, O, A, H, B, device='cpu', use_tb=True, **kw):
     if kind == 'td3_bc':
@@ -460,7 +512,7 @@ if __name__ == '__main__':
     args = ap.parse_args()
     GOLD.mkdir(parents=True, exist_ok=True)
     ref = load_reference()
-    todo = [args.only] if args.only else ['replay', 'utils', 'tiny', 'full', 'pixels']
+    todo = [args.only] if args.only else ['replay', 'utils', 'tiny', 'full', 'pixels', 'pixel_ddpg']
     kinds = args.kinds.split(',') if args.kinds else None
     if kinds:
         TINY_KINDS = tuple(k for k in TINY_KINDS if k.partition('-')[0] in kinds)
@@ -468,4 +520,4 @@ if __name__ == '__main__':
         if t == 'full':
             gen_full(ref, only_kinds=kinds)
         else:
-            {'replay': gen_replay, 'utils': gen_utils, 'tiny': gen_tiny, 'pixels': gen_pixels}[t](ref)
+            {'replay': gen_replay, 'utils': gen_utils, 'tiny': gen_tiny, 'pixels': gen_pixels, 'pixel_ddpg': gen_pixel_ddpg}[t](ref)
