@@ -8,6 +8,7 @@ Reference classes mirrored (file:line in /root/reference):
   RNDAgent    agents/unsupervised_learning/rnd.py:63-159     ICMAgent  agents/unsupervised_learning/icm.py:48-139
   ICMAPTAgent agents/unsupervised_learning/icm_apt.py:60-158 DisagreementAgent agents/unsupervised_learning/disagreement.py:50-136
   DIAYNAgent  agents/unsupervised_learning/diayn.py:32-176     ProtoAgent agents/unsupervised_learning/proto.py:46-207 (states)
+  DDPGAgent with obs_type='pixels': Encoder ddpg.py:12-39, pixel Actor/Critic :42-123, update :213-328 (RandomShiftsAug utils.py:222-254)
   APSAgent    agents/unsupervised_learning/aps.py:82-320       SMMAgent   agents/unsupervised_learning/smm.py:115-281 (states)
 
 Python here is orchestration only: it builds the initial weights with torch's CPU RNG in the reference's
@@ -23,7 +24,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import utils
-from .engine import AgentEngine, IntrEngine
+from .engine import AgentEngine, IntrEngine, PixelEngine
 
 _OFFLINE_ACTOR_KEYS = ['policy.0.weight', 'policy.0.bias', 'policy.1.weight', 'policy.1.bias',
                        'policy.3.weight', 'policy.3.bias', 'policy.5.weight', 'policy.5.bias']
@@ -497,8 +498,13 @@ class DDPGAgent(_AgentBase):
     def __init__(self, name, reward_free, obs_type, obs_shape, action_shape, device, lr, feature_dim, hidden_dim,
                  critic_target_tau, num_expl_steps, update_every_steps, stddev_schedule, nstep, batch_size, stddev_clip,
                  init_critic, use_tb, use_wandb, meta_dim=0, skill_type='uniform', *, precision='fp32', seed=0):
+        if obs_type == 'pixels':
+            if type(self) is not DDPGAgent or meta_dim:
+                raise NotImplementedError("exorl_amd: obs_type='pixels' is built for DDPGAgent itself (no meta, no intrinsic module) this round")
+            return self._init_pixels(reward_free, obs_shape, action_shape, device, lr, feature_dim, hidden_dim, critic_target_tau, num_expl_steps,
+                                     update_every_steps, stddev_schedule, batch_size, stddev_clip, init_critic, use_tb, use_wandb, precision, seed)
         if obs_type != 'states':
-            raise NotImplementedError("exorl_amd DDPGAgent: obs_type='pixels' (conv encoder, SURVEY K14-K15) is not built yet")
+            raise NotImplementedError(f"exorl_amd DDPGAgent: unknown obs_type {obs_type!r}")
         self.reward_free = reward_free
         self.obs_type = obs_type
         self.obs_shape = obs_shape
@@ -528,11 +534,79 @@ class DDPGAgent(_AgentBase):
     def _engine_kw(self):
         return {}
 
+    # ---- obs_type == 'pixels' (ddpg.py:12-39 Encoder, :42-123 pixel Actor/Critic, :213-328) -----------------------------------------
+    def _init_pixels(self, reward_free, obs_shape, action_shape, device, lr, feature_dim, hidden_dim, critic_target_tau, num_expl_steps,
+                     update_every_steps, stddev_schedule, batch_size, stddev_clip, init_critic, use_tb, use_wandb, precision, seed):
+        self.reward_free, self.obs_type, self.obs_shape = reward_free, 'pixels', tuple(obs_shape)
+        self.action_dim, self.hidden_dim, self.feature_dim = action_shape[0], hidden_dim, feature_dim
+        self.lr, self.device, self.critic_target_tau = lr, device, critic_target_tau
+        self.update_every_steps, self.use_tb, self.use_wandb = update_every_steps, use_tb, use_wandb
+        self.num_expl_steps, self.stddev_schedule, self.stddev_clip, self.init_critic = num_expl_steps, stddev_schedule, stddev_clip, init_critic
+        self.solved_meta = None
+        self.world_size = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            raise NotImplementedError('exorl_amd: the pixel path is single-GPU this round')
+        c = obs_shape[0]
+        w = _pixel_init(c, obs_shape[1], self.action_dim, feature_dim, hidden_dim)
+        self.engine = PixelEngine(obs_shape, self.action_dim, feature_dim, hidden_dim, batch_size, lr=lr, tau=critic_target_tau,
+                                  stddev_clip=stddev_clip, precision=precision, seed=seed, device=device)
+        self.obs_dim = w['repr_dim']
+        conv_shapes = [s for l in range(4) for s in ((32, c if l == 0 else 32, 3, 3), (32,))]
+        self.encoder = _PixelNetView(self.engine, 0, _ENC_KEYS, conv_shapes)
+        self.actor = _PixelNetView(self.engine, 1, _PIX_ACTOR_KEYS)
+        self.critic = _PixelNetView(self.engine, 2, _PIX_CRITIC_KEYS)
+        self.critic_target = _PixelNetView(self.engine, 3, _PIX_CRITIC_KEYS)
+        for view, ts in ((self.encoder, w['encoder']), (self.actor, w['actor']), (self.critic, w['critic'])):
+            for p, t in zip(view.parameters(), ts):
+                p.copy_(t.reshape(p.shape))
+        self.engine.sync_target()
+        self.aug = _Identity()
+        self.encoder_opt = True            # the reference's `if self.encoder_opt is not None` checks hold for pixels
+        self.noise_hook = None             # tests: callable(shape) -> standard normals for the TruncatedNormal draws
+        self.shift_hook = None             # tests: callable(batch) -> (batch, 2) RandomShiftsAug draws
+        self._slots = None
+        self.training = True
+
+    def _update_pixels(self, replay_iter, step):
+        eng = self.engine
+        if hasattr(replay_iter, 'sample_into'):
+            self._slots = self._slots or eng.batch_slots()
+            replay_iter.sample_into(self._slots, eng.batch)
+        else:
+            obs, action, reward, discount, next_obs = next(replay_iter)[:5]
+            eng.set_batch(obs, action, reward, discount, next_obs)
+        stddev = self._stddev(step)
+        B, A = eng.batch, self.action_dim
+        so = self.shift_hook(B) if self.shift_hook else None
+        sn = self.shift_hook(B) if self.shift_hook else None
+        nc = self.noise_hook((B, A)) if self.noise_hook else None
+        na = self.noise_hook((B, A)) if self.noise_hook else None
+        eng.update(stddev, so, sn, nc, na)
+        metrics = dict()
+        if self.use_tb or self.use_wandb:
+            raw = eng.metrics_raw()
+            for idx, name in _CRITIC_METRICS + [(L.M_ACTOR_LOGPROB, 'actor_logprob')]:
+                metrics[name] = float(raw[idx])
+            metrics['actor_ent'] = float(np.float32(0.5 + 0.5 * np.log(2 * np.pi) + np.log(stddev)) * self.action_dim)
+        return metrics
+
+    def __getstate__(self):
+        if getattr(self, 'obs_type', 'states') == 'pixels':
+            raise NotImplementedError('exorl_amd: pickling the pixel agent is not built yet; use the state_dicts of .encoder/.actor/.critic')
+        return super().__getstate__()
+
     def train(self, training=True):
+        if getattr(self, 'obs_type', 'states') == 'pixels':
+            self.training = training
+            for n in (self.encoder, self.actor, self.critic):
+                n.train(training)
+            return
         super().train(training)
         self.encoder.train(training)
 
     def init_from(self, other):
+        if self.obs_type == 'pixels':
+            utils.hard_update_params(other.encoder, self.encoder)
         utils.hard_update_params(other.actor, self.actor)
         if self.init_critic:          # critic.trunk = first 4 tensors (ddpg.py:209-210)
             for p, t in zip(other.critic.parameters()[:4], self.critic.parameters()[:4]):
@@ -549,6 +623,13 @@ class DDPGAgent(_AgentBase):
         return meta
 
     def act(self, obs, meta, step, eval_mode):
+        if self.obs_type == 'pixels':
+            stddev = self._stddev(step)
+            noise = self.noise_hook((1, self.action_dim)) if (self.noise_hook and not eval_mode) else None
+            a = self.engine.act(np.ascontiguousarray(obs), stddev, eval_mode, noise)
+            if not eval_mode and step < self.num_expl_steps:
+                a.uniform_(-1.0, 1.0)
+            return a.cpu().numpy()
         parts = [np.asarray(obs, np.float32).reshape(-1)] + [np.asarray(v, np.float32).reshape(-1) for v in meta.values()]
         return self._act(np.concatenate(parts), step, eval_mode)
 
@@ -556,6 +637,8 @@ class DDPGAgent(_AgentBase):
         metrics = dict()
         if step % self.update_every_steps != 0:      # ddpg.py:302-303 — no batch is consumed
             return metrics
+        if self.obs_type == 'pixels':
+            return self._update_pixels(replay_iter, step)
         stddev = self._stddev(step)
         self._step(replay_iter, stddev)
         if self.use_tb or self.use_wandb:
@@ -1089,6 +1172,55 @@ class ProtoAgent(_IntrAgent):
             u = torch.as_tensor(np.asarray(self.cat_hook(self.num_protos), np.float32), device=self.engine.device)
         self.intr.update(s.obs, None, s.next_obs, s.reward, s.reward, True, cat_uniform=u.data_ptr() if u is not None else None)
         self._keep_u = u
+
+
+_ENC_KEYS = [f'convnet.{i}.{w}' for i in (0, 2, 4, 6) for w in ('weight', 'bias')]
+_PIX_ACTOR_KEYS = ['trunk.0.weight', 'trunk.0.bias', 'trunk.1.weight', 'trunk.1.bias'] + [f'policy.{i}.{w}' for i in (0, 2, 4) for w in ('weight', 'bias')]
+_PIX_CRITIC_KEYS = (['trunk.0.weight', 'trunk.0.bias', 'trunk.1.weight', 'trunk.1.bias'] +
+                    [f'{q}.{i}.{w}' for q in ('Q1', 'Q2') for i in (0, 2, 4) for w in ('weight', 'bias')])
+
+
+class _PixelNetView(NetView):
+    """NetView over a PixelEngine net; conv weights are exposed in torch's (co, ci, 3, 3) shape."""
+
+    def __init__(self, engine, net, keys, shapes=None):
+        self._engine, self._net, self._keys, self._on_change = engine, net, list(keys), None
+        self.training = True
+        self._params = []
+        for i in range(len(keys)):
+            t = engine.tensor(net, i, L.T_PARAM)
+            self._params.append(t.view(*shapes[i]) if shapes else t)
+
+    def grads(self):
+        return [self._engine.tensor(self._net, i, L.T_GRAD) for i in range(len(self._keys))]
+
+
+def _pixel_init(c_in, hw, A, F, H):
+    """Initial tensors of Encoder, pixel Actor, pixel Critic (and the critic_target's discarded draws) in the reference's RNG order
+    (ddpg.py:165-181): every module default-initialised at construction, then weight_init — orthogonal with the ReLU gain for
+    Conv2d, gain 1 for Linear, zero biases (utils.py:59-69)."""
+    def orth(m, gain=1.0):
+        nn.init.orthogonal_(m.weight.data, gain)
+        if m.bias is not None:
+            m.bias.data.fill_(0.0)
+    convs = [nn.Conv2d(c_in, 32, 3, stride=2)] + [nn.Conv2d(32, 32, 3, stride=1) for _ in range(3)]
+    for m in convs:
+        orth(m, nn.init.calculate_gain('relu'))
+    e = (hw - 3) // 2 + 1 - 6
+    R = 32 * e * e
+
+    def net(head_in, out, n_heads):
+        mods = [nn.Linear(R, F), nn.LayerNorm(F)]
+        for _ in range(n_heads):
+            mods += [nn.Linear(head_in, H), nn.Linear(H, H), nn.Linear(H, out)]
+        for m in mods:
+            if isinstance(m, nn.Linear):
+                orth(m)
+        return [t for m in mods for t in (m.weight.data, m.bias.data)]
+    actor = net(F, A, 1)
+    critic = net(F + A, 1, 2)
+    net(F + A, 1, 2)                      # critic_target's draws, overwritten by load_state_dict
+    return {'encoder': [t for m in convs for t in (m.weight.data, m.bias.data)], 'actor': actor, 'critic': critic, 'repr_dim': R}
 
 
 class _Identity:

@@ -273,6 +273,94 @@ class IntrEngine:
         L.check(self.lib.exorl_intr_opt_steps(self.h, C.byref(v), 1))
 
 
+class PixelEngine:
+    """DDPG on pixel observations (exorl_pixel_agent_t): augmentation, conv encoder, pixel actor/critic and their update."""
+    NETS = {'encoder': 0, 'actor': 1, 'critic': 2, 'critic_target': 3}
+
+    def __init__(self, obs_shape, act_dim, feature_dim, hidden_dim, batch, lr=1e-4, tau=0.01, stddev_clip=0.3, precision='fp32', seed=0,
+                 device='cuda'):
+        self.lib = L.load()
+        self.device = _require_gpu(device)
+        c, h, w = obs_shape
+        if h != w:
+            raise L.ExorlError(f'pixel observations must be square, got {obs_shape}')
+        self.obs_shape, self.act_dim, self.batch = tuple(obs_shape), act_dim, batch
+        self.cfg = L.PixelCfg(c, h, act_dim, feature_dim, hidden_dim, batch, PRECISION[precision], 0, lr, tau,
+                              stddev_clip if stddev_clip is not None else 0.0, 0.0, seed)
+        nbytes = self.lib.exorl_pixel_agent_workspace_bytes(C.byref(self.cfg))
+        if nbytes == 0:
+            raise L.ExorlError(self.lib.exorl_last_error().decode())
+        with torch.cuda.device(self.device):
+            self.workspace = torch.zeros(nbytes + 256, dtype=torch.uint8, device=self.device)
+            base = self.workspace.data_ptr()
+            off = (-base) % 256
+            handle = C.c_void_p()
+            L.check(self.lib.exorl_pixel_agent_create(C.byref(self.cfg), base + off, nbytes, C.byref(handle)))
+        self.h = handle
+        self._f32 = self.workspace[off:off + nbytes].view(torch.float32)
+
+    def __del__(self):
+        h, self.h = getattr(self, 'h', None), None
+        if h:
+            self.lib.exorl_pixel_agent_destroy(h)
+
+    def _view(self, ptr, numel):
+        off = (ptr - self._f32.data_ptr()) // 4
+        return self._f32[off:off + numel]
+
+    def num_tensors(self, net):
+        n = C.c_int32()
+        L.check(self.lib.exorl_pixel_agent_num_tensors(self.h, net, C.byref(n)))
+        return n.value
+
+    def tensor(self, net, index, what=L.T_PARAM):
+        p, r, c = C.c_void_p(), C.c_int64(), C.c_int64()
+        L.check(self.lib.exorl_pixel_agent_tensor(self.h, net, index, what, C.byref(p), C.byref(r), C.byref(c)))
+        v = self._view(p.value, r.value * c.value)
+        return v.view(r.value, c.value) if c.value > 1 else v
+
+    def sync_target(self):
+        L.check(self.lib.exorl_pixel_agent_sync_target(self.h, L.current_stream()))
+
+    def batch_slots(self):
+        out = L.BatchOut()
+        L.check(self.lib.exorl_pixel_agent_batch_slots(self.h, C.byref(out)))
+        return out
+
+    def _u8(self, x):
+        t = torch.as_tensor(x)
+        if t.dtype != torch.uint8:
+            raise L.ExorlError(f'pixel observations must be uint8 (got {t.dtype}), as the replay buffer stores them')
+        return t.to(self.device, non_blocking=True).contiguous()
+
+    def _f(self, x):
+        return torch.as_tensor(x).to(self.device, torch.float32, non_blocking=True).contiguous()
+
+    def set_batch(self, obs, action, reward, discount, next_obs):
+        ts = [self._u8(obs), self._f(action), self._f(reward), self._f(discount), self._u8(next_obs)]
+        L.check(self.lib.exorl_pixel_agent_set_batch(self.h, *[t.data_ptr() for t in ts], L.current_stream()))
+        self._keep = ts
+
+    def update(self, stddev, shifts_obs=None, shifts_next=None, noise_critic=None, noise_actor=None):
+        i32 = lambda x: None if x is None else torch.as_tensor(np.ascontiguousarray(x, np.int32)).to(self.device)
+        f32 = lambda x: None if x is None else self._f(x)
+        ts = [i32(shifts_obs), i32(shifts_next), f32(noise_critic), f32(noise_actor)]
+        L.check(self.lib.exorl_pixel_agent_update(self.h, stddev, *[L.ptr(t) for t in ts], L.current_stream()))
+        self._keep_u = ts
+
+    def metrics_raw(self):
+        host = np.zeros(L.N_METRICS, np.float32)
+        L.check(self.lib.exorl_pixel_agent_metrics(self.h, host.ctypes.data, L.current_stream()))
+        return host
+
+    def act(self, obs, stddev, eval_mode, noise=None):
+        o = self._u8(obs)
+        out = torch.empty(self.act_dim, dtype=torch.float32, device=self.device)
+        nz = self._f(noise) if noise is not None else None
+        L.check(self.lib.exorl_pixel_agent_act(self.h, o.data_ptr(), stddev, int(eval_mode), L.ptr(nz), out.data_ptr(), L.current_stream()))
+        return out
+
+
 class ReplayEngine:
     """HBM-resident episodic arena (exorl_replay_t)."""
 

@@ -114,3 +114,77 @@ def test_encoder_batch_vs_oracle(lib):
 
 def _fwd_any(p, x):
     return pixels.encoder_fwd(p, x)
+
+
+# ---------------------------------------------------------------------------------------------------- DDPG on pixels
+def make_pixel_agent(C_, HW, A, F, H, B, use_tb=True, precision='fp32'):
+    from exorl_amd import agents
+    return agents.DDPGAgent('ddpg', True, 'pixels', (C_, HW, HW), (A,), 'cuda', 1e-4, F, H, 0.01, 2000, 2, 0.2, 3, B, 0.3, True, use_tb, False,
+                            precision=precision)
+
+
+def load_pixel_params(ag, C_, A, F, H, R=39200):
+    import _synth
+    esh, ash, csh = pixels.pixel_param_shapes(C_, A, F, H, R)
+    ps = [_synth.synth_params(sh, 50 + i) for i, sh in enumerate((esh, ash, csh))]
+    for view, p in zip((ag.encoder, ag.actor, ag.critic), ps):
+        view.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+    ag.engine.sync_target()
+    return [list(p.values()) for p in ps]
+
+
+def test_pixel_ddpg_vs_reference(gold):
+    """3 update() calls of the reference's DDPGAgent(obs_type='pixels') (tests/golden/pixel_ddpg.npz): metrics and final weights."""
+    import _synth
+    z = np.load(gold / 'pixel_ddpg.npz')
+    C_, HW, A, F, H, B, N = [int(v) for v in z['dims']]
+    ag = make_pixel_agent(C_, HW, A, F, H, B)
+    load_pixel_params(ag, C_, A, F, H)
+    noise = _synth.NoiseStream(21)
+    shifts = iter(z['shifts'])
+    ag.noise_hook = noise.draw
+    ag.shift_hook = lambda n: next(shifts)
+    keys = [str(k) for k in z['metric_keys']]
+    for i in range(N):
+        batch = (z[f'batch/{i}/obs'], z[f'batch/{i}/action'], z[f'batch/{i}/reward'], z[f'batch/{i}/discount'], z[f'batch/{i}/next_obs'])
+        assert ag.update(iter([]), 2 * i + 1) == {}
+        m = ag.update(iter([batch]), 2 * i)
+        assert sorted(m.keys()) == keys
+        np.testing.assert_allclose(np.array([m[k] for k in keys]), z['metrics'][i], rtol=1e-4, atol=3e-6, err_msg=f'step {i} {keys}')
+    for nm, view in (('encoder', ag.encoder), ('actor', ag.actor), ('critic', ag.critic), ('critic_target', ag.critic_target)):
+        for k, v in view.state_dict().items():
+            v = v.cpu().numpy()
+            if f'final/{nm}/{k}' in z.files:
+                np.testing.assert_allclose(v, z[f'final/{nm}/{k}'], rtol=1e-4, atol=2e-6, err_msg=f'{nm}.{k}')
+            else:
+                np.testing.assert_allclose(v.reshape(-1)[::997], z[f'final_sample/{nm}/{k}'], rtol=1e-4, atol=2e-6, err_msg=f'{nm}.{k}')
+    # act(): eval = tanh(policy(trunk(encoder(obs)))) on the raw frame
+    a = ag.act(z['batch/0/obs'][0], {}, 10**6, True)
+    assert a.shape == (A,) and np.all(np.abs(a) <= 1.0)
+
+
+def test_pixel_ddpg_batch_vs_oracle():
+    """Shipped widths (feature_dim 50, hidden 1024) at a batch that spans many workgroups; 64x64 frames with 9 stacked channels."""
+    import _synth
+    for (C_, HW, A, F, H, B) in ((3, 84, 6, 50, 1024, 24), (9, 64, 4, 50, 256, 16)):
+        R = 32 * ((HW - 3) // 2 + 1 - 6) ** 2
+        ag = make_pixel_agent(C_, HW, A, F, H, B)
+        enc, actor, critic = load_pixel_params(ag, C_, A, F, H, R)
+        orc = pixels.OraclePixelDDPG(enc, actor, critic)
+        rs = np.random.RandomState(1)
+        ns, ns2 = _synth.NoiseStream(4), _synth.NoiseStream(4)
+        ag.noise_hook = ns.draw
+        sh = []
+        ag.shift_hook = lambda n: sh[-1].pop(0)
+        for i in range(2):
+            obs, nobs = rs.randint(0, 256, (B, C_, HW, HW)).astype(np.uint8), rs.randint(0, 256, (B, C_, HW, HW)).astype(np.uint8)
+            b = _synth.synth_batch(3, i, B, 4, A)
+            so, sn = rs.randint(0, 9, (B, 2)).astype(np.int32), rs.randint(0, 9, (B, 2)).astype(np.int32)
+            sh.append([so, sn])
+            m = ag.update(iter([(obs, b[1], b[2], b[3], nobs)]), 2 * i)
+            mo = orc.update((obs, b[1], b[2], b[3], nobs), 2 * i, so, sn, ns2.draw((B, A)), ns2.draw((B, A)))
+            for k, v in mo.items():
+                assert abs(m[k] - v) <= 2e-4 * abs(v) + 1e-5, (C_, i, k, m[k], v)
+        for got, want in zip(ag.encoder.grads(), orc.last_enc_grads):
+            got = got.cpu().numpy().reshape(want.shape)
+            np.testing.assert_allclose(got, want, rtol=5e-3, atol=1e-3 * np.abs(want).max() + 1e-9)

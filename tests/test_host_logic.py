@@ -101,6 +101,18 @@ def test_aps_init_matches_reference_rng_order(gold):
         np.testing.assert_array_equal(t.numpy(), z[f'init/aps/{k}'], err_msg=k)
 
 
+def test_pixel_init_matches_reference_rng_order(gold):
+    """DDPGAgent(obs_type='pixels') under torch.manual_seed(5): Encoder (orthogonal with the ReLU gain), pixel Actor, pixel Critic."""
+    from exorl_amd import agents
+    z = np.load(gold / 'pixel_ddpg.npz')
+    C_, HW, A, F, H = [int(v) for v in z['dims'][:5]]
+    torch.manual_seed(5)
+    w = agents._pixel_init(C_, HW, A, F, H)
+    for nm in ('encoder', 'actor', 'critic'):
+        got = np.array([[float(t.double().sum()), float((t.double() ** 2).sum())] for t in w[nm]])
+        np.testing.assert_allclose(got, z[f'init_sums/{nm}'], rtol=1e-6, atol=1e-6, err_msg=nm)
+
+
 def test_proto_init_matches_reference_rng_order(gold):
     """proto.py:55-67 draws: predictor, projector (weight_init applied twice), protos — after the DDPG nets."""
     from exorl_amd import agents

@@ -222,6 +222,8 @@ def gen_pixel_ddpg(ref):
     torch.manual_seed(5)
     agent = ref.ddpg.DDPGAgent('ddpg', True, 'pixels', (C, HW, HW), (A,), 'cpu', 1e-4, F, H, 0.01, 2000, 2, 0.2, 3, B, 0.3, True, True, False)
     out = {'dims': np.array([C, HW, A, F, H, B, N])}
+    for nm, net in (('encoder', agent.encoder), ('actor', agent.actor), ('critic', agent.critic)):      # initial weights under manual_seed(5)
+        out[f'init_sums/{nm}'] = np.array([[float(v.double().sum()), float((v.double() ** 2).sum())] for v in net.state_dict().values()])
     for i, (nm, net) in enumerate((('encoder', agent.encoder), ('actor', agent.actor), ('critic', agent.critic))):
         shapes = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
         params = _synth.synth_params(shapes, 50 + i)
