@@ -55,7 +55,8 @@ class IntrCfg(C.Structure):
 
 class IntrBatch(C.Structure):
     _fields_ = [('obs', c_void_p), ('obs_ld', c_int64), ('action', c_void_p), ('action_ld', c_int64), ('next_obs', c_void_p),
-                ('next_obs_ld', c_int64), ('skill', c_void_p), ('skill_ld', c_int64), ('extr_reward', c_void_p), ('reward_out', c_void_p), ('cat_uniform', c_void_p)]
+                ('next_obs_ld', c_int64), ('skill', c_void_p), ('skill_ld', c_int64), ('extr_reward', c_void_p), ('reward_out', c_void_p), ('next_obs_target', c_void_p),
+                ('next_obs_target_ld', c_int64), ('dobs_out', c_void_p), ('cat_uniform', c_void_p)]
 
 
 class PixelCfg(C.Structure):
@@ -76,6 +77,12 @@ PROTOTYPES = {
     'exorl_pixel_agent_batch_slots': (C.c_int, [c_void_p, P(BatchOut)]),
     'exorl_pixel_agent_set_batch': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'exorl_pixel_agent_update': (C.c_int, [c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'exorl_pixel_agent_augment': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    'exorl_pixel_agent_encode': (C.c_int, [c_void_p, c_int32, c_int32, P(c_void_p), c_void_p]),
+    'exorl_pixel_agent_encoder_step': (C.c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p]),
+    'exorl_pixel_agent_encoder_target': (C.c_int, [c_void_p, c_float, c_int32, c_void_p]),
+    'exorl_pixel_agent_set_train_encoder': (C.c_int, [c_void_p, c_int32]),
+    'exorl_pixel_agent_encoder_target_ptr': (C.c_int, [c_void_p, P(c_void_p)]),
     'exorl_pixel_agent_metrics': (C.c_int, [c_void_p, c_void_p, c_void_p]),
     'exorl_pixel_agent_act': (C.c_int, [c_void_p, c_void_p, c_float, c_int32, c_void_p, c_void_p, c_void_p]),
     'exorl_aug_shift': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_uint64, c_uint64, c_void_p, c_void_p]),

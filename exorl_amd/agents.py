@@ -499,8 +499,8 @@ class DDPGAgent(_AgentBase):
                  critic_target_tau, num_expl_steps, update_every_steps, stddev_schedule, nstep, batch_size, stddev_clip,
                  init_critic, use_tb, use_wandb, meta_dim=0, skill_type='uniform', *, precision='fp32', seed=0):
         if obs_type == 'pixels':
-            if type(self) is not DDPGAgent or meta_dim:
-                raise NotImplementedError("exorl_amd: obs_type='pixels' is built for DDPGAgent itself (no meta, no intrinsic module) this round")
+            if not (type(self) is DDPGAgent or getattr(self, '_PIXELS_OK', False)) or meta_dim:
+                raise NotImplementedError("exorl_amd: obs_type='pixels' is built for DDPGAgent and ProtoAgent (no meta) this round")
             return self._init_pixels(reward_free, obs_shape, action_shape, device, lr, feature_dim, hidden_dim, critic_target_tau, num_expl_steps,
                                      update_every_steps, stddev_schedule, batch_size, stddev_clip, init_critic, use_tb, use_wandb, precision, seed)
         if obs_type != 'states':
@@ -1130,6 +1130,7 @@ class ProtoAgent(_IntrAgent):
     """agents/unsupervised_learning/proto.py:46-207 (configs/agent/proto.yaml) on state observations: the encoder is the identity,
     so encoder_target and the encoder's share of proto_opt vanish; the intrinsic reward is computed on next_obs (proto.py:175-177)."""
     LOSS_KEY = 'repr_loss'
+    _PIXELS_OK = True
 
     def __init__(self, pred_dim, proj_dim, queue_size, num_protos, tau, encoder_target_tau, topk, update_encoder, **kwargs):
         super().__init__(**kwargs)
@@ -1139,6 +1140,13 @@ class ProtoAgent(_IntrAgent):
         self.num_protos = num_protos
         self.update_encoder = update_encoder
         self.encoder_target = _Identity()
+        self._precision = kwargs.get('precision', 'fp32')
+        if self.obs_type == 'pixels':            # encoder_target = deepcopy(encoder) (proto.py:55): no RNG draws
+            c = self.obs_shape[0]
+            shapes = [s for l in range(4) for s in ((32, c if l == 0 else 32, 3, 3), (32,))]
+            self.engine.encoder_target(init=True)
+            self.encoder_target = _ParamList(_ENC_KEYS, self.engine.encoder_target_tensors(shapes))
+            self._dobs = torch.zeros(self.engine.batch, self.obs_dim, device=self.engine.device)
         O = self.obs_dim
         w = _proto_init(O, pred_dim, proj_dim, num_protos)
         self.intr = IntrEngine('proto', O, self.action_dim, proj_dim, self.engine.batch, rep_dim=pred_dim, lr=self.lr, knn_k=topk,
@@ -1157,27 +1165,89 @@ class ProtoAgent(_IntrAgent):
     queue_ptr = property(lambda self: self.intr.queue_ptr(), lambda self, v: self.intr.queue_ptr(v))
 
     def init_from(self, other):         # proto.py:87-96
+        if self.obs_type == 'pixels':
+            utils.hard_update_params(other.encoder, self.encoder)
         utils.hard_update_params(other.actor, self.actor)
         utils.hard_update_params(other.predictor, self.predictor)
         utils.hard_update_params(other.projector, self.projector)
         utils.hard_update_params(other.protos, self.protos)
         if self.init_critic:
             utils.hard_update_params(other.critic, self.critic)
-        self.params_changed()
+        if self.obs_type != 'pixels':
+            self.params_changed()
+
+    def _cat_u(self):
+        if self.cat_hook is None:
+            return None
+        return torch.as_tensor(np.asarray(self.cat_hook(self.num_protos), np.float32), device=self.engine.device)
 
     def _intr_step(self):
         s = self._slots = self._slots or self.engine.batch_slots()
-        u = None
-        if self.cat_hook is not None:
-            u = torch.as_tensor(np.asarray(self.cat_hook(self.num_protos), np.float32), device=self.engine.device)
+        u = self._cat_u()
         self.intr.update(s.obs, None, s.next_obs, s.reward, s.reward, True, cat_uniform=u.data_ptr() if u is not None else None)
         self._keep_u = u
+
+    def _update_pixels(self, replay_iter, step):
+        """proto.py:159-207 on pixels: augment once; the proto step reaches the encoder through proto_opt; reward from the re-encoded
+        next_obs; DDPG step with the encoding detached in update_critic; Polyak updates."""
+        eng = self.engine
+        if hasattr(replay_iter, 'sample_into'):
+            self._slots = self._slots or eng.batch_slots()
+            replay_iter.sample_into(self._slots, eng.batch)
+        else:
+            obs, action, reward, discount, next_obs = next(replay_iter)[:5]
+            eng.set_batch(obs, action, reward, discount, next_obs)
+        s = self._slots = self._slots or eng.batch_slots()
+        B, A = eng.batch, self.action_dim
+        eng.augment(self.shift_hook(B) if self.shift_hook else None, self.shift_hook(B) if self.shift_hook else None)
+        if self.reward_free:
+            fo = eng.encode(0)
+            ft = eng.encode(1, target=True)
+            self.intr.update(fo, None, ft, None, s.reward, 2, next_obs_target=ft, dobs_out=self._dobs.data_ptr())
+            eng.encoder_step(0, self._dobs.data_ptr(), 1)
+            fn = eng.encode(1)
+            u = self._cat_u()
+            self.intr.update(fo, None, fn, s.reward, s.reward, False, cat_uniform=u.data_ptr() if u is not None else None)
+            self._keep_u = u
+        stddev = self._stddev(step)
+        eng.set_train_encoder(False)
+        eng.update(stddev, None, None, self.noise_hook((B, A)) if self.noise_hook else None, self.noise_hook((B, A)) if self.noise_hook else None,
+                   keep_augmented=True)
+        eng.encoder_target(self.encoder_target_tau)
+        metrics = dict()
+        if self.use_tb or self.use_wandb:
+            raw = eng.metrics_raw()
+            for idx, name in _CRITIC_METRICS + [(L.M_ACTOR_LOGPROB, 'actor_logprob')]:
+                metrics[name] = float(raw[idx])
+            metrics['actor_ent'] = float(np.float32(0.5 + 0.5 * np.log(2 * np.pi) + np.log(stddev)) * self.action_dim)
+            if self.reward_free:
+                ri = self.intr.metrics_raw()
+                metrics['repr_loss'] = float(ri[L.IM_LOSS])
+                metrics['intr_reward'] = float(ri[L.IM_INTR_REWARD])
+                metrics['extr_reward'] = float(ri[L.IM_EXTR_REWARD])
+        return metrics
+
+    def update(self, replay_iter, step):
+        if self.obs_type == 'pixels':
+            if step % self.update_every_steps != 0:
+                return dict()
+            return self._update_pixels(replay_iter, step)
+        return super().update(replay_iter, step)
 
 
 _ENC_KEYS = [f'convnet.{i}.{w}' for i in (0, 2, 4, 6) for w in ('weight', 'bias')]
 _PIX_ACTOR_KEYS = ['trunk.0.weight', 'trunk.0.bias', 'trunk.1.weight', 'trunk.1.bias'] + [f'policy.{i}.{w}' for i in (0, 2, 4) for w in ('weight', 'bias')]
 _PIX_CRITIC_KEYS = (['trunk.0.weight', 'trunk.0.bias', 'trunk.1.weight', 'trunk.1.bias'] +
                     [f'{q}.{i}.{w}' for q in ('Q1', 'Q2') for i in (0, 2, 4) for w in ('weight', 'bias')])
+
+
+class _ParamList(NetView):
+    """A NetView over explicit tensors (encoder_target: a Polyak copy that lives outside the engine's net table)."""
+
+    def __init__(self, keys, tensors):
+        self._engine, self._net, self._keys, self._on_change = None, None, list(keys), None
+        self.training = True
+        self._params = list(tensors)
 
 
 class _PixelNetView(NetView):

@@ -1017,7 +1017,7 @@ static int launch_l2norm(const float* x, float* y, float* nrm, int rows, int D, 
     return 0;
 }
 
-static int proto_update(exorl_intr* it, const exorl_intr_batch& b, bool train, hipStream_t s) {
+static int proto_update(exorl_intr* it, const exorl_intr_batch& b, bool train, hipStream_t s, bool want_reward = true) {
     const auto& c = it->cfg;
     const int B = c.batch, O = c.obs_dim, D = c.rep_dim, P = c.num_protos, prec = c.precision;
     float* Pm = it->flat[EXORL_T_PARAM];
@@ -1033,7 +1033,9 @@ static int proto_update(exorl_intr* it, const exorl_intr_batch& b, bool train, h
         GemmProblem ps{it->sn, C, it->scores_s, nullptr, B, P, D, D, D, P};
         EXORL_TRY(gemm_grouped(prec, 0, 0, &ps, 1, false, false, s));
         // target branch (no gradient): predictor_target on next_obs, Sinkhorn assignment
-        GemmProblem pt{b.next_obs, Pm + it->pred_t.W, it->tn, Pm + it->pred_t.b, B, D, O, b.next_obs_ld, O, D};
+        const float* nt = b.next_obs_target ? b.next_obs_target : b.next_obs;
+        const int64_t nt_ld = b.next_obs_target ? b.next_obs_target_ld : b.next_obs_ld;
+        GemmProblem pt{nt, Pm + it->pred_t.W, it->tn, Pm + it->pred_t.b, B, D, O, nt_ld, O, D};
         EXORL_TRY(gemm_grouped(prec, 0, 0, &pt, 1, false, false, s));
         EXORL_TRY(launch_l2norm(it->tn, it->tn, nullptr, B, D, s));
         GemmProblem pq{it->tn, C, it->scores_t, nullptr, B, P, D, D, D, P};
@@ -1062,8 +1064,15 @@ static int proto_update(exorl_intr* it, const exorl_intr_batch& b, bool train, h
         EXORL_TRY(colsum(it->dz1, G + it->pred.b, B, D, 1, 0, 0, s));
         GemmProblem gw{it->dz1, b.obs, G + it->pred.W, nullptr, D, O, B, D, b.obs_ld, O};
         EXORL_TRY(gemm_grouped(prec, 1, 1, &gw, 1, false, false, s));
+        if (b.dobs_out) {                      // d(loss)/d(obs) = dz1 Wp, before Wp moves: the caller's encoder continues the backward pass
+            GemmProblem gx{it->dz1, Pm + it->pred.W, b.dobs_out, nullptr, B, O, D, D, O, O};
+            EXORL_TRY(gemm_grouped(prec, 0, 1, &gx, 1, false, false, s));
+        }
         EXORL_TRY(intr_adam(it, s));
+        // utils.soft_update_params(predictor, predictor_target, encoder_target_tau) (proto.py:202-203): nothing reads the target before the next update
+        EXORL_TRY(soft_update(Pm + it->pred.W, Pm + it->pred_t.W, it->pred_t.b + round_up(c.rep_dim, 4) - it->pred_t.W, c.target_tau, s));
     }
+    if (!want_reward) return 0;
     // compute_intr_reward(next_obs) (proto.py:103-124)
     EXORL_TRY(launch_l2norm(C, C, nullptr, P, D, s));
     GemmProblem pz{b.next_obs, Pm + it->pred.W, it->sn, Pm + it->pred.b, B, D, O, b.next_obs_ld, O, D};
@@ -1078,8 +1087,6 @@ static int proto_update(exorl_intr* it, const exorl_intr_batch& b, bool train, h
     EXORL_TRY(exorl_knn_topk(it->sn, B, it->queue, c.queue_size, D, c.knn_k, it->topk, s));
     hipLaunchKernelGGL(kth_reward_kernel, dim3(1), dim3(1024), 0, s, it->topk, b.extr_reward, b.reward_out, B, c.knn_k, it->metrics);
     EXORL_LAUNCH_CHECK();
-    if (train)                                     // utils.soft_update_params(predictor, predictor_target, encoder_target_tau) (proto.py:202-203)
-        EXORL_TRY(soft_update(Pm + it->pred.W, Pm + it->pred_t.W, it->pred_t.b + round_up(c.rep_dim, 4) - it->pred_t.W, c.target_tau, s));
     return 0;
 }
 
@@ -1200,7 +1207,7 @@ int exorl_intr_update(exorl_intr_t* it, const exorl_intr_batch* b, int32_t train
         case EXORL_INTR_ICM: return icm_update(it, *b, train != 0, s);
         case EXORL_INTR_ICM_APT: return apt_update(it, *b, train != 0, s);
         case EXORL_INTR_DISAGREEMENT: return disagreement_update(it, *b, train != 0, s);
-        case EXORL_INTR_PROTO: return proto_update(it, *b, train != 0, s);
+        case EXORL_INTR_PROTO: return proto_update(it, *b, train != 0, s, train != 2);
         case EXORL_INTR_APS: return aps_update(it, *b, train != 0, s);
         case EXORL_INTR_SMM: return smm_update(it, *b, train != 0, s);
         default: return diayn_update(it, *b, train != 0, s);

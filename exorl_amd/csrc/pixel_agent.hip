@@ -93,6 +93,11 @@ struct exorl_pixel_agent {
     float* act_ws = nullptr;                     // B = 1 inference scratch
     int64_t t = 0;
     uint64_t noise_counter = 0, aug_counter = 0, act_counter = 0;
+    // Proto on pixels (proto.py:46-85): encoder_target (Polyak copy) and the encoder's second Adam state (proto_opt's)
+    float *enc_target = nullptr, *enc_m2 = nullptr, *enc_v2 = nullptr;
+    int64_t t2 = 0;
+    bool augmented = false;
+    bool train_encoder = true;      // false: update_critic received obs.detach() (proto.py:190-193): encoder_opt.step() finds no gradients
 };
 
 namespace exorl {
@@ -120,6 +125,7 @@ static void pcarve(exorl_pixel_agent* a, PCarver& c) {
     for (int w = 0; w < 4; ++w) a->flat[1][w] = c.take(a->actor.total);
     for (int w = 0; w < 4; ++w) a->flat[2][w] = c.take(a->critic.total);
     a->flat[3][0] = c.take(a->critic.total);
+    a->enc_target = c.take(a->enc_total); a->enc_m2 = c.take(a->enc_total); a->enc_v2 = c.take(a->enc_total);
     a->obs = reinterpret_cast<unsigned char*>(c.take((B * img + 3) / 4));
     a->next_obs = reinterpret_cast<unsigned char*>(c.take((B * img + 3) / 4));
     a->action = c.take(B * A); a->reward = c.take(B); a->discount = c.take(B);
@@ -299,20 +305,74 @@ int exorl_pixel_agent_batch_slots(exorl_pixel_agent_t* a, exorl_batch_out* out) 
 
 // One DDPG update on the batch in the slots. shifts_*: (B,2) int32 augmentation shifts (utils.py:244-248) or null -> Philox;
 // noise_*: (B,A) standard normals for the two TruncatedNormal draws (critic target first, actor second) or null -> Philox.
+// RandomShiftsAug of obs and next_obs (ddpg.py:213-215; proto.py:168-170 augments once and encodes several times)
+int exorl_pixel_agent_augment(exorl_pixel_agent_t* a, const int32_t* shifts_obs, const int32_t* shifts_next, void* stream) {
+    EXORL_REQUIRE(a, "pixel_agent_augment: null handle");
+    hipStream_t s = as_stream(stream);
+    const auto& c = a->cfg;
+    EXORL_TRY(exorl_aug_shift(a->obs, c.batch, c.c_in, c.hw, 4, shifts_obs, c.seed, 2 * a->aug_counter, a->aug_o, s));
+    EXORL_TRY(exorl_aug_shift(a->next_obs, c.batch, c.c_in, c.hw, 4, shifts_next, c.seed, 2 * a->aug_counter + 1, a->aug_n, s));
+    a->aug_counter += 1;
+    a->augmented = true;
+    return 0;
+}
+
+// encoder (target != 0: encoder_target) on the augmented obs (which == 0) or next_obs (which == 1); *feat_out_dev -> (batch, repr_dim)
+int exorl_pixel_agent_encode(exorl_pixel_agent_t* a, int32_t which, int32_t target, float** feat_out_dev, void* stream) {
+    EXORL_REQUIRE(a && feat_out_dev && a->augmented && (which == 0 || which == 1), "pixel_agent_encode: bad arguments (augment first)");
+    const auto& c = a->cfg;
+    return exorl_encoder_forward(target ? a->enc_target : a->flat[0][0], c.c_in, c.hw, which ? a->aug_n : a->aug_o, c.batch, which ? a->enc_ws_n : a->enc_ws_o,
+                                 feat_out_dev, stream);
+}
+
+// Backward through the encoder pass last run by exorl_pixel_agent_encode(which, 0) from dfeat_dev (batch, repr_dim; overwritten), then
+// one Adam step of the encoder with optimiser state `opt` (0: encoder_opt, ddpg.py:188-190; 1: the encoder's slots in proto_opt, proto.py:75-78)
+int exorl_pixel_agent_encoder_step(exorl_pixel_agent_t* a, int32_t which, float* dfeat_dev, int32_t opt, void* stream) {
+    EXORL_REQUIRE(a && dfeat_dev && (which == 0 || which == 1) && (opt == 0 || opt == 1), "pixel_agent_encoder_step: bad arguments");
+    hipStream_t s = as_stream(stream);
+    const auto& c = a->cfg;
+    EXORL_TRY(exorl_encoder_backward(a->flat[0][0], c.c_in, c.hw, which ? a->aug_n : a->aug_o, c.batch, which ? a->enc_ws_n : a->enc_ws_o, dfeat_dev,
+                                     a->flat[0][1], s));
+    if (opt == 0) { a->t += 1; return padam(a, 0, a->enc_total, nullptr, s); }
+    a->t2 += 1;
+    return adam_step(a->flat[0][0], a->flat[0][1], a->enc_m2, a->enc_v2, a->enc_total, c.lr, 0.9f, 0.999f, 1e-8f, a->t2, nullptr, 0.f, s);
+}
+
+// encoder_target: init != 0 copies the encoder (deepcopy at construction), else Polyak with rate tau (proto.py:200-201)
+int exorl_pixel_agent_encoder_target(exorl_pixel_agent_t* a, float tau, int32_t init, void* stream) {
+    EXORL_REQUIRE(a, "pixel_agent_encoder_target: null handle");
+    if (init) {
+        EXORL_CHECK_HIP(hipMemcpyAsync(a->enc_target, a->flat[0][0], a->enc_total * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)));
+        return 0;
+    }
+    return soft_update(a->flat[0][0], a->enc_target, a->enc_total, tau, as_stream(stream));
+}
+
+int exorl_pixel_agent_set_train_encoder(exorl_pixel_agent_t* a, int32_t enable) {
+    EXORL_REQUIRE(a, "pixel_agent_set_train_encoder: null handle");
+    a->train_encoder = enable != 0;
+    return 0;
+}
+
+int exorl_pixel_agent_encoder_target_ptr(exorl_pixel_agent_t* a, void** ptr_dev) {
+    EXORL_REQUIRE(a && ptr_dev, "pixel_agent_encoder_target_ptr: null argument");
+    *ptr_dev = a->enc_target;
+    return 0;
+}
+
 int exorl_pixel_agent_update(exorl_pixel_agent_t* a, float stddev, const int32_t* shifts_obs, const int32_t* shifts_next, const float* noise_c,
                              const float* noise_a, void* stream) {
     EXORL_REQUIRE(a && stddev > 0.f, "pixel_agent_update: bad arguments");
     hipStream_t s = as_stream(stream);
     const auto& c = a->cfg;
-    const int B = c.batch, A = c.act_dim, F = c.feature_dim, R = a->R, FA = F + A, prec = c.precision;
+    const int B = c.batch, A = c.act_dim, F = c.feature_dim, FA = F + A, prec = c.precision;
     const float inv_b = 1.0f / (float)B;
     float *Pe = a->flat[0][0], *Pa = a->flat[1][0], *Pc = a->flat[2][0], *Pt = a->flat[3][0];
     float *Ge = a->flat[0][1], *Ga = a->flat[1][1], *Gc = a->flat[2][1];
     a->t += 1;
-    // ---- aug_and_encode (ddpg.py:213-215, 312-315)
-    EXORL_TRY(exorl_aug_shift(a->obs, B, c.c_in, c.hw, 4, shifts_obs, c.seed, 2 * a->aug_counter, a->aug_o, s));
-    EXORL_TRY(exorl_aug_shift(a->next_obs, B, c.c_in, c.hw, 4, shifts_next, c.seed, 2 * a->aug_counter + 1, a->aug_n, s));
-    a->aug_counter += 1;
+    // ---- aug_and_encode (ddpg.py:213-215, 312-315); shifts_obs == (const int32_t*)-1: keep the images exorl_pixel_agent_augment made
+    if (shifts_obs != reinterpret_cast<const int32_t*>(-1)) EXORL_TRY(exorl_pixel_agent_augment(a, shifts_obs, shifts_next, stream));
+    EXORL_REQUIRE(a->augmented, "pixel_agent_update: no augmented batch");
     EXORL_TRY(exorl_encoder_forward(Pe, c.c_in, c.hw, a->aug_o, B, a->enc_ws_o, &a->feat_o, s));
     EXORL_TRY(exorl_encoder_forward(Pe, c.c_in, c.hw, a->aug_n, B, a->enc_ws_n, &a->feat_n, s));
     // ---- update_critic (ddpg.py:240-268)
@@ -336,10 +396,10 @@ int exorl_pixel_agent_update(exorl_pixel_agent_t* a, float stddev, const int32_t
     for (int i = 0; i < 2; ++i) EXORL_TRY(mlp_backward(a->critic.head[i], Pc, Gc, a->xq_c, FA, B, a->dxq[i], prec, s));
     hipLaunchKernelGGL(add_cols_kernel, dim3(grid1((int64_t)B * F)), dim3(256), 0, s, a->dxq[0], (int64_t)FA, a->dxq[1], (int64_t)FA, 0, F, a->dh, B);
     EXORL_LAUNCH_CHECK();
-    EXORL_TRY(trunk_backward(a, a->critic, Pc, Gc, a->feat_o, B, a->tc, a->dh, a->dfeat, prec, s));
-    EXORL_TRY(exorl_encoder_backward(Pe, c.c_in, c.hw, a->aug_o, B, a->enc_ws_o, a->dfeat, Ge, s));
+    EXORL_TRY(trunk_backward(a, a->critic, Pc, Gc, a->feat_o, B, a->tc, a->dh, a->train_encoder ? a->dfeat : nullptr, prec, s));
+    if (a->train_encoder) EXORL_TRY(exorl_encoder_backward(Pe, c.c_in, c.hw, a->aug_o, B, a->enc_ws_o, a->dfeat, Ge, s));
     EXORL_TRY(padam(a, 2, a->critic.total, nullptr, s));
-    EXORL_TRY(padam(a, 0, a->enc_total, nullptr, s));
+    if (a->train_encoder) EXORL_TRY(padam(a, 0, a->enc_total, nullptr, s));
     // ---- update_actor (ddpg.py:270-292) on obs.detach(): the encoding computed above, the critic just updated
     EXORL_TRY(trunk_forward(a, a->actor, Pa, a->feat_o, B, a->ta_o, prec, s));
     EXORL_TRY(mlp_forward(pol, Pa, a->ta_o.h, F, B, prec, s));

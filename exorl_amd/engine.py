@@ -252,11 +252,11 @@ class IntrEngine:
         self._rms.copy_(torch.from_numpy(raw))
 
     def update(self, obs, action, next_obs, extr_reward, reward_out, train=True, skill=None, obs_ld=None, action_ld=None,
-               next_obs_ld=None, skill_ld=0, cat_uniform=None):
-        """Device pointers (ints) + row strides in floats; see exorl_intr_batch."""
+               next_obs_ld=None, skill_ld=0, cat_uniform=None, next_obs_target=None, dobs_out=None):
+        """Device pointers (ints) + row strides in floats; see exorl_intr_batch. train: True/1, False/0, or 2 (optimiser step only)."""
         b = L.IntrBatch(obs, obs_ld or self.obs_dim, action, action_ld or self.act_dim, next_obs, next_obs_ld or self.obs_dim,
-                        skill, skill_ld, extr_reward, reward_out, cat_uniform)
-        L.check(self.lib.exorl_intr_update(self.h, C.byref(b), int(bool(train)), L.current_stream()))
+                        skill, skill_ld, extr_reward, reward_out, next_obs_target, self.obs_dim, dobs_out, cat_uniform)
+        L.check(self.lib.exorl_intr_update(self.h, C.byref(b), 2 if train == 2 else int(bool(train)), L.current_stream()))
 
     def metrics_raw(self):
         host = np.zeros(L.N_INTR_METRICS, np.float32)
@@ -341,12 +341,47 @@ class PixelEngine:
         L.check(self.lib.exorl_pixel_agent_set_batch(self.h, *[t.data_ptr() for t in ts], L.current_stream()))
         self._keep = ts
 
-    def update(self, stddev, shifts_obs=None, shifts_next=None, noise_critic=None, noise_actor=None):
-        i32 = lambda x: None if x is None else torch.as_tensor(np.ascontiguousarray(x, np.int32)).to(self.device)
+    def _i32(self, x):
+        return None if x is None else torch.as_tensor(np.ascontiguousarray(x, np.int32)).to(self.device)
+
+    def update(self, stddev, shifts_obs=None, shifts_next=None, noise_critic=None, noise_actor=None, keep_augmented=False):
         f32 = lambda x: None if x is None else self._f(x)
-        ts = [i32(shifts_obs), i32(shifts_next), f32(noise_critic), f32(noise_actor)]
-        L.check(self.lib.exorl_pixel_agent_update(self.h, stddev, *[L.ptr(t) for t in ts], L.current_stream()))
+        ts = [self._i32(shifts_obs), self._i32(shifts_next), f32(noise_critic), f32(noise_actor)]
+        ptrs = [L.ptr(t) for t in ts]
+        if keep_augmented:                  # reuse the images exorl_pixel_agent_augment made (sentinel pointer, see the header)
+            ptrs[0] = C.c_void_p(-1)
+        L.check(self.lib.exorl_pixel_agent_update(self.h, stddev, *ptrs, L.current_stream()))
         self._keep_u = ts
+
+    def augment(self, shifts_obs=None, shifts_next=None):
+        ts = [self._i32(shifts_obs), self._i32(shifts_next)]
+        L.check(self.lib.exorl_pixel_agent_augment(self.h, L.ptr(ts[0]), L.ptr(ts[1]), L.current_stream()))
+        self._keep_s = ts
+
+    def encode(self, which, target=False):
+        """Device pointer of the (batch, repr_dim) features of the augmented obs (which=0) / next_obs (1)."""
+        p = C.c_void_p()
+        L.check(self.lib.exorl_pixel_agent_encode(self.h, which, int(bool(target)), C.byref(p), L.current_stream()))
+        return p.value
+
+    def encoder_step(self, which, dfeat_ptr, opt):
+        L.check(self.lib.exorl_pixel_agent_encoder_step(self.h, which, dfeat_ptr, opt, L.current_stream()))
+
+    def encoder_target(self, tau=0.0, init=False):
+        L.check(self.lib.exorl_pixel_agent_encoder_target(self.h, tau, int(bool(init)), L.current_stream()))
+
+    def encoder_target_tensors(self, shapes):
+        p = C.c_void_p()
+        L.check(self.lib.exorl_pixel_agent_encoder_target_ptr(self.h, C.byref(p)))
+        out, off = [], 0
+        for shp in shapes:
+            n = int(np.prod(shp))
+            out.append(self._view(p.value + 4 * off, n).view(*shp))
+            off += (n + 3) // 4 * 4
+        return out
+
+    def set_train_encoder(self, enable):
+        L.check(self.lib.exorl_pixel_agent_set_train_encoder(self.h, int(bool(enable))))
 
     def metrics_raw(self):
         host = np.zeros(L.N_METRICS, np.float32)

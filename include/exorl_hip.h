@@ -334,12 +334,17 @@ typedef struct exorl_intr_batch {
     const float* skill;    int64_t skill_ld;
     const float* extr_reward;
     float* reward_out;
+    const float* next_obs_target; int64_t next_obs_target_ld;   /* Proto on pixels: encoder_target(next_obs) for the Sinkhorn branch
+                                                                   (proto.py:144-148); null -> next_obs */
+    float* dobs_out;            /* Proto: if set, receives d(loss)/d(obs rows) (batch, obs_dim) so the caller can continue the backward pass
+                                   into its encoder (proto_opt owns the encoder's parameters too, proto.py:75-78) */
     const float* cat_uniform;   /* Proto: num_protos uniforms in [0,1) for Categorical(prob).sample() (proto.py:112); SMM: the VAE's
                                    epsilon, (batch, 128) standard normals (smm.py:62); null -> Philox */
 } exorl_intr_batch;
 /* train != 0: the module's optimiser step (update_rnd / update_icm / update_disagreement / update_diayn) then
  * compute_intr_reward under the updated module (rnd.py:121-124, icm.py:106-110, icm_apt.py:123-127, disagreement.py:106-112,
- * diayn.py:143-147); train == 0: compute_intr_reward only. */
+ * diayn.py:143-147); train == 0: compute_intr_reward only; train == 2 (Proto): the optimiser step only — with an encoder in front
+ * the reward is computed from features re-encoded after that step (proto.py:173-177). */
 int exorl_intr_update(exorl_intr_t* m, const exorl_intr_batch* batch, int32_t train, void* stream);
 int exorl_intr_metrics(exorl_intr_t* m, float* host_out /* EXORL_N_INTR_METRICS */, void* stream);
 /* optimiser step count of the module's Adam: set == 0 reads into *steps, else writes it (snapshot restore) */
@@ -399,6 +404,17 @@ int exorl_pixel_agent_set_batch(exorl_pixel_agent_t* a, const unsigned char* obs
 int exorl_pixel_agent_update(exorl_pixel_agent_t* a, float stddev, const int32_t* shifts_obs_dev, const int32_t* shifts_next_dev,
                              const float* noise_critic_dev, const float* noise_actor_dev, void* stream);
 int exorl_pixel_agent_metrics(exorl_pixel_agent_t* a, float* host_out /* EXORL_N_METRICS */, void* stream);
+/* Primitives for agents that put a module between augmentation and the DDPG step (Proto on pixels, proto.py:159-207): augment once,
+ * encode with the online or the target encoder, push a feature gradient back through the encoder with a chosen optimiser state,
+ * maintain encoder_target; exorl_pixel_agent_update with shifts_obs_dev == (const int32_t*)-1 then reuses the augmented batch. */
+int exorl_pixel_agent_augment(exorl_pixel_agent_t* a, const int32_t* shifts_obs_dev, const int32_t* shifts_next_dev, void* stream);
+int exorl_pixel_agent_encode(exorl_pixel_agent_t* a, int32_t which, int32_t target, float** feat_out_dev, void* stream);
+int exorl_pixel_agent_encoder_step(exorl_pixel_agent_t* a, int32_t which, float* dfeat_dev, int32_t opt, void* stream);
+int exorl_pixel_agent_encoder_target(exorl_pixel_agent_t* a, float tau, int32_t init, void* stream);
+int exorl_pixel_agent_encoder_target_ptr(exorl_pixel_agent_t* a, void** ptr_dev);
+/* enable == 0: update() treats the encoding as detached in update_critic (what the reward-free agents pass, proto.py:190-193):
+ * no encoder backward, encoder_opt does not step. Default 1 (plain DDPG, ddpg.py:316-319). */
+int exorl_pixel_agent_set_train_encoder(exorl_pixel_agent_t* a, int32_t enable);
 int exorl_pixel_agent_act(exorl_pixel_agent_t* a, const unsigned char* obs_dev, float stddev, int32_t eval_mode, const float* noise_dev,
                           float* action_out_dev, void* stream);
 

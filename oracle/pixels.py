@@ -176,7 +176,9 @@ class OraclePixelDDPG:
         gt, dfeat = self.nets.Trunk.bwd(p[0:4], c1, dx[:, :F], need_dfeat)
         return gt + g1 + g2, dfeat, dx[:, F:]
 
-    def update(self, batch, step, shifts_obs, shifts_next, noise_c, noise_a):
+    def update(self, batch, step, shifts_obs, shifts_next, noise_c, noise_a, train_encoder=True):
+        """train_encoder=False: the caller passed obs.detach() to update_critic (proto.py:190-193 and the other reward-free agents), so
+        encoder_opt.step() finds no gradients and the encoder does not move."""
         if step % self.every != 0:
             return {}
         obs, action, reward, discount, next_obs = batch[:5]
@@ -194,11 +196,13 @@ class OraclePixelDDPG:
         e1, e2 = (q1 - y).astype(F32), (q2 - y).astype(F32)
         m = dict(batch_reward=float(reward.mean(dtype=F32)), critic_target_q=float(y.mean(dtype=F32)), critic_q1=float(q1.mean(dtype=F32)),
                  critic_q2=float(q2.mean(dtype=F32)), critic_loss=float(((e1 * e1).sum(dtype=F32) + (e2 * e2).sum(dtype=F32)) / F32(B)))
-        gc, dfeat, _ = self._critic_bwd(self.critic, cc, (F32(2) * e1 / F32(B)).astype(F32), (F32(2) * e2 / F32(B)).astype(F32), True)
-        ge, _ = encoder_bwd(self.enc, ecache, dfeat)
-        self.last_critic_grads, self.last_enc_grads = gc, ge
+        gc, dfeat, _ = self._critic_bwd(self.critic, cc, (F32(2) * e1 / F32(B)).astype(F32), (F32(2) * e2 / F32(B)).astype(F32), train_encoder)
+        self.last_critic_grads = gc
         self.critic_opt.step(self.critic, gc)
-        self.enc_opt.step(self.enc, ge)
+        if train_encoder:
+            ge, _ = encoder_bwd(self.enc, ecache, dfeat)
+            self.last_enc_grads = ge
+            self.enc_opt.step(self.enc, ge)
         # update_actor (ddpg.py:270-292) on obs.detach()
         mu, (c1, acts) = self._actor(fo)
         a = nets.truncated_normal_sample(mu, noise_a, self.std, self.clip)
@@ -215,4 +219,34 @@ class OraclePixelDDPG:
         m.update(actor_loss=float(-np.minimum(q1, q2).mean(dtype=F32)), actor_ent=float(nets.normal_entropy(self.std) * A),
                  actor_logprob=float(nets.normal_log_prob(a, mu, self.std).sum(dtype=F32) / F32(B)))
         nets.soft_update(self.critic, self.critic_target, self.tau)
+        return m
+
+
+class OracleProtoPixels:
+    """ProtoAgent.update with obs_type='pixels' (proto.py:159-207): augment once; update_proto through encoder(obs) with the encoder in
+    proto_opt and encoder_target(next_obs) in the Sinkhorn branch; reward from encoder(next_obs) AFTER that step; DDPG update (the
+    encoder also steps with encoder_opt on the critic loss); Polyak updates of encoder_target, predictor_target, critic_target."""
+
+    def __init__(self, ddpg, proto, encoder_target_tau=0.05, lr=1e-4):
+        self.ddpg, self.proto, self.ttau = ddpg, proto, encoder_target_tau
+        self.enc_t = [p.copy() for p in ddpg.enc]
+        self.proto_enc_opt = ddpg.nets.Adam(ddpg.enc, lr)            # the encoder's slots in proto_opt: a second Adam state
+
+    def update(self, batch, step, shifts_obs, shifts_next, u_cat, noise_c, noise_a):
+        if step % self.ddpg.every != 0:
+            return {}
+        obs, action, extr, discount, next_obs = batch[:5]
+        ao, an = random_shifts_aug(obs, shifts_obs), random_shifts_aug(next_obs, shifts_next)
+        fo, ecache = encoder_fwd(self.ddpg.enc, ao)
+        ft, _ = encoder_fwd(self.enc_t, an)
+        loss = self.proto.update(fo, ft)
+        ge, _ = encoder_bwd(self.ddpg.enc, ecache, self.proto.last_dobs)
+        self.proto_enc_opt.step(self.ddpg.enc, ge)
+        fn, _ = encoder_fwd(self.ddpg.enc, an)
+        intr = self.proto.reward(fn, u_cat)
+        self.last_intr = intr
+        m = self.ddpg.update((obs, action, intr, discount, next_obs), step, shifts_obs, shifts_next, noise_c, noise_a, train_encoder=False)
+        self.ddpg.nets.soft_update(self.ddpg.enc, self.enc_t, self.ttau)
+        self.proto.soft_update()
+        m.update(repr_loss=loss, intr_reward=float(intr.mean(dtype=F32)), extr_reward=float(np.asarray(extr, F32).mean(dtype=F32)))
         return m

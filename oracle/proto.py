@@ -92,6 +92,7 @@ class OracleProto:
         ds = l2_normalize_bwd(dsn, sn, nrm)
         gproj, dz1 = mlp_bwd(self.p[2:6], acts, ds, need_dx=True)
         dW, db, _ = linear_bwd(obs, self.p[0], dz1, need_dx=False)
+        self.last_dobs = (dz1 @ self.p[0]).astype(F32)        # d(loss)/d(obs): continues into the encoder on pixels (proto.py:75-78,131)
         self.last_grads = [dW, db] + gproj + [dC]
         self.opt.step(self.p, self.last_grads)
         return float(loss)

@@ -190,3 +190,44 @@ def test_pixel_ddpg_batch_vs_oracle():
             # second-step gradients: the two sides' weights already differ by Adam's rounding-noise moves, and ReLU pre-activations
             # next to zero (about 1.5 M of them per image batch here) fall on different sides
             np.testing.assert_allclose(got, want, rtol=5e-3, atol=3e-2 * np.abs(want).max() + 1e-9)
+
+
+def test_pixel_proto_vs_reference(gold):
+    """Proto on pixels (BASELINE config 4 in miniature): 3 update() calls of the reference agent (tests/golden/pixel_proto.npz)."""
+    import _synth
+    from exorl_amd import agents
+    z = np.load(gold / 'pixel_proto.npz')
+    C_, HW, A, F, H, B, N, PD, PJ, Q, NP = [int(v) for v in z['dims']]
+    ag = agents.ProtoAgent(pred_dim=PD, proj_dim=PJ, queue_size=Q, num_protos=NP, tau=0.1, encoder_target_tau=0.05, topk=3, update_encoder=True,
+                           name='proto', reward_free=True, obs_type='pixels', obs_shape=(C_, HW, HW), action_shape=(A,), device='cuda', lr=1e-4,
+                           feature_dim=F, hidden_dim=H, critic_target_tau=0.01, num_expl_steps=2000, update_every_steps=2, stddev_schedule=0.2,
+                           nstep=3, batch_size=B, stddev_clip=0.3, init_critic=True, use_tb=True, use_wandb=False)
+    load_pixel_params(ag, C_, A, F, H)
+    psh = [[('weight', (PD, 39200)), ('bias', (PD,))], [('trunk.0.weight', (PJ, PD)), ('trunk.0.bias', (PJ,)), ('trunk.2.weight', (PD, PJ)), ('trunk.2.bias', (PD,))],
+           [('weight', (NP, PD))]]
+    for i, (view, sh) in enumerate(zip((ag.predictor, ag.projector, ag.protos), psh)):
+        view.load_state_dict({k: torch.from_numpy(v) for k, v in _synth.synth_params(sh, 53 + i).items()})
+    utils_hard = lambda src, dst: [t.copy_(p) for p, t in zip(src.parameters(), dst.parameters())]
+    utils_hard(ag.predictor, ag.predictor_target)
+    ag.engine.encoder_target(init=True)
+    noise = _synth.NoiseStream(21)
+    shifts, us = iter(z['shifts']), iter(z['cat_uniform'])
+    ag.noise_hook = noise.draw
+    ag.shift_hook = lambda n: next(shifts)
+    ag.cat_hook = lambda n: next(us)
+    keys = [str(k) for k in z['metric_keys']]
+    for i in range(N):
+        batch = (z[f'batch/{i}/obs'], z[f'batch/{i}/action'], z[f'batch/{i}/reward'], z[f'batch/{i}/discount'], z[f'batch/{i}/next_obs'])
+        m = ag.update(iter([batch]), 2 * i)
+        assert sorted(m.keys()) == keys
+        np.testing.assert_allclose(np.array([m[k] for k in keys]), z['metrics'][i], rtol=2e-4, atol=3e-6, err_msg=f'step {i} {keys}')
+    for nm, view in (('encoder', ag.encoder), ('encoder_target', ag.encoder_target), ('critic', ag.critic), ('protos', ag.protos),
+                     ('projector', ag.projector), ('predictor_target', ag.predictor_target)):
+        for k, v in view.state_dict().items():
+            v = v.cpu().numpy()
+            if f'final/{nm}/{k}' in z.files:
+                np.testing.assert_allclose(v, z[f'final/{nm}/{k}'], rtol=1e-4, atol=2e-6, err_msg=f'{nm}.{k}')
+            else:
+                np.testing.assert_allclose(v.reshape(-1)[::997], z[f'final_sample/{nm}/{k}'], rtol=1e-4, atol=2e-6, err_msg=f'{nm}.{k}')
+    np.testing.assert_allclose(ag.queue.cpu().numpy(), z['final/queue'], rtol=1e-4, atol=1e-6)
+    assert ag.queue_ptr == int(z['final/queue_ptr'])

@@ -60,3 +60,36 @@ def test_pixel_ddpg_trajectory(gold):
                 np.testing.assert_allclose(p, z[f'final/{nm}/{k}'], rtol=1e-4, atol=2e-6, err_msg=f'{nm}.{k}')
             else:
                 np.testing.assert_allclose(p.reshape(-1)[::997], z[f'final_sample/{nm}/{k}'], rtol=1e-4, atol=2e-6, err_msg=f'{nm}.{k}')
+
+
+def _proto_pixel_oracle(z):
+    import _synth
+    from oracle.proto import OracleProto
+    C, HW, A, F, H, B, N, PD, PJ, Q, NP = [int(v) for v in z['dims']]
+    esh, ash, csh = pixels.pixel_param_shapes(C, A, F, H)
+    psh = [[('weight', (PD, 39200)), ('bias', (PD,))], [('trunk.0.weight', (PJ, PD)), ('trunk.0.bias', (PJ,)), ('trunk.2.weight', (PD, PJ)), ('trunk.2.bias', (PD,))],
+           [('weight', (NP, PD))]]
+    enc, actor, critic = [list(_synth.synth_params(sh, 50 + i).values()) for i, sh in enumerate((esh, ash, csh))]
+    pp = [v for i, sh in enumerate(psh) for v in _synth.synth_params(sh, 53 + i).values()]
+    ddpg = pixels.OraclePixelDDPG(enc, actor, critic)
+    return pixels.OracleProtoPixels(ddpg, OracleProto(pp, queue_size=Q)), (C, HW, A, F, H, B, N, PD, PJ, Q, NP), (esh, ash, csh)
+
+
+def test_pixel_proto_trajectory(gold):
+    """Oracle Proto-on-pixels (BASELINE config 4 in miniature) vs 3 update() calls of the reference agent."""
+    import _synth
+    z = np.load(gold / 'pixel_proto.npz')
+    ag, (C, HW, A, F, H, B, N, PD, PJ, Q, NP), (esh, ash, csh) = _proto_pixel_oracle(z)
+    noise = _synth.NoiseStream(21)
+    keys = [str(k) for k in z['metric_keys']]
+    for i in range(N):
+        batch = (z[f'batch/{i}/obs'], z[f'batch/{i}/action'], z[f'batch/{i}/reward'], z[f'batch/{i}/discount'], z[f'batch/{i}/next_obs'])
+        m = ag.update(batch, 2 * i, z['shifts'][2 * i], z['shifts'][2 * i + 1], z['cat_uniform'][i], noise.draw((B, A)), noise.draw((B, A)))
+        got = np.array([m[k] for k in keys])
+        np.testing.assert_allclose(got, z['metrics'][i], rtol=1e-4, atol=2e-6, err_msg=f'step {i} {keys}')
+    for (k, _), p, t in zip(esh, ag.ddpg.enc, ag.enc_t):
+        np.testing.assert_allclose(p, z[f'final/encoder/{k}'], rtol=1e-4, atol=2e-6, err_msg=k)
+        np.testing.assert_allclose(t, z[f'final/encoder_target/{k}'], rtol=1e-4, atol=2e-6, err_msg=k)
+    np.testing.assert_allclose(ag.proto.p[6], z['final/protos/weight'], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(ag.proto.queue, z['final/queue'], rtol=1e-4, atol=1e-6)
+    assert ag.proto.queue_ptr == int(z['final/queue_ptr'])

@@ -268,6 +268,73 @@ def gen_pixel_ddpg(ref):
     print('pixel ddpg', keys, out['metrics'][-1])
 
 
+def gen_pixel_proto(ref):
+    """ProtoAgent with obs_type='pixels' (proto.py:46-207; BASELINE config 4 in miniature): 3 update() calls, B=4."""
+    import math
+    import torch.distributions as pyd
+    U = ref.utils
+    C, HW, A, F, H, B, N = 3, 84, 3, 16, 32, 4, 3
+    PD, PJ, Q, NP = 8, 16, 24, 6
+    torch.manual_seed(5)
+    agent = ref.proto.ProtoAgent(pred_dim=PD, proj_dim=PJ, queue_size=Q, num_protos=NP, tau=0.1, encoder_target_tau=0.05, topk=3, update_encoder=True,
+                                 name='proto', reward_free=True, obs_type='pixels', obs_shape=(C, HW, HW), action_shape=(A,), device='cpu', lr=1e-4,
+                                 feature_dim=F, hidden_dim=H, critic_target_tau=0.01, num_expl_steps=2000, update_every_steps=2,
+                                 stddev_schedule=0.2, nstep=3, batch_size=B, stddev_clip=0.3, init_critic=True, use_tb=True, use_wandb=False)
+    out = {'dims': np.array([C, HW, A, F, H, B, N, PD, PJ, Q, NP])}
+    mods = (('encoder', agent.encoder), ('actor', agent.actor), ('critic', agent.critic), ('predictor', agent.predictor),
+            ('projector', agent.projector), ('protos', agent.protos))
+    for i, (nm, net) in enumerate(mods):
+        shapes = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+        params = _synth.synth_params(shapes, 50 + i)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    agent.critic_target.load_state_dict(agent.critic.state_dict())
+    agent.encoder_target.load_state_dict(agent.encoder.state_dict())
+    agent.predictor_target.load_state_dict(agent.predictor.state_dict())
+    rs = np.random.RandomState(8)
+    shifts, noise, us = [], _synth.NoiseStream(21), []
+    o_sn, o_randint, o_cat = U._standard_normal, torch.randint, pyd.Categorical.sample
+
+    def p_randint(lo, hi, size, device=None, dtype=None):
+        sh = rs.randint(lo, hi, tuple(size))
+        shifts.append(sh.reshape(-1, 2).astype(np.int32))
+        return torch.from_numpy(sh).to(dtype)
+
+    def p_cat(self, sample_shape=torch.Size()):
+        u = rs.uniform(0, 1, self.probs.shape[0])
+        us.append(u)
+        cdf = torch.cumsum(self.probs.double(), dim=1).numpy()
+        idx = [min(int(np.searchsorted(cdf[i], u[i] * cdf[i, -1], side='right')), cdf.shape[1] - 1) for i in range(len(u))]
+        return torch.tensor(idx, dtype=torch.long)
+    U._standard_normal = lambda shape, dtype, device: torch.from_numpy(noise.draw(shape)).to(dtype)
+    torch.randint, pyd.Categorical.sample = p_randint, p_cat
+    metrics = []
+    try:
+        for i in range(N):
+            b = _synth.synth_batch(61, i, B, 4, A)
+            obs = rs.randint(0, 256, (B, C, HW, HW)).astype(np.uint8)
+            nobs = rs.randint(0, 256, (B, C, HW, HW)).astype(np.uint8)
+            out[f'batch/{i}/obs'], out[f'batch/{i}/next_obs'] = obs, nobs
+            out[f'batch/{i}/action'], out[f'batch/{i}/reward'], out[f'batch/{i}/discount'] = b[1], b[2], b[3]
+            m = agent.update(iter([(obs, b[1], b[2], b[3], nobs)]), 2 * i)
+            metrics.append({k: float(v) for k, v in m.items()})
+    finally:
+        U._standard_normal, torch.randint, pyd.Categorical.sample = o_sn, o_randint, o_cat
+    out['shifts'], out['cat_uniform'] = np.stack(shifts), np.stack(us)
+    keys = sorted(metrics[0].keys())
+    out['metric_keys'] = np.array(keys)
+    out['metrics'] = np.array([[m[k] for k in keys] for m in metrics], np.float64)
+    for nm, net in mods + (('critic_target', agent.critic_target), ('encoder_target', agent.encoder_target), ('predictor_target', agent.predictor_target)):
+        for k, v in net.state_dict().items():
+            v = v.numpy()
+            if v.size <= 20000:
+                out[f'final/{nm}/{k}'] = v.copy()
+            else:
+                out[f'final_sample/{nm}/{k}'] = v.reshape(-1)[::997].copy()
+    out['final/queue'], out['final/queue_ptr'] = agent.queue.numpy().copy(), np.array(agent.queue_ptr)
+    np.savez_compressed(GOLD / 'pixel_proto.npz', **out)
+    print('pixel proto', keys, out['metrics'][-1])
+
+
 # ----------------------------------------------------------------------------- agents (G3/G4)
 def make_agent(ref, kind, O, A, H, B, device='cpu', use_tb=True, **kw):
     if kind == 'td3_bc':
@@ -514,7 +581,7 @@ if __name__ == '__main__':
     args = ap.parse_args()
     GOLD.mkdir(parents=True, exist_ok=True)
     ref = load_reference()
-    todo = [args.only] if args.only else ['replay', 'utils', 'tiny', 'full', 'pixels', 'pixel_ddpg']
+    todo = [args.only] if args.only else ['replay', 'utils', 'tiny', 'full', 'pixels', 'pixel_ddpg', 'pixel_proto']
     kinds = args.kinds.split(',') if args.kinds else None
     if kinds:
         TINY_KINDS = tuple(k for k in TINY_KINDS if k.partition('-')[0] in kinds)
@@ -522,4 +589,4 @@ if __name__ == '__main__':
         if t == 'full':
             gen_full(ref, only_kinds=kinds)
         else:
-            {'replay': gen_replay, 'utils': gen_utils, 'tiny': gen_tiny, 'pixels': gen_pixels, 'pixel_ddpg': gen_pixel_ddpg}[t](ref)
+            {'replay': gen_replay, 'utils': gen_utils, 'tiny': gen_tiny, 'pixels': gen_pixels, 'pixel_ddpg': gen_pixel_ddpg, 'pixel_proto': gen_pixel_proto}[t](ref)
