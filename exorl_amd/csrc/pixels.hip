@@ -67,16 +67,14 @@ __global__ void conv_weight_shadow_kernel(const float* __restrict__ W, float* __
 // in_scale: in = in / 255 - 0.5 (Encoder.forward, ddpg.py:36). relu: ReLU epilogue. mask: out *= (mask > 0) (dgrad through the ReLU of
 // the layer below). Zero padding `pad` (0 forward, 2 for dgrad). co_n <= 32 output channels, ci_n input channels.
 __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ in, const float* __restrict__ Wt, const float* __restrict__ bias,
-                                                      const float* __restrict__ mask, float* __restrict__ out, int ci_n, int co_n, int ih, int iw,
+                                                      const float* __restrict__ mask, float* __restrict__ out, int ci_n, int ih, int iw,
                                                       int oh, int ow, int stride, int pad, int in_scale, int relu) {
     extern __shared__ float lds[];
     const int tin = (CONV_TILE - 1) * stride + 3;                 // input tile edge
-    float* wl = lds;                                              // [ci][9][co_n]
-    float* tile = lds + ci_n * 9 * co_n;                          // [ci][tin][tin]
+    float* tile = lds;                                            // [ci][tin][tin]
     const int tiles_x = (ow + CONV_TILE - 1) / CONV_TILE;
     const int ty0 = (blockIdx.x / tiles_x) * CONV_TILE, tx0 = (blockIdx.x % tiles_x) * CONV_TILE;
     const int n = blockIdx.y;
-    for (int i = threadIdx.x; i < ci_n * 9 * co_n; i += 256) wl[i] = Wt[i];
     const int iy0 = ty0 * stride - pad, ix0 = tx0 * stride - pad;
     const float* inn = in + (int64_t)n * ci_n * ih * iw;
     for (int i = threadIdx.x; i < ci_n * tin * tin; i += 256) {
@@ -95,25 +93,24 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
     float acc[CONV_CO];
 #pragma unroll
     for (int co = 0; co < CONV_CO; ++co) acc[co] = 0.f;
+    // The 32 weights of one (ci, tap) are wave-uniform and contiguous in the shadow: the compiler fetches them with scalar loads
+    // (s_load_dwordx16 x 2) and the FMAs take them as SGPR operands — one LDS read (the pixel) per 32 FMAs instead of one per FMA.
     for (int ci = 0; ci < ci_n; ++ci) {
         const float* t = tile + ci * tin * tin + (ly * stride) * tin + lx * stride;
+        const float* wci = Wt + (int64_t)ci * 9 * CONV_CO;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int tap = 0; tap < 9; ++tap) {
+            const float v = t[(tap / 3) * tin + (tap % 3)];
+            const float* w = wci + tap * CONV_CO;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const float v = t[ky * tin + kx];
-                const float* w = wl + (ci * 9 + ky * 3 + kx) * co_n;
-#pragma unroll
-                for (int co = 0; co < CONV_CO; ++co)
-                    if (co < co_n) acc[co] += v * w[co];
-            }
+            for (int co = 0; co < CONV_CO; ++co) acc[co] += v * w[co];
+        }
     }
     if (oy >= oh || ox >= ow) return;
-    float* o = out + (int64_t)n * co_n * oh * ow + (int64_t)oy * ow + ox;
-    const float* mk = mask ? mask + (int64_t)n * co_n * oh * ow + (int64_t)oy * ow + ox : nullptr;
+    float* o = out + (int64_t)n * CONV_CO * oh * ow + (int64_t)oy * ow + ox;
+    const float* mk = mask ? mask + (int64_t)n * CONV_CO * oh * ow + (int64_t)oy * ow + ox : nullptr;
 #pragma unroll
     for (int co = 0; co < CONV_CO; ++co) {
-        if (co >= co_n) break;
         float v = acc[co] + (bias ? bias[co] : 0.f);
         if (relu) v = fmaxf(v, 0.f);
         if (mk) v = mk[(int64_t)co * oh * ow] > 0.f ? v : 0.f;
@@ -124,14 +121,14 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
 static int conv3x3(const float* in, const float* Wt, const float* bias, const float* mask, float* out, int n, int ci_n, int co_n, int ih, int iw,
                    int oh, int ow, int stride, int pad, int in_scale, int relu, hipStream_t s) {
     const int tin = (CONV_TILE - 1) * stride + 3;
-    const size_t lds = ((size_t)ci_n * 9 * co_n + (size_t)ci_n * tin * tin) * sizeof(float);
-    EXORL_REQUIRE(lds <= 160 * 1024 && co_n <= CONV_CO, "conv3x3: tile does not fit LDS (ci=%d stride=%d) or co=%d > 32", ci_n, stride, co_n);
+    const size_t lds = (size_t)ci_n * tin * tin * sizeof(float);
+    EXORL_REQUIRE(lds <= 160 * 1024 && co_n == CONV_CO, "conv3x3: tile does not fit LDS (ci=%d stride=%d) or co=%d != 32", ci_n, stride, co_n);
     static bool attr = false;
     if (!attr) {
         EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL(conv3x3_kernel, dim3(cdiv(oh, CONV_TILE) * cdiv(ow, CONV_TILE), n), dim3(256), lds, s, in, Wt, bias, mask, out, ci_n, co_n,
+    hipLaunchKernelGGL(conv3x3_kernel, dim3(cdiv(oh, CONV_TILE) * cdiv(ow, CONV_TILE), n), dim3(256), lds, s, in, Wt, bias, mask, out, ci_n,
                        ih, iw, oh, ow, stride, pad, in_scale, relu);
     EXORL_LAUNCH_CHECK();
     return 0;
