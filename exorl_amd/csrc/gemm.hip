@@ -434,9 +434,8 @@ typedef __attribute__((address_space(3))) void lds_void;
 constexpr int G16G_NSTG = 4;
 constexpr int G16G_IMG = 64 * ROWB;                // 8 KB per operand image
 
-template <bool AT, bool BT>
+template <bool AT, bool BT, int NSTG = G16G_NSTG>
 __device__ __forceinline__ void gemm16g_body(const Gemm16Batch& gb, unsigned char* smem) {
-    constexpr int NSTG = G16G_NSTG;
     constexpr int IMG = G16G_IMG;
 
     int pidx = blockIdx.z, m0, n0;
@@ -515,9 +514,9 @@ __device__ __forceinline__ void gemm16g_body(const Gemm16Batch& gb, unsigned cha
     auto step = [&](auto sc, int t) {              // k-tile t sits in stage sc
         constexpr int st = decltype(sc)::value;
         // tile t has landed once at most the fills of the two younger tiles remain outstanding (4 DMA pieces per tile per wave)
-        const int younger = nk - 1 - t;
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        const int younger = nk - 1 - t;            // NSTG - 2 younger tiles may still be in flight
+        if (NSTG >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (NSTG >= 3 && younger >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();              // every wave's pieces of tile t are in LDS; stage st-1 is no longer being read
         asm volatile("" ::: "memory");
@@ -540,14 +539,18 @@ __device__ __forceinline__ void gemm16g_body(const Gemm16Batch& gb, unsigned cha
     };
 
     fill(std::integral_constant<int, 0>{});
-    fill(std::integral_constant<int, 1>{});
-    fill(std::integral_constant<int, 2>{});
-    for (int t = 0; t < nk; t += NSTG) {
+    if constexpr (NSTG >= 3) fill(std::integral_constant<int, 1>{});
+    if constexpr (NSTG >= 4) fill(std::integral_constant<int, 2>{});
+    int t = 0;
+    for (; t + NSTG <= nk; t += NSTG) {
         step(std::integral_constant<int, 0>{}, t);
         step(std::integral_constant<int, 1>{}, t + 1);
-        step(std::integral_constant<int, 2>{}, t + 2);
-        step(std::integral_constant<int, 3>{}, t + 3);
+        if constexpr (NSTG >= 3) step(std::integral_constant<int, 2>{}, t + 2);
+        if constexpr (NSTG >= 4) step(std::integral_constant<int, 3>{}, t + 3);
     }
+    if (t < nk) step(std::integral_constant<int, 0>{}, t);                 // nk % NSTG tail (stages continue from 0)
+    if (t + 1 < nk) step(std::integral_constant<int, 1>{}, t + 1);
+    if constexpr (NSTG >= 4) { if (t + 2 < nk) step(std::integral_constant<int, 2>{}, t + 2); }
 
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] += acc2[i];
@@ -757,10 +760,10 @@ static bool g16h_fits(const Gemm16Batch& gb, int count) {
     return true;
 }
 
-template <bool AT, bool BT>
+template <bool AT, bool BT, int NSTG = G16G_NSTG>
 __global__ __launch_bounds__(256) void gemm16g_kernel(const Gemm16Batch gb) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[G16G_NSTG * 2 * G16G_IMG];
-    gemm16g_body<AT, BT>(gb, smem);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NSTG * 2 * G16G_IMG];
+    gemm16g_body<AT, BT, NSTG>(gb, smem);
 }
 
 // One launch for the wgrad and dgrad GEMMs of a Linear(H,H) backward: both read dZ (wgrad as a k image, dgrad as a row image)
@@ -814,6 +817,8 @@ static int launch16(const Gemm16Batch& gb, int count, int tiles64, int tiles128,
             g2.count = count;
             g2.xcd_map = ((var & 2048) && xcd_map_ok(g2, count, 64)) ? 1 : 0;     // measured: no gain over id order (12.8 vs 12.5 us) -> opt-in
             if (g2.xcd_map) hipLaunchKernelGGL((gemm16g_kernel<AL != 0, BL != 0>), dim3(tiles64 * count, 1, 1), dim3(256), 0, s, g2);
+            else if (var & 4096) hipLaunchKernelGGL((gemm16g_kernel<AL != 0, BL != 0, 3>), dim3(tiles64, 1, count), dim3(256), 0, s, g2);   // 3 WGs/CU
+            else if (var & 8192) hipLaunchKernelGGL((gemm16g_kernel<AL != 0, BL != 0, 2>), dim3(tiles64, 1, count), dim3(256), 0, s, g2);   // 5 WGs/CU
             else hipLaunchKernelGGL((gemm16g_kernel<AL != 0, BL != 0>), dim3(tiles64, 1, count), dim3(256), 0, s, g2);
         }
         EXORL_LAUNCH_CHECK();

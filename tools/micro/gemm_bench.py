@@ -36,7 +36,7 @@ def run(al, bl, M, N, K, variant, iters=50):
     return float(np.median(ms[:n.value])) * 1e3
 
 
-names = {0: 'glds 64x64 id-order', 2048: 'glds 64x64 xcd-block', 1024: 'glds 128x128 s4', 1536: 'glds 128x128 s2'}
+names = {0: 'glds 64x64 s4', 4096: 'glds 64x64 s3', 8192: 'glds 64x64 s2'}
 for (al, bl, M, N, K, tag) in [(0, 0, 2048, H, H, 'fwd 2048'), (0, 0, 1024, H, H, 'fwd 1024'), (0, 0, 4096, H, H, 'fwd 4096'), (0, 1, 1024, H, H, 'dgrad'),
                                (1, 1, H, H, 1024, 'wgrad')]:
     for v, nm in names.items():
