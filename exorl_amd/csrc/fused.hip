@@ -1058,6 +1058,7 @@ __global__ __launch_bounds__(256) void finalize_adam_kernel(FinalizeArgs f, Fuse
             const float4 gv = reinterpret_cast<const float4*>(a.g)[gi4];
             float4 mv = reinterpret_cast<float4*>(a.m)[gi4];
             float4 vv = reinterpret_cast<float4*>(a.v)[gi4];
+            float4 tv = a.target ? reinterpret_cast<float4*>(a.target)[gi4] : make_float4(0.f, 0.f, 0.f, 0.f);     // all five streams in flight
             adam_elem(pv.x, gv.x, mv.x, vv.x, c); adam_elem(pv.y, gv.y, mv.y, vv.y, c);
             adam_elem(pv.z, gv.z, mv.z, vv.z, c); adam_elem(pv.w, gv.w, mv.w, vv.w, c);
             reinterpret_cast<float4*>(a.p)[gi4] = pv;
@@ -1068,7 +1069,6 @@ __global__ __launch_bounds__(256) void finalize_adam_kernel(FinalizeArgs f, Fuse
                 reinterpret_cast<ushort4*>(sh.w1b + (int64_t)t * H * H)[e4] = q;
             }
             if (a.target) {
-                float4 tv = reinterpret_cast<float4*>(a.target)[gi4];
                 tv.x = polyak(pv.x, tv.x, c.tau, c.one_minus_tau); tv.y = polyak(pv.y, tv.y, c.tau, c.one_minus_tau);
                 tv.z = polyak(pv.z, tv.z, c.tau, c.one_minus_tau); tv.w = polyak(pv.w, tv.w, c.tau, c.one_minus_tau);
                 reinterpret_cast<float4*>(a.target)[gi4] = tv;
@@ -1127,7 +1127,7 @@ int finalize_adam(const FinalizeArgs& f, const FusedAdamArgs& a, const ShadowSpe
     const int64_t total = f.n_heads * ((int64_t)(f.nout + 1) * f.H + (f.nout > 16 ? 32 : 16)) + f.n_trunks * (int64_t)(3 + f.in_dim) * f.H;
     const int nb_fin = cdiv(total, 256);
     int nb_w1 = cdiv((int64_t)a.n_heads * f.H * f.H / 4, 256);
-    if (nb_w1 > 1024) nb_w1 = 1024;
+    if (nb_w1 > 2048) nb_w1 = 2048;
     hipLaunchKernelGGL(finalize_adam_kernel, dim3(nb_fin + nb_w1), dim3(256), 0, s, f, a, sh, nb_fin);
     EXORL_LAUNCH_CHECK();
     return 0;
