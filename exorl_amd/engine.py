@@ -13,7 +13,7 @@ from . import _lib as L
 
 KIND = {'td3_bc': L.AGENT_TD3_BC, 'td3': L.AGENT_TD3, 'bc': L.AGENT_BC, 'ddpg': L.AGENT_DDPG, 'crr': L.AGENT_CRR, 'cql': L.AGENT_CQL,
         'aps': L.AGENT_APS}
-PRECISION = {'fp32': L.PREC_F32, 'f32': L.PREC_F32, 'bf16': L.PREC_BF16}
+PRECISION = {'fp32': L.PREC_F32, 'f32': L.PREC_F32, 'bf16': L.PREC_BF16, 'bf16x3': L.PREC_BF16X3}
 METRIC_KEYS = {L.M_BATCH_REWARD: 'batch_reward', L.M_CRITIC_TARGET_Q: 'critic_target_q', L.M_CRITIC_Q1: 'critic_q1',
                L.M_CRITIC_Q2: 'critic_q2', L.M_CRITIC_LOSS: 'critic_loss', L.M_ACTOR_LOSS: 'actor_loss',
                L.M_ACTOR_LOGPROB: 'actor_logprob'}

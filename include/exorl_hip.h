@@ -115,6 +115,9 @@ typedef struct exorl_agent exorl_agent_t;
 
 #define EXORL_PREC_F32  0      /* v_mfma_f32_32x32x2_f32: exact fp32 products, parity mode */
 #define EXORL_PREC_BF16 1      /* v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulate, fp32 master weights */
+#define EXORL_PREC_BF16X3 2    /* split-bf16: every GEMM operand x = hi + lo (two bf16), product = hi*hi + hi*lo + lo*hi on the bf16 MFMA,
+                                  fp32 accumulate; everything else as EXORL_PREC_F32. ~2^-16 relative product error: per-step losses stay
+                                  within the 1e-4 parity bar of the fp32 reference (tests/test_gpu_agent.py) at about twice fp32 mode's rate */
 
 #define EXORL_NET_ACTOR         0
 #define EXORL_NET_CRITIC        1

@@ -73,13 +73,15 @@ def load_synth(ag, kind, O, A, H, seed):
     return list(pa.values()), (list(pc.values()) if pc else None)
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
 @pytest.mark.parametrize('kind', ['td3_bc', 'td3', 'bc', 'ddpg', 'crr'])
-def test_full_size_vs_reference_fp32(gold, kind):
+def test_full_size_vs_reference_fp32(gold, kind, precision):
     """BASELINE dims (H=1024; B=1024, BC 256). North-star bar: per-step losses within 1e-4 rtol of the
-    reference PyTorch-CPU fp32 path (tests/golden/full_*.json), 10 steps; final parameter checksums too."""
+    reference PyTorch-CPU fp32 path (tests/golden/full_*.json), 10 steps; final parameter checksums too.
+    Both parity-grade modes are held to it: exact-fp32 MFMA products and split-bf16 (hi/lo) MFMA products."""
     g = json.load(open(gold / f'full_{kind}.json'))
     O, A, H, B = g['dims']
-    ag = make(kind, O, A, H, B)
+    ag = make(kind, O, A, H, B, precision=precision)
     load_synth(ag, kind, O, A, H, g['param_seed'])
     ns = _synth.NoiseStream(g['noise_seed'])
     ag.noise_hook = ns.draw

@@ -26,7 +26,7 @@ def bf16_round(x):
 SHAPES = [(64, 64, 32), (100, 70, 50), (1, 6, 1024), (1024, 1024, 1024), (1024, 30, 1024), (37, 129, 67), (2048, 1024, 24)]
 
 
-@pytest.mark.parametrize('prec', [0, 1])
+@pytest.mark.parametrize('prec', [0, 1, 2])
 @pytest.mark.parametrize('al,bl', [(0, 0), (0, 1), (1, 1), (1, 0)])
 @pytest.mark.parametrize('M,N,K', SHAPES)
 def test_gemm(lib, prec, al, bl, M, N, K):
@@ -44,7 +44,7 @@ def test_gemm(lib, prec, al, bl, M, N, K):
         L.check(lib.exorl_gemm(prec, al, bl, M, N, K, a.data_ptr(), A_st.shape[1], b.data_ptr(), B_st.shape[1],
                                c.data_ptr(), N, bi.data_ptr(), relu, acc, None))
         torch.cuda.synchronize()
-        Ar, Br = (A, B) if prec == 0 else (bf16_round(A), bf16_round(B))
+        Ar, Br = (bf16_round(A), bf16_round(B)) if prec == 1 else (A, B)
         ref = Ar.astype(np.float64) @ Br.astype(np.float64) + bias
         if relu:
             ref = np.maximum(ref, 0)
@@ -52,7 +52,8 @@ def test_gemm(lib, prec, al, bl, M, N, K):
             ref = ref + C0
         scale = np.abs(Ar).astype(np.float64) @ np.abs(Br).astype(np.float64) + 1.0
         err = np.abs(c.cpu().numpy() - ref) / scale
-        assert err.max() < 2e-6, (prec, al, bl, M, N, K, relu, acc, err.max())   # fp32 accumulation order only
+        # fp32 accumulation order only; split-bf16 (prec 2) drops the lo*lo term and the third bf16 digit: <= 3 * 2^-18 per product
+        assert err.max() < (1.2e-5 if prec == 2 else 2e-6), (prec, al, bl, M, N, K, relu, acc, err.max())
 
 
 @pytest.mark.parametrize('al,bl', [(0, 0), (0, 1), (1, 1)])
