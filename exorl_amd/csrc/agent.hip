@@ -91,9 +91,18 @@ struct Fork {
     hipStream_t side(hipStream_t s) const { return on ? aux : s; }
 };
 
-struct FwdBufs { float *h1, *xhat, *rstd, *h2, *out; unsigned short *h1b, *xhatb; };
-struct BwdBufs { float *dz2, *dh1; unsigned short* dz2b; };
-struct NetShadow { float* w0t; unsigned short* w1b; unsigned short* w0b; };   // W0 transposed per trunk; W1 as bf16 per head; W0 as K-padded bf16
+// *l: lo planes of the split-bf16 mode (same shapes as the bf16 buffers; x = hi + lo), null otherwise
+struct FwdBufs { float *h1, *xhat, *rstd, *h2, *out; unsigned short *h1b, *xhatb, *h1l, *xhatl; };
+struct BwdBufs { float *dz2, *dh1; unsigned short *dz2b, *dz2l; };
+struct NetShadow { float* w0t; unsigned short* w1b; unsigned short* w0b; unsigned short *w1l, *w0l; };   // W0 transposed per trunk; W1 as bf16 per head; W0 as K-padded bf16
+// bf16 activation pipeline: plain bf16 mode, or split-bf16 with hi/lo planes (H, batch multiples of 64: see planes_ok)
+static bool fast16(int prec, const NetShadow& sh) { return prec == EXORL_PREC_BF16 || (prec == EXORL_PREC_BF16X3 && sh.w1l); }
+static Gemm16Problem g16(const unsigned short* A, const unsigned short* Al, const unsigned short* B, const unsigned short* Bl, int64_t aoff,
+                         int64_t boff, float* C, const float* bias, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc) {
+    Gemm16Problem p{A + aoff, B + boff, C, bias, M, N, K, lda, ldb, ldc};
+    if (Al && Bl) { p.A_lo = Al + aoff; p.B_lo = Bl + boff; }
+    return p;
+}
 struct Partials { float *Ph, *Pt, *Pw; };                  // per-chunk partial gradients (fused.hip)
 
 static ShadowSpec shadow_spec(const NetDesc& d, const NetShadow& sh, const NetShadow* target) {
@@ -101,10 +110,12 @@ static ShadowSpec shadow_spec(const NetDesc& d, const NetShadow& sh, const NetSh
     s.n_trunks = d.n_trunks; s.n_heads = d.n_heads; s.in_dim = d.in_dim; s.H = d.H;
     for (int t = 0; t < d.n_trunks; ++t) s.w0_off[t] = d.W0 + t * d.trunk_stride;
     for (int i = 0; i < d.n_heads; ++i) s.w1_off[i] = d.W1 + i * d.head_stride;
-    s.w0t = sh.w0t; s.w1b = sh.w1b; s.w0b = sh.w0b;
+    s.w0t = sh.w0t; s.w1b = sh.w1b; s.w0b = sh.w0b; s.w1l = sh.w1l; s.w0l = sh.w0l;
     s.t_w0t = target ? target->w0t : nullptr;
     s.t_w1b = target ? target->w1b : nullptr;
     s.t_w0b = target ? target->w0b : nullptr;
+    s.t_w1l = target ? target->w1l : nullptr;
+    s.t_w0l = target ? target->w0l : nullptr;
     return s;
 }
 
@@ -113,11 +124,11 @@ static int net_forward(const NetDesc& d, const float* P, const NetShadow& sh, co
                        bool no_head = false) {
     const int H = d.H;
     const int64_t act = (int64_t)rows * H;
-    const bool bf = prec == EXORL_PREC_BF16;
+    const bool bf = fast16(prec, sh);
     // fast mode keeps the trunk activations as bf16 only (MFMA operand + LN backward input): 4 B/elem written instead of 10
     if (bf && sh.w0b && trunk_fwd16_supported(H))
         EXORL_TRY(trunk_fwd16(x, ldx, sh.w0b, P + d.b0, P + d.g, P + d.beta, save ? f.rstd : nullptr, f.h1b, save ? f.xhatb : nullptr, rows,
-                              d.in_dim, H, d.n_trunks, act, d.trunk_stride, s));
+                              d.in_dim, H, d.n_trunks, act, d.trunk_stride, s, sh.w0l, f.h1l, f.xhatl));
     else
         EXORL_TRY(trunk_fwd(x, ldx, sh.w0t, P + d.b0, P + d.g, P + d.beta, bf ? nullptr : f.h1, (save && !bf) ? f.xhat : nullptr,
                             save ? f.rstd : nullptr, bf ? f.h1b : nullptr, (bf && save) ? f.xhatb : nullptr, rows, d.in_dim, H,
@@ -125,8 +136,8 @@ static int net_forward(const NetDesc& d, const float* P, const NetShadow& sh, co
     if (bf) {
         Gemm16Problem q[2];
         for (int i = 0; i < d.n_heads; ++i)
-            q[i] = Gemm16Problem{f.h1b + (d.n_trunks == d.n_heads ? i : 0) * act, sh.w1b + (int64_t)i * H * H, f.h2 + i * act,
-                                 P + d.b1 + i * d.head_stride, rows, H, H, H, H, H};
+            q[i] = g16(f.h1b, f.h1l, sh.w1b, sh.w1l, (d.n_trunks == d.n_heads ? i : 0) * act, (int64_t)i * H * H, f.h2 + i * act,
+                       P + d.b1 + i * d.head_stride, rows, H, H, H, H, H);
         EXORL_TRY(gemm16_grouped(0, 0, q, d.n_heads, true, false, s));
     } else {
         GemmProblem p[2];
@@ -148,7 +159,7 @@ static int net_forward(const NetDesc& d, const float* P, const NetShadow& sh, co
 // The critic on (obs, a_data) and its Polyak target on (next_obs, next_action) in shared launches (bf16 mode): the two forward
 // chains are independent, same shapes, different weights -> 3 launches instead of 6, each filling the chip twice as deep.
 static bool forward2_supported(const NetDesc& d, int prec, const NetShadow& sa, const NetShadow& sb) {
-    return prec == EXORL_PREC_BF16 && sa.w0b && sb.w0b && trunk_fwd16_supported(d.H) && d.out_dim == 1 && d.n_heads == 2 && d.H % 4 == 0;
+    return fast16(prec, sa) && fast16(prec, sb) && sa.w0b && sb.w0b && trunk_fwd16_supported(d.H) && d.out_dim == 1 && d.n_heads == 2 && d.H % 4 == 0;
 }
 static int net_forward2(const NetDesc& d, const float* Pa, const NetShadow& sa, const float* xa, const FwdBufs& fa, bool save_a,
                         const float* Pb, const NetShadow& sb, const float* xb, const FwdBufs& fb, bool save_b, int64_t ldx, int rows,
@@ -166,15 +177,16 @@ static int net_forward2(const NetDesc& d, const float* Pa, const NetShadow& sa, 
         for (int t = 0; t < d.n_trunks; ++t)
             tb.it[nt++] = TrunkItem{x[k], sh[k]->w0b + t * wst, P[k] + d.b0 + t * d.trunk_stride, P[k] + d.g + t * d.trunk_stride,
                                     P[k] + d.beta + t * d.trunk_stride, save[k] ? f[k]->rstd + (int64_t)t * rows : nullptr,
-                                    f[k]->h1b + t * act, save[k] ? f[k]->xhatb + t * act : nullptr};
+                                    f[k]->h1b + t * act, save[k] ? f[k]->xhatb + t * act : nullptr, sh[k]->w0l ? sh[k]->w0l + t * wst : nullptr,
+                                    f[k]->h1l ? f[k]->h1l + t * act : nullptr, (save[k] && f[k]->xhatl) ? f[k]->xhatl + t * act : nullptr};
     EXORL_TRY(trunk_fwd16_batch(tb, nt, ldx, rows, d.in_dim, H, s));
     Gemm16Problem q[4];
     HeadBatch hb{};
     int nq = 0;
     for (int k = 0; k < 2; ++k)
         for (int i = 0; i < d.n_heads; ++i) {
-            q[nq] = Gemm16Problem{f[k]->h1b + (d.n_trunks == d.n_heads ? i : 0) * act, sh[k]->w1b + (int64_t)i * H * H, f[k]->h2 + i * act,
-                                  P[k] + d.b1 + i * d.head_stride, rows, H, H, H, H, H};
+            q[nq] = g16(f[k]->h1b, f[k]->h1l, sh[k]->w1b, sh[k]->w1l, (d.n_trunks == d.n_heads ? i : 0) * act, (int64_t)i * H * H, f[k]->h2 + i * act,
+                        P[k] + d.b1 + i * d.head_stride, rows, H, H, H, H, H);
             hb.it[nq] = HeadItem{f[k]->h2 + i * act, P[k] + d.W2 + i * d.head_stride, P[k] + d.b2 + i * d.head_stride, f[k]->out + (int64_t)i * rows};
             ++nq;
         }
@@ -191,16 +203,16 @@ static int net_backward(const NetDesc& d, const float* P, const NetShadow& sh, f
     const int H = d.H;
     const int64_t act = (int64_t)rows * H;
     const bool paired = d.n_trunks == d.n_heads;
-    const bool bf = prec == EXORL_PREC_BF16;
+    const bool bf = fast16(prec, sh);
     if (have_dz2) {
         // dz2 and the head partials were produced by qhead
     } else if (d.out_dim > 16) {
         EXORL_REQUIRE(d.n_heads == 1, "net_backward: wide heads are single-net only");
         EXORL_TRY(head_bwd_wide(dout, P + d.W2, f.h2, bf ? nullptr : b.dz2, bf ? b.dz2b : nullptr, G ? pt.Ph : nullptr, rows, H, d.out_dim,
-                                act, d.head_stride, G ? 1 : 0, s));
+                                act, d.head_stride, G ? 1 : 0, s, bf ? b.dz2l : nullptr));
     } else {
         EXORL_TRY(head_bwd(dout, P + d.W2, f.h2, bf ? nullptr : b.dz2, bf ? b.dz2b : nullptr, G ? pt.Ph : nullptr, rows, H, d.out_dim,
-                           d.n_heads, act, d.head_stride, G ? 1 : 0, s));
+                           d.n_heads, act, d.head_stride, G ? 1 : 0, s, bf ? b.dz2l : nullptr));
     }
     if (bf) {
         Gemm16Problem q[4];
@@ -209,31 +221,31 @@ static int net_backward(const NetDesc& d, const float* P, const NetShadow& sh, f
         if (G && !fk.on) {                           // wgrad + dgrad in one launch (independent readers of dz2)
             for (int i = 0; i < d.n_heads; ++i) {    // dW1_i[n][k] = sum_m dz2_i[m][n] h1[m][k]
                 at[nq] = 1;
-                q[nq++] = Gemm16Problem{b.dz2b + i * act, f.h1b + (paired ? i : 0) * act, G + d.W1 + i * d.head_stride, nullptr,
-                                        H, H, rows, H, H, H};
+                q[nq++] = g16(b.dz2b, b.dz2l, f.h1b, f.h1l, i * act, (paired ? i : 0) * act, G + d.W1 + i * d.head_stride, nullptr,
+                              H, H, rows, H, H, H);
             }
             const int nd = paired ? d.n_heads : 1;   // shared trunk: the heads' dgrads add into one dh1 -> only the first joins
             for (int i = 0; i < nd; ++i) {           // dh1[m][k] = sum_n dz2_i[m][n] W1_i[n][k]
                 at[nq] = 0;
-                q[nq++] = Gemm16Problem{b.dz2b + i * act, sh.w1b + (int64_t)i * H * H, b.dh1 + (paired ? i : 0) * act, nullptr,
-                                        rows, H, H, H, H, H};
+                q[nq++] = g16(b.dz2b, b.dz2l, sh.w1b, sh.w1l, i * act, (int64_t)i * H * H, b.dh1 + (paired ? i : 0) * act, nullptr,
+                              rows, H, H, H, H, H);
             }
             EXORL_TRY(gemm16_grouped_mixed(at, q, nq, s));
             for (int i = nd; i < d.n_heads; ++i) {
-                Gemm16Problem r{b.dz2b + i * act, sh.w1b + (int64_t)i * H * H, b.dh1, nullptr, rows, H, H, H, H, H};
+                Gemm16Problem r = g16(b.dz2b, b.dz2l, sh.w1b, sh.w1l, i * act, (int64_t)i * H * H, b.dh1, nullptr, rows, H, H, H, H, H);
                 EXORL_TRY(gemm16_grouped(0, 1, &r, 1, false, true, s));
             }
         } else {
             if (G) {
                 for (int i = 0; i < d.n_heads; ++i)
-                    q[i] = Gemm16Problem{b.dz2b + i * act, f.h1b + (paired ? i : 0) * act, G + d.W1 + i * d.head_stride, nullptr,
-                                         H, H, rows, H, H, H};
+                    q[i] = g16(b.dz2b, b.dz2l, f.h1b, f.h1l, i * act, (paired ? i : 0) * act, G + d.W1 + i * d.head_stride, nullptr,
+                               H, H, rows, H, H, H);
                 EXORL_TRY(fk.fork(s));                 // wgrad only feeds the optimiser: off the dgrad -> LN-backward chain
                 EXORL_TRY(gemm16_grouped(1, 1, q, d.n_heads, false, false, fk.side(s)));
             }
             for (int i = 0; i < d.n_heads; ++i)
-                q[i] = Gemm16Problem{b.dz2b + i * act, sh.w1b + (int64_t)i * H * H, b.dh1 + (paired ? i : 0) * act, nullptr,
-                                     rows, H, H, H, H, H};
+                q[i] = g16(b.dz2b, b.dz2l, sh.w1b, sh.w1l, i * act, (int64_t)i * H * H, b.dh1 + (paired ? i : 0) * act, nullptr,
+                           rows, H, H, H, H, H);
             if (paired) {
                 EXORL_TRY(gemm16_grouped(0, 1, q, d.n_heads, false, false, s));
             } else {
@@ -261,7 +273,7 @@ static int net_backward(const NetDesc& d, const float* P, const NetShadow& sh, f
     const bool dx_fused = dx && !G;              // dgrad-only pass: d/d(input columns) in the LayerNorm-backward kernel itself
     EXORL_TRY(ln_bwd(b.dh1, f.h1, f.xhat, bf ? f.h1b : nullptr, bf ? f.xhatb : nullptr, f.rstd, P + d.g, pt.Pt, rows, H, d.n_trunks,
                      act, d.trunk_stride, G ? 1 : 0, s, dx_fused ? sh.w0t + (int64_t)dx_col0 * H : nullptr, (int64_t)d.in_dim * H,
-                     dx_fused ? dx : nullptr, dx_cols));
+                     dx_fused ? dx : nullptr, dx_cols, bf ? f.h1l : nullptr, bf ? f.xhatl : nullptr));
     if (dx && !dx_fused)       // dx[m][j] = sum_c dz0[m][c] W0[c][col0+j]: a row-dot against rows col0.. of the transposed shadow
         EXORL_TRY(head_fwd4(b.dh1, sh.w0t + (int64_t)dx_col0 * H, nullptr, dx, rows, H, dx_cols, 0, d.n_trunks, act,
                             (int64_t)d.in_dim * H, (int64_t)rows * dx_cols, s));
@@ -346,6 +358,12 @@ struct exorl_agent {
 
 namespace exorl {
 
+// split-bf16 mode runs the bf16 activation pipeline on hi/lo planes when every H x H GEMM tiles by 64 (the LDS-DMA kernel has no
+// edge handling); other shapes take the fp32 activation pipeline with the operands split inside the GEMM (gemm_kernel<BF16X3>)
+static bool planes_ok(const exorl_agent_cfg& cfg) {
+    return cfg.precision == EXORL_PREC_BF16X3 && cfg.hidden_dim % 64 == 0 && cfg.batch % 64 == 0 && trunk_fwd16_supported(cfg.hidden_dim);
+}
+
 static void carve(exorl_agent* a, Carver& c) {
     const auto& cfg = a->cfg;
     const int64_t B = cfg.batch, O = cfg.obs_dim, A = cfg.act_dim, H = cfg.hidden_dim, W = O + A;
@@ -359,11 +377,14 @@ static void carve(exorl_agent* a, Carver& c) {
     a->obs = c.take(B * O); a->action = c.take(B * A); a->reward = c.take(B); a->discount = c.take(B); a->next_obs = c.take(B * O);
     a->xa = c.take(2 * B * O);
     auto take_u16 = [&](int64_t n) { return reinterpret_cast<unsigned short*>(c.take((n + 1) / 2)); };
-    const bool bf = cfg.precision == EXORL_PREC_BF16;
+    const bool x3 = planes_ok(cfg);
+    const bool bf = cfg.precision == EXORL_PREC_BF16 || x3;
+    auto take_lo = [&](int64_t n) { return x3 ? take_u16(n) : nullptr; };
     a->fa = FwdBufs{c.take(2 * B * H), c.take(2 * B * H), c.take(2 * B), c.take(2 * B * H), c.take(2 * B * AO), bf ? take_u16(2 * B * H) : nullptr,
-                    bf ? take_u16(2 * B * H) : nullptr};
-    a->ba = BwdBufs{c.take(B * H), c.take(B * H), bf ? take_u16(B * H) : nullptr};
-    a->sh_actor = NetShadow{c.take(O * H), bf ? take_u16(H * H) : nullptr, bf ? take_u16(H * round_up(O, 32)) : nullptr};
+                    bf ? take_u16(2 * B * H) : nullptr, take_lo(2 * B * H), take_lo(2 * B * H)};
+    a->ba = BwdBufs{c.take(B * H), c.take(B * H), bf ? take_u16(B * H) : nullptr, take_lo(B * H)};
+    a->sh_actor = NetShadow{c.take(O * H), bf ? take_u16(H * H) : nullptr, bf ? take_u16(H * round_up(O, 32)) : nullptr, take_lo(H * H),
+                            take_lo(H * round_up(O, 32))};
     a->pa = Partials{c.take((int64_t)head_chunks(B) * ((AO + 1) * H + 32)), c.take((int64_t)trunk_chunks(B) * 3 * H),
                      c.take((int64_t)outer_chunks(B) * O * H)};
     a->dpre = c.take(B * AO);
@@ -372,15 +393,17 @@ static void carve(exorl_agent* a, Carver& c) {
     a->state = reinterpret_cast<StepState*>(c.take((sizeof(StepState) + 3) / 4));
     a->act_x = c.take(ACT_ROWS * O);
     a->act_noise = c.take(ACT_ROWS * A);
-    a->fact = FwdBufs{c.take(ACT_ROWS * H), nullptr, nullptr, c.take(ACT_ROWS * H), c.take(ACT_ROWS * AO), bf ? take_u16(ACT_ROWS * H) : nullptr, nullptr};
+    a->fact = FwdBufs{c.take(ACT_ROWS * H), nullptr, nullptr, c.take(ACT_ROWS * H), c.take(ACT_ROWS * AO), bf ? take_u16(ACT_ROWS * H) : nullptr, nullptr,
+                      nullptr, nullptr};
     if (a->has_critic) {
         const int64_t nt = a->critic.n_trunks;
         a->xc_cur = c.take(B * W); a->xc_next = c.take(B * W); a->xc_pi = c.take(B * W);
         const int64_t od = a->critic.out_dim;
-        a->ft = FwdBufs{c.take(nt * B * H), nullptr, nullptr, c.take(2 * B * H), c.take(2 * B * od), bf ? take_u16(nt * B * H) : nullptr, nullptr};
+        a->ft = FwdBufs{c.take(nt * B * H), nullptr, nullptr, c.take(2 * B * H), c.take(2 * B * od), bf ? take_u16(nt * B * H) : nullptr, nullptr,
+                        take_lo(nt * B * H), nullptr};
         a->fc = FwdBufs{c.take(nt * RC * H), c.take(nt * RC * H), c.take(nt * RC), c.take(2 * RC * H), c.take(2 * RC * od), bf ? take_u16(nt * RC * H) : nullptr,
-                        bf ? take_u16(nt * RC * H) : nullptr};
-        a->bc = BwdBufs{c.take(2 * RC * H), c.take(nt * RC * H), bf ? take_u16(2 * RC * H) : nullptr};
+                        bf ? take_u16(nt * RC * H) : nullptr, take_lo(nt * RC * H), take_lo(nt * RC * H)};
+        a->bc = BwdBufs{c.take(2 * RC * H), c.take(nt * RC * H), bf ? take_u16(2 * RC * H) : nullptr, take_lo(2 * RC * H)};
         if (cfg.kind == EXORL_AGENT_CQL) {
             a->x_all = c.take(RC * W);
             a->dq_all = c.take(2 * RC);
@@ -394,10 +417,13 @@ static void carve(exorl_agent* a, Carver& c) {
             const int64_t R = B * cfg.num_value_samples;
             a->xc_rep = c.take(R * W);
             a->crr_w = c.take(B);
-            a->fr = FwdBufs{bf ? nullptr : c.take(nt * R * H), nullptr, nullptr, c.take(2 * R * H), c.take(2 * R), bf ? take_u16(nt * R * H) : nullptr, nullptr};
+            a->fr = FwdBufs{bf ? nullptr : c.take(nt * R * H), nullptr, nullptr, c.take(2 * R * H), c.take(2 * R), bf ? take_u16(nt * R * H) : nullptr, nullptr,
+                            take_lo(nt * R * H), nullptr};
         }
-        a->sh_critic = NetShadow{c.take(nt * W * H), bf ? take_u16(2 * H * H) : nullptr, bf ? take_u16(nt * H * round_up(W, 32)) : nullptr};
-        a->sh_target = NetShadow{c.take(nt * W * H), bf ? take_u16(2 * H * H) : nullptr, bf ? take_u16(nt * H * round_up(W, 32)) : nullptr};
+        a->sh_critic = NetShadow{c.take(nt * W * H), bf ? take_u16(2 * H * H) : nullptr, bf ? take_u16(nt * H * round_up(W, 32)) : nullptr,
+                                 take_lo(2 * H * H), take_lo(nt * H * round_up(W, 32))};
+        a->sh_target = NetShadow{c.take(nt * W * H), bf ? take_u16(2 * H * H) : nullptr, bf ? take_u16(nt * H * round_up(W, 32)) : nullptr,
+                                 take_lo(2 * H * H), take_lo(nt * H * round_up(W, 32))};
         a->pc = Partials{c.take(2 * (int64_t)qhead_chunks(RC) * ((od + 1) * H + 32)), c.take(nt * (int64_t)trunk_chunks(RC) * 3 * H),
                          c.take(nt * (int64_t)outer_chunks(RC) * W * H)};
     }
@@ -482,14 +508,14 @@ static int run_qhead(exorl_agent* a, int mode, hipStream_t s) {
     const int64_t act = (int64_t)B * H;
     const float* Pc = a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM];
     const float* Pt = a->flat[EXORL_NET_CRITIC_TARGET][EXORL_T_PARAM];
-    const bool bf = a->cfg.precision == EXORL_PREC_BF16;
+    const bool bf = a->bc.dz2b != nullptr;
     QHeadArgs q{};
     for (int i = 0; i < 2; ++i) {
         q.a[i] = a->fc.h2 + i * act; q.W[i] = Pc + d.W2 + i * d.head_stride; q.b[i] = Pc + d.b2 + i * d.head_stride;
         q.a[2 + i] = a->ft.h2 + i * act; q.W[2 + i] = Pt + d.W2 + i * d.head_stride; q.b[2 + i] = Pt + d.b2 + i * d.head_stride;
     }
     q.q = a->fc.out; q.tq = a->ft.out; q.reward = a->reward; q.discount = a->discount;
-    q.dz = bf ? nullptr : a->bc.dz2; q.dzb = bf ? a->bc.dz2b : nullptr; q.act = act;
+    q.dz = bf ? nullptr : a->bc.dz2; q.dzb = bf ? a->bc.dz2b : nullptr; q.dzl = bf ? a->bc.dz2l : nullptr; q.act = act;
     q.P = mode == 0 ? a->pc.Ph : nullptr;
     q.abs_part = a->abs_part;
     q.rows = B; q.H = H; q.mode = mode; q.inv_bg = a->inv_bg;
@@ -599,7 +625,8 @@ static int phase2(exorl_agent* a, float stddev, hipStream_t s) {
     // the obs half (rows B..2B) of the stacked actor forward
     FwdBufs f{a->fa.h1 + (int64_t)B * H, a->fa.xhat + (int64_t)B * H, a->fa.rstd + B, a->fa.h2 + (int64_t)B * H,
               a->fa.out + (int64_t)B * A, a->fa.h1b ? a->fa.h1b + (int64_t)B * H : nullptr,
-              a->fa.xhatb ? a->fa.xhatb + (int64_t)B * H : nullptr};
+              a->fa.xhatb ? a->fa.xhatb + (int64_t)B * H : nullptr, a->fa.h1l ? a->fa.h1l + (int64_t)B * H : nullptr,
+              a->fa.xhatl ? a->fa.xhatl + (int64_t)B * H : nullptr};
     if (!a->has_critic)       // BC (bc.py:82): the only forward of the step
         EXORL_TRY(net_forward(a->actor, Pa, a->sh_actor, a->xa + (int64_t)B * O, O, B, f, true, true, prec, s));
     if (a->want_metrics)                        // actor_loss / batch_reward(BC) metrics only (the gradient is formed in head_bwd)
@@ -677,7 +704,8 @@ static int cql_phase2(exorl_agent* a, hipStream_t s) {
                            a->bc, a->da, O, A, prec, s, a->fk));
     FwdBufs f{a->fa.h1 + (int64_t)B * H, a->fa.xhat + (int64_t)B * H, a->fa.rstd + B, a->fa.h2 + (int64_t)B * H,
               a->fa.out + (int64_t)B * 2 * A, a->fa.h1b ? a->fa.h1b + (int64_t)B * H : nullptr,
-              a->fa.xhatb ? a->fa.xhatb + (int64_t)B * H : nullptr};
+              a->fa.xhatb ? a->fa.xhatb + (int64_t)B * H : nullptr, a->fa.h1l ? a->fa.h1l + (int64_t)B * H : nullptr,
+              a->fa.xhatl ? a->fa.xhatl + (int64_t)B * H : nullptr};
     DoutSpec dm{};
     dm.mode = EXORL_DOUT_CQL_ACTOR; dm.da = a->da; dm.da_nets = a->critic.n_trunks; dm.raw = f.out; dm.z = a->noise_a;
     dm.alpha_ptr = &a->cql->alpha; dm.inv_bg = a->inv_bg; dm.seed = cfg.seed; dm.counter = 4; dm.counter_ptr = &a->state->noise_counter;
@@ -873,7 +901,9 @@ int exorl_agent_act(exorl_agent_t* a, const float* obs, int32_t n, float stddev,
     const int O = a->cfg.obs_dim, A = a->cfg.act_dim;
     for (int r0 = 0; r0 < n; r0 += ACT_ROWS) {
         const int rows = n - r0 < ACT_ROWS ? n - r0 : ACT_ROWS;
-        EXORL_TRY(net_forward(a->actor, a->flat[EXORL_NET_ACTOR][EXORL_T_PARAM], a->sh_actor, obs + (int64_t)r0 * O, O, rows, a->fact, false,
+        NetShadow sh = a->sh_actor;                 // act() rows do not tile by 64: split-bf16 takes the in-GEMM split here
+        sh.w1l = sh.w0l = nullptr;
+        EXORL_TRY(net_forward(a->actor, a->flat[EXORL_NET_ACTOR][EXORL_T_PARAM], sh, obs + (int64_t)r0 * O, O, rows, a->fact, false,
                               a->cfg.kind != EXORL_AGENT_CQL,
                               a->cfg.precision, s));
         if (a->cfg.kind == EXORL_AGENT_CQL) {       // SquashedNormal: mean = tanh(loc), sample = tanh(loc + std z)  (cql.py:122-131)

@@ -22,6 +22,10 @@ __device__ __forceinline__ unsigned short f2bf(float x) {
     bf16_t b = (bf16_t)x;
     return __builtin_bit_cast(unsigned short, b);
 }
+// lo plane of the split-bf16 representation x = hi + lo, hi = bf16(x)
+__device__ __forceinline__ unsigned short f2bf_lo(float x) { return f2bf(x - __uint_as_float((unsigned)f2bf(x) << 16)); }
+__device__ __forceinline__ ushort4 f4_to_bf4(const float4& v) { ushort4 q; q.x = f2bf(v.x); q.y = f2bf(v.y); q.z = f2bf(v.z); q.w = f2bf(v.w); return q; }
+__device__ __forceinline__ ushort4 f4_to_bf4_lo(const float4& v) { ushort4 q; q.x = f2bf_lo(v.x); q.y = f2bf_lo(v.y); q.z = f2bf_lo(v.z); q.w = f2bf_lo(v.w); return q; }
 
 // ------------------------------------------------------------------------------------------------
 // trunk forward: h = tanh(LN(x W0^T + b0) * g + beta).
@@ -171,7 +175,9 @@ __global__ __launch_bounds__(512) void trunk_fwd_kernel(const float* __restrict_
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
 typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4_t;
 
-template <int T>     // T = H / 128 column tiles per wave
+// X3 (split-bf16 mode): x and W0 enter as hi + lo pairs, z = hi*hi + hi*lo + lo*hi (fp32-grade first layer), and h / xhat
+// leave as hi + lo planes.
+template <int T, bool X3>     // T = H / 128 column tiles per wave
 __global__ __launch_bounds__(512) void trunk_fwd16_kernel(const TrunkBatch tb, int64_t ldx, int rows, int in_dim, int Kp) {
     constexpr int H = T * 128;
     __shared__ float red[2][8][16];
@@ -196,14 +202,29 @@ __global__ __launch_bounds__(512) void trunk_fwd16_kernel(const TrunkBatch tb, i
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     for (int k0 = 0; k0 < Kp; k0 += 32) {
-        bf16x8_t bx;
+        bf16x8_t bx, bxl;
         const int kb = k0 + 8 * kq;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bx[j] = (__bf16)((live && kb + j < in_dim) ? x[(int64_t)row * ldx + kb + j] : 0.f);
+        for (int j = 0; j < 8; ++j) {
+            const float xv = (live && kb + j < in_dim) ? x[(int64_t)row * ldx + kb + j] : 0.f;
+            bx[j] = (__bf16)xv;
+            if constexpr (X3) bxl[j] = (__bf16)(xv - (float)bx[j]);
+        }
         bf16x8_t aw[T];
 #pragma unroll
         for (int t = 0; t < T; ++t)
             aw[t] = *reinterpret_cast<const bf16x8_t*>(Wb + (int64_t)(col0 + t * 16 + rn) * Kp + kb);
+        if constexpr (X3) {
+            f32x4_t cross[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const bf16x8_t awl = *reinterpret_cast<const bf16x8_t*>(it.W0l + (int64_t)(col0 + t * 16 + rn) * Kp + kb);
+                cross[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[t], bxl, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                cross[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(awl, bx, cross[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[t] += cross[t];
+        }
 #pragma unroll
         for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[t], bx, acc[t], 0, 0, 0);
     }
@@ -245,14 +266,14 @@ __global__ __launch_bounds__(512) void trunk_fwd16_kernel(const TrunkBatch tb, i
         const float4 g = *reinterpret_cast<const float4*>(gain + net * pstride + c);
         const float4 be = *reinterpret_cast<const float4*>(beta + net * pstride + c);
         const float xh[4] = {acc[t][0] * rs, acc[t][1] * rs, acc[t][2] * rs, acc[t][3] * rs};
-        ushort4 q;
-        q.x = f2bf(tanh_fast(xh[0] * g.x + be.x)); q.y = f2bf(tanh_fast(xh[1] * g.y + be.y));
-        q.z = f2bf(tanh_fast(xh[2] * g.z + be.z)); q.w = f2bf(tanh_fast(xh[3] * g.w + be.w));
-        *reinterpret_cast<ushort4*>(hb + o + c) = q;
+        const float4 hv = make_float4(tanh_fast(xh[0] * g.x + be.x), tanh_fast(xh[1] * g.y + be.y), tanh_fast(xh[2] * g.z + be.z),
+                                      tanh_fast(xh[3] * g.w + be.w));
+        *reinterpret_cast<ushort4*>(hb + o + c) = f4_to_bf4(hv);
+        if constexpr (X3) *reinterpret_cast<ushort4*>(it.hl + o + c) = f4_to_bf4_lo(hv);
         if (xhb) {
-            ushort4 u;
-            u.x = f2bf(xh[0]); u.y = f2bf(xh[1]); u.z = f2bf(xh[2]); u.w = f2bf(xh[3]);
-            *reinterpret_cast<ushort4*>(xhb + o + c) = u;
+            const float4 xv = make_float4(xh[0], xh[1], xh[2], xh[3]);
+            *reinterpret_cast<ushort4*>(xhb + o + c) = f4_to_bf4(xv);
+            if constexpr (X3) *reinterpret_cast<ushort4*>(it.xhl + o + c) = f4_to_bf4_lo(xv);
         }
     }
     if (rstd && wave == 0 && kq == 0) rstd[net * (int64_t)rows + row] = rs;
@@ -265,7 +286,11 @@ int trunk_fwd16_batch(const TrunkBatch& tb, int count, int64_t ldx, int rows, in
                   H, in_dim, count);
     const int Kp = (int)round_up(in_dim, 32);
     const dim3 grid(cdiv(rows, 16), count);
-#define EXORL_TF16(T) hipLaunchKernelGGL((trunk_fwd16_kernel<T>), grid, dim3(512), 0, s, tb, ldx, rows, in_dim, Kp)
+    const bool x3 = tb.it[0].W0l != nullptr;
+    for (int i = 0; i < count; ++i)
+        EXORL_REQUIRE((tb.it[i].W0l != nullptr) == x3 && (!x3 || (tb.it[i].hl && (!tb.it[i].xhb || tb.it[i].xhl))), "trunk_fwd16: inconsistent lo planes");
+#define EXORL_TF16(T) do { if (x3) hipLaunchKernelGGL((trunk_fwd16_kernel<T, true>), grid, dim3(512), 0, s, tb, ldx, rows, in_dim, Kp); \
+                           else hipLaunchKernelGGL((trunk_fwd16_kernel<T, false>), grid, dim3(512), 0, s, tb, ldx, rows, in_dim, Kp); } while (0)
     switch (H / 128) {
         case 1: EXORL_TF16(1); break;
         case 2: EXORL_TF16(2); break;
@@ -283,13 +308,14 @@ int trunk_fwd16_batch(const TrunkBatch& tb, int count, int64_t ldx, int rows, in
 
 int trunk_fwd16(const float* x, int64_t ldx, const unsigned short* W0b, const float* b0, const float* gain, const float* beta, float* rstd,
                 unsigned short* h_bf16, unsigned short* xhat_bf16, int rows, int in_dim, int H, int nets, int64_t astride, int64_t pstride,
-                hipStream_t s) {
+                hipStream_t s, const unsigned short* W0l, unsigned short* h_lo, unsigned short* xhat_lo) {
     EXORL_REQUIRE(h_bf16 && nets >= 1 && nets <= 4, "trunk_fwd16: bad arguments");
     TrunkBatch tb{};
     const int64_t wstride = (int64_t)H * round_up(in_dim, 32);
     for (int n = 0; n < nets; ++n)
         tb.it[n] = TrunkItem{x, W0b + n * wstride, b0 + n * pstride, gain + n * pstride, beta + n * pstride, rstd ? rstd + (int64_t)n * rows : nullptr,
-                             h_bf16 + n * astride, xhat_bf16 ? xhat_bf16 + n * astride : nullptr};
+                             h_bf16 + n * astride, xhat_bf16 ? xhat_bf16 + n * astride : nullptr, W0l ? W0l + n * wstride : nullptr,
+                             h_lo ? h_lo + n * astride : nullptr, (xhat_bf16 && xhat_lo) ? xhat_lo + n * astride : nullptr};
     return trunk_fwd16_batch(tb, nets, ldx, rows, in_dim, H, s);
 }
 
@@ -355,7 +381,8 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(float* dh, const float* __r
                                                      const float* __restrict__ rstd, const float* __restrict__ gain,
                                                      float* __restrict__ P, int rows, int H, int64_t astride,
                                                      int64_t pstride, const float* __restrict__ w0t, int64_t tstride,
-                                                     float* __restrict__ dx, int dx_cols) {
+                                                     float* __restrict__ dx, int dx_cols, const unsigned short* __restrict__ hl,
+                                                     const unsigned short* __restrict__ xhl) {
     __shared__ __attribute__((aligned(16))) float red[PARAMS ? 8 * 1024 : 4];
     const int net = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -382,6 +409,12 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(float* dh, const float* __r
                 if constexpr (B16) {
                     hv = bf4_to_f4(reinterpret_cast<const ushort4*>(hb + o)[c4]);
                     xh[i] = bf4_to_f4(reinterpret_cast<const ushort4*>(xhb + o)[c4]);
+                    if (hl) {                            // split-bf16 mode: hi + lo planes
+                        const float4 l1 = bf4_to_f4(reinterpret_cast<const ushort4*>(hl + o)[c4]);
+                        const float4 l2 = bf4_to_f4(reinterpret_cast<const ushort4*>(xhl + o)[c4]);
+                        hv.x += l1.x; hv.y += l1.y; hv.z += l1.z; hv.w += l1.w;
+                        xh[i].x += l2.x; xh[i].y += l2.y; xh[i].z += l2.z; xh[i].w += l2.w;
+                    }
                 } else {
                     hv = reinterpret_cast<const float4*>(h + o)[c4];
                     xh[i] = reinterpret_cast<const float4*>(xhat + o)[c4];
@@ -464,12 +497,14 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(float* dh, const float* __r
 
 int ln_bwd(float* dh, const float* h, const float* xhat, const unsigned short* h_bf16, const unsigned short* xhat_bf16,
            const float* rstd, const float* gain, float* P, int rows, int H, int nets, int64_t astride, int64_t pstride,
-           int want_params, hipStream_t s, const float* w0t, int64_t tstride, float* dx, int dx_cols) {
+           int want_params, hipStream_t s, const float* w0t, int64_t tstride, float* dx, int dx_cols, const unsigned short* h_lo,
+           const unsigned short* xhat_lo) {
     EXORL_REQUIRE(H >= 4 && H <= 1024 && H % 4 == 0, "ln_bwd: unsupported H=%d", H);
     EXORL_REQUIRE(!dx || (!want_params && w0t && dx_cols >= 1), "ln_bwd: the dx epilogue belongs to the dgrad-only pass");
     const dim3 grid(cdiv(rows, TB_ROWS), nets);
     const bool b16 = h_bf16 && xhat_bf16;
-#define EXORL_LNB(PA, BB) hipLaunchKernelGGL((ln_bwd_kernel<PA, BB>), grid, dim3(512), 0, s, dh, h, xhat, h_bf16, xhat_bf16, rstd, gain, P, rows, H, astride, pstride, w0t, tstride, dx, dx_cols)
+    EXORL_REQUIRE((h_lo != nullptr) == (xhat_lo != nullptr) && (!h_lo || b16), "ln_bwd: lo planes come in pairs, with the bf16 hi planes");
+#define EXORL_LNB(PA, BB) hipLaunchKernelGGL((ln_bwd_kernel<PA, BB>), grid, dim3(512), 0, s, dh, h, xhat, h_bf16, xhat_bf16, rstd, gain, P, rows, H, astride, pstride, w0t, tstride, dx, dx_cols, h_lo, xhat_lo)
     if (want_params) { if (b16) EXORL_LNB(true, true); else EXORL_LNB(true, false); }
     else             { if (b16) EXORL_LNB(false, true); else EXORL_LNB(false, false); }
 #undef EXORL_LNB
@@ -711,7 +746,8 @@ template <int NO>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const DoutSpec dspec, const float* __restrict__ W,
                                                        const float* __restrict__ a, float* __restrict__ dz,
                                                        unsigned short* __restrict__ dzb, float* __restrict__ P, int rows,
-                                                       int H, int nout, int64_t astride, int64_t pstride, int want_params) {
+                                                       int H, int nout, int64_t astride, int64_t pstride, int want_params,
+                                                       unsigned short* __restrict__ dzl) {
     __shared__ float ds[HB_ROWS * 16];
     __shared__ float lam_s[5];
     const int net = blockIdx.y;
@@ -770,11 +806,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const DoutSpec dspec, con
         v.x = av.x > 0.f ? sacc.x : 0.f; v.y = av.y > 0.f ? sacc.y : 0.f;
         v.z = av.z > 0.f ? sacc.z : 0.f; v.w = av.w > 0.f ? sacc.w : 0.f;
         if (dz) reinterpret_cast<float4*>(dz + o)[c4] = v;
-        if (dzb) {
-            ushort4 q;
-            q.x = f2bf(v.x); q.y = f2bf(v.y); q.z = f2bf(v.z); q.w = f2bf(v.w);
-            reinterpret_cast<ushort4*>(dzb + o)[c4] = q;
-        }
+        if (dzb) reinterpret_cast<ushort4*>(dzb + o)[c4] = f4_to_bf4(v);
+        if (dzl) reinterpret_cast<ushort4*>(dzl + o)[c4] = f4_to_bf4_lo(v);
         pb.x += v.x; pb.y += v.y; pb.z += v.z; pb.w += v.w;
     }
     if (want_params) {
@@ -786,12 +819,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const DoutSpec dspec, con
 }
 
 int head_bwd(const DoutSpec& dspec, const float* W, const float* a, float* dz, unsigned short* dz_bf16, float* P, int rows,
-             int H, int nout, int nets, int64_t astride, int64_t pstride, int want_params, hipStream_t s) {
+             int H, int nout, int nets, int64_t astride, int64_t pstride, int want_params, hipStream_t s, unsigned short* dz_lo) {
     EXORL_REQUIRE(nout >= 1 && nout <= 16 && H % 4 == 0 && H <= 1024, "head_bwd: nout=%d H=%d unsupported", nout, H);
     dim3 grid(cdiv(rows, HB_ROWS), nets);
-    if (nout == 1) hipLaunchKernelGGL((head_bwd_kernel<1>), grid, dim3(256), 0, s, dspec, W, a, dz, dz_bf16, P, rows, H, nout, astride, pstride, want_params);
-    else if (nout <= 8) hipLaunchKernelGGL((head_bwd_kernel<8>), grid, dim3(256), 0, s, dspec, W, a, dz, dz_bf16, P, rows, H, nout, astride, pstride, want_params);
-    else hipLaunchKernelGGL((head_bwd_kernel<16>), grid, dim3(256), 0, s, dspec, W, a, dz, dz_bf16, P, rows, H, nout, astride, pstride, want_params);
+    if (nout == 1) hipLaunchKernelGGL((head_bwd_kernel<1>), grid, dim3(256), 0, s, dspec, W, a, dz, dz_bf16, P, rows, H, nout, astride, pstride, want_params, dz_lo);
+    else if (nout <= 8) hipLaunchKernelGGL((head_bwd_kernel<8>), grid, dim3(256), 0, s, dspec, W, a, dz, dz_bf16, P, rows, H, nout, astride, pstride, want_params, dz_lo);
+    else hipLaunchKernelGGL((head_bwd_kernel<16>), grid, dim3(256), 0, s, dspec, W, a, dz, dz_bf16, P, rows, H, nout, astride, pstride, want_params, dz_lo);
     EXORL_LAUNCH_CHECK();
     return 0;
 }
@@ -800,7 +833,8 @@ int head_bwd(const DoutSpec& dspec, const float* W, const float* a, float* dz, u
 __global__ __launch_bounds__(256) void head_bwd_wide_kernel(const DoutSpec dspec, const float* __restrict__ W,
                                                             const float* __restrict__ a, float* __restrict__ dz,
                                                             unsigned short* __restrict__ dzb, float* __restrict__ P, int rows, int H,
-                                                            int nout, int64_t astride, int64_t pstride, int want_params) {
+                                                            int nout, int64_t astride, int64_t pstride, int want_params,
+                                                            unsigned short* __restrict__ dzl) {
     __shared__ float ds[HB_ROWS * 32];
     const int net = blockIdx.z;
     const int row0 = blockIdx.y * HB_ROWS;
@@ -839,6 +873,7 @@ __global__ __launch_bounds__(256) void head_bwd_wide_kernel(const DoutSpec dspec
         const float v = av > 0.f ? sacc : 0.f;
         if (dz) dz[o] = v;
         if (dzb) dzb[o] = f2bf(v);
+        if (dzl) dzl[o] = f2bf_lo(v);
         pb += v;
     }
     if (want_params) {
@@ -850,10 +885,10 @@ __global__ __launch_bounds__(256) void head_bwd_wide_kernel(const DoutSpec dspec
 }
 
 int head_bwd_wide(const DoutSpec& dspec, const float* W, const float* a, float* dz, unsigned short* dz_bf16, float* P, int rows, int H,
-                  int nout, int64_t astride, int64_t pstride, int want_params, hipStream_t s) {
+                  int nout, int64_t astride, int64_t pstride, int want_params, hipStream_t s, unsigned short* dz_lo) {
     EXORL_REQUIRE(nout > 16 && nout <= 32, "head_bwd_wide: nout=%d out of range", nout);
     hipLaunchKernelGGL(head_bwd_wide_kernel, dim3(cdiv(H, 256), cdiv(rows, HB_ROWS), 1), dim3(256), 0, s, dspec, W, a, dz, dz_bf16, P, rows,
-                       H, nout, astride, pstride, want_params);
+                       H, nout, astride, pstride, want_params, dz_lo);
     EXORL_LAUNCH_CHECK();
     return 0;
 }
@@ -954,11 +989,8 @@ __global__ __launch_bounds__(256) void qhead_kernel(const QHeadArgs g) {
             v.z = av.z > 0.f ? d * w[n].z : 0.f; v.w = av.w > 0.f ? d * w[n].w : 0.f;
             const int64_t o = n * g.act + (int64_t)(row0 + r) * H;
             if (g.dz) reinterpret_cast<float4*>(g.dz + o)[c4] = v;
-            if (g.dzb) {
-                ushort4 u;
-                u.x = f2bf(v.x); u.y = f2bf(v.y); u.z = f2bf(v.z); u.w = f2bf(v.w);
-                reinterpret_cast<ushort4*>(g.dzb + o)[c4] = u;
-            }
+            if (g.dzb) reinterpret_cast<ushort4*>(g.dzb + o)[c4] = f4_to_bf4(v);
+            if (g.dzl) reinterpret_cast<ushort4*>(g.dzl + o)[c4] = f4_to_bf4_lo(v);
             pb.x += v.x; pb.y += v.y; pb.z += v.z; pb.w += v.w;
         }
         if (Pn) {
@@ -1064,18 +1096,14 @@ __global__ __launch_bounds__(256) void finalize_adam_kernel(FinalizeArgs f, Fuse
             reinterpret_cast<float4*>(a.p)[gi4] = pv;
             reinterpret_cast<float4*>(a.m)[gi4] = mv;
             reinterpret_cast<float4*>(a.v)[gi4] = vv;
-            if (sh.w1b) {
-                ushort4 q; q.x = f2bf(pv.x); q.y = f2bf(pv.y); q.z = f2bf(pv.z); q.w = f2bf(pv.w);
-                reinterpret_cast<ushort4*>(sh.w1b + (int64_t)t * H * H)[e4] = q;
-            }
+            if (sh.w1b) reinterpret_cast<ushort4*>(sh.w1b + (int64_t)t * H * H)[e4] = f4_to_bf4(pv);
+            if (sh.w1l) reinterpret_cast<ushort4*>(sh.w1l + (int64_t)t * H * H)[e4] = f4_to_bf4_lo(pv);
             if (a.target) {
                 tv.x = polyak(pv.x, tv.x, c.tau, c.one_minus_tau); tv.y = polyak(pv.y, tv.y, c.tau, c.one_minus_tau);
                 tv.z = polyak(pv.z, tv.z, c.tau, c.one_minus_tau); tv.w = polyak(pv.w, tv.w, c.tau, c.one_minus_tau);
                 reinterpret_cast<float4*>(a.target)[gi4] = tv;
-                if (sh.t_w1b) {
-                    ushort4 q; q.x = f2bf(tv.x); q.y = f2bf(tv.y); q.z = f2bf(tv.z); q.w = f2bf(tv.w);
-                    reinterpret_cast<ushort4*>(sh.t_w1b + (int64_t)t * H * H)[e4] = q;
-                }
+                if (sh.t_w1b) reinterpret_cast<ushort4*>(sh.t_w1b + (int64_t)t * H * H)[e4] = f4_to_bf4(tv);
+                if (sh.t_w1l) reinterpret_cast<ushort4*>(sh.t_w1l + (int64_t)t * H * H)[e4] = f4_to_bf4_lo(tv);
             }
         }
         return;
@@ -1113,9 +1141,11 @@ __global__ __launch_bounds__(256) void finalize_adam_kernel(FinalizeArgs f, Fuse
                 // derived copies of the first-layer weight (ShadowSpec): transposed fp32 and K-padded bf16
                 sh.w0t[net * nw + (int64_t)k * H + cc] = pn;
                 if (sh.w0b) sh.w0b[(int64_t)net * H * Kp + (int64_t)cc * Kp + k] = f2bf(pn);
+                if (sh.w0l) sh.w0l[(int64_t)net * H * Kp + (int64_t)cc * Kp + k] = f2bf_lo(pn);
                 if (a.target && sh.t_w0t) {
                     sh.t_w0t[net * nw + (int64_t)k * H + cc] = tn;
                     if (sh.t_w0b) sh.t_w0b[(int64_t)net * H * Kp + (int64_t)cc * Kp + k] = f2bf(tn);
+                    if (sh.t_w0l) sh.t_w0l[(int64_t)net * H * Kp + (int64_t)cc * Kp + k] = f2bf_lo(tn);
                 }
             }
         }

@@ -56,7 +56,9 @@ int trunk_fwd(const float* x, int64_t ldx, const float* W0T, const float* b0, co
               int H, int nets, int64_t astride, int64_t pstride, int64_t tstride, hipStream_t s);
 // per-net operands of one trunk / scalar head, so that nets whose parameters live in different buffers (critic and its Polyak
 // target) share a launch
-struct TrunkItem { const float* x; const unsigned short* W0b; const float *b0, *gain, *beta; float* rstd; unsigned short *hb, *xhb; };
+// W0l / hl / xhl: lo planes of the split-bf16 mode (x = hi + lo); null in plain bf16 mode
+struct TrunkItem { const float* x; const unsigned short* W0b; const float *b0, *gain, *beta; float* rstd; unsigned short *hb, *xhb;
+                   const unsigned short* W0l; unsigned short *hl, *xhl; };
 struct TrunkBatch { TrunkItem it[4]; };
 int trunk_fwd16_batch(const TrunkBatch& tb, int count, int64_t ldx, int rows, int in_dim, int H, hipStream_t s);
 struct HeadItem { const float* a; const float* W; const float* b; float* out; };
@@ -66,10 +68,11 @@ int head_fwd1_batch(const HeadBatch& hb, int count, int rows, int H, hipStream_t
 bool trunk_fwd16_supported(int H);
 int trunk_fwd16(const float* x, int64_t ldx, const unsigned short* W0b, const float* b0, const float* gain, const float* beta, float* rstd,
                 unsigned short* h_bf16, unsigned short* xhat_bf16, int rows, int in_dim, int H, int nets, int64_t astride, int64_t pstride,
-                hipStream_t s);
+                hipStream_t s, const unsigned short* W0l = nullptr, unsigned short* h_lo = nullptr, unsigned short* xhat_lo = nullptr);
 int ln_bwd(float* dh, const float* h, const float* xhat, const unsigned short* h_bf16, const unsigned short* xhat_bf16,
            const float* rstd, const float* gain, float* P, int rows, int H, int nets, int64_t astride, int64_t pstride,
-           int want_params, hipStream_t s, const float* w0t = nullptr, int64_t tstride = 0, float* dx = nullptr, int dx_cols = 0);
+           int want_params, hipStream_t s, const float* w0t = nullptr, int64_t tstride = 0, float* dx = nullptr, int dx_cols = 0,
+           const unsigned short* h_lo = nullptr, const unsigned short* xhat_lo = nullptr);
 int trunk_chunks(int rows);
 int outer_reduce(const float* u, int64_t ldu, int J, const float* v, float* P, int rows, int H, int nets, int64_t vstride,
                  hipStream_t s);
@@ -115,7 +118,7 @@ struct DoutSpec {
     float inv_bg, alpha, stddev;
 };
 int head_bwd(const DoutSpec& dspec, const float* W, const float* a, float* dz, unsigned short* dz_bf16, float* P, int rows,
-             int H, int nout, int nets, int64_t astride, int64_t pstride, int want_params, hipStream_t s);
+             int H, int nout, int nets, int64_t astride, int64_t pstride, int want_params, hipStream_t s, unsigned short* dz_lo = nullptr);
 int head_chunks(int rows);
 // Scalar critic heads, forward and backward in one kernel (single-GPU whole-step path, no metrics): Q1,Q2 (and the target's
 // Q1',Q2') row dots, the loss gradient at the head output, dz2 = dQ * W2 * [h2 > 0] and the per-chunk parameter partials.
@@ -127,7 +130,7 @@ struct QHeadArgs {
     const float* b[4];
     float *q, *tq;           // (2, rows) outputs
     const float *reward, *discount;
-    float* dz; unsigned short* dzb; int64_t act;
+    float* dz; unsigned short* dzb; unsigned short* dzl; int64_t act;     // dzl: lo plane (split-bf16) or null
     float* P;                // head partials [net][chunk][(1+1)H + 16] or null
     float* abs_part;         // [chunk][2]
     int rows, H, mode;
@@ -177,6 +180,7 @@ struct ShadowSpec {
     float* t_w0t;                      // same for the Polyak target (nullptr if none)
     unsigned short* t_w1b;
     unsigned short* t_w0b;
+    unsigned short *w1l, *w0l, *t_w1l, *t_w0l;     // lo planes of the bf16 copies (split-bf16 mode), same shapes; or nullptr
 };
 int refresh_shadows(const float* p, int64_t n, const ShadowSpec& sh, bool target, hipStream_t s);
 
@@ -282,7 +286,7 @@ int cql_alpha_step(CqlScalars* sc, const float* stats, const AdamConst* c_dev, f
 // policy output for act(): tanh(mu) (eval) or tanh(mu + std z)
 int cql_act(const float* raw, const float* noise, uint64_t seed, uint64_t counter, int eval_mode, float* out, int rows, int A, hipStream_t s);
 int head_bwd_wide(const DoutSpec& dspec, const float* W, const float* a, float* dz, unsigned short* dz_bf16, float* P, int rows, int H,
-                  int nout, int64_t astride, int64_t pstride, int want_params, hipStream_t s);
+                  int nout, int64_t astride, int64_t pstride, int want_params, hipStream_t s, unsigned short* dz_lo = nullptr);
 
 // CRR (crr.py:121-142): xc_rep[(b*n+i)] = [obs_b | TruncatedNormal(mu_b).sample(clip)] for i < n
 int repeat_sample(const float* obs, const float* mu, const float* noise, uint64_t seed, const uint64_t* counter_ptr, uint64_t counter,

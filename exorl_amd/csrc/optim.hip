@@ -14,8 +14,11 @@ __device__ __forceinline__ unsigned short to_bf16(float x) {
 }
 
 // Writes the derived copies (ShadowSpec) of the 4 parameters at flat index 4*i4.
+__device__ __forceinline__ unsigned short to_bf16_lo(float x) { return to_bf16(x - __uint_as_float((unsigned)to_bf16(x) << 16)); }
+
+// w1l / w0l: lo planes (split-bf16 mode) or null
 __device__ __forceinline__ void write_shadows(int64_t i4, const float4& pv, const ShadowSpec& sh, float* w0t,
-                                              unsigned short* w1b, unsigned short* w0b) {
+                                              unsigned short* w1b, unsigned short* w0b, unsigned short* w1l, unsigned short* w0l) {
     const int64_t idx = 4 * i4;
     const int64_t hh = (int64_t)sh.H * sh.H, w0n = (int64_t)sh.H * sh.in_dim;
     for (int t = 0; t < sh.n_heads; ++t) {
@@ -23,7 +26,10 @@ __device__ __forceinline__ void write_shadows(int64_t i4, const float4& pv, cons
             unsigned short* d = w1b + t * hh + (idx - sh.w1_off[t]);
             const float e[4] = {pv.x, pv.y, pv.z, pv.w};
             for (int q = 0; q < 4; ++q)
-                if (idx + q < sh.w1_off[t] + hh) d[q] = to_bf16(e[q]);
+                if (idx + q < sh.w1_off[t] + hh) {
+                    d[q] = to_bf16(e[q]);
+                    if (w1l) w1l[t * hh + (idx - sh.w1_off[t]) + q] = to_bf16_lo(e[q]);
+                }
             return;
         }
     }
@@ -37,6 +43,7 @@ __device__ __forceinline__ void write_shadows(int64_t i4, const float4& pv, cons
                     if (w0b) {
                         const int64_t Kp = (sh.in_dim + 31) / 32 * 32;
                         w0b[t * (int64_t)sh.H * Kp + (l / sh.in_dim) * Kp + l % sh.in_dim] = to_bf16(e[q]);
+                        if (w0l) w0l[t * (int64_t)sh.H * Kp + (l / sh.in_dim) * Kp + l % sh.in_dim] = to_bf16_lo(e[q]);
                     }
                 }
             }
@@ -49,7 +56,7 @@ __global__ __launch_bounds__(256) void refresh_shadows_kernel(const float* __res
                                                               int target) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
         write_shadows(i, reinterpret_cast<const float4*>(p)[i], sh, target ? sh.t_w0t : sh.w0t, target ? sh.t_w1b : sh.w1b,
-                      target ? sh.t_w0b : sh.w0b);
+                      target ? sh.t_w0b : sh.w0b, target ? sh.t_w1l : sh.w1l, target ? sh.t_w0l : sh.w0l);
 }
 
 int refresh_shadows(const float* p, int64_t n, const ShadowSpec& sh, bool target, hipStream_t s) {
@@ -88,9 +95,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
             tv.z = polyak(pv.z, tv.z, c.tau, c.one_minus_tau);
             tv.w = polyak(pv.w, tv.w, c.tau, c.one_minus_tau);
             reinterpret_cast<float4*>(target)[i] = tv;
-            if (has_shadows) write_shadows(i, tv, sh, sh.t_w0t, sh.t_w1b, sh.t_w0b);
+            if (has_shadows) write_shadows(i, tv, sh, sh.t_w0t, sh.t_w1b, sh.t_w0b, sh.t_w1l, sh.t_w0l);
         }
-        if (has_shadows) write_shadows(i, pv, sh, sh.w0t, sh.w1b, sh.w0b);
+        if (has_shadows) write_shadows(i, pv, sh, sh.w0t, sh.w1b, sh.w0b, sh.w1l, sh.w0l);
     }
 }
 

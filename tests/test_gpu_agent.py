@@ -33,12 +33,14 @@ def nets_of(ag):
     return [('actor', ag.actor)] + ([('critic', ag.critic), ('critic_target', ag.critic_target)] if hasattr(ag, 'critic') else [])
 
 
-@pytest.mark.parametrize('kind', ['td3_bc', 'td3', 'bc', 'ddpg', 'crr', 'crr-exp', 'crr-identity'])
-def test_tiny_trajectory_vs_reference(gold, kind):
-    """Seeded construction reproduces the reference's init; 5 update() calls reproduce its metrics and weights."""
+@pytest.mark.parametrize('kind,precision', [(k, 'fp32') for k in ['td3_bc', 'td3', 'bc', 'ddpg', 'crr', 'crr-exp', 'crr-identity']] +
+                         [('td3_bc', 'bf16x3'), ('crr', 'bf16x3')])
+def test_tiny_trajectory_vs_reference(gold, kind, precision):
+    """Seeded construction reproduces the reference's init; 5 update() calls reproduce its metrics and weights.
+    (bf16x3 at these sizes is the in-GEMM operand split: widths below 64 do not use the hi/lo plane pipeline.)"""
     z = np.load(gold / f'tiny_{kind}.npz')
     torch.manual_seed(21)
-    ag = make(kind, 5, 3, 32, 8)
+    ag = make(kind, 5, 3, 32, 8, precision=precision)
     for nm, net in nets_of(ag):
         for k, v in net.state_dict().items():
             # same RNG draw order as the reference; QR itself differs in the last ulp across host CPUs
@@ -325,11 +327,12 @@ def test_cql_tiny_trajectory_vs_reference(gold, variant):
         np.testing.assert_allclose(ag.log_critic_alpha.numpy(), z['final/log_critic_alpha'], rtol=1e-5, atol=1e-8)
 
 
-def test_cql_full_size_vs_reference_fp32(gold):
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_cql_full_size_vs_reference_fp32(gold, precision):
     """BASELINE.json configs[2] shapes: CQL, quadruped (O=78, A=12), H=1024, B=1024, n_samples=3 -> critic on 10 B rows."""
     g = json.load(open(gold / 'full_cql.json'))
     O, A, H, B = g['dims']
-    ag = make('cql', O, A, H, B)
+    ag = make('cql', O, A, H, B, precision=precision)
     load_synth(ag, 'cql', O, A, H, g['param_seed'])
     ns = _synth.NoiseStream(g['noise_seed'])
     from oracle.agents import uniform_from_normal
@@ -366,7 +369,7 @@ def test_cql_act_and_graph():
         assert torch.equal(p, q)
 
 
-@pytest.mark.parametrize('kind,precision', [('td3_bc', 'fp32'), ('td3', 'fp32'), ('ddpg', 'fp32'), ('td3_bc', 'bf16')])
+@pytest.mark.parametrize('kind,precision', [('td3_bc', 'fp32'), ('td3', 'fp32'), ('ddpg', 'fp32'), ('td3_bc', 'bf16'), ('td3_bc', 'bf16x3')])
 def test_no_metrics_fast_path_matches_metrics_path(kind, precision):
     """use_tb=False takes the fused scalar-head kernels (Q forward + loss gradient + dz2 in one launch, lambda applied after
     the critic's linear backward) — same arithmetic as the metric-producing path up to rounding; also through the captured graph."""
