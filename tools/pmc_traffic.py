@@ -1,0 +1,37 @@
+"""Fabric-side traffic per launch of the dominant kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counters in KB).
+
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <kernel-substring> <out.json> [note]
+
+FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (wide coalesced reads are tallied at half their bytes).
+"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+
+def per_kernel(path, counter, pat):
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] != counter or pat not in r['Kernel_Name']:
+            continue
+        n = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('exorl::', '')
+        acc[n].append(float(r['Counter_Value']))
+    return acc
+
+
+fetch_csv, write_csv, pat, out = sys.argv[1:5]
+note = sys.argv[5] if len(sys.argv) > 5 else ''
+f, w = per_kernel(fetch_csv, 'FETCH_SIZE', pat), per_kernel(write_csv, 'WRITE_SIZE', pat)
+nf, nw = sum(len(v) for v in f.values()), sum(len(v) for v in w.values())
+fetch = sum(sum(v) for v in f.values()) / nf * 1024.0
+write = sum(sum(v) for v in w.values()) / nw * 1024.0
+json.dump({'kernel': f'*{pat}* (launch-weighted mean over the step)',
+           'per_kernel_fetch_KB_raw': {k: sum(v) / len(v) for k, v in f.items()},
+           'per_kernel_write_KB': {k: sum(v) / len(v) for k, v in w.items()},
+           'launches_counted': {'fetch_pass': nf, 'write_pass': nw},
+           'fetch_size_bytes_raw': fetch, 'fetch_size_bytes_corrected_x2': 2 * fetch, 'write_size_bytes': write,
+           'traffic_bytes_per_launch': 2 * fetch + write,
+           'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); counters are reported in KB',
+           'note': note}, open(out, 'w'), indent=1)
+print(open(out).read())

@@ -16,7 +16,7 @@ print(f'{"kernel":60s} {"calls":>7s} {"avg_us":>9s} {"us/step":>9s} {"%":>6s}')
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print(f'{n[:60]:60s} {c:7d} {t / c / 1e3:9.2f} {t / nsteps / 1e3:9.1f} {100 * t / tot:6.2f}')
 print(f'total kernel time per step: {tot / nsteps / 1e3:.1f} us')
-idx = [i for i, r in enumerate(rows) if 'step_begin' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'step_begin' in r['Kernel_Name'] or 'gather_nstep' in r['Kernel_Name']]
 if len(idx) > 20:
     a, b = idx[len(idx) // 2] - 1, idx[len(idx) // 2 + 1] - 1
     t0 = int(rows[a]['Start_Timestamp'])
