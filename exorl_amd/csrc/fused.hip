@@ -177,10 +177,12 @@ typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4_t;
 
 // X3 (split-bf16 mode): x and W0 enter as hi + lo pairs, z = hi*hi + hi*lo + lo*hi (fp32-grade first layer), and h / xhat
 // leave as hi + lo planes.
+#define TF16_LD(T) (16 * (T) + 16)
 template <int T, bool X3>     // T = H / 128 column tiles per wave
 __global__ __launch_bounds__(512) void trunk_fwd16_kernel(const TrunkBatch tb, int64_t ldx, int rows, int in_dim, int Kp) {
     constexpr int H = T * 128;
     __shared__ float red[2][8][16];
+    __shared__ __attribute__((aligned(16))) unsigned short stage[8][16][TF16_LD(T)];      // per-wave 16 x 16T output slab (+16 B row pad)
     const TrunkItem& it = tb.it[blockIdx.y];
     const float* __restrict__ x = it.x;
     const float* __restrict__ b0 = it.b0;
@@ -258,24 +260,42 @@ __global__ __launch_bounds__(512) void trunk_fwd16_kernel(const TrunkBatch tb, i
 #pragma unroll
     for (int w = 0; w < 8; ++w) var += red[1][w][rn];
     const float rs = 1.0f / sqrtf(var * (1.0f / (float)H) + LN_EPS2);
-    if (!live) return;
-    const int64_t o = net * astride + (int64_t)row * H;
+    float4 hv[T], xv[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         const int c = col0 + t * 16 + 4 * kq;
         const float4 g = *reinterpret_cast<const float4*>(gain + net * pstride + c);
         const float4 be = *reinterpret_cast<const float4*>(beta + net * pstride + c);
-        const float xh[4] = {acc[t][0] * rs, acc[t][1] * rs, acc[t][2] * rs, acc[t][3] * rs};
-        const float4 hv = make_float4(tanh_fast(xh[0] * g.x + be.x), tanh_fast(xh[1] * g.y + be.y), tanh_fast(xh[2] * g.z + be.z),
-                                      tanh_fast(xh[3] * g.w + be.w));
-        *reinterpret_cast<ushort4*>(hb + o + c) = f4_to_bf4(hv);
-        if constexpr (X3) *reinterpret_cast<ushort4*>(it.hl + o + c) = f4_to_bf4_lo(hv);
-        if (xhb) {
-            const float4 xv = make_float4(xh[0], xh[1], xh[2], xh[3]);
-            *reinterpret_cast<ushort4*>(xhb + o + c) = f4_to_bf4(xv);
-            if constexpr (X3) *reinterpret_cast<ushort4*>(it.xhl + o + c) = f4_to_bf4_lo(xv);
-        }
+        xv[t] = make_float4(acc[t][0] * rs, acc[t][1] * rs, acc[t][2] * rs, acc[t][3] * rs);
+        hv[t] = make_float4(tanh_fast(xv[t].x * g.x + be.x), tanh_fast(xv[t].y * g.y + be.y), tanh_fast(xv[t].z * g.z + be.z),
+                            tanh_fast(xv[t].w * g.w + be.w));
     }
+    // The MFMA C layout gives a lane 4 consecutive columns of one row (8 B of bf16); stored directly that is 32 B per row per
+    // instruction. Each wave transposes its 16 x 16T slab through LDS instead, so a store instruction writes whole 32T-byte row slabs.
+    unsigned short* mine = &stage[wave][0][0];
+    auto flush = [&](unsigned short* __restrict__ plane, const float4 (&v)[T], bool lo) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+            *reinterpret_cast<ushort4*>(mine + rn * TF16_LD(T) + t * 16 + 4 * kq) = lo ? f4_to_bf4_lo(v[t]) : f4_to_bf4(v[t]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int idx = lane; idx < 32 * T; idx += 64) {
+            const int r = idx / (2 * T), ch = idx % (2 * T);
+            const uint4 q = *reinterpret_cast<const uint4*>(mine + r * TF16_LD(T) + 8 * ch);
+            const int grow = blockIdx.x * 16 + r;
+            // (plain stores on purpose: streaming/non-temporal stores shortened this kernel by 4 us and lengthened its consumers,
+            // the H x H GEMM and LayerNorm backward, by 5 + 2 us — the slab is wanted in L2 / Infinity Cache)
+            if (grow < rows) *reinterpret_cast<uint4*>(plane + net * astride + (int64_t)grow * H + col0 + 8 * ch) = q;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    flush(hb, hv, false);
+    if constexpr (X3) flush(it.hl, hv, true);
+    if (xhb) {
+        flush(xhb, xv, false);
+        if constexpr (X3) flush(it.xhl, xv, true);
+    }
+    if (!live) return;
     if (rstd && wave == 0 && kq == 0) rstd[net * (int64_t)rows + row] = rs;
 }
 

@@ -87,11 +87,14 @@ def test_full_size_vs_reference_fp32(gold, kind, precision):
     load_synth(ag, kind, O, A, H, g['param_seed'])
     ns = _synth.NoiseStream(g['noise_seed'])
     ag.noise_hook = ns.draw
+    worst = 0.0
     for i in range(g['nsteps']):
         step = 2 * i if kind == 'ddpg' else i
         m = ag.update(iter([_synth.synth_batch(g['batch_seed'], i, B, O, A)]), step)
         for k, v in g['fp32']['metrics'][i].items():
             assert abs(m[k] - v) <= 1e-4 * abs(v) + 1e-6, (kind, i, k, m[k], v, g['fp64']['metrics'][i][k])
+            worst = max(worst, abs(m[k] - v) / (abs(v) + 1e-2))
+    print(f'[parity margin] {kind} {precision}: worst relative metric error over {g["nsteps"]} steps = {worst:.2e} (bar 1e-4)')
     for nm, net in nets_of(ag):
         flat = torch.cat([p.double().reshape(-1) for p in net.parameters()])
         s, s2, mx = g['fp32']['checksums'][nm]
