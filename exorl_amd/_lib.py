@@ -1,6 +1,7 @@
 """ctypes binding of libexorl_hip.so (include/exorl_hip.h). No fallback: if the HIP library is
 missing or a call fails, this raises — the product path never routes around the GPU kernels."""
 import ctypes as C
+import os
 from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
@@ -176,6 +177,9 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    tune = os.environ.get('EXORL_GEMM_TUNE')        # kernel-variant experiments (tools/micro): bit mask for exorl_gemm_tune
+    if tune:
+        lib.exorl_gemm_tune(int(tune))
     return lib
 
 

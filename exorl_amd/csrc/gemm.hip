@@ -544,9 +544,32 @@ __device__ __forceinline__ void gemm16g_body(const Gemm16Batch& gb, unsigned cha
         constexpr int st = decltype(sc)::value;
         // tile t has landed once at most the fills of the two younger tiles remain outstanding (4 DMA pieces per tile per wave)
         const int younger = nk - 1 - t;            // NSTG - 2 younger tiles may still be in flight
-        if (NSTG >= 4 && younger >= 2) { if constexpr (X3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-        else if (NSTG >= 3 && younger >= 1) { if constexpr (X3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int allowed = younger < NSTG - 2 ? younger : NSTG - 2;
+#define EXORL_WAITC(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+        if constexpr (X3) {
+            switch (allowed) {
+                case 0: EXORL_WAITC(0); break;
+                case 1: EXORL_WAITC(8); break;
+                case 2: EXORL_WAITC(16); break;
+                case 3: EXORL_WAITC(24); break;
+                case 4: EXORL_WAITC(32); break;
+                case 5: EXORL_WAITC(40); break;
+                default: EXORL_WAITC(48); break;
+            }
+        } else {
+            switch (allowed) {
+                case 0: EXORL_WAITC(0); break;
+                case 1: EXORL_WAITC(4); break;
+                case 2: EXORL_WAITC(8); break;
+                case 3: EXORL_WAITC(12); break;
+                case 4: EXORL_WAITC(16); break;
+                case 5: EXORL_WAITC(20); break;
+                case 6: EXORL_WAITC(24); break;
+                case 7: EXORL_WAITC(28); break;
+                default: EXORL_WAITC(32); break;
+            }
+        }
+#undef EXORL_WAITC
         __builtin_amdgcn_s_barrier();              // every wave's pieces of tile t are in LDS; stage st-1 is no longer being read
         asm volatile("" ::: "memory");
         if (t + NSTG - 1 < nk) fill(std::integral_constant<int, (st + NSTG - 1) % NSTG>{});
@@ -583,19 +606,19 @@ __device__ __forceinline__ void gemm16g_body(const Gemm16Batch& gb, unsigned cha
         acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[3], bfr[3], acc2, 0, 0, 0);
     };
 
-    fill(std::integral_constant<int, 0>{});
-    if constexpr (NSTG >= 3) fill(std::integral_constant<int, 1>{});
-    if constexpr (NSTG >= 4) fill(std::integral_constant<int, 2>{});
+    static_assert(NSTG >= 2 && NSTG <= 10 && (X3 ? NSTG <= 8 : true), "stage count out of range of the vmcnt table");
+#define EXORL_FILL0(I) if constexpr (NSTG > I + 1) { if (I < nk) fill(std::integral_constant<int, I>{}); }
+    EXORL_FILL0(0) EXORL_FILL0(1) EXORL_FILL0(2) EXORL_FILL0(3) EXORL_FILL0(4) EXORL_FILL0(5) EXORL_FILL0(6) EXORL_FILL0(7) EXORL_FILL0(8)
+#undef EXORL_FILL0
     int t = 0;
+#define EXORL_STEP(I) if constexpr (NSTG > I) step(std::integral_constant<int, I>{}, t + I);
     for (; t + NSTG <= nk; t += NSTG) {
-        step(std::integral_constant<int, 0>{}, t);
-        step(std::integral_constant<int, 1>{}, t + 1);
-        if constexpr (NSTG >= 3) step(std::integral_constant<int, 2>{}, t + 2);
-        if constexpr (NSTG >= 4) step(std::integral_constant<int, 3>{}, t + 3);
+        EXORL_STEP(0) EXORL_STEP(1) EXORL_STEP(2) EXORL_STEP(3) EXORL_STEP(4) EXORL_STEP(5) EXORL_STEP(6) EXORL_STEP(7) EXORL_STEP(8) EXORL_STEP(9)
     }
-    if (t < nk) step(std::integral_constant<int, 0>{}, t);                 // nk % NSTG tail (stages continue from 0)
-    if (t + 1 < nk) step(std::integral_constant<int, 1>{}, t + 1);
-    if constexpr (NSTG >= 4) { if (t + 2 < nk) step(std::integral_constant<int, 2>{}, t + 2); }
+#undef EXORL_STEP
+#define EXORL_TAIL(I) if constexpr (NSTG > I + 1) { if (t + I < nk) step(std::integral_constant<int, I>{}, t + I); }     // nk % NSTG tail
+    EXORL_TAIL(0) EXORL_TAIL(1) EXORL_TAIL(2) EXORL_TAIL(3) EXORL_TAIL(4) EXORL_TAIL(5) EXORL_TAIL(6) EXORL_TAIL(7) EXORL_TAIL(8)
+#undef EXORL_TAIL
 
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = X3 ? (acc2[i] + acc3[i]) + acc[i] : acc[i] + acc2[i];      // small terms first
@@ -819,9 +842,43 @@ __global__ __launch_bounds__(256) void gemm16x3_kernel(const Gemm16Batch gb) {
 }
 __global__ __launch_bounds__(256) void gemm16x3_mixed_kernel(const Gemm16Batch gb) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 4 * G16G_IMG];
-    if (gb.a_t[blockIdx.z]) gemm16g_body<true, true, 2, true>(gb, smem);
+    const int p = gb.xcd_map ? (int)(blockIdx.x & 7) / (8 / gb.count) : (int)blockIdx.z;
+    if (gb.a_t[p]) gemm16g_body<true, true, 2, true>(gb, smem);
     else gemm16g_body<false, true, 2, true>(gb, smem);
 }
+
+// Deep-pipeline variants (experiment, tuning bits 16384 / 32768): dynamic LDS up to the full 160 KB of a CU, to test whether the
+// k-loop is bound by bytes in flight (in-flight bytes <= LDS bytes). It is not: 5 x 32 KB split-bf16 stages with one workgroup per CU
+// run 35.8 us per launch against 24.6 us for 2 stages x 2 workgroups; plain bf16 10 stages x 1 workgroup 23.8 us against 13.7 us, and
+// 5 stages x 2 workgroups 13.75 us (no change). Together with the XCD-block mapping (no change either, so not fabric traffic) this
+// leaves LDS bandwidth: a 64 x 64 tile of 32 x 32 wave tiles reads every operand image twice, 128 KB (+64 KB of DMA writes) per CU
+// and k-tile pair in split mode = ~1500 LDS cycles of the ~2100 measured. Wave tiles of 64 x 32 or 64 x 64 are the lever, at the price
+// of half as many workgroups on a batch-1024 problem (the 128 x 128 experiment above).
+template <bool AT, bool BT, int NSTG, bool X3>
+__global__ __launch_bounds__(256) void gemm16d_kernel(const Gemm16Batch gb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_d[];
+    gemm16g_body<AT, BT, NSTG, X3>(gb, smem_d);
+}
+template <int NSTG, bool X3>
+__global__ __launch_bounds__(256) void gemm16d_mixed_kernel(const Gemm16Batch gb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_d[];
+    const int p = gb.xcd_map ? (int)(blockIdx.x & 7) / (8 / gb.count) : (int)blockIdx.z;
+    if (gb.a_t[p]) gemm16g_body<true, true, NSTG, X3>(gb, smem_d);
+    else gemm16g_body<false, true, NSTG, X3>(gb, smem_d);
+}
+template <int NSTG, bool X3>
+static int g16d_enable() {
+    static bool done = false;
+    if (done) return 0;
+    const int lds = NSTG * (X3 ? 4 : 2) * G16G_IMG;
+    EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm16d_kernel<false, false, NSTG, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm16d_kernel<false, true, NSTG, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm16d_kernel<true, true, NSTG, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm16d_mixed_kernel<NSTG, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    done = true;
+    return 0;
+}
+constexpr int G16D_X3_STAGES = 5;      // 5 x 32 KB = 160 KB: one workgroup per CU, four k-tiles (128 KB) in flight
 
 // One launch for the wgrad and dgrad GEMMs of a Linear(H,H) backward: both read dZ (wgrad as a k image, dgrad as a row image)
 // and are independent, so 2 x 512 tiles fill the 256 CUs four deep instead of two launches two deep, and one kernel boundary
@@ -872,8 +929,14 @@ static int launch16(const Gemm16Batch& gb, int count, int tiles64, int tiles128,
                   gb.p[i].ldb % 8 == 0 && reinterpret_cast<uintptr_t>(gb.p[i].A_lo) % 16 == 0 && reinterpret_cast<uintptr_t>(gb.p[i].B_lo) % 16 == 0 &&
                   reinterpret_cast<uintptr_t>(gb.p[i].A) % 16 == 0 && reinterpret_cast<uintptr_t>(gb.p[i].B) % 16 == 0;
         EXORL_REQUIRE(okx, "gemm16_grouped: split-bf16 operands need M, N, K multiples of 64 and 16-byte aligned hi/lo planes");
-        g2.xcd_map = 0;
-        hipLaunchKernelGGL((gemm16x3_kernel<AL != 0, BL != 0>), dim3(tiles64, 1, count), dim3(256), 0, s, g2);
+        g2.count = count;
+        g2.xcd_map = ((var & 2048) && xcd_map_ok(g2, count, 64)) ? 1 : 0;
+        if (var & 16384) {
+            EXORL_TRY((g16d_enable<G16D_X3_STAGES, true>()));
+            hipLaunchKernelGGL((gemm16d_kernel<AL != 0, BL != 0, G16D_X3_STAGES, true>), g2.xcd_map ? dim3(tiles64 * count, 1, 1) : dim3(tiles64, 1, count),
+                               dim3(256), G16D_X3_STAGES * 4 * G16G_IMG, s, g2);
+        } else if (g2.xcd_map) hipLaunchKernelGGL((gemm16x3_kernel<AL != 0, BL != 0>), dim3(tiles64 * count, 1, 1), dim3(256), 0, s, g2);
+        else hipLaunchKernelGGL((gemm16x3_kernel<AL != 0, BL != 0>), dim3(tiles64, 1, count), dim3(256), 0, s, g2);
         EXORL_LAUNCH_CHECK();
         if (prof) {
             EXORL_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s));
@@ -891,7 +954,15 @@ static int launch16(const Gemm16Batch& gb, int count, int tiles64, int tiles128,
         } else {
             g2.count = count;
             g2.xcd_map = ((var & 2048) && xcd_map_ok(g2, count, 64)) ? 1 : 0;     // measured: no gain over id order (12.8 vs 12.5 us) -> opt-in
-            if (g2.xcd_map) hipLaunchKernelGGL((gemm16g_kernel<AL != 0, BL != 0>), dim3(tiles64 * count, 1, 1), dim3(256), 0, s, g2);
+            if (var & 16384) {            // 10 x 16 KB = 160 KB, one workgroup per CU
+                EXORL_TRY((g16d_enable<10, false>()));
+                hipLaunchKernelGGL((gemm16d_kernel<AL != 0, BL != 0, 10, false>), g2.xcd_map ? dim3(tiles64 * count, 1, 1) : dim3(tiles64, 1, count),
+                                   dim3(256), 10 * 2 * G16G_IMG, s, g2);
+            } else if (var & 32768) {     // 5 x 16 KB = 80 KB, two workgroups per CU
+                EXORL_TRY((g16d_enable<5, false>()));
+                hipLaunchKernelGGL((gemm16d_kernel<AL != 0, BL != 0, 5, false>), g2.xcd_map ? dim3(tiles64 * count, 1, 1) : dim3(tiles64, 1, count),
+                                   dim3(256), 5 * 2 * G16G_IMG, s, g2);
+            } else if (g2.xcd_map) hipLaunchKernelGGL((gemm16g_kernel<AL != 0, BL != 0>), dim3(tiles64 * count, 1, 1), dim3(256), 0, s, g2);
             else if (var & 4096) hipLaunchKernelGGL((gemm16g_kernel<AL != 0, BL != 0, 3>), dim3(tiles64, 1, count), dim3(256), 0, s, g2);   // 3 WGs/CU
             else if (var & 8192) hipLaunchKernelGGL((gemm16g_kernel<AL != 0, BL != 0, 2>), dim3(tiles64, 1, count), dim3(256), 0, s, g2);   // 5 WGs/CU
             else hipLaunchKernelGGL((gemm16g_kernel<AL != 0, BL != 0>), dim3(tiles64, 1, count), dim3(256), 0, s, g2);
@@ -959,7 +1030,14 @@ int gemm16_grouped_mixed(const int* a_layouts, const Gemm16Problem* probs, int c
         EXORL_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.used], s));
     }
     if (x3) {
-        hipLaunchKernelGGL(gemm16x3_mixed_kernel, dim3(t64, 1, count), dim3(256), 0, s, gb);
+        gb.count = count;
+        gb.xcd_map = (g_gemm16_variant >= 0 && (g_gemm16_variant & 2048) && xcd_map_ok(gb, count, 64)) ? 1 : 0;
+        if (g_gemm16_variant >= 0 && (g_gemm16_variant & 16384)) {
+            EXORL_TRY((g16d_enable<G16D_X3_STAGES, true>()));
+            hipLaunchKernelGGL((gemm16d_mixed_kernel<G16D_X3_STAGES, true>), gb.xcd_map ? dim3(t64 * count, 1, 1) : dim3(t64, 1, count), dim3(256),
+                               G16D_X3_STAGES * 4 * G16G_IMG, s, gb);
+        } else if (gb.xcd_map) hipLaunchKernelGGL(gemm16x3_mixed_kernel, dim3(t64 * count, 1, 1), dim3(256), 0, s, gb);
+        else hipLaunchKernelGGL(gemm16x3_mixed_kernel, dim3(t64, 1, count), dim3(256), 0, s, gb);
     } else if (g16h_fits(gb, count)) {
         EXORL_TRY(g16h_enable());
         int t128 = 0;
@@ -969,7 +1047,13 @@ int gemm16_grouped_mixed(const int* a_layouts, const Gemm16Problem* probs, int c
     } else {
         gb.count = count;
         gb.xcd_map = (g_gemm16_variant >= 0 && (g_gemm16_variant & 2048) && xcd_map_ok(gb, count, 64)) ? 1 : 0;
-        if (gb.xcd_map) hipLaunchKernelGGL(gemm16g_mixed_kernel, dim3(t64 * count, 1, 1), dim3(256), 0, s, gb);
+        if (g_gemm16_variant >= 0 && (g_gemm16_variant & 16384)) {
+            EXORL_TRY((g16d_enable<10, false>()));
+            hipLaunchKernelGGL((gemm16d_mixed_kernel<10, false>), gb.xcd_map ? dim3(t64 * count, 1, 1) : dim3(t64, 1, count), dim3(256), 10 * 2 * G16G_IMG, s, gb);
+        } else if (g_gemm16_variant >= 0 && (g_gemm16_variant & 32768)) {
+            EXORL_TRY((g16d_enable<5, false>()));
+            hipLaunchKernelGGL((gemm16d_mixed_kernel<5, false>), gb.xcd_map ? dim3(t64 * count, 1, 1) : dim3(t64, 1, count), dim3(256), 5 * 2 * G16G_IMG, s, gb);
+        } else if (gb.xcd_map) hipLaunchKernelGGL(gemm16g_mixed_kernel, dim3(t64 * count, 1, 1), dim3(256), 0, s, gb);
         else hipLaunchKernelGGL(gemm16g_mixed_kernel, dim3(t64, 1, count), dim3(256), 0, s, gb);
     }
     EXORL_LAUNCH_CHECK();
