@@ -850,10 +850,13 @@ __global__ __launch_bounds__(256) void gemm16x3_mixed_kernel(const Gemm16Batch g
 // Deep-pipeline variants (experiment, tuning bits 16384 / 32768): dynamic LDS up to the full 160 KB of a CU, to test whether the
 // k-loop is bound by bytes in flight (in-flight bytes <= LDS bytes). It is not: 5 x 32 KB split-bf16 stages with one workgroup per CU
 // run 35.8 us per launch against 24.6 us for 2 stages x 2 workgroups; plain bf16 10 stages x 1 workgroup 23.8 us against 13.7 us, and
-// 5 stages x 2 workgroups 13.75 us (no change). Together with the XCD-block mapping (no change either, so not fabric traffic) this
-// leaves LDS bandwidth: a 64 x 64 tile of 32 x 32 wave tiles reads every operand image twice, 128 KB (+64 KB of DMA writes) per CU
-// and k-tile pair in split mode = ~1500 LDS cycles of the ~2100 measured. Wave tiles of 64 x 32 or 64 x 64 are the lever, at the price
-// of half as many workgroups on a batch-1024 problem (the 128 x 128 experiment above).
+// 5 stages x 2 workgroups 13.75 us (no change). The XCD-block mapping changes nothing either (23.3 vs 23.4 us), so it is not fabric
+// traffic, and the LDS array is at ~half its rate (128 KB of ds_read_b128 at 256 B/clk + 64 KB of DMA writes per CU and k-tile pair
+// = ~1000 of the ~2100 cycles). What is left is the operand delivery rate of a CU through the LDS-DMA path: 64 KB per 2100 cycles =
+// 73 GB/s, the same ~75 GB/s the plain bf16 kernel sustains and the 68-90 GB/s per CU MI355X_MICROARCH.md lists for LDS-DMA fills
+// ("ldsdma-fill", "ring-gemm"); it needs >= 2 workgroups per CU to be reached. Split-bf16 moves twice the bytes and takes twice the
+// time. Fewer operand bytes per FLOP (64 x 32 / 64 x 64 wave tiles) is the lever, at the price of half as many workgroups on a
+// batch-1024 problem (the 128 x 128 experiment above).
 template <bool AT, bool BT, int NSTG, bool X3>
 __global__ __launch_bounds__(256) void gemm16d_kernel(const Gemm16Batch gb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_d[];
