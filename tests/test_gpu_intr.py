@@ -143,8 +143,24 @@ def build_pair(kind, O, A, H, B, R, precision='fp32', **kw):
     ('disagreement', (24, 6, 256, 128, 0), {}),
 ])
 def test_shipped_widths_vs_oracle(kind, dims, kw):
+    _shipped_widths(kind, dims, kw, 'fp32')
+
+
+@pytest.mark.parametrize('kind,dims,kw', [
+    ('rnd', (24, 6, 1024, 1024, 512), {}),
+    ('icm_apt', (24, 6, 1024, 1024, 512), dict(knn_k=12)),
+    ('disagreement', (24, 6, 1024, 1024, 0), {}),
+    ('diayn', (24, 6, 1024, 1024, 16), {}),
+])
+def test_shipped_widths_vs_oracle_bf16x3(kind, dims, kw):
+    """Split-bf16 MFMA operands (DDPG step on hi/lo planes, module MLPs split inside the generic GEMM) against the fp32 oracle:
+    metrics at the same 1e-4, intrinsic rewards row by row."""
+    _shipped_widths(kind, dims, kw, 'bf16x3')
+
+
+def _shipped_widths(kind, dims, kw, precision):
     O, A, H, B, R = dims
-    ag, orc, ish = build_pair(kind, O, A, H, B, R, **kw)
+    ag, orc, ish = build_pair(kind, O, A, H, B, R, precision=precision, **kw)
     ns = _synth.NoiseStream(11)
     ag.noise_hook = ns.draw
     ns2 = _synth.NoiseStream(11)
@@ -161,12 +177,19 @@ def test_shipped_widths_vs_oracle(kind, dims, kw):
         # APS: the reward is a 12-NN distance in a 10-d feature space divided by its running mean — the rounding-noise-sized moves
         # Adam makes on the feature net (see assert_mostly_close) shift neighbour distances by ~1e-4 relative after the first step
         rt, at = (1e-3, 1e-4) if kind == 'aps' else (2e-4, 5e-5)
+        if precision != 'fp32':      # split-bf16 products carry ~1e-5 of the logit / feature scale; a reward is a difference of those
+            rt, at = 1e-3, 2e-4
         assert_mostly_close(intr, orc.last_intr, rt, at, 2e-3 * np.abs(orc.last_intr).max() + 10 * at, 2e-2, f'{kind} intr reward step {i}')
+        # actor_loss = -mean_b Q(s_b, pi(s_b)) is a cancelling mean here (4e-3 against |Q| ~ 0.1-0.5 per sample): in split-bf16 mode
+        # the 1e-4 is taken against a 0.1 scale for it, as for any signed mean; fp32 mode keeps the tight absolute floor
+        at_m = 1e-5 if precision != 'fp32' else 2e-6
         for k, v in mo.items():
-            assert abs(m[k] - v) <= 1e-4 * abs(v) + 2e-6, (kind, i, k, m[k], v)
+            assert abs(m[k] - v) <= 1e-4 * abs(v) + at_m, (kind, i, k, m[k], v)
     mod = module_of(ag)[1]
     for (k, _), p, want in zip(ish, mod.parameters(), orc.module.p):
         assert_mostly_close(p.cpu().numpy().reshape(want.shape), want, 1e-4, 2e-6, 2 * 1e-4 * 3, err_msg=k)
+    if precision != 'fp32':
+        return
     # module gradients of the last step, tensor by tensor
     n_train = 6 if kind == 'rnd' else len(ish)
     for i in range(n_train):
