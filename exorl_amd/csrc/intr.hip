@@ -610,7 +610,7 @@ struct exorl_intr {
     Lin trunk{};                           // APT: Linear(O, R) of the trunk; LayerNorm gain/beta offsets below
     int64_t ln_g = 0, ln_b = 0;
     float *xn = nullptr, *xf = nullptr, *xb = nullptr, *dxf = nullptr, *dxb = nullptr;
-    float *x2 = nullptr, *z = nullptr, *rep = nullptr, *xhat = nullptr, *rstd = nullptr, *drep = nullptr, *dz = nullptr, *topk = nullptr;
+    float *x2 = nullptr, *z = nullptr, *rep = nullptr, *xhat = nullptr, *rstd = nullptr, *drep = nullptr, *dz = nullptr, *topk = nullptr, *d2 = nullptr;    // d2: squared-distance scratch of the kNN (B x n_tgt)
     float *fe = nullptr, *be = nullptr, *metrics = nullptr, *bn = nullptr;
     RmsState* rms = nullptr;
     // Proto: predictor (Linear) in front of net[0] = projector; prototypes C; frozen predictor_target; candidate queue
@@ -715,6 +715,7 @@ static void carve_intr(exorl_intr* it, ICarver& c) {
         it->bn = c.take(2 * O + 1);
     } else if (g.kind == EXORL_INTR_APS) {
         it->topk = c.take(B * g.knn_k);
+        it->d2 = c.take(B * round_up(B, 64));
     } else if (g.kind == EXORL_INTR_SMM) {
         const int64_t C = SMM_CODE_DIM;
         it->mu = c.take(B * C); it->lv = c.take(B * C); it->eps = c.take(B * C); it->code = c.take(B * C); it->dcode = c.take(B * C);
@@ -726,6 +727,7 @@ static void carve_intr(exorl_intr* it, ICarver& c) {
         it->colsum_p = c.take(P); it->scal = c.take(4);
         it->queue = c.take((int64_t)g.queue_size * R);
         it->topk = c.take(B * g.knn_k);
+        it->d2 = c.take(B * round_up(g.queue_size, 64));
     } else if (g.kind == EXORL_INTR_DISAGREEMENT) {
         it->xf = c.take(B * it->net[0].L[0].in);
     } else if (g.kind != EXORL_INTR_DIAYN) {
@@ -736,6 +738,7 @@ static void carve_intr(exorl_intr* it, ICarver& c) {
             it->x2 = c.take(2 * B * O); it->z = c.take(2 * B * R); it->rep = c.take(2 * B * R); it->xhat = c.take(2 * B * R);
             it->rstd = c.take(2 * B); it->drep = c.take(2 * B * R); it->dz = c.take(2 * B * R);
             it->topk = c.take(B * g.knn_k);
+            it->d2 = c.take(B * round_up(B, 64));
         }
     }
 }
@@ -873,7 +876,7 @@ static int apt_update(exorl_intr* it, const exorl_intr_batch& b, bool train, hip
         EXORL_TRY(intr_adam(it, s));
     }
     EXORL_TRY(apt_trunk(it, b.obs, b.obs_ld, B, s));                                                 // icm_apt.py:106-110
-    EXORL_TRY(exorl_knn_topk(it->rep, B, it->rep, B, R, c.knn_k, it->topk, s));
+    EXORL_TRY(knn_topk(it->rep, B, it->rep, B, R, c.knn_k, it->topk, it->d2, s));
     hipLaunchKernelGGL(pbe_reward_kernel, dim3(1), dim3(1024), 0, s, it->topk, b.extr_reward, b.reward_out, B, c.knn_k, c.knn_avg, c.knn_rms,
                        c.knn_clip, it->rms, it->metrics);
     EXORL_LAUNCH_CHECK();
@@ -1002,7 +1005,7 @@ static int aps_update(exorl_intr* it, const exorl_intr_batch& b, bool train, hip
     }
     EXORL_TRY(mlp_forward(it->net[0], P, b.next_obs, b.next_obs_ld, B, prec, s));                    // aps.py:161-168
     const float* rep = it->net[0].act[2];
-    EXORL_TRY(exorl_knn_topk(rep, B, rep, B, D, c.knn_k, it->topk, s));
+    EXORL_TRY(knn_topk(rep, B, rep, B, D, c.knn_k, it->topk, it->d2, s));
     hipLaunchKernelGGL(pbe_reward_kernel, dim3(1), dim3(1024), 0, s, it->topk, b.extr_reward, b.reward_out, B, c.knn_k, c.knn_avg, c.knn_rms,
                        c.knn_clip, it->rms, it->metrics);
     hipLaunchKernelGGL(aps_sf_reward_kernel, dim3(1), dim3(1024), 0, s, rep, b.skill, b.skill_ld, b.reward_out, B, D, it->metrics);
@@ -1084,7 +1087,7 @@ static int proto_update(exorl_intr* it, const exorl_intr_batch& b, bool train, h
                        0x70726f746full, it->cat_counter++, it->queue, it->queue_ptr, B, P, D, (int*)nullptr);
     EXORL_LAUNCH_CHECK();
     it->queue_ptr = (it->queue_ptr + P) % c.queue_size;
-    EXORL_TRY(exorl_knn_topk(it->sn, B, it->queue, c.queue_size, D, c.knn_k, it->topk, s));
+    EXORL_TRY(knn_topk(it->sn, B, it->queue, c.queue_size, D, c.knn_k, it->topk, it->d2, s));
     hipLaunchKernelGGL(kth_reward_kernel, dim3(1), dim3(1024), 0, s, it->topk, b.extr_reward, b.reward_out, B, c.knn_k, it->metrics);
     EXORL_LAUNCH_CHECK();
     return 0;

@@ -74,6 +74,8 @@ int ln_bwd(float* dh, const float* h, const float* xhat, const unsigned short* h
            int want_params, hipStream_t s, const float* w0t = nullptr, int64_t tstride = 0, float* dx = nullptr, int dx_cols = 0,
            const unsigned short* h_lo = nullptr, const unsigned short* xhat_lo = nullptr);
 int trunk_chunks(int rows);
+// k smallest L2 distances of every src row to the tgt rows, ascending (knn.hip); d2 = scratch, n_src x round_up(n_tgt, 64) floats
+int knn_topk(const float* src, int n_src, const float* tgt, int n_tgt, int dim, int k, float* out, float* d2, hipStream_t s);
 int outer_reduce(const float* u, int64_t ldu, int J, const float* v, float* P, int rows, int H, int nets, int64_t vstride,
                  hipStream_t s);
 int outer_chunks(int rows);

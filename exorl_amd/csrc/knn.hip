@@ -2,49 +2,97 @@
 // a set of target rows, sorted ascending. Replaces the broadcast (b1,b2,c) temporaries + topk of
 //   /root/reference/utils/utils.py:289-300 (PBE, APT reward, 2 GiB temp at B=1024,c=512) and
 //   /root/reference/agents/unsupervised_learning/proto.py:114-119 (Proto reward vs the 2048-row queue).
-// One wave per source row, 4 rows per workgroup. Target rows stream through LDS in 64-row x 64-column tiles
-// (padded to 65 floats per row: conflict-free column walks); lane j owns target row j of the tile and
-// accumulates sum (s-t)^2 in the difference form the reference uses (not the |s|^2+|t|^2-2st GEMM form,
-// which loses the exact zeros on the diagonal that PBE relies on). Distances land in an LDS row per wave;
-// k rounds of wave-wide arg-min extraction produce the sorted top-k (wavefront-level top-k, no sort of B).
+// Two launches:
+//   pairdist2_kernel  squared distances in the difference form the reference uses, sum_c (s_c - t_c)^2 (not the
+//     |s|^2 + |t|^2 - 2 s.t GEMM form, which loses the exact zeros on the diagonal that PBE relies on), as a register-blocked
+//     tile kernel: a workgroup owns 64 source x 64 target rows, a thread a 4 x 4 block of pairs (rows ty + 16 i, tx + 16 j),
+//     both operands staged through LDS in 32-column chunks and read back as ds_read_b128 along c (row stride 36 floats:
+//     conflict-free for 16 consecutive rows). 2 LDS reads per 32 VALU operations; every operand byte is read from L2 once per
+//     64-row block of the other operand instead of once per 4 rows.
+//   knn_select_kernel one wave per source row: its row of squared distances -> LDS, k rounds of wave-wide arg-min extraction
+//     (wavefront-level top-k, no sort of the row), sqrt on the way out.
 #include "kernels.h"
 
 namespace exorl {
 
 constexpr int KNN_MAX_TGT = 4096;
 constexpr int KNN_MAX_K = 64;
+constexpr int PD_T = 64, PD_K = 32, PD_LD = PD_K + 4;
 
-__global__ __launch_bounds__(256) void knn_topk_kernel(const float* __restrict__ src, int n_src,
-                                                       const float* __restrict__ tgt, int n_tgt, int dim, int k,
-                                                       float* __restrict__ out) {
+__global__ __launch_bounds__(256) void pairdist2_kernel(const float* __restrict__ src, int n_src, const float* __restrict__ tgt,
+                                                        int n_tgt, int dim, float* __restrict__ d2, int ld, int vec) {
+    __shared__ __attribute__((aligned(16))) float S[PD_T * PD_LD];
+    __shared__ __attribute__((aligned(16))) float T[PD_T * PD_LD];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int s0 = blockIdx.y * PD_T, t0 = blockIdx.x * PD_T;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int c0 = 0; c0 < dim; c0 += PD_K) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + 256 * u, r = idx >> 3, c = c0 + 4 * (idx & 7);
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+            if (vec && c + 4 <= dim) {
+                if (s0 + r < n_src) a = *reinterpret_cast<const float4*>(src + (int64_t)(s0 + r) * dim + c);
+                if (t0 + r < n_tgt) b = *reinterpret_cast<const float4*>(tgt + (int64_t)(t0 + r) * dim + c);
+            } else {
+                float av[4] = {0.f, 0.f, 0.f, 0.f}, bv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (c + q < dim && s0 + r < n_src) av[q] = src[(int64_t)(s0 + r) * dim + c + q];
+                    if (c + q < dim && t0 + r < n_tgt) bv[q] = tgt[(int64_t)(t0 + r) * dim + c + q];
+                }
+                a = make_float4(av[0], av[1], av[2], av[3]);
+                b = make_float4(bv[0], bv[1], bv[2], bv[3]);
+            }
+            *reinterpret_cast<float4*>(S + r * PD_LD + 4 * (idx & 7)) = a;
+            *reinterpret_cast<float4*>(T + r * PD_LD + 4 * (idx & 7)) = b;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < PD_K; c += 4) {
+            float4 sv[4], tv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sv[i] = *reinterpret_cast<const float4*>(S + (ty + 16 * i) * PD_LD + c);
+                tv[i] = *reinterpret_cast<const float4*>(T + (tx + 16 * i) * PD_LD + c);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float d = sv[i].x - tv[j].x; acc[i][j] += d * d;
+                    d = sv[i].y - tv[j].y; acc[i][j] += d * d;
+                    d = sv[i].z - tv[j].z; acc[i][j] += d * d;
+                    d = sv[i].w - tv[j].w; acc[i][j] += d * d;
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = s0 + ty + 16 * i;
+        if (r >= n_src) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = t0 + tx + 16 * j;
+            if (t < ld) d2[(int64_t)r * ld + t] = t < n_tgt ? acc[i][j] : INFINITY;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void knn_select_kernel(const float* __restrict__ d2, int n_src, int n_pad, int k,
+                                                         float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* tile = smem;                       // [64][65]
-    float* srow = tile + 64 * 65;             // [4][64]   current 64-column chunk of the 4 source rows
-    float* dist = srow + 4 * 64;              // [4][n_tgt_pad]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + wave;
-    const int n_pad = (n_tgt + 63) & ~63;
-    float* mydist = dist + wave * n_pad;
-    for (int t0 = 0; t0 < n_tgt; t0 += 64) {
-        float acc = 0.f;
-        for (int c0 = 0; c0 < dim; c0 += 64) {
-            __syncthreads();
-            for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-                const int r = i >> 6, c = i & 63;
-                tile[r * 65 + c] = (t0 + r < n_tgt && c0 + c < dim) ? tgt[(int64_t)(t0 + r) * dim + c0 + c] : 0.f;
-            }
-            srow[wave * 64 + lane] = (row < n_src && c0 + lane < dim) ? src[(int64_t)row * dim + c0 + lane] : 0.f;
-            __syncthreads();
-#pragma unroll 8
-            for (int c = 0; c < 64; ++c) {
-                const float d = srow[wave * 64 + c] - tile[lane * 65 + c];
-                acc += d * d;
-            }
-        }
-        mydist[t0 + lane] = (t0 + lane < n_tgt) ? sqrtf(acc) : INFINITY;
-    }
-    __syncthreads();
-    if (row >= n_src) return;
+    if (row >= n_src) return;                      // wave-uniform; no workgroup barriers below
+    float* mydist = smem + wave * n_pad;
+    for (int t = lane; t < n_pad; t += 64) mydist[t] = d2[(int64_t)row * n_pad + t];
+    __builtin_amdgcn_wave_barrier();
     for (int j = 0; j < k; ++j) {
         float best = INFINITY;
         int bi = 0x7fffffff;
@@ -59,12 +107,24 @@ __global__ __launch_bounds__(256) void knn_topk_kernel(const float* __restrict__
             if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
         }
         if (lane == 0) {
-            out[(int64_t)row * k + j] = best;
+            out[(int64_t)row * k + j] = sqrtf(best);
             if (bi < n_pad) mydist[bi] = INFINITY;
         }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
     }
+}
+
+// d2: caller's scratch of n_src x round_up(n_tgt, 64) floats (the engines carve it from their workspace)
+int knn_topk(const float* src, int n_src, const float* tgt, int n_tgt, int dim, int k, float* out, float* d2, hipStream_t s) {
+    const int n_pad = (n_tgt + 63) & ~63;
+    float* g_d2 = d2;
+    const int vec = (dim % 4 == 0 && reinterpret_cast<uintptr_t>(src) % 16 == 0 && reinterpret_cast<uintptr_t>(tgt) % 16 == 0) ? 1 : 0;
+    hipLaunchKernelGGL(pairdist2_kernel, dim3(n_pad / PD_T, cdiv(n_src, PD_T)), dim3(256), 0, s, src, n_src, tgt, n_tgt, dim, g_d2, n_pad, vec);
+    EXORL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(knn_select_kernel, dim3(cdiv(n_src, 4)), dim3(256), 4 * (size_t)n_pad * sizeof(float), s, g_d2, n_src, n_pad, k, out);
+    EXORL_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // namespace exorl
@@ -76,9 +136,20 @@ extern "C" int exorl_knn_topk(const float* src, int32_t n_src, const float* tgt,
     EXORL_REQUIRE(n_src > 0 && n_tgt > 0 && n_tgt <= KNN_MAX_TGT && dim > 0, "knn_topk: unsupported sizes n_src=%d n_tgt=%d (max %d) dim=%d",
                   n_src, n_tgt, KNN_MAX_TGT, dim);
     EXORL_REQUIRE(k >= 1 && k <= KNN_MAX_K && k <= n_tgt, "knn_topk: k=%d out of range (<= %d, <= n_tgt)", k, KNN_MAX_K);
-    const int n_pad = (n_tgt + 63) & ~63;
-    const size_t lds = (64 * 65 + 4 * 64 + 4 * (size_t)n_pad) * sizeof(float);
-    hipLaunchKernelGGL(knn_topk_kernel, dim3(cdiv(n_src, 4)), dim3(256), lds, as_stream(stream), src, n_src, tgt, n_tgt, dim, k, out);
-    EXORL_LAUNCH_CHECK();
-    return 0;
+    // stand-alone entry (tests, callers without a workspace): library-owned scratch, grown on demand outside graph capture
+    static float* scratch = nullptr;
+    static size_t scratch_floats = 0;
+    const size_t need = (size_t)n_src * ((n_tgt + 63) & ~63);
+    hipStream_t s = as_stream(stream);
+    if (need > scratch_floats) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        EXORL_CHECK_HIP(hipStreamIsCapturing(s, &cs));
+        EXORL_REQUIRE(cs == hipStreamCaptureStatusNone, "knn_topk: the stand-alone entry sizes its scratch on first use; call it once before capturing");
+        EXORL_CHECK_HIP(hipDeviceSynchronize());
+        if (scratch) EXORL_CHECK_HIP(hipFree(scratch));
+        scratch = nullptr; scratch_floats = 0;
+        EXORL_CHECK_HIP(hipMalloc(&scratch, need * sizeof(float)));
+        scratch_floats = need;
+    }
+    return knn_topk(src, n_src, tgt, n_tgt, dim, k, out, scratch, s);
 }
