@@ -330,35 +330,44 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
     const float n = nrm[row];
     for (int j = lane; j < D; j += 64) dx[(int64_t)row * D + j] = (dy[(int64_t)row * D + j] - y[(int64_t)row * D + j] * s) / n;
 }
-// Sinkhorn-Knopp on S = scores / tau in the (B, P) layout of the scores (the reference works on the transpose):
-//   stage 0: scal[0] = max S                      stage 1: E = exp(S/tau - max/tau), scal[1] = sum E        (single block each)
-__global__ __launch_bounds__(1024) void sk_max_kernel(const float* __restrict__ S, int64_t n, float* __restrict__ scal) {
-    __shared__ float red[17];
-    float m = -INFINITY;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, S[i]);
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) { float r = red[0]; for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = fmaxf(r, red[i]); scal[0] = r; }
+// Sinkhorn-Knopp on S = scores / tau in the (B, P) layout of the scores (the reference works on the transpose). The global
+// max (Q -= Q.max(), proto.py:16) and the global sum (Q /= Q.sum(), :18) are formed from per-row values, a wave per row:
+//   sk_rowmax: rowred[b] = max_p S[b,p]
+//   sk_exp   : mx = max_b rowred[b] (every wave re-reduces the B values, fixed order); E = exp(S/tau - mx/tau); rowred[B+b] = sum_p E
+//   sk_row(first): total = sum_b rowred[B+b] (again per wave), E /= total
+__device__ __forceinline__ float sk_reduce_all(const float* __restrict__ v, int n, int lane, bool is_max) {
+    float r = is_max ? -INFINITY : 0.f;
+    for (int i = lane; i < n; i += 64) r = is_max ? fmaxf(r, v[i]) : r + v[i];
+    return is_max ? wave_max(r) : wave_sum(r);
 }
-__global__ __launch_bounds__(1024) void sk_exp_kernel(const float* __restrict__ S, float* __restrict__ E, int64_t n, float inv_tau,
-                                                      float* __restrict__ scal) {
-    __shared__ float red[17];
-    const float mx = scal[0] * inv_tau;
+__global__ __launch_bounds__(256) void sk_rowmax_kernel(const float* __restrict__ S, int rows, int P, float* __restrict__ rowred) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float m = -INFINITY;
+    for (int j = lane; j < P; j += 64) m = fmaxf(m, S[(int64_t)row * P + j]);
+    m = wave_max(m);
+    if (lane == 0) rowred[row] = m;
+}
+__global__ __launch_bounds__(256) void sk_exp_kernel(const float* __restrict__ S, float* __restrict__ E, int rows, int P, float inv_tau,
+                                                     float* __restrict__ rowred) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float mx = sk_reduce_all(rowred, rows, lane, true) * inv_tau;
     float s = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { const float e = expf(S[i] * inv_tau - mx); E[i] = e; s += e; }
-    s = block_sum(s, red);
-    if (threadIdx.x == 0) scal[1] = s;
+    for (int j = lane; j < P; j += 64) { const float e = expf(S[(int64_t)row * P + j] * inv_tau - mx); E[(int64_t)row * P + j] = e; s += e; }
+    s = wave_sum(s);
+    if (lane == 0) rowred[rows + row] = s;
 }
 // one Sinkhorn half-iteration pair, wave per row b: E[b,p] *= colscale_p, then the row is rescaled to sum `target`
 // (1/B inside the loop, 1 for the final normalisation). first != 0: colscale_p = 1/total (the Q /= Q.sum() of proto.py:18).
-__global__ __launch_bounds__(256) void sk_row_kernel(float* __restrict__ E, const float* __restrict__ colsum, const float* __restrict__ scal,
+__global__ __launch_bounds__(256) void sk_row_kernel(float* __restrict__ E, const float* __restrict__ colsum, const float* __restrict__ rowred,
                                                      int rows, int P, int first, float rP, float target) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
+    const float total = first ? sk_reduce_all(rowred + rows, rows, lane, false) : 1.0f;
     float s = 0.f;
     for (int j = lane; j < P; j += 64) {
-        const float v = E[(int64_t)row * P + j] * (first ? 1.0f / scal[1] : rP / colsum[j]);
+        const float v = E[(int64_t)row * P + j] * (first ? 1.0f / total : rP / colsum[j]);
         E[(int64_t)row * P + j] = v;
         s += v;
     }
@@ -387,40 +396,53 @@ __global__ __launch_bounds__(256) void proto_loss_kernel(const float* __restrict
     l = wave_sum(l);
     if (lane == 0) loss_row[row] = l;
 }
-// Categorical(softmax over the batch of scores[:, p]).sample() by inverse CDF (proto.py:109-112), one workgroup per prototype;
-// the chosen z row goes straight into the candidate queue (proto.py:115-117)
+// Categorical(softmax over the batch of scores[:, p]).sample() by inverse CDF (proto.py:109-112); the chosen z row goes straight
+// into the candidate queue (proto.py:115-117). A workgroup owns 16 prototypes: the (B, 16) slab of scores is read as 64-byte row
+// segments (a column per workgroup reads B separate cache lines), exp'd into LDS, and 16 lanes run the 16 serial double-precision
+// prefix walks side by side (serial in double, as the oracle / torch.multinomial's cumulative table).
+template <int PC_P>
 __global__ __launch_bounds__(256) void proto_candidates_kernel(const float* __restrict__ scores, const float* __restrict__ z,
                                                                const float* __restrict__ u_in, uint64_t seed, uint64_t counter,
                                                                float* __restrict__ queue, int64_t qrow0, int B, int P, int D,
                                                                int* __restrict__ cand_out) {
-    extern __shared__ float pr[];               // B probabilities (unnormalised), then prefix sums
-    __shared__ float red[17];
-    __shared__ int pick;
-    const int p = blockIdx.x;
+    extern __shared__ float pr[];               // [B][PC_P + 1] unnormalised probabilities
+    __shared__ float cmax[256 / PC_P][PC_P];
+    __shared__ int pick[PC_P];
+    const int p0 = blockIdx.x * PC_P;
+    constexpr int NBL = 256 / PC_P;
+    const int pl = threadIdx.x % PC_P, bl = threadIdx.x / PC_P;      // prototype lane, row lane
+    const bool live = p0 + pl < P;
     float mx = -INFINITY;
-    for (int b = threadIdx.x; b < B; b += blockDim.x) mx = fmaxf(mx, scores[(int64_t)b * P + p]);
-    mx = wave_max(mx);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    for (int b = bl; b < B; b += NBL) {
+        const float v = live ? scores[(int64_t)b * P + p0 + pl] : 0.f;
+        pr[b * (PC_P + 1) + pl] = v;
+        mx = fmaxf(mx, v);
+    }
+    cmax[bl][pl] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    for (int b = threadIdx.x; b < B; b += blockDim.x) pr[b] = expf(scores[(int64_t)b * P + p] - mx);
+    mx = cmax[0][pl];
+    for (int i = 1; i < NBL; ++i) mx = fmaxf(mx, cmax[i][pl]);
+    for (int b = bl; b < B; b += NBL) pr[b * (PC_P + 1) + pl] = expf(pr[b * (PC_P + 1) + pl] - mx);
     __syncthreads();
-    if (threadIdx.x == 0) {                     // serial prefix in double, as the oracle / torch.multinomial's cumulative table
+    if (threadIdx.x < PC_P && live) {
+        const int p = p0 + pl;
         double acc = 0.0;
-        for (int b = 0; b < B; ++b) acc += (double)pr[b];
+        for (int b = 0; b < B; ++b) acc += (double)pr[b * (PC_P + 1) + pl];
         float u;
         if (u_in) u = u_in[p];
         else { uint32_t c[4] = {(uint32_t)p, 7u, (uint32_t)counter, (uint32_t)(counter >> 32)}; Philox::gen(c, seed); u = (float)c[0] * 2.3283064365386963e-10f; }
         const double thr = (double)u * acc;
         double run = 0.0;
         int k = B - 1;
-        for (int b = 0; b < B; ++b) { run += (double)pr[b]; if (run > thr) { k = b; break; } }
-        pick = k;
+        for (int b = 0; b < B; ++b) { run += (double)pr[b * (PC_P + 1) + pl]; if (run > thr) { k = b; break; } }
+        pick[pl] = k;
         if (cand_out) cand_out[p] = k;
     }
     __syncthreads();
-    const int k = pick;
-    for (int j = threadIdx.x; j < D; j += blockDim.x) queue[(qrow0 + p) * D + j] = z[(int64_t)k * D + j];
+    for (int q = 0; q < PC_P && p0 + q < P; ++q) {
+        const int k = pick[q];
+        for (int j = threadIdx.x; j < D; j += blockDim.x) queue[(qrow0 + p0 + q) * D + j] = z[(int64_t)k * D + j];
+    }
 }
 // reward = topk-th smallest distance (proto.py:119-124) + reward bookkeeping; single block
 __global__ __launch_bounds__(1024) void kth_reward_kernel(const float* __restrict__ topk, const float* extr, float* reward, int B, int k,
@@ -576,12 +598,16 @@ int mlp_backward(const Mlp& m, const float* P, float* G, const float* x, int64_t
     for (int l = n - 1; l >= 0; --l) {
         const Lin& L = m.L[l];
         float* d = m.dact[l];
+        bool summed = false;
         if (l < n - 1 || m.relu_last) {
-            const int64_t cnt = (int64_t)rows * L.out;
-            hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(cnt)), dim3(256), 0, s, d, m.act[l], cnt);
-            EXORL_LAUNCH_CHECK();
+            summed = relu_bwd_colsum(d, m.act[l], G + L.b, rows, L.out, s) == 0;      // mask and bias gradient in one pass over dZ
+            if (!summed) {
+                const int64_t cnt = (int64_t)rows * L.out;
+                hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(cnt)), dim3(256), 0, s, d, m.act[l], cnt);
+                EXORL_LAUNCH_CHECK();
+            }
         }
-        EXORL_TRY(colsum(d, G + L.b, rows, L.out, 1, 0, 0, s));
+        if (!summed) EXORL_TRY(colsum(d, G + L.b, rows, L.out, 1, 0, 0, s));
         const float* in = l ? m.act[l - 1] : x;
         GemmProblem w{d, in, G + L.W, nullptr, L.out, L.in, rows, L.out, l ? (int64_t)L.in : ldx, L.in};          // dW[o][i] = sum_r d[r][o] in[r][i]
         EXORL_TRY(gemm_grouped(prec, 1, 1, &w, 1, false, false, s));
@@ -610,7 +636,7 @@ struct exorl_intr {
     Lin trunk{};                           // APT: Linear(O, R) of the trunk; LayerNorm gain/beta offsets below
     int64_t ln_g = 0, ln_b = 0;
     float *xn = nullptr, *xf = nullptr, *xb = nullptr, *dxf = nullptr, *dxb = nullptr;
-    float *x2 = nullptr, *z = nullptr, *rep = nullptr, *xhat = nullptr, *rstd = nullptr, *drep = nullptr, *dz = nullptr, *topk = nullptr, *d2 = nullptr;    // d2: squared-distance scratch of the kNN (B x n_tgt)
+    float *x2 = nullptr, *z = nullptr, *rep = nullptr, *xhat = nullptr, *rstd = nullptr, *drep = nullptr, *dz = nullptr, *topk = nullptr, *d2 = nullptr, *skr = nullptr;    // d2: squared-distance scratch of the kNN (B x n_tgt)
     float *fe = nullptr, *be = nullptr, *metrics = nullptr, *bn = nullptr;
     RmsState* rms = nullptr;
     // Proto: predictor (Linear) in front of net[0] = projector; prototypes C; frozen predictor_target; candidate queue
@@ -724,7 +750,7 @@ static void carve_intr(exorl_intr* it, ICarver& c) {
         const int64_t P = g.num_protos;
         it->z1 = c.take(B * R); it->dz1 = c.take(B * R); it->sn = c.take(B * R); it->nrm = c.take(B); it->tn = c.take(B * R);
         it->scores_s = c.take(B * P); it->scores_t = c.take(B * P); it->dscores = c.take(B * P); it->dsn = c.take(B * R);
-        it->colsum_p = c.take(P); it->scal = c.take(4);
+        it->colsum_p = c.take(P); it->scal = c.take(4); it->skr = c.take(2 * B);
         it->queue = c.take((int64_t)g.queue_size * R);
         it->topk = c.take(B * g.knn_k);
         it->d2 = c.take(B * round_up(g.queue_size, 64));
@@ -1044,13 +1070,13 @@ static int proto_update(exorl_intr* it, const exorl_intr_batch& b, bool train, h
         GemmProblem pq{it->tn, C, it->scores_t, nullptr, B, P, D, D, D, P};
         EXORL_TRY(gemm_grouped(prec, 0, 0, &pq, 1, false, false, s));
         const int64_t n = (int64_t)B * P;
-        hipLaunchKernelGGL(sk_max_kernel, dim3(1), dim3(1024), 0, s, it->scores_t, n, it->scal);
-        hipLaunchKernelGGL(sk_exp_kernel, dim3(1), dim3(1024), 0, s, it->scores_t, it->scores_t, n, inv_tau, it->scal);
-        hipLaunchKernelGGL(sk_row_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->scores_t, it->colsum_p, it->scal, B, P, 1, 0.f, 0.f);
+        hipLaunchKernelGGL(sk_rowmax_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->scores_t, B, P, it->skr);
+        hipLaunchKernelGGL(sk_exp_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->scores_t, it->scores_t, B, P, inv_tau, it->skr);
+        hipLaunchKernelGGL(sk_row_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->scores_t, it->colsum_p, it->skr, B, P, 1, 0.f, 0.f);
         EXORL_LAUNCH_CHECK();
         for (int iter = 0; iter < 3; ++iter) {     // u = r / Q.sum(1); Q *= u; Q *= c / Q.sum(0)   (+ the final Q / Q.sum(0) folded into the last pass)
             EXORL_TRY(colsum(it->scores_t, it->colsum_p, B, P, 1, 0, 0, s));
-            hipLaunchKernelGGL(sk_row_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->scores_t, it->colsum_p, it->scal, B, P, 0, 1.0f / (float)P,
+            hipLaunchKernelGGL(sk_row_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->scores_t, it->colsum_p, it->skr, B, P, 0, 1.0f / (float)P,
                                iter == 2 ? 1.0f : 1.0f / (float)B);
             EXORL_LAUNCH_CHECK();
         }
@@ -1083,8 +1109,15 @@ static int proto_update(exorl_intr* it, const exorl_intr_batch& b, bool train, h
     EXORL_TRY(launch_l2norm(it->sn, it->sn, nullptr, B, D, s));
     GemmProblem pc{it->sn, C, it->scores_s, nullptr, B, P, D, D, D, P};
     EXORL_TRY(gemm_grouped(prec, 0, 0, &pc, 1, false, false, s));
-    hipLaunchKernelGGL(proto_candidates_kernel, dim3(P), dim3(256), (size_t)B * sizeof(float), s, it->scores_s, it->sn, b.cat_uniform,
-                       0x70726f746full, it->cat_counter++, it->queue, it->queue_ptr, B, P, D, (int*)nullptr);
+#define EXORL_PCAND(PP) hipLaunchKernelGGL(proto_candidates_kernel<PP>, dim3(cdiv(P, PP)), dim3(256), (size_t)B * (PP + 1) * sizeof(float), s, it->scores_s, \
+                                            it->sn, b.cat_uniform, 0x70726f746full, it->cat_counter++, it->queue, it->queue_ptr, B, P, D, (int*)nullptr)
+    if ((size_t)B * 17 * sizeof(float) <= 64 * 1024) EXORL_PCAND(16);
+    else if ((size_t)B * 9 * sizeof(float) <= 64 * 1024) EXORL_PCAND(8);
+    else {
+        EXORL_REQUIRE((size_t)B * 5 * sizeof(float) <= 64 * 1024, "intr: Proto candidate sampling supports batch <= 3276 (got %d)", B);
+        EXORL_PCAND(4);
+    }
+#undef EXORL_PCAND
     EXORL_LAUNCH_CHECK();
     it->queue_ptr = (it->queue_ptr + P) % c.queue_size;
     EXORL_TRY(knn_topk(it->sn, B, it->queue, c.queue_size, D, c.knn_k, it->topk, it->d2, s));

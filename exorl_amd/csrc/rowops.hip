@@ -153,8 +153,58 @@ __global__ __launch_bounds__(1024) void ln_param_grad_kernel(const float* __rest
     }
 }
 
+// vector form (H % 4 == 0): 32 columns per workgroup (8 float4 lanes x 32 row lanes), as colsum4_kernel
+__global__ __launch_bounds__(256) void ln_param_grad4_kernel(const float* __restrict__ dh, const float* __restrict__ h,
+                                                              const float* __restrict__ xhat, float* __restrict__ dgain,
+                                                              float* __restrict__ dbeta, int rows, int H, int64_t astride, int64_t pstride) {
+    __shared__ float4 red[2][32][8];
+    const int net = blockIdx.y;
+    const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 32 + 4 * cg;
+    float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sb = sg;
+    if (c < H) {
+        for (int r0 = rl; r0 < rows; r0 += 64) {
+            float4 hv[2], dv[2], xv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = r0 + 32 * u;
+                if (r < rows) {
+                    const int64_t i = net * astride + (int64_t)r * H + c;
+                    hv[u] = *reinterpret_cast<const float4*>(h + i);
+                    dv[u] = *reinterpret_cast<const float4*>(dh + i);
+                    xv[u] = *reinterpret_cast<const float4*>(xhat + i);
+                } else {
+                    hv[u] = dv[u] = xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float4 dy = make_float4(dv[u].x * (1.0f - hv[u].x * hv[u].x), dv[u].y * (1.0f - hv[u].y * hv[u].y),
+                                              dv[u].z * (1.0f - hv[u].z * hv[u].z), dv[u].w * (1.0f - hv[u].w * hv[u].w));
+                sg.x += dy.x * xv[u].x; sg.y += dy.y * xv[u].y; sg.z += dy.z * xv[u].z; sg.w += dy.w * xv[u].w;
+                sb.x += dy.x; sb.y += dy.y; sb.z += dy.z; sb.w += dy.w;
+            }
+        }
+    }
+    red[0][rl][cg] = sg;
+    red[1][rl][cg] = sb;
+    __syncthreads();
+    if (rl < 2 && c < H) {
+        float4 t = red[rl][0][cg];
+#pragma unroll
+        for (int i = 1; i < 32; ++i) { t.x += red[rl][i][cg].x; t.y += red[rl][i][cg].y; t.z += red[rl][i][cg].z; t.w += red[rl][i][cg].w; }
+        *reinterpret_cast<float4*>((rl == 0 ? dgain : dbeta) + net * pstride + c) = t;
+    }
+}
+
 int ln_param_grad(const float* dh, const float* h, const float* xhat, float* dgain, float* dbeta,
                   int rows, int H, int nets, int64_t astride, int64_t pstride, hipStream_t s) {
+    auto al = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+    if (H % 4 == 0 && astride % 4 == 0 && pstride % 4 == 0 && al(dh) && al(h) && al(xhat) && al(dgain) && al(dbeta)) {
+        hipLaunchKernelGGL(ln_param_grad4_kernel, dim3(cdiv(H, 32), nets), dim3(256), 0, s, dh, h, xhat, dgain, dbeta, rows, H, astride, pstride);
+        EXORL_LAUNCH_CHECK();
+        return 0;
+    }
     dim3 grid(cdiv(H, 64), nets);
     hipLaunchKernelGGL(ln_param_grad_kernel, grid, dim3(1024), 0, s, dh, h, xhat, dgain, dbeta, rows, H, astride, pstride);
     EXORL_LAUNCH_CHECK();
@@ -174,9 +224,80 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
     if (ry == 0 && c < cols) out[net * pstride + c] = t;
 }
 
+// Vector form (cols % 4 == 0, 16-byte aligned): a workgroup owns 32 columns (8 float4 lanes x 32 row lanes) -> cols/32 workgroups
+// instead of cols/64, four independent row loads in flight per thread, fixed-order sum of the 32 row lanes through LDS.
+// MASK: the ReLU backward of the layer is applied on the way (x = act > 0 ? x : 0, written back) — mlp_backward's
+// relu_bwd + bias-gradient pair in one pass over dZ.
+template <bool MASK>
+__global__ __launch_bounds__(256) void colsum4_kernel(float* __restrict__ x, const float* __restrict__ act, float* __restrict__ out, int rows,
+                                                      int cols, int64_t astride, int64_t pstride) {
+    __shared__ float4 red[32][8];
+    const int net = blockIdx.y;
+    const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 32 + 4 * cg;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < cols) {
+        float* xb = x + net * astride + c;
+        const float* ab = MASK ? act + net * astride + c : nullptr;
+        int r = rl;
+        for (; r + 96 < rows; r += 128) {
+            float4 v[4], a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] = *reinterpret_cast<const float4*>(xb + (int64_t)(r + 32 * u) * cols);
+                if constexpr (MASK) a[u] = *reinterpret_cast<const float4*>(ab + (int64_t)(r + 32 * u) * cols);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if constexpr (MASK) {
+                    v[u].x = a[u].x > 0.f ? v[u].x : 0.f; v[u].y = a[u].y > 0.f ? v[u].y : 0.f;
+                    v[u].z = a[u].z > 0.f ? v[u].z : 0.f; v[u].w = a[u].w > 0.f ? v[u].w : 0.f;
+                    *reinterpret_cast<float4*>(xb + (int64_t)(r + 32 * u) * cols) = v[u];
+                }
+                acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+            }
+        }
+        for (; r < rows; r += 32) {
+            float4 v = *reinterpret_cast<const float4*>(xb + (int64_t)r * cols);
+            if constexpr (MASK) {
+                const float4 a = *reinterpret_cast<const float4*>(ab + (int64_t)r * cols);
+                v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
+                *reinterpret_cast<float4*>(xb + (int64_t)r * cols) = v;
+            }
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    red[rl][cg] = acc;
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+        float4 t = red[0][cg];
+#pragma unroll
+        for (int i = 1; i < 32; ++i) { t.x += red[i][cg].x; t.y += red[i][cg].y; t.z += red[i][cg].z; t.w += red[i][cg].w; }
+        *reinterpret_cast<float4*>(out + net * pstride + c) = t;
+    }
+}
+
+static bool colsum_vec_ok(const float* x, const float* out, int cols, int64_t astride, int64_t pstride) {
+    return cols % 4 == 0 && astride % 4 == 0 && pstride % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0;
+}
+
 int colsum(const float* x, float* out, int rows, int cols, int nets, int64_t astride, int64_t pstride, hipStream_t s) {
+    if (colsum_vec_ok(x, out, cols, astride, pstride)) {
+        hipLaunchKernelGGL((colsum4_kernel<false>), dim3(cdiv(cols, 32), nets), dim3(256), 0, s, const_cast<float*>(x), (const float*)nullptr, out,
+                           rows, cols, astride, pstride);
+        EXORL_LAUNCH_CHECK();
+        return 0;
+    }
     dim3 grid(cdiv(cols, 64), nets);
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(1024), 0, s, x, out, rows, cols, astride, pstride);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
+// x = act > 0 ? x : 0 in place, out[c] = sum_r x[r][c]; returns 1 (and does nothing) when the shapes need the two-kernel form
+int relu_bwd_colsum(float* x, const float* act, float* out, int rows, int cols, hipStream_t s) {
+    if (!colsum_vec_ok(x, out, cols, 0, 0) || reinterpret_cast<uintptr_t>(act) % 16 != 0) return 1;
+    hipLaunchKernelGGL((colsum4_kernel<true>), dim3(cdiv(cols, 32), 1), dim3(256), 0, s, x, act, out, rows, cols, (int64_t)0, (int64_t)0);
     EXORL_LAUNCH_CHECK();
     return 0;
 }
