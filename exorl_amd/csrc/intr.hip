@@ -407,6 +407,7 @@ __global__ __launch_bounds__(256) void proto_candidates_kernel(const float* __re
                                                                int* __restrict__ cand_out) {
     extern __shared__ float pr[];               // [B][PC_P + 1] unnormalised probabilities
     __shared__ float cmax[256 / PC_P][PC_P];
+    __shared__ double csum[256 / PC_P][PC_P];
     __shared__ int pick[PC_P];
     const int p0 = blockIdx.x * PC_P;
     constexpr int NBL = 256 / PC_P;
@@ -424,17 +425,32 @@ __global__ __launch_bounds__(256) void proto_candidates_kernel(const float* __re
     for (int i = 1; i < NBL; ++i) mx = fmaxf(mx, cmax[i][pl]);
     for (int b = bl; b < B; b += NBL) pr[b * (PC_P + 1) + pl] = expf(pr[b * (PC_P + 1) + pl] - mx);
     __syncthreads();
+    // inverse CDF in double, blocked: the NBL row lanes of a prototype each sum a contiguous chunk of rows in row order, one lane
+    // chains the chunk totals in chunk order, and the walk to the first row with run > u * total restarts from the prefix of the
+    // chunk that contains it. Same sequence of partial sums as one serial walk up to the association of double additions
+    // (~1e-16 relative: the pick can differ only if u * total falls that close to a boundary).
+    const int chunk = (B + NBL - 1) / NBL;
+    {
+        double c = 0.0;
+        const int b0 = bl * chunk, b1 = b0 + chunk < B ? b0 + chunk : B;
+        for (int b = b0; b < b1; ++b) c += (double)pr[b * (PC_P + 1) + pl];
+        csum[bl][pl] = c;
+    }
+    __syncthreads();
     if (threadIdx.x < PC_P && live) {
         const int p = p0 + pl;
         double acc = 0.0;
-        for (int b = 0; b < B; ++b) acc += (double)pr[b * (PC_P + 1) + pl];
+        for (int i = 0; i < NBL; ++i) acc += csum[i][pl];
         float u;
         if (u_in) u = u_in[p];
         else { uint32_t c[4] = {(uint32_t)p, 7u, (uint32_t)counter, (uint32_t)(counter >> 32)}; Philox::gen(c, seed); u = (float)c[0] * 2.3283064365386963e-10f; }
         const double thr = (double)u * acc;
         double run = 0.0;
-        int k = B - 1;
-        for (int b = 0; b < B; ++b) { run += (double)pr[b * (PC_P + 1) + pl]; if (run > thr) { k = b; break; } }
+        int j = 0;
+        while (j < NBL - 1 && !(run + csum[j][pl] > thr)) { run += csum[j][pl]; ++j; }
+        const int b1 = (j + 1) * chunk < B ? (j + 1) * chunk : B;
+        int k = b1 < B - 1 ? b1 : B - 1;          // reached only if rounding keeps the chunk's own walk at or below thr
+        for (int b = j * chunk; b < b1; ++b) { run += (double)pr[b * (PC_P + 1) + pl]; if (run > thr) { k = b; break; } }
         pick[pl] = k;
         if (cand_out) cand_out[p] = k;
     }
