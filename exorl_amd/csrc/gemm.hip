@@ -33,8 +33,9 @@ struct GemmProfile {
 static GemmProfile g_prof;
 constexpr size_t PROF_MAX_LAUNCHES = 1 << 15;
 
+constexpr int GEMM_MAX_GROUP = 16;     // problems per launch of the generic kernel (split-K slabs of one layer share a launch)
 struct GemmBatch {
-    GemmProblem p[4];
+    GemmProblem p[GEMM_MAX_GROUP];
     int relu;
     int accumulate;
 };
@@ -1148,7 +1149,7 @@ static bool aligned_for_vec(const GemmProblem& p, int al, int bl) {
 // Launches up to 4 independent problems (same layouts / epilogue flags) as one grid.
 int gemm_grouped(int precision, int a_layout, int b_layout, const GemmProblem* probs, int count, bool relu,
                  bool accumulate, hipStream_t s) {
-    EXORL_REQUIRE(count >= 1 && count <= 4, "gemm_grouped: count %d out of range", count);
+    EXORL_REQUIRE(count >= 1 && count <= GEMM_MAX_GROUP, "gemm_grouped: count %d out of range", count);
     GemmBatch gb;
     memset(&gb, 0, sizeof(gb));
     int max_tiles = 0;

@@ -608,6 +608,48 @@ int mlp_forward(const Mlp& m, const float* P, const float* x, int64_t ldx, int r
     return 0;
 }
 
+// n nets of identical shape on the same input (an ensemble): each layer's GEMMs of all nets share one grouped launch
+int mlp_forward_many(const Mlp* nets, int n, const float* P, const float* x, int64_t ldx, int rows, int prec, hipStream_t s) {
+    EXORL_REQUIRE(n >= 1 && n <= 16, "mlp_forward_many: %d nets", n);
+    const int nl = (int)nets[0].L.size();
+    for (int l = 0; l < nl; ++l) {
+        GemmProblem p[16];
+        for (int m = 0; m < n; ++m) {
+            const Lin& L = nets[m].L[l];
+            p[m] = GemmProblem{l ? nets[m].act[l - 1] : x, P + L.W, nets[m].act[l], P + L.b, rows, L.out, L.in, l ? (int64_t)L.in : ldx, L.in, L.out};
+        }
+        EXORL_TRY(gemm_grouped(prec, 0, 0, p, n, l < nl - 1 || nets[0].relu_last, false, s));
+    }
+    return 0;
+}
+// backward of the same ensemble (no d/d(input)): masks + bias gradients per net, weight gradients and hidden dgrads grouped
+int mlp_backward_many(const Mlp* nets, int n, const float* P, float* G, const float* x, int64_t ldx, int rows, int prec, hipStream_t s) {
+    EXORL_REQUIRE(n >= 1 && n <= 16, "mlp_backward_many: %d nets", n);
+    const int nl = (int)nets[0].L.size();
+    for (int l = nl - 1; l >= 0; --l) {
+        GemmProblem w[16], g[16];
+        for (int m = 0; m < n; ++m) {
+            const Lin& L = nets[m].L[l];
+            float* d = nets[m].dact[l];
+            bool summed = false;
+            if (l < nl - 1 || nets[m].relu_last) {
+                summed = relu_bwd_colsum(d, nets[m].act[l], G + L.b, rows, L.out, s) == 0;
+                if (!summed) {
+                    const int64_t cnt = (int64_t)rows * L.out;
+                    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(cnt)), dim3(256), 0, s, d, nets[m].act[l], cnt);
+                    EXORL_LAUNCH_CHECK();
+                }
+            }
+            if (!summed) EXORL_TRY(colsum(d, G + L.b, rows, L.out, 1, 0, 0, s));
+            w[m] = GemmProblem{d, l ? nets[m].act[l - 1] : x, G + L.W, nullptr, L.out, L.in, rows, L.out, l ? (int64_t)L.in : ldx, L.in};
+            if (l) g[m] = GemmProblem{d, P + L.W, nets[m].dact[l - 1], nullptr, rows, L.in, L.out, L.out, L.in, L.in};
+        }
+        EXORL_TRY(gemm_grouped(prec, 1, 1, w, n, false, false, s));
+        if (l) EXORL_TRY(gemm_grouped(prec, 0, 1, g, n, false, false, s));
+    }
+    return 0;
+}
+
 // dact[last] holds d(loss)/d(output); writes parameter gradients into G and, if dx, d(loss)/d(input) (rows, in0)
 int mlp_backward(const Mlp& m, const float* P, float* G, const float* x, int64_t ldx, int rows, float* dx, int prec, hipStream_t s) {
     const int n = (int)m.L.size();
@@ -933,21 +975,19 @@ static int disagreement_update(exorl_intr* it, const exorl_intr_batch& b, bool t
     float* G = it->flat[EXORL_T_GRAD];
     EXORL_TRY(launch_concat(b.obs, b.obs_ld, O, b.action, b.action_ld, A, it->xf, B, s));
     if (train) {                                                                                     // disagreement.py:19-33,64-80
+        EXORL_TRY(mlp_forward_many(it->net, n, P, it->xf, O + A, B, prec, s));          // the 5 models' layers share launches
         for (int m = 0; m < n; ++m) {
-            EXORL_TRY(mlp_forward(it->net[m], P, it->xf, O + A, B, prec, s));
             hipLaunchKernelGGL(icm_err_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->net[m].act[1], O, b.next_obs, b.next_obs_ld, nullptr, nullptr,
                                A, it->fe + (int64_t)m * B, nullptr, it->net[m].dact[1], nullptr, B, 1.0f / ((float)B * (float)n));
             EXORL_LAUNCH_CHECK();
-            EXORL_TRY(mlp_backward(it->net[m], P, G, it->xf, O + A, B, nullptr, prec, s));
         }
+        EXORL_TRY(mlp_backward_many(it->net, n, P, G, it->xf, O + A, B, prec, s));
         EXORL_TRY(launch_mean(it->fe, B * n, 1.0f / ((float)B * (float)n), it->metrics + EXORL_IM_LOSS, 0, s));
         EXORL_TRY(intr_adam(it, s));
     }
     PredSet ps{};
-    for (int m = 0; m < n; ++m) {                                                                    // disagreement.py:35-47
-        EXORL_TRY(mlp_forward(it->net[m], P, it->xf, O + A, B, prec, s));
-        ps.p[m] = it->net[m].act[1];
-    }
+    EXORL_TRY(mlp_forward_many(it->net, n, P, it->xf, O + A, B, prec, s));                           // disagreement.py:35-47
+    for (int m = 0; m < n; ++m) ps.p[m] = it->net[m].act[1];
     if (b.extr_reward) EXORL_TRY(launch_mean(b.extr_reward, B, 1.0f / (float)B, it->metrics + EXORL_IM_EXTR_REWARD, 0, s));
     hipLaunchKernelGGL(disagreement_reward_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, ps, n, b.reward_out, B, O);
     EXORL_LAUNCH_CHECK();

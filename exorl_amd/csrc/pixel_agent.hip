@@ -6,7 +6,7 @@
 // Built from the blocks of the other translation units: pixels.hip (RandomShiftsAug, conv encoder forward/backward), the generic
 // grouped GEMM + Linear/ReLU stack helpers (intr.hip), LayerNorm/tanh row kernels (rowops.hip), loss/sampling kernels (loss.hip),
 // Adam/Polyak (optim.hip). The one shape the generic GEMM handles badly is the trunk's Linear(39200, 50): 16 row tiles of a
-// K = 39200 reduction would occupy 16 CUs, so it runs as a 16-way split-K (4 grouped launches) + a fixed-order reduce.
+// K = 39200 reduction would occupy 16 CUs, so it runs as a 16-way split-K (one grouped launch, 256 workgroups) + a fixed-order reduce.
 #include <vector>
 
 #include "kernels.h"
@@ -153,17 +153,15 @@ static void pcarve(exorl_pixel_agent* a, PCarver& c) {
 static int trunk_forward(exorl_pixel_agent* a, const PNet& n, const float* P, const float* x, int rows, const TrunkAct& t, int prec, hipStream_t s) {
     const int D = n.D, F = n.F;
     int kc = (int)round_up(cdiv(D, SPLITK), 4);
-    for (int s0 = 0; s0 < SPLITK; s0 += 4) {
-        GemmProblem p[4];
-        int cnt = 0;
-        for (int i = 0; i < 4; ++i) {
-            const int k0 = (s0 + i) * kc;
-            if (k0 >= D) break;
-            const int k = D - k0 < kc ? D - k0 : kc;
-            p[cnt++] = GemmProblem{x + k0, P + n.trunk.W + k0, a->splitk + (int64_t)(s0 + i) * rows * F, nullptr, rows, F, k, D, D, F};
-        }
-        if (cnt) EXORL_TRY(gemm_grouped(prec, 0, 0, p, cnt, false, false, s));
+    GemmProblem p[SPLITK];                     // all slabs in one launch: SPLITK x rows/64 workgroups
+    int cnt = 0;
+    for (int i = 0; i < SPLITK; ++i) {
+        const int k0 = i * kc;
+        if (k0 >= D) break;
+        const int k = D - k0 < kc ? D - k0 : kc;
+        p[cnt++] = GemmProblem{x + k0, P + n.trunk.W + k0, a->splitk + (int64_t)i * rows * F, nullptr, rows, F, k, D, D, F};
     }
+    EXORL_TRY(gemm_grouped(prec, 0, 0, p, cnt, false, false, s));
     const int splits = cdiv(D, kc);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid1((int64_t)rows * F)), dim3(256), 0, s, a->splitk, P + n.trunk.b, t.z, (int64_t)rows * F, F, splits);
     EXORL_LAUNCH_CHECK();

@@ -14,6 +14,7 @@ from exorl_amd.replay_buffer import ArenaIterator
 
 C_, HW, A, B = 3, 84, 9, int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 kind = sys.argv[2] if len(sys.argv) > 2 else 'proto'
+precision = sys.argv[3] if len(sys.argv) > 3 else 'fp32'
 EPISODES, EP_LEN = 40, 250
 eng = ReplayEngine((C_, HW, HW), np.uint8, A, 0, EPISODES * (EP_LEN + 1) + 64, EPISODES + 8, 'cuda')
 rs = np.random.RandomState(0)
@@ -28,7 +29,7 @@ eng.seed_philox(1)
 it = ArenaIterator(eng, B, 3, 0.99, 'philox')
 kw = dict(name=kind, reward_free=True, obs_type='pixels', obs_shape=(C_, HW, HW), action_shape=(A,), device='cuda', lr=1e-4, feature_dim=50,
           hidden_dim=1024, critic_target_tau=0.01, num_expl_steps=2000, update_every_steps=2, stddev_schedule=0.2, nstep=3, batch_size=B,
-          stddev_clip=0.3, init_critic=True, use_tb=False, use_wandb=False)
+          stddev_clip=0.3, init_critic=True, use_tb=False, use_wandb=False, precision=precision)
 torch.manual_seed(1)
 if kind == 'proto':
     ag = agents.ProtoAgent(pred_dim=128, proj_dim=512, queue_size=2048, num_protos=512, tau=0.1, encoder_target_tau=0.05, topk=3, update_encoder=True, **kw)
@@ -43,4 +44,4 @@ for i in range(n):
     ag.update(it, 2 * (i + 3))
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print(f'{kind} pixels B={B}: {n / dt:.2f} update()/s, {1e3 * dt / n:.1f} ms per update', flush=True)
+print(f'{kind} pixels B={B} {precision}: {n / dt:.2f} update()/s, {1e3 * dt / n:.1f} ms per update', flush=True)
