@@ -230,20 +230,23 @@ def test_hip_graph_step_equals_eager(kind):
     assert m1 == m2
 
 
-@pytest.mark.parametrize('kind', ['td3_bc', 'ddpg', 'bc', 'crr'])
-def test_virtual_ranks_equal_single_rank(kind):
+@pytest.mark.parametrize('kind,precision', [('td3_bc', 'fp32'), ('ddpg', 'fp32'), ('bc', 'fp32'), ('crr', 'fp32'), ('td3_bc', 'bf16x3'), ('td3_bc', 'bf16')])
+def test_virtual_ranks_equal_single_rank(kind, precision):
     """The HIP engine's phase split (exorl_agent_update_phase) under data parallelism: two engines configured with
     world_size=2 each take half of a global batch; summing their gradient / statistic buffers between phases (what
     RCCL all-reduce does across GPUs) must reproduce the single-engine update on the whole batch."""
     from exorl_amd.engine import AgentEngine
     from exorl_amd import _lib as L
     O, A, H, B = 24, 6, 128, 64
+    if precision != 'fp32':
+        B = 128                      # per-rank batch 64: the bf16 / hi-lo plane pipeline (what bench.py runs under torch.distributed)
     ash, csh = param_shapes(kind, O, A, H)
     pa = list(_synth.synth_params(ash, 1).values())
     pc = list(_synth.synth_params(csh, 2).values()) if csh else None
+    mt, pr_, pa_ = {'fp32': (2e-5, 2e-5, 2e-7), 'bf16x3': (1e-4, 1e-4, 2e-6), 'bf16': (2e-2, 2e-2, 2e-3)}[precision]
 
     def engine(batch, world):
-        e = AgentEngine(kind, O, A, H, batch, world_size=world)
+        e = AgentEngine(kind, O, A, H, batch, world_size=world, precision=precision)
         for i, w in enumerate(pa):
             e.tensor(L.NET_ACTOR, i).copy_(torch.from_numpy(w).reshape(e.tensor(L.NET_ACTOR, i).shape))
         if pc:
@@ -283,12 +286,16 @@ def test_virtual_ranks_equal_single_rank(kind):
         msum = ranks[0].metrics_raw() + ranks[1].metrics_raw()          # partial means add up to the global means
         ms = single.metrics_raw()
         for k in (L.M_BATCH_REWARD, L.M_CRITIC_LOSS, L.M_ACTOR_LOSS, L.M_CRITIC_Q1) if pc else (L.M_BATCH_REWARD, L.M_ACTOR_LOSS):
-            assert abs(msum[k] - ms[k]) <= 2e-5 * abs(ms[k]) + 1e-6, (kind, step, k, msum[k], ms[k])
+            assert abs(msum[k] - ms[k]) <= mt * abs(ms[k]) + 1e-6 * (mt / 2e-5), (kind, step, k, msum[k], ms[k])
     nets = [L.NET_ACTOR] + ([L.NET_CRITIC, L.NET_CRITIC_TARGET] if pc else [])
     for net in nets:
         p0, p1, ps = ranks[0].flat(net), ranks[1].flat(net), single.flat(net)
         assert torch.equal(p0, p1)                                       # replicas stay bit-identical
-        np.testing.assert_allclose(p0.cpu().numpy(), ps.cpu().numpy(), rtol=2e-5, atol=2e-7)
+        if precision == 'fp32':
+            np.testing.assert_allclose(p0.cpu().numpy(), ps.cpu().numpy(), rtol=pr_, atol=pa_)
+        else:           # Adam moves rounding-noise gradients by +-lr either way (see test_no_metrics_fast_path_matches_metrics_path)
+            d = (p0 - ps).abs()
+            assert float((d > pa_ + pr_ * ps.abs()).float().mean()) <= 5e-3 and float(d.max()) <= 6.5e-4, (net, float(d.max()))
 
 
 def _cql_hook(draws):
