@@ -366,6 +366,11 @@ int trunk_fwd(const float* x, int64_t ldx, const float* W0T, const float* b0, co
 //   dz0 = rstd * (dxh - mean(dxh) - xhat * mean(dxh*xhat)),  dxh = dh*(1-h^2)*gain      (written in place over dh)
 // and per-workgroup partial column sums P[chunk] = [dgain H][dbeta H][db0 H] (PARAMS only).
 constexpr int TB_ROWS = 8;
+// rows per workgroup of the row-chunked backward kernels grow with the batch: the per-chunk partial gradients are summed by the
+// optimiser launch, and CQL's 10 B-row critic pass would otherwise leave 1280 partial rows per parameter to it
+// (measured on CQL, 10240 rows: optimiser launch 84 -> 50 us, the two producers +9 and +7 us)
+static int tb_iters(int rows) { return rows >= 8192 ? 4 : 1; }
+static int or_iters(int rows) { return rows >= 8192 ? 4 : 1; }
 __device__ __forceinline__ float4 bf4_to_f4(ushort4 q) {
     return make_float4(__uint_as_float((unsigned)q.x << 16), __uint_as_float((unsigned)q.y << 16),
                        __uint_as_float((unsigned)q.z << 16), __uint_as_float((unsigned)q.w << 16));
@@ -402,7 +407,7 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(float* dh, const float* __r
                                                      float* __restrict__ P, int rows, int H, int64_t astride,
                                                      int64_t pstride, const float* __restrict__ w0t, int64_t tstride,
                                                      float* __restrict__ dx, int dx_cols, const unsigned short* __restrict__ hl,
-                                                     const unsigned short* __restrict__ xhl) {
+                                                     const unsigned short* __restrict__ xhl, int iters) {
     __shared__ __attribute__((aligned(16))) float red[PARAMS ? 8 * 1024 : 4];
     const int net = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -414,8 +419,8 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(float* dh, const float* __r
         g[i] = c4 < H4 ? reinterpret_cast<const float4*>(gain + net * pstride)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
         pg[i] = pb[i] = pb0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int it = 0; it < TB_ROWS / 8; ++it) {
-        const int row = blockIdx.x * TB_ROWS + it * 8 + wave;
+    for (int it = 0; it < iters; ++it) {           // 8 rows per pass; large batches take 4 passes per workgroup (4x fewer partial rows)
+        const int row = blockIdx.x * TB_ROWS * iters + it * 8 + wave;
         if (row >= rows) continue;                      // wave-uniform
         const int64_t o = net * astride + (int64_t)row * H;
         float4 d[4], xh[4];
@@ -521,17 +526,18 @@ int ln_bwd(float* dh, const float* h, const float* xhat, const unsigned short* h
            const unsigned short* xhat_lo) {
     EXORL_REQUIRE(H >= 4 && H <= 1024 && H % 4 == 0, "ln_bwd: unsupported H=%d", H);
     EXORL_REQUIRE(!dx || (!want_params && w0t && dx_cols >= 1), "ln_bwd: the dx epilogue belongs to the dgrad-only pass");
-    const dim3 grid(cdiv(rows, TB_ROWS), nets);
+    const dim3 grid(trunk_chunks(rows), nets);
     const bool b16 = h_bf16 && xhat_bf16;
+    const int iters = tb_iters(rows);
     EXORL_REQUIRE((h_lo != nullptr) == (xhat_lo != nullptr) && (!h_lo || b16), "ln_bwd: lo planes come in pairs, with the bf16 hi planes");
-#define EXORL_LNB(PA, BB) hipLaunchKernelGGL((ln_bwd_kernel<PA, BB>), grid, dim3(512), 0, s, dh, h, xhat, h_bf16, xhat_bf16, rstd, gain, P, rows, H, astride, pstride, w0t, tstride, dx, dx_cols, h_lo, xhat_lo)
+#define EXORL_LNB(PA, BB) hipLaunchKernelGGL((ln_bwd_kernel<PA, BB>), grid, dim3(512), 0, s, dh, h, xhat, h_bf16, xhat_bf16, rstd, gain, P, rows, H, astride, pstride, w0t, tstride, dx, dx_cols, h_lo, xhat_lo, iters)
     if (want_params) { if (b16) EXORL_LNB(true, true); else EXORL_LNB(true, false); }
     else             { if (b16) EXORL_LNB(false, true); else EXORL_LNB(false, false); }
 #undef EXORL_LNB
     EXORL_LAUNCH_CHECK();
     return 0;
 }
-int trunk_chunks(int rows) { return cdiv(rows, TB_ROWS); }
+int trunk_chunks(int rows) { return cdiv(rows, TB_ROWS * tb_iters(rows)); }
 
 // ------------------------------------------------------------------------------------------------
 // outer-product column reduction: P[chunk][j][c] = sum_{m in chunk} u[m][j] * v[m][c]   (first-layer wgrad:
@@ -539,39 +545,43 @@ int trunk_chunks(int rows) { return cdiv(rows, TB_ROWS); }
 constexpr int OR_ROWS = 32;
 __global__ __launch_bounds__(256) void outer_reduce_kernel(const float* __restrict__ u, int64_t ldu, int J,
                                                            const float* __restrict__ v, float* __restrict__ P, int rows,
-                                                           int H, int64_t vstride) {
+                                                           int H, int64_t vstride, int iters) {
     __shared__ __attribute__((aligned(16))) float us[OR_ROWS][32];
     const int net = blockIdx.z;
-    const int row0 = blockIdx.y * OR_ROWS;
     const int c = blockIdx.x * 256 + threadIdx.x;
     float* Pn = P + ((int64_t)net * gridDim.y + blockIdx.y) * (int64_t)J * H;
-    const int nr = rows - row0 < OR_ROWS ? rows - row0 : OR_ROWS;
     for (int j0 = 0; j0 < J; j0 += 32) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < OR_ROWS * 32; i += 256) {
-            const int r = i >> 5, j = i & 31;
-            us[r][j] = (r < nr && j0 + j < J) ? u[(int64_t)(row0 + r) * ldu + j0 + j] : 0.f;
-        }
-        __syncthreads();
-        if (c < H) {
-            float acc[32];
+        float acc[32];
 #pragma unroll
-            for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+        for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+        for (int sub = 0; sub < iters; ++sub) {
+            const int row0 = (blockIdx.y * iters + sub) * OR_ROWS;
+            const int nr = rows - row0 < OR_ROWS ? rows - row0 : OR_ROWS;       // <= 0 past the end: nothing staged, nothing added
+            __syncthreads();
+            for (int i = threadIdx.x; i < OR_ROWS * 32; i += 256) {
+                const int r = i >> 5, j = i & 31;
+                us[r][j] = (r < nr && j0 + j < J) ? u[(int64_t)(row0 + r) * ldu + j0 + j] : 0.f;
+            }
+            __syncthreads();
+            if (c < H) {
 #pragma unroll 1
-            for (int rb = 0; rb < OR_ROWS; rb += 8) {
-                float vv[8];               // 8 rows in flight at once (memory-level parallelism)
+                for (int rb = 0; rb < OR_ROWS; rb += 8) {
+                    float vv[8];               // 8 rows in flight at once (memory-level parallelism)
 #pragma unroll
-                for (int r = 0; r < 8; ++r) vv[r] = rb + r < nr ? v[net * vstride + (int64_t)(row0 + rb + r) * H + c] : 0.f;
+                    for (int r = 0; r < 8; ++r) vv[r] = rb + r < nr ? v[net * vstride + (int64_t)(row0 + rb + r) * H + c] : 0.f;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
+                    for (int r = 0; r < 8; ++r) {
 #pragma unroll
-                    for (int j4 = 0; j4 < 8; ++j4) {
-                        const float4 uu = *reinterpret_cast<const float4*>(&us[rb + r][4 * j4]);
-                        acc[4 * j4] += uu.x * vv[r]; acc[4 * j4 + 1] += uu.y * vv[r]; acc[4 * j4 + 2] += uu.z * vv[r]; acc[4 * j4 + 3] += uu.w * vv[r];
+                        for (int j4 = 0; j4 < 8; ++j4) {
+                            const float4 uu = *reinterpret_cast<const float4*>(&us[rb + r][4 * j4]);
+                            acc[4 * j4] += uu.x * vv[r]; acc[4 * j4 + 1] += uu.y * vv[r]; acc[4 * j4 + 2] += uu.z * vv[r]; acc[4 * j4 + 3] += uu.w * vv[r];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);     // keep one row's 8 LDS reads live at a time (VGPR budget)
                     }
-                    __builtin_amdgcn_sched_barrier(0);     // keep one row's 8 LDS reads live at a time (VGPR budget)
                 }
             }
+        }
+        if (c < H) {
 #pragma unroll
             for (int j = 0; j < 32; ++j)
                 if (j0 + j < J) Pn[(int64_t)(j0 + j) * H + c] = acc[j];
@@ -581,12 +591,12 @@ __global__ __launch_bounds__(256) void outer_reduce_kernel(const float* __restri
 
 int outer_reduce(const float* u, int64_t ldu, int J, const float* v, float* P, int rows, int H, int nets, int64_t vstride,
                  hipStream_t s) {
-    hipLaunchKernelGGL(outer_reduce_kernel, dim3(cdiv(H, 256), cdiv(rows, OR_ROWS), nets), dim3(256), 0, s, u, ldu, J, v, P, rows,
-                       H, vstride);
+    hipLaunchKernelGGL(outer_reduce_kernel, dim3(cdiv(H, 256), outer_chunks(rows), nets), dim3(256), 0, s, u, ldu, J, v, P, rows,
+                       H, vstride, or_iters(rows));
     EXORL_LAUNCH_CHECK();
     return 0;
 }
-int outer_chunks(int rows) { return cdiv(rows, OR_ROWS); }
+int outer_chunks(int rows) { return cdiv(rows, OR_ROWS * or_iters(rows)); }
 
 // Sums 8 per-lane values over the wave with 10 cross-lane exchanges instead of 48: three butterfly steps that each
 // halve the number of live values (lane l ends up owning value index l & 7), then three plain steps over the remaining
