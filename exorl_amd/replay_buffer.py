@@ -10,9 +10,10 @@ Python; what was per-sample Python (episode pick, start index, gathers, n-step l
 is one HIP launch per batch. Tensors come back on the GPU (the reference's next step was an H2D copy,
 utils.py:55-56, so agents accept either).
 """
+import bisect
 import io
 import os
-from collections import defaultdict
+from collections import OrderedDict, defaultdict
 from pathlib import Path
 
 import numpy as np
@@ -41,6 +42,34 @@ def load_episode(fn):
         return {k: z[k] for k in z.keys()}
 
 
+def _load_or_none(fn):
+    try:
+        return load_episode(fn)
+    except Exception:            # a file still being written: the reference stops the fetch there too (replay_buffer.py:209-212)
+        return None
+
+
+def _load_many(fns, threads):
+    """Decodes episode files in order with a bounded look-ahead (a 5-10 M-transition dataset is thousands of
+    zlib-compressed .npz files; one decoding thread is what made loading minutes)."""
+    if threads <= 1 or len(fns) < 2:
+        for fn in fns:
+            yield _load_or_none(fn)
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        window = 4 * threads
+        pending = [pool.submit(_load_or_none, fn) for fn in fns[:window]]
+        nxt = len(pending)
+        for i in range(len(fns)):
+            ep = pending[i].result()
+            pending[i] = None
+            if nxt < len(fns):
+                pending.append(pool.submit(_load_or_none, fns[nxt]))
+                nxt += 1
+            yield ep
+
+
 class ReplayBufferStorage:
     """Accumulates time-steps and writes finished episodes as episode_{idx}_{len}.npz."""
 
@@ -52,6 +81,10 @@ class ReplayBufferStorage:
         self._current_episode = defaultdict(list)
         self._num_episodes = 0
         self._num_transitions = 0
+        # episodes finished in this process, kept until an in-process loader has taken them: the HBM sampler ingests them from here
+        # instead of re-reading and inflating the file it was just written to; bounded, oldest dropped first
+        self._fresh = OrderedDict()
+        self._fresh_max = 64
         for fn in self._replay_dir.glob('*.npz'):           # resume counters from what is on disk
             self._num_episodes += 1
             self._num_transitions += int(fn.stem.split('_')[2])
@@ -79,7 +112,11 @@ class ReplayBufferStorage:
         idx, length = self._num_episodes, episode_len(episode)
         self._num_episodes += 1
         self._num_transitions += length
-        save_episode(episode, self._replay_dir / f'episode_{idx}_{length}.npz')
+        fn = self._replay_dir / f'episode_{idx}_{length}.npz'
+        save_episode(episode, fn)
+        self._fresh[fn] = episode
+        while len(self._fresh) > self._fresh_max:
+            self._fresh.popitem(last=False)
 
 
 class _Shard:
@@ -108,12 +145,13 @@ class _Shard:
         self.engine = ReplayEngine(obs.shape[1:], obs.dtype, int(np.prod(episode['action'].shape[1:])), meta_dim, cap,
                                    max_eps, ld.device)
 
-    def _store(self, fn):
+    def _store(self, fn, episode=None, reorder=True):
         ld = self.loader
-        try:
-            episode = load_episode(fn)
-        except Exception:
-            return False
+        if episode is None:
+            try:
+                episode = load_episode(fn)
+            except Exception:
+                return False
         n = episode_len(episode)
         self._ensure_engine(episode)
         while n + self.size > ld.max_size:
@@ -123,10 +161,10 @@ class _Shard:
             early.unlink(missing_ok=True)
         self.slot[fn] = self.engine.append_episode(episode, ld.meta_keys)
         self.length[fn] = n
-        self.fns.append(fn)
-        self.fns.sort()
+        bisect.insort(self.fns, fn)                       # == append + sort (replay_buffer.py:185-186), without re-sorting per episode
         self.size += n
-        self.engine.set_order([self.slot[f] for f in self.fns])
+        if reorder:
+            self.engine.set_order([self.slot[f] for f in self.fns])
         if not ld.save_snapshot:
             fn.unlink(missing_ok=True)
         return True
@@ -140,8 +178,8 @@ class _Shard:
         stamp = os.stat(d).st_mtime_ns
         if stamp == self.dir_stamp and self.fns:
             return                                         # nothing was added since the last scan
-        fetched = 0
-        for fn in sorted(d.glob('*.npz'), reverse=True):
+        fetched, todo = 0, []
+        for fn in sorted(d.glob('*.npz'), reverse=True):  # the reference's selection (replay_buffer.py:196-212) ...
             idx, n = (int(x) for x in fn.stem.split('_')[1:])
             if idx % ld.num_workers != self.worker_id:
                 continue
@@ -150,8 +188,22 @@ class _Shard:
             if fetched + n > ld.max_size:
                 break
             fetched += n
-            if not self._store(fn):
+            todo.append(fn)
+        # ... decoded by a thread pool (zlib releases the GIL), stored in the reference's order; the episode table is uploaded once
+        stored = False
+        fresh = getattr(ld.storage, '_fresh', None)
+        if fresh and ld.num_workers == 1:                 # one consumer: hand the in-memory copies over and let the storage forget them
+            have = {fn: fresh.pop(fn) for fn in todo if fn in fresh}
+            rest = iter(_load_many([fn for fn in todo if fn not in have], ld.load_threads))
+            episodes = (have[fn] if fn in have else next(rest) for fn in todo)
+        else:
+            episodes = _load_many(todo, ld.load_threads)
+        for fn, episode in zip(todo, episodes):
+            if episode is None or not self._store(fn, episode, reorder=False):
                 break
+            stored = True
+        if stored:
+            self.engine.set_order([self.slot[f] for f in self.fns])
         self.dir_stamp = os.stat(d).st_mtime_ns
 
 
@@ -159,7 +211,8 @@ class DeviceReplayLoader:
     """What make_replay_loader returns: iterable whose iterator yields device-resident minibatches."""
 
     def __init__(self, storage, max_size, batch_size, num_workers, save_snapshot, nstep, discount, fetch_every=1000,
-                 device='cuda', sampler='mt19937', seed=None, worker_ids=None, max_episodes=None, capacity_rows=None, static=False):
+                 device='cuda', sampler='mt19937', seed=None, worker_ids=None, max_episodes=None, capacity_rows=None, static=False,
+                 load_threads=None):
         self.storage = storage
         self.static = static                # the directory will not change (offline datasets): load once, never re-scan
         self.num_workers = max(1, num_workers)
@@ -175,6 +228,7 @@ class DeviceReplayLoader:
         self.meta_keys = tuple(s.name for s in getattr(storage, '_meta_specs', ()))
         self.max_episodes = max_episodes
         self.capacity_rows = capacity_rows
+        self.load_threads = load_threads if load_threads is not None else min(16, os.cpu_count() or 1)      # episode decode pool
         # which reference workers this process plays: all of them (single process) or a subset (one per DP rank)
         self.worker_ids = list(range(self.num_workers)) if worker_ids is None else list(worker_ids)
 

@@ -173,3 +173,21 @@ def test_storage_writes_reference_format(tmp_path):
     assert ep['skill'].shape == (5, 2)
     st2 = ReplayBufferStorage(specs, (), tmp_path / 'buffer')      # _preload resumes the counters
     assert len(st2) == 7 and st2._num_episodes == 2
+
+
+def test_parallel_episode_decode_keeps_order_and_stops_at_broken_file(tmp_path):
+    """The ingest pool must hand episodes back in the requested order and yield None for an unreadable
+    file, which is where the fetch stops (replay_buffer.py:209-212 breaks out of its loop the same way)."""
+    from exorl_amd import replay_buffer as rb
+    fns = []
+    for i in range(12):
+        ep = dict(observation=np.full((5 + i, 3), i, np.float32), action=np.zeros((5 + i, 2), np.float32),
+                  reward=np.zeros((5 + i, 1), np.float32), discount=np.ones((5 + i, 1), np.float32))
+        fn = tmp_path / f'episode_{i}_{4 + i}.npz'
+        rb.save_episode(ep, fn)
+        fns.append(fn)
+    fns[7].write_bytes(b'not a zip file')
+    for threads in (1, 4):
+        got = list(rb._load_many(fns, threads))
+        assert [None if e is None else int(e['observation'][0, 0]) for e in got] == [0, 1, 2, 3, 4, 5, 6, None, 8, 9, 10, 11]
+        assert all(rb.episode_len(e) == 4 + i for i, e in enumerate(got) if e is not None)
