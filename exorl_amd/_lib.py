@@ -84,6 +84,9 @@ PROTOTYPES = {
     'exorl_pixel_agent_encoder_target': (C.c_int, [c_void_p, c_float, c_int32, c_void_p]),
     'exorl_pixel_agent_set_train_encoder': (C.c_int, [c_void_p, c_int32]),
     'exorl_pixel_agent_encoder_target_ptr': (C.c_int, [c_void_p, P(c_void_p)]),
+    'exorl_pixel_agent_state': (C.c_int, [c_void_p, c_void_p, c_void_p]),
+    'exorl_pixel_agent_set_state': (C.c_int, [c_void_p, c_void_p, c_void_p]),
+    'exorl_pixel_agent_encoder_opt2': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     'exorl_pixel_agent_metrics': (C.c_int, [c_void_p, c_void_p, c_void_p]),
     'exorl_pixel_agent_act': (C.c_int, [c_void_p, c_void_p, c_float, c_int32, c_void_p, c_void_p, c_void_p]),
     'exorl_aug_shift': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_uint64, c_uint64, c_void_p, c_void_p]),
@@ -103,6 +106,7 @@ PROTOTYPES = {
     'exorl_intr_update': (C.c_int, [c_void_p, P(IntrBatch), c_int32, c_void_p]),
     'exorl_intr_metrics': (C.c_int, [c_void_p, c_void_p, c_void_p]),
     'exorl_intr_opt_steps': (C.c_int, [c_void_p, P(c_int64), c_int32]),
+    'exorl_intr_counter': (C.c_int, [c_void_p, c_void_p, c_int32]),
     'exorl_last_error': (C.c_char_p, []),
     'exorl_abi_version': (C.c_int, []),
     'exorl_device_info': (C.c_int, [C.c_char_p, C.c_int, P(C.c_int), P(c_int64)]),

@@ -1332,4 +1332,11 @@ int exorl_intr_opt_steps(exorl_intr_t* it, int64_t* steps, int32_t set) {
     return 0;
 }
 
+int exorl_intr_counter(exorl_intr_t* m, uint64_t* counter_inout, int32_t set) {
+    EXORL_REQUIRE(m && counter_inout, "intr_counter: null argument");
+    if (set) m->cat_counter = *counter_inout;
+    else *counter_inout = m->cat_counter;
+    return 0;
+}
+
 }  // extern "C"

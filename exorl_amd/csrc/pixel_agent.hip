@@ -358,6 +358,27 @@ int exorl_pixel_agent_encoder_target_ptr(exorl_pixel_agent_t* a, void** ptr_dev)
     return 0;
 }
 
+// training state that is not a tensor view: Adam step counts (critic/actor/encoder share one, proto_opt's encoder state has its
+// own) and the Philox counters of the noise / augmentation / act() streams — what a pickled agent needs to continue bit-identically
+int exorl_pixel_agent_state(exorl_pixel_agent_t* a, int64_t* steps2, uint64_t* counters3) {
+    EXORL_REQUIRE(a && steps2 && counters3, "pixel_agent_state: null argument");
+    steps2[0] = a->t; steps2[1] = a->t2;
+    counters3[0] = a->noise_counter; counters3[1] = a->aug_counter; counters3[2] = a->act_counter;
+    return 0;
+}
+int exorl_pixel_agent_set_state(exorl_pixel_agent_t* a, const int64_t* steps2, const uint64_t* counters3) {
+    EXORL_REQUIRE(a && steps2 && counters3 && steps2[0] >= 0 && steps2[1] >= 0, "pixel_agent_set_state: bad arguments");
+    a->t = steps2[0]; a->t2 = steps2[1];
+    a->noise_counter = counters3[0]; a->aug_counter = counters3[1]; a->act_counter = counters3[2];
+    a->augmented = false;
+    return 0;
+}
+int exorl_pixel_agent_encoder_opt2(exorl_pixel_agent_t* a, void** m_dev, void** v_dev, int64_t* n) {
+    EXORL_REQUIRE(a && m_dev && v_dev && n, "pixel_agent_encoder_opt2: null argument");
+    *m_dev = a->enc_m2; *v_dev = a->enc_v2; *n = a->enc_total;
+    return 0;
+}
+
 int exorl_pixel_agent_update(exorl_pixel_agent_t* a, float stddev, const int32_t* shifts_obs, const int32_t* shifts_next, const float* noise_c,
                              const float* noise_a, void* stream) {
     EXORL_REQUIRE(a && stddev > 0.f, "pixel_agent_update: bad arguments");

@@ -272,6 +272,11 @@ class IntrEngine:
         v = C.c_int64(n)
         L.check(self.lib.exorl_intr_opt_steps(self.h, C.byref(v), 1))
 
+    def counter(self, set_to=None):
+        c = C.c_uint64(0 if set_to is None else int(set_to))
+        L.check(self.lib.exorl_intr_counter(self.h, C.byref(c), 0 if set_to is None else 1))
+        return int(c.value)
+
 
 class PixelEngine:
     """DDPG on pixel observations (exorl_pixel_agent_t): augmentation, conv encoder, pixel actor/critic and their update."""
@@ -382,6 +387,34 @@ class PixelEngine:
 
     def set_train_encoder(self, enable):
         L.check(self.lib.exorl_pixel_agent_set_train_encoder(self.h, int(bool(enable))))
+
+    # -- pickling support: everything that defines the training state, as CPU data
+    def export_state(self):
+        torch.cuda.synchronize()
+        steps, ctr = np.zeros(2, np.int64), np.zeros(3, np.uint64)
+        L.check(self.lib.exorl_pixel_agent_state(self.h, steps.ctypes.data, ctr.ctypes.data))
+        st = {'steps': steps, 'counters': ctr, 'tensors': {}}
+        for net in range(4):
+            for what in ((L.T_PARAM,) if net == 3 else (L.T_PARAM, L.T_ADAM_M, L.T_ADAM_V)):
+                st['tensors'][(net, what)] = [self.tensor(net, i, what).cpu() for i in range(self.num_tensors(net))]
+        m, v, n, p = C.c_void_p(), C.c_void_p(), C.c_int64(), C.c_void_p()
+        L.check(self.lib.exorl_pixel_agent_encoder_opt2(self.h, C.byref(m), C.byref(v), C.byref(n)))
+        L.check(self.lib.exorl_pixel_agent_encoder_target_ptr(self.h, C.byref(p)))
+        st['enc_extra'] = [self._view(q.value, n.value).cpu() for q in (m, v, p)]
+        return st
+
+    def import_state(self, st):
+        for (net, what), ts in st['tensors'].items():
+            for i, t in enumerate(ts):
+                self.tensor(net, i, what).copy_(t.reshape(self.tensor(net, i, what).shape))
+        m, v, n, p = C.c_void_p(), C.c_void_p(), C.c_int64(), C.c_void_p()
+        L.check(self.lib.exorl_pixel_agent_encoder_opt2(self.h, C.byref(m), C.byref(v), C.byref(n)))
+        L.check(self.lib.exorl_pixel_agent_encoder_target_ptr(self.h, C.byref(p)))
+        for q, t in zip((m, v, p), st['enc_extra']):
+            self._view(q.value, n.value).copy_(t)
+        steps, ctr = np.ascontiguousarray(st['steps'], np.int64), np.ascontiguousarray(st['counters'], np.uint64)
+        L.check(self.lib.exorl_pixel_agent_set_state(self.h, steps.ctypes.data, ctr.ctypes.data))
+        torch.cuda.synchronize()
 
     def metrics_raw(self):
         host = np.zeros(L.N_METRICS, np.float32)

@@ -352,6 +352,8 @@ int exorl_intr_update(exorl_intr_t* m, const exorl_intr_batch* batch, int32_t tr
 int exorl_intr_metrics(exorl_intr_t* m, float* host_out /* EXORL_N_INTR_METRICS */, void* stream);
 /* optimiser step count of the module's Adam: set == 0 reads into *steps, else writes it (snapshot restore) */
 int exorl_intr_opt_steps(exorl_intr_t* m, int64_t* steps, int32_t set);
+/* Philox counter of the module's own random draws (Proto's categorical candidate picks, SMM's VAE epsilon): part of the pickled state */
+int exorl_intr_counter(exorl_intr_t* m, uint64_t* counter_inout, int32_t set);
 
 /* ---------------------------------------------------------------------------------------------
  * Pixel front end (building blocks; the pixel actor/critic heads are not wired into exorl_agent_* yet).
@@ -415,6 +417,12 @@ int exorl_pixel_agent_encode(exorl_pixel_agent_t* a, int32_t which, int32_t targ
 int exorl_pixel_agent_encoder_step(exorl_pixel_agent_t* a, int32_t which, float* dfeat_dev, int32_t opt, void* stream);
 int exorl_pixel_agent_encoder_target(exorl_pixel_agent_t* a, float tau, int32_t init, void* stream);
 int exorl_pixel_agent_encoder_target_ptr(exorl_pixel_agent_t* a, void** ptr_dev);
+/* Whole-agent pickling (pretrain.py:293-300): steps2 = {Adam step count of encoder_opt/critic_opt/actor_opt, of proto_opt's encoder state},
+ * counters3 = Philox counters of the update-noise, augmentation and act() streams; encoder_opt2 = proto_opt's Adam moments for the
+ * encoder (n floats each, same layout as the encoder's flat parameters, which encoder_target_ptr also uses). */
+int exorl_pixel_agent_state(exorl_pixel_agent_t* a, int64_t* steps2_out, uint64_t* counters3_out);
+int exorl_pixel_agent_set_state(exorl_pixel_agent_t* a, const int64_t* steps2, const uint64_t* counters3);
+int exorl_pixel_agent_encoder_opt2(exorl_pixel_agent_t* a, void** m_dev, void** v_dev, int64_t* n_floats);
 /* enable == 0: update() treats the encoding as detached in update_critic (what the reward-free agents pass, proto.py:190-193):
  * no encoder backward, encoder_opt does not step. Default 1 (plain DDPG, ddpg.py:316-319). */
 int exorl_pixel_agent_set_train_encoder(exorl_pixel_agent_t* a, int32_t enable);

@@ -238,7 +238,7 @@ def test_bf16_mode_tracks_fp32():
         assert abs(res['bf16'][k] - v) <= 3e-2 * abs(v) + 3e-2, (k, res['bf16'][k], v)
 
 
-@pytest.mark.parametrize('kind', ['td3_bc', 'cql', 'rnd', 'icm_apt'])
+@pytest.mark.parametrize('kind', ['td3_bc', 'cql', 'rnd', 'icm_apt', 'proto', 'smm'])
 def test_pickle_roundtrip_continues_bit_identically(kind):
     """pretrain.py:293-300 / finetune.py:222-252 torch.save and torch.load the whole agent object: a restored agent must
     continue the run exactly (parameters, Adam moments and step counts, running statistics)."""
@@ -247,10 +247,15 @@ def test_pickle_roundtrip_continues_bit_identically(kind):
     O, A, H, B, R = 17, 6, 128, 64, 32
     if kind in ('rnd', 'icm_apt'):
         ag = make(kind, O, A, H, B, R)
+    elif kind == 'proto':                    # categorical candidate picks come from the module's own Philox stream
+        ag = make_proto(O, A, H, B, 16, 32, 8, 32)
+    elif kind == 'smm':                      # so does the VAE's epsilon
+        ag = make_smm(O, A, H, B, 4)
     else:
         from test_gpu_agent import make as make_offline
         ag = make_offline(kind, O, A, H, B)
-    upd = (lambda a, i: a.update(iter([_synth.synth_batch(23, i, B, O, A)]), 2 * i))
+    extra = lambda i: ((np.eye(4, dtype=np.float32)[np.random.RandomState(i).randint(0, 4, B)],) if kind == 'smm' else ())
+    upd = (lambda a, i: a.update(iter([_synth.synth_batch(23, i, B, O, A) + extra(i)]), 2 * i))
 
     def hook(agent, seed):
         ns = _synth.NoiseStream(seed)

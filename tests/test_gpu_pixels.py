@@ -231,3 +231,49 @@ def test_pixel_proto_vs_reference(gold):
                 np.testing.assert_allclose(v.reshape(-1)[::997], z[f'final_sample/{nm}/{k}'], rtol=1e-4, atol=2e-6, err_msg=f'{nm}.{k}')
     np.testing.assert_allclose(ag.queue.cpu().numpy(), z['final/queue'], rtol=1e-4, atol=1e-6)
     assert ag.queue_ptr == int(z['final/queue_ptr'])
+
+
+@pytest.mark.parametrize('kind', ['ddpg', 'proto'])
+def test_pixel_agent_pickle_roundtrip_continues_bit_identically(kind):
+    """pretrain.py:293-300 torch.save's the whole agent: the pixel agents carry encoder / actor / critic parameters and Adam moments,
+    the step counts, the Philox counters of the noise and augmentation streams, and (Proto) encoder_target, proto_opt's second
+    Adam state for the encoder, the module and its queue."""
+    import io
+    import pickle
+    import _synth
+    from exorl_amd import agents
+    C_, HW, A, F, H, B = 3, 84, 4, 50, 64, 8
+    kw = dict(name=kind, reward_free=True, obs_type='pixels', obs_shape=(C_, HW, HW), action_shape=(A,), device='cuda', lr=1e-4, feature_dim=F,
+              hidden_dim=H, critic_target_tau=0.01, num_expl_steps=2000, update_every_steps=2, stddev_schedule=0.2, nstep=3, batch_size=B,
+              stddev_clip=0.3, init_critic=True, use_tb=True, use_wandb=False)
+    torch.manual_seed(5)
+    if kind == 'proto':
+        ag = agents.ProtoAgent(pred_dim=16, proj_dim=32, queue_size=32, num_protos=8, tau=0.1, encoder_target_tau=0.05, topk=3, update_encoder=True, **kw)
+    else:
+        ag = agents.DDPGAgent(**kw)
+
+    def batch(i):
+        rs = np.random.RandomState(100 + i)
+        return (rs.randint(0, 256, (B, C_, HW, HW)).astype(np.uint8), rs.uniform(-1, 1, (B, A)).astype(np.float32),
+                rs.uniform(0, 1, (B, 1)).astype(np.float32), np.full((B, 1), 0.97, np.float32), rs.randint(0, 256, (B, C_, HW, HW)).astype(np.uint8))
+    for i in range(2):                       # Philox-drawn noise, shifts and categorical draws: their counters are part of the state
+        ag.update(iter([batch(i)]), 2 * i)
+    buf = io.BytesIO()
+    torch.save({'agent': ag, '_global_step': 2}, buf)
+    buf.seek(0)
+    ag2 = torch.load(buf, weights_only=False)['agent']           # our own file (finetune.py:250)
+    ag3 = pickle.loads(pickle.dumps(ag))
+    ms = []
+    for a in (ag, ag2, ag3):
+        for i in range(2, 4):
+            m = a.update(iter([batch(i)]), 2 * i)
+        ms.append(m)
+    assert ms[0] == ms[1] == ms[2]
+    views = ['encoder', 'actor', 'critic', 'critic_target'] + (['encoder_target', 'predictor', 'predictor_target', 'projector', 'protos'] if kind == 'proto' else [])
+    for other in (ag2, ag3):
+        assert type(other) is type(ag)
+        for nm in views:
+            for (k, p), q in zip(getattr(ag, nm).state_dict().items(), getattr(other, nm).state_dict().values()):
+                assert torch.equal(p, q), (kind, nm, k)
+        if kind == 'proto':
+            assert torch.equal(ag.queue, other.queue) and ag.queue_ptr == other.queue_ptr
