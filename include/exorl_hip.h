@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EXORL_ABI_VERSION 4
+#define EXORL_ABI_VERSION 5
 
 const char* exorl_last_error(void);
 int exorl_abi_version(void);

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert s in _lib.PROTOTYPES, f'{s} has no ctypes prototype'
     assert set(_lib.PROTOTYPES) == set(syms)
     lib.exorl_abi_version.restype = ctypes.c_int
-    assert lib.exorl_abi_version() == 4
+    assert lib.exorl_abi_version() == 5
 
 
 def test_product_fails_loudly_without_gpu():
