@@ -653,7 +653,7 @@ __device__ __forceinline__ void gemm16g_body(const Gemm16Batch& gb, unsigned cha
 // LDS, one workgroup per CU.
 constexpr int G16H_STAGE = 4 * G16G_IMG;           // A0 A1 B0 B1
 
-template <bool AT, bool BT, int NSTG>
+template <bool AT, bool BT, int NSTG, bool X3 = false>
 __device__ __forceinline__ void gemm16h_body(const Gemm16Batch& gb, unsigned char* smem) {
     constexpr int IMG = G16G_IMG;
     const Gemm16Problem& P = gb.p[blockIdx.z];
@@ -672,16 +672,17 @@ __device__ __forceinline__ void gemm16h_body(const Gemm16Batch& gb, unsigned cha
     const int h = lane >> 5;
     const int nk = K >> 6;                         // multiple of NSTG (checked by the launcher)
 
-    f32x16 acc[2][2];
+    constexpr int STAGE = (X3 ? 8 : 4) * IMG;      // A0 A1 B0 B1 [A0l A1l B0l B1l]
+    f32x16 acc[2][2], accx[X3 ? 2 : 1][X3 ? 2 : 1];      // accx: the two cross terms hi*lo + lo*hi of the split-bf16 product, summed
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+            for (int i = 0; i < 16; ++i) { acc[a][b][i] = 0.f; if constexpr (X3) accx[a][b][i] = 0.f; }
 
     // DMA source pointers: for each of the 4 images this wave's two 1-KB pieces (image rows 16*wave + 8j + lane/8)
-    const unsigned short* src[8];
+    const unsigned short* src[X3 ? 16 : 8];
     int64_t kstep[2];
 #pragma unroll
     for (int img = 0; img < 2; ++img)
@@ -689,10 +690,11 @@ __device__ __forceinline__ void gemm16h_body(const Gemm16Batch& gb, unsigned cha
         for (int j = 0; j < 2; ++j) {
             const int rr = 16 * wave + 8 * j + (lane >> 3), p = lane & 7;
             const int ma = m0 + 64 * img, nb = n0 + 64 * img;
-            if constexpr (!AT) src[2 * img + j] = P.A + (int64_t)(ma + rr) * P.lda + 8 * (p ^ ((rr >> 1) & 7));
-            else               src[2 * img + j] = P.A + (int64_t)rr * P.lda + ma + 8 * (p ^ (4 * ((rr >> 1) & 1)));
-            if constexpr (!BT) src[4 + 2 * img + j] = P.B + (int64_t)(nb + rr) * P.ldb + 8 * (p ^ ((rr >> 1) & 7));
-            else               src[4 + 2 * img + j] = P.B + (int64_t)rr * P.ldb + nb + 8 * (p ^ (4 * ((rr >> 1) & 1)));
+            const int64_t oa = !AT ? (int64_t)(ma + rr) * P.lda + 8 * (p ^ ((rr >> 1) & 7)) : (int64_t)rr * P.lda + ma + 8 * (p ^ (4 * ((rr >> 1) & 1)));
+            const int64_t ob = !BT ? (int64_t)(nb + rr) * P.ldb + 8 * (p ^ ((rr >> 1) & 7)) : (int64_t)rr * P.ldb + nb + 8 * (p ^ (4 * ((rr >> 1) & 1)));
+            src[2 * img + j] = P.A + oa;
+            src[4 + 2 * img + j] = P.B + ob;
+            if constexpr (X3) { src[8 + 2 * img + j] = P.A_lo + oa; src[12 + 2 * img + j] = P.B_lo + ob; }
         }
     kstep[0] = AT ? 64 * P.lda : 64;
     kstep[1] = BT ? 64 * P.ldb : 64;
@@ -714,14 +716,17 @@ __device__ __forceinline__ void gemm16h_body(const Gemm16Batch& gb, unsigned cha
 
     auto fill = [&](auto sc) {
         constexpr int st = decltype(sc)::value;
-        unsigned char* base = smem + st * G16H_STAGE + piece;
+        unsigned char* base = smem + st * STAGE + piece;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {              // images A0 A1 B0 B1
+        for (int i = 0; i < (X3 ? 8 : 4); ++i) {   // images A0 A1 B0 B1 [A0l A1l B0l B1l]
             __builtin_amdgcn_global_load_lds((const void*)src[2 * i], (lds_void*)(base + i * IMG), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const void*)src[2 * i + 1], (lds_void*)(base + i * IMG + 8 * ROWB), 16, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { src[i] += kstep[0]; src[4 + i] += kstep[1]; }
+        for (int i = 0; i < 4; ++i) {
+            src[i] += kstep[0]; src[4 + i] += kstep[1];
+            if constexpr (X3) { src[8 + i] += kstep[0]; src[12 + i] += kstep[1]; }
+        }
     };
     auto frag = [&](const unsigned char* img, bool tr, int off) -> bf16x8 {
         if (!tr) return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(img + off));
@@ -735,14 +740,37 @@ __device__ __forceinline__ void gemm16h_body(const Gemm16Batch& gb, unsigned cha
         constexpr int st = decltype(sc)::value;
         // tile t has landed once at most the fills of the two younger tiles remain outstanding (8 DMA pieces per tile per wave)
         const int younger = nk - 1 - t;            // NSTG - 2 younger tiles may still be in flight
+        static_assert(!X3 || NSTG == 2, "split-bf16 128 x 128 tiles: 2 stages of 64 KB");
         if (NSTG >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else if (NSTG >= 3 && younger >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (t + NSTG - 1 < nk) fill(std::integral_constant<int, (st + NSTG - 1) % NSTG>{});
-        const unsigned char* As = smem + st * G16H_STAGE + wm * IMG;
-        const unsigned char* Bs = smem + st * G16H_STAGE + (2 + wn) * IMG;
+        const unsigned char* As = smem + st * STAGE + wm * IMG;
+        const unsigned char* Bs = smem + st * STAGE + (2 + wn) * IMG;
+        if constexpr (X3) {                        // one q (k16) at a time: 8 fragments live instead of 32
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    ah[u] = frag(As, AT, aoff[u][q]);
+                    bh[u] = frag(Bs, BT, boff[u][q]);
+                    al[u] = frag(As + 4 * IMG, AT, aoff[u][q]);
+                    bl[u] = frag(Bs + 4 * IMG, BT, boff[u][q]);
+                }
+#pragma unroll
+                for (int ua = 0; ua < 2; ++ua)
+#pragma unroll
+                    for (int ub = 0; ub < 2; ++ub) {
+                        acc[ua][ub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ua], bh[ub], acc[ua][ub], 0, 0, 0);
+                        accx[ua][ub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ua], bl[ub], accx[ua][ub], 0, 0, 0);
+                        accx[ua][ub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ua], bh[ub], accx[ua][ub], 0, 0, 0);
+                    }
+            }
+            return;
+        }
         bf16x8 af[2][4], bfr[2][4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {              // q-major: the first MFMAs only wait for the first reads
@@ -785,7 +813,7 @@ __device__ __forceinline__ void gemm16h_body(const Gemm16Batch& gb, unsigned cha
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float* dst = crow + (int64_t)((r & 3) + 8 * (r >> 2)) * P.ldc;
-                float v = acc[ta][tb][r] + bias;
+                float v = (X3 ? accx[ta][tb][r] + acc[ta][tb][r] : acc[ta][tb][r]) + bias;
                 if (relu) v = fmaxf(v, 0.f);
                 *dst = gb.accumulate ? v + *dst : v;
             }
@@ -805,6 +833,37 @@ __global__ __launch_bounds__(256) void gemm16h_mixed_kernel(const Gemm16Batch gb
     else gemm16h_body<false, true, NSTG>(gb, smem_h);
 }
 
+template <bool AT, bool BT>
+__global__ __launch_bounds__(256) void gemm16hx3_kernel(const Gemm16Batch gb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
+    gemm16h_body<AT, BT, 2, true>(gb, smem_h);
+}
+__global__ __launch_bounds__(256) void gemm16hx3_mixed_kernel(const Gemm16Batch gb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
+    if (gb.a_t[blockIdx.z]) gemm16h_body<true, true, 2, true>(gb, smem_h);
+    else gemm16h_body<false, true, 2, true>(gb, smem_h);
+}
+constexpr int G16HX3_LDS = 2 * 8 * G16G_IMG;       // 128 KB: one workgroup per CU
+static int g16hx3_enable() {
+    static bool done = false;
+    if (done) return 0;
+    EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm16hx3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, G16HX3_LDS));
+    EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm16hx3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G16HX3_LDS));
+    EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm16hx3_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G16HX3_LDS));
+    EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm16hx3_mixed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G16HX3_LDS));
+    done = true;
+    return 0;
+}
+// 128 x 128 tiles pay off when they still fill the chip: 4-problem launches of 1024^2 outputs are 256 workgroups
+static bool g16hx3_fits(const Gemm16Batch& gb, int count) {
+    if (g_gemm16_variant >= 0 && (g_gemm16_variant & 65536)) return false;        // experiment switch: off
+    int tiles = 0;
+    for (int i = 0; i < count; ++i) {
+        if (gb.p[i].M % 128 != 0 || gb.p[i].N % 128 != 0 || gb.p[i].K % 128 != 0) return false;
+        tiles += (gb.p[i].M >> 7) * (gb.p[i].N >> 7);
+    }
+    return tiles >= 256 || (g_gemm16_variant >= 0 && (g_gemm16_variant & 131072));
+}
 constexpr size_t G16H_LDS = (size_t)G16G_NSTG * G16H_STAGE;      // 128 KB at 4 stages; 64 KB at 2 (two workgroups per CU)
 static int g16h_stages() { return (g_gemm16_variant >= 0 && (g_gemm16_variant & 512)) ? 2 : 4; }
 template <int NSTG>
@@ -823,10 +882,14 @@ static int g16h_enable() { return g16h_stages() == 2 ? g16h_enable_n<2>() : g16h
 static bool g16h_fits(const Gemm16Batch& gb, int count) {
     // measured slower than the 64 x 64 tiles on the 1024-wide layers (15-17 us vs 9-12 us per problem: one workgroup per CU leaves
     // the k-tile chain wait -> barrier -> DMA issue -> LDS reads -> MFMA exposed): opt-in through tuning bit 1024
-    if (g_gemm16_variant < 0 || !(g_gemm16_variant & 1024)) return false;
-    for (int i = 0; i < count; ++i)
+    if (g_gemm16_variant >= 0 && (g_gemm16_variant & 65536)) return false;
+    int tiles = 0;
+    for (int i = 0; i < count; ++i) {
         if (gb.p[i].M % 128 != 0 || gb.p[i].N % 128 != 0) return false;
-    return true;
+        tiles += (gb.p[i].M >> 7) * (gb.p[i].N >> 7);
+    }
+    // by default only where 128 x 128 tiles still give every CU a workgroup (the 4-problem launches); bit 1024 forces them everywhere
+    return tiles >= 256 || (g_gemm16_variant >= 0 && (g_gemm16_variant & 1024));
 }
 
 template <bool AT, bool BT, int NSTG = G16G_NSTG>
@@ -935,7 +998,13 @@ static int launch16(const Gemm16Batch& gb, int count, int tiles64, int tiles128,
         EXORL_REQUIRE(okx, "gemm16_grouped: split-bf16 operands need M, N, K multiples of 64 and 16-byte aligned hi/lo planes");
         g2.count = count;
         g2.xcd_map = ((var & 2048) && xcd_map_ok(g2, count, 64)) ? 1 : 0;
-        if (var & 16384) {
+        if (g16hx3_fits(g2, count)) {
+            EXORL_TRY(g16hx3_enable());
+            int t128 = 0;
+            for (int i = 0; i < count; ++i) { const int t = (gb.p[i].M >> 7) * (gb.p[i].N >> 7); t128 = t > t128 ? t : t128; }
+            g2.xcd_map = 0;
+            hipLaunchKernelGGL((gemm16hx3_kernel<AL != 0, BL != 0>), dim3(t128, 1, count), dim3(256), G16HX3_LDS, s, g2);
+        } else if (var & 16384) {
             EXORL_TRY((g16d_enable<G16D_X3_STAGES, true>()));
             hipLaunchKernelGGL((gemm16d_kernel<AL != 0, BL != 0, G16D_X3_STAGES, true>), g2.xcd_map ? dim3(tiles64 * count, 1, 1) : dim3(tiles64, 1, count),
                                dim3(256), G16D_X3_STAGES * 4 * G16G_IMG, s, g2);
@@ -1036,7 +1105,13 @@ int gemm16_grouped_mixed(const int* a_layouts, const Gemm16Problem* probs, int c
     if (x3) {
         gb.count = count;
         gb.xcd_map = (g_gemm16_variant >= 0 && (g_gemm16_variant & 2048) && xcd_map_ok(gb, count, 64)) ? 1 : 0;
-        if (g_gemm16_variant >= 0 && (g_gemm16_variant & 16384)) {
+        if (g16hx3_fits(gb, count)) {
+            EXORL_TRY(g16hx3_enable());
+            int t128 = 0;
+            for (int i = 0; i < count; ++i) { const int t = (gb.p[i].M >> 7) * (gb.p[i].N >> 7); t128 = t > t128 ? t : t128; }
+            gb.xcd_map = 0;
+            hipLaunchKernelGGL(gemm16hx3_mixed_kernel, dim3(t128, 1, count), dim3(256), G16HX3_LDS, s, gb);
+        } else if (g_gemm16_variant >= 0 && (g_gemm16_variant & 16384)) {
             EXORL_TRY((g16d_enable<G16D_X3_STAGES, true>()));
             hipLaunchKernelGGL((gemm16d_mixed_kernel<G16D_X3_STAGES, true>), gb.xcd_map ? dim3(t64 * count, 1, 1) : dim3(t64, 1, count), dim3(256),
                                G16D_X3_STAGES * 4 * G16G_IMG, s, gb);
