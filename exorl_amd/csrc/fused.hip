@@ -39,7 +39,7 @@ constexpr int TF_LDS_FLOATS = 35 * 1024;      // 140 KB for the W0T chunk: all o
 // the 1024^2 tanh evaluations of libm quality would cost more VALU time than the layer's FMAs)
 __device__ __forceinline__ float tanh_fast(float x) {
     const float e = __expf(2.0f * x);
-    return 1.0f - 2.0f * __frcp_rn(1.0f + e);
+    return 1.0f - 2.0f * __frcp_rn(1.0f + e);      // correctly rounded on purpose: v_rcp_f32's 1 ulp flipped one of CRR's indicator weights in the full-size parity run
 }
 
 template <bool FAST>
@@ -217,12 +217,15 @@ __global__ __launch_bounds__(512) void trunk_fwd16_kernel(const TrunkBatch tb, i
         for (int t = 0; t < T; ++t)
             aw[t] = *reinterpret_cast<const bf16x8_t*>(Wb + (int64_t)(col0 + t * 16 + rn) * Kp + kb);
         if constexpr (X3) {
+            bf16x8_t awl[T];                       // all lo-plane fragments in flight together (the compiler otherwise waits on each)
+#pragma unroll
+            for (int t = 0; t < T; ++t) awl[t] = *reinterpret_cast<const bf16x8_t*>(it.W0l + (int64_t)(col0 + t * 16 + rn) * Kp + kb);
+            __builtin_amdgcn_sched_barrier(0);
             f32x4_t cross[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                const bf16x8_t awl = *reinterpret_cast<const bf16x8_t*>(it.W0l + (int64_t)(col0 + t * 16 + rn) * Kp + kb);
                 cross[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[t], bxl, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                cross[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(awl, bx, cross[t], 0, 0, 0);
+                cross[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(awl[t], bx, cross[t], 0, 0, 0);
             }
 #pragma unroll
             for (int t = 0; t < T; ++t) acc[t] += cross[t];
