@@ -110,6 +110,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=200)
     ap.add_argument('--precision', default=os.environ.get('EXORL_PRECISION', 'bf16x3'), choices=['bf16', 'bf16x3', 'fp32'])
     ap.add_argument('--no-other-modes', action='store_true')
+    ap.add_argument('--rehearse', action='store_true',
+                    help='multi-rank dry run on ONE GPU: gloo backend, every rank on cuda:0 (exercises the data-parallel code path; not a measurement)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--graph', type=int, default=int(os.environ.get('EXORL_GRAPH', '1')))
@@ -122,12 +124,17 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}')
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f'cuda:{local_rank}'
     dist = torch.distributed
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(device))
+        if args.rehearse:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(device))
 
     from exorl_amd import agents, _lib as L
     from exorl_amd.replay_buffer import ArenaIterator
@@ -188,6 +195,8 @@ def main():
             'algorithmic_gflop_per_step': flops / 1e9,
             'step_frac_of_mfma_peak': (world * args.steps / dt) * flops / 1e12 / (PEAK_TFLOPS[args.precision] * world),
         }
+    if rank == 0 and args.rehearse:
+        out['rehearsal'] = 'gloo backend, all ranks on cuda:0: exercises the data-parallel path, not a measurement'
     if world == 1 and not args.no_roofline:
         # instrumented pass of the same loop (eager launches so each GEMM can be bracketed by events)
         agent.disable_graph()
