@@ -95,6 +95,8 @@ PROTOTYPES = {
     'exorl_encoder_workspace_floats': (c_int64, [c_int32, c_int32, c_int32]),
     'exorl_encoder_forward': (C.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, P(c_void_p), c_void_p]),
     'exorl_encoder_backward': (C.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'exorl_encoder_forward_prec': (C.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, P(c_void_p), c_int32, c_void_p]),
+    'exorl_encoder_backward_prec': (C.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     'exorl_intr_workspace_bytes': (c_size_t, [P(IntrCfg)]),
     'exorl_intr_create': (C.c_int, [P(IntrCfg), c_void_p, c_size_t, P(c_void_p)]),
     'exorl_intr_destroy': (C.c_int, [c_void_p]),

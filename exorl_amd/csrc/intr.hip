@@ -1125,7 +1125,6 @@ static int proto_update(exorl_intr* it, const exorl_intr_batch& b, bool train, h
         EXORL_TRY(launch_l2norm(it->tn, it->tn, nullptr, B, D, s));
         GemmProblem pq{it->tn, C, it->scores_t, nullptr, B, P, D, D, D, P};
         EXORL_TRY(gemm_grouped(prec, 0, 0, &pq, 1, false, false, s));
-        const int64_t n = (int64_t)B * P;
         hipLaunchKernelGGL(sk_rowmax_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->scores_t, B, P, it->skr);
         hipLaunchKernelGGL(sk_exp_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->scores_t, it->scores_t, B, P, inv_tau, it->skr);
         hipLaunchKernelGGL(sk_row_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->scores_t, it->colsum_p, it->skr, B, P, 1, 0.f, 0.f);

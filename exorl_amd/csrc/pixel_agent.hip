@@ -319,8 +319,8 @@ int exorl_pixel_agent_augment(exorl_pixel_agent_t* a, const int32_t* shifts_obs,
 int exorl_pixel_agent_encode(exorl_pixel_agent_t* a, int32_t which, int32_t target, float** feat_out_dev, void* stream) {
     EXORL_REQUIRE(a && feat_out_dev && a->augmented && (which == 0 || which == 1), "pixel_agent_encode: bad arguments (augment first)");
     const auto& c = a->cfg;
-    return exorl_encoder_forward(target ? a->enc_target : a->flat[0][0], c.c_in, c.hw, which ? a->aug_n : a->aug_o, c.batch, which ? a->enc_ws_n : a->enc_ws_o,
-                                 feat_out_dev, stream);
+    return exorl_encoder_forward_prec(target ? a->enc_target : a->flat[0][0], c.c_in, c.hw, which ? a->aug_n : a->aug_o, c.batch,
+                                      which ? a->enc_ws_n : a->enc_ws_o, feat_out_dev, c.precision, stream);
 }
 
 // Backward through the encoder pass last run by exorl_pixel_agent_encode(which, 0) from dfeat_dev (batch, repr_dim; overwritten), then
@@ -329,8 +329,8 @@ int exorl_pixel_agent_encoder_step(exorl_pixel_agent_t* a, int32_t which, float*
     EXORL_REQUIRE(a && dfeat_dev && (which == 0 || which == 1) && (opt == 0 || opt == 1), "pixel_agent_encoder_step: bad arguments");
     hipStream_t s = as_stream(stream);
     const auto& c = a->cfg;
-    EXORL_TRY(exorl_encoder_backward(a->flat[0][0], c.c_in, c.hw, which ? a->aug_n : a->aug_o, c.batch, which ? a->enc_ws_n : a->enc_ws_o, dfeat_dev,
-                                     a->flat[0][1], s));
+    EXORL_TRY(exorl_encoder_backward_prec(a->flat[0][0], c.c_in, c.hw, which ? a->aug_n : a->aug_o, c.batch, which ? a->enc_ws_n : a->enc_ws_o, dfeat_dev,
+                                     a->flat[0][1], a->cfg.precision, s));
     if (opt == 0) { a->t += 1; return padam(a, 0, a->enc_total, nullptr, s); }
     a->t2 += 1;
     return adam_step(a->flat[0][0], a->flat[0][1], a->enc_m2, a->enc_v2, a->enc_total, c.lr, 0.9f, 0.999f, 1e-8f, a->t2, nullptr, 0.f, s);
@@ -392,8 +392,8 @@ int exorl_pixel_agent_update(exorl_pixel_agent_t* a, float stddev, const int32_t
     // ---- aug_and_encode (ddpg.py:213-215, 312-315); shifts_obs == (const int32_t*)-1: keep the images exorl_pixel_agent_augment made
     if (shifts_obs != reinterpret_cast<const int32_t*>(-1)) EXORL_TRY(exorl_pixel_agent_augment(a, shifts_obs, shifts_next, stream));
     EXORL_REQUIRE(a->augmented, "pixel_agent_update: no augmented batch");
-    EXORL_TRY(exorl_encoder_forward(Pe, c.c_in, c.hw, a->aug_o, B, a->enc_ws_o, &a->feat_o, s));
-    EXORL_TRY(exorl_encoder_forward(Pe, c.c_in, c.hw, a->aug_n, B, a->enc_ws_n, &a->feat_n, s));
+    EXORL_TRY(exorl_encoder_forward_prec(Pe, c.c_in, c.hw, a->aug_o, B, a->enc_ws_o, &a->feat_o, a->cfg.precision, s));
+    EXORL_TRY(exorl_encoder_forward_prec(Pe, c.c_in, c.hw, a->aug_n, B, a->enc_ws_n, &a->feat_n, a->cfg.precision, s));
     // ---- update_critic (ddpg.py:240-268)
     EXORL_TRY(trunk_forward(a, a->actor, Pa, a->feat_n, B, a->ta_n, prec, s));
     Mlp& pol = a->actor.head[0];
@@ -416,7 +416,7 @@ int exorl_pixel_agent_update(exorl_pixel_agent_t* a, float stddev, const int32_t
     hipLaunchKernelGGL(add_cols_kernel, dim3(grid1((int64_t)B * F)), dim3(256), 0, s, a->dxq[0], (int64_t)FA, a->dxq[1], (int64_t)FA, 0, F, a->dh, B);
     EXORL_LAUNCH_CHECK();
     EXORL_TRY(trunk_backward(a, a->critic, Pc, Gc, a->feat_o, B, a->tc, a->dh, a->train_encoder ? a->dfeat : nullptr, prec, s));
-    if (a->train_encoder) EXORL_TRY(exorl_encoder_backward(Pe, c.c_in, c.hw, a->aug_o, B, a->enc_ws_o, a->dfeat, Ge, s));
+    if (a->train_encoder) EXORL_TRY(exorl_encoder_backward_prec(Pe, c.c_in, c.hw, a->aug_o, B, a->enc_ws_o, a->dfeat, Ge, a->cfg.precision, s));
     EXORL_TRY(padam(a, 2, a->critic.total, nullptr, s));
     if (a->train_encoder) EXORL_TRY(padam(a, 0, a->enc_total, nullptr, s));
     // ---- update_actor (ddpg.py:270-292) on obs.detach(): the encoding computed above, the critic just updated
@@ -468,7 +468,7 @@ int exorl_pixel_agent_act(exorl_pixel_agent_t* a, const unsigned char* obs_dev, 
     float* ews = ws;
     EXORL_TRY(exorl_u8_to_f32(obs_dev, img, x, s));           // act() sees the raw frame: no augmentation (ddpg.py:223-224)
     float* feat = nullptr;
-    EXORL_TRY(exorl_encoder_forward(a->flat[0][0], c.c_in, c.hw, x, 1, ews, &feat, s));
+    EXORL_TRY(exorl_encoder_forward_prec(a->flat[0][0], c.c_in, c.hw, x, 1, ews, &feat, a->cfg.precision, s));
     // B = 1 reuses the batch-sized trunk / policy buffers (act() is never called inside update())
     EXORL_TRY(trunk_forward(a, a->actor, a->flat[1][0], feat, 1, a->ta_n, prec, s));
     Mlp& pol = a->actor.head[0];

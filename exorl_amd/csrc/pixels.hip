@@ -118,8 +118,167 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
     }
 }
 
+// ---- the 32 -> 32 channel layers on the matrix cores (split-bf16 / bf16 modes) -----------------------------------------------------
+// Implicit GEMM per 16 x 16 output tile: M = 32 pixels (two tile rows), N = 32 output channels, K = 9 taps x 32 input channels with
+// k = tap * 32 + ci, so the A fragment of a k16 step (8 consecutive ci of one tap for one pixel) is 16 contiguous bytes of a
+// channels-last bf16 copy of the input tile in LDS: one ds_read_b128 (pixel stride 80 B: conflict-free for 16 consecutive pixels).
+// The NCHW fp32 maps are converted on the way into LDS (hi and, in split mode, lo planes); the layer's weights — 18 k16 steps x 8
+// values per lane and plane — are converted once per workgroup and live in registers; a workgroup walks all tiles of one image.
+// Split mode forms hi*hi + (hi*lo + lo*hi) as in the H x H GEMMs. The output tile goes back through LDS so that the NCHW stores
+// cover 64-byte row segments, with bias / ReLU / the dgrad mask applied there.
+typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
+typedef float cf32x16 __attribute__((ext_vector_type(16)));
+constexpr int CM_PIX = 40;                 // bf16 elements per staged pixel (32 channels + 8 pad = 80 B)
+constexpr int CM_TIN = CONV_TILE + 2;      // 18
+constexpr int CM_OSTR = CONV_TILE * CONV_TILE + 1;
+
+constexpr int CM_THREADS = 512;            // 8 waves: one 32-pixel M-block of the tile each, two waves per SIMD
+constexpr int CM_ITEMS = 16 * CM_TIN * CM_TIN;                                  // staged (channel pair, y, x) items per tile: 5184
+constexpr int CM_IPT = (CM_ITEMS + CM_THREADS - 1) / CM_THREADS;               // 11 per thread
+constexpr int CM_OPT = CONV_CO * CONV_TILE * CONV_TILE / CM_THREADS;           // 16 output elements per thread
+
+template <bool X3>
+__global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* __restrict__ in, const float* __restrict__ Wt,
+                                                                  const float* __restrict__ bias, const float* __restrict__ mask,
+                                                                  float* __restrict__ out, int ih, int iw, int oh, int ow, int pad, int relu) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cm_lds[];
+    unsigned short* xh = reinterpret_cast<unsigned short*>(cm_lds);                       // [18*18][CM_PIX] hi plane
+    unsigned short* xl = xh + CM_TIN * CM_TIN * CM_PIX;                                   // lo plane (split mode)
+    float* os = reinterpret_cast<float*>(xl + (X3 ? CM_TIN * CM_TIN * CM_PIX : 0));       // [32 co][CM_OSTR] output staging
+    cbf16x8* wh = reinterpret_cast<cbf16x8*>(os + CONV_CO * CM_OSTR);                 // [18 k-steps][64 lanes] B fragments, 16 B each
+    cbf16x8* wl = wh + 18 * 64;
+    const int n = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kg = lane >> 5, col = lane & 31;
+    const float* inn = in + (int64_t)n * CONV_CO * ih * iw;
+    // weights -> MFMA B fragments in LDS, lane-linear: B[k][co], k-step s: tap = s >> 1, ci = (s & 1) * 16 + 8 * kg + j
+    for (int s = wave; s < 18; s += CM_THREADS / 64) {
+        cbf16x8 fh, fl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ci = (s & 1) * 16 + 8 * kg + j;
+            const float w = Wt[(ci * 9 + (s >> 1)) * CONV_CO + col];
+            fh[j] = (__bf16)w;
+            fl[j] = (__bf16)(w - (float)fh[j]);
+        }
+        wh[s * 64 + lane] = fh;
+        if constexpr (X3) wl[s * 64 + lane] = fl;
+    }
+    const int tiles_x = (ow + CONV_TILE - 1) / CONV_TILE, tiles_y = (oh + CONV_TILE - 1) / CONV_TILE, ntiles = tiles_x * tiles_y;
+    // The input of tile t+1 is fetched into registers while tile t is on the matrix cores; it is converted and written to LDS once
+    // every wave is done with tile t. (channel pair, y, x) per item; consecutive threads walk x (18-float row segments of the map).
+    float v0[CM_IPT], v1[CM_IPT];
+    auto fetch = [&](int tile) {
+        const int iy0 = (tile / tiles_x) * CONV_TILE - pad, ix0 = (tile % tiles_x) * CONV_TILE - pad;
+#pragma unroll
+        for (int u = 0; u < CM_IPT; ++u) {
+            const int i = tid + CM_THREADS * u;
+            const int xx = i % CM_TIN, yy = (i / CM_TIN) % CM_TIN, cp = i / (CM_TIN * CM_TIN);
+            const int gy = iy0 + yy, gx = ix0 + xx;
+            const bool ok = i < CM_ITEMS && gy >= 0 && gy < ih && gx >= 0 && gx < iw;
+            v0[u] = ok ? inn[((int64_t)(2 * cp) * ih + gy) * iw + gx] : 0.f;
+            v1[u] = ok ? inn[((int64_t)(2 * cp + 1) * ih + gy) * iw + gx] : 0.f;
+        }
+    };
+    fetch(0);
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int ty0 = (tile / tiles_x) * CONV_TILE, tx0 = (tile % tiles_x) * CONV_TILE;
+#pragma unroll
+        for (int u = 0; u < CM_IPT; ++u) {
+            const int i = tid + CM_THREADS * u;
+            if (i < CM_ITEMS) {
+                const int xx = i % CM_TIN, yy = (i / CM_TIN) % CM_TIN, cp = i / (CM_TIN * CM_TIN);
+                const __bf16 h0 = (__bf16)v0[u], h1 = (__bf16)v1[u];
+                const int o = (yy * CM_TIN + xx) * CM_PIX + 2 * cp;
+                *reinterpret_cast<unsigned int*>(xh + o) = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+                if constexpr (X3) {
+                    const __bf16 l0 = (__bf16)(v0[u] - (float)h0), l1 = (__bf16)(v1[u] - (float)h1);
+                    *reinterpret_cast<unsigned int*>(xl + o) = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+                }
+            }
+        }
+        __syncthreads();
+        if (tile + 1 < ntiles) fetch(tile + 1);
+        // this thread's 16 output elements of the tile: the dgrad mask is fetched now, behind the MFMA work
+        unsigned mkbits = 0xffffu;                                              // bit u: output element u passes the mask
+        if (mask) {
+            float mv[CM_OPT];
+#pragma unroll
+            for (int u = 0; u < CM_OPT; ++u) {
+                const int i = tid + CM_THREADS * u;
+                const int px = i % CONV_TILE, py = (i / CONV_TILE) % CONV_TILE, co = i / (CONV_TILE * CONV_TILE);
+                const int oy = ty0 + py, ox = tx0 + px;
+                mv[u] = (oy < oh && ox < ow) ? mask[(((int64_t)n * CONV_CO + co) * oh + oy) * ow + ox] : 1.0f;
+            }
+            mkbits = 0;
+#pragma unroll
+            for (int u = 0; u < CM_OPT; ++u) mkbits |= (mv[u] > 0.f ? 1u : 0u) << u;
+        }
+        cf32x16 acc, accx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accx[r] = 0.f; }
+        const int py = 2 * wave + (col >> 4), px = col & 15;                   // this lane's pixel row of the A operand
+#pragma unroll 2
+        for (int s = 0; s < 18; ++s) {                                          // two k-steps of fragments live at a time (VGPR budget: 256 at 8 waves)
+            const int dy = (s >> 1) / 3, dx = (s >> 1) % 3;
+            const int o = ((py + dy) * CM_TIN + px + dx) * CM_PIX + (s & 1) * 16 + 8 * kg;
+            const cbf16x8 ah = *reinterpret_cast<const cbf16x8*>(xh + o);
+            const cbf16x8 bh = wh[s * 64 + lane];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+            if constexpr (X3) {
+                const cbf16x8 al = *reinterpret_cast<const cbf16x8*>(xl + o);
+                const cbf16x8 bl = wl[s * 64 + lane];
+                accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, accx, 0, 0, 0);
+                accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, accx, 0, 0, 0);
+            }
+        }
+        // C layout: reg r of lane l = pixel (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the M-block, channel l & 31
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * kg;
+            const int p = (2 * wave + (m >> 4)) * CONV_TILE + (m & 15);
+            os[col * CM_OSTR + p] = X3 ? accx[r] + acc[r] : acc[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < CM_OPT; ++u) {
+            const int i = tid + CM_THREADS * u;
+            const int px2 = i % CONV_TILE, py2 = (i / CONV_TILE) % CONV_TILE, co = i / (CONV_TILE * CONV_TILE);
+            const int oy = ty0 + py2, ox = tx0 + px2;
+            if (oy < oh && ox < ow) {
+                float v = os[co * CM_OSTR + py2 * CONV_TILE + px2] + (bias ? bias[co] : 0.f);
+                if (relu) v = fmaxf(v, 0.f);
+                if (!((mkbits >> u) & 1u)) v = 0.f;
+                out[(((int64_t)n * CONV_CO + co) * oh + oy) * ow + ox] = v;
+            }
+        }
+        // the next iteration first writes the input planes only (every wave is past its MFMA reads: second barrier above); os is
+        // rewritten after the next iteration's first barrier, i.e. after every thread has finished the loop above
+    }
+}
+
+static int conv3x3_mfma(const float* in, const float* Wt, const float* bias, const float* mask, float* out, int n, int ih, int iw, int oh, int ow,
+                        int pad, int relu, int prec, hipStream_t s) {
+    const bool x3 = prec == EXORL_PREC_BF16X3;
+    const size_t lds = (size_t)(x3 ? 2 : 1) * CM_TIN * CM_TIN * CM_PIX * sizeof(unsigned short) + (size_t)CONV_CO * CM_OSTR * sizeof(float) +
+                       (size_t)(x3 ? 2 : 1) * 18 * 64 * 16;
+    static bool attr = false;
+    if (!attr) {
+        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr = true;
+    }
+    if (x3) hipLaunchKernelGGL(conv3x3_mfma_kernel<true>, dim3(n), dim3(CM_THREADS), lds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu);
+    else    hipLaunchKernelGGL(conv3x3_mfma_kernel<false>, dim3(n), dim3(CM_THREADS), lds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
+// prec: EXORL_PREC_F32 -> direct fp32 FMA kernel for every layer; bf16 / split-bf16 -> the 32-channel stride-1 layers on MFMA
 static int conv3x3(const float* in, const float* Wt, const float* bias, const float* mask, float* out, int n, int ci_n, int co_n, int ih, int iw,
-                   int oh, int ow, int stride, int pad, int in_scale, int relu, hipStream_t s) {
+                   int oh, int ow, int stride, int pad, int in_scale, int relu, hipStream_t s, int prec = EXORL_PREC_F32) {
+    if (prec != EXORL_PREC_F32 && ci_n == CONV_CO && co_n == CONV_CO && stride == 1 && !in_scale)
+        return conv3x3_mfma(in, Wt, bias, mask, out, n, ih, iw, oh, ow, pad, relu, prec, s);
     const int tin = (CONV_TILE - 1) * stride + 3;
     const size_t lds = (size_t)ci_n * tin * tin * sizeof(float);
     EXORL_REQUIRE(lds <= 160 * 1024 && co_n == CONV_CO, "conv3x3: tile does not fit LDS (ci=%d stride=%d) or co=%d != 32", ci_n, stride, co_n);
@@ -275,7 +434,12 @@ static EncWs enc_carve(const EncGeom& g, int n, float* ws) {
 // the flattened features (n, 32*e*e) are ws_dev's 4th activation map: *h_out_dev points at them.
 int exorl_encoder_forward(const float* params_dev, int32_t c_in, int32_t hw, const float* x_dev, int32_t n, float* ws_dev, float** h_out_dev,
                           void* stream) {
+    return exorl_encoder_forward_prec(params_dev, c_in, hw, x_dev, n, ws_dev, h_out_dev, EXORL_PREC_F32, stream);
+}
+int exorl_encoder_forward_prec(const float* params_dev, int32_t c_in, int32_t hw, const float* x_dev, int32_t n, float* ws_dev, float** h_out_dev,
+                               int32_t prec, void* stream) {
     EXORL_REQUIRE(params_dev && x_dev && ws_dev && n > 0 && c_in > 0 && c_in <= 16 && hw >= 16, "encoder_forward: bad arguments");
+    EXORL_REQUIRE(prec == EXORL_PREC_F32 || prec == EXORL_PREC_BF16 || prec == EXORL_PREC_BF16X3, "encoder_forward: unknown precision %d", prec);
     hipStream_t s = as_stream(stream);
     const EncGeom g = enc_geom(c_in, hw);
     const EncWs w = enc_carve(g, n, ws_dev);
@@ -286,7 +450,7 @@ int exorl_encoder_forward(const float* params_dev, int32_t c_in, int32_t hw, con
                            l > 0 ? w.wb[l] : nullptr, ci);
         EXORL_LAUNCH_CHECK();
         EXORL_TRY(conv3x3(in, w.wf[l], params_dev + g.b_off[l], nullptr, w.act[l + 1], n, ci, CONV_CO, g.edge[l], g.edge[l], g.edge[l + 1],
-                          g.edge[l + 1], l == 0 ? 2 : 1, 0, l == 0 ? 1 : 0, 1, s));
+                          g.edge[l + 1], l == 0 ? 2 : 1, 0, l == 0 ? 1 : 0, 1, s, prec));
         in = w.act[l + 1];
     }
     if (h_out_dev) *h_out_dev = w.act[4];
@@ -297,7 +461,12 @@ int exorl_encoder_forward(const float* params_dev, int32_t c_in, int32_t hw, con
 // parameter gradients are written to grads_dev in the parameters' flat layout. No d/d(pixels).
 int exorl_encoder_backward(const float* params_dev, int32_t c_in, int32_t hw, const float* x_dev, int32_t n, float* ws_dev, float* dh_dev,
                            float* grads_dev, void* stream) {
+    return exorl_encoder_backward_prec(params_dev, c_in, hw, x_dev, n, ws_dev, dh_dev, grads_dev, EXORL_PREC_F32, stream);
+}
+int exorl_encoder_backward_prec(const float* params_dev, int32_t c_in, int32_t hw, const float* x_dev, int32_t n, float* ws_dev, float* dh_dev,
+                                float* grads_dev, int32_t prec, void* stream) {
     EXORL_REQUIRE(params_dev && x_dev && ws_dev && dh_dev && grads_dev && n > 0, "encoder_backward: bad arguments");
+    EXORL_REQUIRE(prec == EXORL_PREC_F32 || prec == EXORL_PREC_BF16 || prec == EXORL_PREC_BF16X3, "encoder_backward: unknown precision %d", prec);
     hipStream_t s = as_stream(stream);
     const EncGeom g = enc_geom(c_in, hw);
     const EncWs w = enc_carve(g, n, ws_dev);
@@ -322,7 +491,7 @@ int exorl_encoder_backward(const float* params_dev, int32_t c_in, int32_t hw, co
         EXORL_TRY(colsum(w.P, grads_dev + g.w_off[l], n, CONV_CO * ci * 9, 1, 0, 0, s));
         EXORL_TRY(colsum(w.Pb, grads_dev + g.b_off[l], n, CONV_CO, 1, 0, 0, s));
         if (l > 0) {              // d(a_l) = full correlation of d(a_{l+1}) with the flipped kernel, masked by a_l > 0
-            EXORL_TRY(conv3x3(d, w.wb[l], nullptr, w.act[l], w.dact[l], n, CONV_CO, CONV_CO, oh, oh, ih, ih, 1, 2, 0, 0, s));
+            EXORL_TRY(conv3x3(d, w.wb[l], nullptr, w.act[l], w.dact[l], n, CONV_CO, CONV_CO, oh, oh, ih, ih, 1, 2, 0, 0, s, prec));
             d = w.dact[l];
         }
     }

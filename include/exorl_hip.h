@@ -374,6 +374,13 @@ int exorl_encoder_forward(const float* params_dev, int32_t c_in, int32_t hw, con
  * grads_dev (flat layout of the parameters). */
 int exorl_encoder_backward(const float* params_dev, int32_t c_in, int32_t hw, const float* x_dev, int32_t n, float* ws_dev, float* dh_dev,
                            float* grads_dev, void* stream);
+/* The same with the 32-channel stride-1 layers (forward and dgrad) on the matrix cores: precision = EXORL_PREC_BF16 / _BF16X3 runs them
+ * as an implicit GEMM on v_mfma_f32_32x32x16_bf16 (split mode: hi*hi + hi*lo + lo*hi); EXORL_PREC_F32 = the two calls above. The first
+ * layer (3 or 9 input channels, stride 2, uint8 scaling) and the weight gradients stay fp32 FMA. */
+int exorl_encoder_forward_prec(const float* params_dev, int32_t c_in, int32_t hw, const float* x_dev, int32_t n, float* ws_dev, float** h_out_dev,
+                               int32_t precision, void* stream);
+int exorl_encoder_backward_prec(const float* params_dev, int32_t c_in, int32_t hw, const float* x_dev, int32_t n, float* ws_dev, float* dh_dev,
+                                float* grads_dev, int32_t precision, void* stream);
 int exorl_u8_to_f32(const unsigned char* x_dev, int64_t n, float* out_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

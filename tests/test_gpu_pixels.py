@@ -35,7 +35,7 @@ def flat_params(lib, plist, c_in, hw=84):
     return flat, offs
 
 
-def run_encoder(lib, plist, x, dh=None):
+def run_encoder(lib, plist, x, dh=None, prec=0):
     from exorl_amd import _lib as L
     n, c_in, hw, _ = x.shape
     flat, offs = flat_params(lib, plist, c_in, hw)
@@ -43,7 +43,7 @@ def run_encoder(lib, plist, x, dh=None):
     X = dev(x.astype(np.float32))
     ws = torch.zeros(lib.exorl_encoder_workspace_floats(n, c_in, hw), device='cuda')
     hp = C.c_void_p()
-    L.check(lib.exorl_encoder_forward(P.data_ptr(), c_in, hw, X.data_ptr(), n, ws.data_ptr(), C.byref(hp), None))
+    L.check(lib.exorl_encoder_forward_prec(P.data_ptr(), c_in, hw, X.data_ptr(), n, ws.data_ptr(), C.byref(hp), prec, None))
     D = lib.exorl_encoder_out_dim(hw)
     off = (hp.value - ws.data_ptr()) // 4
     h = ws[off:off + n * D].view(n, D).clone()
@@ -51,7 +51,7 @@ def run_encoder(lib, plist, x, dh=None):
     if dh is not None:
         G = torch.zeros_like(P)
         DH = dev(dh.astype(np.float32))
-        L.check(lib.exorl_encoder_backward(P.data_ptr(), c_in, hw, X.data_ptr(), n, ws.data_ptr(), DH.data_ptr(), G.data_ptr(), None))
+        L.check(lib.exorl_encoder_backward_prec(P.data_ptr(), c_in, hw, X.data_ptr(), n, ws.data_ptr(), DH.data_ptr(), G.data_ptr(), prec, None))
         g = G.cpu().numpy()
         grads = [g[o:o + p.size].reshape(p.shape) for o, p in zip(offs, plist)]
     torch.cuda.synchronize()
@@ -80,13 +80,14 @@ def test_aug_vs_reference(lib, gold, tag):
         assert min(errs) < 2e-2
 
 
+@pytest.mark.parametrize('prec', [0, 2])           # 0: fp32 FMA convolutions; 2: split-bf16 MFMA implicit GEMM for the 32-channel layers
 @pytest.mark.parametrize('tag', ['c3', 'c9'])
-def test_encoder_vs_reference(lib, gold, tag):
+def test_encoder_vs_reference(lib, gold, tag, prec):
     z = np.load(gold / 'pixels_g5.npz')
     p = [z[f'enc_{tag}_param/{k}'] for k in ENC_KEYS]
     x = z[f'enc_{tag}_x']
     dh = np.random.RandomState(7).standard_normal((2, 39200)).astype(np.float32)
-    h, grads = run_encoder(lib, p, x, dh)
+    h, grads = run_encoder(lib, p, x, dh, prec)
     np.testing.assert_allclose(h[:, ::97], z[f'enc_{tag}_h_sample'], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose([h.astype(np.float64).sum(), (h.astype(np.float64) ** 2).sum()], z[f'enc_{tag}_h_sums'], rtol=1e-5)
     for k, g in zip(ENC_KEYS, grads):
@@ -94,9 +95,11 @@ def test_encoder_vs_reference(lib, gold, tag):
         np.testing.assert_allclose(g, want, rtol=2e-4, atol=2e-5 * np.abs(want).max(), err_msg=k)
 
 
-def test_encoder_batch_vs_oracle(lib):
+@pytest.mark.parametrize('prec', [0, 2, 1])
+def test_encoder_batch_vs_oracle(lib, prec):
     """A batch that spans several workgroups per layer and ragged output tiles (64x64 images: edges 31, 29, 27, 25)."""
     rs = np.random.RandomState(0)
+    rt, at = {0: (1e-4, 1e-5), 2: (1e-4, 1e-5), 1: (3e-2, 3e-3)}[prec]          # plain bf16 operands: 2^-9 per product
     for (n, c, hw) in ((5, 3, 64), (3, 9, 84)):
         p = []
         for l in range(4):
@@ -106,10 +109,14 @@ def test_encoder_batch_vs_oracle(lib):
         ho, cache = pixels.encoder_fwd(p, x) if hw == 84 else _fwd_any(p, x)
         dh = rs.standard_normal(ho.shape).astype(np.float32)
         go, _ = pixels.encoder_bwd(p, cache, dh)
-        h, g = run_encoder(lib, p, x, dh)
-        np.testing.assert_allclose(h, ho, rtol=1e-4, atol=1e-5)
+        h, g = run_encoder(lib, p, x, dh, prec)
+        np.testing.assert_allclose(h, ho, rtol=rt, atol=at)
         for i, (a, b) in enumerate(zip(g, go)):
-            np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-5 * np.abs(b).max(), err_msg=f'grad {i}')
+            if prec == 1:       # bf16 dgrad noise is per element; the gradient as a whole keeps its direction
+                cos = float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+                assert cos > 0.995, (f'grad {i}', cos)
+            else:
+                np.testing.assert_allclose(a, b, rtol=2 * rt, atol=2 * at * np.abs(b).max(), err_msg=f'grad {i}')
 
 
 def _fwd_any(p, x):
