@@ -170,12 +170,14 @@ def test_pixel_ddpg_vs_reference(gold):
     assert a.shape == (A,) and np.all(np.abs(a) <= 1.0)
 
 
-def test_pixel_ddpg_batch_vs_oracle():
-    """Shipped widths (feature_dim 50, hidden 1024) at a batch that spans many workgroups; 64x64 frames with 9 stacked channels."""
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_pixel_ddpg_batch_vs_oracle(precision):
+    """Shipped widths (feature_dim 50, hidden 1024) at a batch that spans many workgroups; 64x64 frames with 9 stacked channels.
+    bf16x3: MFMA implicit-GEMM convolutions and split-bf16 Linear layers against the same fp32 oracle and bar."""
     import _synth
     for (C_, HW, A, F, H, B) in ((3, 84, 6, 50, 1024, 24), (9, 64, 4, 50, 256, 16)):
         R = 32 * ((HW - 3) // 2 + 1 - 6) ** 2
-        ag = make_pixel_agent(C_, HW, A, F, H, B)
+        ag = make_pixel_agent(C_, HW, A, F, H, B, precision=precision)
         enc, actor, critic = load_pixel_params(ag, C_, A, F, H, R)
         orc = pixels.OraclePixelDDPG(enc, actor, critic)
         rs = np.random.RandomState(1)
