@@ -347,6 +347,110 @@ __global__ __launch_bounds__(1024) void conv_wgrad_kernel(const float* __restric
     }
 }
 
+// ---- weight gradients of the 32 -> 32 layers on the matrix cores (bf16 / split-bf16 modes) -------------------------------------
+// dW[co][ci][tap] = sum over pixels p of dY[co][p] X[ci][p + tap]: per tap a 32 x 32 GEMM with K = pixels. One workgroup per
+// image, nine waves = nine taps (+ the bias gradient on the ninth wave as a product with a ones operand); per 16 x 16 output tile
+// the k16 steps are its 16 pixel rows. Both operands are staged channel-major (as they sit in the NCHW maps): dY[co][y][16 x] gives
+// the A fragment (8 consecutive x of one channel) as one aligned ds_read_b128; X gets three copies shifted by the tap's dx so that
+// the B fragment (8 consecutive x + dx of one input channel) is aligned too. Per-image partials in the layout of the fp32 kernel,
+// summed in image order by the same column-sum kernel.
+constexpr int WM_THREADS = 576;
+constexpr int WM_DYC = CONV_TILE * CONV_TILE + 8;          // bf16 per dY channel (+16 B: conflict-free across 16 channels)
+constexpr int WM_XC = CM_TIN * CONV_TILE + 8;              // bf16 per X channel of one shifted copy
+
+template <bool X3>
+__global__ __launch_bounds__(WM_THREADS) void conv_wgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ in, float* __restrict__ P,
+                                                                     float* __restrict__ Pb, int ih, int iw, int oh, int ow) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wm_lds[];
+    unsigned short* dh = reinterpret_cast<unsigned short*>(wm_lds);               // [32][WM_DYC]
+    unsigned short* dl = dh + CONV_CO * WM_DYC;
+    unsigned short* xh = dl + (X3 ? CONV_CO * WM_DYC : 0);                         // [3 dx][32][WM_XC]
+    unsigned short* xl = xh + 3 * CONV_CO * WM_XC;
+    const int n = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, tap = tid >> 6;                  // wave = tap
+    const int kg = lane >> 5, col = lane & 31;
+    const int dyy = tap / 3, dxx = tap % 3;
+    const float* dyn = dy + (int64_t)n * CONV_CO * oh * ow;
+    const float* inn = in + (int64_t)n * CONV_CO * ih * iw;
+    cf32x16 acc, accx, accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accx[r] = 0.f; accb[r] = 0.f; }
+    cbf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    auto pack = [](float a, float b, bool lo) -> unsigned {
+        const __bf16 h0 = (__bf16)a, h1 = (__bf16)b;
+        if (!lo) return (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+        const __bf16 l0 = (__bf16)(a - (float)h0), l1 = (__bf16)(b - (float)h1);
+        return (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+    };
+    const int tiles_x = (ow + CONV_TILE - 1) / CONV_TILE, tiles_y = (oh + CONV_TILE - 1) / CONV_TILE;
+    for (int tile = 0; tile < tiles_x * tiles_y; ++tile) {
+        const int ty0 = (tile / tiles_x) * CONV_TILE, tx0 = (tile % tiles_x) * CONV_TILE;
+        __syncthreads();
+        // dY tile: (co, y, x pair)
+        for (int i = tid; i < CONV_CO * CONV_TILE * (CONV_TILE / 2); i += WM_THREADS) {
+            const int xp = i % (CONV_TILE / 2), y = (i / (CONV_TILE / 2)) % CONV_TILE, co = i / (CONV_TILE * CONV_TILE / 2);
+            const int gy = ty0 + y, gx = tx0 + 2 * xp;
+            const float a = (gy < oh && gx < ow) ? dyn[((int64_t)co * oh + gy) * ow + gx] : 0.f;
+            const float b = (gy < oh && gx + 1 < ow) ? dyn[((int64_t)co * oh + gy) * ow + gx + 1] : 0.f;
+            const int o = co * WM_DYC + y * CONV_TILE + 2 * xp;
+            *reinterpret_cast<unsigned*>(dh + o) = pack(a, b, false);
+            if constexpr (X3) *reinterpret_cast<unsigned*>(dl + o) = pack(a, b, true);
+        }
+        // X tile, three copies: copy dx holds columns tx0 + dx .. tx0 + dx + 15 of rows ty0 .. ty0 + 17: (dx, ci, yy, x pair)
+        for (int i = tid; i < 3 * CONV_CO * CM_TIN * (CONV_TILE / 2); i += WM_THREADS) {
+            const int xp = i % (CONV_TILE / 2), yy = (i / (CONV_TILE / 2)) % CM_TIN, ci = (i / (CM_TIN * CONV_TILE / 2)) % CONV_CO,
+                      dx = i / (CONV_CO * CM_TIN * CONV_TILE / 2);
+            const int gy = ty0 + yy, gx = tx0 + dx + 2 * xp;
+            const float a = (gy < ih && gx < iw) ? inn[((int64_t)ci * ih + gy) * iw + gx] : 0.f;
+            const float b = (gy < ih && gx + 1 < iw) ? inn[((int64_t)ci * ih + gy) * iw + gx + 1] : 0.f;
+            const int o = (dx * CONV_CO + ci) * WM_XC + yy * CONV_TILE + 2 * xp;
+            *reinterpret_cast<unsigned*>(xh + o) = pack(a, b, false);
+            if constexpr (X3) *reinterpret_cast<unsigned*>(xl + o) = pack(a, b, true);
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int y = 0; y < CONV_TILE; ++y) {                    // k16 step = pixel row y of the tile
+            const int oa = col * WM_DYC + y * CONV_TILE + 8 * kg;                               // A: dY[co = col][y][8 kg ..]
+            const int ob = (dxx * CONV_CO + col) * WM_XC + (y + dyy) * CONV_TILE + 8 * kg;      // B: X[ci = col][y + dy][8 kg + dx ..]
+            const cbf16x8 ah = *reinterpret_cast<const cbf16x8*>(dh + oa);
+            const cbf16x8 bh = *reinterpret_cast<const cbf16x8*>(xh + ob);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+            if constexpr (X3) {
+                const cbf16x8 al = *reinterpret_cast<const cbf16x8*>(dl + oa);
+                const cbf16x8 bl = *reinterpret_cast<const cbf16x8*>(xl + ob);
+                accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, accx, 0, 0, 0);
+                accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, accx, 0, 0, 0);
+                if (tap == 8) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ones, accb, 0, 0, 0);      // wave-uniform branch
+            }
+            if (tap == 8) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ones, accb, 0, 0, 0);
+        }
+    }
+    // C layout: reg r of lane l = row (r & 3) + 8 (r >> 2) + 4 (l >> 5) (co), column l & 31 (ci)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * kg;
+        P[(((int64_t)n * CONV_CO + co) * CONV_CO + col) * 9 + tap] = X3 ? accx[r] + acc[r] : acc[r];
+        if (tap == 8 && col == 0) Pb[(int64_t)n * CONV_CO + co] = accb[r];
+    }
+}
+
+static int conv_wgrad_mfma(const float* dy, const float* in, float* P, float* Pb, int n, int ih, int iw, int oh, int ow, int prec, hipStream_t s) {
+    const bool x3 = prec == EXORL_PREC_BF16X3;
+    const size_t lds = (size_t)(x3 ? 2 : 1) * (CONV_CO * WM_DYC + 3 * CONV_CO * WM_XC) * sizeof(unsigned short);
+    static bool attr = false;
+    if (!attr) {
+        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wgrad_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wgrad_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    if (x3) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<true>, dim3(n), dim3(WM_THREADS), lds, s, dy, in, P, Pb, ih, iw, oh, ow);
+    else    hipLaunchKernelGGL(conv_wgrad_mfma_kernel<false>, dim3(n), dim3(WM_THREADS), lds, s, dy, in, P, Pb, ih, iw, oh, ow);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
 // d *= (a > 0): ReLU mask of the top activation against the gradient that arrives from the trunk's Linear
 __global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ d, const float* __restrict__ a, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = a[i] > 0.f ? d[i] : 0.f;
@@ -486,8 +590,12 @@ int exorl_encoder_backward_prec(const float* params_dev, int32_t c_in, int32_t h
             EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr = true;
         }
-        hipLaunchKernelGGL(conv_wgrad_kernel, dim3(n), dim3(1024), lds, s, d, in, w.P, w.Pb, ci, ih, ih, oh, oh, stride, l == 0 ? 1 : 0);
-        EXORL_LAUNCH_CHECK();
+        if (prec != EXORL_PREC_F32 && l > 0)
+            EXORL_TRY(conv_wgrad_mfma(d, in, w.P, w.Pb, n, ih, ih, oh, oh, prec, s));
+        else {
+            hipLaunchKernelGGL(conv_wgrad_kernel, dim3(n), dim3(1024), lds, s, d, in, w.P, w.Pb, ci, ih, ih, oh, oh, stride, l == 0 ? 1 : 0);
+            EXORL_LAUNCH_CHECK();
+        }
         EXORL_TRY(colsum(w.P, grads_dev + g.w_off[l], n, CONV_CO * ci * 9, 1, 0, 0, s));
         EXORL_TRY(colsum(w.Pb, grads_dev + g.b_off[l], n, CONV_CO, 1, 0, 0, s));
         if (l > 0) {              // d(a_l) = full correlation of d(a_{l+1}) with the flipped kernel, masked by a_l > 0
