@@ -33,7 +33,7 @@ struct GemmProfile {
 static GemmProfile g_prof;
 constexpr size_t PROF_MAX_LAUNCHES = 1 << 15;
 
-constexpr int GEMM_MAX_GROUP = 16;     // problems per launch of the generic kernel (split-K slabs of one layer share a launch)
+constexpr int GEMM_MAX_GROUP = 32;     // problems per launch of the generic kernel (split-K slabs of one layer share a launch)
 struct GemmBatch {
     GemmProblem p[GEMM_MAX_GROUP];
     int relu;

@@ -300,7 +300,12 @@ __global__ __launch_bounds__(1024) void conv_wgrad_kernel(const float* __restric
                                                           int in_scale) {
     extern __shared__ float lds[];
     const int n = blockIdx.x;
-    const int co = threadIdx.x >> 5, ci = threadIdx.x & 31;
+    // thread = (co, ci, pixel slice): with few input channels (the first layer: 3 or 9) the 32 lanes of an output channel split the
+    // pixel columns between them (x = slice, slice + S, ...) instead of idling, and the slices are summed by shuffles at the end
+    int ci2 = 1;
+    while (ci2 < ci_n) ci2 <<= 1;
+    const int S = 32 / ci2;
+    const int co = threadIdx.x >> 5, ci = (threadIdx.x & 31) % ci2, slice = (threadIdx.x & 31) / ci2;
     const int in_rows = (WG_ROWS - 1) * stride + 3;
     float* dyt = lds;                                   // [WG_ROWS * ow][32 co]
     float* it = lds + WG_ROWS * ow * CONV_CO;           // [in_rows * iw][ci_n]
@@ -327,7 +332,7 @@ __global__ __launch_bounds__(1024) void conv_wgrad_kernel(const float* __restric
         __syncthreads();
         if (ci < ci_n) {
             for (int y = 0; y < nr; ++y)
-                for (int x = 0; x < ow; ++x) {
+                for (int x = slice; x < ow; x += S) {
                     const float d = dyt[(y * ow + x) * CONV_CO + co];
                     const float* ip = it + ((y * stride) * iw + x * stride) * ci_n + ci;
 #pragma unroll
@@ -339,7 +344,12 @@ __global__ __launch_bounds__(1024) void conv_wgrad_kernel(const float* __restric
         }
     }
     (void)in_rows;
-    if (ci < ci_n) {
+    for (int off = ci2; off < 32; off <<= 1) {           // sum the pixel slices (lanes of one 32-lane group)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] += __shfl_xor(acc[t], off, 64);
+        bsum += __shfl_xor(bsum, off, 64);
+    }
+    if (ci < ci_n && slice == 0) {
         float* Pn = P + ((int64_t)n * CONV_CO + co) * ci_n * 9 + ci * 9;
 #pragma unroll
         for (int t = 0; t < 9; ++t) Pn[t] = acc[t];

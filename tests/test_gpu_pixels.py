@@ -192,8 +192,12 @@ def test_pixel_ddpg_batch_vs_oracle(precision):
             sh.append([so, sn])
             m = ag.update(iter([(obs, b[1], b[2], b[3], nobs)]), 2 * i)
             mo = orc.update((obs, b[1], b[2], b[3], nobs), 2 * i, so, sn, ns2.draw((B, A)), ns2.draw((B, A)))
+            # Adam's first step moves every weight by lr * sign(g); of the 39200 x 50 trunk weights some have gradients at rounding-noise
+            # level, whose sign depends on the summation order (a 32-way split-K of the trunk moved the split-bf16 run's step-1 actor_loss
+            # by 2.6e-3 while the 16-way one, like fp32 in either, stays inside 2e-4): the bar below holds for the shipped configuration
+            rt = 2e-4
             for k, v in mo.items():
-                assert abs(m[k] - v) <= 2e-4 * abs(v) + 1e-5, (C_, i, k, m[k], v)
+                assert abs(m[k] - v) <= rt * abs(v) + 1e-5, (C_, i, k, m[k], v)
         for got, want in zip(ag.encoder.grads(), orc.last_enc_grads):
             got = got.cpu().numpy().reshape(want.shape)
             # second-step gradients: the two sides' weights already differ by Adam's rounding-noise moves, and ReLU pre-activations
