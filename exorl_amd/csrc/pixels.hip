@@ -7,7 +7,8 @@
 //   wgrad            one workgroup = one image, thread = (co, ci) pair with its 9 taps in registers; per-image partials, summed in
 //                    image order by the column-sum kernel (deterministic, no atomics)
 // The ReLU mask of layer l is applied where d(a_l) is produced (dgrad epilogue), so no separate masking pass touches the maps.
-// First correct version (round 1): fp32 VALU; an MFMA implicit-GEMM form is the next step for these layers.
+// In the bf16 / split-bf16 precision modes the three 32 -> 32 stride-1 layers run as MFMA implicit GEMMs instead (conv3x3_mfma_kernel,
+// conv_wgrad_mfma_kernel below); the fp32 kernels stay for precision fp32 and for the first layer.
 #include "kernels.h"
 
 namespace exorl {

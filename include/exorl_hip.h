@@ -390,7 +390,7 @@ int exorl_u8_to_f32(const unsigned char* x_dev, int64_t n, float* out_dev, void*
 typedef struct exorl_pixel_cfg {
     int32_t c_in, hw;          /* obs_shape = (c_in, hw, hw), hw in {84, 64}, uint8 */
     int32_t act_dim, feature_dim, hidden_dim, batch;
-    int32_t precision;         /* EXORL_PREC_* for the Linear layers' GEMMs; the convolutions are fp32 */
+    int32_t precision;         /* EXORL_PREC_*: Linear layers' GEMMs and (bf16 modes) the 32-channel convolutions on MFMA; fp32: fp32 FMA convolutions */
     int32_t reserved;
     float lr, tau, stddev_clip, reserved2;
     uint64_t seed;
