@@ -18,3 +18,8 @@ python tools/micro/unsup_bench.py --precision fp32,bf16x3 2>&1 | grep -v amdgpu.
 cat gpurun_out/${T}_unsup.txt
 for a in "proto fp32" "proto bf16x3" "ddpg fp32" "ddpg bf16x3"; do set -- $a; python tools/micro/pixel_bench.py 1024 $1 $2 2>&1 | grep -v amdgpu.ids >> gpurun_out/${T}_pixels.txt; done
 cat gpurun_out/${T}_pixels.txt
+for a in "cql 78 12 1024" "td3 17 6 512" "td3 17 6 4096" "crr 24 6 1024" "bc 24 6 256 fp32,bf16x3"; do python tools/micro/offline_bench.py $a 2>&1 | grep -v amdgpu.ids >> gpurun_out/${T}_offline.txt; done
+cat gpurun_out/${T}_offline.txt
+bash tools/prof_pixels.sh proto bf16x3 > /dev/null
+bash tools/prof_unsup.sh icm_apt bf16x3 > /dev/null
+bash tools/prof_unsup.sh proto bf16x3 > /dev/null
