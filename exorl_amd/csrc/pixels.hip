@@ -130,23 +130,28 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
 typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
 typedef float cf32x16 __attribute__((ext_vector_type(16)));
 constexpr int CM_PIX = 40;                 // bf16 elements per staged pixel (32 channels + 8 pad = 80 B)
-constexpr int CM_TIN = CONV_TILE + 2;      // 18
-constexpr int CM_OSTR = CONV_TILE * CONV_TILE + 1;
+constexpr int CM_TIN = CONV_TILE + 2;      // 18 (the weight-gradient kernel's X tile)
+constexpr int CM_OSTR = 256 + 1;
 
-constexpr int CM_THREADS = 512;            // 8 waves: one 32-pixel M-block of the tile each, two waves per SIMD
-constexpr int CM_ITEMS = 16 * CM_TIN * CM_TIN;                                  // staged (channel pair, y, x) items per tile: 5184
-constexpr int CM_IPT = (CM_ITEMS + CM_THREADS - 1) / CM_THREADS;               // 11 per thread
-constexpr int CM_OPT = CONV_CO * CONV_TILE * CONV_TILE / CM_THREADS;           // 16 output elements per thread
+constexpr int CM_THREADS = 512;            // 8 waves x 32 pixels = 256 output pixels per pass
+constexpr int CM_PASS = 256;
+constexpr int CM_MAXW = 48;                // widest staged row (output width + 2) this kernel takes: ow <= 46
+constexpr int CM_MAXROWS = 11;             // staged input rows of a pass: the output rows of 256 consecutive pixels (<= 9 for ow >= 32) + 2
+constexpr int CM_IPT = 15;                 // staged (channel pair, y, x) items per thread: 16 * rows * (ow + 2) <= 15 * 512 (host-checked)
+constexpr int CM_OPT = CONV_CO * CM_PASS / CM_THREADS;           // 16 output elements per thread
 
+// A pass covers 256 consecutive output pixels in row-major order of the map (not a square tile: a 39-wide map would pay for 48 x 48),
+// so the staged input is a strip of full-width rows: [rows][ow + 2][CM_PIX] with the tap offsets applied inside it.
 template <bool X3>
 __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* __restrict__ in, const float* __restrict__ Wt,
                                                                   const float* __restrict__ bias, const float* __restrict__ mask,
-                                                                  float* __restrict__ out, int ih, int iw, int oh, int ow, int pad, int relu) {
+                                                                  float* __restrict__ out, int ih, int iw, int oh, int ow, int pad, int relu,
+                                                                  int plane_elems) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cm_lds[];
-    unsigned short* xh = reinterpret_cast<unsigned short*>(cm_lds);                       // [18*18][CM_PIX] hi plane
-    unsigned short* xl = xh + CM_TIN * CM_TIN * CM_PIX;                                   // lo plane (split mode)
-    float* os = reinterpret_cast<float*>(xl + (X3 ? CM_TIN * CM_TIN * CM_PIX : 0));       // [32 co][CM_OSTR] output staging
-    cbf16x8* wh = reinterpret_cast<cbf16x8*>(os + CONV_CO * CM_OSTR);                 // [18 k-steps][64 lanes] B fragments, 16 B each
+    unsigned short* xh = reinterpret_cast<unsigned short*>(cm_lds);                       // [rows][ow + 2][CM_PIX] hi plane
+    unsigned short* xl = xh + plane_elems;                                                // lo plane (split mode)
+    float* os = reinterpret_cast<float*>(xl + (X3 ? plane_elems : 0));                    // [32 co][CM_OSTR] output staging
+    cbf16x8* wh = reinterpret_cast<cbf16x8*>(os + CONV_CO * CM_OSTR);                     // [18 k-steps][64 lanes] B fragments, 16 B each
     cbf16x8* wl = wh + 18 * 64;
     const int n = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -165,32 +170,54 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
         wh[s * 64 + lane] = fh;
         if constexpr (X3) wl[s * 64 + lane] = fl;
     }
-    const int tiles_x = (ow + CONV_TILE - 1) / CONV_TILE, tiles_y = (oh + CONV_TILE - 1) / CONV_TILE, ntiles = tiles_x * tiles_y;
-    // The input of tile t+1 is fetched into registers while tile t is on the matrix cores; it is converted and written to LDS once
-    // every wave is done with tile t. (channel pair, y, x) per item; consecutive threads walk x (18-float row segments of the map).
+    const int npix = oh * ow, npass = (npix + CM_PASS - 1) / CM_PASS, sw = ow + 2;
+    // The input of pass t+1 is fetched into registers while pass t is on the matrix cores; it is converted and written to LDS once
+    // every wave is done with pass t. (channel pair, strip row, x) per item; consecutive threads walk x.
     float v0[CM_IPT], v1[CM_IPT];
-    auto fetch = [&](int tile) {
-        const int iy0 = (tile / tiles_x) * CONV_TILE - pad, ix0 = (tile % tiles_x) * CONV_TILE - pad;
+    auto strip = [&](int pass, int& y0, int& rows) {          // output rows y0 .. y0 + rows - 3 are touched; staged rows = rows
+        const int p0 = pass * CM_PASS, p1 = (p0 + CM_PASS < npix ? p0 + CM_PASS : npix) - 1;
+        y0 = p0 / ow;
+        rows = p1 / ow - y0 + 3;
+    };
+    // item index -> (x, strip row, channel pair) by float reciprocals: exact for these ranges (i < 7680; (i + 0.5) / d is at least
+    // 0.5 / d away from an integer), and ~8 instructions where the integer divisions by run-time values cost ~150 per item
+    const float inv_sw = 1.0f / (float)sw;
+    auto split = [&](int i, int rows, float inv_rows, int& xx, int& yy, int& cp) {
+        const int q = (int)(((float)i + 0.5f) * inv_sw);
+        xx = i - q * sw;
+        cp = (int)(((float)q + 0.5f) * inv_rows);
+        yy = q - cp * rows;
+    };
+    auto fetch = [&](int pass) {
+        int y0, rows;
+        strip(pass, y0, rows);
+        const int items = 16 * rows * sw;
+        const float inv_rows = 1.0f / (float)rows;
 #pragma unroll
         for (int u = 0; u < CM_IPT; ++u) {
             const int i = tid + CM_THREADS * u;
-            const int xx = i % CM_TIN, yy = (i / CM_TIN) % CM_TIN, cp = i / (CM_TIN * CM_TIN);
-            const int gy = iy0 + yy, gx = ix0 + xx;
-            const bool ok = i < CM_ITEMS && gy >= 0 && gy < ih && gx >= 0 && gx < iw;
+            int xx, yy, cp;
+            split(i, rows, inv_rows, xx, yy, cp);
+            const int gy = y0 - pad + yy, gx = xx - pad;
+            const bool ok = i < items && gy >= 0 && gy < ih && gx >= 0 && gx < iw;
             v0[u] = ok ? inn[((int64_t)(2 * cp) * ih + gy) * iw + gx] : 0.f;
             v1[u] = ok ? inn[((int64_t)(2 * cp + 1) * ih + gy) * iw + gx] : 0.f;
         }
     };
     fetch(0);
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int ty0 = (tile / tiles_x) * CONV_TILE, tx0 = (tile % tiles_x) * CONV_TILE;
+    for (int pass = 0; pass < npass; ++pass) {
+        int y0, rows;
+        strip(pass, y0, rows);
+        const int items = 16 * rows * sw, p0 = pass * CM_PASS;
+        const float inv_rows = 1.0f / (float)rows;
 #pragma unroll
         for (int u = 0; u < CM_IPT; ++u) {
             const int i = tid + CM_THREADS * u;
-            if (i < CM_ITEMS) {
-                const int xx = i % CM_TIN, yy = (i / CM_TIN) % CM_TIN, cp = i / (CM_TIN * CM_TIN);
+            if (i < items) {
+                int xx, yy, cp;
+                split(i, rows, inv_rows, xx, yy, cp);
                 const __bf16 h0 = (__bf16)v0[u], h1 = (__bf16)v1[u];
-                const int o = (yy * CM_TIN + xx) * CM_PIX + 2 * cp;
+                const int o = (yy * sw + xx) * CM_PIX + 2 * cp;
                 *reinterpret_cast<unsigned int*>(xh + o) = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
                 if constexpr (X3) {
                     const __bf16 l0 = (__bf16)(v0[u] - (float)h0), l1 = (__bf16)(v1[u] - (float)h1);
@@ -199,17 +226,16 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
             }
         }
         __syncthreads();
-        if (tile + 1 < ntiles) fetch(tile + 1);
-        // this thread's 16 output elements of the tile: the dgrad mask is fetched now, behind the MFMA work
+        if (pass + 1 < npass) fetch(pass + 1);
+        // this thread's 16 output elements of the pass: the dgrad mask is fetched now, behind the MFMA work
         unsigned mkbits = 0xffffu;                                              // bit u: output element u passes the mask
         if (mask) {
             float mv[CM_OPT];
 #pragma unroll
             for (int u = 0; u < CM_OPT; ++u) {
                 const int i = tid + CM_THREADS * u;
-                const int px = i % CONV_TILE, py = (i / CONV_TILE) % CONV_TILE, co = i / (CONV_TILE * CONV_TILE);
-                const int oy = ty0 + py, ox = tx0 + px;
-                mv[u] = (oy < oh && ox < ow) ? mask[(((int64_t)n * CONV_CO + co) * oh + oy) * ow + ox] : 1.0f;
+                const int co = i / CM_PASS, pp = p0 + i % CM_PASS;
+                mv[u] = pp < npix ? mask[((int64_t)n * CONV_CO + co) * npix + pp] : 1.0f;
             }
             mkbits = 0;
 #pragma unroll
@@ -218,11 +244,13 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
         cf32x16 acc, accx;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accx[r] = 0.f; }
-        const int py = 2 * wave + (col >> 4), px = col & 15;                   // this lane's pixel row of the A operand
+        int pa = p0 + 32 * wave + col;                                          // this lane's pixel of the A operand (clamped: tail lanes recompute the last pixel)
+        pa = pa < npix ? pa : npix - 1;
+        const int abase = ((pa / ow - y0) * sw + pa % ow) * CM_PIX + 8 * kg;
 #pragma unroll 2
         for (int s = 0; s < 18; ++s) {                                          // two k-steps of fragments live at a time (VGPR budget: 256 at 8 waves)
             const int dy = (s >> 1) / 3, dx = (s >> 1) % 3;
-            const int o = ((py + dy) * CM_TIN + px + dx) * CM_PIX + (s & 1) * 16 + 8 * kg;
+            const int o = abase + (dy * sw + dx) * CM_PIX + (s & 1) * 16;
             const cbf16x8 ah = *reinterpret_cast<const cbf16x8*>(xh + o);
             const cbf16x8 bh = wh[s * 64 + lane];
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
@@ -233,24 +261,22 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
                 accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, accx, 0, 0, 0);
             }
         }
-        // C layout: reg r of lane l = pixel (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the M-block, channel l & 31
+        // C layout: reg r of lane l = pixel (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the wave's 32, channel l & 31
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = (r & 3) + 8 * (r >> 2) + 4 * kg;
-            const int p = (2 * wave + (m >> 4)) * CONV_TILE + (m & 15);
-            os[col * CM_OSTR + p] = X3 ? accx[r] + acc[r] : acc[r];
+            os[col * CM_OSTR + 32 * wave + m] = X3 ? accx[r] + acc[r] : acc[r];
         }
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < CM_OPT; ++u) {
             const int i = tid + CM_THREADS * u;
-            const int px2 = i % CONV_TILE, py2 = (i / CONV_TILE) % CONV_TILE, co = i / (CONV_TILE * CONV_TILE);
-            const int oy = ty0 + py2, ox = tx0 + px2;
-            if (oy < oh && ox < ow) {
-                float v = os[co * CM_OSTR + py2 * CONV_TILE + px2] + (bias ? bias[co] : 0.f);
+            const int co = i / CM_PASS, pp = p0 + i % CM_PASS;
+            if (pp < npix) {
+                float v = os[co * CM_OSTR + i % CM_PASS] + (bias ? bias[co] : 0.f);
                 if (relu) v = fmaxf(v, 0.f);
                 if (!((mkbits >> u) & 1u)) v = 0.f;
-                out[(((int64_t)n * CONV_CO + co) * oh + oy) * ow + ox] = v;
+                out[((int64_t)n * CONV_CO + co) * npix + pp] = v;
             }
         }
         // the next iteration first writes the input planes only (every wave is past its MFMA reads: second barrier above); os is
@@ -258,19 +284,27 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
     }
 }
 
+// true when the strip of a 256-pixel pass fits the kernel's fixed budgets
+static bool conv3x3_mfma_fits(int oh, int ow) {
+    const int rows = (CM_PASS + ow - 2) / ow + 1 + 2;         // most output rows 256 consecutive pixels can touch, + 2
+    return ow + 2 <= CM_MAXW && 16 * rows * (ow + 2) <= CM_IPT * CM_THREADS && oh * ow >= 1;
+}
 static int conv3x3_mfma(const float* in, const float* Wt, const float* bias, const float* mask, float* out, int n, int ih, int iw, int oh, int ow,
                         int pad, int relu, int prec, hipStream_t s) {
     const bool x3 = prec == EXORL_PREC_BF16X3;
-    const size_t lds = (size_t)(x3 ? 2 : 1) * CM_TIN * CM_TIN * CM_PIX * sizeof(unsigned short) + (size_t)CONV_CO * CM_OSTR * sizeof(float) +
+    const int rows = (CM_PASS + ow - 2) / ow + 1 + 2;
+    const int plane = (int)round_up((int64_t)rows * (ow + 2) * CM_PIX, 8);
+    const size_t lds = (size_t)(x3 ? 2 : 1) * plane * sizeof(unsigned short) + (size_t)CONV_CO * CM_OSTR * sizeof(float) +
                        (size_t)(x3 ? 2 : 1) * 18 * 64 * 16;
+    EXORL_REQUIRE(lds <= 160 * 1024, "conv3x3_mfma: strip of %d rows x %d columns does not fit LDS", rows, ow + 2);
     static bool attr = false;
     if (!attr) {
-        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    if (x3) hipLaunchKernelGGL(conv3x3_mfma_kernel<true>, dim3(n), dim3(CM_THREADS), lds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu);
-    else    hipLaunchKernelGGL(conv3x3_mfma_kernel<false>, dim3(n), dim3(CM_THREADS), lds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu);
+    if (x3) hipLaunchKernelGGL(conv3x3_mfma_kernel<true>, dim3(n), dim3(CM_THREADS), lds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu, plane);
+    else    hipLaunchKernelGGL(conv3x3_mfma_kernel<false>, dim3(n), dim3(CM_THREADS), lds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu, plane);
     EXORL_LAUNCH_CHECK();
     return 0;
 }
@@ -278,7 +312,7 @@ static int conv3x3_mfma(const float* in, const float* Wt, const float* bias, con
 // prec: EXORL_PREC_F32 -> direct fp32 FMA kernel for every layer; bf16 / split-bf16 -> the 32-channel stride-1 layers on MFMA
 static int conv3x3(const float* in, const float* Wt, const float* bias, const float* mask, float* out, int n, int ci_n, int co_n, int ih, int iw,
                    int oh, int ow, int stride, int pad, int in_scale, int relu, hipStream_t s, int prec = EXORL_PREC_F32) {
-    if (prec != EXORL_PREC_F32 && ci_n == CONV_CO && co_n == CONV_CO && stride == 1 && !in_scale)
+    if (prec != EXORL_PREC_F32 && ci_n == CONV_CO && co_n == CONV_CO && stride == 1 && !in_scale && conv3x3_mfma_fits(oh, ow))
         return conv3x3_mfma(in, Wt, bias, mask, out, n, ih, iw, oh, ow, pad, relu, prec, s);
     const int tin = (CONV_TILE - 1) * stride + 3;
     const size_t lds = (size_t)ci_n * tin * tin * sizeof(float);
