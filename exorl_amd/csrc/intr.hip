@@ -694,7 +694,7 @@ struct exorl_intr {
     Lin trunk{};                           // APT: Linear(O, R) of the trunk; LayerNorm gain/beta offsets below
     int64_t ln_g = 0, ln_b = 0;
     float *xn = nullptr, *xf = nullptr, *xb = nullptr, *dxf = nullptr, *dxb = nullptr;
-    float *x2 = nullptr, *z = nullptr, *rep = nullptr, *xhat = nullptr, *rstd = nullptr, *drep = nullptr, *dz = nullptr, *topk = nullptr, *d2 = nullptr, *skr = nullptr;    // d2: squared-distance scratch of the kNN (B x n_tgt)
+    float *x2 = nullptr, *z = nullptr, *rep = nullptr, *xhat = nullptr, *rstd = nullptr, *drep = nullptr, *dz = nullptr, *topk = nullptr, *d2 = nullptr, *skr = nullptr, *splitk = nullptr;    // d2: squared-distance scratch of the kNN (B x n_tgt)
     float *fe = nullptr, *be = nullptr, *metrics = nullptr, *bn = nullptr;
     RmsState* rms = nullptr;
     // Proto: predictor (Linear) in front of net[0] = projector; prototypes C; frozen predictor_target; candidate queue
@@ -809,6 +809,7 @@ static void carve_intr(exorl_intr* it, ICarver& c) {
         it->z1 = c.take(B * R); it->dz1 = c.take(B * R); it->sn = c.take(B * R); it->nrm = c.take(B); it->tn = c.take(B * R);
         it->scores_s = c.take(B * P); it->scores_t = c.take(B * P); it->dscores = c.take(B * P); it->dsn = c.take(B * R);
         it->colsum_p = c.take(P); it->scal = c.take(4); it->skr = c.take(2 * B);
+        if (O >= 4096) it->splitk = c.take(16 * B * R);              // pixel features: split-K scratch of the predictor
         it->queue = c.take((int64_t)g.queue_size * R);
         it->topk = c.take(B * g.knn_k);
         it->d2 = c.take(B * round_up(g.queue_size, 64));
@@ -1102,6 +1103,15 @@ static int launch_l2norm(const float* x, float* y, float* nrm, int rows, int D, 
     return 0;
 }
 
+// predictor Linear(obs_dim, pred_dim): on pixel features (obs_dim = 39200) a (B, 128) output is 32 tiles of a 39200-long reduction,
+// so it runs as a 16-way split-K there
+static int proto_predict(exorl_intr* it, const float* x, int64_t ldx, const float* W, const float* bias, float* out, hipStream_t s) {
+    const auto& c = it->cfg;
+    if (it->splitk) return linear_splitk(c.precision, x, ldx, W, bias, out, c.batch, c.rep_dim, c.obs_dim, it->splitk, 16, s);
+    GemmProblem p{x, W, out, bias, c.batch, c.rep_dim, c.obs_dim, ldx, c.obs_dim, c.rep_dim};
+    return gemm_grouped(c.precision, 0, 0, &p, 1, false, false, s);
+}
+
 static int proto_update(exorl_intr* it, const exorl_intr_batch& b, bool train, hipStream_t s, bool want_reward = true) {
     const auto& c = it->cfg;
     const int B = c.batch, O = c.obs_dim, D = c.rep_dim, P = c.num_protos, prec = c.precision;
@@ -1111,8 +1121,7 @@ static int proto_update(exorl_intr* it, const exorl_intr_batch& b, bool train, h
     const float inv_tau = 1.0f / c.tau;
     if (train) {                                                                                     // proto.py:126-157
         EXORL_TRY(launch_l2norm(C, C, nullptr, P, D, s));                                            // normalize_protos
-        GemmProblem p1{b.obs, Pm + it->pred.W, it->z1, Pm + it->pred.b, B, D, O, b.obs_ld, O, D};
-        EXORL_TRY(gemm_grouped(prec, 0, 0, &p1, 1, false, false, s));
+        EXORL_TRY(proto_predict(it, b.obs, b.obs_ld, Pm + it->pred.W, Pm + it->pred.b, it->z1, s));
         EXORL_TRY(mlp_forward(it->net[0], Pm, it->z1, D, B, prec, s));
         EXORL_TRY(launch_l2norm(it->net[0].act[1], it->sn, it->nrm, B, D, s));
         GemmProblem ps{it->sn, C, it->scores_s, nullptr, B, P, D, D, D, P};
@@ -1120,8 +1129,7 @@ static int proto_update(exorl_intr* it, const exorl_intr_batch& b, bool train, h
         // target branch (no gradient): predictor_target on next_obs, Sinkhorn assignment
         const float* nt = b.next_obs_target ? b.next_obs_target : b.next_obs;
         const int64_t nt_ld = b.next_obs_target ? b.next_obs_target_ld : b.next_obs_ld;
-        GemmProblem pt{nt, Pm + it->pred_t.W, it->tn, Pm + it->pred_t.b, B, D, O, nt_ld, O, D};
-        EXORL_TRY(gemm_grouped(prec, 0, 0, &pt, 1, false, false, s));
+        EXORL_TRY(proto_predict(it, nt, nt_ld, Pm + it->pred_t.W, Pm + it->pred_t.b, it->tn, s));
         EXORL_TRY(launch_l2norm(it->tn, it->tn, nullptr, B, D, s));
         GemmProblem pq{it->tn, C, it->scores_t, nullptr, B, P, D, D, D, P};
         EXORL_TRY(gemm_grouped(prec, 0, 0, &pq, 1, false, false, s));
@@ -1159,8 +1167,7 @@ static int proto_update(exorl_intr* it, const exorl_intr_batch& b, bool train, h
     if (!want_reward) return 0;
     // compute_intr_reward(next_obs) (proto.py:103-124)
     EXORL_TRY(launch_l2norm(C, C, nullptr, P, D, s));
-    GemmProblem pz{b.next_obs, Pm + it->pred.W, it->sn, Pm + it->pred.b, B, D, O, b.next_obs_ld, O, D};
-    EXORL_TRY(gemm_grouped(prec, 0, 0, &pz, 1, false, false, s));
+    EXORL_TRY(proto_predict(it, b.next_obs, b.next_obs_ld, Pm + it->pred.W, Pm + it->pred.b, it->sn, s));
     EXORL_TRY(launch_l2norm(it->sn, it->sn, nullptr, B, D, s));
     GemmProblem pc{it->sn, C, it->scores_s, nullptr, B, P, D, D, D, P};
     EXORL_TRY(gemm_grouped(prec, 0, 0, &pc, 1, false, false, s));

@@ -45,6 +45,9 @@ int ln_param_grad(const float* dh, const float* h, const float* xhat, float* dga
 int colsum(const float* x, float* out, int rows, int cols, int nets, int64_t astride, int64_t pstride, hipStream_t s);
 // fused ReLU backward + column sum (0 = done; 1 = shapes need relu_bwd + colsum separately)
 int relu_bwd_colsum(float* x, const float* act, float* out, int rows, int cols, hipStream_t s);
+// out = x W^T + b with the reduction cut into `splits` slabs in one grouped launch (scratch: splits x rows x F floats), summed in slab order
+int linear_splitk(int prec, const float* x, int64_t ldx, const float* W, const float* b, float* out, int rows, int F, int K, float* scratch,
+                  int splits, hipStream_t s);
 int head_fwd(const float* a, const float* W, const float* b, float* out, int rows, int H, int nout, int tanh_out,
              int nets, int64_t astride, int64_t pstride, int64_t ostride, hipStream_t s);
 int head_bwd_dx(const float* dout, const float* W, const float* a, float* dz, int rows, int H, int nout,

@@ -136,7 +136,6 @@ constexpr int CM_OSTR = 256 + 1;
 constexpr int CM_THREADS = 512;            // 8 waves x 32 pixels = 256 output pixels per pass
 constexpr int CM_PASS = 256;
 constexpr int CM_MAXW = 48;                // widest staged row (output width + 2) this kernel takes: ow <= 46
-constexpr int CM_MAXROWS = 11;             // staged input rows of a pass: the output rows of 256 consecutive pixels (<= 9 for ow >= 32) + 2
 constexpr int CM_IPT = 15;                 // staged (channel pair, y, x) items per thread: 16 * rows * (ow + 2) <= 15 * 512 (host-checked)
 constexpr int CM_OPT = CONV_CO * CM_PASS / CM_THREADS;           // 16 output elements per thread
 

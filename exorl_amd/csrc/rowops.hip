@@ -303,6 +303,37 @@ int relu_bwd_colsum(float* x, const float* act, float* out, int rows, int cols, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// out = x W^T + b for a layer whose fan-in dwarfs its width (the 39200-wide Linear layers on pixel features): a rows x F output is
+// only rows/64 x F/64 tiles, so the reduction is cut into `splits` slabs that run as one grouped launch (splits x tiles workgroups)
+// into `scratch` (splits x rows x F floats) and are summed in slab order.
+__global__ __launch_bounds__(256) void splitk_sum_kernel(const float* __restrict__ P, const float* __restrict__ bias, float* __restrict__ z,
+                                                         int64_t n, int F, int splits) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float acc = bias ? bias[i % F] : 0.f;
+        for (int s = 0; s < splits; ++s) acc += P[(int64_t)s * n + i];
+        z[i] = acc;
+    }
+}
+int linear_splitk(int prec, const float* x, int64_t ldx, const float* W, const float* b, float* out, int rows, int F, int K, float* scratch,
+                  int splits, hipStream_t s) {
+    EXORL_REQUIRE(splits >= 1 && splits <= 32 && scratch, "linear_splitk: bad arguments");
+    const int kc = (int)round_up(cdiv(K, splits), 4);
+    GemmProblem p[32];
+    int cnt = 0;
+    for (int i = 0; i < splits; ++i) {
+        const int k0 = i * kc;
+        if (k0 >= K) break;
+        p[cnt++] = GemmProblem{x + k0, W + k0, scratch + (int64_t)i * rows * F, nullptr, rows, F, K - k0 < kc ? K - k0 : kc, ldx, K, F};
+    }
+    EXORL_TRY(gemm_grouped(prec, 0, 0, p, cnt, false, false, s));
+    const int64_t n = (int64_t)rows * F;
+    const int64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(splitk_sum_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, scratch, b, out, n, F, cnt);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Heads: out[m][j] = b[j] + sum_c a[m][c] W[j][c], j < nout <= 16 (optionally tanh) — one wave per row.
 constexpr int MAX_NOUT = 16;
 
