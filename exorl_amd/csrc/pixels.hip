@@ -131,13 +131,11 @@ typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
 typedef float cf32x16 __attribute__((ext_vector_type(16)));
 constexpr int CM_PIX = 40;                 // bf16 elements per staged pixel (32 channels + 8 pad = 80 B)
 constexpr int CM_TIN = CONV_TILE + 2;      // 18 (the weight-gradient kernel's X tile)
-constexpr int CM_OSTR = 256 + 1;
 
 constexpr int CM_THREADS = 512;            // 8 waves x 32 pixels = 256 output pixels per pass
 constexpr int CM_PASS = 256;
 constexpr int CM_MAXW = 48;                // widest staged row (output width + 2) this kernel takes: ow <= 46
 constexpr int CM_IPT = 15;                 // staged (channel pair, y, x) items per thread: 16 * rows * (ow + 2) <= 15 * 512 (host-checked)
-constexpr int CM_OPT = CONV_CO * CM_PASS / CM_THREADS;           // 16 output elements per thread
 
 // A pass covers 256 consecutive output pixels in row-major order of the map (not a square tile: a 39-wide map would pay for 48 x 48),
 // so the staged input is a strip of full-width rows: [rows][ow + 2][CM_PIX] with the tap offsets applied inside it.
@@ -149,8 +147,7 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
     extern __shared__ __attribute__((aligned(16))) unsigned char cm_lds[];
     unsigned short* xh = reinterpret_cast<unsigned short*>(cm_lds);                       // [rows][ow + 2][CM_PIX] hi plane
     unsigned short* xl = xh + plane_elems;                                                // lo plane (split mode)
-    float* os = reinterpret_cast<float*>(xl + (X3 ? plane_elems : 0));                    // [32 co][CM_OSTR] output staging
-    cbf16x8* wh = reinterpret_cast<cbf16x8*>(os + CONV_CO * CM_OSTR);                     // [18 k-steps][64 lanes] B fragments, 16 B each
+    cbf16x8* wh = reinterpret_cast<cbf16x8*>(xl + (X3 ? plane_elems : 0));                // [18 k-steps][64 lanes] B fragments, 16 B each
     cbf16x8* wl = wh + 18 * 64;
     const int n = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -226,19 +223,23 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
         }
         __syncthreads();
         if (pass + 1 < npass) fetch(pass + 1);
-        // this thread's 16 output elements of the pass: the dgrad mask is fetched now, behind the MFMA work
-        unsigned mkbits = 0xffffu;                                              // bit u: output element u passes the mask
+        // C layout of the 32x32 MFMA: reg r of lane l = pixel (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the wave's 32, channel l & 31 — four
+        // consecutive pixels of one channel per register quad, i.e. 16 contiguous bytes of the NCHW map: the lane stores them itself
+        // (and fetches the dgrad mask the same way, now, behind the MFMA work); no output staging, no second barrier.
+        const int pq = p0 + 32 * wave + 4 * kg;                                 // + 8 q + (0..3), q = r >> 2
+        float* orow = out + ((int64_t)n * CONV_CO + col) * npix;
+        float4 mq[4];
         if (mask) {
-            float mv[CM_OPT];
+            const float* mrow = mask + ((int64_t)n * CONV_CO + col) * npix;
 #pragma unroll
-            for (int u = 0; u < CM_OPT; ++u) {
-                const int i = tid + CM_THREADS * u;
-                const int co = i / CM_PASS, pp = p0 + i % CM_PASS;
-                mv[u] = pp < npix ? mask[((int64_t)n * CONV_CO + co) * npix + pp] : 1.0f;
+            for (int q = 0; q < 4; ++q) {
+                const int pp = pq + 8 * q;
+                if (pp + 3 < npix) mq[q] = *reinterpret_cast<const float4*>(mrow + pp);        // 4-byte aligned vector load
+                else {
+                    mq[q].x = pp < npix ? mrow[pp] : 1.f; mq[q].y = pp + 1 < npix ? mrow[pp + 1] : 1.f;
+                    mq[q].z = pp + 2 < npix ? mrow[pp + 2] : 1.f; mq[q].w = 1.f;
+                }
             }
-            mkbits = 0;
-#pragma unroll
-            for (int u = 0; u < CM_OPT; ++u) mkbits |= (mv[u] > 0.f ? 1u : 0u) << u;
         }
         cf32x16 acc, accx;
 #pragma unroll
@@ -260,26 +261,26 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
                 accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, accx, 0, 0, 0);
             }
         }
-        // C layout: reg r of lane l = pixel (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the wave's 32, channel l & 31
+        const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * kg;
-            os[col * CM_OSTR + 32 * wave + m] = X3 ? accx[r] + acc[r] : acc[r];
-        }
-        __syncthreads();
+        for (int q = 0; q < 4; ++q) {
+            float v[4];
 #pragma unroll
-        for (int u = 0; u < CM_OPT; ++u) {
-            const int i = tid + CM_THREADS * u;
-            const int co = i / CM_PASS, pp = p0 + i % CM_PASS;
-            if (pp < npix) {
-                float v = os[co * CM_OSTR + i % CM_PASS] + (bias ? bias[co] : 0.f);
-                if (relu) v = fmaxf(v, 0.f);
-                if (!((mkbits >> u) & 1u)) v = 0.f;
-                out[((int64_t)n * CONV_CO + co) * npix + pp] = v;
+            for (int e = 0; e < 4; ++e) {
+                v[e] = (X3 ? accx[4 * q + e] + acc[4 * q + e] : acc[4 * q + e]) + bv;
+                if (relu) v[e] = fmaxf(v[e], 0.f);
             }
+            if (mask) {
+                v[0] = mq[q].x > 0.f ? v[0] : 0.f; v[1] = mq[q].y > 0.f ? v[1] : 0.f;
+                v[2] = mq[q].z > 0.f ? v[2] : 0.f; v[3] = mq[q].w > 0.f ? v[3] : 0.f;
+            }
+            const int pp = pq + 8 * q;
+            if (pp + 3 < npix) *reinterpret_cast<float4*>(orow + pp) = make_float4(v[0], v[1], v[2], v[3]);
+            else
+                for (int e = 0; e < 4; ++e)
+                    if (pp + e < npix) orow[pp + e] = v[e];
         }
-        // the next iteration first writes the input planes only (every wave is past its MFMA reads: second barrier above); os is
-        // rewritten after the next iteration's first barrier, i.e. after every thread has finished the loop above
+        __syncthreads();                   // every wave is past its MFMA reads before the next pass rewrites the input planes
     }
 }
 
@@ -293,8 +294,7 @@ static int conv3x3_mfma(const float* in, const float* Wt, const float* bias, con
     const bool x3 = prec == EXORL_PREC_BF16X3;
     const int rows = (CM_PASS + ow - 2) / ow + 1 + 2;
     const int plane = (int)round_up((int64_t)rows * (ow + 2) * CM_PIX, 8);
-    const size_t lds = (size_t)(x3 ? 2 : 1) * plane * sizeof(unsigned short) + (size_t)CONV_CO * CM_OSTR * sizeof(float) +
-                       (size_t)(x3 ? 2 : 1) * 18 * 64 * 16;
+    const size_t lds = (size_t)(x3 ? 2 : 1) * plane * sizeof(unsigned short) + (size_t)(x3 ? 2 : 1) * 18 * 64 * 16;
     EXORL_REQUIRE(lds <= 160 * 1024, "conv3x3_mfma: strip of %d rows x %d columns does not fit LDS", rows, ow + 2);
     static bool attr = false;
     if (!attr) {
