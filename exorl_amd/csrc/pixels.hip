@@ -398,7 +398,7 @@ __global__ __launch_bounds__(1024) void conv_wgrad_kernel(const float* __restric
 // the A fragment (8 consecutive x of one channel) as one aligned ds_read_b128; X gets three copies shifted by the tap's dx so that
 // the B fragment (8 consecutive x + dx of one input channel) is aligned too. Per-image partials in the layout of the fp32 kernel,
 // summed in image order by the same column-sum kernel.
-constexpr int WM_THREADS = 576;
+constexpr int WM_THREADS = 512;            // 8 waves (256 VGPRs each): taps 0..7, the last wave also takes tap 8; wave 0 the bias gradient
 constexpr int WM_DYC = CONV_TILE * CONV_TILE + 8;          // bf16 per dY channel (+16 B: conflict-free across 16 channels)
 constexpr int WM_XC = CM_TIN * CONV_TILE + 8;              // bf16 per X channel of one shifted copy
 
@@ -411,14 +411,14 @@ __global__ __launch_bounds__(WM_THREADS) void conv_wgrad_mfma_kernel(const float
     unsigned short* xh = dl + (X3 ? CONV_CO * WM_DYC : 0);                         // [3 dx][32][WM_XC]
     unsigned short* xl = xh + 3 * CONV_CO * WM_XC;
     const int n = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, tap = tid >> 6;                  // wave = tap
+    const int tid = threadIdx.x, lane = tid & 63, tap = tid >> 6;                  // wave = tap (wave 7: taps 7 and 8)
     const int kg = lane >> 5, col = lane & 31;
     const int dyy = tap / 3, dxx = tap % 3;
     const float* dyn = dy + (int64_t)n * CONV_CO * oh * ow;
     const float* inn = in + (int64_t)n * CONV_CO * ih * iw;
-    cf32x16 acc, accx, accb;
+    cf32x16 acc, accx, accb, acc8, accx8;          // accb: bias gradient (wave 0); acc8 / accx8: tap 8 (wave 7)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accx[r] = 0.f; accb[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accx[r] = 0.f; accb[r] = 0.f; acc8[r] = 0.f; accx8[r] = 0.f; }
     cbf16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
@@ -432,26 +432,51 @@ __global__ __launch_bounds__(WM_THREADS) void conv_wgrad_mfma_kernel(const float
     for (int tile = 0; tile < tiles_x * tiles_y; ++tile) {
         const int ty0 = (tile / tiles_x) * CONV_TILE, tx0 = (tile % tiles_x) * CONV_TILE;
         __syncthreads();
-        // dY tile: (co, y, x pair)
-        for (int i = tid; i < CONV_CO * CONV_TILE * (CONV_TILE / 2); i += WM_THREADS) {
-            const int xp = i % (CONV_TILE / 2), y = (i / (CONV_TILE / 2)) % CONV_TILE, co = i / (CONV_TILE * CONV_TILE / 2);
-            const int gy = ty0 + y, gx = tx0 + 2 * xp;
-            const float a = (gy < oh && gx < ow) ? dyn[((int64_t)co * oh + gy) * ow + gx] : 0.f;
-            const float b = (gy < oh && gx + 1 < ow) ? dyn[((int64_t)co * oh + gy) * ow + gx + 1] : 0.f;
-            const int o = co * WM_DYC + y * CONV_TILE + 2 * xp;
-            *reinterpret_cast<unsigned*>(dh + o) = pack(a, b, false);
-            if constexpr (X3) *reinterpret_cast<unsigned*>(dl + o) = pack(a, b, true);
+        // dY tile: (co, y, x pair); X tile, three copies: copy dx holds columns tx0 + dx .. tx0 + dx + 15 of rows ty0 .. ty0 + 17:
+        // (dx, ci, yy, x pair). Loads are issued in batches before any value is converted and stored, so that their latencies overlap.
+        constexpr int DY_ITEMS = CONV_CO * CONV_TILE * (CONV_TILE / 2), DY_PT = DY_ITEMS / WM_THREADS;                              // 4096, 8
+        constexpr int X_ITEMS = 3 * CONV_CO * CM_TIN * (CONV_TILE / 2), X_PT = X_ITEMS / WM_THREADS;                                // 13824, 27
+        static_assert(DY_ITEMS % WM_THREADS == 0 && X_ITEMS % WM_THREADS == 0 && X_PT % 3 == 0, "staging items divide evenly");
+        {
+            float va[DY_PT], vb[DY_PT];
+#pragma unroll
+            for (int u = 0; u < DY_PT; ++u) {
+                const int i = tid + WM_THREADS * u;
+                const int xp = i % (CONV_TILE / 2), y = (i / (CONV_TILE / 2)) % CONV_TILE, co = i / (CONV_TILE * CONV_TILE / 2);
+                const int gy = ty0 + y, gx = tx0 + 2 * xp;
+                va[u] = (gy < oh && gx < ow) ? dyn[((int64_t)co * oh + gy) * ow + gx] : 0.f;
+                vb[u] = (gy < oh && gx + 1 < ow) ? dyn[((int64_t)co * oh + gy) * ow + gx + 1] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < DY_PT; ++u) {
+                const int i = tid + WM_THREADS * u;
+                const int xp = i % (CONV_TILE / 2), y = (i / (CONV_TILE / 2)) % CONV_TILE, co = i / (CONV_TILE * CONV_TILE / 2);
+                const int o = co * WM_DYC + y * CONV_TILE + 2 * xp;
+                *reinterpret_cast<unsigned*>(dh + o) = pack(va[u], vb[u], false);
+                if constexpr (X3) *reinterpret_cast<unsigned*>(dl + o) = pack(va[u], vb[u], true);
+            }
         }
-        // X tile, three copies: copy dx holds columns tx0 + dx .. tx0 + dx + 15 of rows ty0 .. ty0 + 17: (dx, ci, yy, x pair)
-        for (int i = tid; i < 3 * CONV_CO * CM_TIN * (CONV_TILE / 2); i += WM_THREADS) {
-            const int xp = i % (CONV_TILE / 2), yy = (i / (CONV_TILE / 2)) % CM_TIN, ci = (i / (CM_TIN * CONV_TILE / 2)) % CONV_CO,
-                      dx = i / (CONV_CO * CM_TIN * CONV_TILE / 2);
-            const int gy = ty0 + yy, gx = tx0 + dx + 2 * xp;
-            const float a = (gy < ih && gx < iw) ? inn[((int64_t)ci * ih + gy) * iw + gx] : 0.f;
-            const float b = (gy < ih && gx + 1 < iw) ? inn[((int64_t)ci * ih + gy) * iw + gx + 1] : 0.f;
-            const int o = (dx * CONV_CO + ci) * WM_XC + yy * CONV_TILE + 2 * xp;
-            *reinterpret_cast<unsigned*>(xh + o) = pack(a, b, false);
-            if constexpr (X3) *reinterpret_cast<unsigned*>(xl + o) = pack(a, b, true);
+#pragma unroll 1
+        for (int part = 0; part < 3; ++part) {
+            float va[X_PT / 3], vb[X_PT / 3];
+#pragma unroll
+            for (int u = 0; u < X_PT / 3; ++u) {
+                const int i = tid + WM_THREADS * (part * (X_PT / 3) + u);
+                const int xp = i % (CONV_TILE / 2), yy = (i / (CONV_TILE / 2)) % CM_TIN, ci = (i / (CM_TIN * CONV_TILE / 2)) % CONV_CO,
+                          dx = i / (CONV_CO * CM_TIN * CONV_TILE / 2);
+                const int gy = ty0 + yy, gx = tx0 + dx + 2 * xp;
+                va[u] = (gy < ih && gx < iw) ? inn[((int64_t)ci * ih + gy) * iw + gx] : 0.f;
+                vb[u] = (gy < ih && gx + 1 < iw) ? inn[((int64_t)ci * ih + gy) * iw + gx + 1] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < X_PT / 3; ++u) {
+                const int i = tid + WM_THREADS * (part * (X_PT / 3) + u);
+                const int xp = i % (CONV_TILE / 2), yy = (i / (CONV_TILE / 2)) % CM_TIN, ci = (i / (CM_TIN * CONV_TILE / 2)) % CONV_CO,
+                          dx = i / (CONV_CO * CM_TIN * CONV_TILE / 2);
+                const int o = (dx * CONV_CO + ci) * WM_XC + yy * CONV_TILE + 2 * xp;
+                *reinterpret_cast<unsigned*>(xh + o) = pack(va[u], vb[u], false);
+                if constexpr (X3) *reinterpret_cast<unsigned*>(xl + o) = pack(va[u], vb[u], true);
+            }
         }
         __syncthreads();
 #pragma unroll 2
@@ -460,15 +485,28 @@ __global__ __launch_bounds__(WM_THREADS) void conv_wgrad_mfma_kernel(const float
             const int ob = (dxx * CONV_CO + col) * WM_XC + (y + dyy) * CONV_TILE + 8 * kg;      // B: X[ci = col][y + dy][8 kg + dx ..]
             const cbf16x8 ah = *reinterpret_cast<const cbf16x8*>(dh + oa);
             const cbf16x8 bh = *reinterpret_cast<const cbf16x8*>(xh + ob);
+            cbf16x8 al = ah, bl = bh;
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
             if constexpr (X3) {
-                const cbf16x8 al = *reinterpret_cast<const cbf16x8*>(dl + oa);
-                const cbf16x8 bl = *reinterpret_cast<const cbf16x8*>(xl + ob);
+                al = *reinterpret_cast<const cbf16x8*>(dl + oa);
+                bl = *reinterpret_cast<const cbf16x8*>(xl + ob);
                 accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, accx, 0, 0, 0);
                 accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, accx, 0, 0, 0);
-                if (tap == 8) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ones, accb, 0, 0, 0);      // wave-uniform branch
             }
-            if (tap == 8) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ones, accb, 0, 0, 0);
+            if (tap == 0) {                                      // wave-uniform: bias gradient = dY . ones
+                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ones, accb, 0, 0, 0);
+                if constexpr (X3) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ones, accb, 0, 0, 0);
+            }
+            if (tap == 7) {                                      // wave-uniform: tap 8 = (dy 2, dx 2)
+                const int ob8 = (2 * CONV_CO + col) * WM_XC + (y + 2) * CONV_TILE + 8 * kg;
+                const cbf16x8 bh8 = *reinterpret_cast<const cbf16x8*>(xh + ob8);
+                acc8 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh8, acc8, 0, 0, 0);
+                if constexpr (X3) {
+                    const cbf16x8 bl8 = *reinterpret_cast<const cbf16x8*>(xl + ob8);
+                    accx8 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl8, accx8, 0, 0, 0);
+                    accx8 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh8, accx8, 0, 0, 0);
+                }
+            }
         }
     }
     // C layout: reg r of lane l = row (r & 3) + 8 (r >> 2) + 4 (l >> 5) (co), column l & 31 (ci)
@@ -476,7 +514,8 @@ __global__ __launch_bounds__(WM_THREADS) void conv_wgrad_mfma_kernel(const float
     for (int r = 0; r < 16; ++r) {
         const int co = (r & 3) + 8 * (r >> 2) + 4 * kg;
         P[(((int64_t)n * CONV_CO + co) * CONV_CO + col) * 9 + tap] = X3 ? accx[r] + acc[r] : acc[r];
-        if (tap == 8 && col == 0) Pb[(int64_t)n * CONV_CO + co] = accb[r];
+        if (tap == 7) P[(((int64_t)n * CONV_CO + co) * CONV_CO + col) * 9 + 8] = X3 ? accx8[r] + acc8[r] : acc8[r];
+        if (tap == 0 && col == 0) Pb[(int64_t)n * CONV_CO + co] = accb[r];
     }
 }
 
