@@ -1,5 +1,8 @@
-"""First timing of BASELINE config 4 (Proto, jaco pixels (3,84,84) uint8, A=9, batch 1024, nstep 3) on one MI355X — the round-1 pixel
-path is the correctness version (direct fp32 convolutions); this script records where it stands. Not the bench.py metric."""
+"""update()/s at BASELINE config 4 shapes (Proto or plain DDPG on jaco pixels (3,84,84) uint8, A=9, batch 1024, nstep 3) on one MI355X.
+
+    python tools/micro/pixel_bench.py [batch=1024] [proto|ddpg] [fp32|bf16x3|bf16]
+
+Not the bench.py metric (that is TD3+BC on states); the numbers go to DESIGN.md's pixel section."""
 import sys
 import time
 from pathlib import Path
