@@ -53,6 +53,51 @@ __global__ __launch_bounds__(256) void aug_shift_kernel(const unsigned char* __r
     }
 }
 
+// Same arithmetic, one workgroup per (image, channel): the shift is drawn once per workgroup instead of once per output element (a
+// Philox block per pixel was most of the elementwise kernel's time), and the per-column / per-row source indices and bilinear weights —
+// they depend on (j, sx) and (i, sy) only — are tabulated in LDS. Products and sums per element are formed exactly as above.
+constexpr int AUG_MAXH = 128;
+__global__ __launch_bounds__(256) void aug_shift_rows_kernel(const unsigned char* __restrict__ x, const int* __restrict__ shifts, uint64_t seed,
+                                                             uint64_t counter, float* __restrict__ out, int c, int h, int pad) {
+#pragma clang fp contract(off)
+    __shared__ int c0[2][AUG_MAXH], c1[2][AUG_MAXH];         // [0]: columns (x), [1]: rows (y): clamped source index of tap 0 / tap 1, -1 = zero padding
+    __shared__ float w0[2][AUG_MAXH], w1[2][AUG_MAXH];
+    const int b = blockIdx.x / c, ch = blockIdx.x % c;
+    const int P = h + 2 * pad;
+    const float eps = (float)(1.0 / P), start = -1.0f + eps, end = 1.0f - eps, step = (end - start) / (float)(P - 1);
+    const float unit = (float)(2.0 / P);
+    int sxy[2];
+    if (shifts) { sxy[0] = shifts[2 * b]; sxy[1] = shifts[2 * b + 1]; }
+    else {      // torch.randint(0, 2 pad + 1, (n,1,1,2)): one Philox draw per image
+        uint32_t r[4] = {(uint32_t)b, 13u, (uint32_t)counter, (uint32_t)(counter >> 32)};
+        Philox::gen(r, seed);
+        sxy[0] = (int)(((uint64_t)r[0] * (uint64_t)(2 * pad + 1)) >> 32);
+        sxy[1] = (int)(((uint64_t)r[1] * (uint64_t)(2 * pad + 1)) >> 32);
+    }
+    for (int t = threadIdx.x; t < 2 * h; t += 256) {
+        const int d = t / h, k = t % h;
+        const float g = lin_f32(start, end, step, k, P) + (float)sxy[d] * unit;
+        const float ik = ((g + 1.0f) * (float)P - 1.0f) / 2.0f;
+        const float fk = floorf(ik);
+        const int k0 = (int)fk;
+        w1[d][k] = ik - fk;
+        w0[d][k] = 1.0f - (ik - fk);
+        c0[d][k] = (k0 < 0 || k0 >= P) ? -1 : min(max(k0 - pad, 0), h - 1);
+        c1[d][k] = (k0 + 1 < 0 || k0 + 1 >= P) ? -1 : min(max(k0 + 1 - pad, 0), h - 1);
+    }
+    __syncthreads();
+    const unsigned char* img = x + ((int64_t)b * c + ch) * h * h;
+    float* o = out + ((int64_t)b * c + ch) * h * h;
+    for (int e = threadIdx.x; e < h * h; e += 256) {
+        const int i = e / h, j = e % h;
+        const int y0 = c0[1][i], y1 = c1[1][i], x0 = c0[0][j], x1 = c1[0][j];
+        const float wy0 = w0[1][i], wy1 = w1[1][i], wx0 = w0[0][j], wx1 = w1[0][j];
+        const float t00 = (y0 >= 0 && x0 >= 0) ? (float)img[y0 * h + x0] : 0.f, t01 = (y0 >= 0 && x1 >= 0) ? (float)img[y0 * h + x1] : 0.f;
+        const float t10 = (y1 >= 0 && x0 >= 0) ? (float)img[y1 * h + x0] : 0.f, t11 = (y1 >= 0 && x1 >= 0) ? (float)img[y1 * h + x1] : 0.f;
+        o[e] = t00 * (wy0 * wx0) + t01 * (wy0 * wx1) + t10 * (wy1 * wx0) + t11 * (wy1 * wx1);
+    }
+}
+
 // ---- weight shadows: Wf[ci][tap][co] for the forward pass, Wb[co][tap flipped][ci] for dgrad -----------------------------------
 __global__ void conv_weight_shadow_kernel(const float* __restrict__ W, float* __restrict__ Wf, float* __restrict__ Wb, int ci_n) {
     const int total = CONV_CO * ci_n * 9;
@@ -571,6 +616,12 @@ extern "C" {
 int exorl_aug_shift(const unsigned char* x_dev, int32_t n, int32_t c, int32_t h, int32_t pad, const int32_t* shifts_dev, uint64_t seed,
                     uint64_t counter, float* out_dev, void* stream) {
     EXORL_REQUIRE(x_dev && out_dev && n > 0 && c > 0 && h > 1 && pad >= 0, "aug_shift: bad arguments");
+    if (h <= AUG_MAXH) {
+        hipLaunchKernelGGL(aug_shift_rows_kernel, dim3((unsigned)(n * c)), dim3(256), 0, as_stream(stream), x_dev, shifts_dev, seed, counter, out_dev,
+                           c, h, pad);
+        EXORL_LAUNCH_CHECK();
+        return 0;
+    }
     const int64_t total = (int64_t)n * c * h * h;
     const int64_t blocks = (total + 255) / 256;
     hipLaunchKernelGGL(aug_shift_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, as_stream(stream), x_dev, shifts_dev, seed,
