@@ -4,6 +4,7 @@ replay resident in HBM (BASELINE.json configs[1]; SURVEY.md 8d "Config 2").
     python bench.py --gpus 1 --steps 2000 --warmup 200
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...          (no launcher: starts its N rank processes itself, one per GPU, and relays rank 0's line)
 
 A step = one agent.update(replay_iter, step): HBM gather + n-step relabel of a 1024-row minibatch, critic
 update, actor update, target update (use_tb=False, as configs/offline.yaml:25). Inputs are resident in HBM
@@ -18,7 +19,8 @@ mode (faster, ~4e-4 drift) and the exact-fp32 mode are timed briefly afterwards 
 
 Prints ONE JSON line on rank 0. Extra legs (rank 0, N=1 only): `roofline` — the dominant kernel (the grouped
 1024^3 MFMA GEMM) timed per launch with HIP events on its own stream in a separate instrumented pass of the
-same loop; `cpu_baseline` — the numpy oracle of the same update, bounded to a few seconds, on the host cores.
+same loop; `cpu_baseline` — a torch-CPU twin of the reference's update (oracle/torch_twin.py: the library ops the reference
+uses, pinned to the reference's recorded trajectory) on the host cores this process may use, with the numpy oracle beside it.
 """
 import argparse
 import json
@@ -66,19 +68,19 @@ def synth_replay(rank, world, device):
     return eng
 
 
-def cpu_baseline(budget_s=12.0):
-    """The oracle (numpy fp32, BLAS threads of this host) on a bounded sample of the same workload."""
+def cpu_baseline(budget_s=30.0, numpy_budget_s=6.0):
+    """The reference's CPU path restated, timed on this host: update() incl. sampling, 20 warm-up + up to 200 timed steps.
+    value: torch-CPU twin (nn.Linear / LayerNorm / Adam / autograd — what the reference's agent runs on device='cpu'), threads =
+    the physical cores of one socket this process is allowed to use. numpy_oracle: the numpy restatement the parity tests use."""
     from oracle.agents import OracleAgent, param_shapes
     from oracle.replay import gather_nstep_batch
+    from oracle.torch_twin import TorchTwinTD3BC, usable_cores
     sys.path.insert(0, str(ROOT / 'tests'))
     import _synth
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count() or 1
+    cores, host = usable_cores()
     ash, csh = param_shapes('td3_bc', O, A, H)
-    ag = OracleAgent('td3_bc', list(_synth.synth_params(ash, 5).values()), list(_synth.synth_params(csh, 6).values()))
+    pa, pc = list(_synth.synth_params(ash, 5).values()), list(_synth.synth_params(csh, 6).values())
+    ag = OracleAgent('td3_bc', pa, pc)
     rs = np.random.RandomState(0)
     n_eps = 100                                                    # 100k-transition slice of the arena: same gather
     rows = n_eps * (EP_LEN + 1)
@@ -87,20 +89,57 @@ def cpu_baseline(budget_s=12.0):
     rew = rs.uniform(0, 1, (rows, 1)).astype(np.float32)
     disc = np.ones((rows, 1), np.float32)
 
-    def step(i):
+    def sample():
         e = rs.randint(0, n_eps, B)
         idx = rs.randint(0, EP_LEN, B) + 1
-        batch = gather_nstep_batch(obs, act, rew, disc, e.astype(np.int64) * (EP_LEN + 1), idx, 1, GAMMA)
-        ag.update(batch, i, rs.standard_normal((B, A)).astype(np.float32), rs.standard_normal((B, A)).astype(np.float32))
-    step(0)
-    t0, n = time.perf_counter(), 0
-    while time.perf_counter() - t0 < budget_s and n < 400:
-        step(n + 1)
-        n += 1
-    dt = time.perf_counter() - t0
-    return {'value': n / dt, 'unit': 'gradient-steps/s', 'cores': int(cores), 'kind': 'port',
-            'sample': f'{n} TD3+BC update() steps incl. vectorised n-step gather from a 100k-transition slice, B={B}, '
-                      f'numpy fp32 oracle (oracle/agents.py), {dt:.1f} s'}
+        return (gather_nstep_batch(obs, act, rew, disc, e.astype(np.int64) * (EP_LEN + 1), idx, 1, GAMMA),
+                rs.standard_normal((B, A)).astype(np.float32), rs.standard_normal((B, A)).astype(np.float32))
+
+    def timed(fn, warm, max_steps, budget):
+        for _ in range(warm):
+            fn()
+        t0, n = time.perf_counter(), 0
+        while n < max_steps and (time.perf_counter() - t0 < budget or n < 5):
+            fn()
+            n += 1
+        return n, time.perf_counter() - t0
+
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    tw = TorchTwinTD3BC(O, A, H)
+    tw.load(pa, pc)
+    n_t, dt_t = timed(lambda: tw.update(*sample()), 20, 200, budget_s)
+    torch.set_num_threads(old_threads)
+    step_no = [0]
+
+    def np_step():
+        b, n1, n2 = sample()
+        ag.update(b, step_no[0], n1, n2)
+        step_no[0] += 1
+    n_n, dt_n = timed(np_step, 1, 100, numpy_budget_s)
+    return {'value': n_t / dt_t, 'unit': 'gradient-steps/s', 'cores': int(cores), 'kind': 'port',
+            'sample': f'{n_t} TD3+BC update() steps after 20 warm-up, incl. vectorised n-step gather from a 100k-transition slice, B={B}, '
+                      f'torch {torch.__version__} CPU twin of td3_bc.py:119-189 (oracle/torch_twin.py), {cores} threads, {dt_t:.1f} s',
+            'host': host,
+            'numpy_oracle': {'value': n_n / dt_n, 'steps': n_n, 'seconds': dt_n,
+                             'note': 'oracle/agents.py (numpy fp32, hand-derived backward), default BLAS threads'}}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without torch.distributed.run: start the N rank processes as children (fresh interpreters, one
+    per GPU; nothing here has initialised HIP, and no exec happens in a process that has), wait, return the worst exit code.
+    Rank 0 prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env))
+    return max(abs(p.wait()) for p in procs)
 
 
 def main():
@@ -118,12 +157,13 @@ def main():
     ap.add_argument('--branches', type=int, default=int(os.environ.get('EXORL_BRANCHES', '0')))
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))       # no launcher around us: be the launcher (this process never touches a GPU)
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a number for a different topology')
     if args.rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -174,10 +214,14 @@ def main():
     run(args.steps, args.warmup)
     fence()
     dt = time.perf_counter() - t0
+    ranks_seen = [0]
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        seen = [torch.zeros(1, device=device, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(seen, torch.tensor([rank], device=device, dtype=torch.int64))
+        ranks_seen = sorted(int(x.item()) for x in seen)
 
     out = None
     if rank == 0:
@@ -192,6 +236,7 @@ def main():
                        'parallelism': f'dp{world}', 'hip_graph': use_graph, 'graph_parallel_branches': bool(args.branches) and use_graph,
                        'mfma_operands': {'bf16': 'bf16 (fp32 accumulate, fp32 master weights)', 'fp32': 'fp32',
                                          'bf16x3': 'split bf16: hi*hi + hi*lo + lo*hi (fp32 accumulate); within the 1e-4 parity bar'}[args.precision]},
+            'ranks_seen': ranks_seen,
             'algorithmic_gflop_per_step': flops / 1e9,
             'step_frac_of_mfma_peak': (world * args.steps / dt) * flops / 1e12 / (PEAK_TFLOPS[args.precision] * world),
         }
@@ -213,11 +258,19 @@ def main():
         big = fl >= 2.0 * 2 * B * H * H * 0.99           # the two-problem 1024^3 launches (fwd / dgrad / wgrad of Linear(H,H))
         ach = float(fl[big].mean() / (ms[big].mean() * 1e-3) / 1e12)
         peak = PEAK_TFLOPS[args.precision]
-        traffic = None          # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this command
-        tf = ROOT / 'profiles' / f'r01_pmc_traffic_{args.precision}.json'
-        if tf.exists():
-            traffic = json.load(open(tf))['traffic_bytes_per_launch']
+        # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this command (tools/run_final.sh writes the JSON with
+        # the commit and the kernel names it measured); stale = those kernels are no longer in the library being timed -> null
+        traffic, traffic_src = None, None
+        tfs = sorted((ROOT / 'profiles').glob(f'r*_pmc_traffic_{args.precision}.json'))
+        if tfs:
+            tj = json.load(open(tfs[-1]))
+            blob = (ROOT / 'exorl_amd' / 'libexorl_hip.so').read_bytes()
+            stale = [k for k in tj.get('kernels', []) if k.encode() not in blob]
+            traffic_src = {'file': tfs[-1].name, 'commit': tj.get('commit'), 'kernels': tj.get('kernels'), 'stale_kernels': stale}
+            if not stale and tj.get('kernels'):
+                traffic = tj['traffic_bytes_per_launch']
         out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic,
+                           'traffic_source': traffic_src, 'traffic_source_commit': (traffic_src or {}).get('commit'),
                            'kernel': {'bf16': 'gemm16g_kernel / gemm16g_mixed_kernel (grouped 2-4 x [1024x1024x1024]: fwd, dgrad, wgrad+dgrad of Linear(H,H))',
                                       'bf16x3': 'gemm16x3_kernel / gemm16x3_mixed_kernel (grouped 2-4 x [1024x1024x1024] on hi/lo bf16 planes: fwd, dgrad, '
                                                 'wgrad+dgrad of Linear(H,H))',

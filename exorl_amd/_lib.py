@@ -143,8 +143,10 @@ PROTOTYPES = {
     'exorl_agent_set_parallel_branches': (C.c_int, [c_void_p, c_int32]),
     'exorl_agent_opt_steps': (C.c_int, [c_void_p, P(c_int64), P(c_int64)]),
     'exorl_agent_set_opt_steps': (C.c_int, [c_void_p, c_int64, c_int64]),
-    'exorl_agent_enable_graph': (C.c_int, [c_void_p, c_void_p, c_int32, c_float, c_float]),
-    'exorl_agent_step_graph': (C.c_int, [c_void_p, c_void_p]),
+    'exorl_agent_enable_graph': (C.c_int, [c_void_p, c_void_p, c_int32, c_float, c_float, c_void_p]),
+    'exorl_agent_step_graph': (C.c_int, [c_void_p, c_float, c_void_p]),
+    'exorl_agent_noise_counter': (C.c_int, [c_void_p, P(c_uint64), c_void_p]),
+    'exorl_debug_philox_normal': (C.c_int, [c_uint64, c_uint64, c_int64, c_void_p, c_void_p]),
     'exorl_agent_disable_graph': (C.c_int, [c_void_p]),
     'exorl_gemm': (C.c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int64,
                              c_void_p, c_int64, c_void_p, c_int32, c_int32, c_void_p]),

@@ -250,10 +250,7 @@ class _AgentBase:
 
     def _step(self, replay_iter, stddev):
         if replay_iter is self._graph_iter and self.noise_hook is None:
-            if stddev != self._graph_stddev:          # stddev schedule moved: re-capture with the new constant
-                self._graph_stddev = stddev
-                self.engine.enable_graph(replay_iter.engine, replay_iter.nstep, replay_iter.discount, stddev)
-            self.engine.step_graph()
+            self.engine.step_graph(stddev)            # the std lives in device memory: a moving schedule needs no re-capture
             return
         self._load_batch(replay_iter)
         self._run_update(stddev)

@@ -342,6 +342,7 @@ struct exorl_agent {
     int64_t actor_t = 0, critic_t = 0;       // host mirrors of state->t_*
     uint64_t act_noise_counter = 0;
     float inv_bg = 0.f;
+    float dev_stddev = -1.f;     // host mirror of state->stddev (the last value enqueued for it)
     // captured step (sample + update) — exorl_agent_enable_graph
     hipGraphExec_t graph_exec = nullptr;
     hipGraph_t graph = nullptr;
@@ -541,12 +542,12 @@ static int phase0(exorl_agent* a, float stddev, const float* noise_c, hipStream_
     // critic update) straight into the two critic input buffers, as the epilogue of the actor head
     a->noise_c = noise_c;
     const bool fused_sample = cfg.hidden_dim % 4 == 0 && A > 1;
-    SampleSpec sp{noise_c, cfg.kind == EXORL_AGENT_CRR ? nullptr : a->noise_a, cfg.seed, &a->state->noise_counter, stddev, cfg.stddev_clip,
+    SampleSpec sp{&a->state->stddev, noise_c, cfg.kind == EXORL_AGENT_CRR ? nullptr : a->noise_a, cfg.seed, &a->state->noise_counter, stddev, cfg.stddev_clip,
                   a->xc_next + O, a->xc_pi + O, W, B};
     EXORL_TRY(net_forward(a->actor, Pa, a->sh_actor, a->xa, O, 2 * B, a->fa, true, true, prec, s, fused_sample ? &sp : nullptr));
     if (!fused_sample)
         EXORL_TRY(sample_actions2(a->fa.out, noise_c, cfg.kind == EXORL_AGENT_CRR ? nullptr : a->noise_a, cfg.seed,
-                                  &a->state->noise_counter, stddev, cfg.stddev_clip, a->xc_next + O, a->xc_pi + O, W, B, A, s));
+                                  &a->state->noise_counter, stddev, cfg.stddev_clip, a->xc_next + O, a->xc_pi + O, W, B, A, s, &a->state->stddev));
     const bool qf = qfuse(a);
     if (!a->fk.on && forward2_supported(a->critic, prec, a->sh_target, a->sh_critic)) {
         EXORL_TRY(net_forward2(a->critic, Pt, a->sh_target, a->xc_next, a->ft, false, Pc, a->sh_critic, a->xc_cur, a->fc, true, W, B, s, qf));
@@ -585,7 +586,7 @@ static int phase1(exorl_agent* a, float stddev, const float* noise_a, hipStream_
         const int n = cfg.num_value_samples;
         const float* Pc = a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM];
         EXORL_TRY(repeat_sample(a->obs, a->fa.out + (int64_t)B * A, noise_a, cfg.seed, noise_a ? nullptr : &a->state->noise_counter, 1,
-                                stddev, cfg.stddev_clip, a->xc_rep, B, O, A, n, s));
+                                stddev, cfg.stddev_clip, a->xc_rep, B, O, A, n, s, &a->state->stddev));
         EXORL_TRY(net_forward(a->critic, Pc, a->sh_critic, a->xc_rep, W, B * n, a->fr, false, false, prec, s));      // compute_value
         EXORL_TRY(net_forward(a->critic, Pc, a->sh_critic, a->xc_cur, W, B, a->fc, false, false, prec, s));          // Q(s, a_data)
         EXORL_TRY(crr_weights(a->fr.out, a->fc.out, a->crr_w, B, n, cfg.weight_func, s));
@@ -594,7 +595,7 @@ static int phase1(exorl_agent* a, float stddev, const float* noise_a, hipStream_
     // pi(obs) sample already sits in xc_pi (phase 0); DDPG logs its log-prob (ddpg.py:276,289)
     if ((cfg.kind == EXORL_AGENT_DDPG || cfg.kind == EXORL_AGENT_APS) && a->want_metrics)
         EXORL_TRY(sample_action(a->fa.out + (int64_t)B * A, noise_spec(a, noise_a, 1), stddev, cfg.stddev_clip, 1, a->xc_pi + O, W, B, A,
-                                a->metrics + EXORL_M_ACTOR_LOGPROB, s));
+                                a->metrics + EXORL_M_ACTOR_LOGPROB, s, &a->state->stddev));
     const bool qf = qfuse(a);
     EXORL_TRY(net_forward(a->critic, a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->sh_critic, a->xc_pi, W, B, a->fc, true, false, prec, s,
                           nullptr, qf));
@@ -632,10 +633,10 @@ static int phase2(exorl_agent* a, float stddev, hipStream_t s) {
     if (a->want_metrics)                        // actor_loss / batch_reward(BC) metrics only (the gradient is formed in head_bwd)
         EXORL_TRY(actor_dmu(a->da, A, a->has_critic ? a->critic.n_trunks : 0, (int64_t)B * A, f.out, a->action,
                             a->has_critic ? nullptr : a->reward, a->crr_w, a->dpre, a->stats, a->metrics, B, A, a->inv_bg, cfg.alpha,
-                            cfg.kind, stddev, s));
+                            cfg.kind, stddev, s, &a->state->stddev));
     DoutSpec dm{};
     dm.mode = EXORL_DOUT_ACTOR_MU; dm.da = a->da; dm.da_nets = a->has_critic ? a->critic.n_trunks : 0; dm.mu = f.out; dm.a_data = a->action;
-    dm.kind = cfg.kind; dm.inv_bg = a->inv_bg; dm.stddev = stddev; dm.w = a->crr_w;
+    dm.kind = cfg.kind; dm.inv_bg = a->inv_bg; dm.stddev = stddev; dm.stddev_ptr = &a->state->stddev; dm.w = a->crr_w;
     if (qfuse(a)) {                             // lambda = alpha / mean|Q| from the per-chunk sums qhead left behind
         dm.lam_parts = a->abs_part; dm.lam_chunks = qhead_chunks(B); dm.use_lambda = cfg.kind == EXORL_AGENT_TD3_BC; dm.alpha = cfg.alpha;
     }
@@ -858,6 +859,12 @@ int exorl_agent_update_phase(exorl_agent_t* a, int32_t phase, float stddev, cons
     EXORL_REQUIRE(stddev > 0.f || a->cfg.kind == EXORL_AGENT_CQL, "agent_update_phase: stddev must be > 0");
     hipStream_t s = as_stream(stream);
     a->noise_a = noise_a;
+    // the kernels read the exploration std from the device step state; enqueue a new value only when the schedule moved
+    // (never while capturing: a captured graph is std-agnostic, exorl_agent_step_graph writes it before the launch)
+    if (!a->capturing && a->cfg.kind != EXORL_AGENT_CQL && stddev != a->dev_stddev) {
+        EXORL_TRY(set_device_float(&a->state->stddev, stddev, s));
+        a->dev_stddev = stddev;
+    }
     if (a->cfg.kind == EXORL_AGENT_CQL) {
         a->noise_c = noise_c;
         switch (phase) {
@@ -942,18 +949,23 @@ int exorl_agent_set_opt_steps(exorl_agent_t* a, int64_t actor_steps, int64_t cri
     return push_opt_steps(a);
 }
 
-int exorl_agent_enable_graph(exorl_agent_t* a, exorl_replay_t* r, int32_t nstep, float gamma, float stddev) {
+int exorl_agent_enable_graph(exorl_agent_t* a, exorl_replay_t* r, int32_t nstep, float gamma, float stddev, void* stream) {
     EXORL_REQUIRE(a && r, "agent_enable_graph: null argument");
+    // a previous step (eager or a graph launch) may still be running on the caller's stream and reads the buffers the new graph is
+    // built over; releasing a graph exec that is executing is not allowed either. Setup call: a full stream sync is fine here.
+    EXORL_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
     EXORL_REQUIRE(a->cfg.world_size == 1, "agent_enable_graph: data-parallel steps need host-side all-reduces between phases");
     EXORL_REQUIRE(stddev > 0.f && nstep >= 1, "agent_enable_graph: bad stddev/nstep");
     EXORL_TRY(release_graph(a));
     if (!a->capture_stream) EXORL_CHECK_HIP(hipStreamCreateWithFlags(&a->capture_stream, hipStreamNonBlocking));
     exorl_batch_out slots;
     EXORL_TRY(exorl_agent_batch_slots(a, &slots));
-    // one eager sample: uploads the episode table, sizes the pair buffer, validates nstep vs episode lengths
-    EXORL_TRY(replay_sample_impl(r, a->cfg.batch, nstep, gamma, EXORL_SAMPLER_PHILOX, nullptr, &slots, nullptr, a->capture_stream, nullptr));
+    // what a sample call would do on the host side (episode table upload, pair buffer, nstep vs episode lengths) — no draw is spent
+    EXORL_TRY(replay_prepare(r, a->cfg.batch, nstep, a->capture_stream));
     const uint64_t ctr = replay_philox_counter(r);
     EXORL_CHECK_HIP(hipMemcpyAsync(&a->state->replay_counter, &ctr, sizeof(ctr), hipMemcpyHostToDevice, a->capture_stream));
+    EXORL_TRY(set_device_float(&a->state->stddev, stddev, a->capture_stream));
+    a->dev_stddev = stddev;
     EXORL_CHECK_HIP(hipStreamSynchronize(a->capture_stream));
     const int64_t t_a = a->actor_t, t_c = a->critic_t;
     if (!a->fk.aux) {
@@ -985,6 +997,14 @@ int exorl_agent_enable_graph(exorl_agent_t* a, exorl_replay_t* r, int32_t nstep,
     a->graph = g;
     EXORL_CHECK_HIP(hipGraphInstantiate(&a->graph_exec, g, nullptr, nullptr, 0));
     a->graph_replay = r;
+    return 0;
+}
+
+int exorl_agent_noise_counter(exorl_agent_t* a, uint64_t* counter_out, void* stream) {
+    EXORL_REQUIRE(a && counter_out, "agent_noise_counter: null argument");
+    hipStream_t s = as_stream(stream);
+    EXORL_CHECK_HIP(hipMemcpyAsync(counter_out, &a->state->noise_counter, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    EXORL_CHECK_HIP(hipStreamSynchronize(s));
     return 0;
 }
 
@@ -1025,8 +1045,13 @@ int exorl_agent_disable_graph(exorl_agent_t* a) {
 }
 
 // One captured step: replay sample (Philox) + update phases 0..3, one hipGraphLaunch.
-int exorl_agent_step_graph(exorl_agent_t* a, void* stream) {
+int exorl_agent_step_graph(exorl_agent_t* a, float stddev, void* stream) {
     EXORL_REQUIRE(a && a->graph_exec, "agent_step_graph: no captured graph (call exorl_agent_enable_graph)");
+    EXORL_REQUIRE(stddev > 0.f || a->cfg.kind == EXORL_AGENT_CQL, "agent_step_graph: stddev must be > 0");
+    if (a->cfg.kind != EXORL_AGENT_CQL && stddev != a->dev_stddev) {       // schedule moved: one scalar write ahead of the launch, same stream
+        EXORL_TRY(set_device_float(&a->state->stddev, stddev, as_stream(stream)));
+        a->dev_stddev = stddev;
+    }
     EXORL_CHECK_HIP(hipGraphLaunch(a->graph_exec, as_stream(stream)));
     a->actor_t += 1;
     if (a->has_critic) a->critic_t += 1;

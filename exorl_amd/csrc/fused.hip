@@ -665,7 +665,7 @@ __global__ __launch_bounds__(256) void head_fwd4_kernel(const float* __restrict_
                     const int half = row >= sp.B, m = half ? row - sp.B : row, e = m * nout + j;
                     const float* nb = half ? sp.noise_a : sp.noise_c;
                     const float z = nb ? nb[e] : philox_normal_f(sp.seed, (uint64_t)half + (sp.counter_ptr ? *sp.counter_ptr : 0ull), (uint32_t)e);
-                    const float eps = fminf(fmaxf(z * sp.stddev, -sp.clip), sp.clip);
+                    const float eps = fminf(fmaxf(z * (sp.stddev_ptr ? *sp.stddev_ptr : sp.stddev), -sp.clip), sp.clip);
                     const float x = fminf(fmaxf(v + eps, -1.0f + 1e-6f), 1.0f - 1e-6f);
                     (half ? sp.dst_pi : sp.dst_next)[(int64_t)m * sp.dst_ld + j] = x;
                 }
@@ -763,9 +763,11 @@ __device__ __forceinline__ float dout_value(const DoutSpec& d, int net, int m, i
     const float mv = d.mu[i];
     float dmu;
     if (d.kind == EXORL_AGENT_BC) {
-        dmu = -(d.a_data[i] - mv) / (d.stddev * d.stddev) * d.inv_bg;
+        const float sd = d.stddev_ptr ? *d.stddev_ptr : d.stddev;
+        dmu = -(d.a_data[i] - mv) / (sd * sd) * d.inv_bg;
     } else if (d.kind == EXORL_AGENT_CRR) {
-        dmu = -d.w[m] * (d.a_data[i] - mv) / (d.stddev * d.stddev) * d.inv_bg;     // -(log_prob * w).mean(), crr.py:185-186
+        const float sd = d.stddev_ptr ? *d.stddev_ptr : d.stddev;
+        dmu = -d.w[m] * (d.a_data[i] - mv) / (sd * sd) * d.inv_bg;     // -(log_prob * w).mean(), crr.py:185-186
     } else {
         dmu = 0.f;
         for (int t = 0; t < d.da_nets; ++t) dmu += d.da[((int64_t)t * rows + m) * nout + j];

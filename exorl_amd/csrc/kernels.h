@@ -88,6 +88,7 @@ int outer_chunks(int rows);
 // step (rows < B -> next_action into dst_next, rows >= B -> pi(obs) sample into dst_pi), td3_bc.py:125,151 — saves the
 // separate sampling kernel. noise_* null -> Philox(seed, *counter_ptr + half).
 struct SampleSpec {
+    const float* stddev_ptr;   // device-resident exploration std (StepState::stddev); null -> the `stddev` value below
     const float *noise_c, *noise_a;
     uint64_t seed;
     const uint64_t* counter_ptr;
@@ -123,6 +124,7 @@ struct DoutSpec {
     int kind;                // EXORL_AGENT_*
     int use_lambda;
     float inv_bg, alpha, stddev;
+    const float* stddev_ptr;   // BC / CRR: device-resident std (StepState::stddev); null -> `stddev`
 };
 int head_bwd(const DoutSpec& dspec, const float* W, const float* a, float* dz, unsigned short* dz_bf16, float* P, int rows,
              int H, int nout, int nets, int64_t astride, int64_t pstride, int want_params, hipStream_t s, unsigned short* dz_lo = nullptr);
@@ -223,8 +225,11 @@ struct StepState {
     AdamConst actor, critic;
     double lr, b1, b2, eps, tau;  // the Python-float hyper-parameters torch.optim.Adam holds (dec7() of the fp32 ABI values)
     int has_critic;
+    float stddev;                // exploration std of the step (utils.schedule value): read through a pointer, so a schedule
+                                 // that moves every step needs no re-capture of the hipGraph
 };
 int step_begin(StepState* st, int advance_replay, hipStream_t s);
+int set_device_float(float* dst, float value, hipStream_t s);
 
 __host__ __device__ inline void fill_adam_const(AdamConst& c, double b1t, double b2t, double lr, double b1, double b2, double eps, double tau) {
     // double-precision scalar math, as torch's _single_tensor_adam does in Python floats; beta^t comes from a running
@@ -264,9 +269,10 @@ int prepare_inputs(const float* obs, const float* action, const float* next_obs,
 // both TruncatedNormal draws of a DDPG-family step in one launch: rows 0..B-1 of mu2 -> next_action (draw 0),
 // rows B..2B-1 -> pi(obs) sample (draw 1)
 int sample_actions2(const float* mu2, const float* noise_c, const float* noise_a, uint64_t seed, const uint64_t* counter_ptr,
-                    float stddev, float clip, float* dst_next, float* dst_pi, int64_t dst_ld, int B, int A, hipStream_t s);
+                    float stddev, float clip, float* dst_next, float* dst_pi, int64_t dst_ld, int B, int A, hipStream_t s,
+                    const float* stddev_ptr = nullptr);
 int sample_action(const float* mu, NoiseSpec noise, float stddev, float clip, int use_clip, float* dst, int64_t dst_ld,
-                  int B, int A, float* logprob_sum, hipStream_t s);
+                  int B, int A, float* logprob_sum, hipStream_t s, const float* stddev_ptr = nullptr);
 // ---- CQL (cql.py:152-263)
 struct CqlNoise {            // the five draws of one CQL update; null buffers -> Philox(seed, *counter_ptr + k)
     const float *z_next, *u_rand, *z_cur, *z_nxt, *z_actor;
@@ -297,7 +303,7 @@ int head_bwd_wide(const DoutSpec& dspec, const float* W, const float* a, float* 
 
 // CRR (crr.py:121-142): xc_rep[(b*n+i)] = [obs_b | TruncatedNormal(mu_b).sample(clip)] for i < n
 int repeat_sample(const float* obs, const float* mu, const float* noise, uint64_t seed, const uint64_t* counter_ptr, uint64_t counter,
-                  float stddev, float clip, float* xc_rep, int B, int O, int A, int n, hipStream_t s);
+                  float stddev, float clip, float* xc_rep, int B, int O, int A, int n, hipStream_t s, const float* stddev_ptr = nullptr);
 // w_b = f(min(Q1,Q2)(s_b, a_b) - mean_i min(Q1,Q2)(s_b, a_bi))
 int crr_weights(const float* q_rep, const float* q_data, float* w, int B, int n, int weight_func, hipStream_t s);
 int critic_loss(const float* q, const float* tq, const float* reward, const float* discount, float* dq,
@@ -308,7 +314,7 @@ int sf_q(const float* feat, const float* task, int64_t task_ld, float* q, int B,
 int actor_dq(const float* q, const float* stats, float* dq, int B, float inv_bg, float alpha, int use_lambda,
              hipStream_t s);
 int actor_dmu(const float* da, int64_t da_ld, int da_nets, int64_t da_net_stride, const float* mu, const float* a_data, const float* reward, const float* w, float* dpre, float* stats,
-              float* metrics, int B, int A, float inv_bg, float alpha, int kind, float stddev, hipStream_t s);
+              float* metrics, int B, int A, float inv_bg, float alpha, int kind, float stddev, hipStream_t s, const float* stddev_ptr = nullptr);
 
 // ---- optimiser (optim.hip)
 int adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
@@ -345,6 +351,8 @@ int replay_sample_impl(exorl_replay* r, int32_t batch, int32_t nstep, float gamm
                        const uint64_t* dev_counter, const StageOut* stage = nullptr);
 int replay_obs_bytes(exorl_replay* r);
 uint64_t replay_philox_counter(exorl_replay* r);
+// what a sample call does before its launch, without drawing: episode table upload, pair buffer, nstep vs the shortest episode
+int replay_prepare(exorl_replay* r, int32_t batch, int32_t nstep, hipStream_t s);
 void replay_advance_philox(exorl_replay* r, uint64_t n);
 
 }  // namespace exorl

@@ -73,11 +73,17 @@ __device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t counter, 
     return sqrtf(-2.0f * __logf(u1)) * __cosf(6.283185307179586f * u2);
 }
 
+__global__ void debug_philox_normal_kernel(uint64_t seed, uint64_t counter, int64_t n, float* __restrict__ out) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+        out[e] = philox_normal(seed, counter, (uint32_t)e);
+}
+
 // dst[m][j] = clamp(mu + clamp(noise*std, +-clip), +-(1-1e-6));  optional sum of log N(dst; mu, std)
-__global__ __launch_bounds__(1024) void sample_action_kernel(const float* __restrict__ mu, NoiseSpec noise, float stddev,
+__global__ __launch_bounds__(1024) void sample_action_kernel(const float* __restrict__ mu, NoiseSpec noise, float stddev_val,
                                                              float clip, int use_clip, float* __restrict__ dst,
                                                              int64_t dst_ld, int B, int A, float* logprob_out,
-                                                             float logprob_scale) {
+                                                             float logprob_scale, const float* stddev_ptr) {
+    const float stddev = stddev_ptr ? *stddev_ptr : stddev_val;
     __shared__ float sm[1][16];
     float lp[1] = {0.f};
     const float log_norm = -__logf(stddev) - 0.9189385332046727f;   // -log(std) - log(sqrt(2 pi))
@@ -102,9 +108,10 @@ __global__ __launch_bounds__(1024) void sample_action_kernel(const float* __rest
 
 __global__ __launch_bounds__(256) void sample_actions2_kernel(const float* __restrict__ mu2, const float* __restrict__ noise_c,
                                                               const float* __restrict__ noise_a, uint64_t seed,
-                                                              const uint64_t* __restrict__ counter_ptr, float stddev, float clip,
+                                                              const uint64_t* __restrict__ counter_ptr, float stddev_val, float clip,
                                                               float* __restrict__ dst_next, float* __restrict__ dst_pi,
-                                                              int64_t dst_ld, int B, int A) {
+                                                              int64_t dst_ld, int B, int A, const float* stddev_ptr) {
+    const float stddev = stddev_ptr ? *stddev_ptr : stddev_val;
     const int n = B * A;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n; i += gridDim.x * blockDim.x) {
         const int half = i >= n, e = half ? i - n : i;
@@ -117,9 +124,10 @@ __global__ __launch_bounds__(256) void sample_actions2_kernel(const float* __res
 }
 
 int sample_actions2(const float* mu2, const float* noise_c, const float* noise_a, uint64_t seed, const uint64_t* counter_ptr,
-                    float stddev, float clip, float* dst_next, float* dst_pi, int64_t dst_ld, int B, int A, hipStream_t s) {
+                    float stddev, float clip, float* dst_next, float* dst_pi, int64_t dst_ld, int B, int A, hipStream_t s,
+                    const float* stddev_ptr) {
     hipLaunchKernelGGL(sample_actions2_kernel, dim3(cdiv(2 * B * A, 256)), dim3(256), 0, s, mu2, noise_c, noise_a, seed, counter_ptr,
-                       stddev, clip, dst_next, dst_pi, dst_ld, B, A);
+                       stddev, clip, dst_next, dst_pi, dst_ld, B, A, stddev_ptr);
     EXORL_LAUNCH_CHECK();
     return 0;
 }
@@ -127,8 +135,9 @@ int sample_actions2(const float* mu2, const float* noise_c, const float* noise_a
 __global__ __launch_bounds__(256) void repeat_sample_kernel(const float* __restrict__ obs, const float* __restrict__ mu,
                                                             const float* __restrict__ noise, uint64_t seed,
                                                             const uint64_t* __restrict__ counter_ptr, uint64_t counter,
-                                                            float stddev, float clip, float* __restrict__ xc, int B, int O,
-                                                            int A, int n) {
+                                                            float stddev_val, float clip, float* __restrict__ xc, int B, int O,
+                                                            int A, int n, const float* stddev_ptr) {
+    const float stddev = stddev_ptr ? *stddev_ptr : stddev_val;
     const int W = O + A;
     const int64_t total = (int64_t)B * n * W;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -146,12 +155,12 @@ __global__ __launch_bounds__(256) void repeat_sample_kernel(const float* __restr
 }
 
 int repeat_sample(const float* obs, const float* mu, const float* noise, uint64_t seed, const uint64_t* counter_ptr, uint64_t counter,
-                  float stddev, float clip, float* xc_rep, int B, int O, int A, int n, hipStream_t s) {
+                  float stddev, float clip, float* xc_rep, int B, int O, int A, int n, hipStream_t s, const float* stddev_ptr) {
     const int64_t total = (int64_t)B * n * (O + A);
     int blocks = cdiv(total, 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(repeat_sample_kernel, dim3(blocks), dim3(256), 0, s, obs, mu, noise, seed, counter_ptr, counter, stddev, clip,
-                       xc_rep, B, O, A, n);
+                       xc_rep, B, O, A, n, stddev_ptr);
     EXORL_LAUNCH_CHECK();
     return 0;
 }
@@ -177,9 +186,9 @@ int crr_weights(const float* q_rep, const float* q_data, float* w, int B, int n,
 }
 
 int sample_action(const float* mu, NoiseSpec noise, float stddev, float clip, int use_clip, float* dst, int64_t dst_ld,
-                  int B, int A, float* logprob_sum, hipStream_t s) {
+                  int B, int A, float* logprob_sum, hipStream_t s, const float* stddev_ptr) {
     hipLaunchKernelGGL(sample_action_kernel, dim3(1), dim3(1024), 0, s, mu, noise, stddev, clip, use_clip, dst, dst_ld,
-                       B, A, logprob_sum, 1.0f / (float)B);
+                       B, A, logprob_sum, 1.0f / (float)B, stddev_ptr);
     EXORL_LAUNCH_CHECK();
     return 0;
 }
@@ -287,7 +296,8 @@ __global__ __launch_bounds__(1024) void actor_dmu_kernel(const float* __restrict
                                                          const float* __restrict__ reward, const float* __restrict__ w,
                                                          float* __restrict__ dpre, const float* __restrict__ stats,
                                                          float* __restrict__ metrics, int B, int A, float inv_bg,
-                                                         float alpha, int kind, float stddev) {
+                                                         float alpha, int kind, float stddev_val, const float* stddev_ptr) {
+    const float stddev = stddev_ptr ? *stddev_ptr : stddev_val;
     __shared__ float sm[2][16];
     float v[2] = {0.f, 0.f};
     if (reward)
@@ -337,11 +347,19 @@ __global__ __launch_bounds__(1024) void actor_dmu_kernel(const float* __restrict
 }
 
 int actor_dmu(const float* da, int64_t da_ld, int da_nets, int64_t da_net_stride, const float* mu, const float* a_data, const float* reward, const float* w, float* dpre, float* stats,
-              float* metrics, int B, int A, float inv_bg, float alpha, int kind, float stddev, hipStream_t s) {
+              float* metrics, int B, int A, float inv_bg, float alpha, int kind, float stddev, hipStream_t s, const float* stddev_ptr) {
     hipLaunchKernelGGL(actor_dmu_kernel, dim3(1), dim3(1024), 0, s, da, da_ld, da_nets, da_net_stride, mu, a_data, reward, w, dpre, stats, metrics, B, A,
-                       inv_bg, alpha, kind, stddev);
+                       inv_bg, alpha, kind, stddev, stddev_ptr);
     EXORL_LAUNCH_CHECK();
     return 0;
 }
 
 }  // namespace exorl
+
+extern "C" int exorl_debug_philox_normal(uint64_t seed, uint64_t counter, int64_t n, float* out_dev, void* stream) {
+    using namespace exorl;
+    EXORL_REQUIRE(out_dev && n > 0 && n <= (int64_t)1 << 31, "debug_philox_normal: bad arguments");
+    hipLaunchKernelGGL(debug_philox_normal_kernel, dim3(cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256)), dim3(256), 0, as_stream(stream), seed, counter, n, out_dev);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}

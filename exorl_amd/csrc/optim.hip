@@ -135,6 +135,17 @@ __global__ void step_begin_kernel(StepState* st, int advance_replay) {
     if (threadIdx.x == 0 && blockIdx.x == 0) step_begin_device(st, advance_replay);
 }
 
+__global__ void set_device_float_kernel(float* dst, float value) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = value;
+}
+
+// stream-ordered scalar write (kernel argument, no host buffer whose lifetime would matter)
+int set_device_float(float* dst, float value, hipStream_t s) {
+    hipLaunchKernelGGL(set_device_float_kernel, dim3(1), dim3(64), 0, s, dst, value);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
 int step_begin(StepState* st, int advance_replay, hipStream_t s) {
     hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(64), 0, s, st, advance_replay);
     EXORL_LAUNCH_CHECK();

@@ -386,6 +386,20 @@ int exorl_replay_seed_philox(exorl_replay_t* r, uint64_t seed) {
 }  // extern "C"
 
 namespace exorl {
+int replay_prepare(exorl_replay* r, int32_t batch, int32_t nstep, hipStream_t s) {
+    EXORL_REQUIRE(r && batch > 0, "replay_prepare: bad arguments");
+    EXORL_REQUIRE(!r->order.empty(), "replay_sample: no resident episodes (IndexError in random.choice, replay_buffer.py:169)");
+    EXORL_TRY(upload_table(r, s));
+    if (batch > r->pairs_cap) {
+        if (r->d_pairs) EXORL_CHECK_HIP(hipFree(r->d_pairs));
+        EXORL_CHECK_HIP(hipMalloc((void**)&r->d_pairs, (size_t)batch * 2 * sizeof(int32_t)));
+        r->pairs_cap = batch;
+    }
+    if (nstep > 0)      // Philox draws a start inside every episode: all of them must hold nstep transitions
+        EXORL_REQUIRE(r->min_len - nstep + 1 >= 1, "replay_sample: shortest episode (%d) shorter than nstep=%d", r->min_len, nstep);
+    return 0;
+}
+
 // dev_counter != nullptr: Philox batch counter is read from device memory (graph-replayable); the host copy is
 // still advanced so eager sampling continues the stream afterwards.
 int replay_sample_impl(exorl_replay* r, int32_t batch, int32_t nstep, float gamma, int32_t sampler,
@@ -398,13 +412,7 @@ int replay_sample_impl(exorl_replay* r, int32_t batch, int32_t nstep, float gamm
     EXORL_REQUIRE(out->obs && out->action && out->reward && out->discount && out->next_obs, "replay_sample: null output");
     EXORL_REQUIRE((r->cfg.meta_dim > 0) || out->meta == nullptr, "replay_sample: meta output without meta columns");
     const int n = (int)r->order.size();
-    EXORL_REQUIRE(n > 0, "replay_sample: no resident episodes (IndexError in random.choice, replay_buffer.py:169)");
-    EXORL_TRY(upload_table(r, s));
-    if (batch > r->pairs_cap) {
-        if (r->d_pairs) EXORL_CHECK_HIP(hipFree(r->d_pairs));
-        EXORL_CHECK_HIP(hipMalloc((void**)&r->d_pairs, (size_t)batch * 2 * sizeof(int32_t)));
-        r->pairs_cap = batch;
-    }
+    EXORL_TRY(replay_prepare(r, batch, sampler == EXORL_SAMPLER_PHILOX ? nstep : 0, s));
     if (sampler == EXORL_SAMPLER_MT19937 || sampler == EXORL_SAMPLER_GIVEN) {
         r->h_pairs.resize((size_t)batch * 2);
         if (sampler == EXORL_SAMPLER_MT19937) {
@@ -431,9 +439,7 @@ int replay_sample_impl(exorl_replay* r, int32_t batch, int32_t nstep, float gamm
         }
         EXORL_CHECK_HIP(hipMemcpyAsync(r->d_pairs, r->h_pairs.data(), (size_t)batch * 2 * sizeof(int32_t), hipMemcpyHostToDevice, s));
         if (pairs_out_host) memcpy(pairs_out_host, r->h_pairs.data(), (size_t)batch * 2 * sizeof(int32_t));
-    } else if (sampler == EXORL_SAMPLER_PHILOX) {
-        EXORL_REQUIRE(r->min_len - nstep + 1 >= 1, "replay_sample: shortest episode (%d) shorter than nstep=%d", r->min_len, nstep);
-    } else {
+    } else if (sampler != EXORL_SAMPLER_PHILOX) {
         set_error("replay_sample: unknown sampler %d", sampler);
         return 2;
     }

@@ -135,13 +135,27 @@ class AgentEngine:
         return out
 
     def enable_graph(self, replay_engine, nstep, gamma, stddev):
-        L.check(self.lib.exorl_agent_enable_graph(self.h, replay_engine.h, nstep, gamma, stddev))
+        L.check(self.lib.exorl_agent_enable_graph(self.h, replay_engine.h, nstep, gamma, stddev, L.current_stream()))
+        self.graph_captures = getattr(self, 'graph_captures', 0) + 1
 
     def disable_graph(self):
         L.check(self.lib.exorl_agent_disable_graph(self.h))
 
-    def step_graph(self):
-        L.check(self.lib.exorl_agent_step_graph(self.h, L.current_stream()))
+    def step_graph(self, stddev):
+        L.check(self.lib.exorl_agent_step_graph(self.h, stddev, L.current_stream()))
+
+    def noise_counter(self):
+        """Philox draw counter of the update noise AFTER the steps enqueued so far (synchronises): step k of a DDPG-family agent
+        drew its critic-target noise at counter 2k+2 and its actor noise at 2k+3 (the counter is advanced at the step's start)."""
+        c = C.c_uint64()
+        L.check(self.lib.exorl_agent_noise_counter(self.h, C.byref(c), L.current_stream()))
+        return int(c.value)
+
+    def philox_normal(self, seed, counter, shape):
+        """The standard-normal block the update kernels draw for (seed, counter): element e = row * A + column (test hook)."""
+        out = torch.empty(tuple(shape), dtype=torch.float32, device=self.device)
+        L.check(self.lib.exorl_debug_philox_normal(seed, counter, out.numel(), out.data_ptr(), L.current_stream()))
+        return out
 
     def set_parallel_branches(self, enable):
         L.check(self.lib.exorl_agent_set_parallel_branches(self.h, int(bool(enable))))
@@ -468,6 +482,12 @@ class ReplayEngine:
 
     def evict(self, slot):
         L.check(self.lib.exorl_replay_evict(self.h, slot))
+
+    def num_rows(self):
+        """(live rows, used rows) of the arena; a row is one time-step, an episode holds len+1."""
+        live, used = C.c_int64(), C.c_int64()
+        L.check(self.lib.exorl_replay_num_rows(self.h, C.byref(live), C.byref(used)))
+        return live.value, used.value
 
     def set_order(self, slots):
         arr = np.ascontiguousarray(slots, np.int32)

@@ -207,13 +207,74 @@ class _Shard:
         self.dir_stamp = os.stat(d).st_mtime_ns
 
 
+def relabel_episode(env, episode):
+    """Rewards recomputed from the stored simulator states under `env`'s task (replay_buffer.py:31-42): ExORL datasets are
+    collected reward-free and labelled for the task at load time. `env` is a dm_control-style environment (physics.reset_context /
+    set_state, task.get_reward, reward_spec); there is no MuJoCo in this repo, the call is host glue around the caller's env."""
+    if 'physics' not in episode:
+        raise KeyError("relabel_episode: the episode has no 'physics' states to replay (pass env=None / relabel=False to keep "
+                       "the stored rewards)")
+    spec = env.reward_spec()
+    out = np.empty((len(episode['physics']),) + tuple(spec.shape), spec.dtype)
+    for i, state in enumerate(episode['physics']):
+        with env.physics.reset_context():
+            env.physics.set_state(state)
+        out[i] = env.task.get_reward(env.physics)
+    episode = dict(episode)
+    episode['reward'] = out
+    return episode
+
+
+class _OfflineShard(_Shard):
+    """One worker of OfflineReplayBuffer (replay_buffer.py:45-100): a single ASCENDING scan when the first sample is asked for,
+    episodes taken until the running size exceeds max_size (:62-63 — checked before each file, so the last one overshoots),
+    worker modulo (:65-66), rewards relabelled when an env is given, nothing evicted, re-scanned or deleted. The arena is sized
+    from the selected files (lengths are in the names), not from max_size."""
+
+    @staticmethod
+    def select(replay_dir, max_size, num_workers, worker_id):
+        """The files `_load` keeps (replay_buffer.py:58-75) and their total length, from the names alone."""
+        todo, size = [], 0
+        for fn in sorted(Path(replay_dir).glob('*.npz')):
+            if size > max_size:
+                break
+            idx, n = (int(x) for x in fn.stem.split('_')[1:])
+            if idx % num_workers != worker_id:
+                continue
+            todo.append(fn)
+            size += n
+        return todo, size
+
+    def try_fetch(self):
+        if self.engine is not None or self.since_fetch < 0:
+            return
+        ld = self.loader
+        todo, size = self.select(ld.storage._replay_dir, ld.max_size, ld.num_workers, self.worker_id)
+        if not todo:
+            return
+        ld.max_episodes, ld.capacity_rows = len(todo) + 8, size + len(todo) + 64
+        for fn, episode in zip(todo, _load_many(todo, ld.load_threads)):
+            if episode is None:
+                raise IOError(f'offline dataset: cannot read {fn}')
+            if ld.relabel:
+                episode = relabel_episode(ld.env, episode)
+            self._ensure_engine(episode)
+            self.slot[fn] = self.engine.append_episode(episode, ld.meta_keys)
+            self.length[fn] = episode_len(episode)
+            self.fns.append(fn)
+            self.size += self.length[fn]
+        self.engine.set_order([self.slot[f] for f in self.fns])
+        self.since_fetch = -(1 << 62)            # loaded once (replay_buffer.py:78-80)
+
+
 class DeviceReplayLoader:
     """What make_replay_loader returns: iterable whose iterator yields device-resident minibatches."""
 
     def __init__(self, storage, max_size, batch_size, num_workers, save_snapshot, nstep, discount, fetch_every=1000,
                  device='cuda', sampler='mt19937', seed=None, worker_ids=None, max_episodes=None, capacity_rows=None, static=False,
-                 load_threads=None):
+                 load_threads=None, offline=False, env=None, relabel=False):
         self.storage = storage
+        self.offline, self.env, self.relabel = offline, env, relabel      # OfflineReplayBuffer semantics (see _OfflineShard)
         self.static = static                # the directory will not change (offline datasets): load once, never re-scan
         self.num_workers = max(1, num_workers)
         self.max_size = max_size // self.num_workers          # replay_buffer.py:262
@@ -239,7 +300,7 @@ class DeviceReplayLoader:
 class DeviceReplayIterator:
     def __init__(self, loader):
         self.loader = loader
-        self.shards = [_Shard(loader, w) for w in loader.worker_ids]
+        self.shards = [(_OfflineShard if loader.offline else _Shard)(loader, w) for w in loader.worker_ids]
         self.turn = 0
         self._seeded = False
         # what agent.enable_graph reads; .engine is only set for a static single-shard dataset (see static_engine)
@@ -374,8 +435,14 @@ class _DirStorage:
         self._meta_specs = tuple(meta_specs)
 
 
-def make_offline_replay_loader(env, replay_dir, max_size, batch_size, num_workers, discount, **kw):
-    """replay_buffer.py:246-258 (OfflineReplayBuffer semantics: nstep=1, files kept on disk). Reward
-    re-labelling through MuJoCo physics (relabel_episode, :31-42) is the caller's concern and out of scope."""
-    kw.setdefault('static', True)
-    return DeviceReplayLoader(_DirStorage(replay_dir), max_size, batch_size, num_workers, True, 1, discount, **kw)
+def make_offline_replay_loader(env, replay_dir, max_size, batch_size, num_workers, discount, relabel=None, **kw):
+    """replay_buffer.py:246-258 with OfflineReplayBuffer's semantics (:45-100): ascending one-shot load up to the first episode
+    that takes the size past max_size // workers, nstep = 1, files never touched. relabel=None follows the reference's intent —
+    rewards are relabelled through `env` (relabel_episode, :31-42) whenever an env is given; pass relabel=False (or env=None) to
+    train on the stored rewards. The reference's own class fails before loading anything (`_relable_reward` typo, :72 vs :84)."""
+    if relabel is None:
+        relabel = env is not None
+    if relabel and env is None:
+        raise ValueError('make_offline_replay_loader: relabel=True needs the env whose task defines the reward')
+    return DeviceReplayLoader(_DirStorage(replay_dir), max_size, batch_size, num_workers, True, 1, discount, static=True, offline=True,
+                              env=env, relabel=bool(relabel), **kw)

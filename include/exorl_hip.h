@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EXORL_ABI_VERSION 5
+#define EXORL_ABI_VERSION 6
 
 const char* exorl_last_error(void);
 int exorl_abi_version(void);
@@ -218,11 +218,18 @@ int exorl_agent_set_parallel_branches(exorl_agent_t* a, int32_t enable);
 int exorl_agent_opt_steps(exorl_agent_t* a, int64_t* actor_steps, int64_t* critic_steps);
 int exorl_agent_set_opt_steps(exorl_agent_t* a, int64_t actor_steps, int64_t critic_steps);
 /* Captures exorl_replay_sample(PHILOX) into the agent's batch slots + exorl_agent_update into one hipGraph;
- * exorl_agent_step_graph replays it (all per-step counters and Adam scalars live in device memory).
- * The stream passed to step_graph must not be the one used by other un-synchronised work on the same buffers. */
-int exorl_agent_enable_graph(exorl_agent_t* a, exorl_replay_t* r, int32_t nstep, float gamma, float stddev);
-int exorl_agent_step_graph(exorl_agent_t* a, void* stream);
+ * exorl_agent_step_graph replays it (all per-step counters, Adam scalars and the exploration std live in device memory, so a
+ * stddev schedule — utils.schedule, td3_bc.py:169 — that moves every step costs one scalar write, not a re-capture).
+ * enable_graph synchronises `stream` (the caller's stream, where earlier steps may still run) before touching anything and does not
+ * consume a Philox batch. step_graph launches on `stream`; stddev is the schedule's value for this step. */
+int exorl_agent_enable_graph(exorl_agent_t* a, exorl_replay_t* r, int32_t nstep, float gamma, float stddev, void* stream);
+int exorl_agent_step_graph(exorl_agent_t* a, float stddev, void* stream);
 int exorl_agent_disable_graph(exorl_agent_t* a);
+/* Test hooks for the device-side noise stream (synchronous): the Philox draw counter after the steps enqueued so far, and the
+ * standard-normal block the update kernels generate for (seed, counter) — out[e], e = row * act_dim + column. With these a test
+ * can replay a captured-graph trajectory (device sampler + device noise) through the CPU oracle. */
+int exorl_agent_noise_counter(exorl_agent_t* a, uint64_t* counter_out, void* stream);
+int exorl_debug_philox_normal(uint64_t seed, uint64_t counter, int64_t n, float* out_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Stand-alone operators (used by the agents above; exported for tests and for callers' own nets)

@@ -91,6 +91,63 @@ class OracleReplay:
         return draws, tuple(np.stack([c[j] for c in cols]) for j in range(len(cols[0])))
 
 
+def relabel_episode(env, ep):
+    """replay_buffer.py:31-42: reward[i] = task.get_reward(physics at stored state i), cast to the env's reward spec."""
+    spec = env.reward_spec()
+    rewards = []
+    for st in ep['physics']:
+        with env.physics.reset_context():
+            env.physics.set_state(st)
+        rewards.append(np.full(spec.shape, env.task.get_reward(env.physics), spec.dtype))
+    out = dict(ep)
+    out['reward'] = np.array(rewards, dtype=spec.dtype)
+    return out
+
+
+class OracleOfflineReplay:
+    """OfflineReplayBuffer (replay_buffer.py:45-100): one ascending scan of the directory at the first sample, stop once the running
+    size EXCEEDS max_size (:62-63, so the last episode loaded overshoots), worker modulo (:65-66), optional reward relabelling,
+    nothing evicted or deleted; samples are nstep=1 (:84-96). The shipped class cannot get past `_load` (it calls
+    `_relable_reward`, the method is `_relabel_reward`); this restates the evident intent, pinned by replay_offline_*.npz."""
+
+    def __init__(self, env, max_size, num_workers, discount, worker_id=0, relabel=True):
+        self.env, self.max_size, self.num_workers, self.discount = env, max_size, max(1, num_workers), discount
+        self.worker_id, self.relabel = worker_id, relabel
+        self.size, self.fns, self.episodes, self.loaded = 0, [], {}, False
+        self.py_rng = self.np_rng = None
+
+    def seed(self, py_seed, np_seed):
+        self.py_rng = MT19937.python_seed(py_seed)
+        self.np_rng = MT19937.numpy_seed(np_seed)
+
+    def load(self, directory):
+        for name in sorted(directory.keys()):
+            if self.size > self.max_size:
+                break
+            idx, _ = [int(x) for x in name[:-4].split('_')[1:]]
+            if idx % self.num_workers != self.worker_id:
+                continue
+            ep = directory[name]
+            if self.relabel:
+                ep = relabel_episode(self.env, ep)
+            self.fns.append(name)
+            self.episodes[name] = ep
+            self.size += episode_len(ep)
+        self.loaded = True
+
+    def draw(self, directory):
+        if not self.loaded:
+            self.load(directory)
+        name = self.fns[self.py_rng.py_randbelow(len(self.fns))]
+        idx = self.np_rng.np_randint0(episode_len(self.episodes[name])) + 1
+        return name, idx
+
+    def sample_batch(self, directory, batch):
+        draws = [self.draw(directory) for _ in range(batch)]
+        cols = [gather_nstep(self.episodes[n], i, 1, self.discount) for n, i in draws]
+        return draws, tuple(np.stack([c[j] for c in cols]) for j in range(5))
+
+
 def gather_nstep(ep, idx, nstep, gamma, meta_keys=()):
     """replay_buffer.py:223-235. fp32, products and sums rounded separately (no FMA)."""
     obs = ep['observation'][idx - 1]

@@ -1,0 +1,90 @@
+"""One data-parallel rank of the product path, run as a fresh child process (tests/test_gpu_dp.py starts two of them before the
+parent touches the GPU; bench.py --gpus N does the same with its own children). Every rank sits on cuda:0 and talks gloo, so the
+multi-process branch of exorl_amd.agents (_run_update's phase split + torch.distributed.all_reduce, _metrics' all-reduce,
+make_replay_loader(..., worker_ids=[rank])) executes for real on a one-GPU box."""
+import json
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / 'tests'))
+
+O, A, H, B_GLOBAL, STEPS = 24, 6, 128, 128, 3
+
+
+def write_dataset(path):
+    import _synth
+    from exorl_amd.replay_buffer import ReplayBufferStorage
+    st = ReplayBufferStorage((), (), Path(path))
+    for ep in _synth.synth_episodes(4, [50, 60, 70, 40, 55, 65], O, A):
+        st._store_episode(ep)
+    return st
+
+
+def build_agent(kind, precision, batch, use_tb):
+    import _synth
+    from exorl_amd import agents
+    from oracle.agents import param_shapes
+    if kind == 'td3_bc':
+        ag = agents.TD3BCAgent('td3_bc', (O,), (A,), 'cuda:0', 1e-4, H, 0.01, '0.2', 1, batch, 0.3, use_tb, 2.5, precision=precision)
+    elif kind == 'cql':
+        ag = agents.CQLAgent('cql', (O,), (A,), 'cuda:0', 1e-4, H, 0.01, 1, batch, use_tb, 0.01, 3, 5.0, False, precision=precision)
+    else:
+        ag = agents.BCAgent('bc', (O,), (A,), 'cuda:0', 1e-4, H, batch, '0.2', use_tb, precision=precision)
+    ash, csh = param_shapes(kind, O, A, H)
+    ag.actor.load_state_dict({k: torch.from_numpy(v) for k, v in _synth.synth_params(ash, 1).items()})
+    if csh:
+        ag.critic.load_state_dict({k: torch.from_numpy(v) for k, v in _synth.synth_params(csh, 2).items()})
+        ag.critic_target.load_state_dict(ag.critic.state_dict())
+    return ag
+
+
+def noise_rows(kind, seed, step_rows):
+    """Global noise draws of one step, as (critic, actor) blocks over the GLOBAL batch; a rank uses its row slice."""
+    import _synth
+    return _synth.NoiseStream(seed)
+
+
+def main():
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    data_dir, out_dir = Path(sys.argv[1]), Path(sys.argv[2])
+    dist.init_process_group('gloo', init_method=f"tcp://127.0.0.1:{os.environ['MASTER_PORT']}", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import _synth
+    from exorl_amd.replay_buffer import ReplayBufferStorage, make_replay_loader
+    result = {}
+    Br = B_GLOBAL // world
+    for kind, precision in (('td3_bc', 'fp32'), ('td3_bc', 'bf16x3'), ('bc', 'fp32')):
+        ag = build_agent(kind, precision, Br, True)
+        assert ag.world_size == world
+        st = ReplayBufferStorage((), (), data_dir)               # the directory the parent wrote
+        it = iter(make_replay_loader(st, 10**6, Br, world, True, 1, 0.99, worker_ids=[rank], seed=77))
+        ns = _synth.NoiseStream(9)
+        sl = slice(rank * Br, (rank + 1) * Br)
+        draws = []
+        ag.noise_hook = lambda shape: draws.pop(0)
+        metrics = []
+        for step in range(STEPS):
+            draws[:] = [ns.draw((B_GLOBAL, A))[sl], ns.draw((B_GLOBAL, A))[sl]]
+            m = ag.update(it, step)
+            metrics.append({k: float(v) for k, v in m.items()})
+        torch.cuda.synchronize()
+        tag = f'{kind}_{precision}'
+        nets = [('actor', ag.actor)] + ([('critic', ag.critic), ('critic_target', ag.critic_target)] if hasattr(ag, 'critic') else [])
+        np.savez(out_dir / f'{tag}_rank{rank}.npz', **{n: torch.cat([p.reshape(-1) for p in net.parameters()]).cpu().numpy() for n, net in nets})
+        result[tag] = metrics
+        del ag, it
+    json.dump(result, open(out_dir / f'metrics_rank{rank}.json', 'w'))
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f'rank {rank} done')
+
+
+if __name__ == '__main__':
+    main()

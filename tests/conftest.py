@@ -17,3 +17,31 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def gold():
     return GOLD
+
+
+def pytest_collection_finish(session):
+    """tests/test_gpu_dp.py needs two FRESH processes that share cuda:0 with this one. They are started here — after collection,
+    before any test (hence before this process has made a single HIP call) — and joined by the test's fixture."""
+    if not any('test_gpu_dp' in item.nodeid for item in session.items):
+        return
+    import torch
+    if torch.cuda.device_count() < 1:          # counting devices does not initialise the GPU
+        return
+    import socket
+    import subprocess
+    import tempfile
+    tmp = Path(tempfile.mkdtemp(prefix='exorl_dp_'))
+    data, out = tmp / 'buffer', tmp / 'out'
+    out.mkdir()
+    import _dp_worker
+    _dp_worker.write_dataset(data)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        log = tmp / f'rank{rank}.log'
+        procs.append((subprocess.Popen([sys.executable, str(ROOT / 'tests' / '_dp_worker.py'), str(data), str(out)], env=env,
+                                       stdout=open(log, 'w'), stderr=subprocess.STDOUT), log))
+    session.config._dp_children = {'procs': procs, 'out': out, 'data': data}

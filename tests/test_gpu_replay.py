@@ -50,6 +50,46 @@ def test_golden_batches_bit_exact(gold, tmp_path, name):
     assert resident == list(z['resident'])
 
 
+@pytest.mark.parametrize('name', ['offline_a', 'offline_b_cap', 'offline_c_relabel'])
+def test_offline_loader_golden_batches_bit_exact(gold, tmp_path, name):
+    """The 6-argument offline call shape (train_offline.py:90-93) -> OfflineReplayBuffer semantics (replay_buffer.py:45-100):
+    ascending one-shot load with the `size > max_size` stop, relabelled rewards, nstep=1 samples — the reference's own batches,
+    bit for bit; and the dataset directory is left exactly as it was."""
+    from exorl_amd.replay_buffer import make_replay_loader, save_episode
+    from test_oracle_replay import FakeEnv, offline_episodes
+    z = np.load(gold / f'replay_{name}.npz')
+    O, A, P, max_size, B, NB, seed, relabel = [int(x) for x in z['dims']]
+    eps, lengths = offline_episodes(z)
+    d = tmp_path / 'buffer'
+    d.mkdir()
+    for i, ep in enumerate(eps):
+        save_episode(ep, d / f'episode_{i}_{lengths[i]}.npz')
+    before = sorted((p.name, p.stat().st_size) for p in d.glob('*.npz'))
+    loader = make_replay_loader(FakeEnv(), d, max_size, B, 0, 0.99, relabel=bool(relabel), sampler='mt19937')
+    random.seed(seed)
+    np.random.seed(seed)
+    it = iter(loader)
+    for bi in range(NB):
+        batch = next(it)
+        assert len(batch) == 5
+        for ti, t in enumerate(batch):
+            ref = z[f'batch{bi}_{ti}']
+            got = t.cpu().numpy()
+            assert got.dtype == ref.dtype and got.shape == ref.shape, (name, bi, ti, got.shape, ref.shape)
+            assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), (name, bi, ti)
+    sh = it.shards[0]
+    assert [int(fn.stem.split('_')[1]) for fn in sh.fns] == list(z['resident']) and sh.size == int(z['size'])
+    assert sorted((p.name, p.stat().st_size) for p in d.glob('*.npz')) == before           # nothing evicted, unlinked or rewritten
+    live = sh.engine.num_rows()[0]
+    assert live == sh.size + len(sh.fns)                                                   # arena sized from the data, not max_size
+
+
+def test_offline_loader_needs_env_for_relabel(tmp_path):
+    from exorl_amd.replay_buffer import make_offline_replay_loader
+    with pytest.raises(ValueError, match='relabel=True needs the env'):
+        make_offline_replay_loader(None, tmp_path, 100, 4, 0, 0.99, relabel=True)
+
+
 def test_index_stream_equals_reference_recording(gold, tmp_path):
     from exorl_amd.engine import ReplayEngine
     from exorl_amd import _lib as L

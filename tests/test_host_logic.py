@@ -28,7 +28,8 @@ def test_library_exports_every_declared_symbol():
         assert s in _lib.PROTOTYPES, f'{s} has no ctypes prototype'
     assert set(_lib.PROTOTYPES) == set(syms)
     lib.exorl_abi_version.restype = ctypes.c_int
-    assert lib.exorl_abi_version() == 5
+    version = int(re.search(r'#define EXORL_ABI_VERSION (\d+)', (ROOT / 'include' / 'exorl_hip.h').read_text()).group(1))
+    assert lib.exorl_abi_version() == version
 
 
 def test_product_fails_loudly_without_gpu():
@@ -191,3 +192,20 @@ def test_parallel_episode_decode_keeps_order_and_stops_at_broken_file(tmp_path):
         got = list(rb._load_many(fns, threads))
         assert [None if e is None else int(e['observation'][0, 0]) for e in got] == [0, 1, 2, 3, 4, 5, 6, None, 8, 9, 10, 11]
         assert all(rb.episode_len(e) == 4 + i for i, e in enumerate(got) if e is not None)
+
+
+def test_offline_file_selection_rule(tmp_path):
+    """OfflineReplayBuffer._load's selection (replay_buffer.py:58-75) from file names alone: ascending lexicographic order, stop once
+    the running size EXCEEDS max_size, per-worker modulo. A dataset larger than max_size keeps its FIRST episodes (the online buffer's
+    reverse scan would keep the last ones)."""
+    from exorl_amd.replay_buffer import _OfflineShard
+    lengths = [7, 3, 12, 5, 9, 4, 3, 15, 6, 8, 10, 3, 11]
+    for i, n in enumerate(lengths):
+        (tmp_path / f'episode_{i}_{n}.npz').write_bytes(b'')
+    idx = lambda fns: [int(f.stem.split('_')[1]) for f in fns]
+    todo, size = _OfflineShard.select(tmp_path, 40, 1, 0)
+    assert idx(todo) == [0, 10, 11, 12, 1, 2] and size == 46            # == tests/golden/replay_offline_b_cap.npz 'resident'
+    todo, size = _OfflineShard.select(tmp_path, 10**6, 1, 0)
+    assert idx(todo) == [0, 10, 11, 12, 1, 2, 3, 4, 5, 6, 7, 8, 9] and size == sum(lengths)
+    todo, size = _OfflineShard.select(tmp_path, 20, 2, 1)                 # worker 1 of 2: odd episode indices only
+    assert idx(todo) == [11, 1, 3, 5, 7] and size == 3 + 3 + 5 + 4 + 15   # 15 <= 20 after four files, so a fifth is taken

@@ -4,6 +4,7 @@ import json
 
 import numpy as np
 import pytest
+import torch
 
 import _synth
 from oracle import nets, knn
@@ -146,3 +147,24 @@ def test_cql_tiny_trajectory(gold, variant):
         np.testing.assert_allclose(t, z[f'final/critic_target/{k}'], rtol=1e-4, atol=2e-6, err_msg=k)
     np.testing.assert_allclose(ag.log_actor_alpha[0], z['final/log_actor_alpha'], rtol=1e-5, atol=1e-8)
     np.testing.assert_allclose(ag.log_critic_alpha[0], z['final/log_critic_alpha'], rtol=1e-5, atol=1e-8)
+
+
+def test_torch_twin_matches_reference_trajectory(gold):
+    """bench.py's cpu_baseline times oracle/torch_twin.py (nn.Linear / LayerNorm / Adam, the library ops the reference uses). It must BE
+    the reference's update: the reference's own recorded TD3+BC trajectory at BASELINE dims, first 3 steps, every metric to 2e-5
+    (same torch, same op order -> differences are thread-count summation order only), and its fp64 twin against the fp64 recording."""
+    import json
+    from oracle.torch_twin import TorchTwinTD3BC
+    g = json.load(open(gold / 'full_td3_bc.json'))
+    O, A, H, B = g['dims']
+    ash, csh = param_shapes('td3_bc', O, A, H)
+    torch.set_num_threads(min(8, torch.get_num_threads()))
+    for tag, dt, tol in (('fp32', torch.float32, 6e-5), ('fp64', torch.float64, 1e-9)):
+        tw = TorchTwinTD3BC(O, A, H, dtype=dt)
+        tw.load(list(_synth.synth_params(ash, g['param_seed']).values()), list(_synth.synth_params(csh, g['param_seed'] + 1).values()))
+        ns = _synth.NoiseStream(g['noise_seed'])
+        for i in range(3):
+            m = tw.update(_synth.synth_batch(g['batch_seed'], i, B, O, A), ns.draw((B, A)), ns.draw((B, A)))
+            for k, v in m.items():
+                want = g[tag]['metrics'][i][k]
+                assert abs(v - want) <= tol * abs(want) + tol * 1e-2, (tag, i, k, v, want)

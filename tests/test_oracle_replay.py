@@ -56,6 +56,67 @@ def test_replay_golden(gold, name):
     assert [int(n.split('_')[1]) for n in rb.fns] == list(z['resident'])
 
 
+class FakeEnv:
+    """The stand-in tools/gen_golden.py handed to the reference's relabel_episode (replay_buffer.py:31-42)."""
+
+    class _Physics:
+        def reset_context(self):
+            import contextlib
+            return contextlib.nullcontext()
+
+        def set_state(self, s):
+            self.state = np.array(s, np.float64)
+
+    class _Task:
+        def get_reward(self, physics):
+            return float(np.tanh(physics.state).sum() * 0.25)
+
+    class _Spec:
+        shape, dtype = (1,), np.dtype(np.float32)
+
+    def __init__(self):
+        self.physics, self.task = self._Physics(), self._Task()
+
+    def reward_spec(self):
+        return self._Spec()
+
+
+def offline_episodes(z):
+    O, A, P, max_size, B, NB, seed, relabel = [int(x) for x in z['dims']]
+    lengths = [int(x) for x in z['lengths']]
+    eps = _synth.synth_episodes(seed, lengths, O, A)
+    rs = np.random.RandomState(100 + seed)
+    for ep in eps:
+        ep['physics'] = rs.standard_normal((ep['observation'].shape[0], P))
+    return eps, lengths
+
+
+OFFLINE = ['offline_a', 'offline_b_cap', 'offline_c_relabel']
+
+
+@pytest.mark.parametrize('name', OFFLINE)
+def test_offline_replay_golden(gold, name):
+    """OfflineReplayBuffer semantics (replay_buffer.py:45-100) against the reference's own batches: ascending load with the
+    `size > max_size` stop, nstep=1 samples, relabelled rewards."""
+    from oracle.replay import OracleOfflineReplay
+    z = np.load(gold / f'replay_{name}.npz')
+    O, A, P, max_size, B, NB, seed, relabel = [int(x) for x in z['dims']]
+    eps, lengths = offline_episodes(z)
+    directory = {episode_name(i, L): ep for i, (L, ep) in enumerate(zip(lengths, eps))}
+    rb = OracleOfflineReplay(FakeEnv(), max_size, 0, 0.99, relabel=bool(relabel))
+    rb.seed(seed, seed)
+    for bi in range(NB):
+        _, batch = rb.sample_batch(directory, B)
+        for ti, t in enumerate(batch):
+            ref = z[f'batch{bi}_{ti}']
+            assert t.dtype == ref.dtype and t.shape == ref.shape, (t.dtype, ref.dtype, t.shape, ref.shape)
+            assert np.array_equal(t.view(np.uint8), ref.view(np.uint8)), (name, bi, ti)
+    assert [int(n.split('_')[1]) for n in rb.fns] == list(z['resident']) and rb.size == int(z['size'])
+    if relabel:
+        for i in z['resident']:
+            assert np.array_equal(rb.episodes[episode_name(int(i), lengths[int(i)])]['reward'], z[f'reward{int(i)}'])
+
+
 def test_flat_arena_gather_equals_episode_gather():
     lengths = [7, 3, 12, 5]
     eps = _synth.synth_episodes(1, lengths, 5, 2, 2)

@@ -91,6 +91,80 @@ def gen_replay(ref):
         print('replay', name, 'resident', resident, 'first picks', picks[:5], starts[:5])
 
 
+# ----------------------------------------------------------------------------- offline replay (R5)
+class _FakePhysics:
+    """Stands where dm_control's Physics stands in relabel_episode (replay_buffer.py:31-42): holds the state it was given."""
+
+    def __init__(self):
+        self.state = None
+
+    def reset_context(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def set_state(self, s):
+        self.state = np.array(s, np.float64)
+
+
+class _FakeTask:
+    def get_reward(self, physics):           # any deterministic function of the physics state
+        return float(np.tanh(physics.state).sum() * 0.25)
+
+
+class FakeEnv:
+    def __init__(self, ref):
+        self.physics, self.task, self._ref = _FakePhysics(), _FakeTask(), ref
+
+    def reward_spec(self):
+        return self._ref.Array((1,), np.float32, 'reward')
+
+
+def gen_offline(ref):
+    """OfflineReplayBuffer (replay_buffer.py:45-100) through make_offline_replay_loader (:246-258), num_workers=0.
+    As shipped the class cannot load (`_load` calls self._relable_reward, the method is named _relabel_reward), so:
+      a/b: `_load(relable=False)` is called explicitly (the method's own parameter), then the loader is iterated;
+      c:   the instance gets the missing alias (`_relable_reward = _relabel_reward`) and runs its default path with a fake env.
+    No reference file is modified."""
+    rb = ref.rb
+    lengths = [7, 3, 12, 5, 9, 4, 3, 15, 6, 8, 10, 3, 11]
+    scenarios = {'offline_a': (10**6, 3, False), 'offline_b_cap': (40, 4, False), 'offline_c_relabel': (10**6, 5, True)}
+    for name, (max_size, seed, relabel) in scenarios.items():
+        O, A, B, NB, P = 5, 2, 16, 4, 3
+        eps = _synth.synth_episodes(seed, lengths, O, A)
+        rs = np.random.RandomState(100 + seed)
+        for ep in eps:
+            ep['physics'] = rs.standard_normal((ep['observation'].shape[0], P))
+        with tempfile.TemporaryDirectory() as td:
+            d = Path(td) / 'buffer'
+            d.mkdir()
+            for i, ep in enumerate(eps):
+                rb.save_episode(ep, d / f'episode_{i}_{ep["observation"].shape[0] - 1}.npz')
+            env = FakeEnv(ref)
+            loader = rb.make_offline_replay_loader(env, d, max_size, B, 0, 0.99)
+            ds = loader.dataset
+            if relabel:
+                ds._relable_reward = ds._relabel_reward
+            else:
+                ds._load(relable=False)
+                ds._loaded = True
+            random.seed(seed)
+            np.random.seed(seed)
+            it = iter(loader)
+            batches = [next(it) for _ in range(NB)]
+            resident = [int(fn.stem.split('_')[1]) for fn in ds._episode_fns]
+            out = dict(lengths=np.array(lengths), dims=np.array([O, A, P, max_size, B, NB, seed, int(relabel)]),
+                       resident=np.array(resident, np.int64), size=np.array(ds._size))
+            if relabel:
+                for i in resident:
+                    out[f'reward{i}'] = ds._episodes[d / f'episode_{i}_{lengths[i]}.npz']['reward']
+            for bi, b in enumerate(batches):
+                for ti, t in enumerate(b):
+                    out[f'batch{bi}_{ti}'] = t.numpy()
+            assert sorted(p.name for p in d.glob('*.npz')) == sorted(f'episode_{i}_{n}.npz' for i, n in enumerate(lengths))   # nothing deleted
+        np.savez_compressed(GOLD / f'replay_{name}.npz', **out)
+        print('offline', name, 'resident', resident, 'size', ds._size)
+
+
 # ----------------------------------------------------------------------------- utils (G2)
 def gen_utils(ref):
     U = ref.utils
@@ -542,15 +616,30 @@ FULL = {  # kind: (O, A, H, B)  — BASELINE.json configs (walker / cheetah shap
     'ddpg': (24, 6, 1024, 1024),
     'crr': (24, 6, 1024, 1024),
     'cql': (78, 12, 1024, 1024),         # quadruped shapes, BASELINE.json configs[2]
+    'td3_b4096': (17, 6, 1024, 4096),    # cheetah shapes at the global batch of BASELINE.json configs[4]
 }
+FULL_STEPS = {'td3_b4096': 5}
+SAMPLE_STRIDE = 997                      # every 997th element of each net's flat parameters is stored (final values)
+
+
+def param_sample(agent):
+    """Final parameters at a fixed stride: lets a test compare parameter *deltas* element by element (the update direction and
+    size, not just norms) without shipping 13 MB of weights."""
+    out = {}
+    for nm, net in nets_of(agent):
+        flat = torch.cat([p.detach().double().reshape(-1) for p in net.parameters()])
+        out[nm] = [float(x) for x in flat[::SAMPLE_STRIDE]]
+    return out
 
 
 def gen_full(ref, nsteps=10, only_kinds=None):
     torch.set_num_threads(1)
-    for kind, (O, A, H, B) in FULL.items():
-        if only_kinds and kind not in only_kinds:
+    for name, (O, A, H, B) in FULL.items():
+        if only_kinds and name not in only_kinds:
             continue
-        res = {'dims': [O, A, H, B], 'nsteps': nsteps, 'param_seed': 5, 'batch_seed': 9, 'noise_seed': 13}
+        kind = name.partition('_b')[0] if name.endswith('4096') else name
+        nsteps = FULL_STEPS.get(name, 10)
+        res = {'dims': [O, A, H, B], 'nsteps': nsteps, 'param_seed': 5, 'batch_seed': 9, 'noise_seed': 13, 'sample_stride': SAMPLE_STRIDE}
         for tag, dtype, tdt in (('fp32', np.float32, torch.float32), ('fp64', np.float64, torch.float64)):
             agent = make_agent(ref, kind, O, A, H, B)
             for nm, net in nets_of(agent):
@@ -568,9 +657,9 @@ def gen_full(ref, nsteps=10, only_kinds=None):
                 agent.actor_alpha_opt = torch.optim.Adam([agent.log_actor_alpha], lr=1e-4)
             metrics = run_agent(ref, agent, kind, nsteps, lambda i: _synth.synth_batch(9, i, B, O, A),
                                 _synth.NoiseStream(13), dtype)
-            res[tag] = {'metrics': metrics, 'checksums': checksums(agent)}
-            print('full', kind, tag, metrics[-1])
-        with open(GOLD / f'full_{kind}.json', 'w') as f:
+            res[tag] = {'metrics': metrics, 'checksums': checksums(agent), 'param_sample': param_sample(agent)}
+            print('full', name, tag, metrics[-1])
+        with open(GOLD / f'full_{name}.json', 'w') as f:
             json.dump(res, f, indent=1)
 
 
@@ -581,7 +670,7 @@ if __name__ == '__main__':
     args = ap.parse_args()
     GOLD.mkdir(parents=True, exist_ok=True)
     ref = load_reference()
-    todo = [args.only] if args.only else ['replay', 'utils', 'tiny', 'full', 'pixels', 'pixel_ddpg', 'pixel_proto']
+    todo = [args.only] if args.only else ['replay', 'offline', 'utils', 'tiny', 'full', 'pixels', 'pixel_ddpg', 'pixel_proto']
     kinds = args.kinds.split(',') if args.kinds else None
     if kinds:
         TINY_KINDS = tuple(k for k in TINY_KINDS if k.partition('-')[0] in kinds)
@@ -589,4 +678,4 @@ if __name__ == '__main__':
         if t == 'full':
             gen_full(ref, only_kinds=kinds)
         else:
-            {'replay': gen_replay, 'utils': gen_utils, 'tiny': gen_tiny, 'pixels': gen_pixels, 'pixel_ddpg': gen_pixel_ddpg, 'pixel_proto': gen_pixel_proto}[t](ref)
+            {'replay': gen_replay, 'offline': gen_offline, 'utils': gen_utils, 'tiny': gen_tiny, 'pixels': gen_pixels, 'pixel_ddpg': gen_pixel_ddpg, 'pixel_proto': gen_pixel_proto}[t](ref)

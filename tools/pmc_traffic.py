@@ -8,6 +8,9 @@ import csv
 import json
 import sys
 from collections import defaultdict
+from pathlib import Path
+
+STAMP = Path(__file__).resolve().parent.parent / 'exorl_amd' / '_build_commit.txt'     # written by tools/gpu.sh before the snapshot leaves
 
 
 def per_kernel(path, counter, pat):
@@ -27,6 +30,9 @@ nf, nw = sum(len(v) for v in f.values()), sum(len(v) for v in w.values())
 fetch = sum(sum(v) for v in f.values()) / nf * 1024.0
 write = sum(sum(v) for v in w.values()) / nw * 1024.0
 json.dump({'kernel': f'*{pat}* (launch-weighted mean over the step)',
+           'commit': STAMP.read_text().strip() if STAMP.exists() else None,
+           'kernels': sorted(k.split('<')[0] for k in f),        # bench.py drops the figure when these are gone from the library
+
            'per_kernel_fetch_KB_raw': {k: sum(v) / len(v) for k, v in f.items()},
            'per_kernel_write_KB': {k: sum(v) / len(v) for k, v in w.items()},
            'launches_counted': {'fetch_pass': nf, 'write_pass': nw},
