@@ -233,7 +233,8 @@ def main():
             'vs_baseline': None, 'dtype': {'bf16': 'bf16', 'bf16x3': 'bf16x3', 'fp32': 'f32'}[args.precision], 'data': 'synthetic',
             'config': {'workload': 'TD3+BC walker_walk (O=24,A=6,H=1024), 1M-transition replay in HBM, batch 1024/GPU, '
                                    'nstep=1, Philox sampler, use_tb=False', 'global_batch': B * world,
-                       'parallelism': f'dp{world}', 'hip_graph': use_graph, 'graph_parallel_branches': bool(args.branches) and use_graph,
+                       'parallelism': f'dp{world}', 'dp_collectives': None if world == 1 else ('RCCL all-reduce enqueued by libexorl_hip.so between its phases (exorl_comm_*)' if agent.engine.comm is not None else 'torch.distributed.all_reduce between exorl_agent_update_phase calls'),
+                       'hip_graph': use_graph, 'graph_parallel_branches': bool(args.branches) and use_graph,
                        'mfma_operands': {'bf16': 'bf16 (fp32 accumulate, fp32 master weights)', 'fp32': 'fp32',
                                          'bf16x3': 'split bf16: hi*hi + hi*lo + lo*hi (fp32 accumulate); within the 1e-4 parity bar'}[args.precision]},
             'ranks_seen': ranks_seen,

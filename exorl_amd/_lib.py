@@ -124,6 +124,11 @@ PROTOTYPES = {
     'exorl_replay_seed_philox': (C.c_int, [c_void_p, c_uint64]),
     'exorl_replay_sample': (C.c_int, [c_void_p, c_int32, c_int32, c_float, c_int32, c_void_p, P(BatchOut), c_void_p, c_void_p]),
     'exorl_replay_last_pairs': (C.c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
+    'exorl_comm_unique_id': (C.c_int, [c_void_p]),
+    'exorl_comm_init': (C.c_int, [c_int32, c_int32, c_void_p, P(c_void_p)]),
+    'exorl_comm_destroy': (C.c_int, [c_void_p]),
+    'exorl_comm_allreduce': (C.c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    'exorl_agent_set_comm': (C.c_int, [c_void_p, c_void_p]),
     'exorl_agent_workspace_bytes': (c_size_t, [P(AgentCfg)]),
     'exorl_agent_create': (C.c_int, [P(AgentCfg), c_void_p, c_size_t, P(c_void_p)]),
     'exorl_agent_destroy': (C.c_int, [c_void_p]),

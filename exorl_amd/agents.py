@@ -210,6 +210,11 @@ class _AgentBase:
                 p.copy_(w.reshape(p.shape))
         self.engine.params_changed(sync_target=True)                   # critic_target.load_state_dict(critic.state_dict())
         self.engine.set_metrics(bool(getattr(self, 'use_tb', False) or getattr(self, 'use_wandb', False)))
+        if ws > 1 and not engine_kw.get('use_critic_lagrange'):
+            from .comm import native_comm
+            comm = native_comm(self.engine.device)          # RCCL inside the library when torch.distributed runs on nccl
+            if comm is not None:
+                self.engine.set_comm(comm)
         self._slots = None
         self._graph_iter = None
         self._graph_stddev = None
@@ -277,10 +282,10 @@ class _AgentBase:
         else:
             # reference draw order: critic target, then actor; CRR's second draw is (B*n, A) (crr.py:125)
             nc, na = self._noise(), self._noise(getattr(self, '_second_noise_rows', None))
-        if self.world_size == 1:
+        if self.world_size == 1 or eng.comm is not None:      # one host call: with a communicator the library all-reduces between its phases
             eng.update(stddev, nc, na)
             return
-        dist = torch.distributed
+        dist = torch.distributed                              # gloo / EXORL_DP_COMM=torch: the collectives stay here
         eng.update_phase(0, stddev, nc, na)
         if eng.has_critic:
             dist.all_reduce(eng.flat(L.NET_CRITIC, L.T_GRAD))
@@ -443,7 +448,7 @@ class CQLAgent(_AgentBase):
             nc = np.concatenate([np.asarray(x, np.float32).reshape(-1) for x in (z_next, u_rand, z_cur, z_nxt)])
             na = np.asarray(self.noise_hook((B, A)), np.float32)
         eng = self.engine
-        if self.world_size == 1:
+        if self.world_size == 1 or eng.comm is not None:
             eng.update(1.0, nc, na)
             return
         dist = torch.distributed

@@ -7,7 +7,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / 'csrc'
 LIB = HERE / 'libexorl_hip.so'
-SOURCES = ['api.cpp', 'gemm.hip', 'rowops.hip', 'fused.hip', 'loss.hip', 'cql.hip', 'optim.hip', 'replay.hip', 'agent.hip', 'knn.hip', 'intr.hip', 'pixels.hip', 'pixel_agent.hip']
+SOURCES = ['api.cpp', 'comm.cpp', 'gemm.hip', 'rowops.hip', 'fused.hip', 'loss.hip', 'cql.hip', 'optim.hip', 'replay.hip', 'agent.hip', 'knn.hip', 'intr.hip', 'pixels.hip', 'pixel_agent.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
 
@@ -38,7 +38,7 @@ def build(force=False, verbose=True):
         if verbose and out.strip():
             print(out, file=sys.stderr)
         objs.append(str(obj))
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', str(LIB), *objs]
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', str(LIB), *objs, '-L/opt/rocm/lib', '-lrccl']      # RCCL: exorl_comm_*
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'link failed:\n{r.stdout}')

@@ -352,6 +352,11 @@ struct exorl_agent {
     Fork fk{};                   // parallel-branch plumbing (active while capturing)
     bool parallel_branches = false;  // measured slower than one chain on MI355X (2987 vs 3259 steps/s): opt-in
     bool fuse_opt = false;           // whole-step call on one GPU: partial-gradient reduction happens inside the optimiser launch
+    bool whole_step = false;         // exorl_agent_update / the captured graph drive all four phases: the fused scalar-head kernels may run
+    // data parallel: RCCL communicator attached by exorl_agent_set_comm; the library enqueues the all-reduces between the phases
+    exorl_comm* comm = nullptr;
+    hipStream_t comm_stream = nullptr;           // the 16-byte statistic travels here while the critic's backward pass runs
+    hipEvent_t ev_stats_ready = nullptr, ev_stats_done = nullptr;
     FinalizeArgs pend_c{}, pend_a{};
     bool staged_by_sampler = false;  // captured step: the sampler's gather kernel writes the staged inputs and runs step_begin
     bool want_metrics = true;    // the (B,1)-sized metric reductions are skipped when the caller never reads them (use_tb=False)
@@ -500,7 +505,7 @@ static int opt_step_critic(exorl_agent* a, hipStream_t s) {
 
 // fused scalar-head path: whole-step call on one GPU, nobody reads the metrics, twin scalar heads
 static bool qfuse(const exorl_agent* a) {
-    return a->fuse_opt && !a->want_metrics && a->has_critic && a->critic.n_heads == 2 && a->critic.out_dim == 1 && a->cfg.hidden_dim % 4 == 0 &&
+    return a->whole_step && !a->fk.on && !a->want_metrics && a->has_critic && a->critic.n_heads == 2 && a->critic.out_dim == 1 && a->cfg.hidden_dim % 4 == 0 &&
            (a->cfg.kind == EXORL_AGENT_TD3_BC || a->cfg.kind == EXORL_AGENT_TD3 || a->cfg.kind == EXORL_AGENT_DDPG);
 }
 static int run_qhead(exorl_agent* a, int mode, hipStream_t s) {
@@ -620,6 +625,13 @@ static int phase2(exorl_agent* a, float stddev, hipStream_t s) {
         dq.use_lambda = cfg.kind == EXORL_AGENT_TD3_BC;
         const bool qf = qfuse(a);
         if (qf) EXORL_TRY(run_qhead(a, 1, s));   // Q(s, pi(s)), its min-routing gradient (lambda applied later), dz2, sum|Q| partials
+        if (qf && a->comm && dq.use_lambda) {    // lambda needs sum|Q| over the GLOBAL batch (td3_bc.py:154): reduce it while the critic's
+            EXORL_TRY(reduce_pairs(a->abs_part, qhead_chunks(B), a->stats, s));          // backward pass runs (it does not depend on lambda)
+            EXORL_CHECK_HIP(hipEventRecord(a->ev_stats_ready, s));
+            EXORL_CHECK_HIP(hipStreamWaitEvent(a->comm_stream, a->ev_stats_ready, 0));
+            EXORL_TRY(comm_allreduce_sum(a->comm, a->stats, 4, a->comm_stream));
+            EXORL_CHECK_HIP(hipEventRecord(a->ev_stats_done, a->comm_stream));
+        }
         EXORL_TRY(net_backward(a->critic, a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->sh_critic, nullptr, a->pc, a->xc_pi, W, B, a->fc,
                                dq, a->bc, a->da, O, A, prec, s, a->fk, nullptr, qf));
     }
@@ -639,6 +651,10 @@ static int phase2(exorl_agent* a, float stddev, hipStream_t s) {
     dm.kind = cfg.kind; dm.inv_bg = a->inv_bg; dm.stddev = stddev; dm.stddev_ptr = &a->state->stddev; dm.w = a->crr_w;
     if (qfuse(a)) {                             // lambda = alpha / mean|Q| from the per-chunk sums qhead left behind
         dm.lam_parts = a->abs_part; dm.lam_chunks = qhead_chunks(B); dm.use_lambda = cfg.kind == EXORL_AGENT_TD3_BC; dm.alpha = cfg.alpha;
+        if (a->comm && dm.use_lambda) {          // the all-reduced statistic (one 'chunk': stats[0] = global sum |Q|)
+            EXORL_CHECK_HIP(hipStreamWaitEvent(s, a->ev_stats_done, 0));
+            dm.lam_parts = a->stats; dm.lam_chunks = 1;
+        }
     }
     EXORL_TRY(net_backward(a->actor, Pa, a->sh_actor, a->flat[EXORL_NET_ACTOR][EXORL_T_GRAD], a->pa, a->xa + (int64_t)B * O, O, B, f,
                            dm, a->ba, nullptr, 0, 0, prec, s, a->fk, a->fuse_opt ? &a->pend_a : nullptr));
@@ -775,6 +791,7 @@ int exorl_agent_destroy(exorl_agent_t* a) {
     if (!a) return 0;
     (void)release_graph(a);
     if (a->capture_stream) (void)hipStreamDestroy(a->capture_stream);
+    if (a->comm_stream) { (void)hipStreamDestroy(a->comm_stream); (void)hipEventDestroy(a->ev_stats_ready); (void)hipEventDestroy(a->ev_stats_done); }
     if (a->fk.aux) { (void)hipStreamDestroy(a->fk.aux); (void)hipEventDestroy(a->fk.ev_fork); (void)hipEventDestroy(a->fk.ev_join); }
     if (a->owns_ws) (void)hipFree(a->ws);
     delete a;
@@ -886,12 +903,41 @@ int exorl_agent_update_phase(exorl_agent_t* a, int32_t phase, float stddev, cons
 
 int exorl_agent_update(exorl_agent_t* a, float stddev, const float* noise_c, const float* noise_a, void* stream) {
     EXORL_REQUIRE(a, "agent_update: null handle");
-    // nothing is exchanged between the phases of a whole-step call: the optimiser launches reduce the gradient partials themselves
-    a->fuse_opt = a->cfg.world_size == 1 && !a->fk.on;
-    int rc = 0;
-    for (int p = 0; p < 4 && rc == 0; ++p) rc = exorl_agent_update_phase(a, p, stddev, noise_c, noise_a, stream);
+    const bool dp = a->comm != nullptr;
+    EXORL_REQUIRE(a->cfg.world_size == 1 || dp, "agent_update: world_size=%d needs a communicator (exorl_agent_set_comm), or drive "
+                  "exorl_agent_update_phase and all-reduce between the phases yourself", a->cfg.world_size);
+    hipStream_t s = as_stream(stream);
+    // one GPU: nothing is exchanged between the phases, the optimiser launches reduce the gradient partials themselves.
+    // data parallel: gradients are finalised into the flat buffers, sum-all-reduced over RCCL on this stream, then stepped.
+    a->whole_step = true;
+    a->fuse_opt = !dp && !a->fk.on;
+    const int kind = a->cfg.kind;
+    int rc = exorl_agent_update_phase(a, 0, stddev, noise_c, noise_a, stream);
+    if (rc == 0 && dp && a->has_critic) rc = comm_allreduce_sum(a->comm, a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD], a->critic.total, s);
+    if (rc == 0) rc = exorl_agent_update_phase(a, 1, stddev, noise_c, noise_a, stream);
+    // TD3+BC's sum |Q| (lambda) / CQL's sum log pi (entropy temperature); the fused scalar-head path moves it inside phase 2
+    if (rc == 0 && dp && ((kind == EXORL_AGENT_TD3_BC && !qfuse(a)) || kind == EXORL_AGENT_CQL)) rc = comm_allreduce_sum(a->comm, a->stats, 4, s);
+    if (rc == 0) rc = exorl_agent_update_phase(a, 2, stddev, noise_c, noise_a, stream);
+    if (rc == 0 && dp) rc = comm_allreduce_sum(a->comm, a->flat[EXORL_NET_ACTOR][EXORL_T_GRAD], a->actor.total, s);
+    if (rc == 0) rc = exorl_agent_update_phase(a, 3, stddev, noise_c, noise_a, stream);
     a->fuse_opt = false;
+    a->whole_step = false;
     return rc;
+}
+
+int exorl_agent_set_comm(exorl_agent_t* a, exorl_comm_t* c) {
+    EXORL_REQUIRE(a, "agent_set_comm: null handle");
+    EXORL_REQUIRE(!a->graph_exec, "agent_set_comm: disable the captured graph first");
+    EXORL_REQUIRE(!c || comm_nranks(c) == a->cfg.world_size, "agent_set_comm: communicator has %d ranks, the agent was built for world_size=%d "
+                  "(its means are over batch * world_size)", comm_nranks(c), a->cfg.world_size);
+    EXORL_REQUIRE(!c || !a->cfg.use_critic_lagrange, "agent_set_comm: CQL with use_critic_lagrange is single-GPU");
+    if (c && !a->comm_stream) {
+        EXORL_CHECK_HIP(hipStreamCreateWithFlags(&a->comm_stream, hipStreamNonBlocking));
+        EXORL_CHECK_HIP(hipEventCreateWithFlags(&a->ev_stats_ready, hipEventDisableTiming));
+        EXORL_CHECK_HIP(hipEventCreateWithFlags(&a->ev_stats_done, hipEventDisableTiming));
+    }
+    a->comm = c;
+    return 0;
 }
 
 int exorl_agent_stats_buffer(exorl_agent_t* a, void** ptr, int64_t* numel) {
@@ -954,7 +1000,7 @@ int exorl_agent_enable_graph(exorl_agent_t* a, exorl_replay_t* r, int32_t nstep,
     // a previous step (eager or a graph launch) may still be running on the caller's stream and reads the buffers the new graph is
     // built over; releasing a graph exec that is executing is not allowed either. Setup call: a full stream sync is fine here.
     EXORL_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
-    EXORL_REQUIRE(a->cfg.world_size == 1, "agent_enable_graph: data-parallel steps need host-side all-reduces between phases");
+    EXORL_REQUIRE(a->cfg.world_size == 1 && !a->comm, "agent_enable_graph: data-parallel steps are enqueued eagerly (exorl_agent_update with a communicator)");
     EXORL_REQUIRE(stddev > 0.f && nstep >= 1, "agent_enable_graph: bad stddev/nstep");
     EXORL_TRY(release_graph(a));
     if (!a->capture_stream) EXORL_CHECK_HIP(hipStreamCreateWithFlags(&a->capture_stream, hipStreamNonBlocking));
@@ -983,8 +1029,10 @@ int exorl_agent_enable_graph(exorl_agent_t* a, exorl_replay_t* r, int32_t nstep,
     int rc = replay_sample_impl(r, a->cfg.batch, nstep, gamma, EXORL_SAMPLER_PHILOX, nullptr, &slots, nullptr, a->capture_stream,
                                 &a->state->replay_counter, a->staged_by_sampler ? &stage : nullptr);
     a->fuse_opt = !a->fk.on;
+    a->whole_step = true;
     for (int p = 0; p < 4 && rc == 0; ++p) rc = exorl_agent_update_phase(a, p, stddev, nullptr, nullptr, a->capture_stream);
     a->fuse_opt = false;
+    a->whole_step = false;
     a->staged_by_sampler = false;
     a->capturing = false;
     a->fk.on = false;

@@ -229,6 +229,9 @@ struct StepState {
                                  // that moves every step needs no re-capture of the hipGraph
 };
 int step_begin(StepState* st, int advance_replay, hipStream_t s);
+// out[0] = sum_i parts[2i], out[1] = sum_i parts[2i+1] in a fixed order (qhead's per-chunk [sum |min Q|, sum min Q] -> the 4-float
+// statistics buffer that is all-reduced under data parallelism)
+int reduce_pairs(const float* parts, int chunks, float* out, hipStream_t s);
 int set_device_float(float* dst, float value, hipStream_t s);
 
 __host__ __device__ inline void fill_adam_const(AdamConst& c, double b1t, double b2t, double lr, double b1, double b2, double eps, double tau) {
@@ -350,6 +353,10 @@ int replay_sample_impl(exorl_replay* r, int32_t batch, int32_t nstep, float gamm
                        const int32_t* pairs_host, const exorl_batch_out* out, int32_t* pairs_out_host, hipStream_t s,
                        const uint64_t* dev_counter, const StageOut* stage = nullptr);
 int replay_obs_bytes(exorl_replay* r);
+// comm.cpp (exorl_comm is the C ABI's opaque struct, declared at global scope in exorl_hip.h)
+int comm_allreduce_sum(exorl_comm* c, float* buf, int64_t n, hipStream_t s);
+int comm_nranks(const exorl_comm* c);
+
 uint64_t replay_philox_counter(exorl_replay* r);
 // what a sample call does before its launch, without drawing: episode table upload, pair buffer, nstep vs the shortest episode
 int replay_prepare(exorl_replay* r, int32_t batch, int32_t nstep, hipStream_t s);

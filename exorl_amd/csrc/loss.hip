@@ -73,6 +73,20 @@ __device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t counter, 
     return sqrtf(-2.0f * __logf(u1)) * __cosf(6.283185307179586f * u2);
 }
 
+__global__ __launch_bounds__(256) void reduce_pairs_kernel(const float* __restrict__ parts, int chunks, float* __restrict__ out) {
+    __shared__ float sm[2][16];
+    float v[2] = {0.f, 0.f};
+    for (int i = threadIdx.x; i < chunks; i += blockDim.x) { v[0] += parts[2 * i]; v[1] += parts[2 * i + 1]; }
+    block_sum<2>(v, sm);
+    if (threadIdx.x == 0) { out[0] = v[0]; out[1] = v[1]; }
+}
+
+int reduce_pairs(const float* parts, int chunks, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_pairs_kernel, dim3(1), dim3(256), 0, s, parts, chunks, out);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
 __global__ void debug_philox_normal_kernel(uint64_t seed, uint64_t counter, int64_t n, float* __restrict__ out) {
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
         out[e] = philox_normal(seed, counter, (uint32_t)e);

@@ -51,6 +51,7 @@ class AgentEngine:
         self.h = handle
         self._f32 = self.workspace[self._ws_off:self._ws_off + nbytes].view(torch.float32)
         self.has_critic = kind != 'bc'
+        self.comm = None
 
     def __del__(self):
         h, self.h = getattr(self, 'h', None), None
@@ -133,6 +134,11 @@ class AgentEngine:
         L.check(self.lib.exorl_agent_act(self.h, o.data_ptr(), n, stddev, int(eval_mode), L.ptr(nz), out.data_ptr(),
                                          L.current_stream()))
         return out
+
+    def set_comm(self, comm):
+        """Attach an exorl_amd.comm.Comm of cfg.world_size ranks: update() then runs the data-parallel step in one call."""
+        L.check(self.lib.exorl_agent_set_comm(self.h, comm.h if comm is not None else None))
+        self.comm = comm
 
     def enable_graph(self, replay_engine, nstep, gamma, stddev):
         L.check(self.lib.exorl_agent_enable_graph(self.h, replay_engine.h, nstep, gamma, stddev, L.current_stream()))

@@ -96,6 +96,21 @@ int exorl_replay_sample(exorl_replay_t* r, int32_t batch, int32_t nstep, float g
 int exorl_replay_last_pairs(exorl_replay_t* r, int32_t batch, int32_t* pairs_host, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Data-parallel communicator: RCCL over xGMI, one per process / GPU. The reference has no distributed path; these
+ * are the exchanges its single-process update implies when the batch is sharded: critic gradients before critic_opt.step()
+ * (td3_bc.py:140-142), the batch-global sum |Q| behind lambda (:154), actor gradients before actor_opt.step() (:158-160).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct exorl_comm exorl_comm_t;
+#define EXORL_COMM_ID_BYTES 128
+/* Rank 0 makes the id and hands the bytes to the other ranks by any channel (torch.distributed broadcast, MPI, a file). */
+int exorl_comm_unique_id(void* id_out_host /* EXORL_COMM_ID_BYTES */);
+/* Collective over all ranks, on the caller's current HIP device. */
+int exorl_comm_init(int32_t rank, int32_t nranks, const void* id_host, exorl_comm_t** out);
+int exorl_comm_destroy(exorl_comm_t* c);
+/* In-place float32 sum all-reduce, enqueued on `stream`. */
+int exorl_comm_allreduce(exorl_comm_t* c, float* buf_dev, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Agents
  * ---------------------------------------------------------------------------------------------- */
 typedef struct exorl_agent exorl_agent_t;
@@ -201,6 +216,10 @@ int exorl_agent_update(exorl_agent_t* a, float stddev, const float* noise_critic
 int exorl_agent_update_phase(exorl_agent_t* a, int32_t phase, float stddev, const float* noise_critic_dev,
                              const float* noise_actor_dev, void* stream);
 int exorl_agent_stats_buffer(exorl_agent_t* a, void** ptr_dev, int64_t* numel);
+/* Attach a communicator of cfg.world_size ranks (NULL detaches): exorl_agent_update then runs the four phases AND the all-reduces
+ * between them on `stream` — no host round trip inside a step. The 16-byte statistic is reduced on a second stream while the critic's
+ * backward pass runs (lambda enters only at the actor head: the critic backward is linear in its output gradient). */
+int exorl_agent_set_comm(exorl_agent_t* a, exorl_comm_t* c);
 /* CQL: entropy temperature state (log_actor_alpha and its Adam moments), host <-> device: host[0..2]; with
  * use_critic_lagrange also host[3..5] = log_critic_alpha and its Adam moments (pass a 6-float array). */
 int exorl_agent_cql_alpha(exorl_agent_t* a, float* log_alpha_host, int32_t set);

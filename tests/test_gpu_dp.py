@@ -61,3 +61,63 @@ def test_two_process_dp_equals_single_process(dp_run, tag):
         else:       # Adam moves rounding-noise gradients by +-lr either way: compare what the steps changed
             d = np.abs(r0[n] - want)
             assert np.mean(d > tol_p[1] + tol_p[0] * np.abs(want)) <= 5e-3 and d.max() <= 6.5e-4, (tag, n, d.max())
+
+
+@pytest.mark.parametrize('kind,precision', [('td3_bc', 'fp32'), ('td3_bc', 'bf16x3'), ('cql', 'fp32'), ('bc', 'fp32')])
+def test_native_comm_single_rank_runs_the_dp_step(kind, precision):
+    """exorl_comm_* and exorl_agent_set_comm on the box's one GPU: a 1-rank RCCL communicator makes every all-reduce an identity, so
+    the LIBRARY-driven data-parallel step (gradients finalised into the flat buffers -> ncclAllReduce on the step's stream -> unfused
+    Adam; TD3+BC's statistic reduced on the side stream behind the critic backward) must equal the hand-driven phase sequence bit
+    for bit with metrics on, and the fused single-GPU step to rounding with metrics off. More ranks cannot share a GPU under RCCL:
+    the N-rank behaviour is covered by the gloo two-process test above (same phases, collectives in Python) and by construction."""
+    import _synth
+    from exorl_amd import _lib as L
+    from exorl_amd.comm import Comm
+    from exorl_amd.engine import AgentEngine
+    from oracle.agents import param_shapes
+    O, A, H, B = 24, 6, 128, 64
+    comm = Comm(0, 1, Comm.unique_id())
+    probe = torch.arange(8, dtype=torch.float32, device='cuda')
+    comm.allreduce(probe)
+    assert torch.equal(probe.cpu(), torch.arange(8, dtype=torch.float32))
+    ash, csh = param_shapes(kind, O, A, H)
+    pa, pc = list(_synth.synth_params(ash, 1).values()), (list(_synth.synth_params(csh, 2).values()) if csh else None)
+
+    def engine(metrics):
+        e = AgentEngine(kind, O, A, H, B, precision=precision, alpha=0.01 if kind == 'cql' else 2.5)
+        for i, w in enumerate(pa):
+            e.tensor(L.NET_ACTOR, i).copy_(torch.from_numpy(w).reshape(e.tensor(L.NET_ACTOR, i).shape))
+        if pc:
+            for i, w in enumerate(pc):
+                e.tensor(L.NET_CRITIC, i).copy_(torch.from_numpy(w).reshape(e.tensor(L.NET_CRITIC, i).shape))
+        e.params_changed(sync_target=True)
+        e.set_metrics(metrics)
+        return e
+    native, hand, native_fast, fused = engine(True), engine(True), engine(False), engine(False)
+    native.set_comm(comm)
+    native_fast.set_comm(comm)
+    ns = _synth.NoiseStream(4)
+    n = 3
+    for step in range(3):
+        batch = _synth.synth_batch(6, step, B, O, A)
+        if kind == 'cql':
+            nc = np.concatenate([ns.draw((B, A)).ravel(), np.tanh(ns.draw((n, B, A))).ravel(), ns.draw((n, B, A)).ravel(), ns.draw((n, B, A)).ravel()])
+            na = ns.draw((B, A))
+        else:
+            nc, na = ns.draw((B, A)), ns.draw((B, A))
+        for e in (native, hand, native_fast, fused):
+            e.set_batch(*batch)
+        native.update(0.2, nc, na)
+        for ph in range(4):
+            hand.update_phase(ph, 0.2, nc, na)
+        native_fast.update(0.2, nc, na)
+        fused.update(0.2, nc, na)
+        assert np.array_equal(native.metrics_raw(), hand.metrics_raw())
+    nets = [L.NET_ACTOR] + ([L.NET_CRITIC, L.NET_CRITIC_TARGET] if pc else [])
+    for net in nets:
+        assert torch.equal(native.flat(net), hand.flat(net)), net
+        d = (native_fast.flat(net) - fused.flat(net)).abs()
+        tol = 2e-6 + 1e-5 * fused.flat(net).abs()
+        assert float((d > tol).float().mean()) <= 5e-3 and float(d.max()) <= 6.5e-4, (net, float(d.max()))
+    native.set_comm(None)
+    native_fast.set_comm(None)
