@@ -157,6 +157,8 @@ PROTOTYPES = {
                              c_void_p, c_int64, c_void_p, c_int32, c_int32, c_void_p]),
     'exorl_gemm_bf16': (C.c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                   c_void_p, c_int32, c_int32, c_void_p]),
+    'exorl_gemm_planes': (C.c_int, [c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+                                    c_void_p, c_int64, c_int32, c_void_p]),
     'exorl_gemm_tune': (C.c_int, [c_int32]),
     'exorl_profile_gemm': (C.c_int, [c_int32]),
     'exorl_profile_gemm_read': (C.c_int, [c_void_p, c_void_p, c_int32, P(c_int32)]),

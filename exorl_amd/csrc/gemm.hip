@@ -892,6 +892,333 @@ static bool g16h_fits(const Gemm16Batch& gb, int count) {
     return tiles >= 256 || (g_gemm16_variant >= 0 && (g_gemm16_variant & 1024));
 }
 
+// ---- "p" kernels: 128 x TN workgroup tile (TN = 128 or 64), k32 stages, 4-deep LDS-DMA ring, XCD-local tile blocks -----------
+// What round 2's measurements changed (tools/micro/fill_bench.hip): a CU pulls ~115 GB/s from its XCD's L2 on EVERY path (LDS-DMA,
+// registers, both) but only 30-40 GB/s from the Infinity Cache, so the ~75 GB/s the kernels above sustain is an L2 miss rate, not a
+// DMA limit: with tiles dealt in id order an XCD walks one tile-row of every problem and re-fetches each B strip once per tile.
+// Here (a) workgroup id -> tile goes through xcd_tile(): the 32 workgroups of an XCD (one per CU, all resident) form a compact block
+// of ONE problem's output (512 x 512 or 512 x 1024), so every operand strip an XCD touches is fetched once and reused 4-8 times while
+// the CUs walk k together; (b) the stage is 32 k wide (32 KB for a split-bf16 128 x 128 tile), four stages deep: two to three
+// stages are always in flight, which a single workgroup per CU needs to cover the DMA latency (the 2 x 64 KB ring above could keep
+// only one); (c) the k-loop is software-pipelined across the barrier: the fragments of the next k16 are read while the MFMAs of the
+// current one issue, the barrier that certifies stage t+1 sits in the middle of step t.
+// LDS images per 64-row block and stage (4 KB): "row image" [64 rows][32 k] with 64-byte rows, 16-byte units swizzled by
+// (row >> 2) & 3 (the 16 lanes of a ds_read_b128 group then hit 16 distinct bank quads); "k image" [32 k][64 rows] = the first half
+// of the 64-k image above (same swizzle, same ds_read_b64_tr_b16 fragments).
+constexpr int G16P_NSTG = 4;
+constexpr int G16P_BLK = 4096;                     // one 64-row block of one plane, 32 k
+__device__ __forceinline__ int lds_off32(int row, int unit) { return row * 64 + ((unit ^ ((row >> 2) & 3)) << 4); }
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void g16p_static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); g16p_static_for<I + 1, N>(f); }
+}
+
+// ds_read_b64_tr_b16 through inline asm: the builtin carries no memory operand, so the compiler assumes it may read what an LDS-DMA
+// still in flight is writing and puts an s_waitcnt vmcnt(0) in front of it — which also waits for the stage that was issued a moment
+// ago, i.e. no prefetch at all for the transposed operands. The asm form is invisible to that pass; its results are fenced by
+// g16p_lds_fence() (an lgkmcnt(0) that names them) before the MFMAs of the next region read them. The two 64-bit halves stay separate
+// variables until that fence: a register move the compiler makes to pack them earlier would copy registers the LDS has not written yet.
+template <int IMM>
+__device__ __forceinline__ v4s16 g16p_read_tr(unsigned addr) {
+    v4s16 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(IMM));
+    return r;
+}
+struct G16pFrag {
+    bf16x8 v;            // MFMA operand (row-image fragments are read straight into it)
+    v4s16 lo, hi;        // k-image fragments: the two transposed 64-bit reads, packed into v by the fence
+};
+__device__ __forceinline__ void g16p_lds_fence(G16pFrag& f) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.lo), "+v"(f.hi));
+    typedef short v8s16 __attribute__((ext_vector_type(8)));
+    const v8s16 v = {f.lo.x, f.lo.y, f.lo.z, f.lo.w, f.hi.x, f.hi.y, f.hi.z, f.hi.w};
+    f.v = __builtin_bit_cast(bf16x8, v);
+}
+
+template <bool AT, bool BT, bool X3, int TN>
+__device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned char* smem, int pidx, int m0, int n0) {
+    constexpr int NBA = 2, NBB = TN / 64, NPL = X3 ? 2 : 1;
+    constexpr int PLANE = (NBA + NBB) * G16P_BLK;          // [A blk0][A blk1][B blk0][B blk1]
+    constexpr int STAGE = NPL * PLANE;                      // hi plane, then lo plane
+    constexpr int NP = (NBA + NBB) * NPL;                   // DMA pieces per wave and stage (one 1-KB piece of every block)
+    constexpr int SB = TN / 64;                             // 32-column sub-tiles of a wave along N (wave tile 64 x TN/2)
+    constexpr int NPAIR = 2 * SB;                           // 32 x 32 accumulators of a wave
+    constexpr int NM = NPAIR * (X3 ? 3 : 1);                // MFMAs per k16
+    constexpr int NF = (2 + SB) * NPL;                      // fragments per k16
+    constexpr int FPG = (NF + NM - 2) / (NM - 1);           // fragments read per MFMA gap: all of them behind the first NM-1 MFMAs
+    const Gemm16Problem& P = gb.p[pidx];
+    const int nk = P.K >> 5;                                // multiple of 4, >= 4 (launcher)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5;
+
+    f32x16 acc[NPAIR], accx[X3 ? NPAIR : 1];                // [ua * SB + ub]; accx: the two cross terms hi*lo + lo*hi
+#pragma unroll
+    for (int a = 0; a < NPAIR; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc[a][i] = 0.f; if constexpr (X3) accx[a][i] = 0.f; }
+
+    // ---- DMA sources: this wave's piece (index `wave`) of every block; per-lane addresses carry the LDS swizzle
+    const unsigned short* src[NP];
+    {
+        const int r4 = lane >> 2, u4 = lane & 3;            // row image piece: 16 rows x 4 units
+        const int r8 = lane >> 3, u8 = lane & 7;            // k image piece: 8 k-rows x 8 units
+#pragma unroll
+        for (int b = 0; b < NBA; ++b) {
+            const int64_t o = !AT ? (int64_t)(m0 + 64 * b + 16 * wave + r4) * P.lda + 8 * (u4 ^ ((r4 >> 2) & 3))
+                                  : (int64_t)(8 * wave + r8) * P.lda + m0 + 64 * b + 8 * (u8 ^ (4 * ((r8 >> 1) & 1)));
+            src[b] = P.A + o;
+            if constexpr (X3) src[NBA + NBB + b] = P.A_lo + o;
+        }
+#pragma unroll
+        for (int b = 0; b < NBB; ++b) {
+            const int64_t o = !BT ? (int64_t)(n0 + 64 * b + 16 * wave + r4) * P.ldb + 8 * (u4 ^ ((r4 >> 2) & 3))
+                                  : (int64_t)(8 * wave + r8) * P.ldb + n0 + 64 * b + 8 * (u8 ^ (4 * ((r8 >> 1) & 1)));
+            src[NBA + b] = P.B + o;
+            if constexpr (X3) src[NBA + NBB + NBA + b] = P.B_lo + o;
+        }
+    }
+    const int64_t kstepA = AT ? 32 * P.lda : 32, kstepB = BT ? 32 * P.ldb : 32;
+    const int piece = wave * 1024;
+
+    // ---- fragment offsets inside a stage's hi plane (lo plane: + PLANE)
+    const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    auto tr_off = [&](int rbase) {      // k image: k-row 8*(g>>1)+qq (+4 for the second half), columns rbase + 16*(g&1) + 4*pp ..+3
+        const int c = rbase + 16 * (g & 1) + 4 * pp;
+        return (8 * (g >> 1) + qq) * ROWB + (((c >> 3) ^ (4 * ((qq >> 1) & 1))) << 4) + ((c & 7) << 1);
+    };
+    int aoff[2][2], boff[SB][2];                    // [sub-tile][q]
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            aoff[u][q] = wm * G16P_BLK + (AT ? tr_off(u * 32) + q * 16 * ROWB : lds_off32(u * 32 + (lane & 31), 2 * q + h));
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int blk = TN == 128 ? wn : 0, r0 = TN == 128 ? u * 32 : wn * 32;
+            boff[u][q] = (NBA + blk) * G16P_BLK + (BT ? tr_off(r0) + q * 16 * ROWB : lds_off32(r0 + (lane & 31), 2 * q + h));
+        }
+    }
+
+    auto fill_one = [&](int st, auto ic) {          // DMA piece I of stage st
+        constexpr int I = decltype(ic)::value;
+        constexpr int pl = I / (NBA + NBB), b = I % (NBA + NBB);
+        __builtin_amdgcn_global_load_lds((const void*)src[I], (lds_void*)(smem + st * STAGE + piece + pl * PLANE + b * G16P_BLK), 16, 0, 0);
+        src[I] += b < NBA ? kstepA : kstepB;
+    };
+    auto fill = [&](int st) { g16p_static_for<0, NP>([&](auto ic) { fill_one(st, ic); }); };
+
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;       // LDS byte address of the ring
+    auto frag = [&](G16pFrag& f, auto plane, bool tr, int st, int off) {     // plane 0 = hi, 1 = lo
+        constexpr int PL = decltype(plane)::value * PLANE;
+        if (!tr) { f.v = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(smem + st * STAGE + PL + off)); return; }
+        const unsigned a = lds0 + st * STAGE + off;
+        f.lo = g16p_read_tr<PL>(a);
+        f.hi = g16p_read_tr<PL + 4 * ROWB>(a);
+    };
+    struct Frags { G16pFrag ah[2], bh[SB], al[X3 ? 2 : 1], bl[X3 ? SB : 1]; };
+    // fragment J of a k16, in the order the MFMAs want them: per plane A0 B0 A1 [B1]
+    auto read_one = [&](Frags& f, int st, int q, auto jc) {
+        constexpr int J = decltype(jc)::value;
+        constexpr int pl = X3 ? J % 2 : 0, k = X3 ? J / 2 : J;           // k: 0 = A0, 1 = B0, 2 = A1, 3 = B1
+        constexpr bool isA = k == 0 || k == 2;
+        constexpr int u = k / 2;
+        if constexpr (isA) {
+            if constexpr (pl == 0) frag(f.ah[u], std::integral_constant<int, 0>{}, AT, st, aoff[u][q]);
+            else frag(f.al[u], std::integral_constant<int, 1>{}, AT, st, aoff[u][q]);
+        } else {
+            if constexpr (pl == 0) frag(f.bh[u], std::integral_constant<int, 0>{}, BT, st, boff[u][q]);
+            else frag(f.bl[u], std::integral_constant<int, 1>{}, BT, st, boff[u][q]);
+        }
+    };
+    static_assert(SB == 2 || NF == 3 * NPL, "fragment list");
+    auto read_all = [&](Frags& f, int st, int q) { g16p_static_for<0, NF>([&](auto jc) { read_one(f, st, q, jc); }); };
+    auto fence = [&](Frags& f) {               // the asm-issued transposed reads of f have landed (see g16p_read_tr)
+        if constexpr (AT) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { g16p_lds_fence(f.ah[u]); if constexpr (X3) g16p_lds_fence(f.al[u]); }
+        }
+        if constexpr (BT) {
+#pragma unroll
+            for (int u = 0; u < SB; ++u) { g16p_lds_fence(f.bh[u]); if constexpr (X3) g16p_lds_fence(f.bl[u]); }
+        }
+    };
+    // MFMA I of a k16. Operands swapped: the accumulator is the TRANSPOSED 32 x 32 block, i.e. lane = output row, registers r..r+3 =
+    // four consecutive output columns -> the epilogue stores 16 bytes per lane (16 stores per wave instead of 64)
+    auto mfma_one = [&](const Frags& f, auto ic) {
+        constexpr int I = decltype(ic)::value;
+        constexpr int pair = X3 ? I / 3 : I, term = X3 ? I % 3 : 0, ua = pair / SB, ub = pair % SB;
+        if constexpr (term == 0) acc[pair] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.bh[ub].v, f.ah[ua].v, acc[pair], 0, 0, 0);
+        else if constexpr (term == 1) accx[pair] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.bl[ub].v, f.ah[ua].v, accx[pair], 0, 0, 0);
+        else accx[pair] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.bh[ub].v, f.al[ua].v, accx[pair], 0, 0, 0);
+    };
+    // One scheduling region = the NM MFMAs of a k16 on `cur`, with the reads of the NEXT k16's fragments into `nxt` (FPG per MFMA gap)
+    // and, when NFILL > 0, one DMA issue of stage `fst` per gap written out between them; sched_barrier(0) after every piece keeps
+    // the machine scheduler from regrouping them (left alone it sinks the reads to just before their use; issued as one block they
+    // exceed the 4-bit lgkmcnt and the compiler waits for all of them). The reads complete in the shadow of the matrix pipe, the next
+    // region opens with waits that cost nothing.
+    auto region = [&](Frags& cur, Frags& nxt, auto has_next, int nst, int nq, auto nfill, int fst) {
+        constexpr bool HN = decltype(has_next)::value;
+        constexpr int NFILL = decltype(nfill)::value;
+        fence(cur);
+        g16p_static_for<0, NM>([&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            mfma_one(cur, ic);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (HN) g16p_static_for<I * FPG, ((I + 1) * FPG < NF ? (I + 1) * FPG : NF)>([&](auto jc) { read_one(nxt, nst, nq, jc); });
+            constexpr int PPG = (NP + NM - 1) / NM;          // DMA pieces per gap (plain bf16 128 x 64 tiles: 3 pieces, 2 MFMAs)
+            if constexpr (NFILL > 0) g16p_static_for<I * PPG, ((I + 1) * PPG < NP ? (I + 1) * PPG : NP)>([&](auto pc) { fill_one(fst, pc); });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    // a stage has landed for this wave once at most `younger` younger stages' pieces are outstanding (NP per stage)
+    auto wait_landed = [&](auto younger) {
+        constexpr int y = decltype(younger)::value;
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(y * NP) : "memory");
+    };
+    Frags f0, f1;
+    using T = std::true_type;
+    using F = std::false_type;
+    using NoFill = std::integral_constant<int, 0>;
+    using Fill = std::integral_constant<int, NP>;
+    // four steps on stages 0..3; LAST = the final group (no fills beyond the last stage, no barrier after the last step). Every
+    // condition is a compile-time constant: a run-time branch in here makes the compiler fall back to lgkmcnt(0) / vmcnt(0)
+    auto group = [&](auto last) {
+        constexpr bool LAST = decltype(last)::value;
+        g16p_static_for<0, G16P_NSTG>([&](auto sc) {         // step s of the group computes on stage s
+            constexpr int s = decltype(sc)::value;
+            region(f0, f1, T{}, s, 1, NoFill{}, 0);          // first k16; reads the second k16 of the same stage
+            if constexpr (!LAST || s < G16P_NSTG - 1) {
+                if constexpr (!LAST || s < G16P_NSTG - 2) wait_landed(std::integral_constant<int, 1>{});   // next stage; one younger stage in flight
+                else wait_landed(std::integral_constant<int, 0>{});
+                __builtin_amdgcn_s_barrier();       // ... landed for every wave; and nobody reads the stage before this one any more
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!LAST || s == 0) region(f1, f0, T{}, (s + 1) % G16P_NSTG, 0, Fill{}, (s + 3) % G16P_NSTG);
+                else region(f1, f0, T{}, (s + 1) % G16P_NSTG, 0, NoFill{}, 0);
+            } else {
+                region(f1, f0, F{}, 0, 0, NoFill{}, 0);
+            }
+        });
+    };
+
+    fill(0); fill(1); fill(2);
+    wait_landed(std::integral_constant<int, 2>{});
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_all(f0, 0, 0);
+    for (int t = 0; t + G16P_NSTG < nk; t += G16P_NSTG) group(F{});
+    group(T{});
+
+    const bool relu = gb.relu != 0;
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < SB; ++tb) {
+            // lane: output row m0 + .. + (lane & 31); registers 4g..4g+3: columns nb + 8g + 4h .. +3
+            const int nb = n0 + wn * (TN / 2) + tb * 32 + 4 * h;
+            float* crow = P.C + (int64_t)(m0 + wm * 64 + ta * 32 + (lane & 31)) * P.ldc + nb;
+            const f32x16& a0 = acc[ta * SB + tb];
+            const f32x16& ax = accx[X3 ? ta * SB + tb : 0];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float4* dst = reinterpret_cast<float4*>(crow + 8 * g4);
+                const float4 bias = P.bias ? *reinterpret_cast<const float4*>(P.bias + nb + 8 * g4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 v;
+                v.x = (X3 ? ax[4 * g4 + 0] + a0[4 * g4 + 0] : a0[4 * g4 + 0]) + bias.x;
+                v.y = (X3 ? ax[4 * g4 + 1] + a0[4 * g4 + 1] : a0[4 * g4 + 1]) + bias.y;
+                v.z = (X3 ? ax[4 * g4 + 2] + a0[4 * g4 + 2] : a0[4 * g4 + 2]) + bias.z;
+                v.w = (X3 ? ax[4 * g4 + 3] + a0[4 * g4 + 3] : a0[4 * g4 + 3]) + bias.w;
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (gb.accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                *dst = v;
+            }
+        }
+}
+
+// workgroup id -> (problem, tile origin): XCD-local blocks when the launcher found the problems uniform, id order otherwise
+template <int TN>
+__device__ __forceinline__ bool g16p_tile(const Gemm16Batch& gb, int& pidx, int& m0, int& n0) {
+    constexpr int SH = TN == 128 ? 7 : 6;
+    if (gb.xcd_map) {
+        const XcdTile xt = xcd_tile(blockIdx.x, gb.count, gb.p[0].M >> 7, gb.p[0].N >> SH);
+        if (!xt.ok) return false;
+        pidx = xt.p; m0 = xt.tm << 7; n0 = xt.tn << SH;
+        return true;
+    }
+    pidx = blockIdx.z;
+    const int tiles_n = gb.p[pidx].N >> SH, ntiles = tiles_n * (gb.p[pidx].M >> 7);
+    if ((int)blockIdx.x >= ntiles) return false;
+    m0 = ((int)blockIdx.x / tiles_n) << 7;
+    n0 = ((int)blockIdx.x % tiles_n) << SH;
+    return true;
+}
+
+template <bool AT, bool BT, bool X3, int TN>
+__global__ __launch_bounds__(256) void gemm16p_kernel(const Gemm16Batch gb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_p[];
+    int pidx, m0, n0;
+    if (!g16p_tile<TN>(gb, pidx, m0, n0)) return;
+    gemm16p_body<AT, BT, X3, TN>(gb, smem_p, pidx, m0, n0);
+}
+
+template <bool X3, int TN>      // wgrad (A as a k image) and dgrad (A as a row image) of one Linear(H,H) in one launch; B is a k image in both
+__global__ __launch_bounds__(256) void gemm16p_mixed_kernel(const Gemm16Batch gb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_p[];
+    int pidx, m0, n0;
+    if (!g16p_tile<TN>(gb, pidx, m0, n0)) return;
+    if (gb.a_t[pidx]) gemm16p_body<true, true, X3, TN>(gb, smem_p, pidx, m0, n0);
+    else gemm16p_body<false, true, X3, TN>(gb, smem_p, pidx, m0, n0);
+}
+constexpr int g16p_lds(bool x3, int tn) { return G16P_NSTG * (x3 ? 2 : 1) * (2 + tn / 64) * G16P_BLK; }
+
+// Tile width for a launch (0 = these kernels do not apply): 128 x 128 when that still gives every CU a workgroup, else 128 x 64.
+static int g16p_pick(const Gemm16Batch& gb, int count, bool x3) {
+    if (g_gemm16_variant >= 0 && (g_gemm16_variant & 262144)) return 0;          // experiment switch: off
+    int t128 = 0;
+    for (int i = 0; i < count; ++i) {
+        const Gemm16Problem& p = gb.p[i];
+        const bool al = p.lda % 8 == 0 && p.ldb % 8 == 0 && reinterpret_cast<uintptr_t>(p.A) % 16 == 0 && reinterpret_cast<uintptr_t>(p.B) % 16 == 0 &&
+                        (!x3 || (p.A_lo && p.B_lo && reinterpret_cast<uintptr_t>(p.A_lo) % 16 == 0 && reinterpret_cast<uintptr_t>(p.B_lo) % 16 == 0));
+        const bool cal = p.ldc % 4 == 0 && reinterpret_cast<uintptr_t>(p.C) % 16 == 0 && reinterpret_cast<uintptr_t>(p.bias) % 16 == 0;     // float4 epilogue
+        if (!al || !cal || p.M % 128 != 0 || p.N % 64 != 0 || p.K % 128 != 0 || p.K < 128) return 0;
+        t128 += p.N % 128 == 0 ? (p.M >> 7) * (p.N >> 7) : 0;
+    }
+    bool n128 = true;
+    for (int i = 0; i < count; ++i) n128 = n128 && gb.p[i].N % 128 == 0;
+    if (g_gemm16_variant >= 0 && (g_gemm16_variant & 524288)) return n128 ? 128 : 64;      // experiment: 128 x 128 wherever it tiles
+    return (n128 && t128 >= 256) ? 128 : 64;
+}
+static bool g16p_uniform(const Gemm16Batch& gb, int count, int tn) {       // xcd_tile()'s preconditions
+    if (g_gemm16_variant >= 0 && (g_gemm16_variant & 1048576)) return false;     // experiment: id order
+    if (!(count == 1 || count == 2 || count == 4)) return false;
+    const int X = 8 / count, sm = X == 8 ? 4 : 2, sn = X == 2 ? 1 : 2;
+    for (int i = 0; i < count; ++i) {
+        if (gb.p[i].M != gb.p[0].M || gb.p[i].N != gb.p[0].N) return false;
+        if ((gb.p[i].M / 128) % sm != 0 || (gb.p[i].N / tn) % sn != 0) return false;
+    }
+    return true;
+}
+template <typename K>
+static int g16p_launch(K kernel, Gemm16Batch& gb, int count, bool x3, int tn, hipStream_t s) {
+    const int lds = g16p_lds(x3, tn);
+    static std::vector<const void*> enabled;         // > 64 KB of dynamic LDS needs the opt-in, once per kernel
+    if (std::find(enabled.begin(), enabled.end(), (const void*)kernel) == enabled.end()) {
+        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        enabled.push_back((const void*)kernel);
+    }
+    gb.count = count;
+    gb.xcd_map = g16p_uniform(gb, count, tn) ? 1 : 0;
+    int tmax = 0, ttot = 0;
+    for (int i = 0; i < count; ++i) { const int t = (gb.p[i].M >> 7) * (gb.p[i].N / tn); tmax = t > tmax ? t : tmax; ttot += t; }
+    hipLaunchKernelGGL(kernel, gb.xcd_map ? dim3(ttot, 1, 1) : dim3(tmax, 1, count), dim3(256), lds, s, gb);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
 template <bool AT, bool BT, int NSTG = G16G_NSTG>
 __global__ __launch_bounds__(256) void gemm16g_kernel(const Gemm16Batch gb) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[NSTG * 2 * G16G_IMG];
@@ -989,6 +1316,20 @@ static int launch16(const Gemm16Batch& gb, int count, int tiles64, int tiles128,
                   gb.p[i].ldb % 8 == 0 && reinterpret_cast<uintptr_t>(gb.p[i].A) % 16 == 0 && reinterpret_cast<uintptr_t>(gb.p[i].B) % 16 == 0;
     bool x3 = false;
     for (int i = 0; i < count; ++i) x3 = x3 || gb.p[i].A_lo || gb.p[i].B_lo;
+    if (const int tn = g16p_pick(g2, count, x3)) {          // 128 x TN tiles, k32 stages, XCD-local blocks (see gemm16p_body)
+        if (x3) {
+            if (tn == 128) EXORL_TRY(g16p_launch(gemm16p_kernel<AL != 0, BL != 0, true, 128>, g2, count, true, 128, s));
+            else EXORL_TRY(g16p_launch(gemm16p_kernel<AL != 0, BL != 0, true, 64>, g2, count, true, 64, s));
+        } else {
+            if (tn == 128) EXORL_TRY(g16p_launch(gemm16p_kernel<AL != 0, BL != 0, false, 128>, g2, count, false, 128, s));
+            else EXORL_TRY(g16p_launch(gemm16p_kernel<AL != 0, BL != 0, false, 64>, g2, count, false, 64, s));
+        }
+        if (prof) {
+            EXORL_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s));
+            g_prof.used += 1;
+        }
+        return 0;
+    }
     if (x3) {
         bool okx = true;
         for (int i = 0; i < count; ++i)
@@ -1102,7 +1443,15 @@ int gemm16_grouped_mixed(const int* a_layouts, const Gemm16Problem* probs, int c
         g_prof.flops.push_back(flops);
         EXORL_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.used], s));
     }
-    if (x3) {
+    if (const int tn = g16p_pick(gb, count, x3)) {
+        if (x3) {
+            if (tn == 128) EXORL_TRY(g16p_launch(gemm16p_mixed_kernel<true, 128>, gb, count, true, 128, s));
+            else EXORL_TRY(g16p_launch(gemm16p_mixed_kernel<true, 64>, gb, count, true, 64, s));
+        } else {
+            if (tn == 128) EXORL_TRY(g16p_launch(gemm16p_mixed_kernel<false, 128>, gb, count, false, 128, s));
+            else EXORL_TRY(g16p_launch(gemm16p_mixed_kernel<false, 64>, gb, count, false, 64, s));
+        }
+    } else if (x3) {
         gb.count = count;
         gb.xcd_map = (g_gemm16_variant >= 0 && (g_gemm16_variant & 2048) && xcd_map_ok(gb, count, 64)) ? 1 : 0;
         if (g16hx3_fits(gb, count)) {
@@ -1302,6 +1651,27 @@ extern "C" int exorl_gemm_bf16(int32_t a_layout, int32_t b_layout, int32_t M, in
                                int32_t relu, int32_t accumulate, void* stream) {
     exorl::Gemm16Problem p{A, B, C, bias, M, N, K, lda, ldb, ldc};
     return exorl::gemm16_grouped(a_layout, b_layout, &p, 1, relu != 0, accumulate != 0, exorl::as_stream(stream));
+}
+
+extern "C" int exorl_gemm_planes(int32_t count, const int32_t* a_layouts, int32_t b_layout, int32_t M, int32_t N, int32_t K,
+                                 const uint16_t* const* A_hi, const uint16_t* const* A_lo, int64_t lda, const uint16_t* const* B_hi,
+                                 const uint16_t* const* B_lo, int64_t ldb, float* const* C, int64_t ldc, int32_t relu, void* stream) {
+    using namespace exorl;
+    EXORL_REQUIRE(count >= 1 && count <= 4 && a_layouts && A_hi && B_hi && C, "gemm_planes: bad arguments");
+    Gemm16Problem p[4];
+    bool mixed = false;
+    for (int i = 0; i < count; ++i) {
+        p[i] = Gemm16Problem{A_hi[i], B_hi[i], C[i], nullptr, M, N, K, lda, ldb, ldc};
+        if (A_lo && A_lo[i]) { p[i].A_lo = A_lo[i]; p[i].B_lo = B_lo ? B_lo[i] : nullptr; }
+        mixed = mixed || a_layouts[i] != a_layouts[0];
+    }
+    if (mixed) {
+        EXORL_REQUIRE(b_layout == 1 && !relu, "gemm_planes: mixed A layouts go with B as a k image and no epilogue (wgrad + dgrad)");
+        int at[4];
+        for (int i = 0; i < count; ++i) at[i] = a_layouts[i];
+        return gemm16_grouped_mixed(at, p, count, as_stream(stream));
+    }
+    return gemm16_grouped(a_layouts[0], b_layout, p, count, relu != 0, false, as_stream(stream));
 }
 
 extern "C" int exorl_gemm(int32_t precision, int32_t a_layout, int32_t b_layout, int32_t M, int32_t N, int32_t K,

@@ -263,6 +263,13 @@ int exorl_gemm(int32_t precision, int32_t a_layout, int32_t b_layout, int32_t M,
 int exorl_gemm_bf16(int32_t a_layout, int32_t b_layout, int32_t M, int32_t N, int32_t K, const uint16_t* A_dev, int64_t lda,
                     const uint16_t* B_dev, int64_t ldb, float* C_dev, int64_t ldc, const float* bias_dev, int32_t relu,
                     int32_t accumulate, void* stream);
+/* Grouped form on bf16 planes, as the agents launch it: up to 4 problems of one shape in ONE launch, each operand given as a hi plane and
+ * (split-bf16) a lo plane with x = hi + lo, or lo == NULL for plain bf16. a_layouts[i] selects problem i's A layout (a Linear's wgrad
+ * and dgrad share a launch with different A layouts); b_layout is common. No bias. Pointer arrays are host arrays of device pointers. */
+int exorl_gemm_planes(int32_t count, const int32_t* a_layouts, int32_t b_layout, int32_t M, int32_t N, int32_t K,
+                      const uint16_t* const* A_hi_dev, const uint16_t* const* A_lo_dev, int64_t lda,
+                      const uint16_t* const* B_hi_dev, const uint16_t* const* B_lo_dev, int64_t ldb,
+                      float* const* C_dev, int64_t ldc, int32_t relu, void* stream);
 /* Tuning switch for the bf16-operand GEMM (tools/micro/gemm_bench.py): -1 = default heuristics. */
 int exorl_gemm_tune(int32_t variant);
 /* Measurement hook (bench.py roofline leg): time every GEMM launch with HIP events on its own stream. */
