@@ -8,7 +8,6 @@ Environment construction, evaluation roll-outs, video and the CSV/TensorBoard lo
 """
 import time
 
-from . import utils
 from .replay_buffer import make_replay_loader
 
 
@@ -23,23 +22,19 @@ def train_offline(agent, replay_dir, num_grad_steps, batch_size, discount, repla
     replay_iter = iter(loader)
     if use_graph and hasattr(agent, 'enable_graph'):
         agent.enable_graph(replay_iter, start_step)      # False (and eager launches) when the pairing cannot be captured
-    train_until_step = utils.Until(start_step + num_grad_steps)
-    eval_every_step = utils.Every(eval_every_steps)
-    log_every_step = utils.Every(log_every_steps)
-    timer = utils.Timer()
+    import torch
     rows = []
-    global_step = start_step
-    while train_until_step(global_step):
-        if eval_fn is not None and eval_every_step(global_step):
+    t_start = t_last = time.time()
+    for global_step in range(start_step, start_step + num_grad_steps):
+        if eval_fn is not None and eval_every_steps and global_step % eval_every_steps == 0:
             eval_fn(global_step, agent)
         metrics = agent.update(replay_iter, global_step)
-        if log_every_step(global_step):
-            import torch
+        if log_every_steps and global_step % log_every_steps == 0:
             torch.cuda.synchronize()
-            elapsed_time, total_time = timer.reset()
-            row = dict(metrics, fps=log_every_steps / max(elapsed_time, 1e-9), total_time=total_time, step=global_step)
+            now = time.time()
+            row = dict(metrics, fps=log_every_steps / max(now - t_last, 1e-9), total_time=now - t_start, step=global_step)
+            t_last = now
             rows.append((global_step, row))
             if log_fn is not None:
                 log_fn(global_step, row)
-        global_step += 1
     return rows

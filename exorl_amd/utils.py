@@ -1,9 +1,8 @@
 """Host-side helpers with the reference's names and meaning (/root/reference/utils/utils.py), for the
-callers of the hot path (pretrain.py / train_offline.py use utils.eval_mode, utils.schedule, utils.Until ...).
+callers of the hot path (pretrain.py / train_offline.py use utils.eval_mode, utils.schedule, utils.set_seed_everywhere ...).
 The tensor math these names used to do on the update path now lives in libexorl_hip.so."""
 import random
 import re
-import time
 
 import numpy as np
 import torch
@@ -77,36 +76,3 @@ def soft_update_params(net, target_net, tau):
         L.check(lib.exorl_soft_update(p.data_ptr(), t.data_ptr(), p.numel(), tau, L.current_stream()))
     if getattr(target_net, '_on_change', None):
         target_net._on_change()
-
-
-class Until:
-    def __init__(self, until, action_repeat=1):
-        self._until, self._action_repeat = until, action_repeat
-
-    def __call__(self, step):
-        if self._until is None:
-            return True
-        return step < self._until // self._action_repeat
-
-
-class Every:
-    def __init__(self, every, action_repeat=1):
-        self._every, self._action_repeat = every, action_repeat
-
-    def __call__(self, step):
-        if self._every is None:
-            return False
-        return step % (self._every // self._action_repeat) == 0
-
-
-class Timer:
-    def __init__(self):
-        self._start_time = self._last_time = time.time()
-
-    def reset(self):
-        now = time.time()
-        elapsed, self._last_time = now - self._last_time, now
-        return elapsed, now - self._start_time
-
-    def total_time(self):
-        return time.time() - self._start_time

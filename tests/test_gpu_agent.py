@@ -542,3 +542,52 @@ def test_graph_follows_a_moving_stddev_schedule():
         runs[tag] = [p.clone() for p in ag.actor.parameters()] + [p.clone() for p in ag.critic.parameters()]
     assert all(torch.equal(p, q) for p, q in zip(runs['graph'], runs['eager']))
     assert any(not torch.equal(p, q) for p, q in zip(runs['graph'], runs['const']))
+
+
+def test_state_dict_snapshot_crosses_to_a_reference_shaped_module(gold, tmp_path):
+    """save_state_dicts writes plain tensors under the reference's parameter names. The file must (i) open with
+    torch.load(weights_only=True) — nothing executable inside; (ii) load STRICTLY into modules built like the reference's Actor / Critic
+    (td3_bc.py:12-56: `policy` / `q1_net` / `q2_net` Sequentials) and make them compute what the engine computes; (iii) come back."""
+    import torch.nn as nn
+    from exorl_amd.snapshot import load_state_dicts, save_state_dicts
+    O, A, H, B = 24, 6, 64, 32
+    torch.manual_seed(5)
+    ag = make('td3_bc', O, A, H, B)
+    ag.noise_hook = _synth.NoiseStream(1).draw
+    for i in range(2):
+        ag.update(iter([_synth.synth_batch(3, i, B, O, A)]), i)
+    save_state_dicts(ag, tmp_path / 'snap.pt')
+    d = torch.load(tmp_path / 'snap.pt', weights_only=True)
+    z = np.load(gold / 'tiny_td3_bc.npz')
+    for net in ('actor', 'critic', 'critic_target'):                           # the reference's own key names, from its recorded state_dicts
+        assert list(d[net].keys()) == [k.split('/', 2)[2] for k in z.files if k.startswith(f'init/{net}/')]
+
+    def mlp(i, o, squash):
+        return nn.Sequential(nn.Linear(i, H), nn.LayerNorm(H), nn.Tanh(), nn.Linear(H, H), nn.ReLU(), nn.Linear(H, o), *([nn.Tanh()] if squash else []))
+
+    class RefActor(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.policy = mlp(O, A, True)
+
+    class RefCritic(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q1_net, self.q2_net = mlp(O + A, 1, False), mlp(O + A, 1, False)
+    ra, rc = RefActor(), RefCritic()
+    ra.load_state_dict(d['actor'], strict=True)
+    rc.load_state_dict(d['critic'], strict=True)
+    obs = np.random.RandomState(0).standard_normal(O).astype(np.float32)
+    np.testing.assert_allclose(ag.act(obs, 0, eval_mode=True), ra.policy(torch.from_numpy(obs)[None]).detach().numpy()[0], rtol=1e-4, atol=1e-6)
+    torch.manual_seed(6)
+    other = make('td3_bc', O, A, H, B)
+    assert load_state_dicts(other, tmp_path / 'snap.pt') == ['actor', 'critic', 'critic_target']
+    for (n1, a), (_, b) in zip(nets_of(ag), nets_of(other)):
+        for p, q in zip(a.parameters(), b.parameters()):
+            assert torch.equal(p, q), n1
+    # and the other direction: a file the reference side would write (actor + critic only) — the target follows the critic
+    torch.save({'actor': ra.state_dict(), 'critic': rc.state_dict()}, tmp_path / 'ref.pt')
+    third = make('td3_bc', O, A, H, B)
+    load_state_dicts(third, tmp_path / 'ref.pt')
+    for p, q in zip(third.critic_target.parameters(), ag.critic.parameters()):
+        assert torch.equal(p, q)

@@ -290,3 +290,52 @@ def test_pixel_agent_pickle_roundtrip_continues_bit_identically(kind):
                 assert torch.equal(p, q), (kind, nm, k)
         if kind == 'proto':
             assert torch.equal(ag.queue, other.queue) and ag.queue_ptr == other.queue_ptr
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_config4_proto_pixels_shipped_dims_vs_oracle(precision):
+    """BASELINE.json configs[3] at the sizes the 115 update()/s figure is quoted on — jaco frames (3, 84, 84) uint8, A = 9, feature_dim 50,
+    hidden 1024, pred_dim 128, proj_dim 512, 512 prototypes, queue 2048, nstep 3 — except the batch: 256 instead of 1024, the largest the
+    numpy oracle turns round inside the test budget (~10 s per oracle step; 2 steps x 2 precisions). Everything batch-shaped in the
+    kernels (MFMA implicit-GEMM convolutions, 16-way split-K trunk, Sinkhorn over the batch, 3-NN against the queue) spans many
+    workgroups at 256. Bar: every metric of both update() calls within 2e-4 of the oracle (pinned to the reference by pixel_proto.npz),
+    the bar test_pixel_ddpg_batch_vs_oracle documents for the 39200-wide layers; step 2 runs against the queue step 1 filled."""
+    import _synth
+    from exorl_amd import agents
+    from oracle.proto import OracleProto
+    C_, HW, A, F, H, B, PD, PJ, Q, NP = 3, 84, 9, 50, 1024, 256, 128, 512, 2048, 512
+    ag = agents.ProtoAgent(pred_dim=PD, proj_dim=PJ, queue_size=Q, num_protos=NP, tau=0.1, encoder_target_tau=0.05, topk=3, update_encoder=True,
+                           name='proto', reward_free=True, obs_type='pixels', obs_shape=(C_, HW, HW), action_shape=(A,), device='cuda', lr=1e-4,
+                           feature_dim=F, hidden_dim=H, critic_target_tau=0.01, num_expl_steps=2000, update_every_steps=2, stddev_schedule=0.2,
+                           nstep=3, batch_size=B, stddev_clip=0.3, init_critic=True, use_tb=True, use_wandb=False, precision=precision)
+    enc, actor, critic = load_pixel_params(ag, C_, A, F, H)
+    psh = [[('weight', (PD, 39200)), ('bias', (PD,))], [('trunk.0.weight', (PJ, PD)), ('trunk.0.bias', (PJ,)), ('trunk.2.weight', (PD, PJ)), ('trunk.2.bias', (PD,))],
+           [('weight', (NP, PD))]]
+    pps = [_synth.synth_params(sh, 53 + i) for i, sh in enumerate(psh)]
+    for view, p in zip((ag.predictor, ag.projector, ag.protos), pps):
+        view.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+    for p, t in zip(ag.predictor.parameters(), ag.predictor_target.parameters()):
+        t.copy_(p)
+    ag.engine.encoder_target(init=True)
+    orc = pixels.OracleProtoPixels(pixels.OraclePixelDDPG(enc, actor, critic), OracleProto([v for p in pps for v in p.values()], queue_size=Q))
+    rs = np.random.RandomState(1)
+    ns, ns2 = _synth.NoiseStream(4), _synth.NoiseStream(4)
+    ag.noise_hook = ns.draw
+    sh, us = [], []
+    ag.shift_hook = lambda n: sh[-1].pop(0)
+    ag.cat_hook = lambda n: us[-1]
+    worst = 0.0
+    for i in range(2):
+        obs, nobs = rs.randint(0, 256, (B, C_, HW, HW)).astype(np.uint8), rs.randint(0, 256, (B, C_, HW, HW)).astype(np.uint8)
+        b = _synth.synth_batch(3, i, B, 4, A)
+        so, sn = rs.randint(0, 9, (B, 2)).astype(np.int32), rs.randint(0, 9, (B, 2)).astype(np.int32)
+        sh.append([so, sn])
+        us.append(rs.uniform(size=NP).astype(np.float32))
+        m = ag.update(iter([(obs, b[1], b[2], b[3], nobs)]), 2 * i)
+        mo = orc.update((obs, b[1], b[2], b[3], nobs), 2 * i, so, sn, us[-1], ns2.draw((B, A)), ns2.draw((B, A)))
+        assert sorted(m.keys()) == sorted(mo.keys())
+        for k, v in mo.items():
+            assert abs(m[k] - v) <= 2e-4 * abs(v) + 1e-5, (precision, i, k, m[k], v)
+            worst = max(worst, abs(m[k] - v) / (abs(v) + 1e-2))
+    print(f'[config 4] proto pixels {precision} B={B}: worst relative metric error {worst:.2e}')
+    np.testing.assert_allclose(ag.queue.cpu().numpy(), orc.proto.queue, rtol=2e-4, atol=2e-5)

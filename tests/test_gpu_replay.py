@@ -185,3 +185,67 @@ def test_full_size_properties(nstep):
     big = np.concatenate([(eng.sample(B, nstep, 0.99, L.SAMPLER_PHILOX), eng.last_pairs(B))[1] for _ in range(20)])
     assert len(np.unique(big[:, 0])) > 0.99 * E
     assert abs(big[:, 1].mean() - (T - nstep + 2) / 2) < 0.05 * T
+
+
+def test_in_process_hand_off_equals_the_file_path(tmp_path):
+    """episodes finished in this process reach the HBM sampler from memory (storage._fresh) instead of being re-read and
+    inflated from the file that was just written. Same batches, bit for bit, as a loader that only ever sees the files — including
+    episodes added between batches (the reference's fetch cycle, replay_buffer.py:192-212)."""
+    from exorl_amd.replay_buffer import ReplayBufferStorage, make_replay_loader
+    O, A, B = 6, 2, 16
+    eps = _synth.synth_episodes(21, [9, 14, 7, 11, 8, 12], O, A)
+    live = ReplayBufferStorage((), (), tmp_path / 'buffer')
+    for ep in eps[:3]:
+        live._store_episode(ep)
+    assert len(live._fresh) == 3
+    cold = ReplayBufferStorage((), (), tmp_path / 'buffer')          # a second process' view: nothing in memory
+    assert len(cold._fresh) == 0
+    its = []
+    for st in (live, cold):
+        random.seed(4)
+        np.random.seed(4)
+        its.append(iter(make_replay_loader(st, 10**6, B, 0, True, 2, 0.99, fetch_every=B)))
+    def same():
+        a, b = next(its[0]), next(its[1])
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    same()
+    assert len(live._fresh) == 0                                      # taken over by the sampler
+    for ep in eps[3:]:
+        live._store_episode(ep)                                        # new episodes while sampling (cold sees them as files)
+    for _ in range(4):
+        same()
+    assert [fn.name for fn in its[0].shards[0].fns] == [fn.name for fn in its[1].shards[0].fns] and len(its[0].shards[0].fns) == 6
+
+
+def test_pixel_arena_past_4_gib_is_addressed_with_64_bit_offsets():
+    """BASELINE config 4 keeps ~21 GB of uint8 frames in one arena: row * obs_bytes leaves 32 bits after row 202,900. A 4.7 GB arena
+    of (3, 84, 84) frames whose bytes are a function of their global row; samples drawn from the episodes past the 2^31- and 2^32-byte
+    marks (and from the first, for contrast) must come back bit-exact, n-step frame included."""
+    from exorl_amd.engine import ReplayEngine
+    from exorl_amd import _lib as L
+    OB, A, T, E, nstep = 3 * 84 * 84, 2, 250, 880, 3
+    rows = E * (T + 1)
+    assert rows * OB > (1 << 32) + (1 << 28)
+    eng = ReplayEngine((3, 84, 84), np.uint8, A, 0, rows + 8, E + 4)
+    base = (np.arange(OB) % 251).astype(np.uint8)
+
+    def frames(r0, n):       # frame of global row r: base + (37 r + (r >> 8)) mod 256, cheap to regenerate for any row
+        off = ((37 * np.arange(r0, r0 + n) + (np.arange(r0, r0 + n) >> 8)) & 255).astype(np.uint8)
+        return (base[None, :] + off[:, None]).reshape(n, 3, 84, 84)
+    slots = []
+    for e in range(E):
+        r0 = e * (T + 1)
+        act = np.tile(np.float32([e, 0.5]), (T + 1, 1))
+        slots.append(eng.append_episode(dict(observation=frames(r0, T + 1), action=act, reward=np.full((T + 1, 1), 1.0, np.float32),
+                                             discount=np.ones((T + 1, 1), np.float32))))
+    eng.set_order(slots)
+    picks = [0, 1, E // 2, (1 << 31) // (OB * (T + 1)) + 1, (1 << 32) // (OB * (T + 1)) + 1, E - 2, E - 1]
+    pairs = np.array([[e, idx] for e in picks for idx in (1, 17, T - nstep + 1)], np.int32)
+    obs, act, rew, disc, nobs = eng.sample(len(pairs), nstep, 0.99, L.SAMPLER_GIVEN, pairs=pairs)
+    for b, (e, idx) in enumerate(pairs):
+        r = e * (T + 1) + idx
+        assert np.array_equal(obs[b].cpu().numpy(), frames(r - 1, 1)[0]), (e, idx)
+        assert np.array_equal(nobs[b].cpu().numpy(), frames(r + nstep - 1, 1)[0]), (e, idx)
+        assert float(act[b, 0]) == e
+    assert (pairs[:, 0].astype(np.int64) * (T + 1) * OB).max() > (1 << 32)

@@ -52,3 +52,42 @@ def test_td3_bc_offline_loop_runs_through_the_captured_graph(tmp_path):
     assert ag.engine.opt_steps() == (50, 50)
     assert any(not torch.equal(p, q) for p, q in zip(before, ag.actor.parameters()))
     assert len(rows) == 5 and rows[0][1]['step'] == 0
+
+
+def test_offline_loop_equals_the_oracle_loop(tmp_path):
+    """the whole offline harness — dataset directory -> OfflineReplayBuffer-semantics loader (MT19937 streams seeded
+    like `utils.set_seed_everywhere`) -> TD3+BC agent.update() — against the oracle doing the same loop on the CPU: the oracle's
+    OfflineReplayBuffer restatement draws the batches (pinned to the reference by replay_offline_*.npz), OracleAgent makes the
+    updates (pinned by tiny_/full_td3_bc fixtures). Logged metrics must agree step by step to 1e-4 and the final actor too."""
+    import random
+    import _synth
+    from exorl_amd import agents
+    from exorl_amd.replay_buffer import load_episode
+    from exorl_amd.train_offline import train_offline
+    from oracle.agents import OracleAgent
+    from oracle.replay import OracleOfflineReplay
+    write_dataset(tmp_path / 'buffer', n_eps=7, ep_len=40)
+    torch.manual_seed(0)
+    ag = agents.TD3BCAgent('td3_bc', (O,), (A,), 'cuda', 1e-4, H, 0.01, '0.2', 1, B, 0.3, True, 2.5)
+    pa = [p.cpu().numpy().copy() for p in ag.actor.parameters()]
+    pc = [p.cpu().numpy().copy() for p in ag.critic.parameters()]
+    ns_gpu, ns_cpu = _synth.NoiseStream(5), _synth.NoiseStream(5)
+    ag.noise_hook = ns_gpu.draw
+    random.seed(3)
+    np.random.seed(3)
+    steps = 6
+    rows = train_offline(ag, tmp_path / 'buffer', steps, B, 0.99, replay_buffer_size=10**6, log_every_steps=1, sampler='mt19937', use_graph=False)
+    # the same loop on the CPU
+    files = sorted((tmp_path / 'buffer').glob('*.npz'))
+    directory = {f'episode_{fn.stem.split("_")[1]}_{fn.stem.split("_")[2]}.npz': load_episode(fn) for fn in files}
+    rb = OracleOfflineReplay(None, 10**6, 0, 0.99, relabel=False)
+    rb.seed(3, 3)
+    orc = OracleAgent('td3_bc', [p.reshape(q.shape) for p, q in zip(pa, pa)], pc)
+    for step in range(steps):
+        _, batch = rb.sample_batch(directory, B)
+        mo = orc.update(batch, step, ns_cpu.draw((B, A)), ns_cpu.draw((B, A)))
+        got = rows[step][1]
+        for k, v in mo.items():
+            assert abs(got[k] - v) <= 1e-4 * abs(v) + 1e-6, (step, k, got[k], v)
+    for p, q in zip(ag.actor.parameters(), orc.actor):
+        np.testing.assert_allclose(p.cpu().numpy().reshape(q.shape), q, rtol=1e-4, atol=2e-6)

@@ -139,8 +139,6 @@ def test_schedule_and_helpers(gold):
     assert np.array_equal(got, z['schedule'])
     with pytest.raises(NotImplementedError):
         utils.schedule('cosine(1,2)', 0)
-    assert utils.Until(10)(9) and not utils.Until(10)(10) and utils.Until(None)(10**9)
-    assert utils.Every(4)(8) and not utils.Every(4)(9) and not utils.Every(None)(0)
 
 
 def test_storage_writes_reference_format(tmp_path):
