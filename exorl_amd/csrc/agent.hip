@@ -273,7 +273,7 @@ static int net_backward(const NetDesc& d, const float* P, const NetShadow& sh, f
     const bool dx_fused = dx && !G;              // dgrad-only pass: d/d(input columns) in the LayerNorm-backward kernel itself
     EXORL_TRY(ln_bwd(b.dh1, f.h1, f.xhat, bf ? f.h1b : nullptr, bf ? f.xhatb : nullptr, f.rstd, P + d.g, pt.Pt, rows, H, d.n_trunks,
                      act, d.trunk_stride, G ? 1 : 0, s, dx_fused ? sh.w0t + (int64_t)dx_col0 * H : nullptr, (int64_t)d.in_dim * H,
-                     dx_fused ? dx : nullptr, dx_cols, bf ? f.h1l : nullptr, bf ? f.xhatl : nullptr));
+                     dx_fused ? dx : nullptr, dx_cols, bf ? f.h1l : nullptr, bf ? f.xhatl : nullptr, (bf && trunk_fwd16_supported(H)) ? P + d.beta : nullptr));
     if (dx && !dx_fused)       // dx[m][j] = sum_c dz0[m][c] W0[c][col0+j]: a row-dot against rows col0.. of the transposed shadow
         EXORL_TRY(head_fwd4(b.dh1, sh.w0t + (int64_t)dx_col0 * H, nullptr, dx, rows, H, dx_cols, 0, d.n_trunks, act,
                             (int64_t)d.in_dim * H, (int64_t)rows * dx_cols, s));

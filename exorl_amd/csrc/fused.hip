@@ -410,16 +410,17 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(float* dh, const float* __r
                                                      float* __restrict__ P, int rows, int H, int64_t astride,
                                                      int64_t pstride, const float* __restrict__ w0t, int64_t tstride,
                                                      float* __restrict__ dx, int dx_cols, const unsigned short* __restrict__ hl,
-                                                     const unsigned short* __restrict__ xhl, int iters) {
+                                                     const unsigned short* __restrict__ xhl, int iters, const float* __restrict__ beta) {
     __shared__ __attribute__((aligned(16))) float red[PARAMS ? 8 * 1024 : 4];
     const int net = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H4 = H >> 2;
-    float4 g[4], pg[4], pb[4], pb0[4];
+    float4 g[4], be[4], pg[4], pb[4], pb0[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c4 = lane + 64 * i;
         g[i] = c4 < H4 ? reinterpret_cast<const float4*>(gain + net * pstride)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        be[i] = (B16 && beta && c4 < H4) ? reinterpret_cast<const float4*>(beta + net * pstride)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
         pg[i] = pb[i] = pb0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     for (int it = 0; it < iters; ++it) {           // 8 rows per pass; large batches take 4 passes per workgroup (4x fewer partial rows)
@@ -435,13 +436,20 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(float* dh, const float* __r
             if (c4 < H4) {
                 float4 hv;
                 if constexpr (B16) {
-                    hv = bf4_to_f4(reinterpret_cast<const ushort4*>(hb + o)[c4]);
                     xh[i] = bf4_to_f4(reinterpret_cast<const ushort4*>(xhb + o)[c4]);
-                    if (hl) {                            // split-bf16 mode: hi + lo planes
-                        const float4 l1 = bf4_to_f4(reinterpret_cast<const ushort4*>(hl + o)[c4]);
+                    if (xhl) {                           // split-bf16 mode: hi + lo planes
                         const float4 l2 = bf4_to_f4(reinterpret_cast<const ushort4*>(xhl + o)[c4]);
-                        hv.x += l1.x; hv.y += l1.y; hv.z += l1.z; hv.w += l1.w;
                         xh[i].x += l2.x; xh[i].y += l2.y; xh[i].z += l2.z; xh[i].w += l2.w;
+                    }
+                    if (beta) {                          // h = tanh(xhat * g + beta) again (as the forward formed it) instead of reading its planes:
+                        hv.x = tanh_fast(xh[i].x * g[i].x + be[i].x); hv.y = tanh_fast(xh[i].y * g[i].y + be[i].y);     // 4 B per element less
+                        hv.z = tanh_fast(xh[i].z * g[i].z + be[i].z); hv.w = tanh_fast(xh[i].w * g[i].w + be[i].w);
+                    } else {
+                        hv = bf4_to_f4(reinterpret_cast<const ushort4*>(hb + o)[c4]);
+                        if (hl) {
+                            const float4 l1 = bf4_to_f4(reinterpret_cast<const ushort4*>(hl + o)[c4]);
+                            hv.x += l1.x; hv.y += l1.y; hv.z += l1.z; hv.w += l1.w;
+                        }
                     }
                 } else {
                     hv = reinterpret_cast<const float4*>(h + o)[c4];
@@ -526,14 +534,14 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(float* dh, const float* __r
 int ln_bwd(float* dh, const float* h, const float* xhat, const unsigned short* h_bf16, const unsigned short* xhat_bf16,
            const float* rstd, const float* gain, float* P, int rows, int H, int nets, int64_t astride, int64_t pstride,
            int want_params, hipStream_t s, const float* w0t, int64_t tstride, float* dx, int dx_cols, const unsigned short* h_lo,
-           const unsigned short* xhat_lo) {
+           const unsigned short* xhat_lo, const float* beta) {
     EXORL_REQUIRE(H >= 4 && H <= 1024 && H % 4 == 0, "ln_bwd: unsupported H=%d", H);
     EXORL_REQUIRE(!dx || (!want_params && w0t && dx_cols >= 1), "ln_bwd: the dx epilogue belongs to the dgrad-only pass");
     const dim3 grid(trunk_chunks(rows), nets);
     const bool b16 = h_bf16 && xhat_bf16;
     const int iters = tb_iters(rows);
     EXORL_REQUIRE((h_lo != nullptr) == (xhat_lo != nullptr) && (!h_lo || b16), "ln_bwd: lo planes come in pairs, with the bf16 hi planes");
-#define EXORL_LNB(PA, BB) hipLaunchKernelGGL((ln_bwd_kernel<PA, BB>), grid, dim3(512), 0, s, dh, h, xhat, h_bf16, xhat_bf16, rstd, gain, P, rows, H, astride, pstride, w0t, tstride, dx, dx_cols, h_lo, xhat_lo, iters)
+#define EXORL_LNB(PA, BB) hipLaunchKernelGGL((ln_bwd_kernel<PA, BB>), grid, dim3(512), 0, s, dh, h, xhat, h_bf16, xhat_bf16, rstd, gain, P, rows, H, astride, pstride, w0t, tstride, dx, dx_cols, h_lo, xhat_lo, iters, beta)
     if (want_params) { if (b16) EXORL_LNB(true, true); else EXORL_LNB(true, false); }
     else             { if (b16) EXORL_LNB(false, true); else EXORL_LNB(false, false); }
 #undef EXORL_LNB
@@ -1116,29 +1124,48 @@ __global__ __launch_bounds__(256) void finalize_adam_kernel(FinalizeArgs f, Fuse
     const AdamConst c = *a.c;
     if (a.bump && blockIdx.x == 0 && threadIdx.x == 0) *a.bump += 1ull;
     const int H = f.H;
-    if ((int)blockIdx.x >= nb_fin) {             // H x H weights: float4 streams, gradient straight from the wgrad GEMM
-        const int64_t hh4 = (int64_t)H * H / 4, n4 = a.n_heads * hh4;
-        for (int64_t i = (int64_t)(blockIdx.x - nb_fin) * blockDim.x + threadIdx.x; i < n4; i += (int64_t)(gridDim.x - nb_fin) * blockDim.x) {
-            const int t = (int)(i / hh4);
-            const int64_t e4 = i % hh4, gi4 = a.w1_off[t] / 4 + e4;
-            float4 pv = reinterpret_cast<float4*>(a.p)[gi4];
-            const float4 gv = reinterpret_cast<const float4*>(a.g)[gi4];
-            float4 mv = reinterpret_cast<float4*>(a.m)[gi4];
-            float4 vv = reinterpret_cast<float4*>(a.v)[gi4];
-            float4 tv = a.target ? reinterpret_cast<float4*>(a.target)[gi4] : make_float4(0.f, 0.f, 0.f, 0.f);     // all five streams in flight
-            adam_elem(pv.x, gv.x, mv.x, vv.x, c); adam_elem(pv.y, gv.y, mv.y, vv.y, c);
-            adam_elem(pv.z, gv.z, mv.z, vv.z, c); adam_elem(pv.w, gv.w, mv.w, vv.w, c);
-            reinterpret_cast<float4*>(a.p)[gi4] = pv;
-            reinterpret_cast<float4*>(a.m)[gi4] = mv;
-            reinterpret_cast<float4*>(a.v)[gi4] = vv;
-            if (sh.w1b) reinterpret_cast<ushort4*>(sh.w1b + (int64_t)t * H * H)[e4] = f4_to_bf4(pv);
-            if (sh.w1l) reinterpret_cast<ushort4*>(sh.w1l + (int64_t)t * H * H)[e4] = f4_to_bf4_lo(pv);
+    if ((int)blockIdx.x >= nb_fin) {             // H x H weights: gradient straight from the wgrad GEMM. 8 consecutive elements per thread
+        // and pass: ten 16-byte loads in flight, and the bf16 hi/lo planes leave as 16-byte stores too (8-byte stores run at ~0.6 of the
+        // 16-byte rate, MI355X_MICROARCH.md) — the pass is HBM-bound (44 B per element with a target)
+        const int64_t hh8 = (int64_t)H * H / 8, n8 = a.n_heads * hh8;
+        for (int64_t i = (int64_t)(blockIdx.x - nb_fin) * blockDim.x + threadIdx.x; i < n8; i += (int64_t)(gridDim.x - nb_fin) * blockDim.x) {
+            const int t = (int)(i / hh8);
+            const int64_t e8 = i % hh8, gi4 = a.w1_off[t] / 4 + 2 * e8;
+            float4 pv[2], gv[2], mv[2], vv[2], tv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                pv[u] = reinterpret_cast<float4*>(a.p)[gi4 + u];
+                gv[u] = reinterpret_cast<const float4*>(a.g)[gi4 + u];
+                mv[u] = reinterpret_cast<float4*>(a.m)[gi4 + u];
+                vv[u] = reinterpret_cast<float4*>(a.v)[gi4 + u];
+                tv[u] = a.target ? reinterpret_cast<float4*>(a.target)[gi4 + u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            ushort4 bh[2], bl[2], th[2], tl[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                adam_elem(pv[u].x, gv[u].x, mv[u].x, vv[u].x, c); adam_elem(pv[u].y, gv[u].y, mv[u].y, vv[u].y, c);
+                adam_elem(pv[u].z, gv[u].z, mv[u].z, vv[u].z, c); adam_elem(pv[u].w, gv[u].w, mv[u].w, vv[u].w, c);
+                reinterpret_cast<float4*>(a.p)[gi4 + u] = pv[u];
+                reinterpret_cast<float4*>(a.m)[gi4 + u] = mv[u];
+                reinterpret_cast<float4*>(a.v)[gi4 + u] = vv[u];
+                bh[u] = f4_to_bf4(pv[u]); bl[u] = f4_to_bf4_lo(pv[u]);
+                if (a.target) {
+                    tv[u].x = polyak(pv[u].x, tv[u].x, c.tau, c.one_minus_tau); tv[u].y = polyak(pv[u].y, tv[u].y, c.tau, c.one_minus_tau);
+                    tv[u].z = polyak(pv[u].z, tv[u].z, c.tau, c.one_minus_tau); tv[u].w = polyak(pv[u].w, tv[u].w, c.tau, c.one_minus_tau);
+                    reinterpret_cast<float4*>(a.target)[gi4 + u] = tv[u];
+                    th[u] = f4_to_bf4(tv[u]); tl[u] = f4_to_bf4_lo(tv[u]);
+                }
+            }
+            auto pack = [](const ushort4& x, const ushort4& y) {
+                uint4 r;
+                r.x = x.x | ((unsigned)x.y << 16); r.y = x.z | ((unsigned)x.w << 16); r.z = y.x | ((unsigned)y.y << 16); r.w = y.z | ((unsigned)y.w << 16);
+                return r;
+            };
+            if (sh.w1b) reinterpret_cast<uint4*>(sh.w1b + (int64_t)t * H * H)[e8] = pack(bh[0], bh[1]);
+            if (sh.w1l) reinterpret_cast<uint4*>(sh.w1l + (int64_t)t * H * H)[e8] = pack(bl[0], bl[1]);
             if (a.target) {
-                tv.x = polyak(pv.x, tv.x, c.tau, c.one_minus_tau); tv.y = polyak(pv.y, tv.y, c.tau, c.one_minus_tau);
-                tv.z = polyak(pv.z, tv.z, c.tau, c.one_minus_tau); tv.w = polyak(pv.w, tv.w, c.tau, c.one_minus_tau);
-                reinterpret_cast<float4*>(a.target)[gi4] = tv;
-                if (sh.t_w1b) reinterpret_cast<ushort4*>(sh.t_w1b + (int64_t)t * H * H)[e4] = f4_to_bf4(tv);
-                if (sh.t_w1l) reinterpret_cast<ushort4*>(sh.t_w1l + (int64_t)t * H * H)[e4] = f4_to_bf4_lo(tv);
+                if (sh.t_w1b) reinterpret_cast<uint4*>(sh.t_w1b + (int64_t)t * H * H)[e8] = pack(th[0], th[1]);
+                if (sh.t_w1l) reinterpret_cast<uint4*>(sh.t_w1l + (int64_t)t * H * H)[e8] = pack(tl[0], tl[1]);
             }
         }
         return;
@@ -1188,10 +1215,10 @@ __global__ __launch_bounds__(256) void finalize_adam_kernel(FinalizeArgs f, Fuse
 }
 
 int finalize_adam(const FinalizeArgs& f, const FusedAdamArgs& a, const ShadowSpec& sh, hipStream_t s) {
-    EXORL_REQUIRE(f.H % 2 == 0 && a.n_heads >= 1 && a.n_heads <= 2, "finalize_adam: unsupported geometry");
+    EXORL_REQUIRE(f.H % 4 == 0 && a.n_heads >= 1 && a.n_heads <= 2, "finalize_adam: unsupported geometry");
     const int64_t total = f.n_heads * ((int64_t)(f.nout + 1) * f.H + (f.nout > 16 ? 32 : 16)) + f.n_trunks * (int64_t)(3 + f.in_dim) * f.H;
     const int nb_fin = cdiv(total, 256);
-    int nb_w1 = cdiv((int64_t)a.n_heads * f.H * f.H / 4, 256);
+    int nb_w1 = cdiv((int64_t)a.n_heads * f.H * f.H / 8, 256);
     if (nb_w1 > 2048) nb_w1 = 2048;
     hipLaunchKernelGGL(finalize_adam_kernel, dim3(nb_fin + nb_w1), dim3(256), 0, s, f, a, sh, nb_fin);
     EXORL_LAUNCH_CHECK();

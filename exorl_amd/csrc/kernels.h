@@ -77,7 +77,7 @@ int trunk_fwd16(const float* x, int64_t ldx, const unsigned short* W0b, const fl
 int ln_bwd(float* dh, const float* h, const float* xhat, const unsigned short* h_bf16, const unsigned short* xhat_bf16,
            const float* rstd, const float* gain, float* P, int rows, int H, int nets, int64_t astride, int64_t pstride,
            int want_params, hipStream_t s, const float* w0t = nullptr, int64_t tstride = 0, float* dx = nullptr, int dx_cols = 0,
-           const unsigned short* h_lo = nullptr, const unsigned short* xhat_lo = nullptr);
+           const unsigned short* h_lo = nullptr, const unsigned short* xhat_lo = nullptr, const float* beta = nullptr);
 int trunk_chunks(int rows);
 // k smallest L2 distances of every src row to the tgt rows, ascending (knn.hip); d2 = scratch, n_src x round_up(n_tgt, 64) floats
 int knn_topk(const float* src, int n_src, const float* tgt, int n_tgt, int dim, int k, float* out, float* d2, hipStream_t s);
