@@ -272,9 +272,10 @@ def main():
                 traffic = tj['traffic_bytes_per_launch']
         out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic,
                            'traffic_source': traffic_src, 'traffic_source_commit': (traffic_src or {}).get('commit'),
-                           'kernel': {'bf16': 'gemm16g_kernel / gemm16g_mixed_kernel (grouped 2-4 x [1024x1024x1024]: fwd, dgrad, wgrad+dgrad of Linear(H,H))',
-                                      'bf16x3': 'gemm16x3_kernel / gemm16x3_mixed_kernel (grouped 2-4 x [1024x1024x1024] on hi/lo bf16 planes: fwd, dgrad, '
-                                                'wgrad+dgrad of Linear(H,H))',
+                           'kernel': {'bf16': 'gemm16p_kernel / gemm16p_mixed_kernel (grouped 2-4 x [1024x1024x1024], 128 x 128 / 128 x 64 tiles: fwd, dgrad, '
+                                              'wgrad+dgrad of Linear(H,H))',
+                                      'bf16x3': 'gemm16p_kernel / gemm16p_mixed_kernel (grouped 2-4 x [1024x1024x1024] on hi/lo bf16 planes, 128 x 128 / 128 x 64 '
+                                                'tiles, k32 stages, XCD-local tile blocks: fwd, dgrad, wgrad+dgrad of Linear(H,H))',
                                       'fp32': 'gemm_kernel (grouped 2x[1024x1024x1024], fwd/dgrad/wgrad of Linear(H,H))'}[args.precision],
                            'flop_convention': 'algorithmic 2*M*N*K (split-bf16 issues 3 MFMAs per product; they are not counted)',
                            'launches': int(big.sum()), 'event_overhead_us': float(ovh.value * 1e3),

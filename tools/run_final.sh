@@ -1,8 +1,9 @@
-# Round-end evidence run on the GPU box: full GPU suite, smoke, default bench, rocprofv3 kernel stats, reward-free and pixel rates.
-set -e
+# Round-end evidence run on the GPU box (tools/gpu.sh stamps the commit first): GPU suite, smoke, default bench, rocprofv3 kernel stats of
+# the default bench command, per-step kernel summary, FETCH/WRITE PMC passes -> traffic JSON (stamped with commit + kernel names),
+# MFMA-utilisation pass, other configs' update rates.     usage: bash tools/run_final.sh <tag>      -> gpurun_out/<tag>_*
 R=$GRAFT_REPO_ROOT
 cd $R
-T=${1:-v13}
+T=${1:-r02}
 timeout -k 10 1000 python -m pytest tests -x -q -m gpu > gpurun_out/${T}_gpu_tests.log 2>&1 || { tail -30 gpurun_out/${T}_gpu_tests.log; exit 1; }
 tail -2 gpurun_out/${T}_gpu_tests.log
 python __graft_entry__.py smoke > gpurun_out/${T}_smoke.log 2>&1 || { tail -20 gpurun_out/${T}_smoke.log; exit 1; }
@@ -10,16 +11,27 @@ tail -1 gpurun_out/${T}_smoke.log
 python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
 cat gpurun_out/${T}_bench.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_prof -o k -- python3 $R/bench.py --graph 0 --no-cpu-baseline --no-roofline --no-other-modes --steps 200 --warmup 20 > $R/gpurun_out/${T}_prof.log 2>&1
+# the default command, as the driver runs it (graph mode, all three precisions, instrumented pass)
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_prof_default -o d -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${T}_prof_default.log 2>&1
+BARGS="--graph 0 --no-cpu-baseline --no-roofline --no-other-modes"
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_prof -o k -- python3 $R/bench.py $BARGS --steps 200 --warmup 20 > $R/gpurun_out/${T}_prof.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${T}_pmc_fetch -o f -- python3 $R/bench.py $BARGS --steps 25 --warmup 5 > $R/gpurun_out/${T}_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${T}_pmc_write -o w -- python3 $R/bench.py $BARGS --steps 25 --warmup 5 > $R/gpurun_out/${T}_pmc_write.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $R/gpurun_out/${T}_pmc_l2 -o l -- python3 $R/bench.py $BARGS --steps 25 --warmup 5 > $R/gpurun_out/${T}_pmc_l2.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/gpurun_out/${T}_pmc_mfma -o m -- python3 $R/bench.py $BARGS --steps 25 --warmup 5 > $R/gpurun_out/${T}_pmc_mfma.log 2>&1
 cd $R
-python tools/prof_summary.py gpurun_out/${T}_prof/k_kernel_trace.csv 220 > gpurun_out/${T}_kernel_summary.txt
-rm -f gpurun_out/${T}_prof/k_kernel_trace.csv
+cp gpurun_out/${T}_prof_default/d_kernel_stats.csv gpurun_out/${T}_rocprofv3_kernel_stats_default_bench.csv
+python tools/prof_summary.py gpurun_out/${T}_prof/k_kernel_trace.csv 220 > gpurun_out/${T}_kernel_summary_bf16x3.txt
+python tools/pmc_traffic.py gpurun_out/${T}_pmc_fetch/f_counter_collection.csv gpurun_out/${T}_pmc_write/w_counter_collection.csv gemm16p gpurun_out/${T}_pmc_traffic_bf16x3.json "eager launches of the bench step (--graph 0), 25 steps" > /dev/null
+for p in fetch write l2 mfma; do python tools/pmc_summary.py gpurun_out/${T}_pmc_$p/*_counter_collection.csv > gpurun_out/${T}_pmc_${p}_summary.txt; done
+rm -f gpurun_out/${T}_prof/k_kernel_trace.csv gpurun_out/${T}_prof_default/d_kernel_trace.csv gpurun_out/${T}_pmc_*/*.csv
+head -30 gpurun_out/${T}_kernel_summary_bf16x3.txt
+cat gpurun_out/${T}_pmc_traffic_bf16x3.json
+head -12 gpurun_out/${T}_pmc_l2_summary.txt
+head -12 gpurun_out/${T}_pmc_mfma_summary.txt
+for a in "cql 78 12 1024" "td3 17 6 512" "td3 17 6 4096" "crr 24 6 1024" "bc 24 6 256 fp32,bf16x3"; do python tools/micro/offline_bench.py $a 2>&1 | grep -v amdgpu.ids >> gpurun_out/${T}_offline.txt; done
+cat gpurun_out/${T}_offline.txt
 python tools/micro/unsup_bench.py --precision fp32,bf16x3 2>&1 | grep -v amdgpu.ids > gpurun_out/${T}_unsup.txt
 cat gpurun_out/${T}_unsup.txt
 for a in "proto fp32" "proto bf16x3" "ddpg fp32" "ddpg bf16x3"; do set -- $a; python tools/micro/pixel_bench.py 1024 $1 $2 2>&1 | grep -v amdgpu.ids >> gpurun_out/${T}_pixels.txt; done
 cat gpurun_out/${T}_pixels.txt
-for a in "cql 78 12 1024" "td3 17 6 512" "td3 17 6 4096" "crr 24 6 1024" "bc 24 6 256 fp32,bf16x3"; do python tools/micro/offline_bench.py $a 2>&1 | grep -v amdgpu.ids >> gpurun_out/${T}_offline.txt; done
-cat gpurun_out/${T}_offline.txt
-bash tools/prof_pixels.sh proto bf16x3 > /dev/null
-bash tools/prof_unsup.sh icm_apt bf16x3 > /dev/null
-bash tools/prof_unsup.sh proto bf16x3 > /dev/null
