@@ -255,7 +255,11 @@ def main():
         L.check(lib.exorl_profile_gemm(0))
         ovh = L.C.c_float()
         L.check(lib.exorl_profile_event_overhead(L.C.byref(ovh), L.current_stream()))
-        fl, ms = fl[:n.value], np.maximum(ms[:n.value] - ovh.value, 1e-4)       # minus the empty event-bracket time
+        # An empty event bracket costs ~4.6 us, but only ~0.7 of it remains once a kernel sits between the two markers: calibrated against the
+        # rocprofv3 --kernel-trace durations of the same launches (round 1: 27.5 raw vs 24.4 -> 0.67; round 2: 26.1 vs 22.9 -> 0.70), so that
+        # avg_us agrees with profiles/*_rocprofv3_kernel_stats_default_bench.csv instead of flattering the kernel by ~1.5 us per launch
+        EVENT_OVERHEAD_KEPT = 0.7
+        fl, ms = fl[:n.value], np.maximum(ms[:n.value] - EVENT_OVERHEAD_KEPT * ovh.value, 1e-4)
         big = fl >= 2.0 * 2 * B * H * H * 0.99           # the two-problem 1024^3 launches (fwd / dgrad / wgrad of Linear(H,H))
         ach = float(fl[big].mean() / (ms[big].mean() * 1e-3) / 1e12)
         peak = PEAK_TFLOPS[args.precision]
@@ -278,7 +282,7 @@ def main():
                                                 'tiles, k32 stages, XCD-local tile blocks: fwd, dgrad, wgrad+dgrad of Linear(H,H))',
                                       'fp32': 'gemm_kernel (grouped 2x[1024x1024x1024], fwd/dgrad/wgrad of Linear(H,H))'}[args.precision],
                            'flop_convention': 'algorithmic 2*M*N*K (split-bf16 issues 3 MFMAs per product; they are not counted)',
-                           'launches': int(big.sum()), 'event_overhead_us': float(ovh.value * 1e3),
+                           'launches': int(big.sum()), 'event_overhead_us': float(ovh.value * 1e3), 'event_overhead_subtracted_us': float(0.7 * ovh.value * 1e3),
                            'avg_us': float(ms[big].mean() * 1e3), 'flop_per_launch': float(fl[big].mean()),
                            'all_gemm_us_per_step': float(ms.sum() * 1e3 / nprof), 'gemm_launches_per_step': n.value / nprof}
     if world == 1 and not args.no_other_modes:
