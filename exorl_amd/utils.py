@@ -1,6 +1,8 @@
 """Host-side helpers with the reference's names and meaning (/root/reference/utils/utils.py), for the
 callers of the hot path (pretrain.py / train_offline.py use utils.eval_mode, utils.schedule, utils.set_seed_everywhere ...).
 The tensor math these names used to do on the update path now lives in libexorl_hip.so."""
+import contextlib
+import functools
 import random
 import re
 
@@ -8,51 +10,61 @@ import numpy as np
 import torch
 
 
-class eval_mode:
-    """utils.py:15-28 — temporarily puts objects with .training/.train() in eval mode."""
-
-    def __init__(self, *models):
-        self.models = models
-
-    def __enter__(self):
-        self.prev_states = [m.training for m in self.models]
-        for m in self.models:
+@contextlib.contextmanager
+def eval_mode(*models):
+    """`with utils.eval_mode(agent): ...` (reference utils.py:15-28): everything with a .training flag and a .train(bool) method is
+    switched to eval for the duration of the block and put back the way it was, also when the block raises."""
+    before = [(m, m.training) for m in models]
+    try:
+        for m, _ in before:
             m.train(False)
-
-    def __exit__(self, *args):
-        for m, state in zip(self.models, self.prev_states):
-            m.train(state)
-        return False
+        yield
+    finally:
+        for m, was in before:
+            m.train(was)
 
 
 def set_seed_everywhere(seed):
-    """utils.py:31-36."""
-    torch.manual_seed(seed)
+    """Seeds the four generators the reference seeds (utils.py:31-36); the HBM replay's MT19937 sampler continues from the `random` /
+    `np.random` state this leaves behind (replay_buffer.py:169,222)."""
+    for seeder in (torch.manual_seed, np.random.seed, random.seed):
+        seeder(seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(seed)
-    np.random.seed(seed)
-    random.seed(seed)
+
+
+_SCHEDULE = re.compile(r'^(linear|step_linear)\((.+)\)$')
+
+
+@functools.lru_cache(maxsize=256)
+def _schedule_segments(spec):
+    """'linear(a,b,T)' -> [(0, T, a, b)]; 'step_linear(a,b,T1,c,T2)' -> [(0, T1, a, b), (T1, T2, b, c)]; a bare number -> a constant.
+    Each segment is (start, duration, value at start, value at end)."""
+    try:
+        return float(spec)
+    except ValueError:
+        pass
+    m = _SCHEDULE.match(spec)
+    if m:
+        v = [float(x) for x in m.group(2).split(',')]
+        if m.group(1) == 'linear' and len(v) == 3:
+            return ((0.0, v[2], v[0], v[1]),)
+        if m.group(1) == 'step_linear' and len(v) == 5:
+            return ((0.0, v[2], v[0], v[1]), (v[2], v[4], v[1], v[3]))
+    raise NotImplementedError(spec)
 
 
 def schedule(schdl, step):
-    """utils.py:199-219: constant | linear(init,final,duration) | step_linear(init,f1,d1,f2,d2)."""
-    try:
-        return float(schdl)
-    except ValueError:
-        m = re.match(r'linear\((.+),(.+),(.+)\)', schdl)
-        if m:
-            init, final, duration = (float(g) for g in m.groups())
-            mix = float(np.clip(step / duration, 0.0, 1.0))
-            return (1.0 - mix) * init + mix * final
-        m = re.match(r'step_linear\((.+),(.+),(.+),(.+),(.+)\)', schdl)
-        if m:
-            init, final1, duration1, final2, duration2 = (float(g) for g in m.groups())
-            if step <= duration1:
-                mix = float(np.clip(step / duration1, 0.0, 1.0))
-                return (1.0 - mix) * init + mix * final1
-            mix = float(np.clip((step - duration1) / duration2, 0.0, 1.0))
-            return (1.0 - mix) * final1 + mix * final2
-    raise NotImplementedError(schdl)
+    """The stddev schedule grammar of the agent YAMLs (utils.py:199-219) as a table of linear segments: the value at `step` on the segment
+    that contains it (a step ON a boundary belongs to the segment that ends there), clamped past the last one. Per segment the same
+    double-precision expression as the reference, (1 - mix) * v0 + mix * v1 with mix = clip((step - start) / duration, 0, 1), so the
+    values are bit-identical (tests/golden/utils_g2.npz)."""
+    segs = _schedule_segments(schdl if isinstance(schdl, str) else repr(float(schdl)))
+    if isinstance(segs, float):
+        return segs
+    start, duration, v0, v1 = next((sg for sg in segs if step <= sg[0] + sg[1]), segs[-1])
+    mix = min(max((step - start) / duration, 0.0), 1.0)
+    return (1.0 - mix) * v0 + mix * v1
 
 
 def to_torch(xs, device):
