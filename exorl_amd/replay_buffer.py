@@ -11,7 +11,6 @@ is one HIP launch per batch. Tensors come back on the GPU (the reference's next 
 utils.py:55-56, so agents accept either).
 """
 import bisect
-import io
 import os
 from collections import OrderedDict, defaultdict
 from pathlib import Path
@@ -24,22 +23,25 @@ from .engine import ReplayEngine
 
 
 def episode_len(episode):
-    # first row of every array is the reset step (zero action / reward): replay_buffer.py:13-15
-    return next(iter(episode.values())).shape[0] - 1
+    """Transitions in an episode dict: every array carries one extra leading row, the reset step (replay_buffer.py:13-15)."""
+    first = next(iter(episode.values()))
+    return len(first) - 1
 
 
 def save_episode(episode, fn):
-    with io.BytesIO() as bs:
-        np.savez_compressed(bs, **episode)
-        bs.seek(0)
-        with Path(fn).open('wb') as f:
-            f.write(bs.read())
+    """One episode -> one compressed .npz (the reference's on-disk format, replay_buffer.py:18-23). Written under a temporary name and
+    renamed, so a loader scanning the directory never sees a half-written file under a name its glob('*.npz') matches."""
+    fn = Path(fn)
+    tmp = fn.with_name(fn.name + '.part')
+    with tmp.open('wb') as f:
+        np.savez_compressed(f, **episode)
+    os.replace(tmp, fn)
 
 
 def load_episode(fn):
-    with Path(fn).open('rb') as f:
-        z = np.load(f)
-        return {k: z[k] for k in z.keys()}
+    """{key: array} of one episode file (replay_buffer.py:25-29); arrays are materialised before the file is closed."""
+    with np.load(Path(fn)) as z:
+        return {k: z[k] for k in z.files}
 
 
 def _load_or_none(fn):
@@ -93,20 +95,22 @@ class ReplayBufferStorage:
         return self._num_transitions
 
     def add(self, time_step, meta):
+        """One environment step (replay_buffer.py:120-141): meta values and the spec'd fields of `time_step` are appended to the open
+        episode; scalars are broadcast to their spec's shape; the step that ends the episode flushes it to disk."""
+        cur = self._current_episode
         for key, value in meta.items():
-            self._current_episode[key].append(value)
+            cur[key].append(value)
         for spec in self._data_specs:
             value = time_step[spec.name]
             if np.isscalar(value):
                 value = np.full(spec.shape, value, spec.dtype)
-            assert spec.shape == value.shape and spec.dtype == value.dtype
-            self._current_episode[spec.name].append(value)
-        if time_step.last():
-            episode = {}
-            for spec in list(self._data_specs) + list(self._meta_specs):
-                episode[spec.name] = np.array(self._current_episode[spec.name], spec.dtype)
-            self._current_episode = defaultdict(list)
-            self._store_episode(episode)
+            if value.shape != spec.shape or value.dtype != spec.dtype:
+                raise AssertionError(f'{spec.name}: got {value.shape} {value.dtype}, spec says {spec.shape} {spec.dtype}')
+            cur[spec.name].append(value)
+        if not time_step.last():
+            return
+        self._current_episode = defaultdict(list)
+        self._store_episode({spec.name: np.array(cur[spec.name], spec.dtype) for spec in (*self._data_specs, *self._meta_specs)})
 
     def _store_episode(self, episode):
         idx, length = self._num_episodes, episode_len(episode)
