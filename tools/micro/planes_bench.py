@@ -1,6 +1,6 @@
 """Grouped GEMM on bf16 hi/lo planes (exorl_gemm_planes) at the agent's launch shapes: correctness against a float64 product of the
 SAME planes, and time per launch by variant (exorl_gemm_tune bits: 262144 = previous kernels, 0 = 128 x TN / k32 / XCD-local,
-1048576 = the same in id order, 524288 = 128 x 128 everywhere).   python tools/micro/planes_bench.py [check]"""
+1048576 = the same in id order, 524288 = 128 x 128 everywhere, 2097152 = 32-wide stages also for the row-image (forward) launches, whose default is 64-wide x 2).   python tools/micro/planes_bench.py [check]"""
 import sys
 from pathlib import Path
 
@@ -86,7 +86,7 @@ if __name__ == '__main__':
     for x3 in (True, False):
         for tag, count, lay, bl, M, N, K in SHAPES:
             ps = make(count, lay, bl, M, N, K, x3)
-            for variant in (0, 524288):
+            for variant in (0, 524288, 2097152):
                 lib.exorl_gemm_tune(variant)
                 for p in ps:
                     p[2].zero_()
@@ -102,7 +102,7 @@ if __name__ == '__main__':
             if check_only:
                 print(f'{"x3" if x3 else "bf16":5s} {tag:26s} ok (max rel err {worst:.1e})', flush=True)
                 continue
-            ts = {v: timed(ps, lay, bl, M, N, K, x3, v) for v in (262144, 0, 1048576, 524288)}
+            ts = {v: timed(ps, lay, bl, M, N, K, x3, v) for v in (262144, 0, 1048576, 524288, 2097152)}
             fl = 2.0 * M * N * K * count
             print(f'{"x3" if x3 else "bf16":5s} {tag:26s} old {ts[262144]:6.2f} us | new {ts[0]:6.2f} us ({fl / ts[0] / 1e6:6.0f} TF/s) | new, id order '
-                  f'{ts[1048576]:6.2f} | 128x128 everywhere {ts[524288]:6.2f}   (err {worst:.1e})', flush=True)
+                  f'{ts[1048576]:6.2f} | 128x128 everywhere {ts[524288]:6.2f} | fwd on k32 stages {ts[2097152]:6.2f}   (err {worst:.1e})', flush=True)
