@@ -403,7 +403,11 @@ __device__ __forceinline__ float wave_sum8(const float (&v)[8], int lane) {
 // B16: h and xhat are read from their bf16 copies (fast mode keeps no fp32 copies of the trunk activations)
 // dx != nullptr (dgrad-only pass): dx[net][row][j] = sum_c dz[row][c] W0T[j][c], j < dx_cols — the d/d(action) the actor
 // step needs (td3_bc.py:152-155) formed from the dz row while it is still in registers; dz itself is then not stored.
-template <bool PARAMS, bool B16>
+// LO: the bf16 copies come as hi + lo planes (split-bf16); RECOMP: h = tanh(xhat g + beta) is recomputed instead of read. Both are template
+// parameters, and every load below is unconditional (column index clamped, surplus lanes masked afterwards): a null check or a bounds
+// guard around a load compiles to branch + load + s_waitcnt vmcnt(0), i.e. the twelve to sixteen loads of a row — and the 24 weight
+// loads of the d/d(action) epilogue — one L2 round trip at a time.
+template <bool PARAMS, bool B16, bool LO, bool RECOMP>
 __global__ __launch_bounds__(512) void ln_bwd_kernel(float* dh, const float* __restrict__ h, const float* __restrict__ xhat,
                                                      const unsigned short* __restrict__ hb, const unsigned short* __restrict__ xhb,
                                                      const float* __restrict__ rstd, const float* __restrict__ gain,
@@ -420,7 +424,7 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(float* dh, const float* __r
     for (int i = 0; i < 4; ++i) {
         const int c4 = lane + 64 * i;
         g[i] = c4 < H4 ? reinterpret_cast<const float4*>(gain + net * pstride)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-        be[i] = (B16 && beta && c4 < H4) ? reinterpret_cast<const float4*>(beta + net * pstride)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        be[i] = (RECOMP && c4 < H4) ? reinterpret_cast<const float4*>(beta + net * pstride)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
         pg[i] = pb[i] = pb0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     for (int it = 0; it < iters; ++it) {           // 8 rows per pass; large batches take 4 passes per workgroup (4x fewer partial rows)
@@ -429,33 +433,52 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(float* dh, const float* __r
         const int64_t o = net * astride + (int64_t)row * H;
         float4 d[4], xh[4];
         float s1 = 0.f, s2 = 0.f;
+        // every stream of the row in flight before the first use
+        float4 dvs[4], hvs[4];
+        ushort4 xb[4], xl[4], hbv[4], hlv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cc = lane + 64 * i < H4 ? lane + 64 * i : 0;
+            dvs[i] = reinterpret_cast<const float4*>(dh + o)[cc];
+            if constexpr (B16) {
+                xb[i] = reinterpret_cast<const ushort4*>(xhb + o)[cc];
+                if constexpr (LO) xl[i] = reinterpret_cast<const ushort4*>(xhl + o)[cc];
+                if constexpr (!RECOMP) {
+                    hbv[i] = reinterpret_cast<const ushort4*>(hb + o)[cc];
+                    if constexpr (LO) hlv[i] = reinterpret_cast<const ushort4*>(hl + o)[cc];
+                }
+            } else {
+                hvs[i] = reinterpret_cast<const float4*>(h + o)[cc];
+                xh[i] = reinterpret_cast<const float4*>(xhat + o)[cc];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c4 = lane + 64 * i;
-            d[i] = xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            d[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c4 >= H4) { xh[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
             if (c4 < H4) {
                 float4 hv;
                 if constexpr (B16) {
-                    xh[i] = bf4_to_f4(reinterpret_cast<const ushort4*>(xhb + o)[c4]);
-                    if (xhl) {                           // split-bf16 mode: hi + lo planes
-                        const float4 l2 = bf4_to_f4(reinterpret_cast<const ushort4*>(xhl + o)[c4]);
+                    xh[i] = bf4_to_f4(xb[i]);
+                    if constexpr (LO) {                  // split-bf16 mode: hi + lo planes
+                        const float4 l2 = bf4_to_f4(xl[i]);
                         xh[i].x += l2.x; xh[i].y += l2.y; xh[i].z += l2.z; xh[i].w += l2.w;
                     }
-                    if (beta) {                          // h = tanh(xhat * g + beta) again (as the forward formed it) instead of reading its planes:
+                    if constexpr (RECOMP) {              // h = tanh(xhat * g + beta) again (as the forward formed it) instead of reading its planes:
                         hv.x = tanh_fast(xh[i].x * g[i].x + be[i].x); hv.y = tanh_fast(xh[i].y * g[i].y + be[i].y);     // 4 B per element less
                         hv.z = tanh_fast(xh[i].z * g[i].z + be[i].z); hv.w = tanh_fast(xh[i].w * g[i].w + be[i].w);
                     } else {
-                        hv = bf4_to_f4(reinterpret_cast<const ushort4*>(hb + o)[c4]);
-                        if (hl) {
-                            const float4 l1 = bf4_to_f4(reinterpret_cast<const ushort4*>(hl + o)[c4]);
+                        hv = bf4_to_f4(hbv[i]);
+                        if constexpr (LO) {
+                            const float4 l1 = bf4_to_f4(hlv[i]);
                             hv.x += l1.x; hv.y += l1.y; hv.z += l1.z; hv.w += l1.w;
                         }
                     }
                 } else {
-                    hv = reinterpret_cast<const float4*>(h + o)[c4];
-                    xh[i] = reinterpret_cast<const float4*>(xhat + o)[c4];
+                    hv = hvs[i];
                 }
-                const float4 dv = reinterpret_cast<const float4*>(dh + o)[c4];
+                const float4 dv = dvs[i];
                 float4 dy;
                 dy.x = dv.x * (1.0f - hv.x * hv.x); dy.y = dv.y * (1.0f - hv.y * hv.y);
                 dy.z = dv.z * (1.0f - hv.z * hv.z); dy.w = dv.w * (1.0f - hv.w * hv.w);
@@ -489,19 +512,16 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(float* dh, const float* __r
                 for (int j0 = 0; j0 < dx_cols; j0 += 8) {
                     float part[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        part[j] = 0.f;
-                        if (j0 + j < dx_cols) {
-                            const float4* wr = reinterpret_cast<const float4*>(w0t + net * tstride + (int64_t)(j0 + j) * H);
+                    for (int j = 0; j < 8; ++j) part[j] = 0.f;
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const int c4 = lane + 64 * i;
-                                if (c4 < H4) {
-                                    const float4 wv = wr[c4];
-                                    part[j] += dzv[i].x * wv.x + dzv[i].y * wv.y + dzv[i].z * wv.z + dzv[i].w * wv.w;
-                                }
-                            }
-                        }
+                    for (int i = 0; i < 4; ++i) {        // 8 weight rows of a column chunk in flight at once (row index clamped: dzv is 0 past H/4,
+                        const int cc = lane + 64 * i < H4 ? lane + 64 * i : 0;          // the surplus outputs are never stored)
+                        float4 wv[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            wv[j] = reinterpret_cast<const float4*>(w0t + net * tstride + (int64_t)(j0 + j < dx_cols ? j0 + j : 0) * H)[cc];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) part[j] += dzv[i].x * wv[j].x + dzv[i].y * wv[j].y + dzv[i].z * wv[j].z + dzv[i].w * wv[j].w;
                     }
                     const float tot = wave_sum8(part, lane);
                     const int j = j0 + (lane & 7);
@@ -541,9 +561,13 @@ int ln_bwd(float* dh, const float* h, const float* xhat, const unsigned short* h
     const bool b16 = h_bf16 && xhat_bf16;
     const int iters = tb_iters(rows);
     EXORL_REQUIRE((h_lo != nullptr) == (xhat_lo != nullptr) && (!h_lo || b16), "ln_bwd: lo planes come in pairs, with the bf16 hi planes");
-#define EXORL_LNB(PA, BB) hipLaunchKernelGGL((ln_bwd_kernel<PA, BB>), grid, dim3(512), 0, s, dh, h, xhat, h_bf16, xhat_bf16, rstd, gain, P, rows, H, astride, pstride, w0t, tstride, dx, dx_cols, h_lo, xhat_lo, iters, beta)
-    if (want_params) { if (b16) EXORL_LNB(true, true); else EXORL_LNB(true, false); }
-    else             { if (b16) EXORL_LNB(false, true); else EXORL_LNB(false, false); }
+    const bool lo = h_lo != nullptr, rc = b16 && beta != nullptr;
+#define EXORL_LNB(PA, BB, LL, RR) hipLaunchKernelGGL((ln_bwd_kernel<PA, BB, LL, RR>), grid, dim3(512), 0, s, dh, h, xhat, h_bf16, xhat_bf16, rstd, gain, P, rows, H, astride, pstride, w0t, tstride, dx, dx_cols, h_lo, xhat_lo, iters, beta)
+#define EXORL_LNB2(PA) do { if (!b16) EXORL_LNB(PA, false, false, false); \
+                             else if (lo && rc) EXORL_LNB(PA, true, true, true); else if (lo) EXORL_LNB(PA, true, true, false); \
+                             else if (rc) EXORL_LNB(PA, true, false, true); else EXORL_LNB(PA, true, false, false); } while (0)
+    if (want_params) EXORL_LNB2(true); else EXORL_LNB2(false);
+#undef EXORL_LNB2
 #undef EXORL_LNB
     EXORL_LAUNCH_CHECK();
     return 0;
@@ -640,18 +664,18 @@ __global__ __launch_bounds__(256) void head_fwd4_kernel(const float* __restrict_
     float4 avs[4];                 // the whole row (H <= 1024) in flight before any use: one memory round trip, not four
 #pragma unroll
     for (int i = 0; i < 4; ++i) avs[i] = lane + 64 * i < H4 ? ar[lane + 64 * i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    // Weight rows are loaded UNCONDITIONALLY (row index clamped, results of the surplus outputs never stored): a `j < nout` guard around
+    // each load compiles to a branch + load + s_waitcnt vmcnt(0) per output and chunk, i.e. 24 serial L2 round trips per row at nout = 6
+    // (7 of the kernel's 11.5 us, visible only in the ISA); all NO loads of a chunk are now in flight together
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int c4 = lane + 64 * i;
-        if (c4 >= H4) break;
+        const int c4 = lane + 64 * i < H4 ? lane + 64 * i : 0;         // lanes past H/4 hold av = 0
         const float4 av = avs[i];
+        float4 wv[NO];
 #pragma unroll
-        for (int j = 0; j < NO; ++j) {
-            if (j < nout) {
-                const float4 wv = reinterpret_cast<const float4*>(Wn + (int64_t)j * H)[c4];
-                acc[j] += av.x * wv.x + av.y * wv.y + av.z * wv.z + av.w * wv.w;
-            }
-        }
+        for (int j = 0; j < NO; ++j) wv[j] = reinterpret_cast<const float4*>(Wn + (int64_t)(j < nout ? j : 0) * H)[c4];
+#pragma unroll
+        for (int j = 0; j < NO; ++j) acc[j] += av.x * wv[j].x + av.y * wv[j].y + av.z * wv[j].z + av.w * wv[j].w;
     }
     if constexpr (NO == 1) {
         float v = wave_sum(acc[0]) + (b ? b[net * pstride] : 0.f);
@@ -824,15 +848,15 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const DoutSpec dspec, con
     float4 w[NO], pw[NO];
 #pragma unroll
     for (int j = 0; j < NO; ++j) {
-        w[j] = j < nout ? reinterpret_cast<const float4*>(W + net * pstride + (int64_t)j * H)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        w[j] = reinterpret_cast<const float4*>(W + net * pstride + (int64_t)(j < nout ? j : 0) * H)[c4];     // unconditional (see head_fwd4): ds is 0 for j >= nout
         pw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float4 pb = make_float4(0.f, 0.f, 0.f, 0.f);
     const int nr = rows - row0 < HB_ROWS ? rows - row0 : HB_ROWS;
     float4 avs[HB_ROWS];
 #pragma unroll
-    for (int r = 0; r < HB_ROWS; ++r)
-        avs[r] = r < nr ? reinterpret_cast<const float4*>(a + net * astride + (int64_t)(row0 + r) * H)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < HB_ROWS; ++r)          // unconditional (row clamped; rows past nr are skipped below)
+        avs[r] = reinterpret_cast<const float4*>(a + net * astride + (int64_t)(row0 + (r < nr ? r : 0)) * H)[c4];
 #pragma unroll
     for (int r = 0; r < HB_ROWS; ++r) {
         if (r >= nr) break;
@@ -942,6 +966,7 @@ int head_chunks(int rows) { return cdiv(rows, HB_ROWS); }
 constexpr int QH_ROWS = 4;      // rows per workgroup: 256 workgroups at B = 1024 (8 rows left half the CUs idle and cost 17.6 us)
 // scalar critic heads forward + backward (see QHeadArgs). One workgroup per chunk of QH_ROWS rows, thread = 4 consecutive
 // columns of both critic nets; the h2 rows read for the dot products stay in registers for the dz2 pass.
+template <int MODE>
 __global__ __launch_bounds__(256) void qhead_kernel(const QHeadArgs g) {
     __shared__ float part[4][4 * QH_ROWS];      // [wave][net * QH_ROWS + r]
     __shared__ float dq[2 * QH_ROWS];
@@ -949,11 +974,23 @@ __global__ __launch_bounds__(256) void qhead_kernel(const QHeadArgs g) {
     const int c4 = threadIdx.x, H = g.H, H4 = H >> 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nr = g.rows - row0 < QH_ROWS ? g.rows - row0 : QH_ROWS;
-    const int nn = g.mode == 0 ? 4 : 2;
+    constexpr int nn = MODE == 0 ? 4 : 2;
     const bool on = c4 < H4;
     float4 avs[2][QH_ROWS];
     float4 w[2];
     float dots[4 * QH_ROWS];
+    // all nn weight rows and nn x QH_ROWS activation rows in flight before the first use: the loads are unconditional (indices clamped,
+    // surplus lanes / rows masked below) — guarded loads compile to one L2 round trip each (see head_fwd4)
+    float4 wvs[nn], ts[nn][QH_ROWS];
+    {
+        const int cc = on ? c4 : 0;
+#pragma unroll
+        for (int n = 0; n < nn; ++n) {
+            wvs[n] = reinterpret_cast<const float4*>(g.W[n])[cc];
+#pragma unroll
+            for (int r = 0; r < QH_ROWS; ++r) ts[n][r] = reinterpret_cast<const float4*>(g.a[n] + (int64_t)(row0 + (r < nr ? r : 0)) * H)[cc];
+        }
+    }
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         if (n >= nn) {
@@ -961,16 +998,13 @@ __global__ __launch_bounds__(256) void qhead_kernel(const QHeadArgs g) {
             for (int r = 0; r < QH_ROWS; ++r) dots[n * QH_ROWS + r] = 0.f;
             continue;
         }
-        const float4 wv = on ? reinterpret_cast<const float4*>(g.W[n])[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 wv = on ? wvs[n < nn ? n : 0] : make_float4(0.f, 0.f, 0.f, 0.f);
         if (n < 2) w[n] = wv;
-        float4 t[QH_ROWS];
-#pragma unroll
-        for (int r = 0; r < QH_ROWS; ++r)
-            t[r] = (on && r < nr) ? reinterpret_cast<const float4*>(g.a[n] + (int64_t)(row0 + r) * H)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int r = 0; r < QH_ROWS; ++r) {
-            dots[n * QH_ROWS + r] = (t[r].x * wv.x + t[r].y * wv.y) + (t[r].z * wv.z + t[r].w * wv.w);
-            if (n < 2) avs[n][r] = t[r];
+            const float4 t = (on && r < nr) ? ts[n < nn ? n : 0][r] : make_float4(0.f, 0.f, 0.f, 0.f);
+            dots[n * QH_ROWS + r] = (t.x * wv.x + t.y * wv.y) + (t.z * wv.z + t.w * wv.w);
+            if (n < 2) avs[n][r] = t;
         }
     }
 #pragma unroll
@@ -993,7 +1027,7 @@ __global__ __launch_bounds__(256) void qhead_kernel(const QHeadArgs g) {
         float d = 0.f;
         if (r < nr) {
             const float q1 = part[0][r], q2 = part[0][QH_ROWS + r];
-            if (g.mode == 0) {
+            if (MODE == 0) {
                 const float y = g.reward[row0 + r] + g.discount[row0 + r] * fminf(part[0][2 * QH_ROWS + r], part[0][3 * QH_ROWS + r]);
                 d = 2.0f * ((n == 0 ? q1 : q2) - y) * g.inv_bg;
             } else {
@@ -1003,7 +1037,7 @@ __global__ __launch_bounds__(256) void qhead_kernel(const QHeadArgs g) {
         }
         dq[threadIdx.x] = d;
     }
-    if (g.mode == 1 && threadIdx.x == 0) {
+    if (MODE == 1 && threadIdx.x == 0) {
         float sa = 0.f, sm = 0.f;
         for (int r = 0; r < nr; ++r) { const float m = fminf(part[0][r], part[0][QH_ROWS + r]); sa += fabsf(m); sm += m; }
         g.abs_part[2 * blockIdx.x] = sa;
@@ -1047,7 +1081,8 @@ int qhead_chunks(int rows) { return cdiv(rows, QH_ROWS); }
 
 int qhead(const QHeadArgs& q, hipStream_t s) {
     EXORL_REQUIRE(q.H % 4 == 0 && q.H <= 1024 && q.rows > 0 && (q.mode == 0 || q.mode == 1), "qhead: unsupported H=%d rows=%d", q.H, q.rows);
-    hipLaunchKernelGGL(qhead_kernel, dim3(cdiv(q.rows, QH_ROWS)), dim3(256), 0, s, q);
+    if (q.mode == 0) hipLaunchKernelGGL(qhead_kernel<0>, dim3(cdiv(q.rows, QH_ROWS)), dim3(256), 0, s, q);
+    else hipLaunchKernelGGL(qhead_kernel<1>, dim3(cdiv(q.rows, QH_ROWS)), dim3(256), 0, s, q);
     EXORL_LAUNCH_CHECK();
     return 0;
 }
