@@ -203,12 +203,26 @@ __global__ __launch_bounds__(512) void trunk_fwd16_kernel(const TrunkBatch tb, i
     f32x4_t acc[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // bias / gain / beta of this lane's columns are fetched NOW, with the inputs and weight fragments, instead of behind the MFMAs and
+    // behind the second LayerNorm barrier (two more L2 round trips on a kernel that is one latency chain)
+    float4 bias4[T], gain4[T], beta4[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int c = col0 + t * 16 + 4 * kq;
+        bias4[t] = *reinterpret_cast<const float4*>(b0 + net * pstride + c);
+        gain4[t] = *reinterpret_cast<const float4*>(gain + net * pstride + c);
+        beta4[t] = *reinterpret_cast<const float4*>(beta + net * pstride + c);
+    }
+    const int64_t xrow = (int64_t)(live ? row : 0) * ldx;          // unconditional loads (see head_fwd4): index clamped, value masked
     for (int k0 = 0; k0 < Kp; k0 += 32) {
         bf16x8_t bx, bxl;
         const int kb = k0 + 8 * kq;
+        float xs[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xs[j] = x[xrow + (kb + j < in_dim ? kb + j : 0)];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float xv = (live && kb + j < in_dim) ? x[(int64_t)row * ldx + kb + j] : 0.f;
+            const float xv = (live && kb + j < in_dim) ? xs[j] : 0.f;
             bx[j] = (__bf16)xv;
             if constexpr (X3) bxl[j] = (__bf16)(xv - (float)bx[j]);
         }
@@ -237,7 +251,7 @@ __global__ __launch_bounds__(512) void trunk_fwd16_kernel(const TrunkBatch tb, i
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-        const float4 b = *reinterpret_cast<const float4*>(b0 + net * pstride + col0 + t * 16 + 4 * kq);
+        const float4 b = bias4[t];
         acc[t][0] += b.x; acc[t][1] += b.y; acc[t][2] += b.z; acc[t][3] += b.w;
         s += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
     }
@@ -266,9 +280,8 @@ __global__ __launch_bounds__(512) void trunk_fwd16_kernel(const TrunkBatch tb, i
     float4 hv[T], xv[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-        const int c = col0 + t * 16 + 4 * kq;
-        const float4 g = *reinterpret_cast<const float4*>(gain + net * pstride + c);
-        const float4 be = *reinterpret_cast<const float4*>(beta + net * pstride + c);
+        const float4 g = gain4[t];
+        const float4 be = beta4[t];
         xv[t] = make_float4(acc[t][0] * rs, acc[t][1] * rs, acc[t][2] * rs, acc[t][3] * rs);
         hv[t] = make_float4(tanh_fast(xv[t].x * g.x + be.x), tanh_fast(xv[t].y * g.y + be.y), tanh_fast(xv[t].z * g.z + be.z),
                             tanh_fast(xv[t].w * g.w + be.w));
@@ -592,24 +605,36 @@ __global__ __launch_bounds__(256) void outer_reduce_kernel(const float* __restri
         for (int sub = 0; sub < iters; ++sub) {
             const int row0 = (blockIdx.y * iters + sub) * OR_ROWS;
             const int nr = rows - row0 < OR_ROWS ? rows - row0 : OR_ROWS;       // <= 0 past the end: nothing staged, nothing added
+            // all OR_ROWS rows of this thread's column and the staged u values are requested up front, unconditionally (row clamped; the
+            // staged u of a row past the end is 0, so whatever the clamped v row holds contributes nothing): one memory round trip per
+            // sub-block instead of four guarded ones
+            float vall[OR_ROWS];
+            const int cc = c < H ? c : 0;
+#pragma unroll
+            for (int r = 0; r < OR_ROWS; ++r) vall[r] = v[net * vstride + (int64_t)(row0 + (r < nr ? r : 0)) * H + cc];
+            float ust[OR_ROWS * 32 / 256];
+#pragma unroll
+            for (int q = 0; q < OR_ROWS * 32 / 256; ++q) {
+                const int i = threadIdx.x + 256 * q, r = i >> 5, j = i & 31;
+                ust[q] = u[(int64_t)(row0 + (r < nr ? r : 0)) * ldu + (j0 + j < J ? j0 + j : 0)];
+            }
             __syncthreads();
-            for (int i = threadIdx.x; i < OR_ROWS * 32; i += 256) {
-                const int r = i >> 5, j = i & 31;
-                us[r][j] = (r < nr && j0 + j < J) ? u[(int64_t)(row0 + r) * ldu + j0 + j] : 0.f;
+#pragma unroll
+            for (int q = 0; q < OR_ROWS * 32 / 256; ++q) {
+                const int i = threadIdx.x + 256 * q, r = i >> 5, j = i & 31;
+                us[r][j] = (r < nr && j0 + j < J) ? ust[q] : 0.f;
             }
             __syncthreads();
             if (c < H) {
 #pragma unroll 1
                 for (int rb = 0; rb < OR_ROWS; rb += 8) {
-                    float vv[8];               // 8 rows in flight at once (memory-level parallelism)
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) vv[r] = rb + r < nr ? v[net * vstride + (int64_t)(row0 + rb + r) * H + c] : 0.f;
 #pragma unroll
                     for (int r = 0; r < 8; ++r) {
+                        const float vr = vall[rb + r];
 #pragma unroll
                         for (int j4 = 0; j4 < 8; ++j4) {
                             const float4 uu = *reinterpret_cast<const float4*>(&us[rb + r][4 * j4]);
-                            acc[4 * j4] += uu.x * vv[r]; acc[4 * j4 + 1] += uu.y * vv[r]; acc[4 * j4 + 2] += uu.z * vv[r]; acc[4 * j4 + 3] += uu.w * vv[r];
+                            acc[4 * j4] += uu.x * vr; acc[4 * j4 + 1] += uu.y * vr; acc[4 * j4 + 2] += uu.z * vr; acc[4 * j4 + 3] += uu.w * vr;
                         }
                         __builtin_amdgcn_sched_barrier(0);     // keep one row's 8 LDS reads live at a time (VGPR budget)
                     }
@@ -1093,6 +1118,13 @@ int qhead(const QHeadArgs& q, hipStream_t s) {
 __device__ __forceinline__ float chunk_sum(const float* __restrict__ p, int n, int64_t stride) {
     float acc = 0.f;
     int ch = 0;
+    for (; ch + 32 <= n; ch += 32) {            // 32 in flight: the 256 qhead chunks are 8 dependent rounds instead of 16 (same order of adds)
+        float t[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) t[q] = p[(int64_t)(ch + q) * stride];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) acc += t[q];
+    }
     for (; ch + 16 <= n; ch += 16) {
         float t[16];
 #pragma unroll
