@@ -177,7 +177,10 @@ typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4_t;
 
 // X3 (split-bf16 mode): x and W0 enter as hi + lo pairs, z = hi*hi + hi*lo + lo*hi (fp32-grade first layer), and h / xhat
 // leave as hi + lo planes.
-#define TF16_LD(T) (16 * (T) + 16)
+// slab row stride in bf16 elements: + 8 (16 B) puts row r of the 8-byte transposing writes 4 banks after row r - 1, so the 32 lanes a
+// write instruction retires together (16 rows x 2 column quads) hit 64 distinct banks for T = 8; + 16 made rows r and r + 8 collide
+// (SQ_LDS_BANK_CONFLICT was 64 % of the kernel's LDS cycles)
+#define TF16_LD(T) (16 * (T) + 8)
 template <int T, bool X3>     // T = H / 128 column tiles per wave
 __global__ __launch_bounds__(512) void trunk_fwd16_kernel(const TrunkBatch tb, int64_t ldx, int rows, int in_dim, int Kp) {
     constexpr int H = T * 128;
@@ -315,6 +318,147 @@ __global__ __launch_bounds__(512) void trunk_fwd16_kernel(const TrunkBatch tb, i
     if (rstd && wave == 0 && kq == 0) rstd[net * (int64_t)rows + row] = rs;
 }
 
+// 8 rows per workgroup. The per-element epilogue (LayerNorm affine, tanh, 2-4 bf16 plane conversions: ~40 VALU instructions) is what a
+// trunk workgroup spends its time on, and with 16 rows a 2048-row launch is 128 workgroups — half the CUs idle while the rest each grind
+// 16 x H elements. An MFMA tile still has 16 batch-row slots, so the 8 rows are entered twice, zeroed in opposite halves
+//   B0[k][j] = x[j & 7][k] for j < 8, else 0       B1[k][j] = x[j & 7][k] for j >= 8, else 0
+// and C = A_p B0 + A_(p+T/2) B1 gives lane (j, kq) row j & 7 of column tile p (j < 8) or p + T/2 (j >= 8): all 64 lanes hold
+// distinct outputs, half as many as in the 16-row kernel.
+template <int T, bool X3>     // T = H / 128 column tiles per wave, even
+__global__ __launch_bounds__(512) void trunk_fwd8_kernel(const TrunkBatch tb, int64_t ldx, int rows, int in_dim, int Kp) {
+    constexpr int H = T * 128, TP = T / 2;
+    __shared__ float red[2][8][8];
+    __shared__ __attribute__((aligned(16))) unsigned short stage[8][8][TF16_LD(T)];      // per-wave 8 x 16T output slab (+16 B row pad)
+    const TrunkItem& it = tb.it[blockIdx.y];
+    const float* __restrict__ x = it.x;
+    float* __restrict__ rstd = it.rstd;
+    unsigned short* __restrict__ hb = it.hb;
+    unsigned short* __restrict__ xhb = it.xhb;
+    const unsigned short* __restrict__ Wb = it.W0b;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rn = lane & 15, kq = lane >> 4, r8 = rn & 7, half = rn >> 3;
+    const int row = blockIdx.x * 8 + r8;
+    const bool live = row < rows;
+    const int col0 = wave * (H / 8);
+    f32x4_t acc[TP];
+#pragma unroll
+    for (int p = 0; p < TP; ++p) acc[p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float4 bias4[TP], gain4[TP], beta4[TP];       // fetched with the inputs and weight fragments (one memory round trip for the kernel)
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+        const int c = col0 + (p + TP * half) * 16 + 4 * kq;
+        bias4[p] = *reinterpret_cast<const float4*>(it.b0 + c);
+        gain4[p] = *reinterpret_cast<const float4*>(it.gain + c);
+        beta4[p] = *reinterpret_cast<const float4*>(it.beta + c);
+    }
+    const int64_t xrow = (int64_t)(live ? row : 0) * ldx;          // unconditional loads: index clamped, value masked
+    for (int k0 = 0; k0 < Kp; k0 += 32) {
+        const int kb = k0 + 8 * kq;
+        float xs[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xs[j] = x[xrow + (kb + j < in_dim ? kb + j : 0)];
+        bf16x8_t aw[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) aw[t] = *reinterpret_cast<const bf16x8_t*>(Wb + (int64_t)(col0 + t * 16 + rn) * Kp + kb);
+        bf16x8_t awl[X3 ? T : 1];
+        if constexpr (X3) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) awl[t] = *reinterpret_cast<const bf16x8_t*>(it.W0l + (int64_t)(col0 + t * 16 + rn) * Kp + kb);
+        }
+        bf16x8_t b0, b1, b0l, b1l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xv = (live && kb + j < in_dim) ? xs[j] : 0.f;
+            const __bf16 hi = (__bf16)xv;
+            const __bf16 lo = (__bf16)(xv - (float)hi);
+            const __bf16 zero = (__bf16)0.f;
+            b0[j] = half ? zero : hi; b1[j] = half ? hi : zero;
+            b0l[j] = half ? zero : lo; b1l[j] = half ? lo : zero;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (X3) {
+            f32x4_t cross[TP];
+#pragma unroll
+            for (int p = 0; p < TP; ++p) {
+                cross[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[p], b0l, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                cross[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[p + TP], b1l, cross[p], 0, 0, 0);
+                cross[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(awl[p], b0, cross[p], 0, 0, 0);
+                cross[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(awl[p + TP], b1, cross[p], 0, 0, 0);
+            }
+#pragma unroll
+            for (int p = 0; p < TP; ++p) acc[p] += cross[p];
+        }
+#pragma unroll
+        for (int p = 0; p < TP; ++p) {
+            acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[p], b0, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[p + TP], b1, acc[p], 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+        const float4 b = bias4[p];
+        acc[p][0] += b.x; acc[p][1] += b.y; acc[p][2] += b.z; acc[p][3] += b.w;
+        s += (acc[p][0] + acc[p][1]) + (acc[p][2] + acc[p][3]);
+    }
+    s += __shfl_xor(s, 8, 64);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (lane < 8) red[0][wave][r8] = s;
+    __syncthreads();
+    float mean = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) mean += red[0][w][r8];
+    mean *= 1.0f / (float)H;
+    float s2 = 0.f;
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc[p][i] -= mean; s2 += acc[p][i] * acc[p][i]; }
+    }
+    s2 += __shfl_xor(s2, 8, 64);
+    s2 += __shfl_xor(s2, 16, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (lane < 8) red[1][wave][r8] = s2;
+    __syncthreads();
+    float var = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) var += red[1][w][r8];
+    const float rs = 1.0f / sqrtf(var * (1.0f / (float)H) + LN_EPS2);
+    float4 hv[TP], xv[TP];
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+        const float4 g = gain4[p];
+        const float4 be = beta4[p];
+        xv[p] = make_float4(acc[p][0] * rs, acc[p][1] * rs, acc[p][2] * rs, acc[p][3] * rs);
+        hv[p] = make_float4(tanh_fast(xv[p].x * g.x + be.x), tanh_fast(xv[p].y * g.y + be.y), tanh_fast(xv[p].z * g.z + be.z),
+                            tanh_fast(xv[p].w * g.w + be.w));
+    }
+    // each wave transposes its 8 x 16T slab through LDS so that a store instruction writes whole 32T-byte row slabs (see trunk_fwd16_kernel)
+    unsigned short* mine = &stage[wave][0][0];
+    auto flush = [&](unsigned short* __restrict__ plane, const float4 (&v)[TP], bool lo) {
+#pragma unroll
+        for (int p = 0; p < TP; ++p)
+            *reinterpret_cast<ushort4*>(mine + r8 * TF16_LD(T) + (p + TP * half) * 16 + 4 * kq) = lo ? f4_to_bf4_lo(v[p]) : f4_to_bf4(v[p]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int idx = lane; idx < 16 * T; idx += 64) {
+            const int r = idx / (2 * T), ch = idx % (2 * T);
+            const uint4 q = *reinterpret_cast<const uint4*>(mine + r * TF16_LD(T) + 8 * ch);
+            const int grow = blockIdx.x * 8 + r;
+            if (grow < rows) *reinterpret_cast<uint4*>(plane + (int64_t)grow * H + col0 + 8 * ch) = q;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    flush(hb, hv, false);
+    if constexpr (X3) flush(it.hl, hv, true);
+    if (xhb) {
+        flush(xhb, xv, false);
+        if constexpr (X3) flush(it.xhl, xv, true);
+    }
+    if (rstd && wave == 0 && lane < 8 && live) rstd[row] = rs;
+}
+
 bool trunk_fwd16_supported(int H) { return H >= 128 && H <= 1024 && H % 128 == 0; }
 
 int trunk_fwd16_batch(const TrunkBatch& tb, int count, int64_t ldx, int rows, int in_dim, int H, hipStream_t s) {
@@ -325,6 +469,24 @@ int trunk_fwd16_batch(const TrunkBatch& tb, int count, int64_t ldx, int rows, in
     const bool x3 = tb.it[0].W0l != nullptr;
     for (int i = 0; i < count; ++i)
         EXORL_REQUIRE((tb.it[i].W0l != nullptr) == x3 && (!x3 || (tb.it[i].hl && (!tb.it[i].xhb || tb.it[i].xhl))), "trunk_fwd16: inconsistent lo planes");
+    const int var = tune_variant();
+    // 8-row workgroups where 16-row ones would leave CUs idle (measured, H = 1024: 2048 rows x 1 net 13.4 -> 10.3 us, 1024 x 2 nets 12.9 -> 10.0);
+    // at 256 or more 16-row workgroups the 8-row grid is two rounds per CU and slower (1024 rows x 4 nets: 13.1 -> 16.2 us)
+    const bool rows8 = H % 256 == 0 && !(var & 4194304) && ((var & 8388608) || cdiv(rows, 16) * count < 256);
+    if (rows8) {
+        const dim3 grid8(cdiv(rows, 8), count);
+#define EXORL_TF8(T) do { if (x3) hipLaunchKernelGGL((trunk_fwd8_kernel<T, true>), grid8, dim3(512), 0, s, tb, ldx, rows, in_dim, Kp); \
+                          else hipLaunchKernelGGL((trunk_fwd8_kernel<T, false>), grid8, dim3(512), 0, s, tb, ldx, rows, in_dim, Kp); } while (0)
+        switch (H / 256) {
+            case 1: EXORL_TF8(2); break;
+            case 2: EXORL_TF8(4); break;
+            case 3: EXORL_TF8(6); break;
+            default: EXORL_TF8(8); break;
+        }
+#undef EXORL_TF8
+        EXORL_LAUNCH_CHECK();
+        return 0;
+    }
 #define EXORL_TF16(T) do { if (x3) hipLaunchKernelGGL((trunk_fwd16_kernel<T, true>), grid, dim3(512), 0, s, tb, ldx, rows, in_dim, Kp); \
                            else hipLaunchKernelGGL((trunk_fwd16_kernel<T, false>), grid, dim3(512), 0, s, tb, ldx, rows, in_dim, Kp); } while (0)
     switch (H / 128) {
@@ -428,7 +590,7 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(float* dh, const float* __r
                                                      int64_t pstride, const float* __restrict__ w0t, int64_t tstride,
                                                      float* __restrict__ dx, int dx_cols, const unsigned short* __restrict__ hl,
                                                      const unsigned short* __restrict__ xhl, int iters, const float* __restrict__ beta) {
-    __shared__ __attribute__((aligned(16))) float red[PARAMS ? 8 * 1024 : 4];
+    __shared__ __attribute__((aligned(16))) float red[PARAMS ? 3 * 8 * 1024 : 4];      // 96 KB of the CU's 160: the three column vectors at once
     const int net = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H4 = H >> 2;
@@ -543,21 +705,24 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(float* dh, const float* __r
             }
         }
     }
-    if constexpr (PARAMS) {        // cross-wave sums of the three column vectors, one at a time through 32 KB of LDS
+    if constexpr (PARAMS) {        // cross-wave sums of the three column vectors: one barrier, then 3 x 8 LDS reads per column
         float* Pn = P + ((int64_t)net * gridDim.x + blockIdx.x) * 3 * H;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c4 = lane + 64 * i;
-                if (c4 < H4) reinterpret_cast<float4*>(red + wave * 1024)[c4] = q == 0 ? pg[i] : (q == 1 ? pb[i] : pb0[i]);
+        for (int i = 0; i < 4; ++i) {
+            const int c4 = lane + 64 * i;
+            if (c4 < H4) {
+                reinterpret_cast<float4*>(red + wave * 1024)[c4] = pg[i];
+                reinterpret_cast<float4*>(red + (8 + wave) * 1024)[c4] = pb[i];
+                reinterpret_cast<float4*>(red + (16 + wave) * 1024)[c4] = pb0[i];
             }
-            __syncthreads();
-            for (int c = tid; c < H; c += 512) {
+        }
+        __syncthreads();
+        for (int c = tid; c < H; c += 512) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
                 float sacc = 0.f;
 #pragma unroll
-                for (int w = 0; w < 8; ++w) sacc += red[w * 1024 + c];
+                for (int w = 0; w < 8; ++w) sacc += red[(q * 8 + w) * 1024 + c];
                 Pn[q * H + c] = sacc;
             }
         }
@@ -846,6 +1011,30 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const DoutSpec dspec, con
     const int row0 = blockIdx.x * HB_ROWS;
     const int c4 = threadIdx.x;
     const int H4 = H >> 2;
+    // Every global read of the kernel is issued here, before the first barrier, so that the weight rows, the activation rows and the
+    // loss-gradient inputs share one memory round trip with the lambda partials (a load behind a barrier or a branch costs its own).
+    const int c4c = c4 < H4 ? c4 : 0;
+    const int nr = rows - row0 < HB_ROWS ? rows - row0 : HB_ROWS;
+    float4 w[NO], pw[NO], avs[HB_ROWS];
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+        w[j] = reinterpret_cast<const float4*>(W + net * pstride + (int64_t)(j < nout ? j : 0) * H)[c4c];     // ds is 0 for j >= nout
+        pw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int r = 0; r < HB_ROWS; ++r)          // row clamped; rows past nr are skipped below
+        avs[r] = reinterpret_cast<const float4*>(a + net * astride + (int64_t)(row0 + (r < nr ? r : 0)) * H)[c4c];
+    // deterministic-actor gradient (TD3 / TD3+BC / DDPG): its inputs are read now, lambda is applied after the reduction below
+    const bool mu_path = dspec.mode == EXORL_DOUT_ACTOR_MU && dspec.kind != EXORL_AGENT_BC && dspec.kind != EXORL_AGENT_CRR;
+    const int dr = (threadIdx.x >> 4) & (HB_ROWS - 1), dj = threadIdx.x & 15;
+    const bool dlive = threadIdx.x < HB_ROWS * 16 && row0 + dr < rows && dj < nout;
+    float mu_v = 0.f, da_v = 0.f, ad_v = 0.f;
+    if (mu_path) {
+        const int i = (dlive ? row0 + dr : 0) * nout + (dlive ? dj : 0);
+        mu_v = dspec.mu[i];
+        for (int t = 0; t < dspec.da_nets; ++t) da_v += dspec.da[(int64_t)t * rows * nout + i];
+        if (dspec.kind == EXORL_AGENT_TD3_BC) ad_v = dspec.a_data[i];
+    }
     float lam = 1.0f;
     if (dspec.mode == EXORL_DOUT_ACTOR_MU && dspec.lam_parts && dspec.use_lambda) {     // lambda = alpha / mean |min(Q1,Q2)| (td3_bc.py:154)
         float sabs = 0.f;
@@ -858,8 +1047,15 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const DoutSpec dspec, con
         lam = lam_s[4];
     }
     if (threadIdx.x < HB_ROWS * 16) {
-        const int r = threadIdx.x >> 4, j = threadIdx.x & 15;
-        ds[threadIdx.x] = (row0 + r < rows && j < nout) ? dout_value(dspec, net, row0 + r, j, rows, nout, lam) : 0.f;
+        float dv = 0.f;
+        if (mu_path) {            // same arithmetic as dout_value's last branch
+            float dmu = da_v * lam;
+            if (dspec.kind == EXORL_AGENT_TD3_BC) dmu += 2.0f * dspec.inv_bg / (float)nout * (mu_v - ad_v);
+            dv = dlive ? dmu * (1.0f - mu_v * mu_v) : 0.f;
+        } else if (dlive) {
+            dv = dout_value(dspec, net, row0 + dr, dj, rows, nout, lam);
+        }
+        ds[threadIdx.x] = dv;
     }
     __syncthreads();
     const int64_t nh = (int64_t)(nout + 1) * H + 16;
@@ -870,18 +1066,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const DoutSpec dspec, con
         Pn[(int64_t)(nout + 1) * H + threadIdx.x] = sj;
     }
     if (c4 >= H4) return;
-    float4 w[NO], pw[NO];
-#pragma unroll
-    for (int j = 0; j < NO; ++j) {
-        w[j] = reinterpret_cast<const float4*>(W + net * pstride + (int64_t)(j < nout ? j : 0) * H)[c4];     // unconditional (see head_fwd4): ds is 0 for j >= nout
-        pw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
     float4 pb = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int nr = rows - row0 < HB_ROWS ? rows - row0 : HB_ROWS;
-    float4 avs[HB_ROWS];
-#pragma unroll
-    for (int r = 0; r < HB_ROWS; ++r)          // unconditional (row clamped; rows past nr are skipped below)
-        avs[r] = reinterpret_cast<const float4*>(a + net * astride + (int64_t)(row0 + (r < nr ? r : 0)) * H)[c4];
 #pragma unroll
     for (int r = 0; r < HB_ROWS; ++r) {
         if (r >= nr) break;

@@ -1669,6 +1669,8 @@ extern "C" int exorl_profile_event_overhead(float* ms_out, void* stream) {
     return 0;
 }
 
+namespace exorl { int tune_variant() { return g_gemm16_variant < 0 ? 0 : g_gemm16_variant; } }
+
 extern "C" int exorl_gemm_tune(int32_t variant) {
     exorl::g_gemm16_variant = variant;
     return 0;

@@ -129,6 +129,7 @@ struct DoutSpec {
 int head_bwd(const DoutSpec& dspec, const float* W, const float* a, float* dz, unsigned short* dz_bf16, float* P, int rows,
              int H, int nout, int nets, int64_t astride, int64_t pstride, int want_params, hipStream_t s, unsigned short* dz_lo = nullptr);
 int head_chunks(int rows);
+int tune_variant();      // exorl_gemm_tune's experiment bits (0 = defaults)
 // Scalar critic heads, forward and backward in one kernel (single-GPU whole-step path, no metrics): Q1,Q2 (and the target's
 // Q1',Q2') row dots, the loss gradient at the head output, dz2 = dQ * W2 * [h2 > 0] and the per-chunk parameter partials.
 //   mode 0 (critic step, td3_bc.py:126-131): dQ_n = 2 (Q_n - (r + D min(Q1',Q2'))) * inv_bg
