@@ -104,6 +104,10 @@ static Gemm16Problem g16(const unsigned short* A, const unsigned short* Al, cons
     return p;
 }
 struct Partials { float *Ph, *Pt, *Pw; };                  // per-chunk partial gradients (fused.hip)
+// Adam on the H x H weights launched on a side stream as soon as their gradient exists (right behind the wgrad GEMM): it is the HBM-bound
+// 80 % of the optimiser pass and depends on nothing the LayerNorm-backward -> first-layer-wgrad chain produces, so the two run side by side
+// (graph: parallel branches) and the optimiser launch that follows the chain only handles the small tensors.
+struct EarlyW1 { const Fork* fo; FusedAdamArgs fa; ShadowSpec sh; bool* launched; };
 
 static ShadowSpec shadow_spec(const NetDesc& d, const NetShadow& sh, const NetShadow* target) {
     ShadowSpec s{};
@@ -199,7 +203,8 @@ static int net_forward2(const NetDesc& d, const float* Pa, const NetShadow& sa, 
 // consumer adds them) receives d/dx[:, col0:col0+dx_cols].
 static int net_backward(const NetDesc& d, const float* P, const NetShadow& sh, float* G, const Partials& pt, const float* x,
                         int64_t ldx, int rows, const FwdBufs& f, const DoutSpec& dout, const BwdBufs& b, float* dx, int dx_col0,
-                        int dx_cols, int prec, hipStream_t s, const Fork& fk, FinalizeArgs* defer = nullptr, bool have_dz2 = false) {
+                        int dx_cols, int prec, hipStream_t s, const Fork& fk, FinalizeArgs* defer = nullptr, bool have_dz2 = false,
+                        const EarlyW1* early = nullptr) {
     const int H = d.H;
     const int64_t act = (int64_t)rows * H;
     const bool paired = d.n_trunks == d.n_heads;
@@ -231,6 +236,11 @@ static int net_backward(const NetDesc& d, const float* P, const NetShadow& sh, f
                               rows, H, H, H, H, H);
             }
             EXORL_TRY(gemm16_grouped_mixed(at, q, nq, s));
+            if (early && early->fo->on && defer) {
+                EXORL_TRY(early->fo->fork(s));
+                EXORL_TRY(finalize_adam(FinalizeArgs{}, early->fa, early->sh, early->fo->aux, 2));
+                *early->launched = true;
+            }
             for (int i = nd; i < d.n_heads; ++i) {
                 Gemm16Problem r = g16(b.dz2b, b.dz2l, sh.w1b, sh.w1l, i * act, (int64_t)i * H * H, b.dh1, nullptr, rows, H, H, H, H, H);
                 EXORL_TRY(gemm16_grouped(0, 1, &r, 1, false, true, s));
@@ -358,6 +368,8 @@ struct exorl_agent {
     hipStream_t comm_stream = nullptr;           // the 16-byte statistic travels here while the critic's backward pass runs
     hipEvent_t ev_stats_ready = nullptr, ev_stats_done = nullptr;
     FinalizeArgs pend_c{}, pend_a{};
+    Fork fo;                         // side stream of the early H x H optimiser pass (EarlyW1)
+    bool w1_early[2] = {false, false};   // [0] critic, [1] actor: the H x H part of this step's optimiser pass is already in flight
     bool staged_by_sampler = false;  // captured step: the sampler's gather kernel writes the staged inputs and runs step_begin
     bool want_metrics = true;    // the (B,1)-sized metric reductions are skipped when the caller never reads them (use_tb=False)
 };
@@ -488,13 +500,37 @@ static int push_opt_steps(exorl_agent* a) {
     return 0;
 }
 
+static int ensure_opt_fork(exorl_agent* a) {
+    if (a->fo.aux) return 0;
+    EXORL_CHECK_HIP(hipStreamCreateWithFlags(&a->fo.aux, hipStreamNonBlocking));
+    EXORL_CHECK_HIP(hipEventCreateWithFlags(&a->fo.ev_fork, hipEventDisableTiming));
+    EXORL_CHECK_HIP(hipEventCreateWithFlags(&a->fo.ev_join, hipEventDisableTiming));
+    return 0;
+}
+// Off by default, exorl_gemm_tune bit 16777216 turns it on. Measured (TD3+BC, H = B = 1024, bf16x3): the two branches do overlap, but every
+// cross-stream edge costs ~6 us on this runtime (event record -> wait, in a captured graph as well) and the co-running kernels slow each
+// other (outer_reduce 8.6 -> 17.8 us): the critic's backward tail went from 41 to 54 us, the step from 0.290 to 0.340 ms.
+static bool opt_overlap_enabled() { return (tune_variant() & 16777216) != 0; }
+static FusedAdamArgs fused_adam_args(exorl_agent* a, int net, const NetDesc& d, const AdamConst* c, float* target, uint64_t* bump) {
+    float** f = a->flat[net];
+    return FusedAdamArgs{f[EXORL_T_PARAM], f[EXORL_T_GRAD], f[EXORL_T_ADAM_M], f[EXORL_T_ADAM_V], target, c, d.n_heads,
+                         {d.W1, d.W1 + d.head_stride}, reinterpret_cast<unsigned long long*>(bump)};
+}
+static EarlyW1 early_w1(exorl_agent* a, int net) {
+    const bool critic = net == EXORL_NET_CRITIC;
+    return EarlyW1{&a->fo, fused_adam_args(a, net, critic ? a->critic : a->actor, critic ? &a->state->critic : &a->state->actor,
+                                           critic ? a->flat[EXORL_NET_CRITIC_TARGET][EXORL_T_PARAM] : nullptr, nullptr),
+                   critic ? a->spec_critic : a->spec_actor, &a->w1_early[critic ? 0 : 1]};
+}
 static int opt_step(exorl_agent* a, int net, const NetDesc& d, const FinalizeArgs& pend, const AdamConst* c, float* target, const ShadowSpec& spec,
                     uint64_t* bump, hipStream_t s) {
     float** f = a->flat[net];
     if (a->fuse_opt) {
-        FusedAdamArgs fa{f[EXORL_T_PARAM], f[EXORL_T_GRAD], f[EXORL_T_ADAM_M], f[EXORL_T_ADAM_V], target, c, d.n_heads,
-                         {d.W1, d.W1 + d.head_stride}, reinterpret_cast<unsigned long long*>(bump)};
-        return finalize_adam(pend, fa, spec, s);
+        bool& early = a->w1_early[net == EXORL_NET_CRITIC ? 0 : 1];
+        EXORL_TRY(finalize_adam(pend, fused_adam_args(a, net, d, c, target, bump), spec, s, early ? 1 : 0));
+        if (early) EXORL_TRY(a->fo.join(s));
+        early = false;
+        return 0;
     }
     return adam_step_dev(f[EXORL_T_PARAM], f[EXORL_T_GRAD], f[EXORL_T_ADAM_M], f[EXORL_T_ADAM_V], d.total, c, target, &spec, s, bump);
 }
@@ -573,11 +609,12 @@ static int phase0(exorl_agent* a, float stddev, const float* noise_c, hipStream_
     }
     if (a->want_metrics)
         EXORL_TRY(critic_loss(qv, tqv, a->reward, a->discount, a->dq, a->metrics, B, a->inv_bg, s));   // :133-137
+    const EarlyW1 ew = early_w1(a, EXORL_NET_CRITIC);
     DoutSpec td{};                              // d(2 x MSE)/dQ computed where it is consumed (:127-131)
     td.mode = EXORL_DOUT_TD; td.q = qv; td.tq = tqv; td.reward = a->reward; td.discount = a->discount; td.inv_bg = a->inv_bg;
     td.task = task; td.task_ld = O;
     EXORL_TRY(net_backward(a->critic, Pc, a->sh_critic, a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD], a->pc, a->xc_cur, W, B, a->fc, td,
-                           a->bc, nullptr, 0, 0, prec, s, a->fk, a->fuse_opt ? &a->pend_c : nullptr, qf));                       // :141
+                           a->bc, nullptr, 0, 0, prec, s, a->fk, a->fuse_opt ? &a->pend_c : nullptr, qf, &ew));                  // :141
     return 0;
 }
 
@@ -656,8 +693,9 @@ static int phase2(exorl_agent* a, float stddev, hipStream_t s) {
             dm.lam_parts = a->stats; dm.lam_chunks = 1;
         }
     }
+    const EarlyW1 ew = early_w1(a, EXORL_NET_ACTOR);
     EXORL_TRY(net_backward(a->actor, Pa, a->sh_actor, a->flat[EXORL_NET_ACTOR][EXORL_T_GRAD], a->pa, a->xa + (int64_t)B * O, O, B, f,
-                           dm, a->ba, nullptr, 0, 0, prec, s, a->fk, a->fuse_opt ? &a->pend_a : nullptr));
+                           dm, a->ba, nullptr, 0, 0, prec, s, a->fk, a->fuse_opt ? &a->pend_a : nullptr, false, &ew));
     return 0;
 }
 
@@ -793,6 +831,7 @@ int exorl_agent_destroy(exorl_agent_t* a) {
     if (a->capture_stream) (void)hipStreamDestroy(a->capture_stream);
     if (a->comm_stream) { (void)hipStreamDestroy(a->comm_stream); (void)hipEventDestroy(a->ev_stats_ready); (void)hipEventDestroy(a->ev_stats_done); }
     if (a->fk.aux) { (void)hipStreamDestroy(a->fk.aux); (void)hipEventDestroy(a->fk.ev_fork); (void)hipEventDestroy(a->fk.ev_join); }
+    if (a->fo.aux) { (void)hipStreamDestroy(a->fo.aux); (void)hipEventDestroy(a->fo.ev_fork); (void)hipEventDestroy(a->fo.ev_join); }
     if (a->owns_ws) (void)hipFree(a->ws);
     delete a;
     return 0;
@@ -911,6 +950,7 @@ int exorl_agent_update(exorl_agent_t* a, float stddev, const float* noise_c, con
     // data parallel: gradients are finalised into the flat buffers, sum-all-reduced over RCCL on this stream, then stepped.
     a->whole_step = true;
     a->fuse_opt = !dp && !a->fk.on;
+    if (a->fuse_opt && opt_overlap_enabled()) { EXORL_TRY(ensure_opt_fork(a)); a->fo.on = true; }
     const int kind = a->cfg.kind;
     int rc = exorl_agent_update_phase(a, 0, stddev, noise_c, noise_a, stream);
     if (rc == 0 && dp && a->has_critic) rc = comm_allreduce_sum(a->comm, a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD], a->critic.total, s);
@@ -922,6 +962,8 @@ int exorl_agent_update(exorl_agent_t* a, float stddev, const float* noise_c, con
     if (rc == 0) rc = exorl_agent_update_phase(a, 3, stddev, noise_c, noise_a, stream);
     a->fuse_opt = false;
     a->whole_step = false;
+    a->fo.on = false;
+    a->w1_early[0] = a->w1_early[1] = false;
     return rc;
 }
 
@@ -1019,6 +1061,7 @@ int exorl_agent_enable_graph(exorl_agent_t* a, exorl_replay_t* r, int32_t nstep,
         EXORL_CHECK_HIP(hipEventCreateWithFlags(&a->fk.ev_fork, hipEventDisableTiming));
         EXORL_CHECK_HIP(hipEventCreateWithFlags(&a->fk.ev_join, hipEventDisableTiming));
     }
+    EXORL_TRY(ensure_opt_fork(a));
     EXORL_CHECK_HIP(hipStreamBeginCapture(a->capture_stream, hipStreamCaptureModeThreadLocal));
     a->capturing = true;
     a->fk.on = a->parallel_branches;
@@ -1029,9 +1072,12 @@ int exorl_agent_enable_graph(exorl_agent_t* a, exorl_replay_t* r, int32_t nstep,
     int rc = replay_sample_impl(r, a->cfg.batch, nstep, gamma, EXORL_SAMPLER_PHILOX, nullptr, &slots, nullptr, a->capture_stream,
                                 &a->state->replay_counter, a->staged_by_sampler ? &stage : nullptr);
     a->fuse_opt = !a->fk.on;
+    a->fo.on = a->fuse_opt && opt_overlap_enabled();
     a->whole_step = true;
     for (int p = 0; p < 4 && rc == 0; ++p) rc = exorl_agent_update_phase(a, p, stddev, nullptr, nullptr, a->capture_stream);
     a->fuse_opt = false;
+    a->fo.on = false;
+    a->w1_early[0] = a->w1_early[1] = false;
     a->whole_step = false;
     a->staged_by_sampler = false;
     a->capturing = false;

@@ -1466,13 +1466,21 @@ __global__ __launch_bounds__(256) void finalize_adam_kernel(FinalizeArgs f, Fuse
     }
 }
 
-int finalize_adam(const FinalizeArgs& f, const FusedAdamArgs& a, const ShadowSpec& sh, hipStream_t s) {
-    EXORL_REQUIRE(f.H % 4 == 0 && a.n_heads >= 1 && a.n_heads <= 2, "finalize_adam: unsupported geometry");
-    const int64_t total = f.n_heads * ((int64_t)(f.nout + 1) * f.H + (f.nout > 16 ? 32 : 16)) + f.n_trunks * (int64_t)(3 + f.in_dim) * f.H;
+// part 0: the whole optimiser pass; 1: everything but the H x H weights; 2: the H x H weights only (their gradient is complete as soon
+// as the wgrad GEMM is, so that ~80 % of the pass — the HBM-bound part — can run beside the LayerNorm-backward / first-layer-wgrad chain
+// that produces the other gradients; `f` is not read then)
+int finalize_adam(const FinalizeArgs& f, const FusedAdamArgs& a, const ShadowSpec& sh, hipStream_t s, int part) {
+    EXORL_REQUIRE(sh.H % 4 == 0 && a.n_heads >= 1 && a.n_heads <= 2 && part >= 0 && part <= 2, "finalize_adam: unsupported geometry");
+    const int H = sh.H;
+    const int64_t total = part == 2 ? 0 : f.n_heads * ((int64_t)(f.nout + 1) * f.H + (f.nout > 16 ? 32 : 16)) + f.n_trunks * (int64_t)(3 + f.in_dim) * f.H;
     const int nb_fin = cdiv(total, 256);
-    int nb_w1 = cdiv((int64_t)a.n_heads * f.H * f.H / 8, 256);
+    int nb_w1 = part == 1 ? 0 : cdiv((int64_t)a.n_heads * H * H / 8, 256);
     if (nb_w1 > 2048) nb_w1 = 2048;
-    hipLaunchKernelGGL(finalize_adam_kernel, dim3(nb_fin + nb_w1), dim3(256), 0, s, f, a, sh, nb_fin);
+    FusedAdamArgs aa = a;
+    if (part == 2) aa.bump = nullptr;
+    FinalizeArgs ff = f;
+    if (part == 2) ff.H = H;
+    hipLaunchKernelGGL(finalize_adam_kernel, dim3(nb_fin + nb_w1), dim3(256), 0, s, ff, aa, sh, nb_fin);
     EXORL_LAUNCH_CHECK();
     return 0;
 }

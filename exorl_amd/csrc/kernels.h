@@ -177,7 +177,7 @@ struct FusedAdamArgs {
     unsigned long long* bump;
 };
 struct ShadowSpec;
-int finalize_adam(const FinalizeArgs& f, const FusedAdamArgs& a, const ShadowSpec& sh, hipStream_t s);
+int finalize_adam(const FinalizeArgs& f, const FusedAdamArgs& a, const ShadowSpec& sh, hipStream_t s, int part = 0);
 
 // Derived copies of a net's weights that the kernels read: W0T[in][H] per trunk (coalesced first-layer reads)
 // and, in bf16 mode, W1 as bf16 per head (MFMA operand). Kept current by the Adam kernel itself.

@@ -220,49 +220,49 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
         y0 = p0 / ow;
         rows = p1 / ow - y0 + 3;
     };
-    // item index -> (x, strip row, channel pair) by float reciprocals: exact for these ranges (i < 7680; (i + 0.5) / d is at least
-    // 0.5 / d away from an integer), and ~8 instructions where the integer divisions by run-time values cost ~150 per item
-    const float inv_sw = 1.0f / (float)sw;
-    auto split = [&](int i, int rows, float inv_rows, int& xx, int& yy, int& cp) {
-        const int q = (int)(((float)i + 0.5f) * inv_sw);
-        xx = i - q * sw;
-        cp = (int)(((float)q + 0.5f) * inv_rows);
-        yy = q - cp * rows;
-    };
+    // Staging items: a half-wave (32 lanes) owns one channel pair and walks the strip's (row, x) positions in flattened order j = lane + 32 u,
+    // so global reads are 128-byte runs of a row, the LDS offset is linear in j, and (row, x) advance by a constant step with one carry —
+    // the per-item index arithmetic is a handful of adds (it was two reciprocal divisions per item, and with the conversions made the
+    // kernel VALU-bound: ~8 k cycles of staging per SIMD and pass against 3.5 k cycles of MFMA).
+    const int cp = tid >> 5, jl = tid & 31;
+    const float* in0 = inn + (int64_t)(2 * cp) * ih * iw;
+    const float* in1 = in0 + (int64_t)ih * iw;
+    const int step_y = 32 / sw, step_x = 32 % sw, yy0 = jl / sw, xx0 = jl % sw;
+    typedef float cf32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 cbf16x2 __attribute__((ext_vector_type(2)));
     auto fetch = [&](int pass) {
         int y0, rows;
         strip(pass, y0, rows);
-        const int items = 16 * rows * sw;
-        const float inv_rows = 1.0f / (float)rows;
+        const int nj = rows * sw;
+        int yy = yy0, xx = xx0;
 #pragma unroll
         for (int u = 0; u < CM_IPT; ++u) {
-            const int i = tid + CM_THREADS * u;
-            int xx, yy, cp;
-            split(i, rows, inv_rows, xx, yy, cp);
             const int gy = y0 - pad + yy, gx = xx - pad;
-            const bool ok = i < items && gy >= 0 && gy < ih && gx >= 0 && gx < iw;
-            v0[u] = ok ? inn[((int64_t)(2 * cp) * ih + gy) * iw + gx] : 0.f;
-            v1[u] = ok ? inn[((int64_t)(2 * cp + 1) * ih + gy) * iw + gx] : 0.f;
+            const bool ok = jl + 32 * u < nj && (unsigned)gy < (unsigned)ih && (unsigned)gx < (unsigned)iw;
+            const int off = ok ? gy * iw + gx : 0;                   // unconditional loads (index clamped), masked afterwards
+            const float a0 = in0[off], a1 = in1[off];
+            v0[u] = ok ? a0 : 0.f;
+            v1[u] = ok ? a1 : 0.f;
+            xx += step_x; yy += step_y;
+            if (xx >= sw) { xx -= sw; ++yy; }
         }
     };
     fetch(0);
     for (int pass = 0; pass < npass; ++pass) {
         int y0, rows;
         strip(pass, y0, rows);
-        const int items = 16 * rows * sw, p0 = pass * CM_PASS;
-        const float inv_rows = 1.0f / (float)rows;
+        const int nj = rows * sw, p0 = pass * CM_PASS;
 #pragma unroll
         for (int u = 0; u < CM_IPT; ++u) {
-            const int i = tid + CM_THREADS * u;
-            if (i < items) {
-                int xx, yy, cp;
-                split(i, rows, inv_rows, xx, yy, cp);
-                const __bf16 h0 = (__bf16)v0[u], h1 = (__bf16)v1[u];
-                const int o = (yy * sw + xx) * CM_PIX + 2 * cp;
-                *reinterpret_cast<unsigned int*>(xh + o) = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+            const int j = jl + 32 * u;
+            if (j < nj) {
+                const cf32x2 v = {v0[u], v1[u]};
+                const cbf16x2 h = __builtin_convertvector(v, cbf16x2);
+                const int o = j * CM_PIX + 2 * cp;
+                *reinterpret_cast<unsigned int*>(xh + o) = __builtin_bit_cast(unsigned int, h);
                 if constexpr (X3) {
-                    const __bf16 l0 = (__bf16)(v0[u] - (float)h0), l1 = (__bf16)(v1[u] - (float)h1);
-                    *reinterpret_cast<unsigned int*>(xl + o) = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+                    const cbf16x2 l = __builtin_convertvector(v - __builtin_convertvector(h, cf32x2), cbf16x2);
+                    *reinterpret_cast<unsigned int*>(xl + o) = __builtin_bit_cast(unsigned int, l);
                 }
             }
         }
