@@ -62,7 +62,7 @@ class IntrBatch(C.Structure):
 
 class PixelCfg(C.Structure):
     _fields_ = [('c_in', c_int32), ('hw', c_int32), ('act_dim', c_int32), ('feature_dim', c_int32), ('hidden_dim', c_int32), ('batch', c_int32),
-                ('precision', c_int32), ('reserved', c_int32), ('lr', c_float), ('tau', c_float), ('stddev_clip', c_float), ('reserved2', c_float),
+                ('precision', c_int32), ('meta_dim', c_int32), ('lr', c_float), ('tau', c_float), ('stddev_clip', c_float), ('reserved2', c_float),
                 ('seed', c_uint64)]
 
 
@@ -88,7 +88,7 @@ PROTOTYPES = {
     'exorl_pixel_agent_set_state': (C.c_int, [c_void_p, c_void_p, c_void_p]),
     'exorl_pixel_agent_encoder_opt2': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     'exorl_pixel_agent_metrics': (C.c_int, [c_void_p, c_void_p, c_void_p]),
-    'exorl_pixel_agent_act': (C.c_int, [c_void_p, c_void_p, c_float, c_int32, c_void_p, c_void_p, c_void_p]),
+    'exorl_pixel_agent_act': (C.c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int32, c_void_p, c_void_p, c_void_p]),
     'exorl_aug_shift': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_uint64, c_uint64, c_void_p, c_void_p]),
     'exorl_encoder_param_floats': (c_int64, [c_int32, c_int32]),
     'exorl_encoder_out_dim': (c_int64, [c_int32]),

@@ -509,10 +509,12 @@ class DDPGAgent(_AgentBase):
                  critic_target_tau, num_expl_steps, update_every_steps, stddev_schedule, nstep, batch_size, stddev_clip,
                  init_critic, use_tb, use_wandb, meta_dim=0, skill_type='uniform', *, precision='fp32', seed=0):
         if obs_type == 'pixels':
-            if not (type(self) is DDPGAgent or getattr(self, '_PIXELS_OK', False)) or meta_dim:
-                raise NotImplementedError("exorl_amd: obs_type='pixels' is built for DDPGAgent and ProtoAgent (no meta) this round")
+            if not (type(self) is DDPGAgent or getattr(self, '_PIXELS_OK', False)):
+                raise NotImplementedError(f"exorl_amd: obs_type='pixels' is not built for {type(self).__name__} yet (DDPG, Proto, ICM, ICM-APT, "
+                                          "Disagreement and DIAYN are)")
             return self._init_pixels(reward_free, obs_shape, action_shape, device, lr, feature_dim, hidden_dim, critic_target_tau, num_expl_steps,
-                                     update_every_steps, stddev_schedule, batch_size, stddev_clip, init_critic, use_tb, use_wandb, precision, seed)
+                                     update_every_steps, stddev_schedule, batch_size, stddev_clip, init_critic, use_tb, use_wandb, precision, seed,
+                                     meta_dim)
         if obs_type != 'states':
             raise NotImplementedError(f"exorl_amd DDPGAgent: unknown obs_type {obs_type!r}")
         self.reward_free = reward_free
@@ -546,8 +548,9 @@ class DDPGAgent(_AgentBase):
 
     # ---- obs_type == 'pixels' (ddpg.py:12-39 Encoder, :42-123 pixel Actor/Critic, :213-328) -----------------------------------------
     def _init_pixels(self, reward_free, obs_shape, action_shape, device, lr, feature_dim, hidden_dim, critic_target_tau, num_expl_steps,
-                     update_every_steps, stddev_schedule, batch_size, stddev_clip, init_critic, use_tb, use_wandb, precision, seed):
+                     update_every_steps, stddev_schedule, batch_size, stddev_clip, init_critic, use_tb, use_wandb, precision, seed, meta_dim=0):
         self.reward_free, self.obs_type, self.obs_shape = reward_free, 'pixels', tuple(obs_shape)
+        self._precision, self._pix_meta_dim = precision, meta_dim
         self.action_dim, self.hidden_dim, self.feature_dim = action_shape[0], hidden_dim, feature_dim
         self.lr, self.device, self.critic_target_tau = lr, device, critic_target_tau
         self.update_every_steps, self.use_tb, self.use_wandb = update_every_steps, use_tb, use_wandb
@@ -557,10 +560,10 @@ class DDPGAgent(_AgentBase):
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             raise NotImplementedError('exorl_amd: the pixel path is single-GPU this round')
         c = obs_shape[0]
-        w = _pixel_init(c, obs_shape[1], self.action_dim, feature_dim, hidden_dim)
+        w = _pixel_init(c, obs_shape[1], self.action_dim, feature_dim, hidden_dim, meta_dim)
         self.engine = PixelEngine(obs_shape, self.action_dim, feature_dim, hidden_dim, batch_size, lr=lr, tau=critic_target_tau,
-                                  stddev_clip=stddev_clip, precision=precision, seed=seed, device=device)
-        self.obs_dim = w['repr_dim']
+                                  stddev_clip=stddev_clip, precision=precision, seed=seed, device=device, meta_dim=meta_dim)
+        self.obs_dim = w['repr_dim'] + meta_dim          # ddpg.py:176 obs_dim = encoder.repr_dim + meta_dim
         conv_shapes = [s for l in range(4) for s in ((32, c if l == 0 else 32, 3, 3), (32,))]
         self.encoder = _PixelNetView(self.engine, 0, _ENC_KEYS, conv_shapes)
         self.actor = _PixelNetView(self.engine, 1, _PIX_ACTOR_KEYS)
@@ -631,7 +634,8 @@ class DDPGAgent(_AgentBase):
         if self.obs_type == 'pixels':
             stddev = self._stddev(step)
             noise = self.noise_hook((1, self.action_dim)) if (self.noise_hook and not eval_mode) else None
-            a = self.engine.act(np.ascontiguousarray(obs), stddev, eval_mode, noise)
+            mv = np.concatenate([np.asarray(v, np.float32).reshape(-1) for v in meta.values()]) if self._pix_meta_dim else None
+            a = self.engine.act(np.ascontiguousarray(obs), stddev, eval_mode, noise, mv)
             if not eval_mode and step < self.num_expl_steps:
                 a.uniform_(-1.0, 1.0)
             return a.cpu().numpy()
@@ -718,10 +722,67 @@ class _IntrAgent(DDPGAgent):
     def enable_graph(self, replay_iter, step=0):
         return False                     # the module step is launched eagerly in front of the DDPG chain
 
+    # ---- obs_type == 'pixels' ---------------------------------------------------------------------------------------------------
+    # Every one of these agents augments and encodes obs and next_obs ONCE (icm.py:97-99, icm_apt.py:113-118, disagreement.py:98-100,
+    # diayn.py:137-138), steps its module AND the encoder on the module's loss (encoder_opt.step() inside update_<module>), takes the
+    # intrinsic reward from the updated module on the encodings computed before that step, and hands the critic and the actor those same
+    # encodings detached (`update_critic(obs.detach(), ...)`): after the module step nothing else moves the encoder, and encoder_opt's
+    # second .step() inside update_critic finds no gradients (Adam skips parameters whose .grad is None, step counts included).
+    _PIX_GRAD = 0                        # which encoding carries the graph into the module's loss: 0 obs, 1 next_obs
+
+    def _pix_module(self, fo, fn, s):
+        """Module step + intrinsic reward on the encodings (device pointers); d(loss)/d(encoding) lands in self._dobs."""
+        self.intr.update(fo, s.action, fn, s.reward, s.reward, True, dobs_out=self._dobs.data_ptr())
+
+    def _pix_alloc(self):
+        """Called by the subclass constructors once self.intr exists."""
+        if getattr(self, 'obs_type', 'states') == 'pixels':
+            self._dobs = torch.empty(self.engine.batch, self.obs_dim - self._pix_meta_dim, dtype=torch.float32, device=self.engine.device)
+
+    def _update_pixels(self, replay_iter, step):
+        eng = self.engine
+        M = self._pix_meta_dim
+        s = self._slots = self._slots or eng.batch_slots()
+        if hasattr(replay_iter, 'sample_into'):
+            replay_iter.sample_into(s, eng.batch)
+        else:
+            b = next(replay_iter)
+            eng.set_batch(*b[:5])
+            if M:
+                eng.meta_rows().copy_(torch.as_tensor(b[5]).to(eng.device, torch.float32).reshape(eng.batch, M))
+        B, A = eng.batch, self.action_dim
+        eng.augment(self.shift_hook(B) if self.shift_hook else None, self.shift_hook(B) if self.shift_hook else None)
+        fo, fn = eng.encode(0), eng.encode(1)
+        if self.reward_free:
+            self._pix_module(fo, fn, s)
+            eng.encoder_step(self._PIX_GRAD, self._dobs.data_ptr(), 0)
+        stddev = self._stddev(step)
+        eng.set_train_encoder(False)
+        eng.update(stddev, None, None, self.noise_hook((B, A)) if self.noise_hook else None, self.noise_hook((B, A)) if self.noise_hook else None,
+                   keep_encoded=True)
+        metrics = dict()
+        if self.use_tb or self.use_wandb:
+            raw = eng.metrics_raw()
+            for idx, name in _CRITIC_METRICS + [(L.M_ACTOR_LOGPROB, 'actor_logprob')]:
+                metrics[name] = float(raw[idx])
+            metrics['actor_ent'] = float(np.float32(0.5 + 0.5 * np.log(2 * np.pi) + np.log(stddev)) * self.action_dim)
+            if self.reward_free:
+                ri = self.intr.metrics_raw()
+                metrics[self.LOSS_KEY] = float(ri[L.IM_LOSS])
+                metrics['intr_reward'] = float(ri[L.IM_INTR_REWARD])
+                metrics['extr_reward'] = float(ri[L.IM_EXTR_REWARD])
+                if self.LOSS_KEY == 'diayn_loss':
+                    metrics['diayn_acc'] = float(ri[L.IM_ACC])
+            else:
+                metrics['extr_reward'] = metrics['batch_reward']
+        return metrics
+
     def update(self, replay_iter, step):
         metrics = dict()
         if step % self.update_every_steps != 0:
             return metrics
+        if self.obs_type == 'pixels':
+            return self._update_pixels(replay_iter, step)
         if self.world_size != 1:
             raise NotImplementedError('exorl_amd: the intrinsic-reward modules normalise over the batch (BatchNorm / RMS / kNN) and are '
                                       'single-GPU this round; run data-parallel replicas instead')
@@ -771,6 +832,7 @@ class RNDAgent(_IntrAgent):
 class ICMAgent(_IntrAgent):
     """agents/unsupervised_learning/icm.py:48-139 (configs/agent/icm.yaml)."""
     LOSS_KEY = 'icm_loss'
+    _PIXELS_OK = True
 
     def __init__(self, icm_scale, update_encoder, **kwargs):
         super().__init__(**kwargs)
@@ -783,6 +845,7 @@ class ICMAgent(_IntrAgent):
         self.icm = NetView(self.intr, None, _ICM_KEYS)
         for p, t in zip(self.icm.parameters(), w):
             p.copy_(t.reshape(p.shape))
+        self._pix_alloc()
 
 
 class _PbeView:
@@ -793,6 +856,7 @@ class _PbeView:
 class ICMAPTAgent(_IntrAgent):
     """agents/unsupervised_learning/icm_apt.py:60-158 (configs/agent/icm_apt.yaml)."""
     LOSS_KEY = 'icm_loss'
+    _PIXELS_OK = True
 
     def __init__(self, icm_scale, knn_rms, knn_k, knn_avg, knn_clip, update_encoder, icm_rep_dim, **kwargs):
         super().__init__(**kwargs)
@@ -806,6 +870,7 @@ class ICMAPTAgent(_IntrAgent):
         for p, t in zip(self.icm.parameters(), w):
             p.copy_(t.reshape(p.shape))
         self.pbe = _PbeView(self.intr)
+        self._pix_alloc()
 
 
 _DIS_KEYS = [f'ensemble.{m}.{i}.{w}' for m in range(5) for i in (0, 2) for w in ('weight', 'bias')]
@@ -815,6 +880,7 @@ _DIAYN_KEYS = [f'skill_pred_net.{i}.{w}' for i in (0, 2, 4) for w in ('weight', 
 class DisagreementAgent(_IntrAgent):
     """agents/unsupervised_learning/disagreement.py:50-136 (configs/agent/disagreement.yaml)."""
     LOSS_KEY = 'disagreement_loss'
+    _PIXELS_OK = True
 
     def __init__(self, update_encoder, **kwargs):
         super().__init__(**kwargs)
@@ -830,6 +896,7 @@ class DisagreementAgent(_IntrAgent):
         self.disagreement = NetView(self.intr, None, _DIS_KEYS)
         for p, t in zip(self.disagreement.parameters(), w):
             p.copy_(t.reshape(p.shape))
+        self._pix_alloc()
 
 
 class _Spec:
@@ -872,6 +939,8 @@ class DIAYNAgent(_MetaObsMixin, _IntrAgent):
     """agents/unsupervised_learning/diayn.py:32-176 (configs/agent/diayn.yaml): the skill rides in the batch as a 6th tensor and
     is appended to obs / next_obs for the actor and critic; the discriminator sees the raw next_obs."""
     LOSS_KEY = 'diayn_loss'
+    _PIXELS_OK = True
+    _PIX_GRAD = 1
 
     def __init__(self, update_skill_every_step, skill_dim, diayn_scale, update_encoder, **kwargs):
         self.skill_dim = self._meta_dim = skill_dim
@@ -888,6 +957,10 @@ class DIAYNAgent(_MetaObsMixin, _IntrAgent):
         self.diayn = NetView(self.intr, None, _DIAYN_KEYS)
         for p, t in zip(self.diayn.parameters(), w):
             p.copy_(t.reshape(p.shape))
+        self._pix_alloc()
+
+    def _pix_module(self, fo, fn, s):          # the discriminator reads the next frame's encoding (diayn.py:141-147)
+        self.intr.update(fo, None, fn, s.reward, s.reward, True, skill=s.meta, skill_ld=self.skill_dim, dobs_out=self._dobs.data_ptr())
 
     def get_meta_specs(self):
         return (_Spec((self.skill_dim,), np.float32, 'skill'),)
@@ -1270,7 +1343,7 @@ class _PixelNetView(NetView):
         return [self._engine.tensor(self._net, i, L.T_GRAD) for i in range(len(self._keys))]
 
 
-def _pixel_init(c_in, hw, A, F, H):
+def _pixel_init(c_in, hw, A, F, H, meta_dim=0):
     """Initial tensors of Encoder, pixel Actor, pixel Critic (and the critic_target's discarded draws) in the reference's RNG order
     (ddpg.py:165-181): every module default-initialised at construction, then weight_init — orthogonal with the ReLU gain for
     Conv2d, gain 1 for Linear, zero biases (utils.py:59-69)."""
@@ -1285,7 +1358,7 @@ def _pixel_init(c_in, hw, A, F, H):
     R = 32 * e * e
 
     def net(head_in, out, n_heads):
-        mods = [nn.Linear(R, F), nn.LayerNorm(F)]
+        mods = [nn.Linear(R + meta_dim, F), nn.LayerNorm(F)]
         for _ in range(n_heads):
             mods += [nn.Linear(head_in, H), nn.Linear(H, H), nn.Linear(H, out)]
         for m in mods:

@@ -254,6 +254,17 @@ __global__ __launch_bounds__(256) void apt_drep_kernel(const float* __restrict__
     }
 }
 
+// d(loss)/d(obs) of plain ICM (icm.py:27-45): obs feeds the forward model's and the inverse model's input; dst is dense (B, O)
+__global__ __launch_bounds__(256) void icm_dobs_kernel(const float* __restrict__ dxf, int64_t ldf, const float* __restrict__ dxb, int64_t ldb,
+                                                       float* __restrict__ dst, int B, int O) {
+    const int64_t n = (int64_t)B * O;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / O;
+        const int c = (int)(i - r * O);
+        dst[i] = dxf[r * ldf + c] + dxb[r * ldb + c];
+    }
+}
+
 // Disagreement reward (disagreement.py:35-47): unbiased variance over the ensemble's predictions, mean over features
 struct PredSet { const float* p[EXORL_MAX_ENSEMBLE]; };
 __global__ __launch_bounds__(256) void disagreement_reward_kernel(PredSet ps, int n, float* __restrict__ reward, int rows, int D) {
@@ -622,8 +633,8 @@ int mlp_forward_many(const Mlp* nets, int n, const float* P, const float* x, int
     }
     return 0;
 }
-// backward of the same ensemble (no d/d(input)): masks + bias gradients per net, weight gradients and hidden dgrads grouped
-int mlp_backward_many(const Mlp* nets, int n, const float* P, float* G, const float* x, int64_t ldx, int rows, int prec, hipStream_t s) {
+// backward of the same ensemble: masks + bias gradients per net, weight gradients and hidden dgrads grouped; dx (rows, in0) or null
+int mlp_backward_many(const Mlp* nets, int n, const float* P, float* G, const float* x, int64_t ldx, int rows, int prec, hipStream_t s, float* dx) {
     EXORL_REQUIRE(n >= 1 && n <= 16, "mlp_backward_many: %d nets", n);
     const int nl = (int)nets[0].L.size();
     for (int l = nl - 1; l >= 0; --l) {
@@ -646,6 +657,12 @@ int mlp_backward_many(const Mlp* nets, int n, const float* P, float* G, const fl
         }
         EXORL_TRY(gemm_grouped(prec, 1, 1, w, n, false, false, s));
         if (l) EXORL_TRY(gemm_grouped(prec, 0, 1, g, n, false, false, s));
+        else if (dx)                               // d/d(input) summed over the nets in net order (one accumulating launch per net)
+            for (int m = 0; m < n; ++m) {
+                const Lin& L = nets[m].L[0];
+                GemmProblem gx{nets[m].dact[0], P + L.W, dx, nullptr, rows, L.in, L.out, L.out, L.in, L.in};
+                EXORL_TRY(gemm_grouped(prec, 0, 1, &gx, 1, false, m > 0, s));
+            }
     }
     return 0;
 }
@@ -815,11 +832,12 @@ static void carve_intr(exorl_intr* it, ICarver& c) {
         it->d2 = c.take(B * round_up(g.queue_size, 64));
     } else if (g.kind == EXORL_INTR_DISAGREEMENT) {
         it->xf = c.take(B * it->net[0].L[0].in);
+        it->dxf = c.take(B * it->net[0].L[0].in);
     } else if (g.kind != EXORL_INTR_DIAYN) {
         const int64_t in_f = it->net[0].L[0].in, in_b = it->net[1].L[0].in;
         it->xf = c.take(B * in_f); it->xb = c.take(B * in_b);
+        it->dxf = c.take(B * in_f); it->dxb = c.take(B * in_b);
         if (g.kind == EXORL_INTR_ICM_APT) {
-            it->dxf = c.take(B * in_f); it->dxb = c.take(B * in_b);
             it->x2 = c.take(2 * B * O); it->z = c.take(2 * B * R); it->rep = c.take(2 * B * R); it->xhat = c.take(2 * B * R);
             it->rstd = c.take(2 * B); it->drep = c.take(2 * B * R); it->dz = c.take(2 * B * R);
             it->topk = c.take(B * g.knn_k);
@@ -912,8 +930,12 @@ static int icm_update(exorl_intr* it, const exorl_intr_batch& b, bool train, hip
         EXORL_TRY(icm_errors(it, b.next_obs, b.next_obs_ld, b.action, b.action_ld, true, true, s));
         EXORL_TRY(launch_mean(it->fe, B, 1.0f / (float)B, it->metrics + EXORL_IM_LOSS, 0, s));
         EXORL_TRY(launch_mean(it->be, B, 1.0f / (float)B, it->metrics + EXORL_IM_LOSS, 1, s));
-        EXORL_TRY(mlp_backward(it->net[0], P, G, it->xf, O + A, B, nullptr, prec, s));
-        EXORL_TRY(mlp_backward(it->net[1], P, G, it->xb, 2 * O, B, nullptr, prec, s));
+        EXORL_TRY(mlp_backward(it->net[0], P, G, it->xf, O + A, B, b.dobs_out ? it->dxf : nullptr, prec, s));
+        EXORL_TRY(mlp_backward(it->net[1], P, G, it->xb, 2 * O, B, b.dobs_out ? it->dxb : nullptr, prec, s));
+        if (b.dobs_out) {                          // obs is an encoding: the caller's encoder continues the backward pass (icm.py:64-78)
+            hipLaunchKernelGGL(icm_dobs_kernel, dim3(grid_for((int64_t)B * O)), dim3(256), 0, s, it->dxf, (int64_t)(O + A), it->dxb, (int64_t)(2 * O), b.dobs_out, B, O);
+            EXORL_LAUNCH_CHECK();
+        }
         EXORL_TRY(intr_adam(it, s));
     }
     EXORL_TRY(mlp_forward(it->net[0], P, it->xf, O + A, B, prec, s));                                // icm.py:86-92
@@ -958,6 +980,10 @@ static int apt_update(exorl_intr* it, const exorl_intr_batch& b, bool train, hip
         EXORL_TRY(colsum(it->dz, G + it->trunk.b, 2 * B, R, 1, 0, 0, s));
         GemmProblem w{it->dz, it->x2, G + it->trunk.W, nullptr, R, O, 2 * B, R, O, O};
         EXORL_TRY(gemm_grouped(prec, 1, 1, &w, 1, false, false, s));
+        if (b.dobs_out) {                          // d(loss)/d(obs rows) = dz[:B] W_trunk (next_obs was encoded without a graph, icm_apt.py:116-118)
+            GemmProblem gx{it->dz, P + it->trunk.W, b.dobs_out, nullptr, B, O, R, R, O, O};
+            EXORL_TRY(gemm_grouped(prec, 0, 1, &gx, 1, false, false, s));
+        }
         EXORL_TRY(intr_adam(it, s));
     }
     EXORL_TRY(apt_trunk(it, b.obs, b.obs_ld, B, s));                                                 // icm_apt.py:106-110
@@ -982,7 +1008,8 @@ static int disagreement_update(exorl_intr* it, const exorl_intr_batch& b, bool t
                                A, it->fe + (int64_t)m * B, nullptr, it->net[m].dact[1], nullptr, B, 1.0f / ((float)B * (float)n));
             EXORL_LAUNCH_CHECK();
         }
-        EXORL_TRY(mlp_backward_many(it->net, n, P, G, it->xf, O + A, B, prec, s));
+        EXORL_TRY(mlp_backward_many(it->net, n, P, G, it->xf, O + A, B, prec, s, b.dobs_out ? it->dxf : nullptr));
+        if (b.dobs_out) EXORL_TRY(launch_concat(it->dxf, O + A, O, nullptr, 0, 0, b.dobs_out, B, s));
         EXORL_TRY(launch_mean(it->fe, B * n, 1.0f / ((float)B * (float)n), it->metrics + EXORL_IM_LOSS, 0, s));
         EXORL_TRY(intr_adam(it, s));
     }
@@ -1007,7 +1034,7 @@ static int diayn_update(exorl_intr* it, const exorl_intr_batch& b, bool train, h
         EXORL_LAUNCH_CHECK();
         EXORL_TRY(launch_mean(it->fe, B, 1.0f / (float)B, it->metrics + EXORL_IM_LOSS, 0, s));
         EXORL_TRY(launch_mean(it->be, B, 1.0f / (float)B, it->metrics + EXORL_IM_ACC, 0, s));
-        EXORL_TRY(mlp_backward(it->net[0], P, it->flat[EXORL_T_GRAD], b.next_obs, b.next_obs_ld, B, nullptr, prec, s));
+        EXORL_TRY(mlp_backward(it->net[0], P, it->flat[EXORL_T_GRAD], b.next_obs, b.next_obs_ld, B, b.dobs_out, prec, s));   // dobs_out: d/d(next_obs)
         EXORL_TRY(intr_adam(it, s));
     }
     EXORL_TRY(mlp_forward(it->net[0], P, b.next_obs, b.next_obs_ld, B, prec, s));                    // diayn.py:94-105
@@ -1083,7 +1110,7 @@ static int aps_update(exorl_intr* it, const exorl_intr_batch& b, bool train, hip
         hipLaunchKernelGGL(aps_loss_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->net[0].act[2], b.skill, b.skill_ld, it->net[0].dact[2], it->fe, B, D);
         EXORL_LAUNCH_CHECK();
         EXORL_TRY(launch_mean(it->fe, B, 1.0f / (float)B, it->metrics + EXORL_IM_LOSS, 0, s));
-        EXORL_TRY(mlp_backward(it->net[0], P, it->flat[EXORL_T_GRAD], b.next_obs, b.next_obs_ld, B, nullptr, prec, s));
+        EXORL_TRY(mlp_backward(it->net[0], P, it->flat[EXORL_T_GRAD], b.next_obs, b.next_obs_ld, B, b.dobs_out, prec, s));   // dobs_out: d/d(next_obs)
         EXORL_TRY(intr_adam(it, s));
     }
     EXORL_TRY(mlp_forward(it->net[0], P, b.next_obs, b.next_obs_ld, B, prec, s));                    // aps.py:161-168

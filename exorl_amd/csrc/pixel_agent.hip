@@ -82,7 +82,7 @@ struct exorl_pixel_agent {
     // flat[net][what]; nets: 0 encoder, 1 actor, 2 critic, 3 critic_target (params only)
     float* flat[4][4] = {{nullptr}};
     unsigned char *obs = nullptr, *next_obs = nullptr;
-    float *action = nullptr, *reward = nullptr, *discount = nullptr;
+    float *action = nullptr, *reward = nullptr, *discount = nullptr, *meta = nullptr;      // meta: (batch, meta_dim) skill / task rows
     float *aug_o = nullptr, *aug_n = nullptr, *enc_ws_o = nullptr, *enc_ws_n = nullptr, *feat_o = nullptr, *feat_n = nullptr;
     float* splitk = nullptr;
     TrunkAct ta_n{}, ta_o{}, tt{}, tc{};         // actor on next_obs / obs, target critic, critic
@@ -91,12 +91,13 @@ struct exorl_pixel_agent {
     float *stats = nullptr, *metrics = nullptr;
     int32_t* shifts = nullptr;
     float* act_ws = nullptr;                     // B = 1 inference scratch
-    int64_t t = 0;
+    int64_t t = 0, t_enc = 0;                    // Adam step counts: critic_opt / actor_opt, encoder_opt (equal for plain DDPG)
     uint64_t noise_counter = 0, aug_counter = 0, act_counter = 0;
     // Proto on pixels (proto.py:46-85): encoder_target (Polyak copy) and the encoder's second Adam state (proto_opt's)
     float *enc_target = nullptr, *enc_m2 = nullptr, *enc_v2 = nullptr;
     int64_t t2 = 0;
     bool augmented = false;
+    bool have_feat_o = false, have_feat_n = false;     // feat_o / feat_n hold the online encoder's pass of exorl_pixel_agent_encode
     bool train_encoder = true;      // false: update_critic received obs.detach() (proto.py:190-193): encoder_opt.step() finds no gradients
 };
 
@@ -129,10 +130,11 @@ static void pcarve(exorl_pixel_agent* a, PCarver& c) {
     a->obs = reinterpret_cast<unsigned char*>(c.take((B * img + 3) / 4));
     a->next_obs = reinterpret_cast<unsigned char*>(c.take((B * img + 3) / 4));
     a->action = c.take(B * A); a->reward = c.take(B); a->discount = c.take(B);
+    a->meta = c.take(B * (g.meta_dim > 0 ? g.meta_dim : 1));
     a->aug_o = c.take(B * img); a->aug_n = c.take(B * img);
     const int64_t ews = exorl_encoder_workspace_floats((int32_t)B, g.c_in, g.hw);
     a->enc_ws_o = c.take(ews); a->enc_ws_n = c.take(ews);
-    a->splitk = c.take((int64_t)SPLITK * B * F);
+    a->splitk = c.take((int64_t)(SPLITK + 1) * B * F);
     for (TrunkAct* t : {&a->ta_n, &a->ta_o, &a->tt, &a->tc}) { t->z = c.take(B * F); t->h = c.take(B * F); t->xhat = c.take(B * F); t->rstd = c.take(B); }
     a->xq_t = c.take(B * (F + A)); a->xq_c = c.take(B * (F + A));
     a->dxq[0] = c.take(B * (F + A)); a->dxq[1] = c.take(B * (F + A));
@@ -149,44 +151,56 @@ static void pcarve(exorl_pixel_agent* a, PCarver& c) {
     a->act_ws = c.take(exorl_encoder_workspace_floats(1, g.c_in, g.hw) + img + 4 * F + 2 * 1024 + 64);
 }
 
-// z = x W0^T + b0 (split-K), then LayerNorm + tanh
-static int trunk_forward(exorl_pixel_agent* a, const PNet& n, const float* P, const float* x, int rows, const TrunkAct& t, int prec, hipStream_t s) {
-    const int D = n.D, F = n.F;
-    int kc = (int)round_up(cdiv(D, SPLITK), 4);
-    GemmProblem p[SPLITK];                     // all slabs in one launch: SPLITK x rows/64 workgroups
+// z = [x | meta] W0^T + b0 (split-K over the encoding's columns, one more slab for the meta columns), then LayerNorm + tanh.
+// The trunk's input is cat([encoding, skill]) for the meta-conditioned agents (diayn.py:163-165, ddpg.py:305-312): the two parts stay
+// where they are (x: rows x R inside the encoder workspace, meta: rows x M) and enter as separate GEMM problems.
+static int trunk_forward(exorl_pixel_agent* a, const PNet& n, const float* P, const float* x, const float* meta, int rows, const TrunkAct& t, int prec,
+                         hipStream_t s) {
+    const int D = n.D, F = n.F, R = a->R, M = D - R;
+    int kc = (int)round_up(cdiv(R, SPLITK), 4);
+    GemmProblem p[SPLITK + 1];                 // all slabs in one launch: SPLITK x rows/64 workgroups
     int cnt = 0;
     for (int i = 0; i < SPLITK; ++i) {
         const int k0 = i * kc;
-        if (k0 >= D) break;
-        const int k = D - k0 < kc ? D - k0 : kc;
-        p[cnt++] = GemmProblem{x + k0, P + n.trunk.W + k0, a->splitk + (int64_t)i * rows * F, nullptr, rows, F, k, D, D, F};
+        if (k0 >= R) break;
+        const int k = R - k0 < kc ? R - k0 : kc;
+        p[cnt] = GemmProblem{x + k0, P + n.trunk.W + k0, a->splitk + (int64_t)cnt * rows * F, nullptr, rows, F, k, R, D, F};
+        ++cnt;
+    }
+    if (M > 0) {
+        EXORL_REQUIRE(meta, "pixel_agent: the trunk takes %d meta columns but no meta rows were given", M);
+        p[cnt] = GemmProblem{meta, P + n.trunk.W + R, a->splitk + (int64_t)cnt * rows * F, nullptr, rows, F, M, M, D, F};
+        ++cnt;
     }
     EXORL_TRY(gemm_grouped(prec, 0, 0, p, cnt, false, false, s));
-    const int splits = cdiv(D, kc);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid1((int64_t)rows * F)), dim3(256), 0, s, a->splitk, P + n.trunk.b, t.z, (int64_t)rows * F, F, splits);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid1((int64_t)rows * F)), dim3(256), 0, s, a->splitk, P + n.trunk.b, t.z, (int64_t)rows * F, F, cnt);
     EXORL_LAUNCH_CHECK();
     return ln_tanh_fwd(t.z, P + n.g, P + n.beta, t.h, t.xhat, t.rstd, rows, F, 1, 0, 0, s);
 }
 
-// dh (rows, F) at the trunk output -> parameter grads (W0, b0, gain, beta) and optionally d/d(input) (rows, D)
-static int trunk_backward(exorl_pixel_agent* a, const PNet& n, const float* P, float* G, const float* x, int rows, const TrunkAct& t, const float* dh,
-                          float* dx, int prec, hipStream_t s) {
-    const int D = n.D, F = n.F;
+// dh (rows, F) at the trunk output -> parameter grads (W0, b0, gain, beta) and optionally d/d(encoding) (rows, R)
+static int trunk_backward(exorl_pixel_agent* a, const PNet& n, const float* P, float* G, const float* x, const float* meta, int rows, const TrunkAct& t,
+                          const float* dh, float* dx, int prec, hipStream_t s) {
+    const int D = n.D, F = n.F, R = a->R, M = D - R;
     EXORL_TRY(ln_param_grad(dh, t.h, t.xhat, G + n.g, G + n.beta, rows, F, 1, 0, 0, s));
     EXORL_TRY(ln_tanh_bwd(dh, t.h, t.xhat, t.rstd, P + n.g, a->dz, rows, F, 1, 0, 0, s));
     EXORL_TRY(colsum(a->dz, G + n.trunk.b, rows, F, 1, 0, 0, s));
-    GemmProblem w{a->dz, x, G + n.trunk.W, nullptr, F, D, rows, F, D, D};
+    GemmProblem w{a->dz, x, G + n.trunk.W, nullptr, F, R, rows, F, R, D};
     EXORL_TRY(gemm_grouped(prec, 1, 1, &w, 1, false, false, s));
+    if (M > 0) {
+        GemmProblem wm{a->dz, meta, G + n.trunk.W + R, nullptr, F, M, rows, F, M, D};
+        EXORL_TRY(gemm_grouped(prec, 1, 1, &wm, 1, false, false, s));
+    }
     if (dx) {
-        GemmProblem g{a->dz, P + n.trunk.W, dx, nullptr, rows, D, F, F, D, D};
+        GemmProblem g{a->dz, P + n.trunk.W, dx, nullptr, rows, R, F, F, D, R};
         EXORL_TRY(gemm_grouped(prec, 0, 1, &g, 1, false, false, s));
     }
     return 0;
 }
 
 static int padam(exorl_pixel_agent* a, int net, int64_t n, float* target, hipStream_t s) {
-    return adam_step(a->flat[net][0], a->flat[net][1], a->flat[net][2], a->flat[net][3], n, a->cfg.lr, 0.9f, 0.999f, 1e-8f, a->t, target,
-                     target ? a->cfg.tau : 0.f, s);
+    return adam_step(a->flat[net][0], a->flat[net][1], a->flat[net][2], a->flat[net][3], n, a->cfg.lr, 0.9f, 0.999f, 1e-8f, net == 0 ? a->t_enc : a->t,
+                     target, target ? a->cfg.tau : 0.f, s);
 }
 
 }  // namespace exorl
@@ -200,6 +214,7 @@ static int check_pcfg(const exorl_pixel_cfg* c) {
     EXORL_REQUIRE(c->act_dim >= 1 && c->act_dim <= 64 && c->feature_dim >= 1 && c->feature_dim <= 1024 && c->hidden_dim >= 1 && c->batch >= 1,
                   "pixel_agent: unsupported dims A=%d feature_dim=%d H=%d B=%d", c->act_dim, c->feature_dim, c->hidden_dim, c->batch);
     EXORL_REQUIRE(c->precision == EXORL_PREC_F32 || c->precision == EXORL_PREC_BF16 || c->precision == EXORL_PREC_BF16X3, "pixel_agent: unknown precision %d", c->precision);
+    EXORL_REQUIRE(c->meta_dim >= 0 && c->meta_dim <= 256, "pixel_agent: meta_dim=%d unsupported (0..256)", c->meta_dim);
     return 0;
 }
 
@@ -207,8 +222,8 @@ static void pdescribe(exorl_pixel_agent* a) {
     const auto& c = a->cfg;
     a->R = (int)exorl_encoder_out_dim(c.hw);
     a->enc_total = exorl_encoder_param_floats(c.c_in, c.hw);
-    a->actor = make_pnet(a->R, c.feature_dim, c.hidden_dim, c.feature_dim, c.act_dim, 1);
-    a->critic = make_pnet(a->R, c.feature_dim, c.hidden_dim, c.feature_dim + c.act_dim, 1, 2);
+    a->actor = make_pnet(a->R + c.meta_dim, c.feature_dim, c.hidden_dim, c.feature_dim, c.act_dim, 1);
+    a->critic = make_pnet(a->R + c.meta_dim, c.feature_dim, c.hidden_dim, c.feature_dim + c.act_dim, 1, 2);
 }
 
 size_t exorl_pixel_agent_workspace_bytes(const exorl_pixel_cfg* cfg) {
@@ -297,7 +312,7 @@ int exorl_pixel_agent_batch_slots(exorl_pixel_agent_t* a, exorl_batch_out* out) 
     out->action = a->action; out->action_stride = a->cfg.act_dim;
     out->reward = a->reward; out->discount = a->discount;
     out->next_obs = a->next_obs; out->next_obs_stride = img;
-    out->meta = nullptr; out->meta_stride = 0;
+    out->meta = a->cfg.meta_dim > 0 ? a->meta : nullptr; out->meta_stride = a->cfg.meta_dim;
     return 0;
 }
 
@@ -319,8 +334,11 @@ int exorl_pixel_agent_augment(exorl_pixel_agent_t* a, const int32_t* shifts_obs,
 int exorl_pixel_agent_encode(exorl_pixel_agent_t* a, int32_t which, int32_t target, float** feat_out_dev, void* stream) {
     EXORL_REQUIRE(a && feat_out_dev && a->augmented && (which == 0 || which == 1), "pixel_agent_encode: bad arguments (augment first)");
     const auto& c = a->cfg;
-    return exorl_encoder_forward_prec(target ? a->enc_target : a->flat[0][0], c.c_in, c.hw, which ? a->aug_n : a->aug_o, c.batch,
-                                      which ? a->enc_ws_n : a->enc_ws_o, feat_out_dev, c.precision, stream);
+    EXORL_TRY(exorl_encoder_forward_prec(target ? a->enc_target : a->flat[0][0], c.c_in, c.hw, which ? a->aug_n : a->aug_o, c.batch,
+                                         which ? a->enc_ws_n : a->enc_ws_o, feat_out_dev, c.precision, stream));
+    if (!target) { (which ? a->feat_n : a->feat_o) = *feat_out_dev; (which ? a->have_feat_n : a->have_feat_o) = true; }
+    else (which ? a->have_feat_n : a->have_feat_o) = false;           // the workspace now holds the target encoder's pass
+    return 0;
 }
 
 // Backward through the encoder pass last run by exorl_pixel_agent_encode(which, 0) from dfeat_dev (batch, repr_dim; overwritten), then
@@ -331,7 +349,7 @@ int exorl_pixel_agent_encoder_step(exorl_pixel_agent_t* a, int32_t which, float*
     const auto& c = a->cfg;
     EXORL_TRY(exorl_encoder_backward_prec(a->flat[0][0], c.c_in, c.hw, which ? a->aug_n : a->aug_o, c.batch, which ? a->enc_ws_n : a->enc_ws_o, dfeat_dev,
                                      a->flat[0][1], a->cfg.precision, s));
-    if (opt == 0) { a->t += 1; return padam(a, 0, a->enc_total, nullptr, s); }
+    if (opt == 0) { a->t_enc += 1; return padam(a, 0, a->enc_total, nullptr, s); }
     a->t2 += 1;
     return adam_step(a->flat[0][0], a->flat[0][1], a->enc_m2, a->enc_v2, a->enc_total, c.lr, 0.9f, 0.999f, 1e-8f, a->t2, nullptr, 0.f, s);
 }
@@ -360,17 +378,18 @@ int exorl_pixel_agent_encoder_target_ptr(exorl_pixel_agent_t* a, void** ptr_dev)
 
 // training state that is not a tensor view: Adam step counts (critic/actor/encoder share one, proto_opt's encoder state has its
 // own) and the Philox counters of the noise / augmentation / act() streams — what a pickled agent needs to continue bit-identically
-int exorl_pixel_agent_state(exorl_pixel_agent_t* a, int64_t* steps2, uint64_t* counters3) {
-    EXORL_REQUIRE(a && steps2 && counters3, "pixel_agent_state: null argument");
-    steps2[0] = a->t; steps2[1] = a->t2;
+int exorl_pixel_agent_state(exorl_pixel_agent_t* a, int64_t* steps3, uint64_t* counters3) {
+    EXORL_REQUIRE(a && steps3 && counters3, "pixel_agent_state: null argument");
+    steps3[0] = a->t; steps3[1] = a->t2; steps3[2] = a->t_enc;
     counters3[0] = a->noise_counter; counters3[1] = a->aug_counter; counters3[2] = a->act_counter;
     return 0;
 }
-int exorl_pixel_agent_set_state(exorl_pixel_agent_t* a, const int64_t* steps2, const uint64_t* counters3) {
-    EXORL_REQUIRE(a && steps2 && counters3 && steps2[0] >= 0 && steps2[1] >= 0, "pixel_agent_set_state: bad arguments");
-    a->t = steps2[0]; a->t2 = steps2[1];
+int exorl_pixel_agent_set_state(exorl_pixel_agent_t* a, const int64_t* steps3, const uint64_t* counters3) {
+    EXORL_REQUIRE(a && steps3 && counters3 && steps3[0] >= 0 && steps3[1] >= 0 && steps3[2] >= 0, "pixel_agent_set_state: bad arguments");
+    a->t = steps3[0]; a->t2 = steps3[1]; a->t_enc = steps3[2];
     a->noise_counter = counters3[0]; a->aug_counter = counters3[1]; a->act_counter = counters3[2];
     a->augmented = false;
+    a->have_feat_o = a->have_feat_n = false;
     return 0;
 }
 int exorl_pixel_agent_encoder_opt2(exorl_pixel_agent_t* a, void** m_dev, void** v_dev, int64_t* n) {
@@ -389,43 +408,53 @@ int exorl_pixel_agent_update(exorl_pixel_agent_t* a, float stddev, const int32_t
     float *Pe = a->flat[0][0], *Pa = a->flat[1][0], *Pc = a->flat[2][0], *Pt = a->flat[3][0];
     float *Ge = a->flat[0][1], *Ga = a->flat[1][1], *Gc = a->flat[2][1];
     a->t += 1;
-    // ---- aug_and_encode (ddpg.py:213-215, 312-315); shifts_obs == (const int32_t*)-1: keep the images exorl_pixel_agent_augment made
-    if (shifts_obs != reinterpret_cast<const int32_t*>(-1)) EXORL_TRY(exorl_pixel_agent_augment(a, shifts_obs, shifts_next, stream));
-    EXORL_REQUIRE(a->augmented, "pixel_agent_update: no augmented batch");
-    EXORL_TRY(exorl_encoder_forward_prec(Pe, c.c_in, c.hw, a->aug_o, B, a->enc_ws_o, &a->feat_o, a->cfg.precision, s));
-    EXORL_TRY(exorl_encoder_forward_prec(Pe, c.c_in, c.hw, a->aug_n, B, a->enc_ws_n, &a->feat_n, a->cfg.precision, s));
+    const float* mt = c.meta_dim > 0 ? a->meta : nullptr;
+    // ---- aug_and_encode (ddpg.py:213-215, 312-315); shifts_obs == (const int32_t*)-1: keep the images exorl_pixel_agent_augment made;
+    // (const int32_t*)-2: keep the encodings exorl_pixel_agent_encode(0 / 1, online) made as well — the agents that step the encoder
+    // through their own module pass the critic the encodings computed BEFORE that step (icm.py:97-131, diayn.py:137-170), detached
+    const bool keep_feat = shifts_obs == reinterpret_cast<const int32_t*>(-2);
+    if (keep_feat) {
+        EXORL_REQUIRE(a->have_feat_o && a->have_feat_n && !a->train_encoder, "pixel_agent_update: kept encodings need exorl_pixel_agent_encode(0) and (1) "
+                      "with the online encoder first, and set_train_encoder(0) (they are detached)");
+    } else {
+        if (shifts_obs != reinterpret_cast<const int32_t*>(-1)) EXORL_TRY(exorl_pixel_agent_augment(a, shifts_obs, shifts_next, stream));
+        EXORL_REQUIRE(a->augmented, "pixel_agent_update: no augmented batch");
+        EXORL_TRY(exorl_encoder_forward_prec(Pe, c.c_in, c.hw, a->aug_o, B, a->enc_ws_o, &a->feat_o, a->cfg.precision, s));
+        EXORL_TRY(exorl_encoder_forward_prec(Pe, c.c_in, c.hw, a->aug_n, B, a->enc_ws_n, &a->feat_n, a->cfg.precision, s));
+    }
+    a->have_feat_o = a->have_feat_n = false;
     // ---- update_critic (ddpg.py:240-268)
-    EXORL_TRY(trunk_forward(a, a->actor, Pa, a->feat_n, B, a->ta_n, prec, s));
+    EXORL_TRY(trunk_forward(a, a->actor, Pa, a->feat_n, mt, B, a->ta_n, prec, s));
     Mlp& pol = a->actor.head[0];
     EXORL_TRY(mlp_forward(pol, Pa, a->ta_n.h, F, B, prec, s));
     EXORL_CHECK_HIP(hipMemcpyAsync(a->mu_n, pol.act[2], sizeof(float) * B * A, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(tanh_kernel, dim3(grid1((int64_t)B * A)), dim3(256), 0, s, a->mu_n, (int64_t)B * A);
     EXORL_LAUNCH_CHECK();
-    EXORL_TRY(trunk_forward(a, a->critic, Pt, a->feat_n, B, a->tt, prec, s));
+    EXORL_TRY(trunk_forward(a, a->critic, Pt, a->feat_n, mt, B, a->tt, prec, s));
     EXORL_TRY(launch_concat(a->tt.h, F, F, a->mu_n, A, A, a->xq_t, B, s));           // action columns overwritten by the sample below
     NoiseSpec nc{noise_c, c.seed, 2 * a->noise_counter, nullptr};
     EXORL_TRY(sample_action(a->mu_n, nc, stddev, c.stddev_clip, 1, a->xq_t + F, FA, B, A, nullptr, s));
     // the target's Q heads reuse the critic's Mlp buffers (outputs to q), then are copied to tq
     for (int i = 0; i < 2; ++i) EXORL_TRY(mlp_forward(a->critic.head[i], Pt, a->xq_t, FA, B, prec, s));
     EXORL_CHECK_HIP(hipMemcpyAsync(a->tq, a->q, sizeof(float) * 2 * B, hipMemcpyDeviceToDevice, s));
-    EXORL_TRY(trunk_forward(a, a->critic, Pc, a->feat_o, B, a->tc, prec, s));
+    EXORL_TRY(trunk_forward(a, a->critic, Pc, a->feat_o, mt, B, a->tc, prec, s));
     EXORL_TRY(launch_concat(a->tc.h, F, F, a->action, A, A, a->xq_c, B, s));
     for (int i = 0; i < 2; ++i) EXORL_TRY(mlp_forward(a->critic.head[i], Pc, a->xq_c, FA, B, prec, s));
     EXORL_TRY(critic_loss(a->q, a->tq, a->reward, a->discount, a->dq, a->metrics, B, inv_b, s));
     for (int i = 0; i < 2; ++i) EXORL_TRY(mlp_backward(a->critic.head[i], Pc, Gc, a->xq_c, FA, B, a->dxq[i], prec, s));
     hipLaunchKernelGGL(add_cols_kernel, dim3(grid1((int64_t)B * F)), dim3(256), 0, s, a->dxq[0], (int64_t)FA, a->dxq[1], (int64_t)FA, 0, F, a->dh, B);
     EXORL_LAUNCH_CHECK();
-    EXORL_TRY(trunk_backward(a, a->critic, Pc, Gc, a->feat_o, B, a->tc, a->dh, a->train_encoder ? a->dfeat : nullptr, prec, s));
+    EXORL_TRY(trunk_backward(a, a->critic, Pc, Gc, a->feat_o, mt, B, a->tc, a->dh, a->train_encoder ? a->dfeat : nullptr, prec, s));
     if (a->train_encoder) EXORL_TRY(exorl_encoder_backward_prec(Pe, c.c_in, c.hw, a->aug_o, B, a->enc_ws_o, a->dfeat, Ge, a->cfg.precision, s));
     EXORL_TRY(padam(a, 2, a->critic.total, nullptr, s));
-    if (a->train_encoder) EXORL_TRY(padam(a, 0, a->enc_total, nullptr, s));
+    if (a->train_encoder) { a->t_enc += 1; EXORL_TRY(padam(a, 0, a->enc_total, nullptr, s)); }
     // ---- update_actor (ddpg.py:270-292) on obs.detach(): the encoding computed above, the critic just updated
-    EXORL_TRY(trunk_forward(a, a->actor, Pa, a->feat_o, B, a->ta_o, prec, s));
+    EXORL_TRY(trunk_forward(a, a->actor, Pa, a->feat_o, mt, B, a->ta_o, prec, s));
     EXORL_TRY(mlp_forward(pol, Pa, a->ta_o.h, F, B, prec, s));
     EXORL_CHECK_HIP(hipMemcpyAsync(a->mu_o, pol.act[2], sizeof(float) * B * A, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(tanh_kernel, dim3(grid1((int64_t)B * A)), dim3(256), 0, s, a->mu_o, (int64_t)B * A);
     EXORL_LAUNCH_CHECK();
-    EXORL_TRY(trunk_forward(a, a->critic, Pc, a->feat_o, B, a->tc, prec, s));
+    EXORL_TRY(trunk_forward(a, a->critic, Pc, a->feat_o, mt, B, a->tc, prec, s));
     EXORL_TRY(launch_concat(a->tc.h, F, F, a->mu_o, A, A, a->xq_c, B, s));
     NoiseSpec na{noise_a, c.seed, 2 * a->noise_counter + 1, nullptr};
     EXORL_TRY(sample_action(a->mu_o, na, stddev, c.stddev_clip, 1, a->xq_c + F, FA, B, A, a->metrics + EXORL_M_ACTOR_LOGPROB, s));
@@ -438,7 +467,7 @@ int exorl_pixel_agent_update(exorl_pixel_agent_t* a, float stddev, const int32_t
     hipLaunchKernelGGL(dpre_kernel, dim3(grid1((int64_t)B * A)), dim3(256), 0, s, a->dmu, a->mu_o, pol.dact[2], (int64_t)B * A);
     EXORL_LAUNCH_CHECK();
     EXORL_TRY(mlp_backward(pol, Pa, Ga, a->ta_o.h, F, B, a->dh, prec, s));
-    EXORL_TRY(trunk_backward(a, a->actor, Pa, Ga, a->feat_o, B, a->ta_o, a->dh, nullptr, prec, s));
+    EXORL_TRY(trunk_backward(a, a->actor, Pa, Ga, a->feat_o, mt, B, a->ta_o, a->dh, nullptr, prec, s));
     EXORL_TRY(padam(a, 1, a->actor.total, nullptr, s));
     // ---- soft update (ddpg.py:326-327)
     return soft_update(Pc, Pt, a->critic.total, c.tau, s);
@@ -456,9 +485,10 @@ int exorl_pixel_agent_metrics(exorl_pixel_agent_t* a, float* host, void* stream)
 }
 
 // act (ddpg.py:221-238) for one uint8 image (no augmentation): mean action (eval) or TruncatedNormal sample without clip
-int exorl_pixel_agent_act(exorl_pixel_agent_t* a, const unsigned char* obs_dev, float stddev, int32_t eval_mode, const float* noise_dev,
-                          float* action_out_dev, void* stream) {
-    EXORL_REQUIRE(a && obs_dev && action_out_dev, "pixel_agent_act: null argument");
+int exorl_pixel_agent_act(exorl_pixel_agent_t* a, const unsigned char* obs_dev, const float* meta_dev, float stddev, int32_t eval_mode,
+                          const float* noise_dev, float* action_out_dev, void* stream) {
+    EXORL_REQUIRE(a && obs_dev && action_out_dev && (a->cfg.meta_dim == 0 || meta_dev), "pixel_agent_act: null argument (meta_dim=%d needs meta_dev)",
+                  a ? a->cfg.meta_dim : 0);
     hipStream_t s = as_stream(stream);
     const auto& c = a->cfg;
     const int A = c.act_dim, F = c.feature_dim, prec = c.precision;
@@ -470,7 +500,7 @@ int exorl_pixel_agent_act(exorl_pixel_agent_t* a, const unsigned char* obs_dev, 
     float* feat = nullptr;
     EXORL_TRY(exorl_encoder_forward_prec(a->flat[0][0], c.c_in, c.hw, x, 1, ews, &feat, a->cfg.precision, s));
     // B = 1 reuses the batch-sized trunk / policy buffers (act() is never called inside update())
-    EXORL_TRY(trunk_forward(a, a->actor, a->flat[1][0], feat, 1, a->ta_n, prec, s));
+    EXORL_TRY(trunk_forward(a, a->actor, a->flat[1][0], feat, meta_dev, 1, a->ta_n, prec, s));
     Mlp& pol = a->actor.head[0];
     EXORL_TRY(mlp_forward(pol, a->flat[1][0], a->ta_n.h, F, 1, prec, s));
     EXORL_CHECK_HIP(hipMemcpyAsync(a->mu_n, pol.act[2], sizeof(float) * A, hipMemcpyDeviceToDevice, s));

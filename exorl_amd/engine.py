@@ -303,14 +303,14 @@ class PixelEngine:
     NETS = {'encoder': 0, 'actor': 1, 'critic': 2, 'critic_target': 3}
 
     def __init__(self, obs_shape, act_dim, feature_dim, hidden_dim, batch, lr=1e-4, tau=0.01, stddev_clip=0.3, precision='fp32', seed=0,
-                 device='cuda'):
+                 device='cuda', meta_dim=0):
         self.lib = L.load()
         self.device = _require_gpu(device)
         c, h, w = obs_shape
         if h != w:
             raise L.ExorlError(f'pixel observations must be square, got {obs_shape}')
-        self.obs_shape, self.act_dim, self.batch = tuple(obs_shape), act_dim, batch
-        self.cfg = L.PixelCfg(c, h, act_dim, feature_dim, hidden_dim, batch, PRECISION[precision], 0, lr, tau,
+        self.obs_shape, self.act_dim, self.batch, self.meta_dim = tuple(obs_shape), act_dim, batch, meta_dim
+        self.cfg = L.PixelCfg(c, h, act_dim, feature_dim, hidden_dim, batch, PRECISION[precision], meta_dim, lr, tau,
                               stddev_clip if stddev_clip is not None else 0.0, 0.0, seed)
         nbytes = self.lib.exorl_pixel_agent_workspace_bytes(C.byref(self.cfg))
         if nbytes == 0:
@@ -369,11 +369,13 @@ class PixelEngine:
     def _i32(self, x):
         return None if x is None else torch.as_tensor(np.ascontiguousarray(x, np.int32)).to(self.device)
 
-    def update(self, stddev, shifts_obs=None, shifts_next=None, noise_critic=None, noise_actor=None, keep_augmented=False):
+    def update(self, stddev, shifts_obs=None, shifts_next=None, noise_critic=None, noise_actor=None, keep_augmented=False, keep_encoded=False):
         f32 = lambda x: None if x is None else self._f(x)
         ts = [self._i32(shifts_obs), self._i32(shifts_next), f32(noise_critic), f32(noise_actor)]
         ptrs = [L.ptr(t) for t in ts]
-        if keep_augmented:                  # reuse the images exorl_pixel_agent_augment made (sentinel pointer, see the header)
+        if keep_encoded:                    # reuse the encodings of the last encode(0) / encode(1) (sentinel pointer, see the header)
+            ptrs[0] = C.c_void_p(-2)
+        elif keep_augmented:                # reuse the images exorl_pixel_agent_augment made
             ptrs[0] = C.c_void_p(-1)
         L.check(self.lib.exorl_pixel_agent_update(self.h, stddev, *ptrs, L.current_stream()))
         self._keep_u = ts
@@ -411,7 +413,7 @@ class PixelEngine:
     # -- pickling support: everything that defines the training state, as CPU data
     def export_state(self):
         torch.cuda.synchronize()
-        steps, ctr = np.zeros(2, np.int64), np.zeros(3, np.uint64)
+        steps, ctr = np.zeros(3, np.int64), np.zeros(3, np.uint64)
         L.check(self.lib.exorl_pixel_agent_state(self.h, steps.ctypes.data, ctr.ctypes.data))
         st = {'steps': steps, 'counters': ctr, 'tensors': {}}
         for net in range(4):
@@ -433,6 +435,8 @@ class PixelEngine:
         for q, t in zip((m, v, p), st['enc_extra']):
             self._view(q.value, n.value).copy_(t)
         steps, ctr = np.ascontiguousarray(st['steps'], np.int64), np.ascontiguousarray(st['counters'], np.uint64)
+        if steps.size == 2:                 # ABI-6 pickles: encoder_opt stepped with the other optimisers
+            steps = np.array([steps[0], steps[1], steps[0]], np.int64)
         L.check(self.lib.exorl_pixel_agent_set_state(self.h, steps.ctypes.data, ctr.ctypes.data))
         torch.cuda.synchronize()
 
@@ -441,12 +445,23 @@ class PixelEngine:
         L.check(self.lib.exorl_pixel_agent_metrics(self.h, host.ctypes.data, L.current_stream()))
         return host
 
-    def act(self, obs, stddev, eval_mode, noise=None):
+    def act(self, obs, stddev, eval_mode, noise=None, meta=None):
         o = self._u8(obs)
         out = torch.empty(self.act_dim, dtype=torch.float32, device=self.device)
         nz = self._f(noise) if noise is not None else None
-        L.check(self.lib.exorl_pixel_agent_act(self.h, o.data_ptr(), stddev, int(eval_mode), L.ptr(nz), out.data_ptr(), L.current_stream()))
+        mt = self._f(meta) if meta is not None else None
+        L.check(self.lib.exorl_pixel_agent_act(self.h, o.data_ptr(), L.ptr(mt), stddev, int(eval_mode), L.ptr(nz), out.data_ptr(), L.current_stream()))
         return out
+
+    def meta_rows(self):
+        """(batch, meta_dim) device view of the skill / task rows the trunks read (filled by the sampler or by the caller)."""
+        out = self.batch_slots()
+        return self._view(out.meta, self.batch * self.meta_dim).view(self.batch, self.meta_dim)
+
+    def feature_view(self, ptr):
+        """(batch, repr_dim) tensor over the device pointer encode() returned."""
+        n = self.lib.exorl_encoder_out_dim(self.obs_shape[1])
+        return self._view(ptr, self.batch * n).view(self.batch, n)
 
 
 class ReplayEngine:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EXORL_ABI_VERSION 6
+#define EXORL_ABI_VERSION 7
 
 const char* exorl_last_error(void);
 int exorl_abi_version(void);
@@ -372,8 +372,10 @@ typedef struct exorl_intr_batch {
     float* reward_out;
     const float* next_obs_target; int64_t next_obs_target_ld;   /* Proto on pixels: encoder_target(next_obs) for the Sinkhorn branch
                                                                    (proto.py:144-148); null -> next_obs */
-    float* dobs_out;            /* Proto: if set, receives d(loss)/d(obs rows) (batch, obs_dim) so the caller can continue the backward pass
-                                   into its encoder (proto_opt owns the encoder's parameters too, proto.py:75-78) */
+    float* dobs_out;            /* if set (train != 0): receives the loss gradient at the encoding the module's loss reaches the caller's encoder
+                                   through, dense (batch, obs_dim), so that the caller continues the backward pass: d/d(obs rows) for Proto
+                                   (proto_opt owns the encoder too, proto.py:75-78), ICM, ICM-APT and Disagreement (next_obs is encoded without a
+                                   graph there, icm.py:97-99); d/d(next_obs rows) for DIAYN and APS (diayn.py:78-92, aps.py:147-159) */
     const float* cat_uniform;   /* Proto: num_protos uniforms in [0,1) for Categorical(prob).sample() (proto.py:112); SMM: the VAE's
                                    epsilon, (batch, 128) standard normals (smm.py:62); null -> Philox */
 } exorl_intr_batch;
@@ -418,13 +420,13 @@ int exorl_u8_to_f32(const unsigned char* x_dev, int64_t n, float* out_dev, void*
 
 /* ---------------------------------------------------------------------------------------------
  * DDPG on pixel observations (agents/unsupervised_learning/ddpg.py with obs_type == 'pixels'): augmentation + encoder +
- * pixel Actor (:42-76) / Critic (:79-123) and update (:240-328; the encoder steps with the critic's loss). meta_dim = 0.
+ * pixel Actor (:42-76) / Critic (:79-123) and update (:240-328; the encoder steps with the critic's loss).
  * ------------------------------------------------------------------------------------------- */
 typedef struct exorl_pixel_cfg {
     int32_t c_in, hw;          /* obs_shape = (c_in, hw, hw), hw in {84, 64}, uint8 */
     int32_t act_dim, feature_dim, hidden_dim, batch;
     int32_t precision;         /* EXORL_PREC_*: Linear layers' GEMMs and (bf16 modes) the 32-channel convolutions on MFMA; fp32: fp32 FMA convolutions */
-    int32_t reserved;
+    int32_t meta_dim;          /* skill / task columns concatenated after the encoding in front of the actor's and the critic's trunk (ddpg.py:294-299,305-312) */
     float lr, tau, stddev_clip, reserved2;
     uint64_t seed;
 } exorl_pixel_cfg;
@@ -451,22 +453,25 @@ int exorl_pixel_agent_update(exorl_pixel_agent_t* a, float stddev, const int32_t
 int exorl_pixel_agent_metrics(exorl_pixel_agent_t* a, float* host_out /* EXORL_N_METRICS */, void* stream);
 /* Primitives for agents that put a module between augmentation and the DDPG step (Proto on pixels, proto.py:159-207): augment once,
  * encode with the online or the target encoder, push a feature gradient back through the encoder with a chosen optimiser state,
- * maintain encoder_target; exorl_pixel_agent_update with shifts_obs_dev == (const int32_t*)-1 then reuses the augmented batch. */
+ * maintain encoder_target; exorl_pixel_agent_update with shifts_obs_dev == (const int32_t*)-1 then reuses the augmented batch, and with
+ * (const int32_t*)-2 also the encodings the last exorl_pixel_agent_encode(0, 0) / (1, 0) calls left (what the agents that step the encoder
+ * through their own module hand the critic: computed before that step, detached — icm.py:97-131, diayn.py:137-170; needs
+ * set_train_encoder(0)). */
 int exorl_pixel_agent_augment(exorl_pixel_agent_t* a, const int32_t* shifts_obs_dev, const int32_t* shifts_next_dev, void* stream);
 int exorl_pixel_agent_encode(exorl_pixel_agent_t* a, int32_t which, int32_t target, float** feat_out_dev, void* stream);
 int exorl_pixel_agent_encoder_step(exorl_pixel_agent_t* a, int32_t which, float* dfeat_dev, int32_t opt, void* stream);
 int exorl_pixel_agent_encoder_target(exorl_pixel_agent_t* a, float tau, int32_t init, void* stream);
 int exorl_pixel_agent_encoder_target_ptr(exorl_pixel_agent_t* a, void** ptr_dev);
-/* Whole-agent pickling (pretrain.py:293-300): steps2 = {Adam step count of encoder_opt/critic_opt/actor_opt, of proto_opt's encoder state},
+/* Whole-agent pickling (pretrain.py:293-300): steps3 = {Adam step count of critic_opt/actor_opt, of proto_opt's encoder state, of encoder_opt},
  * counters3 = Philox counters of the update-noise, augmentation and act() streams; encoder_opt2 = proto_opt's Adam moments for the
  * encoder (n floats each, same layout as the encoder's flat parameters, which encoder_target_ptr also uses). */
-int exorl_pixel_agent_state(exorl_pixel_agent_t* a, int64_t* steps2_out, uint64_t* counters3_out);
-int exorl_pixel_agent_set_state(exorl_pixel_agent_t* a, const int64_t* steps2, const uint64_t* counters3);
+int exorl_pixel_agent_state(exorl_pixel_agent_t* a, int64_t* steps3_out, uint64_t* counters3_out);
+int exorl_pixel_agent_set_state(exorl_pixel_agent_t* a, const int64_t* steps3, const uint64_t* counters3);
 int exorl_pixel_agent_encoder_opt2(exorl_pixel_agent_t* a, void** m_dev, void** v_dev, int64_t* n_floats);
 /* enable == 0: update() treats the encoding as detached in update_critic (what the reward-free agents pass, proto.py:190-193):
  * no encoder backward, encoder_opt does not step. Default 1 (plain DDPG, ddpg.py:316-319). */
 int exorl_pixel_agent_set_train_encoder(exorl_pixel_agent_t* a, int32_t enable);
-int exorl_pixel_agent_act(exorl_pixel_agent_t* a, const unsigned char* obs_dev, float stddev, int32_t eval_mode, const float* noise_dev,
+int exorl_pixel_agent_act(exorl_pixel_agent_t* a, const unsigned char* obs_dev, const float* meta_dev /* (meta_dim,) or null */, float stddev, int32_t eval_mode, const float* noise_dev,
                           float* action_out_dev, void* stream);
 
 #ifdef __cplusplus

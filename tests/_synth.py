@@ -28,6 +28,22 @@ def synth_params(shapes, seed):
     return out
 
 
+def synth_conv_params(shapes, seed):
+    """Encoder tensors with activations that stay O(1) through the four ReLU layers (He scaling): 4-D -> N(0,1) * sqrt(2 / fan_in),
+    1-D -> 0.1 N(0,1). For the fixtures whose modules read the raw 39200-wide encoding (synth_params gives 4-D tensors its LayerNorm-gain
+    branch, i.e. weights near 1 and encodings near 1e7 — harmless in front of a LayerNorm, useless in front of an MSE)."""
+    rs = np.random.RandomState(seed)
+    out = {}
+    for name, shape in shapes:
+        shape = tuple(int(s) for s in shape)
+        if len(shape) == 4:
+            w = rs.standard_normal(shape) * np.sqrt(2.0 / (shape[1] * shape[2] * shape[3]))
+        else:
+            w = 0.1 * rs.standard_normal(shape)
+        out[name] = w.astype(np.float32)
+    return out
+
+
 def synth_batch(seed, step, batch, obs_dim, act_dim, gamma=0.99):
     """One minibatch as the sampler would emit it: (obs, action, reward, discount, next_obs)."""
     rs = np.random.RandomState(seed * 100003 + step)

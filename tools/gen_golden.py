@@ -410,6 +410,85 @@ def gen_pixel_proto(ref):
 
 
 # ----------------------------------------------------------------------------- agents (G3/G4)
+PIXEL_INTR = ('icm', 'icm_apt', 'disagreement', 'diayn')
+
+
+def pixel_intr_frames(step, B, C, HW):
+    """uint8 frames of step `step` (regenerated by the tests, not stored)."""
+    rs = np.random.RandomState(1000 + step)
+    return rs.randint(0, 256, (B, C, HW, HW)).astype(np.uint8), rs.randint(0, 256, (B, C, HW, HW)).astype(np.uint8)
+
+
+def gen_pixel_intr(ref, kind):
+    """The reward-free agents with an intrinsic-reward module on pixel observations (icm.py:94-139, icm_apt.py:112-158,
+    disagreement.py:88-136, diayn.py:125-176): 3 update() calls, B=4, (3,84,84) uint8 frames. Weights from _synth.synth_params seeds
+    (encoder 50, actor 51, critic 52, module 53); frames from pixel_intr_frames; augmentation shifts and action noise recorded."""
+    U = ref.utils
+    C, HW, A, F, H, B, N, S = 3, 84, 3, 16, 32, 4, 3, 4
+    torch.manual_seed(5)
+    kw = dict(name=kind, reward_free=True, obs_type='pixels', obs_shape=(C, HW, HW), action_shape=(A,), device='cpu', lr=1e-4, feature_dim=F,
+              hidden_dim=H, critic_target_tau=0.01, num_expl_steps=2000, update_every_steps=2, stddev_schedule=0.2, nstep=3, batch_size=B,
+              stddev_clip=0.3, init_critic=True, use_tb=True, use_wandb=False)
+    if kind == 'icm':
+        agent, mod = ref.icm.ICMAgent(icm_scale=1.0, update_encoder=True, **kw), 'icm'
+    elif kind == 'icm_apt':
+        agent, mod = ref.icm_apt.ICMAPTAgent(icm_scale=1.0, knn_rms=True, knn_k=3, knn_avg=True, knn_clip=0.0, update_encoder=True, icm_rep_dim=16, **kw), 'icm'
+    elif kind == 'disagreement':
+        agent, mod = ref.disagreement.DisagreementAgent(update_encoder=True, **kw), 'disagreement'
+    elif kind == 'diayn':
+        agent, mod = ref.diayn.DIAYNAgent(update_skill_every_step=50, skill_dim=S, diayn_scale=1.0, update_encoder=True, skill_type='uniform', **kw), 'diayn'
+    else:
+        raise ValueError(kind)
+    out = {'dims': np.array([C, HW, A, F, H, B, N, S])}
+    mods = (('encoder', agent.encoder), ('actor', agent.actor), ('critic', agent.critic), (mod, getattr(agent, mod)))
+    for i, (nm, net) in enumerate(mods):
+        shapes = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+        params = (_synth.synth_conv_params if nm == 'encoder' else _synth.synth_params)(shapes, 50 + i)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+        out[f'keys/{nm}'] = np.array([k for k, _ in shapes])
+    agent.critic_target.load_state_dict(agent.critic.state_dict())
+    rs = np.random.RandomState(8)
+    shifts, noise = [], _synth.NoiseStream(21)
+    o_sn, o_randint = U._standard_normal, torch.randint
+
+    def p_randint(lo, hi, size, device=None, dtype=None):
+        sh = rs.randint(lo, hi, tuple(size))
+        shifts.append(sh.reshape(-1, 2).astype(np.int32))
+        return torch.from_numpy(sh).to(dtype)
+    U._standard_normal = lambda shape, dtype, device: torch.from_numpy(noise.draw(shape)).to(dtype)
+    torch.randint = p_randint
+    metrics = []
+    try:
+        for i in range(N):
+            b = _synth.synth_batch(61, i, B, 4, A)
+            obs, nobs = pixel_intr_frames(i, B, C, HW)
+            batch = [obs, b[1], b[2], b[3], nobs]
+            if kind == 'diayn':
+                skill = np.zeros((B, S), np.float32)
+                skill[np.arange(B), np.random.RandomState(70 + i).randint(0, S, B)] = 1.0
+                batch.append(skill)
+                out[f'batch/{i}/skill'] = skill
+            m = agent.update(iter([tuple(batch)]), 2 * i)
+            metrics.append({k: float(v) for k, v in m.items()})
+    finally:
+        U._standard_normal, torch.randint = o_sn, o_randint
+    out['shifts'] = np.stack(shifts)                      # [2 * step + (0 obs | 1 next_obs)]
+    keys = sorted(metrics[0].keys())
+    out['metric_keys'] = np.array(keys)
+    out['metrics'] = np.array([[m[k] for k in keys] for m in metrics], np.float64)
+    for nm, net in mods + (('critic_target', agent.critic_target),):
+        for k, v in net.state_dict().items():
+            v = v.numpy()
+            if v.size <= 20000:
+                out[f'final/{nm}/{k}'] = v.copy()
+            else:                                         # 39200-wide tensors: strided sample
+                out[f'final_sample/{nm}/{k}'] = v.reshape(-1)[::997].copy()
+    if hasattr(agent, 'pbe'):
+        out['final/rms'] = np.array([float(agent.pbe.rms.M), float(agent.pbe.rms.S), float(agent.pbe.rms.n)])
+    np.savez_compressed(GOLD / f'pixel_{kind}.npz', **out)
+    print('pixel', kind, keys, out['metrics'][-1])
+
+
 def make_agent(ref, kind, O, A, H, B, device='cpu', use_tb=True, **kw):
     if kind == 'td3_bc':
         return ref.td3_bc.TD3BCAgent('td3_bc', (O,), (A,), device, 1e-4, H, 0.01, 0.2, 1, B, 0.3, use_tb, 2.5)
@@ -670,7 +749,7 @@ if __name__ == '__main__':
     args = ap.parse_args()
     GOLD.mkdir(parents=True, exist_ok=True)
     ref = load_reference()
-    todo = [args.only] if args.only else ['replay', 'offline', 'utils', 'tiny', 'full', 'pixels', 'pixel_ddpg', 'pixel_proto']
+    todo = [args.only] if args.only else ['replay', 'offline', 'utils', 'tiny', 'full', 'pixels', 'pixel_ddpg', 'pixel_proto'] + [f'pixel_{k}' for k in PIXEL_INTR]
     kinds = args.kinds.split(',') if args.kinds else None
     if kinds:
         TINY_KINDS = tuple(k for k in TINY_KINDS if k.partition('-')[0] in kinds)
@@ -678,4 +757,9 @@ if __name__ == '__main__':
         if t == 'full':
             gen_full(ref, only_kinds=kinds)
         else:
-            {'replay': gen_replay, 'offline': gen_offline, 'utils': gen_utils, 'tiny': gen_tiny, 'pixels': gen_pixels, 'pixel_ddpg': gen_pixel_ddpg, 'pixel_proto': gen_pixel_proto}[t](ref)
+            fns = {'replay': gen_replay, 'offline': gen_offline, 'utils': gen_utils, 'tiny': gen_tiny, 'pixels': gen_pixels, 'pixel_ddpg': gen_pixel_ddpg,
+                   'pixel_proto': gen_pixel_proto}
+            if t.startswith('pixel_') and t[6:] in PIXEL_INTR:
+                gen_pixel_intr(ref, t[6:])
+            else:
+                fns[t](ref)
