@@ -48,7 +48,7 @@ class AgentCfg(C.Structure):
 class IntrCfg(C.Structure):
     _fields_ = [('kind', c_int32), ('obs_dim', c_int32), ('act_dim', c_int32), ('hidden_dim', c_int32), ('rep_dim', c_int32),
                 ('batch', c_int32), ('precision', c_int32), ('knn_k', c_int32), ('knn_avg', c_int32), ('knn_rms', c_int32),
-                ('n_models', c_int32), ('reserved', c_int32), ('lr', c_float), ('scale', c_float), ('knn_clip', c_float), ('clip_val', c_float),
+                ('n_models', c_int32), ('flags', c_int32), ('lr', c_float), ('scale', c_float), ('knn_clip', c_float), ('clip_val', c_float),
                 ('num_protos', c_int32), ('queue_size', c_int32), ('tau', c_float), ('target_tau', c_float),
                 ('sp_lr', c_float), ('vae_lr', c_float), ('vae_beta', c_float), ('state_ent_coef', c_float), ('latent_ent_coef', c_float),
                 ('latent_cond_ent_coef', c_float), ('goal_x', c_float), ('goal_y', c_float)]
@@ -62,7 +62,7 @@ class IntrBatch(C.Structure):
 
 class PixelCfg(C.Structure):
     _fields_ = [('c_in', c_int32), ('hw', c_int32), ('act_dim', c_int32), ('feature_dim', c_int32), ('hidden_dim', c_int32), ('batch', c_int32),
-                ('precision', c_int32), ('meta_dim', c_int32), ('lr', c_float), ('tau', c_float), ('stddev_clip', c_float), ('reserved2', c_float),
+                ('precision', c_int32), ('meta_dim', c_int32), ('lr', c_float), ('tau', c_float), ('stddev_clip', c_float), ('sf_dim', c_int32),
                 ('seed', c_uint64)]
 
 

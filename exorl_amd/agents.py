@@ -511,7 +511,7 @@ class DDPGAgent(_AgentBase):
         if obs_type == 'pixels':
             if not (type(self) is DDPGAgent or getattr(self, '_PIXELS_OK', False)):
                 raise NotImplementedError(f"exorl_amd: obs_type='pixels' is not built for {type(self).__name__} yet (DDPG, Proto, ICM, ICM-APT, "
-                                          "Disagreement and DIAYN are)")
+                                          "Disagreement, DIAYN, APS and SMM are)")
             return self._init_pixels(reward_free, obs_shape, action_shape, device, lr, feature_dim, hidden_dim, critic_target_tau, num_expl_steps,
                                      update_every_steps, stddev_schedule, batch_size, stddev_clip, init_critic, use_tb, use_wandb, precision, seed,
                                      meta_dim)
@@ -560,9 +560,10 @@ class DDPGAgent(_AgentBase):
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             raise NotImplementedError('exorl_amd: the pixel path is single-GPU this round')
         c = obs_shape[0]
-        w = _pixel_init(c, obs_shape[1], self.action_dim, feature_dim, hidden_dim, meta_dim)
+        sf_dim = self._engine_kw().get('sf_dim', 0)         # APS: CriticSF heads (aps.py:94-104)
+        w = _pixel_init(c, obs_shape[1], self.action_dim, feature_dim, hidden_dim, meta_dim, sf_dim)
         self.engine = PixelEngine(obs_shape, self.action_dim, feature_dim, hidden_dim, batch_size, lr=lr, tau=critic_target_tau,
-                                  stddev_clip=stddev_clip, precision=precision, seed=seed, device=device, meta_dim=meta_dim)
+                                  stddev_clip=stddev_clip, precision=precision, seed=seed, device=device, meta_dim=meta_dim, sf_dim=sf_dim)
         self.obs_dim = w['repr_dim'] + meta_dim          # ddpg.py:176 obs_dim = encoder.repr_dim + meta_dim
         conv_shapes = [s for l in range(4) for s in ((32, c if l == 0 else 32, 3, 3), (32,))]
         self.encoder = _PixelNetView(self.engine, 0, _ENC_KEYS, conv_shapes)
@@ -773,6 +774,9 @@ class _IntrAgent(DDPGAgent):
                 metrics['extr_reward'] = float(ri[L.IM_EXTR_REWARD])
                 if self.LOSS_KEY == 'diayn_loss':
                     metrics['diayn_acc'] = float(ri[L.IM_ACC])
+                if self.LOSS_KEY == 'aps_loss':
+                    metrics['intr_ent_reward'] = float(ri[L.IM_ENT_REWARD])
+                    metrics['intr_sf_reward'] = float(ri[L.IM_SF_REWARD])
             else:
                 metrics['extr_reward'] = metrics['batch_reward']
         return metrics
@@ -989,6 +993,11 @@ class APSAgent(_MetaObsMixin, _IntrAgent):
     head, Q = task . features (CriticSF, aps.py:12-60); the task vector rides in the batch and in the trailing columns of obs."""
     KIND = 'aps'
     LOSS_KEY = 'aps_loss'
+    _PIXELS_OK = True
+    _PIX_GRAD = 1                        # update_aps reaches the encoder through next_obs (aps.py:147-159,203-204)
+
+    def _pix_module(self, fo, fn, s):
+        self.intr.update(fo, None, fn, s.reward, s.reward, True, skill=s.meta, skill_ld=self.sf_dim, dobs_out=self._dobs.data_ptr())
 
     def __init__(self, update_task_every_step, sf_dim, knn_rms, knn_k, knn_avg, knn_clip, num_init_steps, lstsq_batch_size, update_encoder,
                  **kwargs):
@@ -1007,6 +1016,7 @@ class APSAgent(_MetaObsMixin, _IntrAgent):
         for p, t in zip(self.aps.parameters(), w):
             p.copy_(t.reshape(p.shape))
         self.pbe = _PbeView(self.intr)
+        self._pix_alloc()
 
     def _engine_kw(self):
         return {'sf_dim': self.sf_dim}
@@ -1036,7 +1046,14 @@ class APSAgent(_MetaObsMixin, _IntrAgent):
         n = 0
         while n < self.lstsq_batch_size:
             batch = next(replay_iter)
-            o, r = torch.as_tensor(batch[0]).to(self.device, torch.float32), torch.as_tensor(batch[2]).to(self.device, torch.float32)
+            r = torch.as_tensor(batch[2]).to(self.device, torch.float32)
+            if self.obs_type == 'pixels':          # aug_and_encode (aps.py:262) through the engine, one batch of frames at a time
+                eng = self.engine
+                eng.set_batch(*batch[:5])
+                eng.augment(self.shift_hook(eng.batch) if self.shift_hook else None, self.shift_hook(eng.batch) if self.shift_hook else None)
+                o = eng.feature_view(eng.encode(0)).clone()
+            else:
+                o = torch.as_tensor(batch[0]).to(self.device, torch.float32)
             obs.append(o)
             reward.append(r.reshape(-1, 1))
             n += o.shape[0]
@@ -1087,6 +1104,8 @@ class SMMAgent(_MetaObsMixin, _IntrAgent):
     rest_i + mean_j log_p_star_j, plus var_j(log_p_star_j) in each critic's loss value; the module writes exactly that reward and
     `critic_loss` carries the variance term (tests/golden/tiny_smm.npz reproduces the reference's numbers)."""
     LOSS_KEY = 'loss_vae'
+    _PIXELS_OK = True                    # smm.py:264-331 with obs_type == 'pixels': the VAE and the skill predictor read the encoding, p*(s) is dropped
+    _PIX_GRAD = 0
 
     def __init__(self, z_dim, sp_lr, vae_lr, vae_beta, state_ent_coef, latent_ent_coef, latent_cond_ent_coef, update_encoder, **kwargs):
         self.z_dim = self._meta_dim = z_dim
@@ -1101,13 +1120,28 @@ class SMMAgent(_MetaObsMixin, _IntrAgent):
         w = _smm_init(O, z_dim, H)
         self.intr = IntrEngine('smm', O, self.action_dim, H, self.engine.batch, rep_dim=z_dim, sp_lr=sp_lr, vae_lr=vae_lr, vae_beta=vae_beta,
                                state_ent_coef=state_ent_coef, latent_ent_coef=latent_ent_coef, latent_cond_ent_coef=latent_cond_ent_coef,
-                               goal=self.goal, precision=self._precision, device=self.device)
+                               goal=self.goal, precision=self._precision, device=self.device, encoded=self.obs_type == 'pixels')
         self.smm = NetView(self.intr, None, _SMM_KEYS)
         for p, t in zip(self.smm.parameters(), w):
             p.copy_(t.reshape(p.shape))
         self.ft_returns = np.zeros(z_dim, dtype=np.float32)
         self.ft_not_finished = [True for _ in range(z_dim)]
         self.eps_hook = None            # tests: callable(shape) -> the VAE's epsilon (torch.randn in smm.py:62)
+        self._pix_alloc()
+
+    def _eps(self):
+        if self.eps_hook is None:
+            return None
+        return torch.as_tensor(np.asarray(self.eps_hook((self.engine.batch, 128)), np.float32), device=self.engine.device).contiguous()
+
+    def _pix_module(self, fo, fn, s):
+        """update_vae on obs_z = [encoding | z] (the encoder steps on the VAE's loss, smm.py:173-185), update_pred on the detached encoding."""
+        eng = self.engine
+        xz = torch.cat([eng.feature_view(fo), eng.meta_rows()], 1).contiguous()
+        e = self._eps()
+        self.intr.update(xz.data_ptr(), None, None, s.reward, s.reward, True, skill=s.meta, obs_ld=xz.shape[1], skill_ld=self.z_dim,
+                         cat_uniform=e.data_ptr() if e is not None else None, dobs_out=self._dobs.data_ptr())
+        self._keep_eps = (e, xz)
 
     def get_meta_specs(self):
         return (_Spec((self.z_dim,), np.float32, 'z'),)
@@ -1161,6 +1195,10 @@ class SMMAgent(_MetaObsMixin, _IntrAgent):
         if step % self.update_every_steps != 0:
             return dict()
         metrics = super().update(replay_iter, step)
+        if self.obs_type == 'pixels':                    # smm.py:260-265: loss_vae / loss_pred ride with use_tb, nothing else is added
+            if self.reward_free and (self.use_tb or self.use_wandb):
+                metrics['loss_pred'] = float(self.intr.metrics_raw()[5])
+            return metrics
         if self.reward_free:                             # smm.py:249-258: these are reported whatever use_tb says
             raw = self.intr.metrics_raw()
             for k in ('icm_loss', 'loss_vae'):
@@ -1343,7 +1381,7 @@ class _PixelNetView(NetView):
         return [self._engine.tensor(self._net, i, L.T_GRAD) for i in range(len(self._keys))]
 
 
-def _pixel_init(c_in, hw, A, F, H, meta_dim=0):
+def _pixel_init(c_in, hw, A, F, H, meta_dim=0, sf_dim=0):
     """Initial tensors of Encoder, pixel Actor, pixel Critic (and the critic_target's discarded draws) in the reference's RNG order
     (ddpg.py:165-181): every module default-initialised at construction, then weight_init — orthogonal with the ReLU gain for
     Conv2d, gain 1 for Linear, zero biases (utils.py:59-69)."""
@@ -1368,6 +1406,9 @@ def _pixel_init(c_in, hw, A, F, H, meta_dim=0):
     actor = net(F, A, 1)
     critic = net(F + A, 1, 2)
     net(F + A, 1, 2)                      # critic_target's draws, overwritten by load_state_dict
+    if sf_dim:                            # APSAgent replaces both with CriticSF after DDPG's constructor ran (aps.py:94-104)
+        critic = net(F + A, sf_dim, 2)
+        net(F + A, sf_dim, 2)
     return {'encoder': [t for m in convs for t in (m.weight.data, m.bias.data)], 'actor': actor, 'critic': critic, 'repr_dim': R}
 
 

@@ -265,6 +265,18 @@ __global__ __launch_bounds__(256) void icm_dobs_kernel(const float* __restrict__
     }
 }
 
+// SMM: d(loss_vae)/d(obs) = d/d(encoder input) - d/d(decoder output) over the observation columns (the reconstruction target is the
+// input itself, F.mse_loss(obs_z, out), smm.py:66)
+__global__ __launch_bounds__(256) void smm_dobs_kernel(const float* __restrict__ dx, const float* __restrict__ dout, int64_t ld, float* __restrict__ dst,
+                                                       int B, int O) {
+    const int64_t n = (int64_t)B * O;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / O;
+        const int c = (int)(i - r * O);
+        dst[i] = dx[r * ld + c] - dout[r * ld + c];
+    }
+}
+
 // Disagreement reward (disagreement.py:35-47): unbiased variance over the ensemble's predictions, mean over features
 struct PredSet { const float* p[EXORL_MAX_ENSEMBLE]; };
 __global__ __launch_bounds__(256) void disagreement_reward_kernel(PredSet ps, int n, float* __restrict__ reward, int rows, int D) {
@@ -575,9 +587,26 @@ __global__ __launch_bounds__(256) void vae_latent_kernel(const float* __restrict
 // sample that is rest_i + mean_j log_p_star_j for the TD gradient, plus var_j(log_p_star_j) in each critic's loss value.
 __global__ __launch_bounds__(1024) void smm_reward_kernel(const float* __restrict__ obs, int64_t ld, const float* __restrict__ hsz,
                                                           const float* __restrict__ hzs, const float* extr, float* reward, int B, int Z,
-                                                          float sec, float lec, float lcec, float gx, float gy, float* __restrict__ metrics) {
+                                                          float sec, float lec, float lcec, float gx, float gy, float* __restrict__ metrics, int encoded) {
     __shared__ float red[17];
     float e = 0.f, sl = 0.f, s1 = 0.f, s2 = 0.f;
+    if (encoded) {                 // pixels: p*(s) is ignored (smm.py:232-235), the reward is a plain (B, 1) column
+        float rs = 0.f;
+        const float hz = lec * logf((float)Z);
+        for (int b = threadIdx.x; b < B; b += blockDim.x) {
+            e += extr ? extr[b] : 0.f;
+            s1 += sec * hsz[b];
+            s2 += lcec * hzs[b];
+            const float r = sec * hsz[b] + hz + lcec * hzs[b];
+            reward[b] = r;
+            rs += r;
+        }
+        e = block_sum(e, red); s1 = block_sum(s1, red); s2 = block_sum(s2, red); rs = block_sum(rs, red);
+        if (threadIdx.x == 0) {
+            metrics[1] = rs / (float)B; metrics[2] = e / (float)B; metrics[3] = 0.f; metrics[4] = s1 / (float)B; metrics[6] = s2 / (float)B; metrics[7] = 0.f;
+        }
+        return;
+    }
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         e += extr ? extr[b] : 0.f;
         const float dx = obs[(int64_t)b * ld] - gx, dy = obs[(int64_t)b * ld + 1] - gy;
@@ -821,6 +850,7 @@ static void carve_intr(exorl_intr* it, ICarver& c) {
         const int64_t C = SMM_CODE_DIM;
         it->mu = c.take(B * C); it->lv = c.take(B * C); it->eps = c.take(B * C); it->code = c.take(B * C); it->dcode = c.take(B * C);
         it->dmu = c.take(B * C); it->dlv = c.take(B * C); it->hsz = c.take(B); it->hzs = c.take(B);
+        it->dxf = c.take(B * (O + R));                           // d/d(obs_z) of the VAE encoder (dobs_out)
     } else if (g.kind == EXORL_INTR_PROTO) {
         const int64_t P = g.num_protos;
         it->z1 = c.take(B * R); it->dz1 = c.take(B * R); it->sn = c.take(B * R); it->nrm = c.take(B); it->tn = c.take(B * R);
@@ -1084,7 +1114,11 @@ static int smm_update(exorl_intr* it, const exorl_intr_batch& b, bool train, hip
     GemmProblem d1{it->dmu, P + it->enc_mu.W, enc.dact[1], nullptr, B, V, C, C, V, V}, d2{it->dlv, P + it->enc_lv.W, enc.dact[1], nullptr, B, V, C, C, V, V};
     EXORL_TRY(gemm_grouped(prec, 0, 1, &d1, 1, false, false, s));
     EXORL_TRY(gemm_grouped(prec, 0, 1, &d2, 1, false, true, s));
-    EXORL_TRY(mlp_backward(enc, P, G, b.obs, b.obs_ld, B, nullptr, prec, s));
+    EXORL_TRY(mlp_backward(enc, P, G, b.obs, b.obs_ld, B, b.dobs_out ? it->dxf : nullptr, prec, s));
+    if (b.dobs_out) {
+        hipLaunchKernelGGL(smm_dobs_kernel, dim3(grid_for((int64_t)B * O)), dim3(256), 0, s, it->dxf, dec.dact[2], (int64_t)W, b.dobs_out, B, O);
+        EXORL_LAUNCH_CHECK();
+    }
     EXORL_TRY(adam_range(it, it->vae_off, it->trainable - it->vae_off, c.vae_lr, s));
     // ---- update_pred (smm.py:187-200): skill discriminator on the raw observation columns
     EXORL_TRY(mlp_forward(zp, P, b.obs, b.obs_ld, B, prec, s));
@@ -1095,7 +1129,7 @@ static int smm_update(exorl_intr* it, const exorl_intr_batch& b, bool train, hip
     EXORL_TRY(adam_range(it, 0, it->vae_off, c.sp_lr, s));
     // ---- reward (smm.py:229-246)
     hipLaunchKernelGGL(smm_reward_kernel, dim3(1), dim3(1024), 0, s, b.obs, b.obs_ld, it->hsz, it->hzs, b.extr_reward, b.reward_out, B, Z,
-                       c.state_ent_coef, c.latent_ent_coef, c.latent_cond_ent_coef, c.goal_x, c.goal_y, it->metrics);
+                       c.state_ent_coef, c.latent_ent_coef, c.latent_cond_ent_coef, c.goal_x, c.goal_y, it->metrics, (c.flags & EXORL_INTR_ENCODED) ? 1 : 0);
     EXORL_LAUNCH_CHECK();
     return 0;
 }

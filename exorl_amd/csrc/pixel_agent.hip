@@ -65,6 +65,25 @@ __global__ __launch_bounds__(256) void dpre_kernel(const float* __restrict__ da,
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dpre[i] = da[i] * (1.0f - mu[i] * mu[i]);
 }
 
+// CriticSF (aps.py:17-60): each head emits sf_dim successor features, Q_n = task . features_n; backward: d/d(features_n) = dQ_n * task
+__global__ __launch_bounds__(256) void sf_dot_kernel(const float* __restrict__ f0, const float* __restrict__ f1, const float* __restrict__ task,
+                                                     int64_t ldt, float* __restrict__ q, int B, int S) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * B) return;
+    const int n = i / B, m = i - n * B;
+    const float* f = (n ? f1 : f0) + (int64_t)m * S;
+    float acc = 0.f;
+    for (int j = 0; j < S; ++j) acc += task[(int64_t)m * ldt + j] * f[j];
+    q[i] = acc;
+}
+__global__ __launch_bounds__(256) void sf_dout_kernel(const float* __restrict__ dq, const float* __restrict__ task, int64_t ldt, float* __restrict__ d0,
+                                                      float* __restrict__ d1, int B, int S) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * B * S) return;
+    const int n = i / (B * S), r = i - n * B * S, m = r / S, j = r - m * S;
+    (n ? d1 : d0)[r] = dq[n * B + m] * task[(int64_t)m * ldt + j];
+}
+
 static int grid1(int64_t n) { const int64_t b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
 
 }  // namespace exorl
@@ -147,7 +166,9 @@ static void pcarve(exorl_pixel_agent* a, PCarver& c) {
     // actor policy: outputs land in mu_* (policy on next_obs shares the Mlp buffers: it is consumed before the obs pass runs)
     take_mlp(a->actor.head[0], c, B, nullptr, nullptr);
     // critic heads: outputs are the halves of q (B each); gradients at the outputs are the halves of dq
-    for (int i = 0; i < 2; ++i) take_mlp(a->critic.head[i], c, B, a->q ? a->q + i * B : nullptr, a->dq ? a->dq + i * B : nullptr);
+    // (CriticSF: the heads emit sf_dim features into their own buffers, q / dq hold the task-weighted scalars)
+    const bool sf = g.sf_dim > 0;
+    for (int i = 0; i < 2; ++i) take_mlp(a->critic.head[i], c, B, (a->q && !sf) ? a->q + i * B : nullptr, (a->dq && !sf) ? a->dq + i * B : nullptr);
     a->act_ws = c.take(exorl_encoder_workspace_floats(1, g.c_in, g.hw) + img + 4 * F + 2 * 1024 + 64);
 }
 
@@ -215,6 +236,8 @@ static int check_pcfg(const exorl_pixel_cfg* c) {
                   "pixel_agent: unsupported dims A=%d feature_dim=%d H=%d B=%d", c->act_dim, c->feature_dim, c->hidden_dim, c->batch);
     EXORL_REQUIRE(c->precision == EXORL_PREC_F32 || c->precision == EXORL_PREC_BF16 || c->precision == EXORL_PREC_BF16X3, "pixel_agent: unknown precision %d", c->precision);
     EXORL_REQUIRE(c->meta_dim >= 0 && c->meta_dim <= 256, "pixel_agent: meta_dim=%d unsupported (0..256)", c->meta_dim);
+    EXORL_REQUIRE(c->sf_dim == 0 || (c->sf_dim >= 1 && c->sf_dim == c->meta_dim), "pixel_agent: sf_dim=%d must equal meta_dim=%d (the task vector is the meta row, aps.py:236-238)",
+                  c->sf_dim, c->meta_dim);
     return 0;
 }
 
@@ -223,7 +246,7 @@ static void pdescribe(exorl_pixel_agent* a) {
     a->R = (int)exorl_encoder_out_dim(c.hw);
     a->enc_total = exorl_encoder_param_floats(c.c_in, c.hw);
     a->actor = make_pnet(a->R + c.meta_dim, c.feature_dim, c.hidden_dim, c.feature_dim, c.act_dim, 1);
-    a->critic = make_pnet(a->R + c.meta_dim, c.feature_dim, c.hidden_dim, c.feature_dim + c.act_dim, 1, 2);
+    a->critic = make_pnet(a->R + c.meta_dim, c.feature_dim, c.hidden_dim, c.feature_dim + c.act_dim, c.sf_dim > 0 ? c.sf_dim : 1, 2);
 }
 
 size_t exorl_pixel_agent_workspace_bytes(const exorl_pixel_cfg* cfg) {
@@ -409,6 +432,19 @@ int exorl_pixel_agent_update(exorl_pixel_agent_t* a, float stddev, const int32_t
     float *Ge = a->flat[0][1], *Ga = a->flat[1][1], *Gc = a->flat[2][1];
     a->t += 1;
     const float* mt = c.meta_dim > 0 ? a->meta : nullptr;
+    const int S = c.sf_dim;
+    auto sf_q = [&]() -> int {                 // Q_n = task . features_n (aps.py:55-58) -> a->q
+        if (S == 0) return 0;
+        hipLaunchKernelGGL(sf_dot_kernel, dim3(cdiv(2 * B, 256)), dim3(256), 0, s, a->critic.head[0].act[2], a->critic.head[1].act[2], mt, (int64_t)c.meta_dim, a->q, B, S);
+        EXORL_LAUNCH_CHECK();
+        return 0;
+    };
+    auto sf_dout = [&]() -> int {              // dQ_n -> gradient at the heads' feature outputs
+        if (S == 0) return 0;
+        hipLaunchKernelGGL(sf_dout_kernel, dim3(cdiv(2 * B * S, 256)), dim3(256), 0, s, a->dq, mt, (int64_t)c.meta_dim, a->critic.head[0].dact[2], a->critic.head[1].dact[2], B, S);
+        EXORL_LAUNCH_CHECK();
+        return 0;
+    };
     // ---- aug_and_encode (ddpg.py:213-215, 312-315); shifts_obs == (const int32_t*)-1: keep the images exorl_pixel_agent_augment made;
     // (const int32_t*)-2: keep the encodings exorl_pixel_agent_encode(0 / 1, online) made as well — the agents that step the encoder
     // through their own module pass the critic the encodings computed BEFORE that step (icm.py:97-131, diayn.py:137-170), detached
@@ -436,11 +472,14 @@ int exorl_pixel_agent_update(exorl_pixel_agent_t* a, float stddev, const int32_t
     EXORL_TRY(sample_action(a->mu_n, nc, stddev, c.stddev_clip, 1, a->xq_t + F, FA, B, A, nullptr, s));
     // the target's Q heads reuse the critic's Mlp buffers (outputs to q), then are copied to tq
     for (int i = 0; i < 2; ++i) EXORL_TRY(mlp_forward(a->critic.head[i], Pt, a->xq_t, FA, B, prec, s));
+    EXORL_TRY(sf_q());
     EXORL_CHECK_HIP(hipMemcpyAsync(a->tq, a->q, sizeof(float) * 2 * B, hipMemcpyDeviceToDevice, s));
     EXORL_TRY(trunk_forward(a, a->critic, Pc, a->feat_o, mt, B, a->tc, prec, s));
     EXORL_TRY(launch_concat(a->tc.h, F, F, a->action, A, A, a->xq_c, B, s));
     for (int i = 0; i < 2; ++i) EXORL_TRY(mlp_forward(a->critic.head[i], Pc, a->xq_c, FA, B, prec, s));
+    EXORL_TRY(sf_q());
     EXORL_TRY(critic_loss(a->q, a->tq, a->reward, a->discount, a->dq, a->metrics, B, inv_b, s));
+    EXORL_TRY(sf_dout());
     for (int i = 0; i < 2; ++i) EXORL_TRY(mlp_backward(a->critic.head[i], Pc, Gc, a->xq_c, FA, B, a->dxq[i], prec, s));
     hipLaunchKernelGGL(add_cols_kernel, dim3(grid1((int64_t)B * F)), dim3(256), 0, s, a->dxq[0], (int64_t)FA, a->dxq[1], (int64_t)FA, 0, F, a->dh, B);
     EXORL_LAUNCH_CHECK();
@@ -460,8 +499,10 @@ int exorl_pixel_agent_update(exorl_pixel_agent_t* a, float stddev, const int32_t
     EXORL_TRY(sample_action(a->mu_o, na, stddev, c.stddev_clip, 1, a->xq_c + F, FA, B, A, a->metrics + EXORL_M_ACTOR_LOGPROB, s));
     a->noise_counter += 1;
     for (int i = 0; i < 2; ++i) EXORL_TRY(mlp_forward(a->critic.head[i], Pc, a->xq_c, FA, B, prec, s));
+    EXORL_TRY(sf_q());
     EXORL_TRY(actor_stats(a->q, a->stats, B, s));
     EXORL_TRY(actor_dq(a->q, a->stats, a->dq, B, inv_b, 0.f, 0, s));
+    EXORL_TRY(sf_dout());
     for (int i = 0; i < 2; ++i) EXORL_TRY(mlp_backward(a->critic.head[i], Pc, Gc, a->xq_c, FA, B, a->dxq[i], prec, s));     // Gc: scratch now
     hipLaunchKernelGGL(add_cols_kernel, dim3(grid1((int64_t)B * A)), dim3(256), 0, s, a->dxq[0], (int64_t)FA, a->dxq[1], (int64_t)FA, F, A, a->dmu, B);
     hipLaunchKernelGGL(dpre_kernel, dim3(grid1((int64_t)B * A)), dim3(256), 0, s, a->dmu, a->mu_o, pol.dact[2], (int64_t)B * A);

@@ -201,12 +201,12 @@ class IntrEngine:
     def __init__(self, kind, obs_dim, act_dim, hidden_dim, batch, rep_dim=0, lr=1e-4, scale=1.0, knn_k=12, knn_avg=True,
                  knn_rms=True, knn_clip=0.0, clip_val=5.0, n_models=0, num_protos=0, queue_size=0, tau=0.1, target_tau=0.05, sp_lr=1e-3, vae_lr=1e-2,
                  vae_beta=0.5, state_ent_coef=1.0, latent_ent_coef=1.0, latent_cond_ent_coef=1.0, goal=(150.0, 75.0), precision='fp32',
-                 device='cuda'):
+                 device='cuda', encoded=False):
         self.lib = L.load()
         self.device = _require_gpu(device)
         self.kind, self.batch, self.obs_dim, self.act_dim = kind, batch, obs_dim, act_dim
         self.cfg = L.IntrCfg(self.KINDS[kind], obs_dim, act_dim, hidden_dim, rep_dim, batch, PRECISION[precision], knn_k, int(bool(knn_avg)),
-                             int(bool(knn_rms)), n_models, 0, lr, scale, knn_clip, clip_val, num_protos, queue_size, tau, target_tau,
+                             int(bool(knn_rms)), n_models, 1 if encoded else 0, lr, scale, knn_clip, clip_val, num_protos, queue_size, tau, target_tau,
                              sp_lr, vae_lr, vae_beta, state_ent_coef, latent_ent_coef, latent_cond_ent_coef, goal[0], goal[1])
         nbytes = self.lib.exorl_intr_workspace_bytes(C.byref(self.cfg))
         if nbytes == 0:
@@ -303,7 +303,7 @@ class PixelEngine:
     NETS = {'encoder': 0, 'actor': 1, 'critic': 2, 'critic_target': 3}
 
     def __init__(self, obs_shape, act_dim, feature_dim, hidden_dim, batch, lr=1e-4, tau=0.01, stddev_clip=0.3, precision='fp32', seed=0,
-                 device='cuda', meta_dim=0):
+                 device='cuda', meta_dim=0, sf_dim=0):
         self.lib = L.load()
         self.device = _require_gpu(device)
         c, h, w = obs_shape
@@ -311,7 +311,7 @@ class PixelEngine:
             raise L.ExorlError(f'pixel observations must be square, got {obs_shape}')
         self.obs_shape, self.act_dim, self.batch, self.meta_dim = tuple(obs_shape), act_dim, batch, meta_dim
         self.cfg = L.PixelCfg(c, h, act_dim, feature_dim, hidden_dim, batch, PRECISION[precision], meta_dim, lr, tau,
-                              stddev_clip if stddev_clip is not None else 0.0, 0.0, seed)
+                              stddev_clip if stddev_clip is not None else 0.0, sf_dim, seed)
         nbytes = self.lib.exorl_pixel_agent_workspace_bytes(C.byref(self.cfg))
         if nbytes == 0:
             raise L.ExorlError(self.lib.exorl_last_error().decode())

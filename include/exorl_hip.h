@@ -302,6 +302,7 @@ int exorl_knn_topk(const float* src_dev, int32_t n_src, const float* tgt_dev, in
 #define EXORL_INTR_APS     6        /* agents/unsupervised_learning/aps.py:63-79,147-175 (the task rides in `skill`) */
 #define EXORL_INTR_SMM     7        /* agents/unsupervised_learning/smm.py:27-112,173-246 (states; obs rows are [obs | z], z also in `skill`) */
 #define EXORL_MAX_ENSEMBLE 8
+#define EXORL_INTR_ENCODED 1       /* exorl_intr_cfg.flags */
 
 typedef struct exorl_intr_cfg {
     int32_t kind;         /* EXORL_INTR_* */
@@ -311,7 +312,9 @@ typedef struct exorl_intr_cfg {
     int32_t precision;    /* EXORL_PREC_* (MFMA operand type of the module's GEMMs) */
     int32_t knn_k, knn_avg, knn_rms;   /* ICM-APT: utils.PBE arguments (configs/agent/icm_apt.yaml) */
     int32_t n_models;     /* Disagreement ensemble size (0 -> 5, disagreement.py:12) */
-    int32_t reserved;
+    int32_t flags;        /* EXORL_INTR_ENCODED: the observation rows are encodings of pixel frames (obs_type == 'pixels') — SMM drops the goal prior
+                             p*(s) from its reward (smm.py:232-235); RND takes the rows as already normalised (BatchNorm2d ran on the frames,
+                             rnd.py:26-27,47-50) and feeds its frozen target net from next_obs, the frozen encoder copy's output (rnd.py:35-39) */
     float lr;             /* Adam, betas (0.9, 0.999), eps 1e-8 */
     float scale;          /* rnd_scale / icm_scale */
     float knn_clip;
@@ -375,7 +378,8 @@ typedef struct exorl_intr_batch {
     float* dobs_out;            /* if set (train != 0): receives the loss gradient at the encoding the module's loss reaches the caller's encoder
                                    through, dense (batch, obs_dim), so that the caller continues the backward pass: d/d(obs rows) for Proto
                                    (proto_opt owns the encoder too, proto.py:75-78), ICM, ICM-APT and Disagreement (next_obs is encoded without a
-                                   graph there, icm.py:97-99); d/d(next_obs rows) for DIAYN and APS (diayn.py:78-92, aps.py:147-159) */
+                                   graph there, icm.py:97-99), SMM (through the VAE's input and its reconstruction target, smm.py:61-70) and RND with
+                                   EXORL_INTR_ENCODED (the predictor's input); d/d(next_obs rows) for DIAYN and APS (diayn.py:78-92, aps.py:147-159) */
     const float* cat_uniform;   /* Proto: num_protos uniforms in [0,1) for Categorical(prob).sample() (proto.py:112); SMM: the VAE's
                                    epsilon, (batch, 128) standard normals (smm.py:62); null -> Philox */
 } exorl_intr_batch;
@@ -427,7 +431,8 @@ typedef struct exorl_pixel_cfg {
     int32_t act_dim, feature_dim, hidden_dim, batch;
     int32_t precision;         /* EXORL_PREC_*: Linear layers' GEMMs and (bf16 modes) the 32-channel convolutions on MFMA; fp32: fp32 FMA convolutions */
     int32_t meta_dim;          /* skill / task columns concatenated after the encoding in front of the actor's and the critic's trunk (ddpg.py:294-299,305-312) */
-    float lr, tau, stddev_clip, reserved2;
+    float lr, tau, stddev_clip;
+    int32_t sf_dim;            /* > 0: CriticSF (aps.py:17-60) — each Q head emits sf_dim successor features, Q = task . features, the task being the meta row */
     uint64_t seed;
 } exorl_pixel_cfg;
 typedef struct exorl_pixel_agent exorl_pixel_agent_t;

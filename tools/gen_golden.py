@@ -410,7 +410,7 @@ def gen_pixel_proto(ref):
 
 
 # ----------------------------------------------------------------------------- agents (G3/G4)
-PIXEL_INTR = ('icm', 'icm_apt', 'disagreement', 'diayn')
+PIXEL_INTR = ('icm', 'icm_apt', 'disagreement', 'diayn', 'aps', 'smm')
 
 
 def pixel_intr_frames(step, B, C, HW):
@@ -437,6 +437,12 @@ def gen_pixel_intr(ref, kind):
         agent, mod = ref.disagreement.DisagreementAgent(update_encoder=True, **kw), 'disagreement'
     elif kind == 'diayn':
         agent, mod = ref.diayn.DIAYNAgent(update_skill_every_step=50, skill_dim=S, diayn_scale=1.0, update_encoder=True, skill_type='uniform', **kw), 'diayn'
+    elif kind == 'aps':
+        agent, mod = ref.aps.APSAgent(update_task_every_step=5, sf_dim=S, knn_rms=True, knn_k=3, knn_avg=True, knn_clip=0.0001, num_init_steps=4096,
+                                      lstsq_batch_size=4096, update_encoder=True, **kw), 'aps'
+    elif kind == 'smm':
+        agent, mod = ref.smm.SMMAgent(z_dim=S, sp_lr=1e-3, vae_lr=1e-4, vae_beta=0.5, state_ent_coef=1.0, latent_ent_coef=1.0, latent_cond_ent_coef=1.0,
+                                      update_encoder=True, **kw), 'smm'
     else:
         raise ValueError(kind)
     out = {'dims': np.array([C, HW, A, F, H, B, N, S])}
@@ -457,21 +463,29 @@ def gen_pixel_intr(ref, kind):
         return torch.from_numpy(sh).to(dtype)
     U._standard_normal = lambda shape, dtype, device: torch.from_numpy(noise.draw(shape)).to(dtype)
     torch.randint = p_randint
+    o_randn, eps_stream = torch.randn, _synth.NoiseStream(33)
+    if kind == 'smm':                                     # the VAE's epsilon (smm.py:62)
+        torch.randn = lambda shape, *a, **k: torch.from_numpy(eps_stream.draw(tuple(shape)))
     metrics = []
     try:
         for i in range(N):
             b = _synth.synth_batch(61, i, B, 4, A)
             obs, nobs = pixel_intr_frames(i, B, C, HW)
             batch = [obs, b[1], b[2], b[3], nobs]
-            if kind == 'diayn':
+            if kind in ('diayn', 'smm'):
                 skill = np.zeros((B, S), np.float32)
                 skill[np.arange(B), np.random.RandomState(70 + i).randint(0, S, B)] = 1.0
                 batch.append(skill)
                 out[f'batch/{i}/skill'] = skill
+            if kind == 'aps':                             # unit-norm task vectors (aps.py:122-128)
+                task = np.random.RandomState(70 + i).standard_normal((B, S)).astype(np.float32)
+                task /= np.linalg.norm(task, axis=1, keepdims=True)
+                batch.append(task)
+                out[f'batch/{i}/skill'] = task
             m = agent.update(iter([tuple(batch)]), 2 * i)
             metrics.append({k: float(v) for k, v in m.items()})
     finally:
-        U._standard_normal, torch.randint = o_sn, o_randint
+        U._standard_normal, torch.randint, torch.randn = o_sn, o_randint, o_randn
     out['shifts'] = np.stack(shifts)                      # [2 * step + (0 obs | 1 next_obs)]
     keys = sorted(metrics[0].keys())
     out['metric_keys'] = np.array(keys)
