@@ -84,6 +84,8 @@ PROTOTYPES = {
     'exorl_pixel_agent_encoder_target': (C.c_int, [c_void_p, c_float, c_int32, c_void_p]),
     'exorl_pixel_agent_set_train_encoder': (C.c_int, [c_void_p, c_int32]),
     'exorl_pixel_agent_encoder_target_ptr': (C.c_int, [c_void_p, P(c_void_p)]),
+    'exorl_pixel_agent_rnd_features': (C.c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    'exorl_pixel_agent_bn_state': (C.c_int, [c_void_p, c_void_p, c_void_p]),
     'exorl_pixel_agent_state': (C.c_int, [c_void_p, c_void_p, c_void_p]),
     'exorl_pixel_agent_set_state': (C.c_int, [c_void_p, c_void_p, c_void_p]),
     'exorl_pixel_agent_encoder_opt2': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),

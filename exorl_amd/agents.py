@@ -511,7 +511,7 @@ class DDPGAgent(_AgentBase):
         if obs_type == 'pixels':
             if not (type(self) is DDPGAgent or getattr(self, '_PIXELS_OK', False)):
                 raise NotImplementedError(f"exorl_amd: obs_type='pixels' is not built for {type(self).__name__} yet (DDPG, Proto, ICM, ICM-APT, "
-                                          "Disagreement, DIAYN, APS and SMM are)")
+                                          "Disagreement, DIAYN, APS, SMM and RND are)")
             return self._init_pixels(reward_free, obs_shape, action_shape, device, lr, feature_dim, hidden_dim, critic_target_tau, num_expl_steps,
                                      update_every_steps, stddev_schedule, batch_size, stddev_clip, init_critic, use_tb, use_wandb, precision, seed,
                                      meta_dim)
@@ -815,22 +815,121 @@ class _IntrAgent(DDPGAgent):
         return metrics
 
 
+class _RndPixelView(_RndView):
+    """agent.rnd on pixels (rnd.py:13-45): normalize_obs is a BatchNorm2d over the frames (buffers in the pixel engine), predictor.0 IS the
+    agent's encoder, target.0 its frozen copy (the pixel engine's encoder_target slot); the six Linear layers live in the module engine."""
+
+    def __init__(self, intr, pixel, encoder_view, target_view):
+        super().__init__(intr, None, _RND_KEYS)
+        self._pixel, self._enc, self._tgt = pixel, encoder_view, target_view
+
+    def _bn(self):
+        b = self._pixel.bn2d()
+        c = (b.numel() - 1) // 2
+        return b[:c], b[c:2 * c], b[2 * c:]
+
+    def state_dict(self):
+        sd = super().state_dict()
+        for pre, view in (('predictor.0.', self._enc), ('target.0.', self._tgt)):
+            sd.update({pre + k: v for k, v in view.state_dict().items()})
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        sd = dict(sd)
+        for pre, view in (('predictor.0.', self._enc), ('target.0.', self._tgt)):
+            sub = {k[len(pre):]: sd.pop(k) for k in list(sd) if k.startswith(pre)}
+            if sub or strict:
+                view.load_state_dict(sub, strict)
+        super().load_state_dict(sd, strict)
+
+
 class RNDAgent(_IntrAgent):
     """agents/unsupervised_learning/rnd.py:63-159 (configs/agent/rnd.yaml)."""
     LOSS_KEY = 'rnd_loss'
+    _PIXELS_OK = True
 
     def __init__(self, rnd_rep_dim, update_encoder, rnd_scale=1., **kwargs):
         super().__init__(**kwargs)
         self.rnd_scale = rnd_scale
         self.update_encoder = update_encoder
         O, H = self.obs_dim, self.hidden_dim
-        w = _seq_init([('lin', O, H), ('lin', H, H), ('lin', H, rnd_rep_dim)] * 2)      # predictor then target (rnd.py:28-43)
+        pixels = self.obs_type == 'pixels'
+        if pixels:      # RND(...) construction order (rnd.py:28-45): the six Linears, then weight_init over predictor (the shared encoder's
+            # convolutions are drawn AGAIN, then its Linears) and target (the copied encoder's convolutions get draws of their own)
+            lins = [nn.Linear(*d) for d in ((O, H), (H, H), (H, rnd_rep_dim)) * 2]
+            c = self.obs_shape[0]
+            shapes = [(32, c if l == 0 else 32, 3, 3) for l in range(4)]
+            w, convs = [], []
+            for half in range(2):
+                cw = [nn.init.orthogonal_(torch.empty(sh), nn.init.calculate_gain('relu')) for sh in shapes]
+                convs.append(cw)
+                for m in lins[3 * half:3 * half + 3]:
+                    nn.init.orthogonal_(m.weight.data)
+                    m.bias.data.fill_(0.0)
+                    w += [m.weight.data, m.bias.data]
+            for view_p, cw in zip(self.encoder.parameters()[0::2], convs[0]):
+                view_p.copy_(cw.reshape(view_p.shape))
+            for view_p in self.encoder.parameters()[1::2]:
+                view_p.zero_()
+        else:
+            w = _seq_init([('lin', O, H), ('lin', H, H), ('lin', H, rnd_rep_dim)] * 2)      # predictor then target (rnd.py:28-43)
         self.intr = IntrEngine('rnd', O, self.action_dim, H, self.engine.batch, rep_dim=rnd_rep_dim, lr=self.lr, scale=rnd_scale,
-                               precision=self._precision, device=self.device)
-        self.rnd = _RndView(self.intr, None, _RND_KEYS)
-        for p, t in zip(self.rnd.parameters(), w):
-            p.copy_(t.reshape(p.shape))
+                               precision=self._precision, device=self.device, encoded=pixels)
+        if pixels:
+            conv_shapes = [s_ for l in range(4) for s_ in ((32, self.obs_shape[0] if l == 0 else 32, 3, 3), (32,))]
+            self.rnd_target_encoder = _ParamList(_ENC_KEYS, self.engine.encoder_target_tensors(conv_shapes))
+            for p, cw in zip(self.rnd_target_encoder.parameters()[0::2], convs[1]):
+                p.copy_(cw)
+            for p in self.rnd_target_encoder.parameters()[1::2]:
+                p.zero_()
+            self.rnd = _RndPixelView(self.intr, self.engine, self.encoder, self.rnd_target_encoder)
+            NetView.load_state_dict(self.rnd, {k: t for k, t in zip(_RND_KEYS, w)})
+        else:
+            self.rnd = _RndView(self.intr, None, _RND_KEYS)
+            for p, t in zip(self.rnd.parameters(), w):
+                p.copy_(t.reshape(p.shape))
         self.intrinsic_reward_rms = _RmsView(self.intr)
+        self._pix_alloc()
+
+    def _update_pixels(self, replay_iter, step):
+        """rnd.py:110-159 on pixels. RND.forward augments the raw frames itself, normalises them with a BatchNorm2d and runs the agent's
+        encoder inside its predictor (and a frozen copy inside its target): update_rnd steps that encoder twice on the same gradients
+        (rnd_opt, then encoder_opt), compute_intr_reward draws another augmentation and runs the moved encoder, and only then are obs and
+        next_obs augmented and encoded for the critic and the actor (detached)."""
+        eng = self.engine
+        s = self._slots = self._slots or eng.batch_slots()
+        if hasattr(replay_iter, 'sample_into'):
+            replay_iter.sample_into(s, eng.batch)
+        else:
+            eng.set_batch(*next(replay_iter)[:5])
+        B, A = eng.batch, self.action_dim
+        sh = lambda: self.shift_hook(B) if self.shift_hook else None
+        if self.reward_free:
+            fp, ft = eng.rnd_features(sh(), 5.0)
+            self.intr.update(fp, None, ft, s.reward, s.reward, 2, dobs_out=self._dobs.data_ptr())
+            eng.encoder_step(0, self._dobs.data_ptr(), 2)
+            fp, ft = eng.rnd_features(sh(), 5.0)
+            self.intr.update(fp, None, ft, s.reward, s.reward, False)
+        stddev = self._stddev(step)
+        eng.set_train_encoder(False)
+        eng.update(stddev, sh(), sh(), self.noise_hook((B, A)) if self.noise_hook else None, self.noise_hook((B, A)) if self.noise_hook else None)
+        metrics = dict()
+        if self.use_tb or self.use_wandb:
+            raw = eng.metrics_raw()
+            for idx, name in _CRITIC_METRICS + [(L.M_ACTOR_LOGPROB, 'actor_logprob')]:
+                metrics[name] = float(raw[idx])
+            metrics['actor_ent'] = float(np.float32(0.5 + 0.5 * np.log(2 * np.pi) + np.log(stddev)) * self.action_dim)
+            ri = self.intr.metrics_raw()
+            if self.reward_free:
+                metrics['rnd_loss'] = float(ri[L.IM_LOSS])
+                metrics['intr_reward'] = float(ri[L.IM_INTR_REWARD])
+                metrics['extr_reward'] = float(ri[L.IM_EXTR_REWARD])
+            else:
+                metrics['extr_reward'] = metrics['batch_reward']
+            M, S_, _n = self.intr.rms_state()
+            metrics['pred_error_mean'] = float(M)
+            metrics['pred_error_std'] = float(np.sqrt(np.float32(S_)))
+        return metrics
 
 
 class ICMAgent(_IntrAgent):

@@ -841,8 +841,10 @@ static void carve_intr(exorl_intr* it, ICarver& c) {
     it->metrics = c.take(EXORL_N_INTR_METRICS);
     it->rms = reinterpret_cast<RmsState*>(c.take(4));
     if (g.kind == EXORL_INTR_RND) {
-        it->xn = c.take(B * O);
-        it->bn = c.take(2 * O + 1);
+        if (!(g.flags & EXORL_INTR_ENCODED)) {     // encoded rows arrive normalised (BatchNorm2d ran on the frames)
+            it->xn = c.take(B * O);
+            it->bn = c.take(2 * O + 1);
+        }
     } else if (g.kind == EXORL_INTR_APS) {
         it->topk = c.take(B * g.knn_k);
         it->d2 = c.take(B * round_up(B, 64));
@@ -910,25 +912,39 @@ static int rnd_forward(exorl_intr* it, const exorl_intr_batch& b, bool with_targ
     const auto& c = it->cfg;
     const int B = c.batch, O = c.obs_dim, R = c.rep_dim;
     const float* P = it->flat[EXORL_T_PARAM];
-    hipLaunchKernelGGL(bn_clamp_kernel, dim3(O), dim3(256), 0, s, b.obs, b.obs_ld, it->xn, B, O, c.clip_val, it->bn);
-    EXORL_LAUNCH_CHECK();
-    EXORL_TRY(mlp_forward(it->net[0], P, it->xn, O, B, c.precision, s));
-    if (with_target) EXORL_TRY(mlp_forward(it->net[1], P, it->xn, O, B, c.precision, s));
+    if (c.flags & EXORL_INTR_ENCODED) {
+        // pixels (rnd.py:26-27,35-39,47-53): BatchNorm2d + clamp ran on the frames, in front of the two encoders; obs is the agent's encoder
+        // on them (the predictor's first stage), next_obs the frozen encoder copy's output (the target's first stage)
+        EXORL_REQUIRE(b.next_obs, "intr_update: RND on encodings reads the frozen encoder's output from next_obs");
+        EXORL_TRY(mlp_forward(it->net[0], P, b.obs, b.obs_ld, B, c.precision, s));
+        EXORL_TRY(mlp_forward(it->net[1], P, b.next_obs, b.next_obs_ld, B, c.precision, s));
+    } else {
+        hipLaunchKernelGGL(bn_clamp_kernel, dim3(O), dim3(256), 0, s, b.obs, b.obs_ld, it->xn, B, O, c.clip_val, it->bn);
+        EXORL_LAUNCH_CHECK();
+        EXORL_TRY(mlp_forward(it->net[0], P, it->xn, O, B, c.precision, s));
+        if (with_target) EXORL_TRY(mlp_forward(it->net[1], P, it->xn, O, B, c.precision, s));
+    }
     hipLaunchKernelGGL(rnd_err_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->net[0].act[2], it->net[1].act[2], it->fe, dpred, B, R);
     EXORL_LAUNCH_CHECK();
     return 0;
 }
 
-static int rnd_update(exorl_intr* it, const exorl_intr_batch& b, bool train, hipStream_t s) {
+// train: 0 reward only, 1 step + reward on the same rows, 2 step only (pixels: the reward pass draws a new augmentation and runs the
+// encoder the step has just moved, rnd.py:98-103, so the caller encodes again in between)
+static int rnd_update(exorl_intr* it, const exorl_intr_batch& b, int train, hipStream_t s) {
     const auto& c = it->cfg;
     const int B = c.batch;
+    const bool enc = (c.flags & EXORL_INTR_ENCODED) != 0;
+    EXORL_REQUIRE(enc || train != 2, "intr_update: RND's step-only call belongs to the encoded (pixel) variant");
     if (train) {                                                                                     // rnd.py:79-96
         EXORL_TRY(rnd_forward(it, b, true, it->net[0].dact[2], s));
         EXORL_TRY(launch_mean(it->fe, B, 1.0f / (float)B, it->metrics + EXORL_IM_LOSS, 0, s));
-        EXORL_TRY(mlp_backward(it->net[0], it->flat[EXORL_T_PARAM], it->flat[EXORL_T_GRAD], it->xn, c.obs_dim, B, nullptr, c.precision, s));
+        EXORL_TRY(mlp_backward(it->net[0], it->flat[EXORL_T_PARAM], it->flat[EXORL_T_GRAD], enc ? b.obs : it->xn, enc ? b.obs_ld : (int64_t)c.obs_dim, B,
+                               enc ? b.dobs_out : nullptr, c.precision, s));
         EXORL_TRY(intr_adam(it, s));
+        if (train == 2) return 0;
     }
-    // compute_intr_reward (rnd.py:98-103): same batch -> same BatchNorm output and frozen target, only the predictor moved
+    // compute_intr_reward (rnd.py:98-103); states: same batch -> same BatchNorm output and frozen target, only the predictor moved
     EXORL_TRY(rnd_forward(it, b, !train, nullptr, s));
     hipLaunchKernelGGL(rnd_reward_kernel, dim3(1), dim3(1024), 0, s, it->fe, b.extr_reward, b.reward_out, B, c.scale, it->rms, it->metrics);
     EXORL_LAUNCH_CHECK();
@@ -1362,7 +1378,7 @@ int exorl_intr_update(exorl_intr_t* it, const exorl_intr_batch* b, int32_t train
                   (!b->skill || (k != EXORL_INTR_DIAYN && k != EXORL_INTR_APS && k != EXORL_INTR_SMM) || b->skill_ld >= it->cfg.rep_dim), "intr_update: a leading dimension is smaller than its row width");
     hipStream_t s = as_stream(stream);
     switch (k) {
-        case EXORL_INTR_RND: return rnd_update(it, *b, train != 0, s);
+        case EXORL_INTR_RND: return rnd_update(it, *b, train, s);
         case EXORL_INTR_ICM: return icm_update(it, *b, train != 0, s);
         case EXORL_INTR_ICM_APT: return apt_update(it, *b, train != 0, s);
         case EXORL_INTR_DISAGREEMENT: return disagreement_update(it, *b, train != 0, s);

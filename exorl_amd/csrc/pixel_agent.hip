@@ -84,6 +84,53 @@ __global__ __launch_bounds__(256) void sf_dout_kernel(const float* __restrict__ 
     (n ? d1 : d0)[r] = dq[n * B + m] * task[(int64_t)m * ldt + j];
 }
 
+// nn.BatchNorm2d(affine=False) in training mode on (n, c, h, w) images, then clamp(+-clip) (rnd.py:26-27,47-50). Statistics per channel over
+// n * h * w values in double (torch's CPU kernel accumulates float inputs in double): partial sums per (channel, chunk), a fixed-order
+// finish, the centred second pass the same way, then one elementwise pass. running_var takes the unbiased estimate, momentum 0.1.
+constexpr int BN2_CHUNKS = 128;
+__global__ __launch_bounds__(256) void bn2d_partial_kernel(const float* __restrict__ x, int n, int c, int64_t hw, const double* __restrict__ mean,
+                                                           double* __restrict__ part) {
+    __shared__ double red[256];
+    const int ch = blockIdx.x, k = blockIdx.y;
+    const int64_t per = (int64_t)n * hw, lo = per * k / BN2_CHUNKS, hi = per * (k + 1) / BN2_CHUNKS;
+    const double m = mean ? mean[ch] : 0.0;
+    double acc = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const int64_t img = i / hw, p = i - img * hw;
+        const double v = (double)x[(img * c + ch) * hw + p] - m;
+        acc += mean ? v * v : v;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[ch * BN2_CHUNKS + k] = red[0];
+}
+// stage 0: mean[ch] = sum(part) / count; stage 1: var, running statistics (stats: mean[c] var[c] count)
+__global__ void bn2d_finish_kernel(const double* __restrict__ part, double* __restrict__ mean, double* __restrict__ var, float* __restrict__ running,
+                                   int c, double count, int stage) {
+    const int ch = threadIdx.x;
+    if (ch >= c) return;
+    double acc = 0.0;
+    for (int k = 0; k < BN2_CHUNKS; ++k) acc += part[ch * BN2_CHUNKS + k];
+    if (stage == 0) { mean[ch] = acc / count; return; }
+    var[ch] = acc / count;
+    running[ch] = 0.9f * running[ch] + 0.1f * (float)mean[ch];
+    running[c + ch] = 0.9f * running[c + ch] + 0.1f * (float)(acc / (count > 1.0 ? count - 1.0 : 1.0));
+    if (ch == 0) running[2 * c] += 1.0f;
+}
+__global__ __launch_bounds__(256) void bn2d_apply_kernel(float* __restrict__ x, int c, int64_t hw, int64_t total, const double* __restrict__ mean,
+                                                         const double* __restrict__ var, float clip) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)((i / hw) % c);
+        const double inv = 1.0 / sqrt(var[ch] + 1e-5);               // torch's CPU kernel: out = x * alpha + beta with alpha = invstd, beta = -mean * invstd
+        const float v = x[i] * (float)inv + (float)(-mean[ch] * inv);
+        x[i] = fminf(fmaxf(v, -clip), clip);
+    }
+}
+
 static int grid1(int64_t n) { const int64_t b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
 
 }  // namespace exorl
@@ -111,9 +158,11 @@ struct exorl_pixel_agent {
     int32_t* shifts = nullptr;
     float* act_ws = nullptr;                     // B = 1 inference scratch
     int64_t t = 0, t_enc = 0;                    // Adam step counts: critic_opt / actor_opt, encoder_opt (equal for plain DDPG)
-    uint64_t noise_counter = 0, aug_counter = 0, act_counter = 0;
+    uint64_t noise_counter = 0, aug_counter = 0, act_counter = 0, rnd_aug_counter = 0;
     // Proto on pixels (proto.py:46-85): encoder_target (Polyak copy) and the encoder's second Adam state (proto_opt's)
     float *enc_target = nullptr, *enc_m2 = nullptr, *enc_v2 = nullptr;
+    float* bn2d = nullptr;                       // RND on pixels: BatchNorm2d running_mean[c] running_var[c] num_batches_tracked
+    double* bn_scratch = nullptr;                // mean[16] var[16] partials[16 * BN2_CHUNKS]
     int64_t t2 = 0;
     bool augmented = false;
     bool have_feat_o = false, have_feat_n = false;     // feat_o / feat_n hold the online encoder's pass of exorl_pixel_agent_encode
@@ -146,6 +195,8 @@ static void pcarve(exorl_pixel_agent* a, PCarver& c) {
     for (int w = 0; w < 4; ++w) a->flat[2][w] = c.take(a->critic.total);
     a->flat[3][0] = c.take(a->critic.total);
     a->enc_target = c.take(a->enc_total); a->enc_m2 = c.take(a->enc_total); a->enc_v2 = c.take(a->enc_total);
+    a->bn2d = c.take(2 * 16 + 1);
+    a->bn_scratch = reinterpret_cast<double*>(c.take(2 * (32 + 16 * BN2_CHUNKS)));
     a->obs = reinterpret_cast<unsigned char*>(c.take((B * img + 3) / 4));
     a->next_obs = reinterpret_cast<unsigned char*>(c.take((B * img + 3) / 4));
     a->action = c.take(B * A); a->reward = c.take(B); a->discount = c.take(B);
@@ -272,6 +323,11 @@ int exorl_pixel_agent_create(const exorl_pixel_cfg* cfg, void* workspace, size_t
     PCarver c(a->ws);
     pcarve(a, c);
     if (hipMemset(a->ws, 0, bytes) != hipSuccess) { set_error("pixel_agent_create: hipMemset failed"); delete a; return 1; }
+    {                                            // BatchNorm2d buffers: running_mean 0, running_var 1, num_batches_tracked 0
+        float ones[16];
+        for (float& o : ones) o = 1.0f;
+        if (hipMemcpy(a->bn2d + cfg->c_in, ones, sizeof(float) * cfg->c_in, hipMemcpyHostToDevice) != hipSuccess) { set_error("pixel_agent_create: hipMemcpy failed"); delete a; return 1; }
+    }
     *out = a;
     return 0;
 }
@@ -367,14 +423,47 @@ int exorl_pixel_agent_encode(exorl_pixel_agent_t* a, int32_t which, int32_t targ
 // Backward through the encoder pass last run by exorl_pixel_agent_encode(which, 0) from dfeat_dev (batch, repr_dim; overwritten), then
 // one Adam step of the encoder with optimiser state `opt` (0: encoder_opt, ddpg.py:188-190; 1: the encoder's slots in proto_opt, proto.py:75-78)
 int exorl_pixel_agent_encoder_step(exorl_pixel_agent_t* a, int32_t which, float* dfeat_dev, int32_t opt, void* stream) {
-    EXORL_REQUIRE(a && dfeat_dev && (which == 0 || which == 1) && (opt == 0 || opt == 1), "pixel_agent_encoder_step: bad arguments");
+    EXORL_REQUIRE(a && dfeat_dev && (which == 0 || which == 1) && opt >= 0 && opt <= 2, "pixel_agent_encoder_step: bad arguments");
     hipStream_t s = as_stream(stream);
     const auto& c = a->cfg;
     EXORL_TRY(exorl_encoder_backward_prec(a->flat[0][0], c.c_in, c.hw, which ? a->aug_n : a->aug_o, c.batch, which ? a->enc_ws_n : a->enc_ws_o, dfeat_dev,
                                      a->flat[0][1], a->cfg.precision, s));
     if (opt == 0) { a->t_enc += 1; return padam(a, 0, a->enc_total, nullptr, s); }
     a->t2 += 1;
-    return adam_step(a->flat[0][0], a->flat[0][1], a->enc_m2, a->enc_v2, a->enc_total, c.lr, 0.9f, 0.999f, 1e-8f, a->t2, nullptr, 0.f, s);
+    EXORL_TRY(adam_step(a->flat[0][0], a->flat[0][1], a->enc_m2, a->enc_v2, a->enc_total, c.lr, 0.9f, 0.999f, 1e-8f, a->t2, nullptr, 0.f, s));
+    if (opt == 2) { a->t_enc += 1; return padam(a, 0, a->enc_total, nullptr, s); }      // rnd.py:86-89: rnd_opt.step() then encoder_opt.step(), same gradients
+    return 0;
+}
+
+// RND on pixels (rnd.py:47-53): x = clamp(BatchNorm2d(RandomShiftsAug(obs))) -> the agent's encoder (*feat_pred_dev, kept for
+// exorl_pixel_agent_encoder_step(0, ...)) and the frozen copy held in the encoder_target slot (*feat_target_dev). shifts_dev: (batch, 2) or null.
+int exorl_pixel_agent_rnd_features(exorl_pixel_agent_t* a, const int32_t* shifts_dev, float clip_val, float** feat_pred_dev, float** feat_target_dev,
+                                   void* stream) {
+    EXORL_REQUIRE(a && feat_pred_dev && feat_target_dev && clip_val > 0.f, "pixel_agent_rnd_features: bad arguments");
+    hipStream_t s = as_stream(stream);
+    const auto& c = a->cfg;
+    const int64_t hw = (int64_t)c.hw * c.hw, total = (int64_t)c.batch * c.c_in * hw;
+    EXORL_TRY(exorl_aug_shift(a->obs, c.batch, c.c_in, c.hw, 4, shifts_dev, c.seed, (1ull << 62) | a->rnd_aug_counter, a->aug_o, s));
+    a->rnd_aug_counter += 1;
+    double *mean = a->bn_scratch, *var = mean + 16, *part = mean + 32;
+    const double count = (double)c.batch * (double)hw;
+    hipLaunchKernelGGL(bn2d_partial_kernel, dim3(c.c_in, BN2_CHUNKS), dim3(256), 0, s, a->aug_o, c.batch, c.c_in, hw, (const double*)nullptr, part);
+    hipLaunchKernelGGL(bn2d_finish_kernel, dim3(1), dim3(16), 0, s, part, mean, var, a->bn2d, c.c_in, count, 0);
+    hipLaunchKernelGGL(bn2d_partial_kernel, dim3(c.c_in, BN2_CHUNKS), dim3(256), 0, s, a->aug_o, c.batch, c.c_in, hw, (const double*)mean, part);
+    hipLaunchKernelGGL(bn2d_finish_kernel, dim3(1), dim3(16), 0, s, part, mean, var, a->bn2d, c.c_in, count, 1);
+    hipLaunchKernelGGL(bn2d_apply_kernel, dim3(grid1(total)), dim3(256), 0, s, a->aug_o, c.c_in, hw, total, (const double*)mean, (const double*)var, clip_val);
+    EXORL_LAUNCH_CHECK();
+    a->augmented = false;                        // aug_o no longer holds a plain augmentation; aug_n is stale
+    a->have_feat_o = a->have_feat_n = false;
+    EXORL_TRY(exorl_encoder_forward_prec(a->flat[0][0], c.c_in, c.hw, a->aug_o, c.batch, a->enc_ws_o, feat_pred_dev, c.precision, stream));
+    return exorl_encoder_forward_prec(a->enc_target, c.c_in, c.hw, a->aug_o, c.batch, a->enc_ws_n, feat_target_dev, c.precision, stream);
+}
+
+// BatchNorm2d buffers of RND's normalize_obs: running_mean[c_in], running_var[c_in], num_batches_tracked (as float)
+int exorl_pixel_agent_bn_state(exorl_pixel_agent_t* a, void** ptr_dev, int64_t* n_floats) {
+    EXORL_REQUIRE(a && ptr_dev && n_floats, "pixel_agent_bn_state: null argument");
+    *ptr_dev = a->bn2d; *n_floats = 2 * a->cfg.c_in + 1;
+    return 0;
 }
 
 // encoder_target: init != 0 copies the encoder (deepcopy at construction), else Polyak with rate tau (proto.py:200-201)
@@ -401,16 +490,16 @@ int exorl_pixel_agent_encoder_target_ptr(exorl_pixel_agent_t* a, void** ptr_dev)
 
 // training state that is not a tensor view: Adam step counts (critic/actor/encoder share one, proto_opt's encoder state has its
 // own) and the Philox counters of the noise / augmentation / act() streams — what a pickled agent needs to continue bit-identically
-int exorl_pixel_agent_state(exorl_pixel_agent_t* a, int64_t* steps3, uint64_t* counters3) {
-    EXORL_REQUIRE(a && steps3 && counters3, "pixel_agent_state: null argument");
+int exorl_pixel_agent_state(exorl_pixel_agent_t* a, int64_t* steps3, uint64_t* counters4) {
+    EXORL_REQUIRE(a && steps3 && counters4, "pixel_agent_state: null argument");
     steps3[0] = a->t; steps3[1] = a->t2; steps3[2] = a->t_enc;
-    counters3[0] = a->noise_counter; counters3[1] = a->aug_counter; counters3[2] = a->act_counter;
+    counters4[0] = a->noise_counter; counters4[1] = a->aug_counter; counters4[2] = a->act_counter; counters4[3] = a->rnd_aug_counter;
     return 0;
 }
-int exorl_pixel_agent_set_state(exorl_pixel_agent_t* a, const int64_t* steps3, const uint64_t* counters3) {
-    EXORL_REQUIRE(a && steps3 && counters3 && steps3[0] >= 0 && steps3[1] >= 0 && steps3[2] >= 0, "pixel_agent_set_state: bad arguments");
+int exorl_pixel_agent_set_state(exorl_pixel_agent_t* a, const int64_t* steps3, const uint64_t* counters4) {
+    EXORL_REQUIRE(a && steps3 && counters4 && steps3[0] >= 0 && steps3[1] >= 0 && steps3[2] >= 0, "pixel_agent_set_state: bad arguments");
     a->t = steps3[0]; a->t2 = steps3[1]; a->t_enc = steps3[2];
-    a->noise_counter = counters3[0]; a->aug_counter = counters3[1]; a->act_counter = counters3[2];
+    a->noise_counter = counters4[0]; a->aug_counter = counters4[1]; a->act_counter = counters4[2]; a->rnd_aug_counter = counters4[3];
     a->augmented = false;
     a->have_feat_o = a->have_feat_n = false;
     return 0;

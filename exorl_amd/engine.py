@@ -413,9 +413,9 @@ class PixelEngine:
     # -- pickling support: everything that defines the training state, as CPU data
     def export_state(self):
         torch.cuda.synchronize()
-        steps, ctr = np.zeros(3, np.int64), np.zeros(3, np.uint64)
+        steps, ctr = np.zeros(3, np.int64), np.zeros(4, np.uint64)
         L.check(self.lib.exorl_pixel_agent_state(self.h, steps.ctypes.data, ctr.ctypes.data))
-        st = {'steps': steps, 'counters': ctr, 'tensors': {}}
+        st = {'steps': steps, 'counters': ctr, 'tensors': {}, 'bn2d': self.bn2d().cpu()}
         for net in range(4):
             for what in ((L.T_PARAM,) if net == 3 else (L.T_PARAM, L.T_ADAM_M, L.T_ADAM_V)):
                 st['tensors'][(net, what)] = [self.tensor(net, i, what).cpu() for i in range(self.num_tensors(net))]
@@ -437,6 +437,10 @@ class PixelEngine:
         steps, ctr = np.ascontiguousarray(st['steps'], np.int64), np.ascontiguousarray(st['counters'], np.uint64)
         if steps.size == 2:                 # ABI-6 pickles: encoder_opt stepped with the other optimisers
             steps = np.array([steps[0], steps[1], steps[0]], np.int64)
+        if ctr.size == 3:
+            ctr = np.concatenate([ctr, np.zeros(1, np.uint64)])
+        if 'bn2d' in st:
+            self.bn2d().copy_(st['bn2d'])
         L.check(self.lib.exorl_pixel_agent_set_state(self.h, steps.ctypes.data, ctr.ctypes.data))
         torch.cuda.synchronize()
 
@@ -452,6 +456,20 @@ class PixelEngine:
         mt = self._f(meta) if meta is not None else None
         L.check(self.lib.exorl_pixel_agent_act(self.h, o.data_ptr(), L.ptr(mt), stddev, int(eval_mode), L.ptr(nz), out.data_ptr(), L.current_stream()))
         return out
+
+    def bn2d(self):
+        """RND's BatchNorm2d buffers: running_mean[c], running_var[c], num_batches_tracked (float) as one device view."""
+        p, n = C.c_void_p(), C.c_int64()
+        L.check(self.lib.exorl_pixel_agent_bn_state(self.h, C.byref(p), C.byref(n)))
+        return self._view(p.value, n.value)
+
+    def rnd_features(self, shifts=None, clip_val=5.0):
+        """(predictor-side, target-side) encodings of clamp(BatchNorm2d(aug(obs))) as device pointers (rnd.py:47-53)."""
+        sh = self._i32(shifts)
+        fp, ft = C.c_void_p(), C.c_void_p()
+        L.check(self.lib.exorl_pixel_agent_rnd_features(self.h, L.ptr(sh), clip_val, C.byref(fp), C.byref(ft), L.current_stream()))
+        self._keep_r = sh
+        return fp.value, ft.value
 
     def meta_rows(self):
         """(batch, meta_dim) device view of the skill / task rows the trunks read (filled by the sampler or by the caller)."""

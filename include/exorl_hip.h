@@ -464,14 +464,21 @@ int exorl_pixel_agent_metrics(exorl_pixel_agent_t* a, float* host_out /* EXORL_N
  * set_train_encoder(0)). */
 int exorl_pixel_agent_augment(exorl_pixel_agent_t* a, const int32_t* shifts_obs_dev, const int32_t* shifts_next_dev, void* stream);
 int exorl_pixel_agent_encode(exorl_pixel_agent_t* a, int32_t which, int32_t target, float** feat_out_dev, void* stream);
-int exorl_pixel_agent_encoder_step(exorl_pixel_agent_t* a, int32_t which, float* dfeat_dev, int32_t opt, void* stream);
+int exorl_pixel_agent_encoder_step(exorl_pixel_agent_t* a, int32_t which, float* dfeat_dev, int32_t opt /* 0 encoder_opt, 1 second state, 2 both */, void* stream);
 int exorl_pixel_agent_encoder_target(exorl_pixel_agent_t* a, float tau, int32_t init, void* stream);
+/* RND on pixels (rnd.py:26-27,35-39,47-53): x = clamp(BatchNorm2d(RandomShiftsAug(obs)), +-clip_val), then the agent's encoder on x
+ * (*feat_pred_dev; exorl_pixel_agent_encoder_step(0, dfeat, 2) continues its backward pass and steps the encoder with rnd_opt's state and
+ * then encoder_opt's, rnd.py:86-89) and the frozen encoder copy kept in the encoder_target slot (*feat_target_dev). Every call draws a new
+ * augmentation and updates the BatchNorm running statistics, as RND.forward does. */
+int exorl_pixel_agent_rnd_features(exorl_pixel_agent_t* a, const int32_t* shifts_dev, float clip_val, float** feat_pred_dev, float** feat_target_dev,
+                                   void* stream);
+int exorl_pixel_agent_bn_state(exorl_pixel_agent_t* a, void** ptr_dev, int64_t* n_floats);   /* running_mean[c] running_var[c] num_batches_tracked */
 int exorl_pixel_agent_encoder_target_ptr(exorl_pixel_agent_t* a, void** ptr_dev);
 /* Whole-agent pickling (pretrain.py:293-300): steps3 = {Adam step count of critic_opt/actor_opt, of proto_opt's encoder state, of encoder_opt},
- * counters3 = Philox counters of the update-noise, augmentation and act() streams; encoder_opt2 = proto_opt's Adam moments for the
+ * counters4 = Philox counters of the update-noise, augmentation, act() and RND-augmentation streams; encoder_opt2 = proto_opt's Adam moments for the
  * encoder (n floats each, same layout as the encoder's flat parameters, which encoder_target_ptr also uses). */
-int exorl_pixel_agent_state(exorl_pixel_agent_t* a, int64_t* steps3_out, uint64_t* counters3_out);
-int exorl_pixel_agent_set_state(exorl_pixel_agent_t* a, const int64_t* steps3, const uint64_t* counters3);
+int exorl_pixel_agent_state(exorl_pixel_agent_t* a, int64_t* steps3_out, uint64_t* counters4_out);
+int exorl_pixel_agent_set_state(exorl_pixel_agent_t* a, const int64_t* steps3, const uint64_t* counters4);
 int exorl_pixel_agent_encoder_opt2(exorl_pixel_agent_t* a, void** m_dev, void** v_dev, int64_t* n_floats);
 /* enable == 0: update() treats the encoding as detached in update_critic (what the reward-free agents pass, proto.py:190-193):
  * no encoder backward, encoder_opt does not step. Default 1 (plain DDPG, ddpg.py:316-319). */

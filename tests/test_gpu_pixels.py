@@ -262,6 +262,8 @@ def _pixel_intr_agent(kind, C_, HW, A, F, H, B, S, precision='fp32'):
     if kind == 'aps':
         return agents.APSAgent(update_task_every_step=5, sf_dim=S, knn_rms=True, knn_k=3, knn_avg=True, knn_clip=0.0001, num_init_steps=4096,
                                lstsq_batch_size=4096, update_encoder=True, **kw), 'aps'
+    if kind == 'rnd':
+        return agents.RNDAgent(rnd_rep_dim=16, update_encoder=True, rnd_scale=1.0, **kw), 'rnd'
     if kind == 'smm':
         return agents.SMMAgent(z_dim=S, sp_lr=1e-3, vae_lr=1e-4, vae_beta=0.5, state_ent_coef=1.0, latent_ent_coef=1.0, latent_cond_ent_coef=1.0,
                                update_encoder=True, **kw), 'smm'
@@ -273,7 +275,7 @@ def _frames(step, B, C_, HW):           # tools/gen_golden.py pixel_intr_frames
     return rs.randint(0, 256, (B, C_, HW, HW)).astype(np.uint8), rs.randint(0, 256, (B, C_, HW, HW)).astype(np.uint8)
 
 
-@pytest.mark.parametrize('kind', ['icm', 'icm_apt', 'disagreement', 'diayn', 'aps', 'smm'])
+@pytest.mark.parametrize('kind', ['icm', 'icm_apt', 'disagreement', 'diayn', 'aps', 'smm', 'rnd'])
 def test_pixel_intrinsic_agents_vs_reference(gold, kind):
     """The module agents on pixel observations against 3 update() calls of the reference's own classes (tests/golden/pixel_<kind>.npz,
     tools/gen_golden.py gen_pixel_intr): obs and next_obs are augmented and encoded once, the module and the encoder step on the module's
@@ -286,6 +288,14 @@ def test_pixel_intrinsic_agents_vs_reference(gold, kind):
     views = (('encoder', ag.encoder), ('actor', ag.actor), ('critic', ag.critic), (mod, getattr(ag, mod)))
     for i, (nm, view) in enumerate(views):
         shapes = [(k, tuple(v.shape)) for k, v in view.state_dict().items()]
+        if nm == 'rnd':         # predictor.0 is the agent's encoder (loaded above); Linear layers seed 53, the frozen encoder copy seed 54
+            lin = [(k, sh) for k, sh in shapes if len(sh) <= 2 and not k.startswith('normalize_obs') and '.0.convnet.' not in k]
+            conv = [(k, sh) for k, sh in shapes if k.startswith('target.0.convnet.')]
+            assert [k for k, _ in lin + conv] == [str(k) for k in z['keys/rnd']]
+            params = dict(_synth.synth_params(lin, 53))
+            params.update(_synth.synth_conv_params(conv, 54))
+            view.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=False)
+            continue
         assert [k for k, _ in shapes] == [str(k) for k in z[f'keys/{nm}']], nm
         params = (_synth.synth_conv_params if nm == 'encoder' else _synth.synth_params)(shapes, 50 + i)
         view.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
@@ -316,7 +326,8 @@ def test_pixel_intrinsic_agents_vs_reference(gold, kind):
             else:
                 np.testing.assert_allclose(v.reshape(-1)[::997], z[f'final_sample/{nm}/{k}'], rtol=1e-4, atol=atol, err_msg=f'{kind} {nm}.{k}')
     if 'final/rms' in z.files:
-        M, S_, n = ag.pbe.rms.M, ag.pbe.rms.S, ag.pbe.rms.n
+        r = ag.intrinsic_reward_rms if kind == 'rnd' else ag.pbe.rms
+        M, S_, n = r.M, r.S, r.n
         np.testing.assert_allclose([float(M), float(S_), float(n)], z['final/rms'], rtol=1e-4)
     meta = {'skill': z['batch/0/skill'][0]} if kind in ('diayn', 'aps', 'smm') else {}
     a = ag.act(obs[0], meta, 10**6, True)

@@ -410,7 +410,7 @@ def gen_pixel_proto(ref):
 
 
 # ----------------------------------------------------------------------------- agents (G3/G4)
-PIXEL_INTR = ('icm', 'icm_apt', 'disagreement', 'diayn', 'aps', 'smm')
+PIXEL_INTR = ('icm', 'icm_apt', 'disagreement', 'diayn', 'aps', 'smm', 'rnd')
 
 
 def pixel_intr_frames(step, B, C, HW):
@@ -440,6 +440,8 @@ def gen_pixel_intr(ref, kind):
     elif kind == 'aps':
         agent, mod = ref.aps.APSAgent(update_task_every_step=5, sf_dim=S, knn_rms=True, knn_k=3, knn_avg=True, knn_clip=0.0001, num_init_steps=4096,
                                       lstsq_batch_size=4096, update_encoder=True, **kw), 'aps'
+    elif kind == 'rnd':
+        agent, mod = ref.rnd.RNDAgent(rnd_rep_dim=16, update_encoder=True, rnd_scale=1.0, **kw), 'rnd'
     elif kind == 'smm':
         agent, mod = ref.smm.SMMAgent(z_dim=S, sp_lr=1e-3, vae_lr=1e-4, vae_beta=0.5, state_ent_coef=1.0, latent_ent_coef=1.0, latent_cond_ent_coef=1.0,
                                       update_encoder=True, **kw), 'smm'
@@ -449,6 +451,14 @@ def gen_pixel_intr(ref, kind):
     mods = (('encoder', agent.encoder), ('actor', agent.actor), ('critic', agent.critic), (mod, getattr(agent, mod)))
     for i, (nm, net) in enumerate(mods):
         shapes = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+        if nm == 'rnd':         # predictor.0 IS agent.encoder (already loaded); the Linear layers get seed 53, the frozen encoder copy seed 54
+            lin = [(k, sh) for k, sh in shapes if len(sh) <= 2 and not k.startswith('normalize_obs') and '.0.convnet.' not in k]
+            conv = [(k, sh) for k, sh in shapes if k.startswith('target.0.convnet.')]
+            params = dict(_synth.synth_params(lin, 53))
+            params.update(_synth.synth_conv_params(conv, 54))
+            net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=False)
+            out[f'keys/{nm}'] = np.array([k for k, _ in lin + conv])
+            continue
         params = (_synth.synth_conv_params if nm == 'encoder' else _synth.synth_params)(shapes, 50 + i)
         net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
         out[f'keys/{nm}'] = np.array([k for k, _ in shapes])
@@ -499,6 +509,9 @@ def gen_pixel_intr(ref, kind):
                 out[f'final_sample/{nm}/{k}'] = v.reshape(-1)[::997].copy()
     if hasattr(agent, 'pbe'):
         out['final/rms'] = np.array([float(agent.pbe.rms.M), float(agent.pbe.rms.S), float(agent.pbe.rms.n)])
+    if hasattr(agent, 'intrinsic_reward_rms'):
+        r = agent.intrinsic_reward_rms
+        out['final/rms'] = np.array([float(r.M), float(r.S), float(r.n)])
     np.savez_compressed(GOLD / f'pixel_{kind}.npz', **out)
     print('pixel', kind, keys, out['metrics'][-1])
 
