@@ -334,7 +334,48 @@ def test_pixel_intrinsic_agents_vs_reference(gold, kind):
     assert a.shape == (A,) and np.all(np.abs(a) <= 1.0)
 
 
-@pytest.mark.parametrize('kind', ['ddpg', 'proto'])
+@pytest.mark.parametrize('kind', ['icm', 'disagreement', 'diayn', 'aps', 'rnd'])
+def test_pixel_module_agents_split_bf16_tracks_fp32(kind):
+    """The MFMA path of the module agents on pixels (split-bf16 convolutions, split-K trunks with the meta slab, 39200-wide module Linears) against
+    the same agent in fp32 — which the reference fixtures pin — on identical inputs at feature_dim 50, hidden 256, batch 16: two updates,
+    every metric within 2e-3 relative on the first and 5e-3 on the second (the fp32 path is the one held to the reference's numbers; this guards the operand planes and the
+    extra GEMM problems of the bf16x3 build)."""
+    import _synth
+    C_, HW, A, F, H, B, S = 3, 84, 4, 50, 256, 16, 4
+    res = {}
+    for precision in ('fp32', 'bf16x3'):
+        torch.manual_seed(11)
+        ag, mod = _pixel_intr_agent(kind, C_, HW, A, F, H, B, S, precision=precision)
+        shapes = [(k, tuple(v.shape)) for k, v in ag.encoder.state_dict().items()]
+        ag.encoder.load_state_dict({k: torch.from_numpy(v) for k, v in _synth.synth_conv_params(shapes, 50).items()})
+        if kind == 'rnd':
+            ag.rnd_target_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in _synth.synth_conv_params(shapes, 54).items()})
+        noise, rs = _synth.NoiseStream(21), np.random.RandomState(3)
+        ag.noise_hook = noise.draw
+        ag.shift_hook = lambda n: rs.randint(0, 9, (n, 2)).astype(np.int32)
+        if kind == 'smm':
+            ag.eps_hook = _synth.NoiseStream(33).draw
+        ms = []
+        for i in range(2):
+            b = _synth.synth_batch(61, i, B, 4, A)
+            obs, nobs = _frames(i, B, C_, HW)
+            batch = [obs, b[1], b[2], b[3], nobs]
+            if kind in ('diayn', 'aps'):
+                m = np.random.RandomState(70 + i).standard_normal((B, S)).astype(np.float32)
+                if kind == 'diayn':
+                    m = np.eye(S, dtype=np.float32)[np.argmax(m, 1)]
+                else:
+                    m /= np.linalg.norm(m, axis=1, keepdims=True)
+                batch.append(m)
+            ms.append(ag.update(iter([tuple(batch)]), 2 * i))
+        res[precision] = ms
+    for i in range(2):          # second update: both sides have taken Adam's sign-like first step from gradients that differ at rounding level
+        rt, at = (2e-3, 2e-5) if i == 0 else (5e-3, 1e-4)
+        for k, v in res['fp32'][i].items():
+            assert abs(res['bf16x3'][i][k] - v) <= rt * abs(v) + at, (kind, i, k, res['bf16x3'][i][k], v)
+
+
+@pytest.mark.parametrize('kind', ['ddpg', 'proto', 'rnd', 'diayn', 'aps'])
 def test_pixel_agent_pickle_roundtrip_continues_bit_identically(kind):
     """pretrain.py:293-300 torch.save's the whole agent: the pixel agents carry encoder / actor / critic parameters and Adam moments,
     the step counts, the Philox counters of the noise and augmentation streams, and (Proto) encoder_target, proto_opt's second
@@ -348,15 +389,27 @@ def test_pixel_agent_pickle_roundtrip_continues_bit_identically(kind):
               hidden_dim=H, critic_target_tau=0.01, num_expl_steps=2000, update_every_steps=2, stddev_schedule=0.2, nstep=3, batch_size=B,
               stddev_clip=0.3, init_critic=True, use_tb=True, use_wandb=False)
     torch.manual_seed(5)
+    S = 4
     if kind == 'proto':
         ag = agents.ProtoAgent(pred_dim=16, proj_dim=32, queue_size=32, num_protos=8, tau=0.1, encoder_target_tau=0.05, topk=3, update_encoder=True, **kw)
+    elif kind == 'rnd':                       # + BatchNorm2d buffers, the frozen encoder copy, rnd_opt's Adam state for the encoder, the RMS
+        ag = agents.RNDAgent(rnd_rep_dim=16, update_encoder=True, rnd_scale=1.0, **kw)
+    elif kind == 'diayn':                     # + the skill columns in front of both trunks
+        ag = agents.DIAYNAgent(update_skill_every_step=50, skill_dim=S, diayn_scale=1.0, update_encoder=True, skill_type='uniform', **kw)
+    elif kind == 'aps':                       # + CriticSF heads, the kNN RMS
+        ag = agents.APSAgent(update_task_every_step=5, sf_dim=S, knn_rms=True, knn_k=3, knn_avg=True, knn_clip=0.0001, num_init_steps=4096,
+                             lstsq_batch_size=4096, update_encoder=True, **kw)
     else:
         ag = agents.DDPGAgent(**kw)
 
     def batch(i):
         rs = np.random.RandomState(100 + i)
-        return (rs.randint(0, 256, (B, C_, HW, HW)).astype(np.uint8), rs.uniform(-1, 1, (B, A)).astype(np.float32),
-                rs.uniform(0, 1, (B, 1)).astype(np.float32), np.full((B, 1), 0.97, np.float32), rs.randint(0, 256, (B, C_, HW, HW)).astype(np.uint8))
+        b = (rs.randint(0, 256, (B, C_, HW, HW)).astype(np.uint8), rs.uniform(-1, 1, (B, A)).astype(np.float32),
+             rs.uniform(0, 1, (B, 1)).astype(np.float32), np.full((B, 1), 0.97, np.float32), rs.randint(0, 256, (B, C_, HW, HW)).astype(np.uint8))
+        if kind in ('diayn', 'aps'):
+            m = rs.standard_normal((B, S)).astype(np.float32)
+            b += (m / np.linalg.norm(m, axis=1, keepdims=True),)
+        return b
     for i in range(2):                       # Philox-drawn noise, shifts and categorical draws: their counters are part of the state
         ag.update(iter([batch(i)]), 2 * i)
     buf = io.BytesIO()
@@ -371,6 +424,7 @@ def test_pixel_agent_pickle_roundtrip_continues_bit_identically(kind):
         ms.append(m)
     assert ms[0] == ms[1] == ms[2]
     views = ['encoder', 'actor', 'critic', 'critic_target'] + (['encoder_target', 'predictor', 'predictor_target', 'projector', 'protos'] if kind == 'proto' else [])
+    views += {'rnd': ['rnd'], 'diayn': ['diayn'], 'aps': ['aps']}.get(kind, [])
     for other in (ag2, ag3):
         assert type(other) is type(ag)
         for nm in views:
