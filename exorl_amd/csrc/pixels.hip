@@ -99,13 +99,36 @@ __global__ __launch_bounds__(256) void aug_shift_rows_kernel(const unsigned char
 }
 
 // ---- weight shadows: Wf[ci][tap][co] for the forward pass, Wb[co][tap flipped][ci] for dgrad -----------------------------------
-__global__ void conv_weight_shadow_kernel(const float* __restrict__ W, float* __restrict__ Wf, float* __restrict__ Wb, int ci_n) {
+// ff / fb (32 -> 32 layers in the bf16 modes): the MFMA kernel's B fragments, hi plane then lo plane, lane-linear — k-step s (tap = s >> 1,
+// ci = (s & 1) * 16 + 8 * (lane >> 5) + j), column lane & 31 — so that a convolution workgroup copies 36 KB into LDS with 16-byte loads
+// instead of converting the layer's 9216 weights itself (1024 workgroups per launch did, ~4.5 us each, ahead of their first pass).
+constexpr int CM_FRAG = 18 * 64;           // 16-byte fragments per plane
+__global__ void conv_weight_shadow_kernel(const float* __restrict__ W, float* __restrict__ Wf, float* __restrict__ Wb, int ci_n,
+                                          uint4* __restrict__ ff, uint4* __restrict__ fb) {
     const int total = CONV_CO * ci_n * 9;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int tap = i % 9, ci = (i / 9) % ci_n, co = i / (9 * ci_n);
         const float w = W[i];                                    // torch layout [co][ci][ky][kx]
         Wf[(ci * 9 + tap) * CONV_CO + co] = w;
         if (Wb) Wb[(co * 9 + (8 - tap)) * ci_n + ci] = w;        // dx = full correlation of dy with the flipped kernel
+    }
+    if (!ff || ci_n != CONV_CO) return;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * CM_FRAG; i += gridDim.x * blockDim.x) {
+        const int dir = i / CM_FRAG, r = i % CM_FRAG, st = r >> 6, lane = r & 63, kg = lane >> 5, col = lane & 31, tap = st >> 1;
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int cin = (st & 1) * 16 + 8 * kg + j;
+            // forward: Wt[ci][tap][co] = W[co][ci][tap]; dgrad: the flipped shadow read with the roles of ci and co exchanged
+            const float w = dir == 0 ? W[(col * CONV_CO + cin) * 9 + tap] : W[(cin * CONV_CO + col) * 9 + (8 - tap)];
+            const __bf16 h = (__bf16)w;
+            const __bf16 l = (__bf16)(w - (float)h);
+            const unsigned hb = __builtin_bit_cast(unsigned short, h), lb = __builtin_bit_cast(unsigned short, l);
+            if (j & 1) { hi[j >> 1] |= hb << 16; lo[j >> 1] |= lb << 16; } else { hi[j >> 1] = hb; lo[j >> 1] = lb; }
+        }
+        uint4* dst = dir == 0 ? ff : fb;
+        dst[r] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        dst[CM_FRAG + r] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
     }
 }
 
@@ -193,23 +216,16 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
     unsigned short* xh = reinterpret_cast<unsigned short*>(cm_lds);                       // [rows][ow + 2][CM_PIX] hi plane
     unsigned short* xl = xh + plane_elems;                                                // lo plane (split mode)
     cbf16x8* wh = reinterpret_cast<cbf16x8*>(xl + (X3 ? plane_elems : 0));                // [18 k-steps][64 lanes] B fragments, 16 B each
-    cbf16x8* wl = wh + 18 * 64;
+    cbf16x8* wl = wh + 18 * 64;                                                           // (CM_FRAG, defined with the shadow kernel)
     const int n = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kg = lane >> 5, col = lane & 31;
     const float* inn = in + (int64_t)n * CONV_CO * ih * iw;
-    // weights -> MFMA B fragments in LDS, lane-linear: B[k][co], k-step s: tap = s >> 1, ci = (s & 1) * 16 + 8 * kg + j
-    for (int s = wave; s < 18; s += CM_THREADS / 64) {
-        cbf16x8 fh, fl;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int ci = (s & 1) * 16 + 8 * kg + j;
-            const float w = Wt[(ci * 9 + (s >> 1)) * CONV_CO + col];
-            fh[j] = (__bf16)w;
-            fl[j] = (__bf16)(w - (float)fh[j]);
-        }
-        wh[s * 64 + lane] = fh;
-        if constexpr (X3) wl[s * 64 + lane] = fl;
+    // the layer's MFMA B fragments (conv_weight_shadow_kernel made them, hi plane then lo plane): a straight 16-byte copy into LDS
+    {
+        const uint4* fr = reinterpret_cast<const uint4*>(Wt);
+        uint4* dst = reinterpret_cast<uint4*>(wh);
+        for (int i = tid; i < (X3 ? 2 : 1) * CM_FRAG; i += CM_THREADS) dst[i] = fr[i];
     }
     const int npix = oh * ow, npass = (npix + CM_PASS - 1) / CM_PASS, sw = ow + 2;
     // The input of pass t+1 is fetched into registers while pass t is on the matrix cores; it is converted and written to LDS once
@@ -355,9 +371,9 @@ static int conv3x3_mfma(const float* in, const float* Wt, const float* bias, con
 
 // prec: EXORL_PREC_F32 -> direct fp32 FMA kernel for every layer; bf16 / split-bf16 -> the 32-channel stride-1 layers on MFMA
 static int conv3x3(const float* in, const float* Wt, const float* bias, const float* mask, float* out, int n, int ci_n, int co_n, int ih, int iw,
-                   int oh, int ow, int stride, int pad, int in_scale, int relu, hipStream_t s, int prec = EXORL_PREC_F32) {
-    if (prec != EXORL_PREC_F32 && ci_n == CONV_CO && co_n == CONV_CO && stride == 1 && !in_scale && conv3x3_mfma_fits(oh, ow))
-        return conv3x3_mfma(in, Wt, bias, mask, out, n, ih, iw, oh, ow, pad, relu, prec, s);
+                   int oh, int ow, int stride, int pad, int in_scale, int relu, hipStream_t s, int prec = EXORL_PREC_F32, const float* frag = nullptr) {
+    if (prec != EXORL_PREC_F32 && ci_n == CONV_CO && co_n == CONV_CO && stride == 1 && !in_scale && frag && conv3x3_mfma_fits(oh, ow))
+        return conv3x3_mfma(in, frag, bias, mask, out, n, ih, iw, oh, ow, pad, relu, prec, s);
     const int tin = (CONV_TILE - 1) * stride + 3;
     const size_t lds = (size_t)ci_n * tin * tin * sizeof(float);
     EXORL_REQUIRE(lds <= 160 * 1024 && co_n == CONV_CO, "conv3x3: tile does not fit LDS (ci=%d stride=%d) or co=%d != 32", ci_n, stride, co_n);
@@ -651,11 +667,12 @@ int64_t exorl_encoder_workspace_floats(int32_t n, int32_t c_in, int32_t hw) {
     for (int l = 1; l <= 4; ++l) f += round_up((int64_t)n * CONV_CO * g.edge[l] * g.edge[l], 64);          // activations
     for (int l = 1; l <= 3; ++l) f += round_up((int64_t)n * CONV_CO * g.edge[l] * g.edge[l], 64);          // d(activations) 1..3
     f += 2 * 4 * round_up((int64_t)CONV_CO * CONV_CO * 9, 64);                                             // Wf, Wb per layer
+    f += 2 * 4 * round_up((int64_t)2 * CM_FRAG * 4, 64);                                                   // MFMA fragment planes (hi, lo) per layer and direction
     f += round_up((int64_t)n * CONV_CO * CONV_CO * 9, 64) + round_up((int64_t)n * CONV_CO, 64);           // wgrad partials
     return f;
 }
 
-struct EncWs { float* act[5]; float* dact[4]; float* wf[4]; float* wb[4]; float *P, *Pb; };
+struct EncWs { float* act[5]; float* dact[4]; float* wf[4]; float* wb[4]; float* ff[4]; float* fb[4]; float *P, *Pb; };
 static EncWs enc_carve(const EncGeom& g, int n, float* ws) {
     EncWs w{};
     int64_t off = 0;
@@ -663,6 +680,7 @@ static EncWs enc_carve(const EncGeom& g, int n, float* ws) {
     for (int l = 1; l <= 4; ++l) w.act[l] = take((int64_t)n * CONV_CO * g.edge[l] * g.edge[l]);
     for (int l = 1; l <= 3; ++l) w.dact[l] = take((int64_t)n * CONV_CO * g.edge[l] * g.edge[l]);
     for (int l = 0; l < 4; ++l) { w.wf[l] = take((int64_t)CONV_CO * CONV_CO * 9); w.wb[l] = take((int64_t)CONV_CO * CONV_CO * 9); }
+    for (int l = 0; l < 4; ++l) { w.ff[l] = take((int64_t)2 * CM_FRAG * 4); w.fb[l] = take((int64_t)2 * CM_FRAG * 4); }
     w.P = take((int64_t)n * CONV_CO * CONV_CO * 9);
     w.Pb = take((int64_t)n * CONV_CO);
     return w;
@@ -684,11 +702,12 @@ int exorl_encoder_forward_prec(const float* params_dev, int32_t c_in, int32_t hw
     const float* in = x_dev;
     for (int l = 0; l < 4; ++l) {
         const int ci = l == 0 ? c_in : CONV_CO;
+        const bool frags = l > 0 && prec != EXORL_PREC_F32;
         hipLaunchKernelGGL(conv_weight_shadow_kernel, dim3(cdiv(CONV_CO * ci * 9, 256)), dim3(256), 0, s, params_dev + g.w_off[l], w.wf[l],
-                           l > 0 ? w.wb[l] : nullptr, ci);
+                           l > 0 ? w.wb[l] : nullptr, ci, frags ? reinterpret_cast<uint4*>(w.ff[l]) : nullptr, frags ? reinterpret_cast<uint4*>(w.fb[l]) : nullptr);
         EXORL_LAUNCH_CHECK();
         EXORL_TRY(conv3x3(in, w.wf[l], params_dev + g.b_off[l], nullptr, w.act[l + 1], n, ci, CONV_CO, g.edge[l], g.edge[l], g.edge[l + 1],
-                          g.edge[l + 1], l == 0 ? 2 : 1, 0, l == 0 ? 1 : 0, 1, s, prec));
+                          g.edge[l + 1], l == 0 ? 2 : 1, 0, l == 0 ? 1 : 0, 1, s, prec, frags ? w.ff[l] : nullptr));
         in = w.act[l + 1];
     }
     if (h_out_dev) *h_out_dev = w.act[4];
@@ -733,7 +752,7 @@ int exorl_encoder_backward_prec(const float* params_dev, int32_t c_in, int32_t h
         EXORL_TRY(colsum(w.P, grads_dev + g.w_off[l], n, CONV_CO * ci * 9, 1, 0, 0, s));
         EXORL_TRY(colsum(w.Pb, grads_dev + g.b_off[l], n, CONV_CO, 1, 0, 0, s));
         if (l > 0) {              // d(a_l) = full correlation of d(a_{l+1}) with the flipped kernel, masked by a_l > 0
-            EXORL_TRY(conv3x3(d, w.wb[l], nullptr, w.act[l], w.dact[l], n, CONV_CO, CONV_CO, oh, oh, ih, ih, 1, 2, 0, 0, s, prec));
+            EXORL_TRY(conv3x3(d, w.wb[l], nullptr, w.act[l], w.dact[l], n, CONV_CO, CONV_CO, oh, oh, ih, ih, 1, 2, 0, 0, s, prec, prec != EXORL_PREC_F32 ? w.fb[l] : nullptr));
             d = w.dact[l];
         }
     }

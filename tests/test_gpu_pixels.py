@@ -375,6 +375,39 @@ def test_pixel_module_agents_split_bf16_tracks_fp32(kind):
             assert abs(res['bf16x3'][i][k] - v) <= rt * abs(v) + at, (kind, i, k, res['bf16x3'][i][k], v)
 
 
+def test_pixel_meta_agent_through_the_hbm_sampler_equals_the_tuple_path():
+    """DIAYN on pixels fed by the device-resident sampler (frames, action, reward, discount AND the skill rows gathered straight into the
+    pixel engine's slots) against the same agent fed the same rows as a tuple: identical metrics, bit for bit."""
+    from exorl_amd.engine import ReplayEngine
+    from exorl_amd.replay_buffer import ArenaIterator
+    from exorl_amd import _lib as L
+    C_, HW, A, F, H, B, S = 3, 84, 4, 50, 64, 8, 4
+    eng = ReplayEngine((C_, HW, HW), np.uint8, A, S, 6 * 21 + 8, 8, 'cuda')
+    rs = np.random.RandomState(0)
+    slots = []
+    for e in range(6):
+        rows = 21
+        skill = np.zeros((rows, S), np.float32)
+        skill[:, e % S] = 1.0
+        ep = dict(observation=rs.randint(0, 256, (rows, C_, HW, HW)).astype(np.uint8), action=rs.uniform(-1, 1, (rows, A)).astype(np.float32),
+                  reward=rs.uniform(0, 1, (rows, 1)).astype(np.float32), discount=np.ones((rows, 1), np.float32), skill=skill)
+        slots.append(eng.append_episode(ep, ('skill',)))
+    eng.set_order(slots)
+    eng.seed_philox(3)
+    it = ArenaIterator(eng, B, 3, 0.99, 'philox')
+    ags = []
+    for _ in range(2):
+        torch.manual_seed(9)
+        ags.append(_pixel_intr_agent('diayn', C_, HW, A, F, H, B, S)[0])
+    for i in range(2):
+        m0 = ags[0].update(it, 2 * i)
+        pairs = eng.last_pairs(B)
+        batch = eng.sample(B, 3, 0.99, L.SAMPLER_GIVEN, pairs=pairs)
+        assert batch[5].shape == (B, S) and torch.all(batch[5].sum(1) == 1.0)
+        m1 = ags[1].update(iter([batch]), 2 * i)
+        assert m0 == m1, (i, m0, m1)
+
+
 @pytest.mark.parametrize('kind', ['ddpg', 'proto', 'rnd', 'diayn', 'aps'])
 def test_pixel_agent_pickle_roundtrip_continues_bit_identically(kind):
     """pretrain.py:293-300 torch.save's the whole agent: the pixel agents carry encoder / actor / critic parameters and Adam moments,
