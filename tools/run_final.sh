@@ -33,5 +33,6 @@ for a in "cql 78 12 1024" "td3 17 6 512" "td3 17 6 4096" "crr 24 6 1024" "bc 24 
 cat gpurun_out/${T}_offline.txt
 python tools/micro/unsup_bench.py --precision fp32,bf16x3 2>&1 | grep -v amdgpu.ids > gpurun_out/${T}_unsup.txt
 cat gpurun_out/${T}_unsup.txt
-for a in "proto fp32" "proto bf16x3" "ddpg fp32" "ddpg bf16x3"; do set -- $a; python tools/micro/pixel_bench.py 1024 $1 $2 2>&1 | grep -v amdgpu.ids >> gpurun_out/${T}_pixels.txt; done
-cat gpurun_out/${T}_pixels.txt
+bash tools/run_pixel_agents.sh ${T}
+bash tools/prof_pixels.sh proto bf16x3 > gpurun_out/${T}_pixel_prof.log 2>&1
+cp gpurun_out/pixel_proto_kernel_summary.txt gpurun_out/${T}_kernel_summary_proto_pixels_bf16x3.txt
