@@ -155,6 +155,8 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--graph', type=int, default=int(os.environ.get('EXORL_GRAPH', '1')))
     ap.add_argument('--branches', type=int, default=int(os.environ.get('EXORL_BRANCHES', '0')))
+    ap.add_argument('--dp1', action='store_true', help='N=1 only: attach a 1-rank RCCL communicator, i.e. time the library-driven data-parallel step '
+                    '(finalised gradients -> ncclAllReduce -> unfused Adam) on one GPU; a diagnostic, not the metric')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'RANK' not in os.environ:
@@ -193,7 +195,16 @@ def main():
             ag.params_changed()
         rit = ArenaIterator(replay, B, 1, GAMMA, 'philox')
         ag.engine.set_parallel_branches(args.branches)
-        return ag, rit, bool(args.graph) and world == 1 and ag.enable_graph(rit)
+        if args.dp1 and world == 1:
+            from exorl_amd.comm import Comm
+            ag.engine.set_comm(Comm(0, 1, Comm.unique_id()))
+        use = False
+        if args.graph:
+            try:
+                use = ag.enable_graph(rit)      # N > 1: only with the library's own communicator (its all-reduces are captured with the step)
+            except Exception as e:              # e.g. a runtime that cannot capture collectives: step eagerly
+                print(f'[bench] rank {rank}: hipGraph capture unavailable ({e}); stepping eagerly', file=sys.stderr, flush=True)
+        return ag, rit, use
 
     agent, it, use_graph = build(args.precision)
 

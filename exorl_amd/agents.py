@@ -239,9 +239,12 @@ class _AgentBase:
     # -- hipGraph fast path: sampler + whole update captured once, replayed with one launch per step
     def enable_graph(self, replay_iter, step=0):
         """Binds `replay_iter` (an ArenaIterator with the Philox sampler) and captures sample+update.
-        Returns False (and stays eager) when the iterator cannot be captured or under data parallelism."""
+        Returns False (and stays eager) when the iterator cannot be captured. A data-parallel step is captured too when its all-reduces
+        are the library's own (RCCL, `engine.comm`): they are enqueued on the capture stream between the phases like any kernel."""
         eng = getattr(replay_iter, 'engine', None)
-        if self.world_size != 1 or eng is None or getattr(replay_iter, 'sampler', None) != L.SAMPLER_PHILOX:
+        if eng is None or getattr(replay_iter, 'sampler', None) != L.SAMPLER_PHILOX:
+            return False
+        if self.world_size != 1 and self.engine.comm is None:       # collectives in Python between the phases: nothing to capture
             return False
         self._graph_stddev = self._stddev(step)
         self.engine.enable_graph(eng, replay_iter.nstep, replay_iter.discount, self._graph_stddev)

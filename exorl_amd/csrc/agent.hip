@@ -940,26 +940,34 @@ int exorl_agent_update_phase(exorl_agent_t* a, int32_t phase, float stddev, cons
     return 2;
 }
 
+// The four phases of one update with the data-parallel exchanges between them (a->comm != nullptr); shared by the eager whole-step call
+// and by the graph capture.
+// one GPU: nothing is exchanged between the phases, the optimiser launches reduce the gradient partials themselves.
+// data parallel: gradients are finalised into the flat buffers, sum-all-reduced over RCCL on this stream, then stepped.
+static int whole_step_body(exorl_agent* a, float stddev, const float* noise_c, const float* noise_a, hipStream_t s) {
+    const bool dp = a->comm != nullptr;
+    const int kind = a->cfg.kind;
+    int rc = exorl_agent_update_phase(a, 0, stddev, noise_c, noise_a, s);
+    if (rc == 0 && dp && a->has_critic) rc = comm_allreduce_sum(a->comm, a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD], a->critic.total, s);
+    if (rc == 0) rc = exorl_agent_update_phase(a, 1, stddev, noise_c, noise_a, s);
+    // TD3+BC's sum |Q| (lambda) / CQL's sum log pi (entropy temperature); the fused scalar-head path moves it inside phase 2
+    if (rc == 0 && dp && ((kind == EXORL_AGENT_TD3_BC && !qfuse(a)) || kind == EXORL_AGENT_CQL)) rc = comm_allreduce_sum(a->comm, a->stats, 4, s);
+    if (rc == 0) rc = exorl_agent_update_phase(a, 2, stddev, noise_c, noise_a, s);
+    if (rc == 0 && dp) rc = comm_allreduce_sum(a->comm, a->flat[EXORL_NET_ACTOR][EXORL_T_GRAD], a->actor.total, s);
+    if (rc == 0) rc = exorl_agent_update_phase(a, 3, stddev, noise_c, noise_a, s);
+    return rc;
+}
+
 int exorl_agent_update(exorl_agent_t* a, float stddev, const float* noise_c, const float* noise_a, void* stream) {
     EXORL_REQUIRE(a, "agent_update: null handle");
     const bool dp = a->comm != nullptr;
     EXORL_REQUIRE(a->cfg.world_size == 1 || dp, "agent_update: world_size=%d needs a communicator (exorl_agent_set_comm), or drive "
                   "exorl_agent_update_phase and all-reduce between the phases yourself", a->cfg.world_size);
     hipStream_t s = as_stream(stream);
-    // one GPU: nothing is exchanged between the phases, the optimiser launches reduce the gradient partials themselves.
-    // data parallel: gradients are finalised into the flat buffers, sum-all-reduced over RCCL on this stream, then stepped.
     a->whole_step = true;
     a->fuse_opt = !dp && !a->fk.on;
     if (a->fuse_opt && opt_overlap_enabled()) { EXORL_TRY(ensure_opt_fork(a)); a->fo.on = true; }
-    const int kind = a->cfg.kind;
-    int rc = exorl_agent_update_phase(a, 0, stddev, noise_c, noise_a, stream);
-    if (rc == 0 && dp && a->has_critic) rc = comm_allreduce_sum(a->comm, a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD], a->critic.total, s);
-    if (rc == 0) rc = exorl_agent_update_phase(a, 1, stddev, noise_c, noise_a, stream);
-    // TD3+BC's sum |Q| (lambda) / CQL's sum log pi (entropy temperature); the fused scalar-head path moves it inside phase 2
-    if (rc == 0 && dp && ((kind == EXORL_AGENT_TD3_BC && !qfuse(a)) || kind == EXORL_AGENT_CQL)) rc = comm_allreduce_sum(a->comm, a->stats, 4, s);
-    if (rc == 0) rc = exorl_agent_update_phase(a, 2, stddev, noise_c, noise_a, stream);
-    if (rc == 0 && dp) rc = comm_allreduce_sum(a->comm, a->flat[EXORL_NET_ACTOR][EXORL_T_GRAD], a->actor.total, s);
-    if (rc == 0) rc = exorl_agent_update_phase(a, 3, stddev, noise_c, noise_a, stream);
+    const int rc = whole_step_body(a, stddev, noise_c, noise_a, s);
     a->fuse_opt = false;
     a->whole_step = false;
     a->fo.on = false;
@@ -1042,7 +1050,8 @@ int exorl_agent_enable_graph(exorl_agent_t* a, exorl_replay_t* r, int32_t nstep,
     // a previous step (eager or a graph launch) may still be running on the caller's stream and reads the buffers the new graph is
     // built over; releasing a graph exec that is executing is not allowed either. Setup call: a full stream sync is fine here.
     EXORL_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
-    EXORL_REQUIRE(a->cfg.world_size == 1 && !a->comm, "agent_enable_graph: data-parallel steps are enqueued eagerly (exorl_agent_update with a communicator)");
+    EXORL_REQUIRE(a->cfg.world_size == 1 || a->comm, "agent_enable_graph: a data-parallel step needs the library's communicator (exorl_agent_set_comm) to be captured; "
+                  "steps whose collectives run in the caller's code are enqueued eagerly");
     EXORL_REQUIRE(stddev > 0.f && nstep >= 1, "agent_enable_graph: bad stddev/nstep");
     EXORL_TRY(release_graph(a));
     if (!a->capture_stream) EXORL_CHECK_HIP(hipStreamCreateWithFlags(&a->capture_stream, hipStreamNonBlocking));
@@ -1071,10 +1080,10 @@ int exorl_agent_enable_graph(exorl_agent_t* a, exorl_replay_t* r, int32_t nstep,
     a->staged_by_sampler = replay_obs_bytes(r) == a->cfg.obs_dim * 4;
     int rc = replay_sample_impl(r, a->cfg.batch, nstep, gamma, EXORL_SAMPLER_PHILOX, nullptr, &slots, nullptr, a->capture_stream,
                                 &a->state->replay_counter, a->staged_by_sampler ? &stage : nullptr);
-    a->fuse_opt = !a->fk.on;
+    a->fuse_opt = !a->comm && !a->fk.on;
     a->fo.on = a->fuse_opt && opt_overlap_enabled();
     a->whole_step = true;
-    for (int p = 0; p < 4 && rc == 0; ++p) rc = exorl_agent_update_phase(a, p, stddev, nullptr, nullptr, a->capture_stream);
+    if (rc == 0) rc = whole_step_body(a, stddev, nullptr, nullptr, a->capture_stream);      // RCCL's all-reduces are captured with the kernels around them
     a->fuse_opt = false;
     a->fo.on = false;
     a->w1_early[0] = a->w1_early[1] = false;

@@ -121,3 +121,41 @@ def test_native_comm_single_rank_runs_the_dp_step(kind, precision):
         assert float((d > tol).float().mean()) <= 5e-3 and float(d.max()) <= 6.5e-4, (net, float(d.max()))
     native.set_comm(None)
     native_fast.set_comm(None)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_dp_step_with_the_library_communicator_is_capturable(precision):
+    """The data-parallel step as ONE hipGraph: device Philox sampler, finalised gradients, RCCL all-reduces (a 1-rank communicator on the
+    box's one GPU; captured on the step's stream and its side stream), unfused Adam — replayed four times and compared bit for bit with
+    the same agent stepping eagerly over an identically seeded replay engine."""
+    import _synth
+    from exorl_amd import agents
+    from exorl_amd.comm import Comm
+    from exorl_amd.engine import ReplayEngine
+    from exorl_amd.replay_buffer import ArenaIterator
+    O, A, H, B, E, T = 24, 6, 256, 64, 12, 30
+    comm = Comm(0, 1, Comm.unique_id())
+
+    def side():
+        eng = ReplayEngine((O,), np.float32, A, 0, E * (T + 1) + 8, E + 4, 'cuda')
+        slots = []
+        for e in range(E):
+            ep = _synth.synth_episodes(40 + e, [T], O, A)[0]
+            slots.append(eng.append_episode(ep))
+        eng.set_order(slots)
+        eng.seed_philox(7)
+        torch.manual_seed(3)
+        ag = agents.TD3BCAgent('td3_bc', (O,), (A,), 'cuda', 1e-4, H, 0.01, '0.2', 1, B, 0.3, False, 2.5, precision=precision, seed=5)
+        ag.engine.set_comm(comm)
+        return ag, ArenaIterator(eng, B, 1, 0.99, 'philox')
+    (g, git), (e, eit) = side(), side()
+    assert g.enable_graph(git) and g.engine.graph_captures == 1
+    for step in range(4):
+        assert g.update(git, step) == {} and e.update(eit, step) == {}
+    for net in ('actor', 'critic', 'critic_target'):
+        for (k, p), q in zip(getattr(g, net).state_dict().items(), getattr(e, net).state_dict().values()):
+            assert torch.equal(p, q), (net, k)
+    assert g.engine.opt_steps() == e.engine.opt_steps() == (4, 4)
+    g.disable_graph()
+    g.engine.set_comm(None)
+    e.engine.set_comm(None)
