@@ -9,6 +9,8 @@
 // The ReLU mask of layer l is applied where d(a_l) is produced (dgrad epilogue), so no separate masking pass touches the maps.
 // In the bf16 / split-bf16 precision modes the three 32 -> 32 stride-1 layers run as MFMA implicit GEMMs instead (conv3x3_mfma_kernel,
 // conv_wgrad_mfma_kernel below); the fp32 kernels stay for precision fp32 and for the first layer.
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace exorl {
@@ -207,7 +209,7 @@ constexpr int CM_IPT = 15;                 // staged (channel pair, y, x) items 
 
 // A pass covers 256 consecutive output pixels in row-major order of the map (not a square tile: a 39-wide map would pay for 48 x 48),
 // so the staged input is a strip of full-width rows: [rows][ow + 2][CM_PIX] with the tap offsets applied inside it.
-template <bool X3>
+template <bool X3, bool MASK>
 __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* __restrict__ in, const float* __restrict__ Wt,
                                                                   const float* __restrict__ bias, const float* __restrict__ mask,
                                                                   float* __restrict__ out, int ih, int iw, int oh, int ow, int pad, int relu,
@@ -264,7 +266,13 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
         }
     };
     fetch(0);
-    for (int pass = 0; pass < npass; ++pass) {
+    const float bv = bias ? bias[col] : 0.f;
+    // One pass. FULL (every pass but the last): all four pixel quads of a lane lie inside the map and there is a next strip to fetch, so the
+    // body has NO run-time branch around a memory instruction — which is what lets the compiler count: the wait in front of the next pass's
+    // conversion becomes vmcnt(<this pass's stores>) instead of vmcnt(0), i.e. the stores of pass t drain under pass t + 1 instead of in
+    // front of it (gfx9 counts stores in vmcnt too; with the guarded tail path in the loop every pass waited for its predecessor's stores).
+    auto body = [&](int pass, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
         int y0, rows;
         strip(pass, y0, rows);
         const int nj = rows * sw, p0 = pass * CM_PASS;
@@ -283,19 +291,19 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
             }
         }
         __syncthreads();
-        if (pass + 1 < npass) fetch(pass + 1);
+        if constexpr (FULL) fetch(pass + 1);
         // C layout of the 32x32 MFMA: reg r of lane l = pixel (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the wave's 32, channel l & 31 — four
         // consecutive pixels of one channel per register quad, i.e. 16 contiguous bytes of the NCHW map: the lane stores them itself
         // (and fetches the dgrad mask the same way, now, behind the MFMA work); no output staging, no second barrier.
         const int pq = p0 + 32 * wave + 4 * kg;                                 // + 8 q + (0..3), q = r >> 2
         float* orow = out + ((int64_t)n * CONV_CO + col) * npix;
         float4 mq[4];
-        if (mask) {
+        if constexpr (MASK) {
             const float* mrow = mask + ((int64_t)n * CONV_CO + col) * npix;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int pp = pq + 8 * q;
-                if (pp + 3 < npix) mq[q] = *reinterpret_cast<const float4*>(mrow + pp);        // 4-byte aligned vector load
+                if (FULL || pp + 3 < npix) mq[q] = *reinterpret_cast<const float4*>(mrow + pp);        // 4-byte aligned vector load
                 else {
                     mq[q].x = pp < npix ? mrow[pp] : 1.f; mq[q].y = pp + 1 < npix ? mrow[pp + 1] : 1.f;
                     mq[q].z = pp + 2 < npix ? mrow[pp + 2] : 1.f; mq[q].w = 1.f;
@@ -322,7 +330,6 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
                 accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, accx, 0, 0, 0);
             }
         }
-        const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float v[4];
@@ -331,18 +338,20 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
                 v[e] = (X3 ? accx[4 * q + e] + acc[4 * q + e] : acc[4 * q + e]) + bv;
                 if (relu) v[e] = fmaxf(v[e], 0.f);
             }
-            if (mask) {
+            if constexpr (MASK) {
                 v[0] = mq[q].x > 0.f ? v[0] : 0.f; v[1] = mq[q].y > 0.f ? v[1] : 0.f;
                 v[2] = mq[q].z > 0.f ? v[2] : 0.f; v[3] = mq[q].w > 0.f ? v[3] : 0.f;
             }
             const int pp = pq + 8 * q;
-            if (pp + 3 < npix) *reinterpret_cast<float4*>(orow + pp) = make_float4(v[0], v[1], v[2], v[3]);
+            if (FULL || pp + 3 < npix) *reinterpret_cast<float4*>(orow + pp) = make_float4(v[0], v[1], v[2], v[3]);
             else
                 for (int e = 0; e < 4; ++e)
                     if (pp + e < npix) orow[pp + e] = v[e];
         }
         __syncthreads();                   // every wave is past its MFMA reads before the next pass rewrites the input planes
-    }
+    };
+    for (int pass = 0; pass + 1 < npass; ++pass) body(pass, std::true_type{});
+    body(npass - 1, std::false_type{});
 }
 
 // true when the strip of a 256-pixel pass fits the kernel's fixed budgets
@@ -359,12 +368,16 @@ static int conv3x3_mfma(const float* in, const float* Wt, const float* bias, con
     EXORL_REQUIRE(lds <= 160 * 1024, "conv3x3_mfma: strip of %d rows x %d columns does not fit LDS", rows, ow + 2);
     static bool attr = false;
     if (!attr) {
-        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    if (x3) hipLaunchKernelGGL(conv3x3_mfma_kernel<true>, dim3(n), dim3(CM_THREADS), lds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu, plane);
-    else    hipLaunchKernelGGL(conv3x3_mfma_kernel<false>, dim3(n), dim3(CM_THREADS), lds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu, plane);
+#define EXORL_CM(XX, MM) hipLaunchKernelGGL((conv3x3_mfma_kernel<XX, MM>), dim3(n), dim3(CM_THREADS), lds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu, plane)
+    if (x3) { if (mask) EXORL_CM(true, true); else EXORL_CM(true, false); }
+    else    { if (mask) EXORL_CM(false, true); else EXORL_CM(false, false); }
+#undef EXORL_CM
     EXORL_LAUNCH_CHECK();
     return 0;
 }
@@ -495,6 +508,8 @@ __global__ __launch_bounds__(WM_THREADS) void conv_wgrad_mfma_kernel(const float
         __syncthreads();
         // dY tile: (co, y, x pair); X tile, three copies: copy dx holds columns tx0 + dx .. tx0 + dx + 15 of rows ty0 .. ty0 + 17:
         // (dx, ci, yy, x pair). Loads are issued in batches before any value is converted and stored, so that their latencies overlap.
+        // (Tried: fetching dY and half of X for the NEXT tile ahead of this tile's MFMA loop and the rest in two batches: 256 VGPRs instead of
+        // 176, and 609 us per launch instead of 430 — not kept.)
         constexpr int DY_ITEMS = CONV_CO * CONV_TILE * (CONV_TILE / 2), DY_PT = DY_ITEMS / WM_THREADS;                              // 4096, 8
         constexpr int X_ITEMS = 3 * CONV_CO * CM_TIN * (CONV_TILE / 2), X_PT = X_ITEMS / WM_THREADS;                                // 13824, 27
         static_assert(DY_ITEMS % WM_THREADS == 0 && X_ITEMS % WM_THREADS == 0 && X_PT % 3 == 0, "staging items divide evenly");
