@@ -936,7 +936,10 @@ __device__ __forceinline__ void g16p_lds_fence(G16pFrag& f) {
 // KS = k per stage (32: 64-byte row-image rows = half cache lines, four stages fit the 128 x 128 split-bf16 tile; 64: whole lines, the
 // 64-wide images and swizzle of the gemm16g kernels above), NSTG = ring depth. A stage's slot is refilled with the stage NSTG ahead as soon
 // as its last fragments have been read, i.e. behind the barrier that opens the stage's last k16.
-template <bool AT, bool BT, bool X3, int TN, int KS, int NSTG>
+// MS = MFMA shape: 32 -> v_mfma_f32_32x32x16_bf16 (a region = one k16), 16 -> v_mfma_f32_16x16x32_bf16 (a region = one k32; row images on
+// 64-wide stages only). Same wave tile, same LDS images, same fragment bytes and MFMA cycles per region pair; the chip holds a higher clock
+// on the 16 x 16 shape under a dense bf16 load (MI355X_MICROARCH.md, DVFS give-back (7)), so the faster one is picked by wall time.
+template <bool AT, bool BT, bool X3, int TN, int KS, int NSTG, int MS = 32>
 __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned char* smem, int pidx, int m0, int n0) {
     constexpr int NBA = 2, NBB = TN / 64, NPL = X3 ? 2 : 1;
     constexpr int BLK = 64 * 2 * KS;                        // one 64-row block of one plane and stage (either image kind)
@@ -944,11 +947,15 @@ __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned cha
     constexpr int STAGE = NPL * PLANE;                      // hi plane, then lo plane
     constexpr int PPW = KS / 32;                            // 1-KB DMA pieces per wave and block
     constexpr int NP = (NBA + NBB) * NPL * PPW;             // DMA pieces per wave and stage
-    constexpr int NQ = KS / 16;                             // k16 regions per stage
-    constexpr int SB = TN / 64;                             // 32-column sub-tiles of a wave along N (wave tile 64 x TN/2)
-    constexpr int NPAIR = 2 * SB;                           // 32 x 32 accumulators of a wave
-    constexpr int NM = NPAIR * (X3 ? 3 : 1);                // MFMAs per k16
-    constexpr int NF = (2 + SB) * NPL;                      // fragments per k16
+    constexpr int NQ = MS == 16 ? KS / 32 : KS / 16;        // regions (k16 / k32) per stage
+    constexpr int SA = 64 / MS;                             // MS-row sub-tiles of a wave along M (wave tile 64 x TN/2)
+    constexpr int SB = TN / (2 * MS);                       // MS-column sub-tiles of a wave along N
+    constexpr int NPAIR = SA * SB;                          // MS x MS accumulators of a wave
+    constexpr int NM = NPAIR * (X3 ? 3 : 1);                // MFMAs per region
+    constexpr int NF = (SA + SB) * NPL;                     // fragments per region
+    constexpr int SMIN = SA < SB ? SA : SB;
+    static_assert(MS == 32 || (MS == 16 && !AT && !BT && KS == 64), "16 x 16 x 32 fragments are built for row images on 64-wide stages");
+    typedef float acc_t __attribute__((ext_vector_type(MS == 16 ? 4 : 16)));
     constexpr int FPG = (NF + NM - 2) / (NM - 1);           // fragments read per MFMA gap: all of them behind the first NM-1 MFMAs
     static_assert(NQ % 2 == 0 && NP * (NSTG - 1) <= 63 && NSTG >= 2, "stage geometry");
     const Gemm16Problem& P = gb.p[pidx];
@@ -959,11 +966,11 @@ __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned cha
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5;
 
-    f32x16 acc[NPAIR], accx[X3 ? NPAIR : 1];                // [ua * SB + ub]; accx: the two cross terms hi*lo + lo*hi
+    acc_t acc[NPAIR], accx[X3 ? NPAIR : 1];                 // [ua * SB + ub]; accx: the two cross terms hi*lo + lo*hi
 #pragma unroll
     for (int a = 0; a < NPAIR; ++a)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { acc[a][i] = 0.f; if constexpr (X3) accx[a][i] = 0.f; }
+        for (int i = 0; i < (MS == 16 ? 4 : 16); ++i) { acc[a][i] = 0.f; if constexpr (X3) accx[a][i] = 0.f; }
 
     // row image: 2*KS-byte rows, 16-byte units swizzled so that the 16 lanes of a ds_read_b128 group hit 16 distinct bank quads
     auto row_off = [](int row, int unit) {
@@ -1003,16 +1010,19 @@ __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned cha
         const int c = rbase + 16 * (g & 1) + 4 * pp;
         return (8 * (g >> 1) + qq) * ROWB + (((c >> 3) ^ (4 * ((qq >> 1) & 1))) << 4) + ((c & 7) << 1);
     };
-    int aoff[2][NQ], boff[SB][NQ];                  // [sub-tile][q]
+    int aoff[SA][NQ], boff[SB][NQ];                 // [sub-tile][q]
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
-            aoff[u][q] = wm * BLK + (AT ? tr_off(u * 32) + q * 16 * ROWB : row_off(u * 32 + (lane & 31), 2 * q + h));
+        for (int u = 0; u < SA; ++u) {
+            if constexpr (MS == 16) aoff[u][q] = wm * BLK + row_off(u * 16 + (lane & 15), 4 * q + (lane >> 4));    // lane: row l & 15, k = 8 (l >> 4) ..+7
+            else aoff[u][q] = wm * BLK + (AT ? tr_off(u * 32) + q * 16 * ROWB : row_off(u * 32 + (lane & 31), 2 * q + h));
+        }
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
-            const int blk = TN == 128 ? wn : 0, r0 = TN == 128 ? u * 32 : wn * 32;
-            boff[u][q] = (NBA + blk) * BLK + (BT ? tr_off(r0) + q * 16 * ROWB : row_off(r0 + (lane & 31), 2 * q + h));
+            const int blk = TN == 128 ? wn : 0, r0 = TN == 128 ? u * MS : wn * 32 + (MS == 16 ? u * 16 : 0);
+            if constexpr (MS == 16) boff[u][q] = (NBA + blk) * BLK + row_off(r0 + (lane & 15), 4 * q + (lane >> 4));
+            else boff[u][q] = (NBA + blk) * BLK + (BT ? tr_off(r0) + q * 16 * ROWB : row_off(r0 + (lane & 31), 2 * q + h));
         }
     }
 
@@ -1032,13 +1042,13 @@ __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned cha
         f.lo = g16p_read_tr<PL>(a);
         f.hi = g16p_read_tr<PL + 4 * ROWB>(a);
     };
-    struct Frags { G16pFrag ah[2], bh[SB], al[X3 ? 2 : 1], bl[X3 ? SB : 1]; };
-    // fragment J of a k16, in the order the MFMAs want them: per plane A0 B0 A1 [B1]
+    struct Frags { G16pFrag ah[SA], bh[SB], al[X3 ? SA : 1], bl[X3 ? SB : 1]; };
+    // fragment J of a region, in the order the MFMAs want them: per plane A0 B0 A1 B1 ... interleaved, then the rest of the longer list
     auto read_one = [&](Frags& f, int st, auto qc, auto jc) {
         constexpr int J = decltype(jc)::value, q = decltype(qc)::value;
-        constexpr int pl = X3 ? J % 2 : 0, k = X3 ? J / 2 : J;           // k: 0 = A0, 1 = B0, 2 = A1, 3 = B1
-        constexpr bool isA = k == 0 || k == 2;
-        constexpr int u = k / 2;
+        constexpr int pl = X3 ? J % 2 : 0, k = X3 ? J / 2 : J;           // k: 0 = A0, 1 = B0, 2 = A1, 3 = B1, ...
+        constexpr bool isA = k < 2 * SMIN ? k % 2 == 0 : SA > SB;
+        constexpr int u = k < 2 * SMIN ? k / 2 : k - SMIN;
         if constexpr (isA) {
             if constexpr (pl == 0) frag(f.ah[u], std::integral_constant<int, 0>{}, AT, st, aoff[u][q]);
             else frag(f.al[u], std::integral_constant<int, 1>{}, AT, st, aoff[u][q]);
@@ -1047,11 +1057,10 @@ __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned cha
             else frag(f.bl[u], std::integral_constant<int, 1>{}, BT, st, boff[u][q]);
         }
     };
-    static_assert(SB == 2 || NF == 3 * NPL, "fragment list");
     auto fence = [&](Frags& f) {               // the asm-issued transposed reads of f have landed (see g16p_read_tr)
         if constexpr (AT) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) { g16p_lds_fence(f.ah[u]); if constexpr (X3) g16p_lds_fence(f.al[u]); }
+            for (int u = 0; u < SA; ++u) { g16p_lds_fence(f.ah[u]); if constexpr (X3) g16p_lds_fence(f.al[u]); }
         }
         if constexpr (BT) {
 #pragma unroll
@@ -1063,9 +1072,15 @@ __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned cha
     auto mfma_one = [&](const Frags& f, auto ic) {
         constexpr int I = decltype(ic)::value;
         constexpr int pair = X3 ? I / 3 : I, term = X3 ? I % 3 : 0, ua = pair / SB, ub = pair % SB;
+        if constexpr (MS == 16) {       // D[n][m]: lane = output row (lane & 15), registers 0..3 = columns 4 (lane >> 4) ..+3
+            if constexpr (term == 0) acc[pair] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.bh[ub].v, f.ah[ua].v, acc[pair], 0, 0, 0);
+            else if constexpr (term == 1) accx[pair] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.bl[ub].v, f.ah[ua].v, accx[pair], 0, 0, 0);
+            else accx[pair] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.bh[ub].v, f.al[ua].v, accx[pair], 0, 0, 0);
+        } else {
         if constexpr (term == 0) acc[pair] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.bh[ub].v, f.ah[ua].v, acc[pair], 0, 0, 0);
         else if constexpr (term == 1) accx[pair] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.bl[ub].v, f.ah[ua].v, accx[pair], 0, 0, 0);
         else accx[pair] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.bh[ub].v, f.al[ua].v, accx[pair], 0, 0, 0);
+        }
     };
     // One scheduling region = the NM MFMAs of a k16 on `cur`, with the reads of the NEXT k16's fragments (stage slot nst_, region NQn) into
     // `nxt` (FPG per MFMA gap) and, when NFILL > 0, the DMA issues of stage slot `fst` written out between them; sched_barrier(0)
@@ -1133,6 +1148,26 @@ __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned cha
     group(T{});
 
     const bool relu = gb.relu != 0;
+    if constexpr (MS == 16) {
+#pragma unroll
+        for (int ta = 0; ta < SA; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < SB; ++tb) {
+                const int nb = n0 + wn * (TN / 2) + tb * 16 + 4 * (lane >> 4);
+                float4* dst = reinterpret_cast<float4*>(P.C + (int64_t)(m0 + wm * 64 + ta * 16 + (lane & 15)) * P.ldc + nb);
+                const float4 bias = P.bias ? *reinterpret_cast<const float4*>(P.bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const acc_t& a0 = acc[ta * SB + tb];
+                const acc_t& ax = accx[X3 ? ta * SB + tb : 0];
+                float4 v;
+                v.x = (X3 ? ax[0] + a0[0] : a0[0]) + bias.x;
+                v.y = (X3 ? ax[1] + a0[1] : a0[1]) + bias.y;
+                v.z = (X3 ? ax[2] + a0[2] : a0[2]) + bias.z;
+                v.w = (X3 ? ax[3] + a0[3] : a0[3]) + bias.w;
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (gb.accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                *dst = v;
+            }
+    } else {
 #pragma unroll
     for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
@@ -1140,8 +1175,8 @@ __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned cha
             // lane: output row m0 + .. + (lane & 31); registers 4g..4g+3: columns nb + 8g + 4h .. +3
             const int nb = n0 + wn * (TN / 2) + tb * 32 + 4 * h;
             float* crow = P.C + (int64_t)(m0 + wm * 64 + ta * 32 + (lane & 31)) * P.ldc + nb;
-            const f32x16& a0 = acc[ta * SB + tb];
-            const f32x16& ax = accx[X3 ? ta * SB + tb : 0];
+            const acc_t& a0 = acc[ta * SB + tb];
+            const acc_t& ax = accx[X3 ? ta * SB + tb : 0];
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 float4* dst = reinterpret_cast<float4*>(crow + 8 * g4);
@@ -1156,6 +1191,7 @@ __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned cha
                 *dst = v;
             }
         }
+    }
 }
 
 // workgroup id -> (problem, tile origin): XCD-local blocks when the launcher found the problems uniform, id order otherwise
@@ -1176,12 +1212,12 @@ __device__ __forceinline__ bool g16p_tile(const Gemm16Batch& gb, int& pidx, int&
     return true;
 }
 
-template <bool AT, bool BT, bool X3, int TN, int KS = 32, int NSTG = 4>
+template <bool AT, bool BT, bool X3, int TN, int KS = 32, int NSTG = 4, int MS = 32>
 __global__ __launch_bounds__(256) void gemm16p_kernel(const Gemm16Batch gb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_p[];
     int pidx, m0, n0;
     if (!g16p_tile<TN>(gb, pidx, m0, n0)) return;
-    gemm16p_body<AT, BT, X3, TN, KS, NSTG>(gb, smem_p, pidx, m0, n0);
+    gemm16p_body<AT, BT, X3, TN, KS, NSTG, MS>(gb, smem_p, pidx, m0, n0);
 }
 
 template <bool X3, int TN>      // wgrad (A as a k image) and dgrad (A as a row image) of one Linear(H,H) in one launch; B is a k image in both
@@ -1342,7 +1378,11 @@ static int launch16(const Gemm16Batch& gb, int count, int tiles64, int tiles128,
         const bool k64 = AL == 0 && BL == 0 && !(g_gemm16_variant >= 0 && (g_gemm16_variant & 2097152));
         if (x3 && k64) {
             if constexpr (AL == 0 && BL == 0) {
-                if (tn == 128) EXORL_TRY(g16p_launch(gemm16p_kernel<false, false, true, 128, 64, 2>, g2, count, true, 128, s, 64, 2));
+                const bool ms16 = g_gemm16_variant >= 0 && (g_gemm16_variant & 4194304);       // experiment: 16 x 16 x 32 MFMAs
+                if (ms16) {
+                    if (tn == 128) EXORL_TRY(g16p_launch(gemm16p_kernel<false, false, true, 128, 64, 2, 16>, g2, count, true, 128, s, 64, 2));
+                    else EXORL_TRY(g16p_launch(gemm16p_kernel<false, false, true, 64, 64, 2, 16>, g2, count, true, 64, s, 64, 2));
+                } else if (tn == 128) EXORL_TRY(g16p_launch(gemm16p_kernel<false, false, true, 128, 64, 2>, g2, count, true, 128, s, 64, 2));
                 else EXORL_TRY(g16p_launch(gemm16p_kernel<false, false, true, 64, 64, 2>, g2, count, true, 64, s, 64, 2));
             }
         } else if (x3) {
