@@ -726,6 +726,56 @@ class _IntrAgent(DDPGAgent):
     def enable_graph(self, replay_iter, step=0):
         return False                     # the module step is launched eagerly in front of the DDPG chain
 
+    # ---- data parallel (last row) ----------------------------------------------------------------------------------------
+    # What these modules compute is batch-global: BatchNorm statistics and the running RMS of the rewards (rnd.py:24,47-60,
+    # utils.py:257-276), kNN particle entropy over the batch (utils.py:279-319), Sinkhorn normalisation and the candidate queue
+    # (proto.py:114-157), SMM's mean_j log p*(s_j), and each steps its own optimiser on a batch mean. Under torch.distributed every rank
+    # therefore all-gathers the sampled rows (one collective of B x (2 obs + act + 1) floats, <= 0.3 MB per rank at the shipped widths)
+    # and runs the module step on the GLOBAL batch: the kernels are deterministic, so the replicas of the module stay bit-identical
+    # without a gradient exchange, every statistic is the single-process one, and each rank keeps its own rows of the reward. The
+    # actor / critic step — the 1024-wide layers, 35 of the step's ~45 GFLOP — runs sharded like the offline agents' (_run_update).
+    @property
+    def _module_batch(self):
+        return self.engine.batch * getattr(self, 'world_size', 1)
+
+    def _dp_buffers(self):
+        if getattr(self, '_dp', None) is None:
+            eng, ws = self.engine, self.world_size
+            B, W, A = eng.batch, self.obs_dim, self.action_dim
+            dev = eng.device
+            pack = torch.empty(B, 2 * W + A + 1, device=dev)
+            gpack = torch.empty(ws * B, 2 * W + A + 1, device=dev)
+            g = dict(obs=torch.empty(ws * B, W, device=dev), action=torch.empty(ws * B, A, device=dev),
+                     next_obs=torch.empty(ws * B, W, device=dev), reward=torch.empty(ws * B, device=dev))
+            O = W - getattr(self, '_meta_dim', 0)
+            slots = L.BatchOut(g['obs'].data_ptr(), W, g['action'].data_ptr(), A, g['reward'].data_ptr(), None, g['next_obs'].data_ptr(), W,
+                               g['obs'].data_ptr() + 4 * O, W)
+            self._dp = (pack, gpack, g, slots)
+        return self._dp
+
+    def _intr_step_dp(self):
+        dist = torch.distributed
+        eng, ws, rank = self.engine, self.world_size, torch.distributed.get_rank()
+        B, W, A = eng.batch, self.obs_dim, self.action_dim
+        local = self._slots = self._slots or eng.batch_slots()
+        pack, gpack, g, gslots = self._dp_buffers()
+        view = lambda ptr, cols: eng._view(ptr, B * cols).view(B, cols)
+        pack[:, :W].copy_(view(local.obs, W))
+        pack[:, W:2 * W].copy_(view(local.next_obs, W))
+        pack[:, 2 * W:2 * W + A].copy_(view(local.action, A))
+        pack[:, 2 * W + A].copy_(eng._view(local.reward, B))
+        dist.all_gather(list(gpack.split(B)), pack)              # rows in rank order = the single-process batch of the equivalence test
+        g['obs'].copy_(gpack[:, :W])
+        g['next_obs'].copy_(gpack[:, W:2 * W])
+        g['action'].copy_(gpack[:, 2 * W:2 * W + A])
+        g['reward'].copy_(gpack[:, 2 * W + A])
+        self._slots = gslots
+        try:
+            self._intr_step()                                    # module optimiser step + rewards of all ws * B rows, identical on every rank
+        finally:
+            self._slots = local
+        eng._view(local.reward, B).copy_(g['reward'][rank * B:(rank + 1) * B])
+
     # ---- obs_type == 'pixels' ---------------------------------------------------------------------------------------------------
     # Every one of these agents augments and encodes obs and next_obs ONCE (icm.py:97-99, icm_apt.py:113-118, disagreement.py:98-100,
     # diayn.py:137-138), steps its module AND the encoder on the module's loss (encoder_opt.step() inside update_<module>), takes the
@@ -790,13 +840,13 @@ class _IntrAgent(DDPGAgent):
             return metrics
         if self.obs_type == 'pixels':
             return self._update_pixels(replay_iter, step)
-        if self.world_size != 1:
-            raise NotImplementedError('exorl_amd: the intrinsic-reward modules normalise over the batch (BatchNorm / RMS / kNN) and are '
-                                      'single-GPU this round; run data-parallel replicas instead')
         stddev = self._stddev(step)
         self._load_batch(replay_iter)
         if self.reward_free:
-            self._intr_step()
+            if self.world_size != 1:
+                self._intr_step_dp()
+            else:
+                self._intr_step()
         self._run_update(stddev)
         if self.use_tb or self.use_wandb:
             metrics.update(self._metrics(_CRITIC_METRICS + [(L.M_ACTOR_LOGPROB, 'actor_logprob')], stddev))
@@ -876,7 +926,7 @@ class RNDAgent(_IntrAgent):
                 view_p.zero_()
         else:
             w = _seq_init([('lin', O, H), ('lin', H, H), ('lin', H, rnd_rep_dim)] * 2)      # predictor then target (rnd.py:28-43)
-        self.intr = IntrEngine('rnd', O, self.action_dim, H, self.engine.batch, rep_dim=rnd_rep_dim, lr=self.lr, scale=rnd_scale,
+        self.intr = IntrEngine('rnd', O, self.action_dim, H, self._module_batch, rep_dim=rnd_rep_dim, lr=self.lr, scale=rnd_scale,
                                precision=self._precision, device=self.device, encoded=pixels)
         if pixels:
             conv_shapes = [s_ for l in range(4) for s_ in ((32, self.obs_shape[0] if l == 0 else 32, 3, 3), (32,))]
@@ -946,7 +996,7 @@ class ICMAgent(_IntrAgent):
         self.update_encoder = update_encoder
         O, A, H = self.obs_dim, self.action_dim, self.hidden_dim
         w = _seq_init([('lin', O + A, H), ('lin', H, O), ('lin', 2 * O, H), ('lin', H, A)])
-        self.intr = IntrEngine('icm', O, A, H, self.engine.batch, lr=self.lr, scale=icm_scale, precision=self._precision,
+        self.intr = IntrEngine('icm', O, A, H, self._module_batch, lr=self.lr, scale=icm_scale, precision=self._precision,
                                device=self.device)
         self.icm = NetView(self.intr, None, _ICM_KEYS)
         for p, t in zip(self.icm.parameters(), w):
@@ -970,7 +1020,7 @@ class ICMAPTAgent(_IntrAgent):
         self.update_encoder = update_encoder
         O, A, H, R = self.obs_dim, self.action_dim, self.hidden_dim, icm_rep_dim
         w = _seq_init([('lin', O, R), ('ln', R), ('lin', R + A, H), ('lin', H, R), ('lin', 2 * R, H), ('lin', H, A)])
-        self.intr = IntrEngine('icm_apt', O, A, H, self.engine.batch, rep_dim=R, lr=self.lr, scale=icm_scale, knn_k=knn_k,
+        self.intr = IntrEngine('icm_apt', O, A, H, self._module_batch, rep_dim=R, lr=self.lr, scale=icm_scale, knn_k=knn_k,
                                knn_avg=knn_avg, knn_rms=knn_rms, knn_clip=knn_clip, precision=self._precision, device=self.device)
         self.icm = NetView(self.intr, None, _APT_KEYS)
         for p, t in zip(self.icm.parameters(), w):
@@ -997,7 +1047,7 @@ class DisagreementAgent(_IntrAgent):
         for _ in range(5):
             for m in (nn.Linear(O + A, H), nn.Linear(H, O)):
                 w += [m.weight.data, m.bias.data]
-        self.intr = IntrEngine('disagreement', O, A, H, self.engine.batch, lr=self.lr, n_models=5, precision=self._precision,
+        self.intr = IntrEngine('disagreement', O, A, H, self._module_batch, lr=self.lr, n_models=5, precision=self._precision,
                                device=self.device)
         self.disagreement = NetView(self.intr, None, _DIS_KEYS)
         for p, t in zip(self.disagreement.parameters(), w):
@@ -1058,7 +1108,7 @@ class DIAYNAgent(_MetaObsMixin, _IntrAgent):
         super().__init__(**kwargs)
         O, H = self.obs_dim - self.skill_dim, self.hidden_dim
         w = _seq_init([('lin', O, H), ('lin', H, H), ('lin', H, skill_dim)])
-        self.intr = IntrEngine('diayn', O, self.action_dim, H, self.engine.batch, rep_dim=skill_dim, lr=self.lr, scale=diayn_scale,
+        self.intr = IntrEngine('diayn', O, self.action_dim, H, self._module_batch, rep_dim=skill_dim, lr=self.lr, scale=diayn_scale,
                                precision=self._precision, device=self.device)
         self.diayn = NetView(self.intr, None, _DIAYN_KEYS)
         for p, t in zip(self.diayn.parameters(), w):
@@ -1112,7 +1162,7 @@ class APSAgent(_MetaObsMixin, _IntrAgent):
         super().__init__(**kwargs)
         O, H = self.obs_dim - self.sf_dim, self.hidden_dim
         w = _seq_init([('lin', O, H), ('lin', H, H), ('lin', H, sf_dim)])
-        self.intr = IntrEngine('aps', O, self.action_dim, H, self.engine.batch, rep_dim=sf_dim, lr=self.lr, knn_k=knn_k, knn_avg=knn_avg,
+        self.intr = IntrEngine('aps', O, self.action_dim, H, self._module_batch, rep_dim=sf_dim, lr=self.lr, knn_k=knn_k, knn_avg=knn_avg,
                                knn_rms=knn_rms, knn_clip=knn_clip, precision=self._precision, device=self.device)
         self.aps = NetView(self.intr, None, _APS_KEYS)
         for p, t in zip(self.aps.parameters(), w):
@@ -1220,7 +1270,7 @@ class SMMAgent(_MetaObsMixin, _IntrAgent):
         O, H = self.obs_dim - z_dim, self.hidden_dim
         self.goal = (150, 75)
         w = _smm_init(O, z_dim, H)
-        self.intr = IntrEngine('smm', O, self.action_dim, H, self.engine.batch, rep_dim=z_dim, sp_lr=sp_lr, vae_lr=vae_lr, vae_beta=vae_beta,
+        self.intr = IntrEngine('smm', O, self.action_dim, H, self._module_batch, rep_dim=z_dim, sp_lr=sp_lr, vae_lr=vae_lr, vae_beta=vae_beta,
                                state_ent_coef=state_ent_coef, latent_ent_coef=latent_ent_coef, latent_cond_ent_coef=latent_cond_ent_coef,
                                goal=self.goal, precision=self._precision, device=self.device, encoded=self.obs_type == 'pixels')
         self.smm = NetView(self.intr, None, _SMM_KEYS)
@@ -1288,7 +1338,7 @@ class SMMAgent(_MetaObsMixin, _IntrAgent):
         s = self._slots
         e = None
         if self.eps_hook is not None:
-            e = torch.as_tensor(np.asarray(self.eps_hook((self.engine.batch, 128)), np.float32), device=self.engine.device).contiguous()
+            e = torch.as_tensor(np.asarray(self.eps_hook((self.intr.batch, 128)), np.float32), device=self.engine.device).contiguous()
         self.intr.update(s.obs, None, None, s.reward, s.reward, True, skill=s.obs + 4 * O, obs_ld=W, skill_ld=W,
                          cat_uniform=e.data_ptr() if e is not None else None)
         self._keep_eps = e
@@ -1367,7 +1417,7 @@ class ProtoAgent(_IntrAgent):
             self._dobs = torch.zeros(self.engine.batch, self.obs_dim, device=self.engine.device)
         O = self.obs_dim
         w = _proto_init(O, pred_dim, proj_dim, num_protos)
-        self.intr = IntrEngine('proto', O, self.action_dim, proj_dim, self.engine.batch, rep_dim=pred_dim, lr=self.lr, knn_k=topk,
+        self.intr = IntrEngine('proto', O, self.action_dim, proj_dim, self._module_batch, rep_dim=pred_dim, lr=self.lr, knn_k=topk,
                                num_protos=num_protos, queue_size=queue_size, tau=tau, target_tau=encoder_target_tau,
                                precision=self._precision, device=self.device)
         self.predictor = _TensorsView(self.intr, [0, 1], ['weight', 'bias'])

@@ -637,7 +637,7 @@ static int phase1(exorl_agent* a, float stddev, const float* noise_a, hipStream_
     // pi(obs) sample already sits in xc_pi (phase 0); DDPG logs its log-prob (ddpg.py:276,289)
     if ((cfg.kind == EXORL_AGENT_DDPG || cfg.kind == EXORL_AGENT_APS) && a->want_metrics)
         EXORL_TRY(sample_action(a->fa.out + (int64_t)B * A, noise_spec(a, noise_a, 1), stddev, cfg.stddev_clip, 1, a->xc_pi + O, W, B, A,
-                                a->metrics + EXORL_M_ACTOR_LOGPROB, s, &a->state->stddev));
+                                a->metrics + EXORL_M_ACTOR_LOGPROB, s, &a->state->stddev, cfg.world_size));
     const bool qf = qfuse(a);
     EXORL_TRY(net_forward(a->critic, a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM], a->sh_critic, a->xc_pi, W, B, a->fc, true, false, prec, s,
                           nullptr, qf));

@@ -276,7 +276,7 @@ int sample_actions2(const float* mu2, const float* noise_c, const float* noise_a
                     float stddev, float clip, float* dst_next, float* dst_pi, int64_t dst_ld, int B, int A, hipStream_t s,
                     const float* stddev_ptr = nullptr);
 int sample_action(const float* mu, NoiseSpec noise, float stddev, float clip, int use_clip, float* dst, int64_t dst_ld,
-                  int B, int A, float* logprob_sum, hipStream_t s, const float* stddev_ptr = nullptr);
+                  int B, int A, float* logprob_sum, hipStream_t s, const float* stddev_ptr = nullptr, int world_size = 1);
 // ---- CQL (cql.py:152-263)
 struct CqlNoise {            // the five draws of one CQL update; null buffers -> Philox(seed, *counter_ptr + k)
     const float *z_next, *u_rand, *z_cur, *z_nxt, *z_actor;

@@ -200,9 +200,10 @@ int crr_weights(const float* q_rep, const float* q_data, float* w, int B, int n,
 }
 
 int sample_action(const float* mu, NoiseSpec noise, float stddev, float clip, int use_clip, float* dst, int64_t dst_ld,
-                  int B, int A, float* logprob_sum, hipStream_t s, const float* stddev_ptr) {
+                  int B, int A, float* logprob_sum, hipStream_t s, const float* stddev_ptr, int world_size) {
+    // the log-prob metric is a partial mean over the GLOBAL batch, like every other metric (agents._metrics sum-all-reduces them)
     hipLaunchKernelGGL(sample_action_kernel, dim3(1), dim3(1024), 0, s, mu, noise, stddev, clip, use_clip, dst, dst_ld,
-                       B, A, logprob_sum, 1.0f / (float)B, stddev_ptr);
+                       B, A, logprob_sum, 1.0f / ((float)B * (float)world_size), stddev_ptr);
     EXORL_LAUNCH_CHECK();
     return 0;
 }

@@ -51,6 +51,84 @@ def noise_rows(kind, seed, step_rows):
     return _synth.NoiseStream(seed)
 
 
+# ---- reward-free agents (sharded actor / critic step, module step on the all-gathered batch: agents._IntrAgent._intr_step_dp) ----------
+UO, UA, UH, UB_GLOBAL, USTEPS = 12, 4, 64, 64, 3
+UNSUP = ['rnd', 'icm', 'icm_apt', 'disagreement', 'diayn', 'aps', 'smm', 'proto']
+U_META = {'diayn': 6, 'aps': 5, 'smm': 4}
+
+
+def build_unsup(kind, batch):
+    """Same seed -> same initial weights in every process (the reference's RNG consumption does not depend on the batch size)."""
+    import test_gpu_intr as T
+    torch.manual_seed(33)
+    if kind == 'proto':
+        return T.make_proto(UO, UA, UH, batch, 16, 32, 16, 256)
+    if kind == 'smm':
+        return T.make_smm(UO, UA, UH, batch, U_META['smm'])
+    return T.make(kind, UO, UA, UH, batch, U_META.get(kind, 16))
+
+
+def unsup_views(ag):
+    views = [('actor', ag.actor), ('critic', ag.critic), ('critic_target', ag.critic_target)]
+    for nm in ('rnd', 'icm', 'disagreement', 'diayn', 'aps', 'smm', 'predictor', 'predictor_target', 'projector', 'protos'):
+        if hasattr(ag, nm):
+            views.append((nm, getattr(ag, nm)))
+    return views
+
+
+def unsup_batch(kind, step, rows=slice(None)):
+    """Global batch of one update (+ the meta rows of DIAYN / APS / SMM); a rank takes its row slice."""
+    import _synth
+    b = list(_synth.synth_batch(41, step, UB_GLOBAL, UO, UA))
+    if kind in U_META:
+        rs = np.random.RandomState(500 + step)
+        Z = U_META[kind]
+        if kind == 'aps':
+            m = rs.standard_normal((UB_GLOBAL, Z)).astype(np.float32)
+            m /= np.linalg.norm(m, axis=1, keepdims=True)
+        else:
+            m = np.eye(Z, dtype=np.float32)[rs.randint(0, Z, UB_GLOBAL)]
+        b.append(m)
+    return tuple(np.ascontiguousarray(x[rows]) for x in b)
+
+
+def unsup_hooks(ag, kind, seed):
+    """Module-side draws (SMM's VAE epsilon, Proto's Categorical uniforms) are over the module's — global — batch: every rank makes the
+    same ones. The device generators of the library are seeded rank-independently and would do; explicit streams keep the parent's
+    single-process run on the same numbers."""
+    import _synth
+    ms = _synth.NoiseStream(seed)
+    if kind == 'smm':
+        ag.eps_hook = lambda shape: ms.draw(shape)
+    if kind == 'proto':
+        rs = np.random.RandomState(seed)
+        ag.cat_hook = lambda n: rs.uniform(0, 1, n).astype(np.float32)
+
+
+def run_unsup(rank, world, out_dir, result):
+    import _synth
+    Br = UB_GLOBAL // world
+    sl = slice(rank * Br, (rank + 1) * Br)
+    for kind in UNSUP:
+        ag = build_unsup(kind, Br)
+        assert ag.world_size == world and ag.intr.batch == UB_GLOBAL
+        unsup_hooks(ag, kind, 17)
+        ns = _synth.NoiseStream(9)
+        draws = []
+        ag.noise_hook = lambda shape: draws.pop(0)
+        metrics, rewards = [], []
+        for i in range(USTEPS):
+            draws[:] = [ns.draw((UB_GLOBAL, UA))[sl], ns.draw((UB_GLOBAL, UA))[sl]]
+            m = ag.update(iter([unsup_batch(kind, i, sl)]), 2 * i)
+            metrics.append({k: float(v) for k, v in m.items()})
+            rewards.append(ag.engine._view(ag.engine.batch_slots().reward, Br).cpu().numpy().copy())
+        torch.cuda.synchronize()
+        np.savez(out_dir / f'unsup_{kind}_rank{rank}.npz', reward=np.stack(rewards),
+                 **{n: torch.cat([p.reshape(-1) for p in v.parameters()]).cpu().numpy() for n, v in unsup_views(ag)})
+        result[f'unsup_{kind}'] = metrics
+        del ag
+
+
 def main():
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     data_dir, out_dir = Path(sys.argv[1]), Path(sys.argv[2])
@@ -80,6 +158,7 @@ def main():
         np.savez(out_dir / f'{tag}_rank{rank}.npz', **{n: torch.cat([p.reshape(-1) for p in net.parameters()]).cpu().numpy() for n, net in nets})
         result[tag] = metrics
         del ag, it
+    run_unsup(rank, world, out_dir, result)
     json.dump(result, open(out_dir / f'metrics_rank{rank}.json', 'w'))
     dist.barrier()
     dist.destroy_process_group()

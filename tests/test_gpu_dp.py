@@ -63,6 +63,44 @@ def test_two_process_dp_equals_single_process(dp_run, tag):
             assert np.mean(d > tol_p[1] + tol_p[0] * np.abs(want)) <= 5e-3 and d.max() <= 6.5e-4, (tag, n, d.max())
 
 
+@pytest.mark.parametrize('kind', ['rnd', 'icm', 'icm_apt', 'disagreement', 'diayn', 'aps', 'smm', 'proto'])
+def test_two_process_sharded_reward_free_agents_equal_single_process(dp_run, kind):
+    """SURVEY 8e, last row: the reward-free agents shard their actor / critic step and run the module step (BatchNorm, RMS, kNN, Sinkhorn,
+    queue, the module optimiser) on the all-gathered batch. Two ranks x B/2 must leave bit-identical replicas, give every row the reward the
+    single-process run on the concatenated batch gives it (module state included: same kernels on the same B rows -> bit-equal), and land
+    on that run's actor / critic to fp32 summation order."""
+    import _dp_worker as W
+    import _synth
+    out = dp_run['out']
+    r0, r1 = np.load(out / f'unsup_{kind}_rank0.npz'), np.load(out / f'unsup_{kind}_rank1.npz')
+    for k in r0.files:
+        if k != 'reward':
+            assert np.array_equal(r0[k], r1[k]), (kind, k)
+    m0, m1 = (json.load(open(out / f'metrics_rank{r}.json'))[f'unsup_{kind}'] for r in (0, 1))
+    assert m0 == m1 and len(m0) == W.USTEPS
+    ag = W.build_unsup(kind, W.UB_GLOBAL)
+    W.unsup_hooks(ag, kind, 17)
+    ns = _synth.NoiseStream(9)
+    draws = []
+    ag.noise_hook = lambda shape: draws.pop(0)
+    Br = W.UB_GLOBAL // 2
+    module_names = [n for n, _ in W.unsup_views(ag)][3:]
+    for i in range(W.USTEPS):
+        draws[:] = [ns.draw((W.UB_GLOBAL, W.UA)), ns.draw((W.UB_GLOBAL, W.UA))]
+        m = ag.update(iter([W.unsup_batch(kind, i)]), 2 * i)
+        rew = ag.engine._view(ag.engine.batch_slots().reward, W.UB_GLOBAL).cpu().numpy()
+        # the module saw the same rows in the same order through the same kernels: its rewards are the single-process ones bit for bit
+        assert np.array_equal(np.concatenate([r0['reward'][i], r1['reward'][i]]), rew), (kind, i)
+        for k, v in m.items():
+            assert abs(m0[i][k] - v) <= 5e-5 * abs(v) + 2e-6, (kind, i, k, m0[i][k], v)
+    for n, v in W.unsup_views(ag):
+        want = torch.cat([p.reshape(-1) for p in v.parameters()]).cpu().numpy()
+        if n in module_names:
+            assert np.array_equal(r0[n], want), (kind, n)
+        else:
+            np.testing.assert_allclose(r0[n], want, rtol=5e-5, atol=5e-7, err_msg=f'{kind} {n}')
+
+
 @pytest.mark.parametrize('kind,precision', [('td3_bc', 'fp32'), ('td3_bc', 'bf16x3'), ('cql', 'fp32'), ('bc', 'fp32')])
 def test_native_comm_single_rank_runs_the_dp_step(kind, precision):
     """exorl_comm_* and exorl_agent_set_comm on the box's one GPU: a 1-rank RCCL communicator makes every all-reduce an identity, so
