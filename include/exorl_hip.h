@@ -272,6 +272,9 @@ int exorl_gemm_planes(int32_t count, const int32_t* a_layouts, int32_t b_layout,
                       float* const* C_dev, int64_t ldc, int32_t relu, void* stream);
 /* Tuning switch for the bf16-operand GEMM (tools/micro/gemm_bench.py): -1 = default heuristics. */
 int exorl_gemm_tune(int32_t variant);
+/* Diagnostic (tools/micro/stamp_bench.py; tuning bit 33554432 selects the stamped build of the forward H x H GEMM): per workgroup
+ * {s_memtime x 4, s_memrealtime x 4} at entry / first k-step / last k-step / stores drained; 8 words per workgroup, <= 1024 workgroups. */
+int exorl_debug_gemm_stamps(uint64_t* out_host, int32_t n_words);
 /* Measurement hook (bench.py roofline leg): time every GEMM launch with HIP events on its own stream. */
 int exorl_profile_gemm(int32_t enable);
 int exorl_profile_gemm_read(double* flops_out_host, float* ms_out_host, int32_t cap, int32_t* n_out);

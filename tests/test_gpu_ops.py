@@ -188,3 +188,52 @@ def test_knn_golden_pbe_and_proto(lib, gold):
     out = torch.empty(10, 3, device='cuda')
     L.check(lib.exorl_knn_topk(zd.data_ptr(), 10, qd.data_ptr(), 20, 6, 3, out.data_ptr(), None))
     np.testing.assert_allclose(out.cpu().numpy()[:, -1:], z['knn_reward'], rtol=1e-5)
+
+
+@pytest.mark.parametrize('x3', [True, False])
+@pytest.mark.parametrize('count,a_layouts,bl,M,N,K', [
+    (4, [0, 0, 0, 0], 0, 1024, 1024, 1024),      # critic + target forward
+    (4, [1, 1, 0, 0], 1, 1024, 1024, 1024),      # critic wgrad + dgrad in one launch
+    (2, [0, 0], 0, 1024, 1024, 1024), (2, [0, 0], 1, 1024, 1024, 1024), (2, [1, 0], 1, 1024, 1024, 1024), (1, [0], 0, 2048, 1024, 1024),
+    (1, [0], 1, 128, 128, 256), (1, [0], 1, 128, 64, 512), (1, [1], 1, 256, 384, 512), (2, [0, 0], 0, 128, 128, 128), (1, [0], 0, 128, 192, 384),
+    (4, [0, 0, 0, 0], 1, 512, 512, 256), (2, [1, 1], 1, 256, 128, 640)])
+def test_gemm_planes_shapes(lib, x3, count, a_layouts, bl, M, N, K):
+    """The grouped H x H GEMM on bf16 hi/lo planes (exorl_gemm_planes: what the agent's six launches call), every operand layout, launch shapes
+    from one stage ring (K = 128) to 32, with REAL lo planes: equal to the float64 product of the same planes (minus lo*lo, which the kernel
+    drops) to fp32 accumulation order, and bit-identical over repeated launches (a stage-ring race shows up as a result that moves)."""
+    from exorl_amd import _lib as L
+    C = L.C
+    g = torch.Generator(device='cuda').manual_seed(M + N + K + count + bl)
+
+    def split(x):
+        hi = x.to(torch.bfloat16)
+        return hi, (x - hi.float()).to(torch.bfloat16)
+    ps = []
+    for i in range(count):
+        A = torch.randn((M, K) if a_layouts[i] == 0 else (K, M), device='cuda', generator=g)
+        B = torch.randn((N, K) if bl == 0 else (K, N), device='cuda', generator=g)
+        ps.append((split(A), split(B), torch.zeros(M, N, device='cuda')))
+    arr = lambda xs: (C.c_void_p * count)(*[x.data_ptr() for x in xs])
+    lay = (C.c_int32 * count)(*a_layouts)
+    lda, ldb = (K if a_layouts[0] == 0 else M), (K if bl == 0 else N)
+
+    def launch():
+        L.check(lib.exorl_gemm_planes(count, lay, bl, M, N, K, arr([p[0][0] for p in ps]), arr([p[0][1] for p in ps]) if x3 else None, lda,
+                                      arr([p[1][0] for p in ps]), arr([p[1][1] for p in ps]) if x3 else None, ldb, arr([p[2] for p in ps]), N, 0,
+                                      torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        return [p[2].clone() for p in ps]
+    first = launch()
+    for i, ((ah, alo), (bh, blo), _) in enumerate(ps):
+        Ad = ah.double() + (alo.double() if x3 else 0)
+        Bd = bh.double() + (blo.double() if x3 else 0)
+        Ad = Ad if a_layouts[i] == 0 else Ad.t()
+        Bd = Bd.t() if bl == 0 else Bd
+        ref = Ad @ Bd
+        if x3:
+            ref = ref - (alo.double() if a_layouts[i] == 0 else alo.double().t()) @ (blo.double().t() if bl == 0 else blo.double())
+        err = float((first[i].double() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-6, (i, err)
+    for _ in range(6):
+        again = launch()
+        assert all(torch.equal(a, b) for a, b in zip(first, again))
