@@ -168,6 +168,11 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a number for a different topology')
     if args.rehearse:
         local_rank = 0
+    if world > 1:
+        # N > 1 has never run on real multi-GPU hardware from this repo (one GPU per box): if a collective hangs, leave a traceback and a
+        # non-zero exit within ten minutes instead of holding the node until the driver's limit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get('EXORL_BENCH_WATCHDOG_S', '600')), exit=True)
     torch.cuda.set_device(local_rank)
     device = f'cuda:{local_rank}'
     dist = torch.distributed
@@ -319,8 +324,10 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        import faulthandler
+        faulthandler.cancel_dump_traceback_later()
         dist.destroy_process_group()
 
 

@@ -9,6 +9,8 @@ CSRC = HERE / 'csrc'
 LIB = HERE / 'libexorl_hip.so'
 SOURCES = ['api.cpp', 'comm.cpp', 'gemm.hip', 'rowops.hip', 'fused.hip', 'loss.hip', 'cql.hip', 'optim.hip', 'replay.hip', 'agent.hip', 'knn.hip', 'intr.hip', 'pixels.hip', 'pixel_agent.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+if os.environ.get('EXORL_GEMM_EXPERIMENTS'):       # the measured-and-not-adopted GEMM schedules (tools/micro/ws_bench.py, ms16_bench.py)
+    FLAGS.append('-DEXORL_GEMM_EXPERIMENTS')
 
 
 def needs_build():

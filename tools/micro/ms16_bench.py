@@ -1,5 +1,5 @@
 """A/B of the MFMA shape in the forward (row x row image) launches of the H x H GEMM: 32x32x16 (default) against 16x16x32 (exorl_gemm_tune
-bit 4194304), same tiles / stages / LDS images; correctness against a float64 product of the same planes, then interleaved timing.
+bit 4194304; needs a library built with -DEXORL_GEMM_EXPERIMENTS), same tiles / stages / LDS images; correctness against a float64 product of the same planes, then interleaved timing.
 python tools/micro/ms16_bench.py"""
 import sys
 from pathlib import Path
