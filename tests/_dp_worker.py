@@ -33,6 +33,8 @@ def build_agent(kind, precision, batch, use_tb):
     from oracle.agents import param_shapes
     if kind == 'td3_bc':
         ag = agents.TD3BCAgent('td3_bc', (O,), (A,), 'cuda:0', 1e-4, H, 0.01, '0.2', 1, batch, 0.3, use_tb, 2.5, precision=precision)
+    elif kind == 'td3':
+        ag = agents.TD3Agent('td3', (O,), (A,), 'cuda:0', 1e-4, H, 0.01, '0.2', 1, batch, 0.3, use_tb, precision=precision)
     elif kind == 'cql':
         ag = agents.CQLAgent('cql', (O,), (A,), 'cuda:0', 1e-4, H, 0.01, 1, batch, use_tb, 0.01, 3, 5.0, False, precision=precision)
     else:
@@ -45,10 +47,19 @@ def build_agent(kind, precision, batch, use_tb):
     return ag
 
 
-def noise_rows(kind, seed, step_rows):
-    """Global noise draws of one step, as (critic, actor) blocks over the GLOBAL batch; a rank uses its row slice."""
-    import _synth
-    return _synth.NoiseStream(seed)
+def sliced_noise_hook(ns, rows):
+    """noise_hook over the GLOBAL batch: every draw is made for all B_GLOBAL rows (so that every process consumes the stream alike) and the
+    caller keeps its row slice; CQL's (n, B, A) blocks slice their middle axis and its uniform(-1, 1) actions are a squashed normal draw."""
+    def hook(shape, dist='normal'):
+        if len(shape) == 2:
+            out = ns.draw((B_GLOBAL, shape[1]))[rows]
+        else:
+            out = ns.draw((shape[0], B_GLOBAL, shape[2]))[:, rows]
+        return np.ascontiguousarray(np.tanh(out) if dist == 'uniform' else out)
+    return hook
+
+
+HOOKED = [('td3', 'fp32'), ('cql', 'fp32')]          # the kinds run through sliced_noise_hook (CQL: its own _run_update branch under torch.distributed)
 
 
 # ---- reward-free agents (sharded actor / critic step, module step on the all-gathered batch: agents._IntrAgent._intr_step_dp) ----------
@@ -155,6 +166,19 @@ def main():
         torch.cuda.synchronize()
         tag = f'{kind}_{precision}'
         nets = [('actor', ag.actor)] + ([('critic', ag.critic), ('critic_target', ag.critic_target)] if hasattr(ag, 'critic') else [])
+        np.savez(out_dir / f'{tag}_rank{rank}.npz', **{n: torch.cat([p.reshape(-1) for p in net.parameters()]).cpu().numpy() for n, net in nets})
+        result[tag] = metrics
+        del ag, it
+    for kind, precision in HOOKED:
+        ag = build_agent(kind, precision, Br, True)
+        assert ag.world_size == world
+        st = ReplayBufferStorage((), (), data_dir)
+        it = iter(make_replay_loader(st, 10**6, Br, world, True, 1, 0.99, worker_ids=[rank], seed=78))
+        ag.noise_hook = sliced_noise_hook(_synth.NoiseStream(11), slice(rank * Br, (rank + 1) * Br))
+        metrics = [{k: float(v) for k, v in ag.update(it, step).items()} for step in range(STEPS)]
+        torch.cuda.synchronize()
+        tag = f'{kind}_{precision}'
+        nets = [('actor', ag.actor), ('critic', ag.critic), ('critic_target', ag.critic_target)]
         np.savez(out_dir / f'{tag}_rank{rank}.npz', **{n: torch.cat([p.reshape(-1) for p in net.parameters()]).cpu().numpy() for n, net in nets})
         result[tag] = metrics
         del ag, it

@@ -63,6 +63,36 @@ def test_two_process_dp_equals_single_process(dp_run, tag):
             assert np.mean(d > tol_p[1] + tol_p[0] * np.abs(want)) <= 5e-3 and d.max() <= 6.5e-4, (tag, n, d.max())
 
 
+@pytest.mark.parametrize('tag', ['td3_fp32', 'cql_fp32'])
+def test_two_process_dp_equals_single_process_hooked(dp_run, tag):
+    """TD3 (no batch-global statistic) and CQL — whose _run_update has its own torch.distributed branch (critic gradients, the summed log pi
+    behind the entropy temperature, actor gradients) and five noise tensors per step — as two ranks x B/2 against one process x B."""
+    import _dp_worker as W
+    import _synth
+    from exorl_amd.replay_buffer import ReplayBufferStorage, make_replay_loader
+    out = dp_run['out']
+    r0, r1 = np.load(out / f'{tag}_rank0.npz'), np.load(out / f'{tag}_rank1.npz')
+    for k in r0.files:
+        assert np.array_equal(r0[k], r1[k]), (tag, k)
+    m0, m1 = (json.load(open(out / f'metrics_rank{r}.json'))[tag] for r in (0, 1))
+    assert m0 == m1 and len(m0) == W.STEPS
+    kind, precision = tag.rsplit('_', 1)
+    ag = W.build_agent(kind, precision, W.B_GLOBAL, True)
+    st = ReplayBufferStorage((), (), dp_run['data'])
+    its = [iter(make_replay_loader(st, 10**6, W.B_GLOBAL // 2, 2, True, 1, 0.99, worker_ids=[r], seed=78)) for r in (0, 1)]
+    ag.noise_hook = W.sliced_noise_hook(_synth.NoiseStream(11), slice(None))
+    for step in range(W.STEPS):
+        halves = [next(it) for it in its]
+        batch = tuple(torch.cat([h[j] for h in halves]) for j in range(5))
+        m = ag.update(iter([batch]), step)
+        assert set(m) == set(m0[step])
+        for k, v in m.items():
+            assert abs(m0[step][k] - v) <= 5e-5 * abs(v) + 2e-6, (tag, step, k, m0[step][k], v)
+    for n, net in (('actor', ag.actor), ('critic', ag.critic), ('critic_target', ag.critic_target)):
+        want = torch.cat([p.reshape(-1) for p in net.parameters()]).cpu().numpy()
+        np.testing.assert_allclose(r0[n], want, rtol=5e-5, atol=5e-7, err_msg=f'{tag} {n}')
+
+
 @pytest.mark.parametrize('kind', ['rnd', 'icm', 'icm_apt', 'disagreement', 'diayn', 'aps', 'smm', 'proto'])
 def test_two_process_sharded_reward_free_agents_equal_single_process(dp_run, kind):
     """SURVEY 8e, last row: the reward-free agents shard their actor / critic step and run the module step (BatchNorm, RMS, kNN, Sinkhorn,
