@@ -955,17 +955,26 @@ __device__ unsigned long long g16p_stamps[8 * 1024];
 // STAG = 0 | 2 | 4: the waves of a workgroup run in lockstep between barriers, so with one instruction stream they issue their DMA pieces
 // in the same MFMA gaps. With STAG phases, wave w places its pieces in the gaps g = w mod STAG (mod STAG): STAG copies of the k-loop that
 // differ only in that placement, chosen once per wave in front of the loop.
-template <bool AT, bool BT, bool X3, int TN, int KS, int NSTG, int MS = 32, bool WS = false, bool STAMP = false, int ABL = 0, int SPREAD = 1, int STAG = 0>
+// NW = waves per workgroup, all of them loading and computing (4, or 8 = 512 threads on the same 128 x TN tile with half-size wave tiles).
+// tools/micro/fill_bench.hip: ONE wave issues an LDS-DMA piece about every 100 cycles whatever it keeps in flight (4 waves per CU deliver
+// 85 GB/s at 8, 16 or 32 pieces in flight each; 8 waves 117 GB/s, where the CU's L2 path saturates) — a 128 x 64 tile needs 24 pieces per
+// 384 MFMA-cycles, i.e. more issue slots than four waves have.
+template <bool AT, bool BT, bool X3, int TN, int KS, int NSTG, int MS = 32, bool WS = false, bool STAMP = false, int ABL = 0, int SPREAD = 1, int STAG = 0,
+          int NW = 4>
 __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned char* smem, int pidx, int m0, int n0) {
     constexpr int NBA = 2, NBB = TN / 64, NPL = X3 ? 2 : 1;
+    constexpr int WR = (NW == 8 && TN == 64) ? 32 : 64;     // wave tile: WR rows x WC columns
+    constexpr int WC = NW == 8 ? 32 : TN / 2;
+    constexpr int WN = TN / WC;                             // waves along N (the rest along M)
+    static_assert((NW == 4 || (NW == 8 && MS == 32 && !WS && KS == 64)) && (128 / WR) * WN == NW, "wave grid");
     constexpr int BLK = 64 * 2 * KS;                        // one 64-row block of one plane and stage (either image kind)
     constexpr int PLANE = (NBA + NBB) * BLK;                // [A blk0][A blk1][B blk0][B blk1]
     constexpr int STAGE = NPL * PLANE;                      // hi plane, then lo plane
-    constexpr int PPW = KS / 32;                            // 1-KB DMA pieces per wave and block
+    constexpr int PPW = KS / 8 / NW;                        // 1-KB DMA pieces per wave and block
     constexpr int NP = (NBA + NBB) * NPL * PPW;             // DMA pieces per wave and stage
     constexpr int NQ = MS == 16 ? KS / 32 : KS / 16;        // regions (k16 / k32) per stage
-    constexpr int SA = 64 / MS;                             // MS-row sub-tiles of a wave along M (wave tile 64 x TN/2)
-    constexpr int SB = TN / (2 * MS);                       // MS-column sub-tiles of a wave along N
+    constexpr int SA = WR / MS;                             // MS-row sub-tiles of a wave along M
+    constexpr int SB = WC / MS;                             // MS-column sub-tiles of a wave along N
     constexpr int NPAIR = SA * SB;                          // MS x MS accumulators of a wave
     constexpr int NM = NPAIR * (X3 ? 3 : 1);                // MFMAs per region
     constexpr int NF = (SA + SB) * NPL;                     // fragments per region
@@ -986,8 +995,10 @@ __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned cha
     const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = WS && wave_id >= 4;                 // wave-uniform role
     const int wave = WS ? (wave_id & 3) : wave_id;          // consumer: its 64 x TN/2 quadrant; loader: which pieces of a block it fetches
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int h = lane >> 5;
+    const int arow0 = (wm * WR) & 63, ablk = (wm * WR) >> 6;        // this wave's rows inside A block ablk
+    const int bcol0 = (wn * WC) & 63, bblk = (wn * WC) >> 6;        // this wave's columns inside B block bblk
 
     acc_t acc[NPAIR], accx[X3 ? NPAIR : 1];                 // [ua * SB + ub]; accx: the two cross terms hi*lo + lo*hi
 #pragma unroll
@@ -1012,7 +1023,7 @@ __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned cha
             for (int b = 0; b < NBA + NBB; ++b)
 #pragma unroll
                 for (int j = 0; j < PPW; ++j) {
-                    const int pc = wave + 4 * j;
+                    const int pc = wave + NW * j;
                     const bool isA = b < NBA;
                     const bool tr = isA ? AT : BT;
                     const int64_t ld = isA ? P.lda : P.ldb;
@@ -1038,12 +1049,12 @@ __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned cha
     for (int q = 0; q < NQ; ++q) {
 #pragma unroll
         for (int u = 0; u < SA; ++u) {
-            if constexpr (MS == 16) aoff[u][q] = wm * BLK + row_off(u * 16 + (lane & 15), 4 * q + (lane >> 4));    // lane: row l & 15, k = 8 (l >> 4) ..+7
-            else aoff[u][q] = wm * BLK + (AT ? tr_off(u * 32) + q * 16 * ROWB : row_off(u * 32 + (lane & 31), 2 * q + h));
+            if constexpr (MS == 16) aoff[u][q] = ablk * BLK + row_off(arow0 + u * 16 + (lane & 15), 4 * q + (lane >> 4));    // lane: row l & 15, k = 8 (l >> 4) ..+7
+            else aoff[u][q] = ablk * BLK + (AT ? tr_off(arow0 + u * 32) + q * 16 * ROWB : row_off(arow0 + u * 32 + (lane & 31), 2 * q + h));
         }
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
-            const int blk = TN == 128 ? wn : 0, r0 = TN == 128 ? u * MS : wn * 32 + (MS == 16 ? u * 16 : 0);
+            const int blk = bblk, r0 = bcol0 + u * MS;
             if constexpr (MS == 16) boff[u][q] = (NBA + blk) * BLK + row_off(r0 + (lane & 15), 4 * q + (lane >> 4));
             else boff[u][q] = (NBA + blk) * BLK + (BT ? tr_off(r0) + q * 16 * ROWB : row_off(r0 + (lane & 31), 2 * q + h));
         }
@@ -1052,7 +1063,7 @@ __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned cha
     auto fill_one = [&](int st, auto ic) {          // DMA piece I of stage slot st
         constexpr int I = decltype(ic)::value;
         constexpr int j = I % PPW, b = (I / PPW) % (NBA + NBB), pl = I / (PPW * (NBA + NBB));
-        __builtin_amdgcn_global_load_lds((const void*)src[I], (lds_void*)(smem + st * STAGE + pl * PLANE + b * BLK + (wave + 4 * j) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)src[I], (lds_void*)(smem + st * STAGE + pl * PLANE + b * BLK + (wave + NW * j) * 1024), 16, 0, 0);
         src[I] += b < NBA ? kstepA : kstepB;
     };
     auto fill = [&](int st) { g16p_static_for<0, NP>([&](auto ic) { fill_one(st, ic); }); };
@@ -1241,8 +1252,8 @@ __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned cha
         for (int ta = 0; ta < SA; ++ta)
 #pragma unroll
             for (int tb = 0; tb < SB; ++tb) {
-                const int nb = n0 + wn * (TN / 2) + tb * 16 + 4 * (lane >> 4);
-                float4* dst = reinterpret_cast<float4*>(P.C + (int64_t)(m0 + wm * 64 + ta * 16 + (lane & 15)) * P.ldc + nb);
+                const int nb = n0 + wn * WC + tb * 16 + 4 * (lane >> 4);
+                float4* dst = reinterpret_cast<float4*>(P.C + (int64_t)(m0 + wm * WR + ta * 16 + (lane & 15)) * P.ldc + nb);
                 const float4 bias = P.bias ? *reinterpret_cast<const float4*>(P.bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
                 const acc_t& a0 = acc[ta * SB + tb];
                 const acc_t& ax = accx[X3 ? ta * SB + tb : 0];
@@ -1257,12 +1268,12 @@ __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned cha
             }
     } else {
 #pragma unroll
-    for (int ta = 0; ta < 2; ++ta)
+    for (int ta = 0; ta < SA; ++ta)
 #pragma unroll
         for (int tb = 0; tb < SB; ++tb) {
             // lane: output row m0 + .. + (lane & 31); registers 4g..4g+3: columns nb + 8g + 4h .. +3
-            const int nb = n0 + wn * (TN / 2) + tb * 32 + 4 * h;
-            float* crow = P.C + (int64_t)(m0 + wm * 64 + ta * 32 + (lane & 31)) * P.ldc + nb;
+            const int nb = n0 + wn * WC + tb * 32 + 4 * h;
+            float* crow = P.C + (int64_t)(m0 + wm * WR + ta * 32 + (lane & 31)) * P.ldc + nb;
             const acc_t& a0 = acc[ta * SB + tb];
             const acc_t& ax = accx[X3 ? ta * SB + tb : 0];
 #pragma unroll
@@ -1283,7 +1294,7 @@ __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned cha
     if constexpr (STAMP) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(3);
-        if (lane == 0 && blockIdx.x < 256) {             // 32 words per workgroup: wave w at [8 w .. 8 w + 7]
+        if (lane == 0 && blockIdx.x < 256 && wave_id < 4) {             // 32 words per workgroup: wave w (< 4) at [8 w .. 8 w + 7]
             unsigned long long* o = g16p_stamps + blockIdx.x * 32 + wave_id * 8;
             o[0] = st_t[0]; o[1] = st_t[1]; o[2] = st_t[2]; o[3] = st_t[3];
             o[4] = st_r[1]; o[5] = st_r[2]; o[6] = wacc_v; o[7] = wacc_b;
@@ -1317,6 +1328,13 @@ __global__ __launch_bounds__(256) void gemm16p_kernel(const Gemm16Batch gb) {
 }
 
 #ifdef EXORL_GEMM_EXPERIMENTS
+template <bool AT, bool BT, bool X3, int TN, bool STAMP = false>      // 8 waves per workgroup, all loading and computing; 64-wide stages x 2
+__global__ __launch_bounds__(512) void gemm16p8_kernel(const Gemm16Batch gb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_p[];
+    int pidx, m0, n0;
+    if (!g16p_tile<TN>(gb, pidx, m0, n0)) return;
+    gemm16p_body<AT, BT, X3, TN, 64, 2, 32, false, STAMP, 0, 2, 0, 8>(gb, smem_p, pidx, m0, n0);
+}
 template <bool AT, bool BT, bool X3, int TN>      // wave-specialised (512 threads: 4 MFMA waves + 4 loader waves), k32 stages x 4
 __global__ __launch_bounds__(512) void gemm16w_kernel(const Gemm16Batch gb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_p[];
@@ -1359,9 +1377,6 @@ static int g16p_pick(const Gemm16Batch& gb, int count, bool x3) {
     bool n128 = true;
     for (int i = 0; i < count; ++i) n128 = n128 && gb.p[i].N % 128 == 0;
     if (g_gemm16_variant >= 0 && (g_gemm16_variant & 524288)) return n128 ? 128 : 64;      // experiment: 128 x 128 wherever it tiles
-#ifdef EXORL_GEMM_EXPERIMENTS
-    if (g_gemm16_variant >= 0 && (g_gemm16_variant & 268435456)) return 64;                // experiment: 128 x 64 everywhere
-#endif
     return (n128 && t128 >= 256) ? 128 : 64;
 }
 static bool g16p_uniform(const Gemm16Batch& gb, int count, int tn) {       // xcd_tile()'s preconditions
@@ -1500,8 +1515,14 @@ static int launch16(const Gemm16Batch& gb, int count, int tiles64, int tiles128,
 #ifdef EXORL_GEMM_EXPERIMENTS      // measured and not adopted ("what was tried on the GEMM"): kept reproducible, not in the default build
         if (x3 && !done) {
             done = true;
-            if (tn == 64 && (var_ & 268435456)) EXORL_TRY(g16p_launch(gemm16p_kernel<AL != 0, BL != 0, true, 64, 32, 2>, g2, count, true, 64, s, 32, 2));
-            else if (var_ & 8388608) {          // wave-specialised workgroups
+            if (k64 && (var_ & 268435456)) {        // 8 waves per workgroup, all loading and computing (forward launches)
+                if constexpr (AL == 0 && BL == 0) {
+                    if (tn == 128 && stamped) EXORL_TRY(g16p_launch(gemm16p8_kernel<false, false, true, 128, true>, g2, count, true, 128, s, 64, 2, 512));
+                    else if (tn == 128) EXORL_TRY(g16p_launch(gemm16p8_kernel<false, false, true, 128>, g2, count, true, 128, s, 64, 2, 512));
+                    else if (stamped) EXORL_TRY(g16p_launch(gemm16p8_kernel<false, false, true, 64, true>, g2, count, true, 64, s, 64, 2, 512));
+                    else EXORL_TRY(g16p_launch(gemm16p8_kernel<false, false, true, 64>, g2, count, true, 64, s, 64, 2, 512));
+                }
+            } else if (var_ & 8388608) {          // wave-specialised workgroups
                 if (tn == 128) EXORL_TRY(g16p_launch(gemm16w_kernel<AL != 0, BL != 0, true, 128>, g2, count, true, 128, s, 32, 4, 512));
                 else EXORL_TRY(g16p_launch(gemm16w_kernel<AL != 0, BL != 0, true, 64>, g2, count, true, 64, s, 32, 4, 512));
             } else if (k64 && (var_ & 4194304) && !(var_ & 1073741824)) {          // 16 x 16 x 32 MFMAs

@@ -21,6 +21,9 @@ CASES = [('fwd x4 128x128 k64x2', 4, [0, 0, 0, 0], 0, 0), ('  .. refill in one r
          ('  .. old, no MFMA', 4, [0, 0, 0, 0], 0, 3 * A), ('fwd x4 128x128 k32x4', 4, [0, 0, 0, 0], 0, K32), ('fwd x2 128x64 k64x2', 2, [0, 0], 0, 0),
          ('fwd x2 128x64 k32x4', 2, [0, 0], 0, K32), ('dgrad x4 128x128 k32x4', 4, [0, 0, 0, 0], 1, 0), ('dgrad x2 128x64 k32x4', 2, [0, 0], 1, 0),
          ('wgrad x4 128x128 k32x4', 4, [1, 1, 1, 1], 1, 0)]
+import os
+if os.environ.get('EXORL_GEMM_EXPERIMENTS'):      # library built with the experiments: the 8-wave forward kernels
+    CASES += [('fwd x4 128x128 k64x2, 8 waves', 4, [0, 0, 0, 0], 0, 268435456), ('fwd x2 128x64 k64x2, 8 waves', 2, [0, 0], 0, 268435456)]
 M = N = K = H
 for tag, count, lay, bl, extra in CASES:
     ps = make(count, lay, bl, M, N, K, True)

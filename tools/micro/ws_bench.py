@@ -2,7 +2,8 @@
 planes, then interleaved timing. Variants are exorl_gemm_tune masks: 0 = default (a stage's LDS-DMA refill spread over two k-regions),
 536870912 = the previous schedule (whole refill in the region behind the barrier); in a build with -DEXORL_GEMM_EXPERIMENTS also
 8388608 = wave-specialised 512-thread workgroups (4 MFMA waves + 4 loader waves), 4194304 = 16x16x32 MFMAs (forward launches),
-1073741824 (+4194304) = per-wave DMA placement in 2 (4) phases, 268435456 = 128 x 64 tiles on a 2-deep ring everywhere.
+1073741824 (+4194304) = per-wave DMA placement in 2 (4) phases, 268435456 = 512-thread workgroups whose 8 waves all load and compute
+(forward launches).
     python tools/micro/ws_bench.py [more masks]"""
 import sys
 from pathlib import Path
