@@ -959,8 +959,12 @@ __device__ unsigned long long g16p_stamps[8 * 1024];
 // tools/micro/fill_bench.hip: ONE wave issues an LDS-DMA piece about every 100 cycles whatever it keeps in flight (4 waves per CU deliver
 // 85 GB/s at 8, 16 or 32 pieces in flight each; 8 waves 117 GB/s, where the CU's L2 path saturates) — a 128 x 64 tile needs 24 pieces per
 // 384 MFMA-cycles, i.e. more issue slots than four waves have.
+// PFD > 0: one more wave (id NW) that computes nothing: it walks PFD stages ahead of the ring and touches this workgroup's 1/32 share of the
+// lines the XCD's tile block will need (one dword per 128-byte line into a dead register), so that the fabric round trip of the FIRST touch of
+// every operand line — each XCD fetches each of its lines exactly once per launch — is taken ahead of the LDS-DMA stream instead of inside it.
+// It joins every stage barrier (that is its pacing: far-ahead lines would push unread ones out of a 4 MB L2) and exits after the last one.
 template <bool AT, bool BT, bool X3, int TN, int KS, int NSTG, int MS = 32, bool WS = false, bool STAMP = false, int ABL = 0, int SPREAD = 1, int STAG = 0,
-          int NW = 4>
+          int NW = 4, int PFD = 0>
 __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned char* smem, int pidx, int m0, int n0) {
     constexpr int NBA = 2, NBB = TN / 64, NPL = X3 ? 2 : 1;
     constexpr int WR = (NW == 8 && TN == 64) ? 32 : 64;     // wave tile: WR rows x WC columns
@@ -994,6 +998,39 @@ __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned cha
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = WS && wave_id >= 4;                 // wave-uniform role
+    if constexpr (PFD > 0) {
+        static_assert(!AT && !BT && KS == 64 && !WS, "the prefetch wave is written for row images on 64-wide stages (one line per row and stage)");
+        if (wave_id == NW) {
+            int nA = 0, nB = 0, rA = 0, rB = 0;
+            if (gb.xcd_map) {                   // the XCD's tile block (xcd_tile): rows rA .. rA + nA of A, rows rB .. rB + nB of B
+                const int X = 8 / gb.count, sm = X == 8 ? 4 : 2, sn = X == 2 ? 1 : 2, xq = (blockIdx.x & 7) % X;
+                const int bm = (P.M >> 7) / sm, bn = (P.N / TN) / sn;
+                nA = bm * 128; rA = (xq / sn) * nA;
+                nB = bn * TN;  rB = (xq % sn) * nB;
+            }
+            const int nl = (nA + nB) * NPL, slot = blockIdx.x >> 3;
+            // every touch loads into the SAME register, which stays live (read-write operand) until the loads have landed: an asm output the
+            // compiler believes dead would be handed to the next value and overwritten when the data arrives
+            unsigned dead = 0;
+            auto touch = [&](int t) {           // this workgroup's share of stage t's lines: line l = (operand, plane, row)
+                for (int l = slot * 64 + lane; l < nl; l += 32 * 64) {
+                    const bool isB = l >= nA * NPL;
+                    const int ll = isB ? l - nA * NPL : l, n = isB ? nB : nA, pl = ll / n, r = ll % n;
+                    const unsigned short* base = isB ? (pl ? P.B_lo : P.B) : (pl ? P.A_lo : P.A);
+                    const unsigned short* ptr = base + (int64_t)((isB ? rB : rA) + r) * (isB ? P.ldb : P.lda) + (int64_t)t * KS;
+                    asm volatile("global_load_dword %0, %1, off" : "+v"(dead) : "v"(ptr) : "memory");
+                }
+            };
+            for (int t = NSTG; t < PFD && t < nst; ++t) touch(t);
+            __builtin_amdgcn_s_barrier();                               // B_0
+            for (int t = 0; t + 1 < nst; ++t) {
+                if (t + PFD < nst) touch(t + PFD);
+                __builtin_amdgcn_s_barrier();                           // B_{t+1}
+            }
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(dead) :: "memory");
+            return;
+        }
+    }
     const int wave = WS ? (wave_id & 3) : wave_id;          // consumer: its 64 x TN/2 quadrant; loader: which pieces of a block it fetches
     const int wm = wave / WN, wn = wave % WN;
     const int h = lane >> 5;
@@ -1328,6 +1365,13 @@ __global__ __launch_bounds__(256) void gemm16p_kernel(const Gemm16Batch gb) {
 }
 
 #ifdef EXORL_GEMM_EXPERIMENTS
+template <bool X3, int TN, int NWV, int PFD, bool STAMP = false>      // NWV computing waves + one prefetch wave PFD stages ahead (forward launches)
+__global__ __launch_bounds__(64 * (NWV + 1)) void gemm16pf_kernel(const Gemm16Batch gb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_p[];
+    int pidx, m0, n0;
+    if (!g16p_tile<TN>(gb, pidx, m0, n0)) return;
+    gemm16p_body<false, false, X3, TN, 64, 2, 32, false, STAMP, 0, 2, 0, NWV, PFD>(gb, smem_p, pidx, m0, n0);
+}
 template <bool AT, bool BT, bool X3, int TN, bool STAMP = false>      // 8 waves per workgroup, all loading and computing; 64-wide stages x 2
 __global__ __launch_bounds__(512) void gemm16p8_kernel(const Gemm16Batch gb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_p[];
@@ -1515,7 +1559,17 @@ static int launch16(const Gemm16Batch& gb, int count, int tiles64, int tiles128,
 #ifdef EXORL_GEMM_EXPERIMENTS      // measured and not adopted ("what was tried on the GEMM"): kept reproducible, not in the default build
         if (x3 && !done) {
             done = true;
-            if (k64 && (var_ & 268435456)) {        // 8 waves per workgroup, all loading and computing (forward launches)
+            if (k64 && (var_ & 134217728) && !(var_ & 67108864) && !stamped) {        // + a prefetch wave (bit 27): 8 + 1 waves on 128 x 64 tiles (with bit
+                if constexpr (AL == 0 && BL == 0) {                                  // 28), 4 + 1 otherwise; bit 30 = 10 instead of 6 stages ahead
+                    const bool far = (var_ & 1073741824) != 0;
+                    if (tn == 64 && (var_ & 268435456) && far) EXORL_TRY(g16p_launch(gemm16pf_kernel<true, 64, 8, 10>, g2, count, true, 64, s, 64, 2, 576));
+                    else if (tn == 64 && (var_ & 268435456)) EXORL_TRY(g16p_launch(gemm16pf_kernel<true, 64, 8, 6>, g2, count, true, 64, s, 64, 2, 576));
+                    else if (tn == 64 && far) EXORL_TRY(g16p_launch(gemm16pf_kernel<true, 64, 4, 10>, g2, count, true, 64, s, 64, 2, 320));
+                    else if (tn == 64) EXORL_TRY(g16p_launch(gemm16pf_kernel<true, 64, 4, 6>, g2, count, true, 64, s, 64, 2, 320));
+                    else if (var_ & 268435456) EXORL_TRY(g16p_launch(gemm16p8_kernel<false, false, true, 128>, g2, count, true, 128, s, 64, 2, 512));
+                    else EXORL_TRY(g16p_launch(gemm16p_kernel<false, false, true, 128, 64, 2, 32, false, 0, 2>, g2, count, true, 128, s, 64, 2));
+                }
+            } else if (k64 && (var_ & 268435456)) {        // 8 waves per workgroup, all loading and computing (forward launches)
                 if constexpr (AL == 0 && BL == 0) {
                     if (tn == 128 && stamped) EXORL_TRY(g16p_launch(gemm16p8_kernel<false, false, true, 128, true>, g2, count, true, 128, s, 64, 2, 512));
                     else if (tn == 128) EXORL_TRY(g16p_launch(gemm16p8_kernel<false, false, true, 128>, g2, count, true, 128, s, 64, 2, 512));
