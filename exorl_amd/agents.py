@@ -142,7 +142,7 @@ class _AgentBase:
                           'queue': (it.queue.cpu(), it.queue_ptr()) if it.queue is not None else None, 'counter': it.counter()}
         skip = {'engine', 'intr', 'actor', 'critic', 'critic_target', 'rnd', 'icm', 'pbe', 'intrinsic_reward_rms', 'disagreement', 'diayn',
                 'predictor', 'predictor_target', 'projector', 'protos', 'queue', 'encoder_target', 'cat_hook', 'aps', 'smm', 'eps_hook', 'aug', 'encoder',
-                'noise_hook', 'shift_hook', '_slots', '_graph_iter', '_graph_stddev', '_ctor', 'rnd_target_encoder', '_dobs'}
+                'noise_hook', 'shift_hook', '_slots', '_graph_iter', '_graph_stddev', '_ctor', 'rnd_target_encoder', '_dobs', '_dp'}
         st['attrs'] = {k: v for k, v in self.__dict__.items() if k not in skip and not k.startswith('_keep')}
         return st
 

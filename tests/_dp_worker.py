@@ -134,6 +134,13 @@ def run_unsup(rank, world, out_dir, result):
             metrics.append({k: float(v) for k, v in m.items()})
             rewards.append(ag.engine._view(ag.engine.batch_slots().reward, Br).cpu().numpy().copy())
         torch.cuda.synchronize()
+        if kind == 'icm_apt':                  # a snapshot taken inside a data-parallel run (pretrain.py:293-300 pickles the agent): the gathered-batch
+            import pickle                      # buffers must not ride along, the clone must carry the module state
+            clone = pickle.loads(pickle.dumps(ag))
+            assert clone.intr.rms_state() == ag.intr.rms_state() and clone.intr.batch == ag.intr.batch
+            for pa, pb in zip(clone.icm.parameters(), ag.icm.parameters()):
+                assert torch.equal(pa, pb)
+            del clone
         np.savez(out_dir / f'unsup_{kind}_rank{rank}.npz', reward=np.stack(rewards),
                  **{n: torch.cat([p.reshape(-1) for p in v.parameters()]).cpu().numpy() for n, v in unsup_views(ag)})
         result[f'unsup_{kind}'] = metrics
