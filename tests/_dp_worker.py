@@ -35,6 +35,8 @@ def build_agent(kind, precision, batch, use_tb):
         ag = agents.TD3BCAgent('td3_bc', (O,), (A,), 'cuda:0', 1e-4, H, 0.01, '0.2', 1, batch, 0.3, use_tb, 2.5, precision=precision)
     elif kind == 'td3':
         ag = agents.TD3Agent('td3', (O,), (A,), 'cuda:0', 1e-4, H, 0.01, '0.2', 1, batch, 0.3, use_tb, precision=precision)
+    elif kind == 'crr':
+        ag = agents.CRRAgent('crr', (O,), (A,), 'cuda:0', 1e-4, H, 0.01, 4, 'exp', '0.2', 1, batch, 0.3, use_tb, precision=precision)
     elif kind == 'cql':
         ag = agents.CQLAgent('cql', (O,), (A,), 'cuda:0', 1e-4, H, 0.01, 1, batch, use_tb, 0.01, 3, 5.0, False, precision=precision)
     else:
@@ -47,19 +49,22 @@ def build_agent(kind, precision, batch, use_tb):
     return ag
 
 
-def sliced_noise_hook(ns, rows):
+def sliced_noise_hook(ns, rows, local_rows):
     """noise_hook over the GLOBAL batch: every draw is made for all B_GLOBAL rows (so that every process consumes the stream alike) and the
-    caller keeps its row slice; CQL's (n, B, A) blocks slice their middle axis and its uniform(-1, 1) actions are a squashed normal draw."""
+    caller keeps its row slice; CQL's (n, B, A) blocks slice their middle axis and its uniform(-1, 1) actions are a squashed normal draw;
+    CRR's (B n, A) block of repeated samples is laid out b * n + sample (crr.py:125, einops 'b x -> (b n) x'): n rows per batch row."""
     def hook(shape, dist='normal'):
         if len(shape) == 2:
-            out = ns.draw((B_GLOBAL, shape[1]))[rows]
+            k = shape[0] // local_rows
+            start, stop, _ = rows.indices(B_GLOBAL)
+            out = ns.draw((k * B_GLOBAL, shape[1]))[k * start:k * stop]
         else:
             out = ns.draw((shape[0], B_GLOBAL, shape[2]))[:, rows]
         return np.ascontiguousarray(np.tanh(out) if dist == 'uniform' else out)
     return hook
 
 
-HOOKED = [('td3', 'fp32'), ('cql', 'fp32')]          # the kinds run through sliced_noise_hook (CQL: its own _run_update branch under torch.distributed)
+HOOKED = [('td3', 'fp32'), ('cql', 'fp32'), ('crr', 'fp32')]          # the kinds run through sliced_noise_hook (CQL: its own _run_update branch under torch.distributed)
 
 
 # ---- reward-free agents (sharded actor / critic step, module step on the all-gathered batch: agents._IntrAgent._intr_step_dp) ----------
@@ -181,7 +186,7 @@ def main():
         assert ag.world_size == world
         st = ReplayBufferStorage((), (), data_dir)
         it = iter(make_replay_loader(st, 10**6, Br, world, True, 1, 0.99, worker_ids=[rank], seed=78))
-        ag.noise_hook = sliced_noise_hook(_synth.NoiseStream(11), slice(rank * Br, (rank + 1) * Br))
+        ag.noise_hook = sliced_noise_hook(_synth.NoiseStream(11), slice(rank * Br, (rank + 1) * Br), Br)
         metrics = [{k: float(v) for k, v in ag.update(it, step).items()} for step in range(STEPS)]
         torch.cuda.synchronize()
         tag = f'{kind}_{precision}'

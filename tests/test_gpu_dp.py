@@ -63,9 +63,9 @@ def test_two_process_dp_equals_single_process(dp_run, tag):
             assert np.mean(d > tol_p[1] + tol_p[0] * np.abs(want)) <= 5e-3 and d.max() <= 6.5e-4, (tag, n, d.max())
 
 
-@pytest.mark.parametrize('tag', ['td3_fp32', 'cql_fp32'])
+@pytest.mark.parametrize('tag', ['td3_fp32', 'cql_fp32', 'crr_fp32'])
 def test_two_process_dp_equals_single_process_hooked(dp_run, tag):
-    """TD3 (no batch-global statistic) and CQL — whose _run_update has its own torch.distributed branch (critic gradients, the summed log pi
+    """TD3 (no batch-global statistic), CRR (value samples repeated n times per row) and CQL — whose _run_update has its own torch.distributed branch (critic gradients, the summed log pi
     behind the entropy temperature, actor gradients) and five noise tensors per step — as two ranks x B/2 against one process x B."""
     import _dp_worker as W
     import _synth
@@ -80,7 +80,7 @@ def test_two_process_dp_equals_single_process_hooked(dp_run, tag):
     ag = W.build_agent(kind, precision, W.B_GLOBAL, True)
     st = ReplayBufferStorage((), (), dp_run['data'])
     its = [iter(make_replay_loader(st, 10**6, W.B_GLOBAL // 2, 2, True, 1, 0.99, worker_ids=[r], seed=78)) for r in (0, 1)]
-    ag.noise_hook = W.sliced_noise_hook(_synth.NoiseStream(11), slice(None))
+    ag.noise_hook = W.sliced_noise_hook(_synth.NoiseStream(11), slice(None), W.B_GLOBAL)
     for step in range(W.STEPS):
         halves = [next(it) for it in its]
         batch = tuple(torch.cat([h[j] for h in halves]) for j in range(5))
