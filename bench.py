@@ -170,9 +170,9 @@ def main():
         local_rank = 0
     if world > 1:
         # N > 1 has never run on real multi-GPU hardware from this repo (one GPU per box): if a collective hangs, leave a traceback and a
-        # non-zero exit within ten minutes instead of holding the node until the driver's limit
+        # non-zero exit within five minutes instead of holding the node until the driver's limit
         import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ.get('EXORL_BENCH_WATCHDOG_S', '600')), exit=True)
+        faulthandler.dump_traceback_later(int(os.environ.get('EXORL_BENCH_WATCHDOG_S', '300')), exit=True)
     torch.cuda.set_device(local_rank)
     device = f'cuda:{local_rank}'
     dist = torch.distributed
