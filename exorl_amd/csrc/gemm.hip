@@ -1202,8 +1202,10 @@ __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned cha
             constexpr bool PENDING = SPREAD > 1 && (s > 0 ? !LAST : !FIRST);
             g16p_static_for<0, NQ - 1>([&](auto qc) {        // all but the last k16 of the stage: read the next k16 of the same stage
                 constexpr int q = decltype(qc)::value;
-                if constexpr (PENDING && q < SPREAD - 1)
+                if constexpr (PENDING && q < SPREAD - 1) {
                     region(fr[q & 1], fr[(q + 1) & 1], T{}, s, std::integral_constant<int, q + 1>{}, Fill{}, (s + NSTG - 1) % NSTG, std::integral_constant<int, q + 1>{}, phase);
+                    if constexpr (STAG == -1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // diagnostic (plain-bf16 anomaly): drain behind the region-0 issue
+                }
                 else
                     region(fr[q & 1], fr[(q + 1) & 1], T{}, s, std::integral_constant<int, q + 1>{}, NoFill{}, 0, C0{}, phase);
             });
@@ -1272,8 +1274,8 @@ __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned cha
             group(F{}, T{}, phase);
         }
     };
-    static_assert(STAG == 0 || ((STAG == 2 || STAG == 4) && NM % STAG == 0 && !WS), "stagger");
-    if constexpr (STAG == 0) kloop(std::integral_constant<int, -1>{});
+    static_assert(STAG <= 0 || ((STAG == 2 || STAG == 4) && NM % STAG == 0 && !WS), "stagger");
+    if constexpr (STAG <= 0) kloop(std::integral_constant<int, -1>{});
     else if constexpr (STAG == 2) { if (wave & 1) kloop(std::integral_constant<int, 1>{}); else kloop(C0{}); }
     else {
         if (wave == 0) kloop(C0{});
@@ -1591,6 +1593,18 @@ static int launch16(const Gemm16Batch& gb, int count, int tiles64, int tiles128,
                     else EXORL_TRY(g16p_launch(gemm16p_kernel<false, false, true, 64, 64, 2, 32, false, 0, 2, 2>, g2, count, true, 64, s, 64, 2));
                 }
             } else done = false;
+        }
+#endif
+#ifdef EXORL_GEMM_EXPERIMENTS
+        if (!x3 && !done && (var_ & 67108864) && !stamped) {        // the plain-bf16 anomaly: SPREAD = 2 on plain planes; bit 27: + drain
+            done = true;
+            if (var_ & 134217728) {
+                if (tn == 128) EXORL_TRY(g16p_launch(gemm16p_kernel<AL != 0, BL != 0, false, 128, 32, 4, 32, false, 0, 2, -1>, g2, count, false, 128, s));
+                else EXORL_TRY(g16p_launch(gemm16p_kernel<AL != 0, BL != 0, false, 64, 32, 4, 32, false, 0, 2, -1>, g2, count, false, 64, s));
+            } else {
+                if (tn == 128) EXORL_TRY(g16p_launch(gemm16p_kernel<AL != 0, BL != 0, false, 128, 32, 4, 32, false, 0, 2>, g2, count, false, 128, s));
+                else EXORL_TRY(g16p_launch(gemm16p_kernel<AL != 0, BL != 0, false, 64, 32, 4, 32, false, 0, 2>, g2, count, false, 64, s));
+            }
         }
 #endif
         if (done) {
