@@ -196,7 +196,8 @@ def test_knn_golden_pbe_and_proto(lib, gold):
     (4, [1, 1, 0, 0], 1, 1024, 1024, 1024),      # critic wgrad + dgrad in one launch
     (2, [0, 0], 0, 1024, 1024, 1024), (2, [0, 0], 1, 1024, 1024, 1024), (2, [1, 0], 1, 1024, 1024, 1024), (1, [0], 0, 2048, 1024, 1024),
     (1, [0], 1, 128, 128, 256), (1, [0], 1, 128, 64, 512), (1, [1], 1, 256, 384, 512), (2, [0, 0], 0, 128, 128, 128), (1, [0], 0, 128, 192, 384),
-    (4, [0, 0, 0, 0], 1, 512, 512, 256), (2, [1, 1], 1, 256, 128, 640)])
+    (4, [0, 0, 0, 0], 1, 512, 512, 256), (2, [1, 1], 1, 256, 128, 640),
+    (2, [0, 0], 0, 10240, 1024, 1024), (2, [0, 0], 1, 4096, 1024, 1024), (2, [1, 1], 1, 1024, 1024, 4096)])       # CQL's 10 B-row pass; B = 4096: dgrad rows, wgrad reduction length
 def test_gemm_planes_shapes(lib, x3, count, a_layouts, bl, M, N, K):
     """The grouped H x H GEMM on bf16 hi/lo planes (exorl_gemm_planes: what the agent's six launches call), every operand layout, launch shapes
     from one stage ring (K = 128) to 32, with REAL lo planes: equal to the float64 product of the same planes (minus lo*lo, which the kernel
