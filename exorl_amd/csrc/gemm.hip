@@ -1163,7 +1163,6 @@ __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned cha
         constexpr bool HN = decltype(has_next)::value;
         constexpr int NFILL = decltype(nfill)::value;
         constexpr int F0 = decltype(chunk)::value * NP / SPREAD, F1 = (decltype(chunk)::value + 1) * NP / SPREAD;      // this region's share of the refill
-        fence(cur);
         g16p_static_for<0, NM>([&](auto ic) {
             constexpr int I = decltype(ic)::value;
             if constexpr (ABL != 3) mfma_one(cur, ic);
@@ -1179,6 +1178,13 @@ __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned cha
             }
             __builtin_amdgcn_sched_barrier(0);
         });
+        // The fence of the fragments just requested closes the region that issued them — the same place in the instruction stream as the head
+        // of the next region, but inside the same basic block. Round 2 had it at the head of the consuming region: wherever a branch or a loop
+        // back-edge lay between the two (the nst == NSTG test behind the prologue reads, the group loop) the register allocator was free to
+        // resolve the join with v_mov copies of the asm outputs BEFORE the wait, i.e. copies of registers the LDS had not written yet
+        // (tools/check_async_reads.py shows them in the round-2 ISA of every SPREAD = 2 kernel with a k-image operand, split-bf16 included;
+        // the plain-bf16 launches — 2-4 MFMAs between the reads and the copy — lost that race visibly: DESIGN 4, "the SPREAD = 2 anomaly").
+        if constexpr (HN && ABL != 2) fence(nxt);
     };
     // a stage has landed for this wave once at most `younger` younger stages' pieces are outstanding (NP per stage)
     auto wait_landed = [&](auto younger) {
@@ -1204,7 +1210,6 @@ __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned cha
                 constexpr int q = decltype(qc)::value;
                 if constexpr (PENDING && q < SPREAD - 1) {
                     region(fr[q & 1], fr[(q + 1) & 1], T{}, s, std::integral_constant<int, q + 1>{}, Fill{}, (s + NSTG - 1) % NSTG, std::integral_constant<int, q + 1>{}, phase);
-                    if constexpr (STAG == -1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // diagnostic (plain-bf16 anomaly): drain behind the region-0 issue
                 }
                 else
                     region(fr[q & 1], fr[(q + 1) & 1], T{}, s, std::integral_constant<int, q + 1>{}, NoFill{}, 0, C0{}, phase);
@@ -1262,6 +1267,7 @@ __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned cha
     asm volatile("" ::: "memory");
     stamp(1);
     g16p_static_for<0, NF>([&](auto jc) { read_one(fr[0], 0, std::integral_constant<int, 0>{}, jc); });
+    fence(fr[0]);                               // before any control flow (see region())
     auto kloop = [&](auto phase) {
         if constexpr (SPREAD == 1) {
             for (int t = 0; t + NSTG < nst; t += NSTG) group(F{}, F{}, phase);
@@ -1595,18 +1601,6 @@ static int launch16(const Gemm16Batch& gb, int count, int tiles64, int tiles128,
             } else done = false;
         }
 #endif
-#ifdef EXORL_GEMM_EXPERIMENTS
-        if (!x3 && !done && (var_ & 67108864) && !stamped) {        // the plain-bf16 anomaly: SPREAD = 2 on plain planes; bit 27: + drain
-            done = true;
-            if (var_ & 134217728) {
-                if (tn == 128) EXORL_TRY(g16p_launch(gemm16p_kernel<AL != 0, BL != 0, false, 128, 32, 4, 32, false, 0, 2, -1>, g2, count, false, 128, s));
-                else EXORL_TRY(g16p_launch(gemm16p_kernel<AL != 0, BL != 0, false, 64, 32, 4, 32, false, 0, 2, -1>, g2, count, false, 64, s));
-            } else {
-                if (tn == 128) EXORL_TRY(g16p_launch(gemm16p_kernel<AL != 0, BL != 0, false, 128, 32, 4, 32, false, 0, 2>, g2, count, false, 128, s));
-                else EXORL_TRY(g16p_launch(gemm16p_kernel<AL != 0, BL != 0, false, 64, 32, 4, 32, false, 0, 2>, g2, count, false, 64, s));
-            }
-        }
-#endif
         if (done) {
         } else if (x3 && k64) {
             if constexpr (AL == 0 && BL == 0) {
@@ -1633,12 +1627,15 @@ static int launch16(const Gemm16Batch& gb, int count, int tiles64, int tiles128,
         } else if (x3) {
             if (tn == 128) EXORL_TRY(g16p_launch(gemm16p_kernel<AL != 0, BL != 0, true, 128, 32, 4, 32, false, 0, 2>, g2, count, true, 128, s));
             else EXORL_TRY(g16p_launch(gemm16p_kernel<AL != 0, BL != 0, true, 64, 32, 4, 32, false, 0, 2>, g2, count, true, 64, s));
-        } else {
-            // plain bf16 planes keep the refill in one region: with SPREAD = 2 the k-image B operand came out wrong on these 2-4-MFMA regions
-            // (tests/test_gpu_ops.py::test_gemm_bf16_operands, non-deterministically; the split-bf16 launches, 6-12 MFMAs per region, hold
-            // bit-exact results at every shape of test_gemm_planes_shapes) — unexplained, so not used where it was seen
+        } else if (sp1) {
             if (tn == 128) EXORL_TRY(g16p_launch(gemm16p_kernel<AL != 0, BL != 0, false, 128>, g2, count, false, 128, s));
             else EXORL_TRY(g16p_launch(gemm16p_kernel<AL != 0, BL != 0, false, 64>, g2, count, false, 64, s));
+        } else {
+            // plain bf16 planes take the two-region refill as well (round 3). Round 2 kept them on SPREAD = 1 because the k-image B operand came out
+            // wrong, run-to-run different, under SPREAD = 2: that was the pre-fence register copy described in region() — a compiler-placed v_mov of
+            // an asm-issued LDS read's destination — not the schedule (tests/test_gpu_ops.py::test_gemm_plain_bf16_k_image_regression).
+            if (tn == 128) EXORL_TRY(g16p_launch(gemm16p_kernel<AL != 0, BL != 0, false, 128, 32, 4, 32, false, 0, 2>, g2, count, false, 128, s));
+            else EXORL_TRY(g16p_launch(gemm16p_kernel<AL != 0, BL != 0, false, 64, 32, 4, 32, false, 0, 2>, g2, count, false, 64, s));
         }
         if (prof) {
             EXORL_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s));
@@ -1777,9 +1774,12 @@ int gemm16_grouped_mixed(const int* a_layouts, const Gemm16Problem* probs, int c
         } else if (x3) {
             if (tn == 128) EXORL_TRY(g16p_launch(gemm16p_mixed_kernel<true, 128, 2>, gb, count, true, 128, s));
             else EXORL_TRY(g16p_launch(gemm16p_mixed_kernel<true, 64, 2>, gb, count, true, 64, s));
-        } else {
+        } else if (sp1) {
             if (tn == 128) EXORL_TRY(g16p_launch(gemm16p_mixed_kernel<false, 128>, gb, count, false, 128, s));
             else EXORL_TRY(g16p_launch(gemm16p_mixed_kernel<false, 64>, gb, count, false, 64, s));
+        } else {
+            if (tn == 128) EXORL_TRY(g16p_launch(gemm16p_mixed_kernel<false, 128, 2>, gb, count, false, 128, s));
+            else EXORL_TRY(g16p_launch(gemm16p_mixed_kernel<false, 64, 2>, gb, count, false, 64, s));
         }
     } else if (x3) {
         gb.count = count;

@@ -89,6 +89,79 @@ def test_gemm_bf16_operands(lib, al, bl, M, N, K):
         assert err.max() < 2e-6, (al, bl, M, N, K, relu, acc, err.max())
 
 
+@pytest.mark.parametrize('al', [0, 1])
+@pytest.mark.parametrize('M,N,K', [(128, 128, 256), (256, 384, 512), (1024, 1024, 1024)])
+def test_gemm_plain_bf16_k_image_regression(lib, al, M, N, K):
+    """Round 2's unexplained wrong results: plain-bf16 planes with a k-image B operand under the two-region stage refill (SPREAD = 2) came out
+    wrong and run-to-run different — in 20 of 20 launches at 1024^3. Cause (round 3, read off the ISA with tools/check_async_reads.py): the fence
+    of the asm-issued ds_read_b64_tr_b16 fragments sat behind a branch, and the register allocator resolved the join with v_mov copies of their
+    destination registers BEFORE the wait. Fixed in gemm16p_body (fence in the issuing basic block); plain bf16 now takes SPREAD = 2 by default,
+    so this is the formerly failing launch: 20 launches per shape, each equal to the float64 product, all bit-identical."""
+    from exorl_amd import _lib as L
+    rs = np.random.RandomState(0)
+    A = bf16_round(rs.standard_normal((M, K)).astype(np.float32))
+    B = bf16_round(rs.standard_normal((K, N)).astype(np.float32))
+    bias = rs.standard_normal(N).astype(np.float32)
+    A_st = A if al == 0 else np.ascontiguousarray(A.T)
+    a = torch.from_numpy(A_st).cuda().to(torch.bfloat16).contiguous()
+    b = torch.from_numpy(B).cuda().to(torch.bfloat16).contiguous()
+    bi = dev(bias)
+    ref = A.astype(np.float64) @ B.astype(np.float64) + bias
+    scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64) + 1.0
+    first = None
+    for it in range(20):
+        c = torch.full((M, N), float('nan'), device='cuda')
+        L.check(lib.exorl_gemm_bf16(al, 1, M, N, K, a.data_ptr(), A_st.shape[1], b.data_ptr(), N, c.data_ptr(), N, bi.data_ptr(), 0, 0, None))
+        torch.cuda.synchronize()
+        got = c.cpu().numpy()
+        assert (np.abs(got - ref) / scale).max() < 2e-6, (al, M, N, K, it)
+        first = got if first is None else first
+        assert np.array_equal(got, first), (al, M, N, K, it)
+
+
+def test_gemm_first_launch_of_a_fresh_process():
+    """The single-tile form of the same failure showed only in the FIRST launch of a process (cold instruction cache: the waves of a workgroup
+    drift apart, the LDS returns late). One fresh interpreter per layout pair makes exactly one launch of each kernel family — plain-bf16 and
+    split-bf16 planes, k-image operands — and compares it with the float64 product."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    code = r"""
+import sys, ctypes as C
+import numpy as np, torch
+sys.path.insert(0, %r)
+from exorl_amd import _lib as L
+lib = L.load()
+al, x3 = int(sys.argv[1]), int(sys.argv[2])
+M, N, K = 128, 128, 256
+g = torch.Generator(device='cuda').manual_seed(1)
+A = torch.randn((M, K) if al == 0 else (K, M), device='cuda', generator=g)
+B = torch.randn((K, N), device='cuda', generator=g)
+split = lambda x: (x.to(torch.bfloat16), (x - x.to(torch.bfloat16).float()).to(torch.bfloat16))
+(ah, al_), (bh, bl_) = split(A), split(B)
+c = torch.full((M, N), float('nan'), device='cuda')
+if x3:
+    arr = lambda t: (C.c_void_p * 1)(t.data_ptr())
+    L.check(lib.exorl_gemm_planes(1, (C.c_int32 * 1)(al), 1, M, N, K, arr(ah), arr(al_), A.shape[1], arr(bh), arr(bl_), N, arr(c), N, 0, None))
+    Ad, Bd = ah.double() + al_.double(), bh.double() + bl_.double()
+    lolo = al_.double() @ bl_.double() if al == 0 else al_.double().T @ bl_.double()
+else:
+    L.check(lib.exorl_gemm_bf16(al, 1, M, N, K, ah.data_ptr(), A.shape[1], bh.data_ptr(), N, c.data_ptr(), N, None, 0, 0, None))
+    Ad, Bd, lolo = ah.double(), bh.double(), 0.0
+torch.cuda.synchronize()
+ref = (Ad if al == 0 else Ad.T) @ Bd - lolo
+scale = (Ad.abs() if al == 0 else Ad.abs().T) @ Bd.abs() + 1.0
+err = float(((c.double() - ref).abs() / scale).max())
+print('ERR', err)
+sys.exit(0 if err < 2e-6 else 3)
+""" % str(root)
+    for al in (0, 1):
+        for x3 in (0, 1):
+            r = subprocess.run([sys.executable, '-c', code, str(al), str(x3)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+            assert r.returncode == 0, (al, x3, r.stdout[-2000:])
+
+
 def test_gemm_f32_is_exact_fp32_products(lib):
     """Parity mode must not round operands: integers up to 2^12 multiply exactly in fp32 MFMA."""
     from exorl_amd import _lib as L

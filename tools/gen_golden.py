@@ -409,6 +409,118 @@ def gen_pixel_proto(ref):
     print('pixel proto', keys, out['metrics'][-1])
 
 
+CONFIG4 = dict(C=3, HW=84, A=9, F=50, H=1024, B=1024, N=3, PD=128, PJ=512, Q=2048, NP=512)
+
+
+def config4_inputs(step, B, C, HW, A, NP):
+    """Inputs of update() number `step` of the config-4 fixture, regenerated from seeds on both sides (nothing batch-sized is stored):
+    uint8 frames, the (action, reward, discount) rows, the two augmentation shift blocks and the Categorical uniforms."""
+    rs = np.random.RandomState(4000 + step)
+    obs = rs.randint(0, 256, (B, C, HW, HW)).astype(np.uint8)
+    nobs = rs.randint(0, 256, (B, C, HW, HW)).astype(np.uint8)
+    b = _synth.synth_batch(3, step, B, 4, A)
+    so, sn = rs.randint(0, 9, (B, 2)).astype(np.int32), rs.randint(0, 9, (B, 2)).astype(np.int32)
+    u = rs.uniform(size=NP).astype(np.float32)
+    return obs, nobs, b[1], b[2], b[3], so, sn, u
+
+
+def config4_params(C, A, F, H, PD, PJ, NP, R=39200):
+    """Explicit weights of the config-4 fixture: He-scaled convolutions (encodings stay O(1), as under the reference's own orthogonal
+    init), 1/sqrt(fan_in) Linear layers. Returns dict module -> ordered dict of arrays (reference state_dict keys)."""
+    enc_keys = [f'convnet.{i}.{w}' for i in (0, 2, 4, 6) for w in ('weight', 'bias')]
+    esh = list(zip(enc_keys, [s for l in range(4) for s in ((32, C if l == 0 else 32, 3, 3), (32,))]))
+    tr = [('trunk.0.weight', (F, R)), ('trunk.0.bias', (F,)), ('trunk.1.weight', (F,)), ('trunk.1.bias', (F,))]
+    head = lambda pre, i_, o_: [(f'{pre}.0.weight', (H, i_)), (f'{pre}.0.bias', (H,)), (f'{pre}.2.weight', (H, H)), (f'{pre}.2.bias', (H,)),
+                                (f'{pre}.4.weight', (o_, H)), (f'{pre}.4.bias', (o_,))]
+    ash = tr + head('policy', F, A)
+    csh = tr + head('Q1', F + A, 1) + head('Q2', F + A, 1)
+    return {'encoder': _synth.synth_conv_params(esh, 70), 'actor': _synth.synth_params(ash, 71), 'critic': _synth.synth_params(csh, 72),
+            'predictor': _synth.synth_params([('weight', (PD, R)), ('bias', (PD,))], 73),
+            'projector': _synth.synth_params([('trunk.0.weight', (PJ, PD)), ('trunk.0.bias', (PJ,)), ('trunk.2.weight', (PD, PJ)), ('trunk.2.bias', (PD,))], 74),
+            'protos': _synth.synth_params([('weight', (NP, PD))], 75)}
+
+
+def _run_config4(ref, threads):
+    import time
+    import torch.distributions as pyd
+    U = ref.utils
+    c = CONFIG4
+    C, HW, A, F, H, B, N, PD, PJ, Q, NP = (c[k] for k in ('C', 'HW', 'A', 'F', 'H', 'B', 'N', 'PD', 'PJ', 'Q', 'NP'))
+    torch.set_num_threads(threads)
+    torch.manual_seed(5)
+    agent = ref.proto.ProtoAgent(pred_dim=PD, proj_dim=PJ, queue_size=Q, num_protos=NP, tau=0.1, encoder_target_tau=0.05, topk=3, update_encoder=True,
+                                 name='proto', reward_free=True, obs_type='pixels', obs_shape=(C, HW, HW), action_shape=(A,), device='cpu', lr=1e-4,
+                                 feature_dim=F, hidden_dim=H, critic_target_tau=0.01, num_expl_steps=2000, update_every_steps=2,
+                                 stddev_schedule=0.2, nstep=3, batch_size=B, stddev_clip=0.3, init_critic=True, use_tb=True, use_wandb=False)
+    params = config4_params(C, A, F, H, PD, PJ, NP)
+    mods = (('encoder', agent.encoder), ('actor', agent.actor), ('critic', agent.critic), ('predictor', agent.predictor),
+            ('projector', agent.projector), ('protos', agent.protos))
+    for nm, net in mods:
+        sd = net.state_dict()
+        assert list(sd.keys()) == list(params[nm].keys()), (nm, list(sd.keys()))
+        net.load_state_dict({k: torch.from_numpy(v).reshape(sd[k].shape) for k, v in params[nm].items()})
+    agent.critic_target.load_state_dict(agent.critic.state_dict())
+    agent.encoder_target.load_state_dict(agent.encoder.state_dict())
+    agent.predictor_target.load_state_dict(agent.predictor.state_dict())
+    noise = _synth.NoiseStream(22)
+    o_sn, o_randint, o_cat = U._standard_normal, torch.randint, pyd.Categorical.sample
+    state = {}
+
+    def p_randint(lo, hi, size, device=None, dtype=None):
+        sh = state['shifts'].pop(0)
+        assert tuple(size) == (B, 1, 1, 2) and lo == 0 and hi == 9, (lo, hi, size)
+        return torch.from_numpy(sh.reshape(tuple(size)).astype(np.int64)).to(dtype)
+
+    def p_cat(self, sample_shape=torch.Size()):
+        u = state['u'].astype(np.float64)
+        cdf = torch.cumsum(self.probs.double(), dim=1).numpy()
+        idx = [min(int(np.searchsorted(cdf[i], u[i] * cdf[i, -1], side='right')), cdf.shape[1] - 1) for i in range(len(u))]
+        return torch.tensor(idx, dtype=torch.long)
+    U._standard_normal = lambda shape, dtype, device: torch.from_numpy(noise.draw(shape)).to(dtype)
+    torch.randint, pyd.Categorical.sample = p_randint, p_cat
+    metrics = []
+    try:
+        for i in range(N):
+            obs, nobs, act, rew, disc, so, sn, u = config4_inputs(i, B, C, HW, A, NP)
+            state['shifts'], state['u'] = [so, sn], u
+            t0 = time.time()
+            m = agent.update(iter([(obs, act, rew, disc, nobs)]), 2 * i)
+            print(f'config4 reference ({threads} threads) step {i}: {time.time() - t0:.1f} s', {k: round(float(v), 6) for k, v in m.items()}, flush=True)
+            metrics.append({k: float(v) for k, v in m.items()})
+    finally:
+        U._standard_normal, torch.randint, pyd.Categorical.sample = o_sn, o_randint, o_cat
+    return agent, mods, params, metrics
+
+
+def gen_config4(ref):
+    """BASELINE.json configs[3] AT ITS OWN SIZES, run through the reference itself: ProtoAgent(obs_type='pixels') on (3, 84, 84) uint8 frames,
+    A = 9, feature_dim 50, hidden 1024, pred_dim 128, proj_dim 512, 512 prototypes, queue 2048, nstep 3, batch 1024 (configs/agent/proto.yaml +
+    pretrain.yaml), three update() calls on the CPU in fp32 — twice: on all threads and on ONE thread. The two runs differ only in the
+    blocking of torch's conv / addmm partial sums, i.e. their difference is the reference's own fp32 reproducibility floor at this size
+    (`metrics_1thread`; the tests quote it next to the bar). Stored: per-step metrics, every 997th element of every final and initial tensor,
+    a queue sample. Frames, rows, shifts, uniforms and noise are regenerated from seeds (config4_inputs)."""
+    agent, mods, params, metrics = _run_config4(ref, os.cpu_count() or 8)
+    _, _, _, metrics1 = _run_config4(ref, 1)
+    c = CONFIG4
+    out = {'dims': np.array([c[k] for k in ('C', 'HW', 'A', 'F', 'H', 'B', 'N', 'PD', 'PJ', 'Q', 'NP')])}
+    keys = sorted(metrics[0].keys())
+    out['metric_keys'] = np.array(keys)
+    out['metrics'] = np.array([[m[k] for k in keys] for m in metrics], np.float64)
+    out['metrics_1thread'] = np.array([[m[k] for k in keys] for m in metrics1], np.float64)
+    samp = lambda w: w.copy() if w.size <= 4096 else w.reshape(-1)[::997].copy()
+    for nm, net in mods + (('critic_target', agent.critic_target), ('encoder_target', agent.encoder_target), ('predictor_target', agent.predictor_target)):
+        for k, v in net.state_dict().items():
+            v = v.numpy()
+            out[f'final_sample/{nm}/{k}'] = samp(v)
+            out[f'init_sample/{nm}/{k}'] = samp(params[nm.replace('_target', '')][k].reshape(v.shape))
+    out['final/queue_sample'], out['final/queue_ptr'] = agent.queue.numpy().reshape(-1)[::97].copy(), np.array(agent.queue_ptr)
+    np.savez_compressed(GOLD / 'config4_proto_b1024.npz', **out)
+    rel = np.abs(out['metrics'] - out['metrics_1thread']) / (np.abs(out['metrics']) + 1e-12)
+    print('config4 proto', keys)
+    print(out['metrics'])
+    print('relative difference all-threads vs 1 thread per step:', rel.max(axis=1), 'worst key per step', [keys[j] for j in rel.argmax(axis=1)])
+
+
 # ----------------------------------------------------------------------------- agents (G3/G4)
 PIXEL_INTR = ('icm', 'icm_apt', 'disagreement', 'diayn', 'aps', 'smm', 'rnd')
 
@@ -776,7 +888,7 @@ if __name__ == '__main__':
     args = ap.parse_args()
     GOLD.mkdir(parents=True, exist_ok=True)
     ref = load_reference()
-    todo = [args.only] if args.only else ['replay', 'offline', 'utils', 'tiny', 'full', 'pixels', 'pixel_ddpg', 'pixel_proto'] + [f'pixel_{k}' for k in PIXEL_INTR]
+    todo = [args.only] if args.only else ['replay', 'offline', 'utils', 'tiny', 'full', 'pixels', 'pixel_ddpg', 'pixel_proto', 'config4'] + [f'pixel_{k}' for k in PIXEL_INTR]
     kinds = args.kinds.split(',') if args.kinds else None
     if kinds:
         TINY_KINDS = tuple(k for k in TINY_KINDS if k.partition('-')[0] in kinds)
@@ -785,7 +897,7 @@ if __name__ == '__main__':
             gen_full(ref, only_kinds=kinds)
         else:
             fns = {'replay': gen_replay, 'offline': gen_offline, 'utils': gen_utils, 'tiny': gen_tiny, 'pixels': gen_pixels, 'pixel_ddpg': gen_pixel_ddpg,
-                   'pixel_proto': gen_pixel_proto}
+                   'pixel_proto': gen_pixel_proto, 'config4': gen_config4}
             if t.startswith('pixel_') and t[6:] in PIXEL_INTR:
                 gen_pixel_intr(ref, t[6:])
             else:
