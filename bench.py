@@ -17,6 +17,13 @@ Default precision is `bf16x3` (split-bf16 MFMA operands, hi*hi + hi*lo + lo*hi):
 north-star parity bar (per-step losses within 1e-4 rtol of the fp32 reference, tests/test_gpu_agent.py). The plain-bf16
 mode (faster, ~4e-4 drift) and the exact-fp32 mode are timed briefly afterwards and reported under `other_modes`.
 
+Other workloads of BASELINE.json through the same harness: `--config 5` = TD3 on cheetah_run shapes (O=17, A=6), 10 M transitions, global batch
+4096 (512 per GPU on 8). `--scaling strong` fixes the GLOBAL batch at the config's (per-rank B/N; `value` = global steps per second, SURVEY 8d's
+definition of the curve); the default `weak` fixes the per-GPU batch.
+N > 1 is timed on the collective path the two-process tests execute (torch.distributed.all_reduce — RCCL under nccl — between the library's
+phases); the library's own RCCL communicator with the whole data-parallel step captured as one hipGraph is then tried behind a watchdog and
+reported when it completes (it has never met a second GPU on this pool: if it hangs, the first number is printed and the process exits 0).
+
 Prints ONE JSON line on rank 0. Extra legs (rank 0, N=1 only): `roofline` — the dominant kernel (the grouped
 1024^3 MFMA GEMM) timed per launch with HIP events on its own stream in a separate instrumented pass of the
 same loop; `cpu_baseline` — a torch-CPU twin of the reference's update (oracle/torch_twin.py: the library ops the reference
@@ -35,13 +42,18 @@ import torch
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-O, A, H, B = 24, 6, 1024, 1024          # walker_walk states / td3_bc.yaml
+O, A, H, B = 24, 6, 1024, 1024          # walker_walk states / td3_bc.yaml (BASELINE configs[1]); --config 5 rebinds them
 EPISODES, EP_LEN = 1000, 1000           # 1 M transitions
 GAMMA = 0.99
+CONFIGS = {     # BASELINE.json configs by their 1-based number: agent, O, A, global batch, episodes, per-GPU batch under weak scaling
+    2: dict(agent='td3_bc', task='walker_walk', O=24, A=6, B=1024, episodes=1000, weak_b=1024),
+    5: dict(agent='td3', task='cheetah_run', O=17, A=6, B=4096, episodes=10000, weak_b=512),
+}
 PEAK_TFLOPS = {'bf16': 2500.0, 'bf16x3': 2500.0, 'fp32': 157.3}     # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 
 
-def algorithmic_flops_per_step(batch=B):
+def algorithmic_flops_per_step(batch=None):
+    batch = B if batch is None else batch
     actor = O * H + H * H + H * A
     critic = 2 * ((O + A) * H + H * H + H)
     a_f, c_f = 2 * actor * batch, 2 * critic * batch
@@ -143,11 +155,16 @@ def spawn_ranks(n):
 
 
 def main():
+    global O, A, B, EPISODES
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2000)
     ap.add_argument('--warmup', type=int, default=200)
     ap.add_argument('--precision', default=os.environ.get('EXORL_PRECISION', 'bf16x3'), choices=['bf16', 'bf16x3', 'fp32'])
+    ap.add_argument('--config', type=int, default=2, choices=sorted(CONFIGS), help='BASELINE.json configs entry (1-based): 2 = TD3+BC walker_walk, global '
+                    'batch 1024 (the headline metric); 5 = TD3 cheetah_run, 10 M transitions, global batch 4096 (8 x 512)')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'], help='weak: per-GPU batch fixed (config 2: 1024, config 5: 512), value counts '
+                    'per-GPU-batch step-equivalents; strong: GLOBAL batch fixed at the config\'s (per-rank B/N), value = global steps/s (SURVEY 8d)')
     ap.add_argument('--no-other-modes', action='store_true')
     ap.add_argument('--rehearse', action='store_true',
                     help='multi-rank dry run on ONE GPU: gloo backend, every rank on cuda:0 (exercises the data-parallel code path; not a measurement)')
@@ -155,6 +172,8 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--graph', type=int, default=int(os.environ.get('EXORL_GRAPH', '1')))
     ap.add_argument('--branches', type=int, default=int(os.environ.get('EXORL_BRANCHES', '0')))
+    ap.add_argument('--native-comm', type=int, default=int(os.environ.get('EXORL_BENCH_NATIVE', '1')),
+                    help='N > 1 on nccl: after the torch.distributed-path number, try the library\'s own RCCL communicator + captured step behind a watchdog')
     ap.add_argument('--dp1', action='store_true', help='N=1 only: attach a 1-rank RCCL communicator, i.e. time the library-driven data-parallel step '
                     '(finalised gradients -> ncclAllReduce -> unfused Adam) on one GPU; a diagnostic, not the metric')
     args = ap.parse_args()
@@ -166,11 +185,19 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if args.gpus != world:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a number for a different topology')
+    cfg = CONFIGS[args.config]
+    O, A, B, EPISODES = cfg['O'], cfg['A'], cfg['B'], cfg['episodes']
+    if args.scaling == 'strong':
+        if B % world:
+            raise SystemExit(f'--scaling strong: global batch {B} does not divide over {world} ranks')
+        PB = B // world                     # per-rank rows of the fixed global batch
+    else:
+        PB = cfg['weak_b']
+    global_batch = PB * world
     if args.rehearse:
         local_rank = 0
     if world > 1:
-        # N > 1 has never run on real multi-GPU hardware from this repo (one GPU per box): if a collective hangs, leave a traceback and a
-        # non-zero exit within five minutes instead of holding the node until the driver's limit
+        # if a collective hangs, leave a traceback and a non-zero exit within five minutes instead of holding the node until the driver's limit
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ.get('EXORL_BENCH_WATCHDOG_S', '300')), exit=True)
     torch.cuda.set_device(local_rank)
@@ -191,14 +218,16 @@ def main():
 
     def build(precision):
         torch.manual_seed(1)
-        ag = agents.TD3BCAgent('td3_bc', (O,), (A,), device, 1e-4, H, 0.01, '0.2', 1, B, 0.3, False, 2.5,
-                               precision=precision, seed=1 + rank)
+        if cfg['agent'] == 'td3_bc':
+            ag = agents.TD3BCAgent('td3_bc', (O,), (A,), device, 1e-4, H, 0.01, '0.2', 1, PB, 0.3, False, 2.5, precision=precision, seed=1 + rank)
+        else:
+            ag = agents.TD3Agent('td3', (O,), (A,), device, 1e-4, H, 0.01, '0.2', 1, PB, 0.3, False, precision=precision, seed=1 + rank)
         if world > 1:                       # identical initial weights on every rank
             for net in (ag.actor, ag.critic, ag.critic_target):
                 for p in net.parameters():
                     dist.broadcast(p, 0)
             ag.params_changed()
-        rit = ArenaIterator(replay, B, 1, GAMMA, 'philox')
+        rit = ArenaIterator(replay, PB, 1, GAMMA, 'philox')
         ag.engine.set_parallel_branches(args.branches)
         if args.dp1 and world == 1:
             from exorl_amd.comm import Comm
@@ -211,10 +240,7 @@ def main():
                 print(f'[bench] rank {rank}: hipGraph capture unavailable ({e}); stepping eagerly', file=sys.stderr, flush=True)
         return ag, rit, use
 
-    agent, it, use_graph = build(args.precision)
-
-    def run(n, step0, ag=None, rit=None):
-        ag, rit = ag or agent, rit or it
+    def run(n, step0, ag, rit):
         for i in range(n):
             ag.update(rit, step0 + i)
 
@@ -224,39 +250,93 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    run(args.warmup, 0)
-    fence()
-    t0 = time.perf_counter()
-    run(args.steps, args.warmup)
-    fence()
-    dt = time.perf_counter() - t0
+    def timed(ag, rit):
+        """W warm-up steps, then exactly K steps between two barrier + synchronize fences; MAX over ranks."""
+        run(args.warmup, 0, ag, rit)
+        fence()
+        t0 = time.perf_counter()
+        run(args.steps, args.warmup, ag, rit)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    agent, it, use_graph = build(args.precision)
+    dt = timed(agent, it)
     ranks_seen = [0]
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
         seen = [torch.zeros(1, device=device, dtype=torch.int64) for _ in range(world)]
         dist.all_gather(seen, torch.tensor([rank], device=device, dtype=torch.int64))
         ranks_seen = sorted(int(x.item()) for x in seen)
 
-    out = None
-    if rank == 0:
-        flops = algorithmic_flops_per_step()
-        out = {
-            'metric': 'gradient-steps/sec TD3+BC walker_walk batch=1024', 'value': world * args.steps / dt,
-            'unit': 'gradient-steps/s (batch-1024 step-equivalents)', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+    def collectives_of(ag):
+        if world == 1:
+            return None
+        return ('RCCL all-reduce enqueued by libexorl_hip.so between its phases (exorl_comm_*)' if ag.engine.comm is not None
+                else 'torch.distributed.all_reduce between exorl_agent_update_phase calls')
+
+    def result(dt_, graph_, coll_):
+        per_s = args.steps / dt_
+        flops = algorithmic_flops_per_step(PB)
+        weak = args.scaling == 'weak'
+        label = {'td3_bc': 'TD3+BC', 'td3': 'TD3'}[cfg['agent']]
+        return {
+            'metric': f"gradient-steps/sec {label} {cfg['task']} batch={B}", 'value': (world if weak else 1) * per_s,
+            'unit': f'gradient-steps/s (batch-{PB} step-equivalents)' if weak else f'gradient-steps/s (global batch {global_batch})', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt_ / args.steps, 'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None, 'dtype': {'bf16': 'bf16', 'bf16x3': 'bf16x3', 'fp32': 'f32'}[args.precision], 'data': 'synthetic',
-            'config': {'workload': 'TD3+BC walker_walk (O=24,A=6,H=1024), 1M-transition replay in HBM, batch 1024/GPU, '
-                                   'nstep=1, Philox sampler, use_tb=False', 'global_batch': B * world,
-                       'parallelism': f'dp{world}', 'dp_collectives': None if world == 1 else ('RCCL all-reduce enqueued by libexorl_hip.so between its phases (exorl_comm_*)' if agent.engine.comm is not None else 'torch.distributed.all_reduce between exorl_agent_update_phase calls'),
-                       'hip_graph': use_graph, 'graph_parallel_branches': bool(args.branches) and use_graph,
+            'config': {'workload': f"{label} {cfg['task']} (O={O},A={A},H={H}), {EPISODES * EP_LEN // 1000000}M-transition replay in HBM, batch {PB}/GPU, "
+                                   'nstep=1, Philox sampler, use_tb=False', 'baseline_config': args.config, 'global_batch': global_batch, 'per_gpu_batch': PB,
+                       'parallelism': f'dp{world}', 'dp_collectives': coll_,
+                       'hip_graph': graph_, 'graph_parallel_branches': bool(args.branches) and graph_,
                        'mfma_operands': {'bf16': 'bf16 (fp32 accumulate, fp32 master weights)', 'fp32': 'fp32',
                                          'bf16x3': 'split bf16: hi*hi + hi*lo + lo*hi (fp32 accumulate); within the 1e-4 parity bar'}[args.precision]},
             'ranks_seen': ranks_seen,
             'algorithmic_gflop_per_step': flops / 1e9,
-            'step_frac_of_mfma_peak': (world * args.steps / dt) * flops / 1e12 / (PEAK_TFLOPS[args.precision] * world),
+            'step_frac_of_mfma_peak': per_s * flops / 1e12 / PEAK_TFLOPS[args.precision],
         }
+
+    out = result(dt, use_graph, collectives_of(agent)) if rank == 0 else None
+    if world > 1 and args.native_comm and not args.rehearse and agent.engine.comm is None:
+        # Second leg: the library's own RCCL communicator, whole data-parallel step captured as one hipGraph. It has only ever run as a 1-rank
+        # communicator on this pool, so it runs behind its own watchdog: on a hang the number already in hand is printed and every rank exits 0.
+        import faulthandler
+        import threading
+        faulthandler.cancel_dump_traceback_later()
+
+        def give_up():
+            if rank == 0:
+                out['native_comm'] = {'status': 'timed out (watchdog): the torch.distributed-path number above stands'}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        dog = threading.Timer(float(os.environ.get('EXORL_BENCH_NATIVE_WATCHDOG_S', '120')), give_up)
+        dog.daemon = True
+        dog.start()
+        native = None
+        try:
+            from exorl_amd import comm as comm_mod
+            os.environ['EXORL_DP_COMM'] = 'native'
+            comm_mod._cached = None
+            ag2, it2, g2 = build(args.precision)
+            if ag2.engine.comm is not None:
+                dt2 = timed(ag2, it2)
+                native = {'status': 'ok', 'ms_per_step': 1e3 * dt2 / args.steps, 'hip_graph': g2, 'dp_collectives': collectives_of(ag2)}
+                if rank == 0 and dt2 < dt:          # report the faster of the two verified-by-execution paths as the value, keep both on record
+                    first = {k: out[k] for k in ('value', 'ms_per_step')}
+                    first['dp_collectives'], first['hip_graph'] = out['config']['dp_collectives'], out['config']['hip_graph']
+                    out = result(dt2, g2, collectives_of(ag2))
+                    out['torch_distributed_path'] = first
+            else:
+                native = {'status': 'RCCL communicator refused; torch.distributed path stands'}
+        except Exception as e:                  # any failure of the unverified leg leaves the first number standing
+            native = {'status': f'failed: {type(e).__name__}: {e}'[:300]}
+        dog.cancel()
+        if rank == 0:
+            out['native_comm'] = native
+
     if rank == 0 and args.rehearse:
         out['rehearsal'] = 'gloo backend, all ranks on cuda:0: exercises the data-parallel path, not a measurement'
     if world == 1 and not args.no_roofline:
@@ -264,7 +344,7 @@ def main():
         agent.disable_graph()
         L.check(lib.exorl_profile_gemm(1))
         nprof = 50
-        run(nprof, args.warmup + args.steps)
+        run(nprof, args.warmup + args.steps, agent, it)
         cap = 1 << 15
         fl, ms, n = np.zeros(cap, np.float64), np.zeros(cap, np.float32), L.C.c_int32()
         L.check(lib.exorl_profile_gemm_read(fl.ctypes.data, ms.ctypes.data, cap, L.C.byref(n)))
@@ -276,7 +356,7 @@ def main():
         # avg_us agrees with profiles/*_rocprofv3_kernel_stats_default_bench.csv instead of flattering the kernel by ~1.5 us per launch
         EVENT_OVERHEAD_KEPT = 0.7
         fl, ms = fl[:n.value], np.maximum(ms[:n.value] - EVENT_OVERHEAD_KEPT * ovh.value, 1e-4)
-        big = fl >= 2.0 * 2 * B * H * H * 0.99           # the two-problem 1024^3 launches (fwd / dgrad / wgrad of Linear(H,H))
+        big = fl >= 2.0 * 2 * PB * H * H * 0.99           # the two-problem 1024^3 launches (fwd / dgrad / wgrad of Linear(H,H))
         ach = float(fl[big].mean() / (ms[big].mean() * 1e-3) / 1e12)
         peak = PEAK_TFLOPS[args.precision]
         # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this command (tools/run_final.sh writes the JSON with
@@ -321,14 +401,17 @@ def main():
             d2 = time.perf_counter() - t0
             out['other_modes'][prec] = {'value': n2 / d2, 'ms_per_step': 1e3 * d2 / n2, 'steps': n2, 'hip_graph': g2, 'parity': notes[prec]}
             del ag2, it2
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.config == 2 and args.scaling == 'weak':
         out['cpu_baseline'] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         import faulthandler
         faulthandler.cancel_dump_traceback_later()
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
 
 
 if __name__ == '__main__':

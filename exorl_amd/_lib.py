@@ -16,7 +16,7 @@ SAMPLER_MT19937, SAMPLER_PHILOX, SAMPLER_GIVEN = 0, 1, 2
 AGENT_TD3_BC, AGENT_TD3, AGENT_BC, AGENT_DDPG, AGENT_CRR, AGENT_CQL, AGENT_APS = 0, 1, 2, 3, 4, 5, 6
 M_CRITIC_CQL, M_CRITIC_CQL_LOGSUM, M_ACTOR_ALPHA, M_ACTOR_ALPHA_LOSS, M_ACTOR_ENT = 10, 11, 12, 13, 14
 CRR_WEIGHT = {'identity': 0, 'indicator': 1, 'exp': 2}
-PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
+PREC_F32, PREC_BF16, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2, 3
 NET_ACTOR, NET_CRITIC, NET_CRITIC_TARGET = 0, 1, 2
 T_PARAM, T_GRAD, T_ADAM_M, T_ADAM_V = 0, 1, 2, 3
 M_BATCH_REWARD, M_CRITIC_TARGET_Q, M_CRITIC_Q1, M_CRITIC_Q2, M_CRITIC_LOSS, M_ACTOR_LOSS, M_ACTOR_LOGPROB = range(7)
@@ -145,6 +145,7 @@ PROTOTYPES = {
     'exorl_agent_stats_buffer': (C.c_int, [c_void_p, P(c_void_p), P(c_int64)]),
     'exorl_agent_cql_alpha': (C.c_int, [c_void_p, c_void_p, c_int32]),
     'exorl_agent_act': (C.c_int, [c_void_p, c_void_p, c_int32, c_float, c_int32, c_void_p, c_void_p, c_void_p]),
+    'exorl_agent_act_host': (C.c_int, [c_void_p, c_void_p, c_int32, c_float, c_int32, c_void_p, c_void_p, c_void_p]),
     'exorl_agent_metrics': (C.c_int, [c_void_p, c_void_p, c_void_p]),
     'exorl_agent_set_metrics': (C.c_int, [c_void_p, c_int32]),
     'exorl_agent_set_parallel_branches': (C.c_int, [c_void_p, c_int32]),
@@ -162,6 +163,7 @@ PROTOTYPES = {
     'exorl_gemm_planes': (C.c_int, [c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                     c_void_p, c_int64, c_int32, c_void_p]),
     'exorl_gemm_tune': (C.c_int, [c_int32]),
+    'exorl_debug_precision_override': (C.c_int, [c_int32]),
     'exorl_debug_gemm_stamps': (C.c_int, [c_void_p, c_int32]),
     'exorl_profile_gemm': (C.c_int, [c_int32]),
     'exorl_profile_gemm_read': (C.c_int, [c_void_p, c_void_p, c_int32, P(c_int32)]),

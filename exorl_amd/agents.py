@@ -185,6 +185,9 @@ class _AgentBase:
         ws = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             ws = torch.distributed.get_world_size()
+            # every rank draws its own rows of the global batch's noise: without this all ranks share one Philox stream and the global
+            # batch repeats each noise block world_size times (the reference's single process draws B x A iid normals)
+            seed = (seed + 0x9E3779B1 * torch.distributed.get_rank()) & 0x7FFFFFFFFFFFFFFF if ws > 1 else seed
         self.world_size = ws
         # initial weights first (CPU RNG order: actor, critic, critic_target — td3_bc.py:86-93)
         actor0 = _mlp_init(obs_dim, hidden_dim, 2 * action_dim if self.KIND == 'cql' else action_dim, 1, 1)
@@ -247,7 +250,20 @@ class _AgentBase:
         if self.world_size != 1 and self.engine.comm is None:       # collectives in Python between the phases: nothing to capture
             return False
         self._graph_stddev = self._stddev(step)
-        self.engine.enable_graph(eng, replay_iter.nstep, replay_iter.discount, self._graph_stddev)
+        ok = True
+        try:
+            self.engine.enable_graph(eng, replay_iter.nstep, replay_iter.discount, self._graph_stddev)
+        except L.ExorlError:
+            if self.world_size == 1:
+                raise
+            ok = False
+        if self.world_size != 1:                 # a capture refused on one rank must send EVERY rank down the eager path
+            flag = torch.tensor([1.0 if ok else 0.0], device=self.engine.device)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            if float(flag[0]) == 0.0:
+                if ok:
+                    self.engine.disable_graph()
+                return False
         self._graph_iter = replay_iter
         return True
 
@@ -314,12 +330,17 @@ class _AgentBase:
 
     def _act(self, obs_vec, step, eval_mode):
         stddev = self._stddev(step)
+        noise = self.noise_hook((1, self.action_dim)) if (self.noise_hook and not eval_mode) else None
+        explore = (not eval_mode) and step < self.num_expl_steps
+        if not explore and isinstance(obs_vec, np.ndarray):
+            a = self.engine.act_host(obs_vec, stddev, eval_mode, noise)      # one kernel launch, result in a pinned host slot
+            if a is not None:
+                return a
         if eval_mode:
             a = self.engine.act(obs_vec, stddev, True)
         else:
-            noise = self.noise_hook((1, self.action_dim)) if self.noise_hook else None
             a = self.engine.act(obs_vec, stddev, False, noise)
-            if step < self.num_expl_steps:
+            if explore:
                 a.uniform_(-1.0, 1.0)
         return a.cpu().numpy()[0]
 
@@ -1477,10 +1498,14 @@ class ProtoAgent(_IntrAgent):
             u = self._cat_u()
             self.intr.update(fo, None, fn, s.reward, s.reward, False, cat_uniform=u.data_ptr() if u is not None else None)
             self._keep_u = u
+            # proto.py:190-191 encodes obs and next_obs again for the actor / critic: next_obs with the weights and the input of the reward
+            # pass above — the same values, kept — and obs with the stepped encoder, the one pass left to make (4 of the update's 20
+            # forward convolutions gone)
+            eng.encode(0)
         stddev = self._stddev(step)
         eng.set_train_encoder(False)
         eng.update(stddev, None, None, self.noise_hook((B, A)) if self.noise_hook else None, self.noise_hook((B, A)) if self.noise_hook else None,
-                   keep_augmented=True)
+                   keep_augmented=not self.reward_free, keep_encoded=self.reward_free)
         eng.encoder_target(self.encoder_target_tau)
         metrics = dict()
         if self.use_tb or self.use_wandb:

@@ -1,10 +1,12 @@
 """Process-wide RCCL communicator of libexorl_hip.so (exorl_comm_*, include/exorl_hip.h) for data-parallel agents.
 
 The reference has no multi-GPU path; SURVEY 8e derives the exchanges its update implies (critic grads, sum|Q|, actor grads). Under
-torch.distributed with the nccl (= RCCL) backend every agent attaches this communicator, and exorl_agent_update enqueues the
-all-reduces between its phases itself: one host call per step, nothing from Python in between. torch.distributed is only the
-bootstrap channel for the 128-byte id. EXORL_DP_COMM=torch keeps the collectives in Python (torch.distributed.all_reduce between
-exorl_agent_update_phase calls) — also what runs under the gloo backend, where several ranks may share one GPU.
+torch.distributed the default keeps the collectives with torch.distributed (all_reduce between exorl_agent_update_phase calls — RCCL
+when the backend is nccl; the path the two-process tests execute). EXORL_DP_COMM=native attaches this communicator instead:
+exorl_agent_update then enqueues the all-reduces between its phases itself — one host call per step, capturable into the step's
+hipGraph; torch.distributed is only the bootstrap channel for the 128-byte id. OPT-IN because it is UNVERIFIED beyond one rank: this
+pool gives one GPU per box, so RCCL has only ever run here as a 1-rank communicator. bench.py --gpus N tries it behind a
+watchdog after it has a number from the default path.
 """
 import ctypes as C
 import os
@@ -45,14 +47,14 @@ class Comm:
 
 def native_comm(device):
     """The communicator spanning torch.distributed's ranks, created on first use (collective: every rank must get here), or None
-    when the collectives stay with torch.distributed (not initialised, gloo backend, EXORL_DP_COMM=torch, or RCCL refused)."""
+    when the collectives stay with torch.distributed (not initialised, gloo backend, EXORL_DP_COMM != native, or RCCL refused)."""
     global _cached
     dist = torch.distributed
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return None
     if _cached is not None:
         return _cached or None
-    if dist.get_backend() != 'nccl' or os.environ.get('EXORL_DP_COMM', 'native') == 'torch':
+    if dist.get_backend() != 'nccl' or os.environ.get('EXORL_DP_COMM', 'torch') != 'native':
         _cached = False
         return None
     rank, world = dist.get_rank(), dist.get_world_size()

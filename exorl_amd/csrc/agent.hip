@@ -346,6 +346,7 @@ struct exorl_agent {
     Partials pa{}, pc{};
     float *stats = nullptr, *metrics = nullptr;      // contiguous: stats[4] then metrics[EXORL_N_METRICS]
     float *act_x = nullptr, *act_noise = nullptr;
+    float* act_part = nullptr; unsigned int* act_ticket = nullptr;      // one-launch act(): head shares per workgroup, arrival ticket
     FwdBufs fact{};
     StepState* state = nullptr;  // device-resident counters + Adam scalars (graph-replayable)
     const float *noise_c = nullptr, *noise_a = nullptr;   // caller-supplied noise of the step in flight (parity tests)
@@ -411,6 +412,8 @@ static void carve(exorl_agent* a, Carver& c) {
     a->state = reinterpret_cast<StepState*>(c.take((sizeof(StepState) + 3) / 4));
     a->act_x = c.take(ACT_ROWS * O);
     a->act_noise = c.take(ACT_ROWS * A);
+    a->act_part = c.take((int64_t)cdiv(H, 4) * ACT_FAST_ROWS * 16);
+    a->act_ticket = reinterpret_cast<unsigned int*>(c.take(4));
     a->fact = FwdBufs{c.take(ACT_ROWS * H), nullptr, nullptr, c.take(ACT_ROWS * H), c.take(ACT_ROWS * AO), bf ? take_u16(ACT_ROWS * H) : nullptr, nullptr,
                       nullptr, nullptr};
     if (a->has_critic) {
@@ -997,11 +1000,38 @@ int exorl_agent_stats_buffer(exorl_agent_t* a, void** ptr, int64_t* numel) {
     return 0;
 }
 
+// one launch for <= ACT_FAST_ROWS rows of a tanh-mean policy (every agent kind but CQL's tanh-Gaussian); obs / noise on the device or on the host
+static bool act_fast_ok(const exorl_agent* a, int n) {
+    return a->cfg.kind != EXORL_AGENT_CQL && act_fast_supported(n, a->cfg.obs_dim, a->cfg.hidden_dim, a->actor.out_dim) && !(tune_variant() & 2);
+}
+static int act_fast_launch(exorl_agent* a, const float* obs_dev, const float* obs_host, int n, float stddev, int eval_mode, const float* noise_dev,
+                           const float* noise_host, float* out, hipStream_t s) {
+    EXORL_REQUIRE(eval_mode || stddev > 0.f, "agent_act: stddev must be > 0 in sampling mode");
+    const NetDesc& d = a->actor;
+    ActFast f{};
+    f.x_dev = obs_dev; f.x_host = obs_host; f.w0t = a->sh_actor.w0t; f.P = a->flat[EXORL_NET_ACTOR][EXORL_T_PARAM];
+    f.b0 = d.b0; f.g = d.g; f.beta = d.beta; f.W1 = d.W1; f.b1 = d.b1; f.W2 = d.W2; f.b2 = d.b2;
+    f.part = a->act_part; f.ticket = a->act_ticket; f.noise_dev = noise_dev; f.noise_host = noise_host;
+    f.seed = a->cfg.seed;
+    f.counter = (eval_mode || noise_dev || noise_host) ? 0ull : ((1ull << 63) | a->act_noise_counter++);      // act_noise_spec's counter space
+    f.out = out; f.stddev = stddev; f.rows = n; f.in_dim = a->cfg.obs_dim; f.H = a->cfg.hidden_dim; f.nout = d.out_dim; f.eval_mode = eval_mode;
+    return act_fast(f, s);
+}
+
+int exorl_agent_act_host(exorl_agent_t* a, const float* obs_host, int32_t n, float stddev, int32_t eval_mode, const float* noise_host,
+                         float* action_out, void* stream) {
+    EXORL_REQUIRE(a && obs_host && action_out && n > 0, "agent_act_host: bad arguments");
+    EXORL_REQUIRE(act_fast_ok(a, n), "agent_act_host: needs <= %d rows, a tanh-mean policy (not CQL), obs_dim <= 256 and hidden_dim %% 4 == 0; use exorl_agent_act",
+                  ACT_FAST_ROWS);
+    return act_fast_launch(a, nullptr, obs_host, n, stddev, eval_mode, nullptr, noise_host, action_out, as_stream(stream));
+}
+
 int exorl_agent_act(exorl_agent_t* a, const float* obs, int32_t n, float stddev, int32_t eval_mode, const float* noise,
                     float* out, void* stream) {
     EXORL_REQUIRE(a && obs && out && n > 0, "agent_act: bad arguments");
     hipStream_t s = as_stream(stream);
     const int O = a->cfg.obs_dim, A = a->cfg.act_dim;
+    if (act_fast_ok(a, n)) return act_fast_launch(a, obs, nullptr, n, stddev, eval_mode, noise, nullptr, out, s);
     for (int r0 = 0; r0 < n; r0 += ACT_ROWS) {
         const int rows = n - r0 < ACT_ROWS ? n - r0 : ACT_ROWS;
         NetShadow sh = a->sh_actor;                 // act() rows do not tile by 64: split-bf16 takes the in-GEMM split here

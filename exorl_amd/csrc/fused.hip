@@ -1372,6 +1372,29 @@ __device__ __forceinline__ void step_small(const FusedAdamArgs& a, const AdamCon
     }
 }
 
+typedef float v4f_nt __attribute__((ext_vector_type(4)));
+typedef unsigned v4u_nt __attribute__((ext_vector_type(4)));
+// Measured and NOT adopted (round 3; exorl_gemm_tune bit 4 switches it on): non-temporal loads and stores for the optimiser pass's streams, on
+// the theory that 117 MB touched once per step should not churn a 32 MB L2. The step got SLOWER — 0.3035 ms against 0.2868 ms with plain
+// accesses (bench.py, same box): the gradient the wgrad GEMM has just written and the weights the next forward reads are served from the L2 /
+// Infinity Cache when they are left there.
+template <bool NT>
+__device__ __forceinline__ float4 ld4(const float* p, int64_t i4) {
+    if constexpr (NT) { const v4f_nt v = __builtin_nontemporal_load(reinterpret_cast<const v4f_nt*>(p) + i4); return make_float4(v.x, v.y, v.z, v.w); }
+    else return reinterpret_cast<const float4*>(p)[i4];
+}
+template <bool NT>
+__device__ __forceinline__ void st4(float* p, int64_t i4, const float4& v) {
+    if constexpr (NT) { const v4f_nt w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, reinterpret_cast<v4f_nt*>(p) + i4); }
+    else reinterpret_cast<float4*>(p)[i4] = v;
+}
+template <bool NT>
+__device__ __forceinline__ void st4u(unsigned short* p, int64_t i8, const uint4& v) {
+    if constexpr (NT) { const v4u_nt w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, reinterpret_cast<v4u_nt*>(p) + i8); }
+    else reinterpret_cast<uint4*>(p)[i8] = v;
+}
+
+template <bool NT>
 __global__ __launch_bounds__(256) void finalize_adam_kernel(FinalizeArgs f, FusedAdamArgs a, ShadowSpec sh, int nb_fin) {
     const AdamConst c = *a.c;
     if (a.bump && blockIdx.x == 0 && threadIdx.x == 0) *a.bump += 1ull;
@@ -1386,25 +1409,25 @@ __global__ __launch_bounds__(256) void finalize_adam_kernel(FinalizeArgs f, Fuse
             float4 pv[2], gv[2], mv[2], vv[2], tv[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                pv[u] = reinterpret_cast<float4*>(a.p)[gi4 + u];
-                gv[u] = reinterpret_cast<const float4*>(a.g)[gi4 + u];
-                mv[u] = reinterpret_cast<float4*>(a.m)[gi4 + u];
-                vv[u] = reinterpret_cast<float4*>(a.v)[gi4 + u];
-                tv[u] = a.target ? reinterpret_cast<float4*>(a.target)[gi4 + u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                pv[u] = ld4<NT>(a.p, gi4 + u);
+                gv[u] = ld4<NT>(a.g, gi4 + u);
+                mv[u] = ld4<NT>(a.m, gi4 + u);
+                vv[u] = ld4<NT>(a.v, gi4 + u);
+                tv[u] = a.target ? ld4<NT>(a.target, gi4 + u) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             ushort4 bh[2], bl[2], th[2], tl[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 adam_elem(pv[u].x, gv[u].x, mv[u].x, vv[u].x, c); adam_elem(pv[u].y, gv[u].y, mv[u].y, vv[u].y, c);
                 adam_elem(pv[u].z, gv[u].z, mv[u].z, vv[u].z, c); adam_elem(pv[u].w, gv[u].w, mv[u].w, vv[u].w, c);
-                reinterpret_cast<float4*>(a.p)[gi4 + u] = pv[u];
-                reinterpret_cast<float4*>(a.m)[gi4 + u] = mv[u];
-                reinterpret_cast<float4*>(a.v)[gi4 + u] = vv[u];
+                st4<NT>(a.p, gi4 + u, pv[u]);
+                st4<NT>(a.m, gi4 + u, mv[u]);
+                st4<NT>(a.v, gi4 + u, vv[u]);
                 bh[u] = f4_to_bf4(pv[u]); bl[u] = f4_to_bf4_lo(pv[u]);
                 if (a.target) {
                     tv[u].x = polyak(pv[u].x, tv[u].x, c.tau, c.one_minus_tau); tv[u].y = polyak(pv[u].y, tv[u].y, c.tau, c.one_minus_tau);
                     tv[u].z = polyak(pv[u].z, tv[u].z, c.tau, c.one_minus_tau); tv[u].w = polyak(pv[u].w, tv[u].w, c.tau, c.one_minus_tau);
-                    reinterpret_cast<float4*>(a.target)[gi4 + u] = tv[u];
+                    st4<NT>(a.target, gi4 + u, tv[u]);
                     th[u] = f4_to_bf4(tv[u]); tl[u] = f4_to_bf4_lo(tv[u]);
                 }
             }
@@ -1413,6 +1436,7 @@ __global__ __launch_bounds__(256) void finalize_adam_kernel(FinalizeArgs f, Fuse
                 r.x = x.x | ((unsigned)x.y << 16); r.y = x.z | ((unsigned)x.w << 16); r.z = y.x | ((unsigned)y.y << 16); r.w = y.z | ((unsigned)y.w << 16);
                 return r;
             };
+            // the bf16 planes are the next GEMMs' operands: plain stores (they should stay in cache)
             if (sh.w1b) reinterpret_cast<uint4*>(sh.w1b + (int64_t)t * H * H)[e8] = pack(bh[0], bh[1]);
             if (sh.w1l) reinterpret_cast<uint4*>(sh.w1l + (int64_t)t * H * H)[e8] = pack(bl[0], bl[1]);
             if (a.target) {
@@ -1480,7 +1504,8 @@ int finalize_adam(const FinalizeArgs& f, const FusedAdamArgs& a, const ShadowSpe
     if (part == 2) aa.bump = nullptr;
     FinalizeArgs ff = f;
     if (part == 2) ff.H = H;
-    hipLaunchKernelGGL(finalize_adam_kernel, dim3(nb_fin + nb_w1), dim3(256), 0, s, ff, aa, sh, nb_fin);
+    if (tune_variant() & 4) hipLaunchKernelGGL(finalize_adam_kernel<true>, dim3(nb_fin + nb_w1), dim3(256), 0, s, ff, aa, sh, nb_fin);
+    else hipLaunchKernelGGL(finalize_adam_kernel<false>, dim3(nb_fin + nb_w1), dim3(256), 0, s, ff, aa, sh, nb_fin);
     EXORL_LAUNCH_CHECK();
     return 0;
 }

@@ -108,6 +108,20 @@ __device__ __forceinline__ void store_tile(unsigned char* lds, int tid, const fl
         if constexpr (L == 0) { row = (tid >> 3) + 32 * u; unit = tid & 7; }
         else                  { row = 2 * (tid & 31) + u;  unit = tid >> 5; }
         uint4 w;
+        if constexpr (PREC == EXORL_PREC_BF16X6) {      // three planes: hi, mid = bf16(x - hi), lo = bf16(x - hi - mid): images at +0, +2, +4 tiles
+            float md[8], lw[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float r1 = bf16_residual(reg[u][j]);
+                md[j] = r1;
+                lw[j] = bf16_residual(r1);
+            }
+            uint4 m2, l2;
+            m2.x = pack_bf16(md[0], md[1]); m2.y = pack_bf16(md[2], md[3]); m2.z = pack_bf16(md[4], md[5]); m2.w = pack_bf16(md[6], md[7]);
+            l2.x = pack_bf16(lw[0], lw[1]); l2.y = pack_bf16(lw[2], lw[3]); l2.z = pack_bf16(lw[4], lw[5]); l2.w = pack_bf16(lw[6], lw[7]);
+            *reinterpret_cast<uint4*>(lds + 2 * TILEB + lds_off(row, unit)) = m2;
+            *reinterpret_cast<uint4*>(lds + 4 * TILEB + lds_off(row, unit)) = l2;
+        }
         if constexpr (PREC == EXORL_PREC_BF16X3) {      // lo image two tiles after the hi image (A_hi B_hi A_lo B_lo)
             uint4 l;
             l.x = pack_bf16(bf16_residual(reg[u][0]), bf16_residual(reg[u][1])); l.y = pack_bf16(bf16_residual(reg[u][2]), bf16_residual(reg[u][3]));
@@ -129,8 +143,13 @@ template <int PREC, int AL, int BL, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
     constexpr int KU = (PREC == EXORL_PREC_F32) ? 4 : 8;   // k elements per 16-byte unit
     constexpr int KPT = KU * 8;                            // k elements per LDS tile
-    constexpr bool X3 = PREC == EXORL_PREC_BF16X3;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2][X3 ? 4 : 2][TILEB];
+    constexpr bool X3 = PREC == EXORL_PREC_BF16X3, X6 = PREC == EXORL_PREC_BF16X6;
+    constexpr int NT = X6 ? 6 : (X3 ? 4 : 2);              // LDS tiles per stage: [A p0][B p0][A p1][B p1][A p2][B p2]
+    // two stages; the three-plane mode needs 96 KB, past the 64 KB a static array may have: dynamic there
+    extern __shared__ __attribute__((aligned(16))) unsigned char gk_dyn[];
+    __shared__ __attribute__((aligned(16))) unsigned char gk_static[X6 ? 16 : 2 * NT * TILEB];
+    unsigned char* const smem_base = X6 ? gk_dyn : gk_static;
+    auto smem = [&](int stage, int tile) { return smem_base + (stage * NT + tile) * TILEB; };
 
     const GemmProblem& P = gb.p[blockIdx.z];
     const int M = P.M, N = P.N, K = P.K;
@@ -154,8 +173,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
     const int nk = (K + KPT - 1) / KPT;
     load_tile<AL, VEC, KU>(P.A, P.lda, M, K, m0, 0, tid, ra);
     load_tile<BL, VEC, KU>(P.B, P.ldb, N, K, n0, 0, tid, rb);
-    store_tile<AL, PREC, KU>(smem[0][0], tid, ra);
-    store_tile<BL, PREC, KU>(smem[0][1], tid, rb);
+    store_tile<AL, PREC, KU>(smem(0, 0), tid, ra);
+    store_tile<BL, PREC, KU>(smem(0, 1), tid, rb);
     __syncthreads();
 
     const int arow = wm * 32 + (lane & 31);
@@ -167,8 +186,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
             load_tile<AL, VEC, KU>(P.A, P.lda, M, K, m0, (kt + 1) * KPT, tid, ra);
             load_tile<BL, VEC, KU>(P.B, P.ldb, N, K, n0, (kt + 1) * KPT, tid, rb);
         }
-        const unsigned char* As = smem[cur][0];
-        const unsigned char* Bs = smem[cur][1];
+        const unsigned char* As = smem(cur, 0);
+        const unsigned char* Bs = smem(cur, 1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint4 a = *reinterpret_cast<const uint4*>(As + lds_off(arow, 2 * q + h));
@@ -187,11 +206,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
                     acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bl), acc2, 0, 0, 0);
                     acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, b), acc3, 0, 0, 0);
                 }
+                if constexpr (X6) {       // acc: hi*hi; acc2: hi*mid + mid*hi (~2^-8 of it); acc3: hi*lo + lo*hi + mid*mid (~2^-16)
+                    const uint4 am = *reinterpret_cast<const uint4*>(As + 2 * TILEB + lds_off(arow, 2 * q + h));
+                    const uint4 bm = *reinterpret_cast<const uint4*>(Bs + 2 * TILEB + lds_off(brow, 2 * q + h));
+                    const uint4 al = *reinterpret_cast<const uint4*>(As + 4 * TILEB + lds_off(arow, 2 * q + h));
+                    const uint4 bl = *reinterpret_cast<const uint4*>(Bs + 4 * TILEB + lds_off(brow, 2 * q + h));
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bm), acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, am), __builtin_bit_cast(bf16x8, b), acc2, 0, 0, 0);
+                    acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bl), acc3, 0, 0, 0);
+                    acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, b), acc3, 0, 0, 0);
+                    acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, am), __builtin_bit_cast(bf16x8, bm), acc3, 0, 0, 0);
+                }
             }
         }
         if (kt + 1 < nk) {
-            store_tile<AL, PREC, KU>(smem[cur ^ 1][0], tid, ra);
-            store_tile<BL, PREC, KU>(smem[cur ^ 1][1], tid, rb);
+            store_tile<AL, PREC, KU>(smem(cur ^ 1, 0), tid, ra);
+            store_tile<BL, PREC, KU>(smem(cur ^ 1, 1), tid, rb);
         }
         __syncthreads();
     }
@@ -200,6 +230,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
     if constexpr (X3) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = (acc2[i] + acc3[i]) + acc[i];      // cross terms first
+    }
+    if constexpr (X6) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = (acc3[i] + acc2[i]) + acc[i];      // smallest class first
     }
     const int n = n0 + wn * 32 + (lane & 31);
     if (n < N) {
@@ -1871,8 +1905,17 @@ static int launch_layout(const GemmBatch& gb, int count, int max_tiles, bool vec
         g_prof.flops.push_back(f);
         EXORL_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.used], s));
     }
-    if (vec) hipLaunchKernelGGL((gemm_kernel<PREC, AL, BL, true>), grid, block, 0, s, gb);
-    else     hipLaunchKernelGGL((gemm_kernel<PREC, AL, BL, false>), grid, block, 0, s, gb);
+    constexpr size_t dyn = PREC == EXORL_PREC_BF16X6 ? 2 * 6 * TILEB : 0;      // 96 KB: two stages of three planes of A and B
+    if constexpr (PREC == EXORL_PREC_BF16X6) {
+        static bool attr = false;
+        if (!attr) {
+            EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_kernel<PREC, AL, BL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+            EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_kernel<PREC, AL, BL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+            attr = true;
+        }
+    }
+    if (vec) hipLaunchKernelGGL((gemm_kernel<PREC, AL, BL, true>), grid, block, dyn, s, gb);
+    else     hipLaunchKernelGGL((gemm_kernel<PREC, AL, BL, false>), grid, block, dyn, s, gb);
     EXORL_LAUNCH_CHECK();
     if (prof) {
         EXORL_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s));
@@ -1901,9 +1944,21 @@ static bool aligned_for_vec(const GemmProblem& p, int al, int bl) {
 }
 
 // Launches up to 4 independent problems (same layouts / epilogue flags) as one grid.
+// Diagnostic (tools/debug/config4_ablation.py; no product path sets it): which split-bf16 products run with exact fp32 products instead.
+// bits: 1 / 2 forward (row-image A, row-image B) narrow / wide; 4 / 8 wgrad (k-image A and B); 16 / 32 dgrad (row-image A, k-image B);
+// "wide" = a problem dimension >= 8192 (the 39200-wide layers of the pixel agents); 64 / 128 / 256 = conv forward / dgrad / wgrad (pixels.hip)
+static int g_prec_override = 0;
+int prec_override_mask() { return g_prec_override; }
+
 int gemm_grouped(int precision, int a_layout, int b_layout, const GemmProblem* probs, int count, bool relu,
                  bool accumulate, hipStream_t s) {
     EXORL_REQUIRE(count >= 1 && count <= GEMM_MAX_GROUP, "gemm_grouped: count %d out of range", count);
+    if (g_prec_override && precision == EXORL_PREC_BF16X3) {
+        bool wide = false;
+        for (int i = 0; i < count; ++i) wide = wide || probs[i].M >= 8192 || probs[i].N >= 8192 || probs[i].K >= 8192;
+        const int form = (a_layout == 0 && b_layout == 0) ? 0 : (a_layout == 1 && b_layout == 1) ? 1 : (a_layout == 0 && b_layout == 1) ? 2 : -1;
+        if (form >= 0 && (g_prec_override >> (2 * form + (wide ? 1 : 0))) & 1) precision = EXORL_PREC_F32;
+    }
     GemmBatch gb;
     memset(&gb, 0, sizeof(gb));
     int max_tiles = 0;
@@ -1920,6 +1975,7 @@ int gemm_grouped(int precision, int a_layout, int b_layout, const GemmProblem* p
     if (precision == EXORL_PREC_F32) return launch_prec<EXORL_PREC_F32>(gb, count, a_layout, b_layout, max_tiles, vec, s);
     if (precision == EXORL_PREC_BF16) return launch_prec<EXORL_PREC_BF16>(gb, count, a_layout, b_layout, max_tiles, vec, s);
     if (precision == EXORL_PREC_BF16X3) return launch_prec<EXORL_PREC_BF16X3>(gb, count, a_layout, b_layout, max_tiles, vec, s);
+    if (precision == EXORL_PREC_BF16X6) return launch_prec<EXORL_PREC_BF16X6>(gb, count, a_layout, b_layout, max_tiles, vec, s);
     set_error("gemm_grouped: unknown precision %d", precision);
     return 2;
 }
@@ -1977,6 +2033,11 @@ extern "C" int exorl_debug_gemm_stamps(uint64_t* out_host, int32_t n_words) {
     EXORL_REQUIRE(out_host && n_words > 0 && n_words <= 8 * 1024, "debug_gemm_stamps: bad arguments");
     EXORL_CHECK_HIP(hipDeviceSynchronize());
     EXORL_CHECK_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(exorl::g16p_stamps), (size_t)n_words * sizeof(uint64_t)));
+    return 0;
+}
+
+extern "C" int exorl_debug_precision_override(int32_t mask) {
+    exorl::g_prec_override = mask;
     return 0;
 }
 

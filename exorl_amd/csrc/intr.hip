@@ -1287,7 +1287,7 @@ static int check_intr_cfg(const exorl_intr_cfg* cfg) {
                   "intr: rep_dim=%d out of range (ICM-APT trunk: <= 1024)", cfg->rep_dim);
     EXORL_REQUIRE(cfg->kind != EXORL_INTR_ICM_APT || (cfg->knn_k >= 1 && cfg->knn_k <= 64 && cfg->knn_k <= cfg->batch && cfg->batch <= 4096),
                   "intr: ICM-APT needs 1 <= knn_k <= min(64, batch) and batch <= 4096 (got k=%d B=%d)", cfg->knn_k, cfg->batch);
-    EXORL_REQUIRE(cfg->precision == EXORL_PREC_F32 || cfg->precision == EXORL_PREC_BF16 || cfg->precision == EXORL_PREC_BF16X3, "intr: unknown precision %d", cfg->precision);
+    EXORL_REQUIRE(cfg->precision >= EXORL_PREC_F32 && cfg->precision <= EXORL_PREC_BF16X6, "intr: unknown precision %d", cfg->precision);
     return 0;
 }
 

@@ -130,6 +130,7 @@ int head_bwd(const DoutSpec& dspec, const float* W, const float* a, float* dz, u
              int H, int nout, int nets, int64_t astride, int64_t pstride, int want_params, hipStream_t s, unsigned short* dz_lo = nullptr);
 int head_chunks(int rows);
 int tune_variant();      // exorl_gemm_tune's experiment bits (0 = defaults)
+int prec_override_mask();    // exorl_debug_precision_override's bits (0 = none; diagnostic)
 // Scalar critic heads, forward and backward in one kernel (single-GPU whole-step path, no metrics): Q1,Q2 (and the target's
 // Q1',Q2') row dots, the loss gradient at the head output, dz2 = dQ * W2 * [h2 > 0] and the per-chunk parameter partials.
 //   mode 0 (critic step, td3_bc.py:126-131): dQ_n = 2 (Q_n - (r + D min(Q1',Q2'))) * inv_bg
@@ -230,6 +231,22 @@ struct StepState {
                                  // that moves every step needs no re-capture of the hipGraph
 };
 int step_begin(StepState* st, int advance_replay, hipStream_t s);
+// act() for up to ACT_FAST_ROWS observation rows in one launch (loss.hip, act_fast_kernel): trunk + LayerNorm + tanh + Linear(H,H) + ReLU +
+// head + tanh + TruncatedNormal draw. x_host / noise_host (host pointers) travel as kernel arguments; `out` may be pinned host memory.
+constexpr int ACT_FAST_ROWS = 2;            // x 256 floats of embedded observation: the kernel-argument block stays under 4 KB
+struct ActFast {
+    const float *x_dev, *x_host;            // one of the two
+    const float *w0t, *P;
+    int64_t b0, g, beta, W1, b1, W2, b2;
+    float* part; unsigned int* ticket;      // scratch: cdiv(H, 4) * rows * nout floats; one zero-initialised word
+    const float *noise_dev, *noise_host;    // at most one; both null -> Philox(seed, counter)
+    uint64_t seed, counter;
+    float* out;
+    float stddev;
+    int rows, in_dim, H, nout, eval_mode;
+};
+bool act_fast_supported(int rows, int in_dim, int H, int nout);
+int act_fast(const ActFast& f, hipStream_t s);
 // out[0] = sum_i parts[2i], out[1] = sum_i parts[2i+1] in a fixed order (qhead's per-chunk [sum |min Q|, sum min Q] -> the 4-float
 // statistics buffer that is all-reduced under data parallelism)
 int reduce_pairs(const float* parts, int chunks, float* out, hipStream_t s);

@@ -120,6 +120,162 @@ __global__ __launch_bounds__(1024) void sample_action_kernel(const float* __rest
     }
 }
 
+// ---- act() in ONE launch (td3_bc.py:107-117, ddpg.py:221-238): the online loop calls the policy once per environment step on ONE
+// observation, so the cost is latency, not FLOPs. Every workgroup recomputes the trunk for the (<= ACT_FAST_ROWS) rows — Linear(in, H) through
+// the transposed fp32 shadow (coalesced), LayerNorm, tanh: 24 k MACs and 100 KB of L2 reads for the walker actor — takes FOUR neurons of the
+// Linear(H, H) + ReLU layer (one wave each: 4 KB of W1 per wave; the 4 MB of fp32 master weights are spread over H / 4 workgroups, no bf16
+// shadow and no GEMM needed at one row), forms its share of the head dots and leaves it in `part`. The last workgroup to arrive (one atomic
+// ticket per workgroup) sums the shares in workgroup order — deterministic — applies bias + tanh and the TruncatedNormal draw (clip = None)
+// and stores the action rows to `out`, which may be pinned host memory: no separate head, sampling or copy launch, no host round trip
+// before the result. fp32 FMA throughout (the parity mode of every precision setting: act() is never the bottleneck on FLOPs).
+struct ActFastArgs {
+    const float* x; int64_t ldx;            // observation rows (device) — or, when x == nullptr, the rows embedded below (kernel arguments)
+    const float *w0t, *P;                   // W0T shadow [in][H]; flat fp32 parameters
+    int64_t b0, g, beta, W1, b1, W2, b2;    // offsets in P
+    float* part;                            // [H / 4][rows][nout] head shares
+    unsigned int* ticket;
+    const float* noise;                     // (rows, nout) standard normals (device), or null -> Philox(seed, counter) unless kn != 0
+    uint64_t seed, counter;
+    float* out;                             // (rows, nout)
+    float stddev;
+    int rows, in_dim, H, nout, eval_mode, kn;
+    float kx[ACT_FAST_ROWS * 256];          // embedded observation rows (x == nullptr)
+    float knoise[ACT_FAST_ROWS * 16];       // embedded noise rows (kn != 0)
+};
+
+__global__ __launch_bounds__(256) void act_fast_kernel(const ActFastArgs a) {
+    extern __shared__ float act_sm[];                   // h1[rows][H], then scratch
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, H = a.H, rows = a.rows, I = a.in_dim, A = a.nout;
+    float* h1 = act_sm;
+    __shared__ float red[ACT_FAST_ROWS][2][4];
+    __shared__ float h2s[ACT_FAST_ROWS][4];
+    __shared__ unsigned int last;
+    // ---- trunk: z = W0 x + b0 (every workgroup, all H columns)
+    for (int r = 0; r < rows; ++r) {
+        const float* x = a.x ? a.x + (int64_t)r * a.ldx : a.kx + r * 256;
+        float s1 = 0.f;
+        for (int n = tid; n < H; n += 256) {
+            float z = a.P[a.b0 + n];
+            for (int i = 0; i < I; ++i) z = fmaf(x[i], a.w0t[(int64_t)i * H + n], z);
+            h1[r * H + n] = z;
+            s1 += z;
+        }
+        s1 = wave_sum(s1);
+        if (lane == 0) red[r][0][wave] = s1;
+    }
+    __syncthreads();
+    for (int r = 0; r < rows; ++r) {                    // LayerNorm (biased variance about the mean, eps 1e-5) + tanh
+        const float mean = (red[r][0][0] + red[r][0][1] + red[r][0][2] + red[r][0][3]) / (float)H;
+        float s2 = 0.f;
+        for (int n = tid; n < H; n += 256) { const float d = h1[r * H + n] - mean; s2 += d * d; }
+        s2 = wave_sum(s2);
+        if (lane == 0) red[r][1][wave] = s2;
+    }
+    __syncthreads();
+    for (int r = 0; r < rows; ++r) {
+        const float mean = (red[r][0][0] + red[r][0][1] + red[r][0][2] + red[r][0][3]) / (float)H;
+        const float var = (red[r][1][0] + red[r][1][1] + red[r][1][2] + red[r][1][3]) / (float)H;
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        for (int n = tid; n < H; n += 256) h1[r * H + n] = tanhf((h1[r * H + n] - mean) * rstd * a.P[a.g + n] + a.P[a.beta + n]);
+    }
+    __syncthreads();
+    // ---- Linear(H, H) + ReLU: wave w -> neuron 4 blockIdx.x + w, all rows
+    const int nn = 4 * blockIdx.x + wave;
+    if (nn < H) {
+        const float4* w1 = reinterpret_cast<const float4*>(a.P + a.W1 + (int64_t)nn * H);
+        float acc[ACT_FAST_ROWS];
+#pragma unroll
+        for (int r = 0; r < ACT_FAST_ROWS; ++r) acc[r] = 0.f;
+        for (int k4 = lane; k4 < H / 4; k4 += 64) {
+            const float4 w = w1[k4];
+#pragma unroll
+            for (int r = 0; r < ACT_FAST_ROWS; ++r)
+                if (r < rows) {
+                    const float4 h = *reinterpret_cast<const float4*>(h1 + r * H + 4 * k4);
+                    acc[r] = fmaf(w.x, h.x, fmaf(w.y, h.y, fmaf(w.z, h.z, fmaf(w.w, h.w, acc[r]))));
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < ACT_FAST_ROWS; ++r)
+            if (r < rows) {
+                const float v = wave_sum(acc[r]);
+                if (lane == 0) h2s[r][wave] = fmaxf(v + a.P[a.b1 + nn], 0.f);
+            }
+    } else if (lane == 0) {
+        for (int r = 0; r < rows; ++r) h2s[r][wave] = 0.f;
+    }
+    __syncthreads();
+    // ---- this workgroup's share of the head dots
+    if (tid < rows * A) {
+        const int r = tid / A, j = tid % A;
+        float v = 0.f;
+        for (int w = 0; w < 4; ++w) {
+            const int n2 = 4 * blockIdx.x + w;
+            if (n2 < H) v = fmaf(a.P[a.W2 + (int64_t)j * H + n2], h2s[r][w], v);
+        }
+        a.part[((int64_t)blockIdx.x * rows + r) * A + j] = v;
+    }
+    // publish the shares, draw a ticket (cdna_hip_programming.md, in-launch split-K reduction): every wave drains its stores, ONE lane makes
+    // the agent-scope release and the relaxed ticket add — a __threadfence() in all 256 threads of all H / 4 workgroups writes the XCD's L2
+    // back once per caller, which is what the first version of this kernel spent most of its 30 us on
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (!last) return;
+    // ---- last workgroup: fixed-order sum over the workgroups (thread t holds workgroup t, t + 256, ...; wave tree, then the four waves)
+    float* fin = act_sm;                                // h1 is dead
+    const int G = gridDim.x;
+    for (int e = 0; e < rows * A; ++e) {
+        float v = 0.f;
+        for (int gidx = tid; gidx < G; gidx += 256) v += a.part[(int64_t)gidx * rows * A + e];
+        v = wave_sum(v);
+        if (lane == 0) fin[e * 4 + wave] = v;
+    }
+    __syncthreads();
+    if (tid < rows * A) {
+        const int j = tid % A;
+        const float pre = ((fin[tid * 4] + fin[tid * 4 + 1]) + (fin[tid * 4 + 2] + fin[tid * 4 + 3])) + a.P[a.b2 + j];
+        const float mu = tanhf(pre);
+        float o = mu;
+        if (!a.eval_mode) {                             // TruncatedNormal(mu, std).sample(clip=None): clamp to +-(1 - 1e-6)
+            const float z = a.kn ? a.knoise[tid] : (a.noise ? a.noise[tid] : philox_normal(a.seed, a.counter, (uint32_t)tid));
+            o = fminf(fmaxf(mu + z * a.stddev, -1.0f + 1e-6f), 1.0f - 1e-6f);
+        }
+        a.out[tid] = o;
+    }
+    if (tid == 0) *a.ticket = 0u;                       // armed for the next call (launches on one stream are ordered)
+}
+
+bool act_fast_supported(int rows, int in_dim, int H, int nout) {
+    return rows >= 1 && rows <= ACT_FAST_ROWS && in_dim <= 256 && nout <= 16 && H % 4 == 0 && H >= 16 && rows * nout <= 256;
+}
+
+int act_fast(const ActFast& f, hipStream_t s) {
+    ActFastArgs a{};
+    a.x = f.x_dev; a.ldx = f.in_dim;
+    a.w0t = f.w0t; a.P = f.P; a.b0 = f.b0; a.g = f.g; a.beta = f.beta; a.W1 = f.W1; a.b1 = f.b1; a.W2 = f.W2; a.b2 = f.b2;
+    a.part = f.part; a.ticket = f.ticket; a.noise = f.noise_dev; a.seed = f.seed; a.counter = f.counter; a.out = f.out; a.stddev = f.stddev;
+    a.rows = f.rows; a.in_dim = f.in_dim; a.H = f.H; a.nout = f.nout; a.eval_mode = f.eval_mode; a.kn = 0;
+    if (f.x_host) {
+        a.x = nullptr;
+        for (int r = 0; r < f.rows; ++r) memcpy(a.kx + r * 256, f.x_host + (int64_t)r * f.in_dim, sizeof(float) * f.in_dim);
+    }
+    if (f.noise_host && !f.eval_mode) { a.kn = 1; memcpy(a.knoise, f.noise_host, sizeof(float) * f.rows * f.nout); }
+    const size_t lds = sizeof(float) * ((size_t)f.rows * f.H > 1024 ? (size_t)f.rows * f.H : 1024);
+    hipLaunchKernelGGL(act_fast_kernel, dim3(cdiv(f.H, 4)), dim3(256), lds, s, a);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
 __global__ __launch_bounds__(256) void sample_actions2_kernel(const float* __restrict__ mu2, const float* __restrict__ noise_c,
                                                               const float* __restrict__ noise_a, uint64_t seed,
                                                               const uint64_t* __restrict__ counter_ptr, float stddev_val, float clip,

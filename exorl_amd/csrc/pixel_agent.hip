@@ -285,7 +285,7 @@ static int check_pcfg(const exorl_pixel_cfg* c) {
                   c->c_in, c->hw, c->hw);
     EXORL_REQUIRE(c->act_dim >= 1 && c->act_dim <= 64 && c->feature_dim >= 1 && c->feature_dim <= 1024 && c->hidden_dim >= 1 && c->batch >= 1,
                   "pixel_agent: unsupported dims A=%d feature_dim=%d H=%d B=%d", c->act_dim, c->feature_dim, c->hidden_dim, c->batch);
-    EXORL_REQUIRE(c->precision == EXORL_PREC_F32 || c->precision == EXORL_PREC_BF16 || c->precision == EXORL_PREC_BF16X3, "pixel_agent: unknown precision %d", c->precision);
+    EXORL_REQUIRE(c->precision >= EXORL_PREC_F32 && c->precision <= EXORL_PREC_BF16X6, "pixel_agent: unknown precision %d", c->precision);
     EXORL_REQUIRE(c->meta_dim >= 0 && c->meta_dim <= 256, "pixel_agent: meta_dim=%d unsupported (0..256)", c->meta_dim);
     EXORL_REQUIRE(c->sf_dim == 0 || (c->sf_dim >= 1 && c->sf_dim == c->meta_dim), "pixel_agent: sf_dim=%d must equal meta_dim=%d (the task vector is the meta row, aps.py:236-238)",
                   c->sf_dim, c->meta_dim);

@@ -117,20 +117,23 @@ __global__ void conv_weight_shadow_kernel(const float* __restrict__ W, float* __
     if (!ff || ci_n != CONV_CO) return;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * CM_FRAG; i += gridDim.x * blockDim.x) {
         const int dir = i / CM_FRAG, r = i % CM_FRAG, st = r >> 6, lane = r & 63, kg = lane >> 5, col = lane & 31, tap = st >> 1;
-        unsigned hi[4], lo[4];
+        unsigned hi[4], lo[4], l3[4];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int cin = (st & 1) * 16 + 8 * kg + j;
             // forward: Wt[ci][tap][co] = W[co][ci][tap]; dgrad: the flipped shadow read with the roles of ci and co exchanged
             const float w = dir == 0 ? W[(col * CONV_CO + cin) * 9 + tap] : W[(cin * CONV_CO + col) * 9 + (8 - tap)];
             const __bf16 h = (__bf16)w;
-            const __bf16 l = (__bf16)(w - (float)h);
-            const unsigned hb = __builtin_bit_cast(unsigned short, h), lb = __builtin_bit_cast(unsigned short, l);
-            if (j & 1) { hi[j >> 1] |= hb << 16; lo[j >> 1] |= lb << 16; } else { hi[j >> 1] = hb; lo[j >> 1] = lb; }
+            const float r1 = w - (float)h;
+            const __bf16 l = (__bf16)r1;                         // second plane: the lo plane of the two-plane mode = the mid plane of the three-plane mode
+            const __bf16 t = (__bf16)(r1 - (float)l);            // third plane (EXORL_PREC_BF16X6)
+            const unsigned hb = __builtin_bit_cast(unsigned short, h), lb = __builtin_bit_cast(unsigned short, l), tb = __builtin_bit_cast(unsigned short, t);
+            if (j & 1) { hi[j >> 1] |= hb << 16; lo[j >> 1] |= lb << 16; l3[j >> 1] |= tb << 16; } else { hi[j >> 1] = hb; lo[j >> 1] = lb; l3[j >> 1] = tb; }
         }
         uint4* dst = dir == 0 ? ff : fb;
         dst[r] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
         dst[CM_FRAG + r] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        dst[2 * CM_FRAG + r] = make_uint4(l3[0], l3[1], l3[2], l3[3]);
     }
 }
 
@@ -209,16 +212,22 @@ constexpr int CM_IPT = 15;                 // staged (channel pair, y, x) items 
 
 // A pass covers 256 consecutive output pixels in row-major order of the map (not a square tile: a 39-wide map would pay for 48 x 48),
 // so the staged input is a strip of full-width rows: [rows][ow + 2][CM_PIX] with the tap offsets applied inside it.
-template <bool X3, bool MASK>
+// NPL = operand planes: 1 plain bf16, 2 split-bf16 (hi*hi + hi*lo + lo*hi), 3 three-plane split (EXORL_PREC_BF16X6: + hi*l3 + l3*hi + lo*lo,
+// products accurate to 3 * 2^-24 — the parity-grade convolution of the pixel agents at ~2x the split-bf16 kernel's MFMA time, where the fp32
+// FMA kernel it replaces took 5.8x)
+template <int NPL, bool MASK>
 __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* __restrict__ in, const float* __restrict__ Wt,
                                                                   const float* __restrict__ bias, const float* __restrict__ mask,
                                                                   float* __restrict__ out, int ih, int iw, int oh, int ow, int pad, int relu,
                                                                   int plane_elems) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cm_lds[];
+    constexpr bool X3 = NPL >= 2, X6 = NPL == 3;
     unsigned short* xh = reinterpret_cast<unsigned short*>(cm_lds);                       // [rows][ow + 2][CM_PIX] hi plane
-    unsigned short* xl = xh + plane_elems;                                                // lo plane (split mode)
-    cbf16x8* wh = reinterpret_cast<cbf16x8*>(xl + (X3 ? plane_elems : 0));                // [18 k-steps][64 lanes] B fragments, 16 B each
+    unsigned short* xl = xh + plane_elems;                                                // second plane (split modes)
+    unsigned short* xt = xl + plane_elems;                                                // third plane (three-plane mode)
+    cbf16x8* wh = reinterpret_cast<cbf16x8*>(xh + NPL * plane_elems);                     // [18 k-steps][64 lanes] B fragments, 16 B each
     cbf16x8* wl = wh + 18 * 64;                                                           // (CM_FRAG, defined with the shadow kernel)
+    cbf16x8* wt = wl + 18 * 64;
     const int n = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kg = lane >> 5, col = lane & 31;
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
     {
         const uint4* fr = reinterpret_cast<const uint4*>(Wt);
         uint4* dst = reinterpret_cast<uint4*>(wh);
-        for (int i = tid; i < (X3 ? 2 : 1) * CM_FRAG; i += CM_THREADS) dst[i] = fr[i];
+        for (int i = tid; i < NPL * CM_FRAG; i += CM_THREADS) dst[i] = fr[i];
     }
     const int npix = oh * ow, npass = (npix + CM_PASS - 1) / CM_PASS, sw = ow + 2;
     // The input of pass t+1 is fetched into registers while pass t is on the matrix cores; it is converted and written to LDS once
@@ -285,8 +294,13 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
                 const int o = j * CM_PIX + 2 * cp;
                 *reinterpret_cast<unsigned int*>(xh + o) = __builtin_bit_cast(unsigned int, h);
                 if constexpr (X3) {
-                    const cbf16x2 l = __builtin_convertvector(v - __builtin_convertvector(h, cf32x2), cbf16x2);
+                    const cf32x2 r1 = v - __builtin_convertvector(h, cf32x2);
+                    const cbf16x2 l = __builtin_convertvector(r1, cbf16x2);
                     *reinterpret_cast<unsigned int*>(xl + o) = __builtin_bit_cast(unsigned int, l);
+                    if constexpr (X6) {
+                        const cbf16x2 t = __builtin_convertvector(r1 - __builtin_convertvector(l, cf32x2), cbf16x2);
+                        *reinterpret_cast<unsigned int*>(xt + o) = __builtin_bit_cast(unsigned int, t);
+                    }
                 }
             }
         }
@@ -310,9 +324,9 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
                 }
             }
         }
-        cf32x16 acc, accx;
+        cf32x16 acc, accx, accy;               // hi*hi | hi*lo + lo*hi | (three planes) hi*l3 + l3*hi + lo*lo
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accx[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accx[r] = 0.f; accy[r] = 0.f; }
         int pa = p0 + 32 * wave + col;                                          // this lane's pixel of the A operand (clamped: tail lanes recompute the last pixel)
         pa = pa < npix ? pa : npix - 1;
         const int abase = ((pa / ow - y0) * sw + pa % ow) * CM_PIX + 8 * kg;
@@ -328,6 +342,13 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
                 const cbf16x8 bl = wl[s * 64 + lane];
                 accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, accx, 0, 0, 0);
                 accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, accx, 0, 0, 0);
+                if constexpr (X6) {
+                    const cbf16x8 at = *reinterpret_cast<const cbf16x8*>(xt + o);
+                    const cbf16x8 bt = wt[s * 64 + lane];
+                    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bt, accy, 0, 0, 0);
+                    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at, bh, accy, 0, 0, 0);
+                    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl, accy, 0, 0, 0);
+                }
             }
         }
 #pragma unroll
@@ -335,7 +356,7 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                v[e] = (X3 ? accx[4 * q + e] + acc[4 * q + e] : acc[4 * q + e]) + bv;
+                v[e] = (X6 ? (accy[4 * q + e] + accx[4 * q + e]) + acc[4 * q + e] : X3 ? accx[4 * q + e] + acc[4 * q + e] : acc[4 * q + e]) + bv;
                 if (relu) v[e] = fmaxf(v[e], 0.f);
             }
             if constexpr (MASK) {
@@ -355,28 +376,33 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
 }
 
 // true when the strip of a 256-pixel pass fits the kernel's fixed budgets
-static bool conv3x3_mfma_fits(int oh, int ow) {
+static bool conv3x3_mfma_fits(int oh, int ow, int prec = EXORL_PREC_BF16X3) {
     const int rows = (CM_PASS + ow - 2) / ow + 1 + 2;         // most output rows 256 consecutive pixels can touch, + 2
-    return ow + 2 <= CM_MAXW && 16 * rows * (ow + 2) <= CM_IPT * CM_THREADS && oh * ow >= 1;
+    const int npl = prec == EXORL_PREC_BF16X6 ? 3 : 2;
+    const size_t lds = (size_t)npl * round_up((int64_t)rows * (ow + 2) * CM_PIX, 8) * sizeof(unsigned short) + (size_t)npl * 18 * 64 * 16;
+    return ow + 2 <= CM_MAXW && 16 * rows * (ow + 2) <= CM_IPT * CM_THREADS && oh * ow >= 1 && lds <= 160 * 1024;
 }
 static int conv3x3_mfma(const float* in, const float* Wt, const float* bias, const float* mask, float* out, int n, int ih, int iw, int oh, int ow,
                         int pad, int relu, int prec, hipStream_t s) {
-    const bool x3 = prec == EXORL_PREC_BF16X3;
+    const int npl = prec == EXORL_PREC_BF16X6 ? 3 : (prec == EXORL_PREC_BF16X3 ? 2 : 1);
     const int rows = (CM_PASS + ow - 2) / ow + 1 + 2;
     const int plane = (int)round_up((int64_t)rows * (ow + 2) * CM_PIX, 8);
-    const size_t lds = (size_t)(x3 ? 2 : 1) * plane * sizeof(unsigned short) + (size_t)(x3 ? 2 : 1) * 18 * 64 * 16;
-    EXORL_REQUIRE(lds <= 160 * 1024, "conv3x3_mfma: strip of %d rows x %d columns does not fit LDS", rows, ow + 2);
+    const size_t lds = (size_t)npl * plane * sizeof(unsigned short) + (size_t)npl * 18 * 64 * 16;
+    EXORL_REQUIRE(lds <= 160 * 1024, "conv3x3_mfma: strip of %d rows x %d columns (%d planes) does not fit LDS", rows, ow + 2, npl);
     static bool attr = false;
     if (!attr) {
-        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-#define EXORL_CM(XX, MM) hipLaunchKernelGGL((conv3x3_mfma_kernel<XX, MM>), dim3(n), dim3(CM_THREADS), lds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu, plane)
-    if (x3) { if (mask) EXORL_CM(true, true); else EXORL_CM(true, false); }
-    else    { if (mask) EXORL_CM(false, true); else EXORL_CM(false, false); }
+#define EXORL_CM(NN, MM) hipLaunchKernelGGL((conv3x3_mfma_kernel<NN, MM>), dim3(n), dim3(CM_THREADS), lds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu, plane)
+    if (npl == 3)      { if (mask) EXORL_CM(3, true); else EXORL_CM(3, false); }
+    else if (npl == 2) { if (mask) EXORL_CM(2, true); else EXORL_CM(2, false); }
+    else               { if (mask) EXORL_CM(1, true); else EXORL_CM(1, false); }
 #undef EXORL_CM
     EXORL_LAUNCH_CHECK();
     return 0;
@@ -385,7 +411,7 @@ static int conv3x3_mfma(const float* in, const float* Wt, const float* bias, con
 // prec: EXORL_PREC_F32 -> direct fp32 FMA kernel for every layer; bf16 / split-bf16 -> the 32-channel stride-1 layers on MFMA
 static int conv3x3(const float* in, const float* Wt, const float* bias, const float* mask, float* out, int n, int ci_n, int co_n, int ih, int iw,
                    int oh, int ow, int stride, int pad, int in_scale, int relu, hipStream_t s, int prec = EXORL_PREC_F32, const float* frag = nullptr) {
-    if (prec != EXORL_PREC_F32 && ci_n == CONV_CO && co_n == CONV_CO && stride == 1 && !in_scale && frag && conv3x3_mfma_fits(oh, ow))
+    if (prec != EXORL_PREC_F32 && ci_n == CONV_CO && co_n == CONV_CO && stride == 1 && !in_scale && frag && conv3x3_mfma_fits(oh, ow, prec))
         return conv3x3_mfma(in, frag, bias, mask, out, n, ih, iw, oh, ow, pad, relu, prec, s);
     const int tin = (CONV_TILE - 1) * stride + 3;
     const size_t lds = (size_t)ci_n * tin * tin * sizeof(float);
@@ -682,7 +708,7 @@ int64_t exorl_encoder_workspace_floats(int32_t n, int32_t c_in, int32_t hw) {
     for (int l = 1; l <= 4; ++l) f += round_up((int64_t)n * CONV_CO * g.edge[l] * g.edge[l], 64);          // activations
     for (int l = 1; l <= 3; ++l) f += round_up((int64_t)n * CONV_CO * g.edge[l] * g.edge[l], 64);          // d(activations) 1..3
     f += 2 * 4 * round_up((int64_t)CONV_CO * CONV_CO * 9, 64);                                             // Wf, Wb per layer
-    f += 2 * 4 * round_up((int64_t)2 * CM_FRAG * 4, 64);                                                   // MFMA fragment planes (hi, lo) per layer and direction
+    f += 2 * 4 * round_up((int64_t)3 * CM_FRAG * 4, 64);                                                   // MFMA fragment planes (hi, second, third) per layer and direction
     f += round_up((int64_t)n * CONV_CO * CONV_CO * 9, 64) + round_up((int64_t)n * CONV_CO, 64);           // wgrad partials
     return f;
 }
@@ -695,7 +721,7 @@ static EncWs enc_carve(const EncGeom& g, int n, float* ws) {
     for (int l = 1; l <= 4; ++l) w.act[l] = take((int64_t)n * CONV_CO * g.edge[l] * g.edge[l]);
     for (int l = 1; l <= 3; ++l) w.dact[l] = take((int64_t)n * CONV_CO * g.edge[l] * g.edge[l]);
     for (int l = 0; l < 4; ++l) { w.wf[l] = take((int64_t)CONV_CO * CONV_CO * 9); w.wb[l] = take((int64_t)CONV_CO * CONV_CO * 9); }
-    for (int l = 0; l < 4; ++l) { w.ff[l] = take((int64_t)2 * CM_FRAG * 4); w.fb[l] = take((int64_t)2 * CM_FRAG * 4); }
+    for (int l = 0; l < 4; ++l) { w.ff[l] = take((int64_t)3 * CM_FRAG * 4); w.fb[l] = take((int64_t)3 * CM_FRAG * 4); }
     w.P = take((int64_t)n * CONV_CO * CONV_CO * 9);
     w.Pb = take((int64_t)n * CONV_CO);
     return w;
@@ -710,14 +736,16 @@ int exorl_encoder_forward(const float* params_dev, int32_t c_in, int32_t hw, con
 int exorl_encoder_forward_prec(const float* params_dev, int32_t c_in, int32_t hw, const float* x_dev, int32_t n, float* ws_dev, float** h_out_dev,
                                int32_t prec, void* stream) {
     EXORL_REQUIRE(params_dev && x_dev && ws_dev && n > 0 && c_in > 0 && c_in <= 16 && hw >= 16, "encoder_forward: bad arguments");
-    EXORL_REQUIRE(prec == EXORL_PREC_F32 || prec == EXORL_PREC_BF16 || prec == EXORL_PREC_BF16X3, "encoder_forward: unknown precision %d", prec);
+    EXORL_REQUIRE(prec >= EXORL_PREC_F32 && prec <= EXORL_PREC_BF16X6, "encoder_forward: unknown precision %d", prec);
     hipStream_t s = as_stream(stream);
     const EncGeom g = enc_geom(c_in, hw);
     const EncWs w = enc_carve(g, n, ws_dev);
     const float* in = x_dev;
+    const int prec_cfg = prec;                  // the fragment shadows follow the configured mode (the backward pass may still want them)
+    if (prec == EXORL_PREC_BF16X3 && (prec_override_mask() & 64)) prec = EXORL_PREC_F32;      // diagnostic (exorl_debug_precision_override)
     for (int l = 0; l < 4; ++l) {
         const int ci = l == 0 ? c_in : CONV_CO;
-        const bool frags = l > 0 && prec != EXORL_PREC_F32;
+        const bool frags = l > 0 && prec_cfg != EXORL_PREC_F32;
         hipLaunchKernelGGL(conv_weight_shadow_kernel, dim3(cdiv(CONV_CO * ci * 9, 256)), dim3(256), 0, s, params_dev + g.w_off[l], w.wf[l],
                            l > 0 ? w.wb[l] : nullptr, ci, frags ? reinterpret_cast<uint4*>(w.ff[l]) : nullptr, frags ? reinterpret_cast<uint4*>(w.fb[l]) : nullptr);
         EXORL_LAUNCH_CHECK();
@@ -738,7 +766,7 @@ int exorl_encoder_backward(const float* params_dev, int32_t c_in, int32_t hw, co
 int exorl_encoder_backward_prec(const float* params_dev, int32_t c_in, int32_t hw, const float* x_dev, int32_t n, float* ws_dev, float* dh_dev,
                                 float* grads_dev, int32_t prec, void* stream) {
     EXORL_REQUIRE(params_dev && x_dev && ws_dev && dh_dev && grads_dev && n > 0, "encoder_backward: bad arguments");
-    EXORL_REQUIRE(prec == EXORL_PREC_F32 || prec == EXORL_PREC_BF16 || prec == EXORL_PREC_BF16X3, "encoder_backward: unknown precision %d", prec);
+    EXORL_REQUIRE(prec >= EXORL_PREC_F32 && prec <= EXORL_PREC_BF16X6, "encoder_backward: unknown precision %d", prec);
     hipStream_t s = as_stream(stream);
     const EncGeom g = enc_geom(c_in, hw);
     const EncWs w = enc_carve(g, n, ws_dev);
@@ -758,8 +786,12 @@ int exorl_encoder_backward_prec(const float* params_dev, int32_t c_in, int32_t h
             EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr = true;
         }
-        if (prec != EXORL_PREC_F32 && l > 0)
-            EXORL_TRY(conv_wgrad_mfma(d, in, w.P, w.Pb, n, ih, ih, oh, oh, prec, s));
+        const int ov = prec == EXORL_PREC_BF16X3 ? prec_override_mask() : 0;                    // diagnostic (exorl_debug_precision_override)
+        // three-plane mode: the weight-gradient kernel stages dY and three shifted copies of X per plane (74 KB): three planes do not fit 160 KB,
+        // so its weight gradients take the fp32 FMA kernel
+        const int prec_w = ((ov & 256) || prec == EXORL_PREC_BF16X6) ? EXORL_PREC_F32 : prec, prec_d = (ov & 128) ? EXORL_PREC_F32 : prec;
+        if (prec_w != EXORL_PREC_F32 && l > 0)
+            EXORL_TRY(conv_wgrad_mfma(d, in, w.P, w.Pb, n, ih, ih, oh, oh, prec_w, s));
         else {
             hipLaunchKernelGGL(conv_wgrad_kernel, dim3(n), dim3(1024), lds, s, d, in, w.P, w.Pb, ci, ih, ih, oh, oh, stride, l == 0 ? 1 : 0);
             EXORL_LAUNCH_CHECK();
@@ -767,7 +799,7 @@ int exorl_encoder_backward_prec(const float* params_dev, int32_t c_in, int32_t h
         EXORL_TRY(colsum(w.P, grads_dev + g.w_off[l], n, CONV_CO * ci * 9, 1, 0, 0, s));
         EXORL_TRY(colsum(w.Pb, grads_dev + g.b_off[l], n, CONV_CO, 1, 0, 0, s));
         if (l > 0) {              // d(a_l) = full correlation of d(a_{l+1}) with the flipped kernel, masked by a_l > 0
-            EXORL_TRY(conv3x3(d, w.wb[l], nullptr, w.act[l], w.dact[l], n, CONV_CO, CONV_CO, oh, oh, ih, ih, 1, 2, 0, 0, s, prec, prec != EXORL_PREC_F32 ? w.fb[l] : nullptr));
+            EXORL_TRY(conv3x3(d, w.wb[l], nullptr, w.act[l], w.dact[l], n, CONV_CO, CONV_CO, oh, oh, ih, ih, 1, 2, 0, 0, s, prec_d, prec_d != EXORL_PREC_F32 ? w.fb[l] : nullptr));
             d = w.dact[l];
         }
     }

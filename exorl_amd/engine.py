@@ -13,7 +13,7 @@ from . import _lib as L
 
 KIND = {'td3_bc': L.AGENT_TD3_BC, 'td3': L.AGENT_TD3, 'bc': L.AGENT_BC, 'ddpg': L.AGENT_DDPG, 'crr': L.AGENT_CRR, 'cql': L.AGENT_CQL,
         'aps': L.AGENT_APS}
-PRECISION = {'fp32': L.PREC_F32, 'f32': L.PREC_F32, 'bf16': L.PREC_BF16, 'bf16x3': L.PREC_BF16X3}
+PRECISION = {'fp32': L.PREC_F32, 'f32': L.PREC_F32, 'bf16': L.PREC_BF16, 'bf16x3': L.PREC_BF16X3, 'bf16x6': L.PREC_BF16X6}
 METRIC_KEYS = {L.M_BATCH_REWARD: 'batch_reward', L.M_CRITIC_TARGET_Q: 'critic_target_q', L.M_CRITIC_Q1: 'critic_q1',
                L.M_CRITIC_Q2: 'critic_q2', L.M_CRITIC_LOSS: 'critic_loss', L.M_ACTOR_LOSS: 'actor_loss',
                L.M_ACTOR_LOGPROB: 'actor_logprob'}
@@ -134,6 +134,24 @@ class AgentEngine:
         L.check(self.lib.exorl_agent_act(self.h, o.data_ptr(), n, stddev, int(eval_mode), L.ptr(nz), out.data_ptr(),
                                          L.current_stream()))
         return out
+
+    def act_host(self, obs, stddev, eval_mode, noise=None):
+        """act() for ONE observation in one kernel launch (exorl_agent_act_host): the row and the optional noise row travel as kernel
+        arguments, the action lands in a pinned host slot. Returns a numpy (act_dim,) array, or None when the fused kernel does not apply
+        (CQL's tanh-Gaussian policy, hidden_dim % 4 != 0) and the caller should take act()."""
+        if self.kind == 'cql' or self.hidden_dim % 4 != 0 or self.obs_dim > 256:
+            return None
+        slot = getattr(self, '_act_slot', None)
+        if slot is None:
+            slot = self._act_slot = torch.zeros(64, dtype=torch.float32).pin_memory()
+        o = np.ascontiguousarray(np.asarray(obs, np.float32).reshape(-1))
+        assert o.size == self.obs_dim, (o.size, self.obs_dim)
+        nz = None if noise is None else np.ascontiguousarray(np.asarray(noise, np.float32).reshape(-1))
+        stream = L.current_stream()
+        L.check(self.lib.exorl_agent_act_host(self.h, o.ctypes.data, 1, float(stddev), int(eval_mode), nz.ctypes.data if nz is not None else None,
+                                              slot.data_ptr(), stream))
+        torch.cuda.current_stream(self.device).synchronize()
+        return slot[:self.act_dim].numpy().copy()
 
     def set_comm(self, comm):
         """Attach an exorl_amd.comm.Comm of cfg.world_size ranks: update() then runs the data-parallel step in one call."""

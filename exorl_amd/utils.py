@@ -5,6 +5,7 @@ import contextlib
 import functools
 import random
 import re
+import time
 
 import numpy as np
 import torch
@@ -88,3 +89,45 @@ def soft_update_params(net, target_net, tau):
         L.check(lib.exorl_soft_update(p.data_ptr(), t.data_ptr(), p.numel(), tau, L.current_stream()))
     if getattr(target_net, '_on_change', None):
         target_net._on_change()
+
+
+class _StepGate:
+    """Shared arithmetic of the training loops' step predicates (pretrain.py:209-215, train_offline.py:84-88): the configured frame count is
+    converted to agent steps by integer division with `action_repeat`, at call time; a count of None switches the gate off."""
+
+    def __init__(self, frames, action_repeat=1):
+        self.frames, self.action_repeat = frames, action_repeat
+
+    def _steps(self):
+        return None if self.frames is None else self.frames // self.action_repeat
+
+
+class Until(_StepGate):
+    """utils.py:87-96: `while train_until_step(step)` — true while step < until // action_repeat; always true when until is None."""
+
+    def __call__(self, step):
+        limit = self._steps()
+        return True if limit is None else step < limit
+
+
+class Every(_StepGate):
+    """utils.py:99-110: `if eval_every_step(step)` — true on multiples of every // action_repeat; never when every is None."""
+
+    def __call__(self, step):
+        period = self._steps()
+        return False if period is None else step % period == 0
+
+
+class Timer:
+    """utils.py:113-125: reset() -> (seconds since the previous reset, seconds since construction); total_time()."""
+
+    def __init__(self):
+        self._t0 = self._lap = time.time()
+
+    def reset(self):
+        now = time.time()
+        lap, self._lap = now - self._lap, now
+        return lap, now - self._t0
+
+    def total_time(self):
+        return time.time() - self._t0

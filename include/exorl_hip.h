@@ -133,6 +133,11 @@ typedef struct exorl_agent exorl_agent_t;
 #define EXORL_PREC_BF16X3 2    /* split-bf16: every GEMM operand x = hi + lo (two bf16), product = hi*hi + hi*lo + lo*hi on the bf16 MFMA,
                                   fp32 accumulate; everything else as EXORL_PREC_F32. ~2^-16 relative product error: per-step losses stay
                                   within the 1e-4 parity bar of the fp32 reference (tests/test_gpu_agent.py) at about twice fp32 mode's rate */
+#define EXORL_PREC_BF16X6 3    /* three-plane split-bf16 (pixel agents and intrinsic modules only): x = hi + mid + lo, three bf16 planes = the 24
+                                  significand bits of fp32 held exactly; product = hi*hi + (hi*mid + mid*hi) + (hi*lo + lo*hi + mid*mid) on the bf16
+                                  MFMA, fp32 accumulate, the three dropped terms <= 3 * 2^-24 per product — fp32-grade products at 6 / 16 of the fp32
+                                  MFMA's cycles. Generic GEMMs and the 32-channel convolutions (forward, dgrad); the convolution weight gradients
+                                  and the first layer run as in EXORL_PREC_F32. */
 
 #define EXORL_NET_ACTOR         0
 #define EXORL_NET_CRITIC        1
@@ -226,6 +231,12 @@ int exorl_agent_cql_alpha(exorl_agent_t* a, float* log_alpha_host, int32_t set);
 /* Policy inference for n rows: out = mean (eval) or TruncatedNormal sample (clip=None). */
 int exorl_agent_act(exorl_agent_t* a, const float* obs_dev, int32_t n, float stddev, int32_t eval_mode,
                     const float* noise_dev, float* action_out_dev, void* stream);
+/* The same for the online loop's one observation per environment step (pretrain.py:271-283 -> ddpg.py:221-238 / td3_bc.py:107-117): obs_host
+ * (n <= 2 rows) and noise_host (or NULL -> device Philox) are HOST pointers copied into the kernel arguments, `action_out` is any
+ * device-accessible address — pinned host memory makes the result visible after a stream synchronise with no copy. One kernel launch, no other
+ * device work. Not for CQL's tanh-Gaussian policy (exorl_agent_act handles it). */
+int exorl_agent_act_host(exorl_agent_t* a, const float* obs_host, int32_t n, float stddev, int32_t eval_mode,
+                         const float* noise_host, float* action_out, void* stream);
 /* Synchronous: copies the metric block of the last update to host. */
 int exorl_agent_metrics(exorl_agent_t* a, float* metrics_host, void* stream);
 /* The reference computes its metrics dict only under use_tb (td3_bc.py:133,162,175); enable = 0 skips the metric
@@ -272,6 +283,10 @@ int exorl_gemm_planes(int32_t count, const int32_t* a_layouts, int32_t b_layout,
                       float* const* C_dev, int64_t ldc, int32_t relu, void* stream);
 /* Tuning switch for the bf16-operand GEMM (tools/micro/gemm_bench.py): -1 = default heuristics. */
 int exorl_gemm_tune(int32_t variant);
+/* Diagnostic only (tools/debug/config4_ablation.py): in EXORL_PREC_BF16X3 mode, run the selected product families with exact fp32 products.
+ * bits 1/2 forward GEMM narrow/wide, 4/8 wgrad, 16/32 dgrad ("wide": a dimension >= 8192), 64/128/256 convolution forward/dgrad/wgrad.
+ * No reference counterpart; the product never calls it. */
+int exorl_debug_precision_override(int32_t mask);
 /* Diagnostic (tools/micro/stamp_bench.py; tuning bit 33554432 selects the stamped build of the forward H x H GEMM): per workgroup
  * {s_memtime x 4, s_memrealtime x 4} at entry / first k-step / last k-step / stores drained; 8 words per workgroup, <= 1024 workgroups. */
 int exorl_debug_gemm_stamps(uint64_t* out_host, int32_t n_words);

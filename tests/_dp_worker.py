@@ -195,6 +195,11 @@ def main():
         result[tag] = metrics
         del ag, it
     run_unsup(rank, world, out_dir, result)
+    # no noise hook: the device Philox stream of each rank (the ranks of one global batch must not repeat each other's noise rows)
+    ag = build_agent('td3_bc', 'fp32', Br, False)
+    seed = int(ag.engine.cfg.seed)
+    np.savez(out_dir / f'noise_rank{rank}.npz', seed=np.uint64(seed), block=ag.engine.philox_normal(seed, 2, (Br, A)).cpu().numpy())
+    del ag
     json.dump(result, open(out_dir / f'metrics_rank{rank}.json', 'w'))
     dist.barrier()
     dist.destroy_process_group()

@@ -90,3 +90,32 @@ def synth_episodes(seed, lengths, obs_dim, act_dim, meta_dim=0, obs_u8=False):
             ep['skill'] = rs.standard_normal((rows, meta_dim)).astype(np.float32)
         eps.append(ep)
     return eps
+
+
+# ---- BASELINE config 4 (Proto on jaco pixels) at its own sizes: tests/golden/config4_proto_b1024.npz (tools/gen_golden.py::gen_config4)
+def config4_inputs(step, B, C, HW, A, NP):
+    """Inputs of update() number `step` of the config-4 fixture, regenerated from seeds on both sides (nothing batch-sized is stored):
+    uint8 frames, the (action, reward, discount) rows, the two augmentation shift blocks and the Categorical uniforms."""
+    rs = np.random.RandomState(4000 + step)
+    obs = rs.randint(0, 256, (B, C, HW, HW)).astype(np.uint8)
+    nobs = rs.randint(0, 256, (B, C, HW, HW)).astype(np.uint8)
+    b = synth_batch(3, step, B, 4, A)
+    so, sn = rs.randint(0, 9, (B, 2)).astype(np.int32), rs.randint(0, 9, (B, 2)).astype(np.int32)
+    u = rs.uniform(size=NP).astype(np.float32)
+    return obs, nobs, b[1], b[2], b[3], so, sn, u
+
+
+def config4_params(C, A, F, H, PD, PJ, NP, R=39200):
+    """Explicit weights of the config-4 fixture: He-scaled convolutions (encodings stay O(1), as under the reference's own orthogonal
+    init), 1/sqrt(fan_in) Linear layers. Returns dict module -> ordered dict of arrays (reference state_dict keys)."""
+    enc_keys = [f'convnet.{i}.{w}' for i in (0, 2, 4, 6) for w in ('weight', 'bias')]
+    esh = list(zip(enc_keys, [s for l in range(4) for s in ((32, C if l == 0 else 32, 3, 3), (32,))]))
+    tr = [('trunk.0.weight', (F, R)), ('trunk.0.bias', (F,)), ('trunk.1.weight', (F,)), ('trunk.1.bias', (F,))]
+    head = lambda pre, i_, o_: [(f'{pre}.0.weight', (H, i_)), (f'{pre}.0.bias', (H,)), (f'{pre}.2.weight', (H, H)), (f'{pre}.2.bias', (H,)),
+                                (f'{pre}.4.weight', (o_, H)), (f'{pre}.4.bias', (o_,))]
+    ash = tr + head('policy', F, A)
+    csh = tr + head('Q1', F + A, 1) + head('Q2', F + A, 1)
+    return {'encoder': synth_conv_params(esh, 70), 'actor': synth_params(ash, 71), 'critic': synth_params(csh, 72),
+            'predictor': synth_params([('weight', (PD, R)), ('bias', (PD,))], 73),
+            'projector': synth_params([('trunk.0.weight', (PJ, PD)), ('trunk.0.bias', (PJ,)), ('trunk.2.weight', (PD, PJ)), ('trunk.2.bias', (PD,))], 74),
+            'protos': synth_params([('weight', (NP, PD))], 75)}

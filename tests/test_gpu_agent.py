@@ -593,23 +593,20 @@ def test_state_dict_snapshot_crosses_to_a_reference_shaped_module(gold, tmp_path
         assert torch.equal(p, q)
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
-def test_config5_eight_virtual_ranks_of_512_vs_reference(gold, precision):
-    """BASELINE.json configs[4]: TD3, cheetah shapes (O=17, A=6, H=1024), global batch 4096 sharded 8 x 512. Eight engines built with
-    world_size=8 take their 512-row shard of the reference's batch; between the phases their gradient buffers are summed in rank order
-    (what the all-reduce does across GPUs) and written back to every rank. Bars: the global means of every step within 1e-4 of the
-    reference's B=4096 run (tests/golden/full_td3_b4096.json), replicas bit-identical, final parameters = the reference's checksums."""
+def _virtual_ranks_vs_reference(gold, fixture, kind, R, precision, alpha):
+    """R engines built with world_size=R each take their B/R-row shard of the reference's batch; between the phases their gradient buffers
+    (and TD3+BC's sum|Q| statistic) are summed in rank order — what the all-reduce does across GPUs — and written back to every rank."""
     from exorl_amd.engine import AgentEngine
     from exorl_amd import _lib as L
-    g = json.load(open(gold / 'full_td3_b4096.json'))
+    g = json.load(open(gold / fixture))
     O, A, H, B = g['dims']
-    R, Br = 8, B // 8
-    ash, csh = param_shapes('td3', O, A, H)
+    Br = B // R
+    ash, csh = param_shapes(kind, O, A, H)
     pa = list(_synth.synth_params(ash, g['param_seed']).values())
     pc = list(_synth.synth_params(csh, g['param_seed'] + 1).values())
     ranks = []
     for r in range(R):
-        e = AgentEngine('td3', O, A, H, Br, world_size=R, precision=precision, alpha=0.0)
+        e = AgentEngine(kind, O, A, H, Br, world_size=R, precision=precision, alpha=alpha)
         for i, w in enumerate(pa):
             e.tensor(L.NET_ACTOR, i).copy_(torch.from_numpy(w).reshape(e.tensor(L.NET_ACTOR, i).shape))
         for i, w in enumerate(pc):
@@ -626,17 +623,20 @@ def test_config5_eight_virtual_ranks_of_512_vs_reference(gold, precision):
     ns = _synth.NoiseStream(g['noise_seed'])
     keys = {'batch_reward': L.M_BATCH_REWARD, 'critic_target_q': L.M_CRITIC_TARGET_Q, 'critic_q1': L.M_CRITIC_Q1, 'critic_q2': L.M_CRITIC_Q2,
             'critic_loss': L.M_CRITIC_LOSS, 'actor_loss': L.M_ACTOR_LOSS}
+    exchanges = {0: lambda: [e.flat(L.NET_CRITIC, L.T_GRAD) for e in ranks], 2: lambda: [e.flat(L.NET_ACTOR, L.T_GRAD) for e in ranks]}
+    if kind == 'td3_bc':
+        exchanges[1] = lambda: [e.stats() for e in ranks]          # lambda = alpha / mean|Q| over the GLOBAL batch (td3_bc.py:154)
     for step in range(g['nsteps']):
         batch = _synth.synth_batch(g['batch_seed'], step, B, O, A)
         n1, n2 = ns.draw((B, A)), ns.draw((B, A))
         sl = [slice(r * Br, (r + 1) * Br) for r in range(R)]
         for e, s_ in zip(ranks, sl):
             e.set_batch(*[x[s_] for x in batch])
-        for ph, bufs in ((0, lambda: [e.flat(L.NET_CRITIC, L.T_GRAD) for e in ranks]), (1, None), (2, lambda: [e.flat(L.NET_ACTOR, L.T_GRAD) for e in ranks]), (3, None)):
+        for ph in range(4):
             for e, s_ in zip(ranks, sl):
                 e.update_phase(ph, 0.2, n1[s_], n2[s_])
-            if bufs:
-                allreduce(bufs())
+            if ph in exchanges:
+                allreduce(exchanges[ph]())
         m = sum(e.metrics_raw() for e in ranks)        # partial means add up to the global means
         for k, idx in keys.items():
             v = g['fp32']['metrics'][step][k]
@@ -647,3 +647,20 @@ def test_config5_eight_virtual_ranks_of_512_vs_reference(gold, precision):
         flat = torch.cat([ranks[0].tensor(net, i).double().reshape(-1) for i in range(ranks[0].num_tensors(net))])
         s, s2, mx = g['fp32']['checksums'][nm]
         assert abs(float((flat * flat).sum()) - s2) <= 1e-5 * s2 and abs(float(flat.abs().max()) - mx) <= 1e-4 * mx, nm
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_config5_eight_virtual_ranks_of_512_vs_reference(gold, precision):
+    """BASELINE.json configs[4]: TD3, cheetah shapes (O=17, A=6, H=1024), global batch 4096 sharded 8 x 512. Bars: the global means of every
+    step within 1e-4 of the reference's B=4096 run (tests/golden/full_td3_b4096.json), replicas bit-identical, final parameters = the
+    reference's checksums."""
+    _virtual_ranks_vs_reference(gold, 'full_td3_b4096.json', 'td3', 8, precision, 0.0)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_headline_strong_scaling_eight_virtual_ranks_of_128_vs_reference(gold, precision):
+    """The headline config under STRONG scaling (bench.py --scaling strong --gpus 8): TD3+BC, walker shapes, the reference's global
+    batch of 1024 sharded 8 x 128, ten steps against tests/golden/full_td3_bc.json at 1e-4. At 128 rows per rank the split-bf16 pipeline stays
+    on the hi/lo-plane kernels (planes_ok: rows % 64 == 0; gemm16p: M % 128 == 0, and the wgrad's K = 128 rows is exactly one four-stage
+    ring), with tiles in id order because one 128-row tile cannot form an XCD block; the third exchange is TD3+BC's 4-float sum|Q|."""
+    _virtual_ranks_vs_reference(gold, 'full_td3_bc.json', 'td3_bc', 8, precision, 2.5)

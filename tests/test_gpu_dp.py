@@ -26,6 +26,15 @@ def dp_run(request):
     return run
 
 
+def test_ranks_draw_different_device_noise(dp_run):
+    """Without a noise hook every rank draws the TruncatedNormal noise of ITS rows on the device: the ranks' Philox streams differ (the rank is
+    folded into the seed in _AgentBase._build), so the global batch has iid noise rows as the reference's single process draws them."""
+    n0, n1 = (np.load(dp_run['out'] / f'noise_rank{r}.npz') for r in (0, 1))
+    assert int(n0['seed']) != int(n1['seed'])
+    assert n0['block'].shape == n1['block'].shape and not np.array_equal(n0['block'], n1['block'])
+    assert abs(float(np.corrcoef(n0['block'].reshape(-1), n1['block'].reshape(-1))[0, 1])) < 0.2
+
+
 @pytest.mark.parametrize('tag', ['td3_bc_fp32', 'td3_bc_bf16x3', 'bc_fp32'])
 def test_two_process_dp_equals_single_process(dp_run, tag):
     import _dp_worker as W

@@ -26,7 +26,7 @@ def bf16_round(x):
 SHAPES = [(64, 64, 32), (100, 70, 50), (1, 6, 1024), (1024, 1024, 1024), (1024, 30, 1024), (37, 129, 67), (2048, 1024, 24)]
 
 
-@pytest.mark.parametrize('prec', [0, 1, 2])
+@pytest.mark.parametrize('prec', [0, 1, 2, 3])
 @pytest.mark.parametrize('al,bl', [(0, 0), (0, 1), (1, 1), (1, 0)])
 @pytest.mark.parametrize('M,N,K', SHAPES)
 def test_gemm(lib, prec, al, bl, M, N, K):
@@ -52,7 +52,8 @@ def test_gemm(lib, prec, al, bl, M, N, K):
             ref = ref + C0
         scale = np.abs(Ar).astype(np.float64) @ np.abs(Br).astype(np.float64) + 1.0
         err = np.abs(c.cpu().numpy() - ref) / scale
-        # fp32 accumulation order only; split-bf16 (prec 2) drops the lo*lo term and the third bf16 digit: <= 3 * 2^-18 per product
+        # fp32 accumulation order only; split-bf16 (prec 2) drops the lo*lo term and the third bf16 digit: <= 3 * 2^-18 per product;
+        # three planes (prec 3) hold all 24 significand bits and drop three terms of <= 2^-24 each: the fp32 bar
         assert err.max() < (1.2e-5 if prec == 2 else 2e-6), (prec, al, bl, M, N, K, relu, acc, err.max())
 
 
@@ -160,6 +161,23 @@ sys.exit(0 if err < 2e-6 else 3)
         for x3 in (0, 1):
             r = subprocess.run([sys.executable, '-c', code, str(al), str(x3)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
             assert r.returncode == 0, (al, x3, r.stdout[-2000:])
+
+
+def test_gemm_three_plane_products_are_fp32_grade(lib):
+    """EXORL_PREC_BF16X6: hi + mid + lo hold an fp32 value exactly, six of the nine plane products are formed. On operands whose products need
+    more than 16 bits — integers up to 2^11 against integers up to 2^11 — split-bf16 (prec 2) is visibly inexact, three planes are exact."""
+    from exorl_amd import _lib as L
+    rs = np.random.RandomState(0)
+    A = rs.randint(-2048, 2048, (64, 64)).astype(np.float32)
+    B = rs.randint(-2048, 2048, (64, 64)).astype(np.float32)
+    a, b = dev(A), dev(np.ascontiguousarray(B.T))
+    want = A.astype(np.float64) @ B.astype(np.float64)
+    err = {}
+    for prec in (2, 3):
+        c = torch.zeros(64, 64, device='cuda')
+        L.check(lib.exorl_gemm(prec, 0, 0, 64, 64, 64, a.data_ptr(), 64, b.data_ptr(), 64, c.data_ptr(), 64, None, 0, 0, None))
+        err[prec] = float(np.abs(c.cpu().numpy().astype(np.float64) - want).max() / np.abs(want).max())
+    assert err[3] < 2e-7 and err[2] > 10 * err[3] + 1e-7, err
 
 
 def test_gemm_f32_is_exact_fp32_products(lib):

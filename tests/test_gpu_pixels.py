@@ -80,7 +80,7 @@ def test_aug_vs_reference(lib, gold, tag):
         assert min(errs) < 2e-2
 
 
-@pytest.mark.parametrize('prec', [0, 2])           # 0: fp32 FMA convolutions; 2: split-bf16 MFMA implicit GEMM for the 32-channel layers
+@pytest.mark.parametrize('prec', [0, 2, 3])        # 0: fp32 FMA convolutions; 2 / 3: split-bf16 / three-plane MFMA implicit GEMM for the 32-channel layers
 @pytest.mark.parametrize('tag', ['c3', 'c9'])
 def test_encoder_vs_reference(lib, gold, tag, prec):
     z = np.load(gold / 'pixels_g5.npz')
@@ -95,11 +95,11 @@ def test_encoder_vs_reference(lib, gold, tag, prec):
         np.testing.assert_allclose(g, want, rtol=2e-4, atol=2e-5 * np.abs(want).max(), err_msg=k)
 
 
-@pytest.mark.parametrize('prec', [0, 2, 1])
+@pytest.mark.parametrize('prec', [0, 2, 3, 1])
 def test_encoder_batch_vs_oracle(lib, prec):
     """A batch that spans several workgroups per layer and ragged output tiles (64x64 images: edges 31, 29, 27, 25)."""
     rs = np.random.RandomState(0)
-    rt, at = {0: (1e-4, 1e-5), 2: (1e-4, 1e-5), 1: (3e-2, 3e-3)}[prec]          # plain bf16 operands: 2^-9 per product
+    rt, at = {0: (1e-4, 1e-5), 2: (1e-4, 1e-5), 3: (1e-4, 1e-5), 1: (3e-2, 3e-3)}[prec]          # plain bf16 operands: 2^-9 per product
     for (n, c, hw) in ((5, 3, 64), (3, 9, 84)):
         p = []
         for l in range(4):
@@ -117,6 +117,27 @@ def test_encoder_batch_vs_oracle(lib, prec):
                 assert cos > 0.995, (f'grad {i}', cos)
             else:
                 np.testing.assert_allclose(a, b, rtol=2 * rt, atol=2 * at * np.abs(b).max(), err_msg=f'grad {i}')
+
+
+def test_encoder_three_plane_convolutions_are_fp32_grade(lib):
+    """EXORL_PREC_BF16X6 against the fp32 FMA kernels on the same inputs: features and every gradient agree to fp32 rounding (a few 1e-7 of
+    the tensor's scale), an order of magnitude closer than the two-plane split — the property that makes it the parity-grade mode of config 4."""
+    rs = np.random.RandomState(3)
+    p = []
+    for l in range(4):
+        ci = 3 if l == 0 else 32
+        p += [(rs.standard_normal((32, ci, 3, 3)) * np.sqrt(2.0 / (ci * 9))).astype(np.float32), (0.1 * rs.standard_normal(32)).astype(np.float32)]
+    x = rs.randint(0, 256, (6, 3, 84, 84)).astype(np.uint8)
+    dh = rs.standard_normal((6, 39200)).astype(np.float32)
+    h0, g0 = run_encoder(lib, p, x, dh, 0)
+    dist = {}
+    for prec in (2, 3):
+        h, g = run_encoder(lib, p, x, dh, prec)
+        e = [float(np.abs(h - h0).max() / np.abs(h0).max())]
+        e += [float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30)) for a, b in zip(g[:6], g0[:6])]      # layers 0-2: their gradients pass through dgrad
+        dist[prec] = max(e)
+    print('encoder vs the fp32 kernels, worst tensor distance: split-bf16', dist[2], 'three-plane', dist[3])
+    assert dist[3] < 2e-6 and dist[2] > 4 * dist[3], dist
 
 
 def _fwd_any(p, x):
@@ -170,7 +191,7 @@ def test_pixel_ddpg_vs_reference(gold):
     assert a.shape == (A,) and np.all(np.abs(a) <= 1.0)
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3', 'bf16x6'])
 def test_pixel_ddpg_batch_vs_oracle(precision):
     """Shipped widths (feature_dim 50, hidden 1024) at a batch that spans many workgroups; 64x64 frames with 9 stacked channels.
     bf16x3: MFMA implicit-GEMM convolutions and split-bf16 Linear layers against the same fp32 oracle and bar."""
@@ -522,3 +543,85 @@ def test_config4_proto_pixels_shipped_dims_vs_oracle(precision):
             worst = max(worst, errs[k])
     print(f'[config 4] proto pixels {precision} B={B}: worst relative metric error {worst:.2e}')
     np.testing.assert_allclose(ag.queue.cpu().numpy(), orc.proto.queue, rtol=2e-4, atol=2e-5 if precision == 'fp32' else 1e-4)
+
+
+def _config4_agent(z, precision):
+    import _synth
+    from exorl_amd import agents
+    C_, HW, A, F, H, B, N, PD, PJ, Q, NP = [int(v) for v in z['dims']]
+    ag = agents.ProtoAgent(pred_dim=PD, proj_dim=PJ, queue_size=Q, num_protos=NP, tau=0.1, encoder_target_tau=0.05, topk=3, update_encoder=True,
+                           name='proto', reward_free=True, obs_type='pixels', obs_shape=(C_, HW, HW), action_shape=(A,), device='cuda', lr=1e-4,
+                           feature_dim=F, hidden_dim=H, critic_target_tau=0.01, num_expl_steps=2000, update_every_steps=2, stddev_schedule=0.2,
+                           nstep=3, batch_size=B, stddev_clip=0.3, init_critic=True, use_tb=True, use_wandb=False, precision=precision)
+    ps = _synth.config4_params(C_, A, F, H, PD, PJ, NP)
+    for nm in ('encoder', 'actor', 'critic', 'predictor', 'projector', 'protos'):
+        view = getattr(ag, nm)
+        sd = view.state_dict()
+        view.load_state_dict({k: torch.from_numpy(v).reshape(sd[k].shape) for k, v in ps[nm].items()})
+    ag.engine.sync_target()
+    for p, t in zip(ag.predictor.parameters(), ag.predictor_target.parameters()):
+        t.copy_(p)
+    ag.engine.encoder_target(init=True)
+    return ag
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x6', 'bf16x3'])
+def test_config4_proto_pixels_b1024_vs_reference(gold, precision):
+    """BASELINE.json configs[3] AT ITS OWN SIZES — jaco frames (3, 84, 84) uint8, A = 9, feature_dim 50, hidden 1024, pred_dim 128, proj_dim 512,
+    512 prototypes, queue 2048, nstep 3, BATCH 1024 — three update() calls against the reference ITSELF (tests/golden/config4_proto_b1024.npz,
+    tools/gen_golden.py::gen_config4; weights, frames, shifts, uniforms and noise regenerated from seeds).
+
+    The bar. The fixture holds four runs of the reference: fp64, and fp32 three ways (oneDNN convolutions on all threads / on one thread, torch's
+    native convolutions). Everything formed BEFORE a network has taken an optimiser step agrees between them to 1e-6, and is held to 1e-4 here.
+    Everything evaluated through a stepped network does not: Adam's first steps move each weight by lr * sign(g), a gradient rounding
+    difference becomes a whole +-lr step wherever it flips a sign (2 M trunk weights), and the reference's own fp32 runs sit 1.1e-3 (update 0),
+    3.0e-3 and 7.3e-3 (updates 1, 2) from its fp64 run on actor_loss (oneDNN; 9e-5 / 7e-4 / 2e-4 on native convolutions) — the reference's fp32
+    trajectory is not defined to 1e-4 at this size. So the reference here is its fp64 trajectory, and a metric passes when it is within 1e-4 of
+    it OR within TWICE the largest distance any of the reference's own three fp32 runs has from it (`band`: three samples of a spread, hence the
+    factor). Measured (round 3, fp32 mode): update 0 within 9.4e-6 on every metric — 100x closer to the fp64 run than the reference's own
+    oneDNN fp32 run (1.1e-3) — updates 1 / 2 within 1.6e-3 / 4.5e-4. Measured distances are printed.
+    `bf16x3` is NOT parity-grade here and is held to 10x the band, as a regression fence only: 3.2e-4 at update 0 (inside the band), 1.1e-2 at
+    updates 1 and 2 (4x outside): its 2^-17 product error flips ~100x more Adam signs than fp32 rounding does. Config 4's parity-grade mode is
+    fp32."""
+    import _synth
+    z = np.load(gold / 'config4_proto_b1024.npz')
+    C_, HW, A, F, H, B, N, PD, PJ, Q, NP = [int(v) for v in z['dims']]
+    keys = [str(k) for k in z['metric_keys']]
+    ref = z['metrics_fp64']
+    band = np.max([np.abs(z[nm] - ref) for nm in ('metrics', 'metrics_1thread', 'metrics_no_onednn')], axis=0)
+    ag = _config4_agent(z, precision)
+    ns = _synth.NoiseStream(22)
+    ag.noise_hook = ns.draw
+    for i in range(N):
+        obs, nobs, act, rew, disc, so, sn, u = _synth.config4_inputs(i, B, C_, HW, A, NP)
+        sh = [so, sn]
+        ag.shift_hook = lambda n: sh.pop(0)
+        ag.cat_hook = lambda n: u
+        m = ag.update(iter([(obs, act, rew, disc, nobs)]), 2 * i)
+        assert sorted(m.keys()) == sorted(keys)
+        rel = {k: abs(m[k] - v) / (abs(v) + 1e-12) for k, v in zip(keys, ref[i])}
+        print(f'[config 4, B=1024, {precision}] update {i}: ' + ' '.join(f'{k}={e:.1e}' for k, e in rel.items()))
+        print(f'[config 4, B=1024] update {i}: the reference\'s own fp32 runs vs its fp64 run: ' +
+              ' '.join(f'{k}={b / (abs(v) + 1e-12):.1e}' for k, v, b in zip(keys, ref[i], band[i])))
+        fence = 10.0 if precision == 'bf16x3' else 2.0
+        for j, (k, v) in enumerate(zip(keys, ref[i])):
+            assert abs(m[k] - v) <= max(1e-4 * abs(v) + 1e-6, fence * band[i][j]), (precision, i, k, m[k], v, band[i][j])
+        if precision != 'bf16x3' and i == 0:      # before chaos sets in: every metric of the first update within 1e-4 of the fp64 reference, no band needed
+            for k, v in zip(keys, ref[i]):
+                assert abs(m[k] - v) <= 1e-4 * abs(v) + 1e-6, (i, k, m[k], v)
+    # parameters after three updates against the reference's fp64 run, every 997th element: the direction of the accumulated step agrees, and
+    # no more steps went the other way than in the reference's own fp32 run (Adam's sign-like first steps: a flipped sign is a 2 lr error)
+    worst = 0.0
+    for nm in ('encoder', 'actor', 'critic', 'predictor', 'projector', 'protos'):
+        for k, t in getattr(ag, nm).state_dict().items():
+            got = t.detach().cpu().numpy().reshape(-1)
+            got = got if got.size <= 4096 else got[::997]
+            init, r64, r32 = (z[f'{tag}/{nm}/{k}'].reshape(-1).astype(np.float64) for tag in ('init_sample', 'final_sample_fp64', 'final_sample'))
+            d, d64, d32 = got - init, r64 - init, r32 - init
+            if np.linalg.norm(d64) < 1e-12:
+                continue
+            cos = float(d @ d64 / (np.linalg.norm(d) * np.linalg.norm(d64) + 1e-30))
+            cos32 = float(d32 @ d64 / (np.linalg.norm(d32) * np.linalg.norm(d64) + 1e-30))
+            assert cos >= min(0.999, cos32 - (2e-2 if precision == 'bf16x3' else 2e-3)), (precision, nm, k, cos, cos32)
+            worst = max(worst, 1 - cos)
+    print(f'[config 4, B=1024, {precision}] parameter steps vs the reference fp64 run: worst 1 - cos = {worst:.2e}')

@@ -207,3 +207,23 @@ def test_offline_file_selection_rule(tmp_path):
     assert idx(todo) == [0, 10, 11, 12, 1, 2, 3, 4, 5, 6, 7, 8, 9] and size == sum(lengths)
     todo, size = _OfflineShard.select(tmp_path, 20, 2, 1)                 # worker 1 of 2: odd episode indices only
     assert idx(todo) == [11, 1, 3, 5, 7] and size == 3 + 3 + 5 + 4 + 15   # 15 <= 20 after four files, so a fifth is taken
+
+
+def test_until_every_timer_semantics():
+    """utils.Until / Every / Timer as the training loops use them (reference utils.py:87-125, pretrain.py:209-215): frame counts are divided by
+    action_repeat at call time, None switches the gate off."""
+    import time
+    from exorl_amd import utils
+    u = utils.Until(100, action_repeat=2)
+    assert [u(s) for s in (0, 49, 50, 51)] == [True, True, False, False]
+    assert utils.Until(None)(10**9) is True
+    e = utils.Every(10, action_repeat=2)
+    assert [e(s) for s in (0, 4, 5, 10, 11)] == [True, False, True, True, False]
+    assert utils.Every(None)(0) is False
+    assert utils.Until(7)(6) and not utils.Until(7)(7) and utils.Every(3)(9) and not utils.Every(3)(10)
+    t = utils.Timer()
+    time.sleep(0.01)
+    lap, total = t.reset()
+    assert 0.005 < lap <= total + 1e-9
+    lap2, total2 = t.reset()
+    assert lap2 < lap and total2 >= total and t.total_time() >= total2

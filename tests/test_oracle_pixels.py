@@ -93,3 +93,53 @@ def test_pixel_proto_trajectory(gold):
     np.testing.assert_allclose(ag.proto.p[6], z['final/protos/weight'], rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(ag.proto.queue, z['final/queue'], rtol=1e-4, atol=1e-6)
     assert ag.proto.queue_ptr == int(z['final/queue_ptr'])
+
+
+def _twin_from_fixture(z, params):
+    from oracle.torch_twin_pixels import TorchTwinProtoPixels
+    C, HW, A, F, H, B, N, PD, PJ, Q, NP = [int(v) for v in z['dims']]
+    tw = TorchTwinProtoPixels(C, HW, A, F, H, PD, PJ, NP, Q)
+    tw.load(params)
+    return tw, (C, HW, A, F, H, B, N, PD, PJ, Q, NP)
+
+
+def test_torch_twin_proto_pixels_matches_reference_miniature(gold):
+    """The torch-CPU twin of Proto-on-pixels (oracle/torch_twin_pixels.py) against the reference's recorded 3-update trajectory."""
+    import _synth
+    z = np.load(gold / 'pixel_proto.npz')
+    C, HW, A, F, H, B, N, PD, PJ, Q, NP = [int(v) for v in z['dims']]
+    esh, ash, csh = pixels.pixel_param_shapes(C, A, F, H)
+    psh = [[('weight', (PD, 39200)), ('bias', (PD,))], [('trunk.0.weight', (PJ, PD)), ('trunk.0.bias', (PJ,)), ('trunk.2.weight', (PD, PJ)), ('trunk.2.bias', (PD,))],
+           [('weight', (NP, PD))]]
+    params = {nm: _synth.synth_params(sh, 50 + i) for i, (nm, sh) in enumerate(zip(('encoder', 'actor', 'critic', 'predictor', 'projector', 'protos'), [esh, ash, csh] + psh))}
+    tw, _ = _twin_from_fixture(z, params)
+    noise = _synth.NoiseStream(21)
+    keys = [str(k) for k in z['metric_keys']]
+    for i in range(N):
+        batch = (z[f'batch/{i}/obs'], z[f'batch/{i}/action'], z[f'batch/{i}/reward'], z[f'batch/{i}/discount'], z[f'batch/{i}/next_obs'])
+        m = tw.update(batch, z['shifts'][2 * i], z['shifts'][2 * i + 1], z['cat_uniform'][i], noise.draw((B, A)), noise.draw((B, A)))
+        np.testing.assert_allclose([m[k] for k in keys], z['metrics'][i], rtol=2e-5, atol=1e-6, err_msg=f'step {i} {keys}')
+    for k, v in tw.encoder.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), z[f'final/encoder/{k}'], rtol=1e-5, atol=1e-6, err_msg=k)
+    np.testing.assert_allclose(tw.queue.numpy(), z['final/queue'], rtol=1e-5, atol=1e-6)
+    assert tw.queue_ptr == int(z['final/queue_ptr'])
+
+
+def test_torch_twin_proto_pixels_matches_reference_config4(gold):
+    """... and at BASELINE config 4's own sizes (batch 1024, hidden 1024, 512 prototypes): the first of the reference's three recorded updates
+    (tests/golden/config4_proto_b1024.npz, `metrics` = the reference on this container's oneDNN fp32 kernels, which the twin shares; one update
+    is ~10-60 s of CPU). What the fixture says about the bar at this size: the reference's own fp32 runs sit 1e-3 (update 0) to 7e-3 (update 2)
+    from its fp64 run on actor_loss — Adam's first steps turn gradient rounding into +-lr steps wherever a sign flips."""
+    import _synth
+    z = np.load(gold / 'config4_proto_b1024.npz')
+    C, HW, A, F, H, B, N, PD, PJ, Q, NP = [int(v) for v in z['dims']]
+    tw, _ = _twin_from_fixture(z, _synth.config4_params(C, A, F, H, PD, PJ, NP))
+    noise = _synth.NoiseStream(22)
+    keys = [str(k) for k in z['metric_keys']]
+    obs, nobs, act, rew, disc, so, sn, u = _synth.config4_inputs(0, B, C, HW, A, NP)
+    m = tw.update((obs, act, rew, disc, nobs), so, sn, u, noise.draw((B, A)), noise.draw((B, A)))
+    np.testing.assert_allclose([m[k] for k in keys], z['metrics'][0], rtol=1e-4, atol=2e-5, err_msg=f'{keys}')
+    # the reference's own runs, as recorded: fp32 on oneDNN (all threads / one thread) and on torch's native convolutions against fp64
+    d = lambda nm: np.abs(z[nm] - z['metrics_fp64']) / (np.abs(z['metrics_fp64']) + 1e-2)
+    assert d('metrics').max() > 1e-3 and d('metrics_1thread').max() > 1e-3 and d('metrics_no_onednn').max() > 1e-4
+    assert d('metrics')[0].max() < 2e-3 and d('metrics_no_onednn')[0].max() < 2e-4       # update 0: 1.1e-3 and 8.8e-5
