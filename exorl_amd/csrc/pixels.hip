@@ -203,7 +203,6 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
 typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
 typedef float cf32x16 __attribute__((ext_vector_type(16)));
 constexpr int CM_PIX = 40;                 // bf16 elements per staged pixel (32 channels + 8 pad = 80 B)
-constexpr int CM_TIN = CONV_TILE + 2;      // 18 (the weight-gradient kernel's X tile)
 
 constexpr int CM_THREADS = 512;            // 8 waves x 32 pixels = 256 output pixels per pass
 constexpr int CM_PASS = 256;
@@ -499,52 +498,55 @@ __global__ __launch_bounds__(1024) void conv_wgrad_kernel(const float* __restric
 // the B fragment (8 consecutive x + dx of one input channel) is aligned too. Per-image partials in the layout of the fp32 kernel,
 // summed in image order by the same column-sum kernel.
 constexpr int WM_THREADS = 512;            // 8 waves (256 VGPRs each): taps 0..7, the last wave also takes tap 8; wave 0 the bias gradient
-constexpr int WM_DYC = CONV_TILE * CONV_TILE + 8;          // bf16 per dY channel (+16 B: conflict-free across 16 channels)
-constexpr int WM_XC = CM_TIN * CONV_TILE + 8;              // bf16 per X channel of one shifted copy
 
-template <bool X3>
+// NPL operand planes (1 bf16, 2 split-bf16, 3 three-plane split); TH = tile height in output rows: 16, or 8 for three planes — dY and the three
+// shifted copies of X take 74 KB of LDS per plane at 16 x 16 (three planes: 221 KB) and 41 KB at 8 x 16 (123 KB)
+template <int NPL, int TH>
 __global__ __launch_bounds__(WM_THREADS) void conv_wgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ in, float* __restrict__ P,
                                                                      float* __restrict__ Pb, int ih, int iw, int oh, int ow) {
+    constexpr bool X3 = NPL >= 2, X6 = NPL == 3;
+    constexpr int TW = CONV_TILE;                              // tile width (16 output columns)
+    constexpr int DYC = TH * TW + 8;                           // bf16 per dY channel (+16 B: conflict-free across 16 channels)
+    constexpr int XR = TH + 2;                                 // X rows of a tile
+    constexpr int XC = XR * TW + 8;                            // bf16 per X channel of one shifted copy
+    constexpr int DPL = CONV_CO * DYC, XPL = 3 * CONV_CO * XC; // elements per plane
     extern __shared__ __attribute__((aligned(16))) unsigned char wm_lds[];
-    unsigned short* dh = reinterpret_cast<unsigned short*>(wm_lds);               // [32][WM_DYC]
-    unsigned short* dl = dh + CONV_CO * WM_DYC;
-    unsigned short* xh = dl + (X3 ? CONV_CO * WM_DYC : 0);                         // [3 dx][32][WM_XC]
-    unsigned short* xl = xh + 3 * CONV_CO * WM_XC;
+    unsigned short* dbase = reinterpret_cast<unsigned short*>(wm_lds);            // [plane][32][DYC]
+    unsigned short* xbase = dbase + NPL * DPL;                                    // [plane][3 dx][32][XC]
     const int n = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, tap = tid >> 6;                  // wave = tap (wave 7: taps 7 and 8)
     const int kg = lane >> 5, col = lane & 31;
     const int dyy = tap / 3, dxx = tap % 3;
     const float* dyn = dy + (int64_t)n * CONV_CO * oh * ow;
     const float* inn = in + (int64_t)n * CONV_CO * ih * iw;
-    cf32x16 acc, accx, accb, acc8, accx8;          // accb: bias gradient (wave 0); acc8 / accx8: tap 8 (wave 7)
+    cf32x16 acc, accx, accy, accb, acc8, accx8, accy8;          // accb: bias gradient (wave 0); acc8 / accx8 / accy8: tap 8 (wave 7)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accx[r] = 0.f; accb[r] = 0.f; acc8[r] = 0.f; accx8[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accx[r] = 0.f; accy[r] = 0.f; accb[r] = 0.f; acc8[r] = 0.f; accx8[r] = 0.f; accy8[r] = 0.f; }
     cbf16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
-    auto pack = [](float a, float b, bool lo) -> unsigned {
+    auto pack = [](float a, float b, int plane) -> unsigned {     // plane 0: bf16(x); 1: bf16(x - p0); 2: bf16(x - p0 - p1)
+        for (int q = 0; q < plane; ++q) { a -= (float)(__bf16)a; b -= (float)(__bf16)b; }
         const __bf16 h0 = (__bf16)a, h1 = (__bf16)b;
-        if (!lo) return (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-        const __bf16 l0 = (__bf16)(a - (float)h0), l1 = (__bf16)(b - (float)h1);
-        return (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+        return (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
     };
-    const int tiles_x = (ow + CONV_TILE - 1) / CONV_TILE, tiles_y = (oh + CONV_TILE - 1) / CONV_TILE;
+    const int tiles_x = (ow + TW - 1) / TW, tiles_y = (oh + TH - 1) / TH;
     for (int tile = 0; tile < tiles_x * tiles_y; ++tile) {
-        const int ty0 = (tile / tiles_x) * CONV_TILE, tx0 = (tile % tiles_x) * CONV_TILE;
+        const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
         __syncthreads();
-        // dY tile: (co, y, x pair); X tile, three copies: copy dx holds columns tx0 + dx .. tx0 + dx + 15 of rows ty0 .. ty0 + 17:
+        // dY tile: (co, y, x pair); X tile, three copies: copy dx holds columns tx0 + dx .. tx0 + dx + 15 of rows ty0 .. ty0 + TH + 1:
         // (dx, ci, yy, x pair). Loads are issued in batches before any value is converted and stored, so that their latencies overlap.
         // (Tried: fetching dY and half of X for the NEXT tile ahead of this tile's MFMA loop and the rest in two batches: 256 VGPRs instead of
         // 176, and 609 us per launch instead of 430 — not kept.)
-        constexpr int DY_ITEMS = CONV_CO * CONV_TILE * (CONV_TILE / 2), DY_PT = DY_ITEMS / WM_THREADS;                              // 4096, 8
-        constexpr int X_ITEMS = 3 * CONV_CO * CM_TIN * (CONV_TILE / 2), X_PT = X_ITEMS / WM_THREADS;                                // 13824, 27
+        constexpr int DY_ITEMS = CONV_CO * TH * (TW / 2), DY_PT = DY_ITEMS / WM_THREADS;
+        constexpr int X_ITEMS = 3 * CONV_CO * XR * (TW / 2), X_PT = X_ITEMS / WM_THREADS;
         static_assert(DY_ITEMS % WM_THREADS == 0 && X_ITEMS % WM_THREADS == 0 && X_PT % 3 == 0, "staging items divide evenly");
         {
             float va[DY_PT], vb[DY_PT];
 #pragma unroll
             for (int u = 0; u < DY_PT; ++u) {
                 const int i = tid + WM_THREADS * u;
-                const int xp = i % (CONV_TILE / 2), y = (i / (CONV_TILE / 2)) % CONV_TILE, co = i / (CONV_TILE * CONV_TILE / 2);
+                const int xp = i % (TW / 2), y = (i / (TW / 2)) % TH, co = i / (TH * TW / 2);
                 const int gy = ty0 + y, gx = tx0 + 2 * xp;
                 va[u] = (gy < oh && gx < ow) ? dyn[((int64_t)co * oh + gy) * ow + gx] : 0.f;
                 vb[u] = (gy < oh && gx + 1 < ow) ? dyn[((int64_t)co * oh + gy) * ow + gx + 1] : 0.f;
@@ -552,10 +554,10 @@ __global__ __launch_bounds__(WM_THREADS) void conv_wgrad_mfma_kernel(const float
 #pragma unroll
             for (int u = 0; u < DY_PT; ++u) {
                 const int i = tid + WM_THREADS * u;
-                const int xp = i % (CONV_TILE / 2), y = (i / (CONV_TILE / 2)) % CONV_TILE, co = i / (CONV_TILE * CONV_TILE / 2);
-                const int o = co * WM_DYC + y * CONV_TILE + 2 * xp;
-                *reinterpret_cast<unsigned*>(dh + o) = pack(va[u], vb[u], false);
-                if constexpr (X3) *reinterpret_cast<unsigned*>(dl + o) = pack(va[u], vb[u], true);
+                const int xp = i % (TW / 2), y = (i / (TW / 2)) % TH, co = i / (TH * TW / 2);
+                const int o = co * DYC + y * TW + 2 * xp;
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<unsigned*>(dbase + pl * DPL + o) = pack(va[u], vb[u], pl);
             }
         }
 #pragma unroll 1
@@ -564,8 +566,7 @@ __global__ __launch_bounds__(WM_THREADS) void conv_wgrad_mfma_kernel(const float
 #pragma unroll
             for (int u = 0; u < X_PT / 3; ++u) {
                 const int i = tid + WM_THREADS * (part * (X_PT / 3) + u);
-                const int xp = i % (CONV_TILE / 2), yy = (i / (CONV_TILE / 2)) % CM_TIN, ci = (i / (CM_TIN * CONV_TILE / 2)) % CONV_CO,
-                          dx = i / (CONV_CO * CM_TIN * CONV_TILE / 2);
+                const int xp = i % (TW / 2), yy = (i / (TW / 2)) % XR, ci = (i / (XR * TW / 2)) % CONV_CO, dx = i / (CONV_CO * XR * TW / 2);
                 const int gy = ty0 + yy, gx = tx0 + dx + 2 * xp;
                 va[u] = (gy < ih && gx < iw) ? inn[((int64_t)ci * ih + gy) * iw + gx] : 0.f;
                 vb[u] = (gy < ih && gx + 1 < iw) ? inn[((int64_t)ci * ih + gy) * iw + gx + 1] : 0.f;
@@ -573,40 +574,53 @@ __global__ __launch_bounds__(WM_THREADS) void conv_wgrad_mfma_kernel(const float
 #pragma unroll
             for (int u = 0; u < X_PT / 3; ++u) {
                 const int i = tid + WM_THREADS * (part * (X_PT / 3) + u);
-                const int xp = i % (CONV_TILE / 2), yy = (i / (CONV_TILE / 2)) % CM_TIN, ci = (i / (CM_TIN * CONV_TILE / 2)) % CONV_CO,
-                          dx = i / (CONV_CO * CM_TIN * CONV_TILE / 2);
-                const int o = (dx * CONV_CO + ci) * WM_XC + yy * CONV_TILE + 2 * xp;
-                *reinterpret_cast<unsigned*>(xh + o) = pack(va[u], vb[u], false);
-                if constexpr (X3) *reinterpret_cast<unsigned*>(xl + o) = pack(va[u], vb[u], true);
+                const int xp = i % (TW / 2), yy = (i / (TW / 2)) % XR, ci = (i / (XR * TW / 2)) % CONV_CO, dx = i / (CONV_CO * XR * TW / 2);
+                const int o = (dx * CONV_CO + ci) * XC + yy * TW + 2 * xp;
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<unsigned*>(xbase + pl * XPL + o) = pack(va[u], vb[u], pl);
             }
         }
         __syncthreads();
 #pragma unroll 2
-        for (int y = 0; y < CONV_TILE; ++y) {                    // k16 step = pixel row y of the tile
-            const int oa = col * WM_DYC + y * CONV_TILE + 8 * kg;                               // A: dY[co = col][y][8 kg ..]
-            const int ob = (dxx * CONV_CO + col) * WM_XC + (y + dyy) * CONV_TILE + 8 * kg;      // B: X[ci = col][y + dy][8 kg + dx ..]
-            const cbf16x8 ah = *reinterpret_cast<const cbf16x8*>(dh + oa);
-            const cbf16x8 bh = *reinterpret_cast<const cbf16x8*>(xh + ob);
-            cbf16x8 al = ah, bl = bh;
+        for (int y = 0; y < TH; ++y) {                           // k16 step = pixel row y of the tile
+            const int oa = col * DYC + y * TW + 8 * kg;                                         // A: dY[co = col][y][8 kg ..]
+            const int ob = (dxx * CONV_CO + col) * XC + (y + dyy) * TW + 8 * kg;                // B: X[ci = col][y + dy][8 kg + dx ..]
+            const cbf16x8 ah = *reinterpret_cast<const cbf16x8*>(dbase + oa);
+            const cbf16x8 bh = *reinterpret_cast<const cbf16x8*>(xbase + ob);
+            cbf16x8 al = ah, bl = bh, at = ah, bt = bh;
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
             if constexpr (X3) {
-                al = *reinterpret_cast<const cbf16x8*>(dl + oa);
-                bl = *reinterpret_cast<const cbf16x8*>(xl + ob);
+                al = *reinterpret_cast<const cbf16x8*>(dbase + DPL + oa);
+                bl = *reinterpret_cast<const cbf16x8*>(xbase + XPL + ob);
                 accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, accx, 0, 0, 0);
                 accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, accx, 0, 0, 0);
             }
-            if (tap == 0) {                                      // wave-uniform: bias gradient = dY . ones
+            if constexpr (X6) {
+                at = *reinterpret_cast<const cbf16x8*>(dbase + 2 * DPL + oa);
+                bt = *reinterpret_cast<const cbf16x8*>(xbase + 2 * XPL + ob);
+                accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bt, accy, 0, 0, 0);
+                accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at, bh, accy, 0, 0, 0);
+                accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl, accy, 0, 0, 0);
+            }
+            if (tap == 0) {                                      // wave-uniform: bias gradient = dY . ones (exact in every plane mode: ones is exact)
                 accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ones, accb, 0, 0, 0);
                 if constexpr (X3) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ones, accb, 0, 0, 0);
+                if constexpr (X6) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at, ones, accb, 0, 0, 0);
             }
             if (tap == 7) {                                      // wave-uniform: tap 8 = (dy 2, dx 2)
-                const int ob8 = (2 * CONV_CO + col) * WM_XC + (y + 2) * CONV_TILE + 8 * kg;
-                const cbf16x8 bh8 = *reinterpret_cast<const cbf16x8*>(xh + ob8);
+                const int ob8 = (2 * CONV_CO + col) * XC + (y + 2) * TW + 8 * kg;
+                const cbf16x8 bh8 = *reinterpret_cast<const cbf16x8*>(xbase + ob8);
                 acc8 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh8, acc8, 0, 0, 0);
                 if constexpr (X3) {
-                    const cbf16x8 bl8 = *reinterpret_cast<const cbf16x8*>(xl + ob8);
+                    const cbf16x8 bl8 = *reinterpret_cast<const cbf16x8*>(xbase + XPL + ob8);
                     accx8 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl8, accx8, 0, 0, 0);
                     accx8 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh8, accx8, 0, 0, 0);
+                    if constexpr (X6) {
+                        const cbf16x8 bt8 = *reinterpret_cast<const cbf16x8*>(xbase + 2 * XPL + ob8);
+                        accy8 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bt8, accy8, 0, 0, 0);
+                        accy8 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at, bh8, accy8, 0, 0, 0);
+                        accy8 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl8, accy8, 0, 0, 0);
+                    }
                 }
             }
         }
@@ -615,23 +629,26 @@ __global__ __launch_bounds__(WM_THREADS) void conv_wgrad_mfma_kernel(const float
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = (r & 3) + 8 * (r >> 2) + 4 * kg;
-        P[(((int64_t)n * CONV_CO + co) * CONV_CO + col) * 9 + tap] = X3 ? accx[r] + acc[r] : acc[r];
-        if (tap == 7) P[(((int64_t)n * CONV_CO + co) * CONV_CO + col) * 9 + 8] = X3 ? accx8[r] + acc8[r] : acc8[r];
+        P[(((int64_t)n * CONV_CO + co) * CONV_CO + col) * 9 + tap] = X6 ? (accy[r] + accx[r]) + acc[r] : X3 ? accx[r] + acc[r] : acc[r];
+        if (tap == 7) P[(((int64_t)n * CONV_CO + co) * CONV_CO + col) * 9 + 8] = X6 ? (accy8[r] + accx8[r]) + acc8[r] : X3 ? accx8[r] + acc8[r] : acc8[r];
         if (tap == 0 && col == 0) Pb[(int64_t)n * CONV_CO + co] = accb[r];
     }
 }
 
 static int conv_wgrad_mfma(const float* dy, const float* in, float* P, float* Pb, int n, int ih, int iw, int oh, int ow, int prec, hipStream_t s) {
-    const bool x3 = prec == EXORL_PREC_BF16X3;
-    const size_t lds = (size_t)(x3 ? 2 : 1) * (CONV_CO * WM_DYC + 3 * CONV_CO * WM_XC) * sizeof(unsigned short);
+    const int npl = prec == EXORL_PREC_BF16X6 ? 3 : (prec == EXORL_PREC_BF16X3 ? 2 : 1);
+    const int th = npl == 3 ? 8 : 16;
+    const size_t lds = (size_t)npl * (CONV_CO * (th * CONV_TILE + 8) + 3 * CONV_CO * ((th + 2) * CONV_TILE + 8)) * sizeof(unsigned short);
     static bool attr = false;
     if (!attr) {
-        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wgrad_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wgrad_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wgrad_mfma_kernel<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wgrad_mfma_kernel<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wgrad_mfma_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    if (x3) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<true>, dim3(n), dim3(WM_THREADS), lds, s, dy, in, P, Pb, ih, iw, oh, ow);
-    else    hipLaunchKernelGGL(conv_wgrad_mfma_kernel<false>, dim3(n), dim3(WM_THREADS), lds, s, dy, in, P, Pb, ih, iw, oh, ow);
+    if (npl == 3)      hipLaunchKernelGGL((conv_wgrad_mfma_kernel<3, 8>), dim3(n), dim3(WM_THREADS), lds, s, dy, in, P, Pb, ih, iw, oh, ow);
+    else if (npl == 2) hipLaunchKernelGGL((conv_wgrad_mfma_kernel<2, 16>), dim3(n), dim3(WM_THREADS), lds, s, dy, in, P, Pb, ih, iw, oh, ow);
+    else               hipLaunchKernelGGL((conv_wgrad_mfma_kernel<1, 16>), dim3(n), dim3(WM_THREADS), lds, s, dy, in, P, Pb, ih, iw, oh, ow);
     EXORL_LAUNCH_CHECK();
     return 0;
 }
@@ -787,9 +804,7 @@ int exorl_encoder_backward_prec(const float* params_dev, int32_t c_in, int32_t h
             attr = true;
         }
         const int ov = prec == EXORL_PREC_BF16X3 ? prec_override_mask() : 0;                    // diagnostic (exorl_debug_precision_override)
-        // three-plane mode: the weight-gradient kernel stages dY and three shifted copies of X per plane (74 KB): three planes do not fit 160 KB,
-        // so its weight gradients take the fp32 FMA kernel
-        const int prec_w = ((ov & 256) || prec == EXORL_PREC_BF16X6) ? EXORL_PREC_F32 : prec, prec_d = (ov & 128) ? EXORL_PREC_F32 : prec;
+        const int prec_w = (ov & 256) ? EXORL_PREC_F32 : prec, prec_d = (ov & 128) ? EXORL_PREC_F32 : prec;
         if (prec_w != EXORL_PREC_F32 && l > 0)
             EXORL_TRY(conv_wgrad_mfma(d, in, w.P, w.Pb, n, ih, ih, oh, oh, prec_w, s));
         else {
