@@ -244,9 +244,14 @@ struct ActFast {
     float* out;
     float stddev;
     int rows, in_dim, H, nout, eval_mode;
+    int first_relu = 0; int64_t W0 = 0;     // pixel policy: the first layer is Linear(in_dim, H) + ReLU with torch-layout weights at offset W0 of P
+                                            // (no W0T shadow, no LayerNorm); b0 is its bias
 };
 bool act_fast_supported(int rows, int in_dim, int H, int nout);
 int act_fast(const ActFast& f, hipStream_t s);
+// pixel act(): tanh(LayerNorm([x | meta] W^T + b)) for one encoding, split over 256 workgroups with an in-launch combine (loss.hip)
+int trunk_one(const float* x, const float* meta, const float* W, const float* b, const float* gain, const float* beta, float* part, unsigned int* ticket,
+              float* out, int R, int M, int F, hipStream_t s);
 // out[0] = sum_i parts[2i], out[1] = sum_i parts[2i+1] in a fixed order (qhead's per-chunk [sum |min Q|, sum min Q] -> the 4-float
 // statistics buffer that is all-reduced under data parallelism)
 int reduce_pairs(const float* parts, int chunks, float* out, hipStream_t s);

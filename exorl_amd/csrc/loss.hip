@@ -143,6 +143,7 @@ struct ActFastArgs {
     float knoise[ACT_FAST_ROWS * 16];       // embedded noise rows (kn != 0)
 };
 
+template <int FIRST>
 __global__ __launch_bounds__(256) void act_fast_kernel(const ActFastArgs a) {
     extern __shared__ float act_sm[];                   // h1[rows][H], then scratch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, H = a.H, rows = a.rows, I = a.in_dim, A = a.nout;
@@ -156,7 +157,13 @@ __global__ __launch_bounds__(256) void act_fast_kernel(const ActFastArgs a) {
         float s1 = 0.f;
         for (int n = tid; n < H; n += 256) {
             float z = a.P[a.b0 + n];
-            for (int i = 0; i < I; ++i) z = fmaf(x[i], a.w0t[(int64_t)i * H + n], z);
+            if constexpr (FIRST == 0) {
+                for (int i = 0; i < I; ++i) z = fmaf(x[i], a.w0t[(int64_t)i * H + n], z);
+            } else {                                    // pixel policy: Linear(feature_dim, H) + ReLU on the trunk's output, torch layout W[n][i]
+                const float* wrow = a.P + a.g + (int64_t)n * I;
+                for (int i = 0; i < I; ++i) z = fmaf(x[i], wrow[i], z);
+                z = fmaxf(z, 0.f);
+            }
             h1[r * H + n] = z;
             s1 += z;
         }
@@ -164,6 +171,7 @@ __global__ __launch_bounds__(256) void act_fast_kernel(const ActFastArgs a) {
         if (lane == 0) red[r][0][wave] = s1;
     }
     __syncthreads();
+    if constexpr (FIRST == 0) {
     for (int r = 0; r < rows; ++r) {                    // LayerNorm (biased variance about the mean, eps 1e-5) + tanh
         const float mean = (red[r][0][0] + red[r][0][1] + red[r][0][2] + red[r][0][3]) / (float)H;
         float s2 = 0.f;
@@ -179,6 +187,7 @@ __global__ __launch_bounds__(256) void act_fast_kernel(const ActFastArgs a) {
         for (int n = tid; n < H; n += 256) h1[r * H + n] = tanhf((h1[r * H + n] - mean) * rstd * a.P[a.g + n] + a.P[a.beta + n]);
     }
     __syncthreads();
+    }
     // ---- Linear(H, H) + ReLU: wave w -> neuron 4 blockIdx.x + w, all rows
     const int nn = 4 * blockIdx.x + wave;
     if (nn < H) {
@@ -265,13 +274,88 @@ int act_fast(const ActFast& f, hipStream_t s) {
     a.w0t = f.w0t; a.P = f.P; a.b0 = f.b0; a.g = f.g; a.beta = f.beta; a.W1 = f.W1; a.b1 = f.b1; a.W2 = f.W2; a.b2 = f.b2;
     a.part = f.part; a.ticket = f.ticket; a.noise = f.noise_dev; a.seed = f.seed; a.counter = f.counter; a.out = f.out; a.stddev = f.stddev;
     a.rows = f.rows; a.in_dim = f.in_dim; a.H = f.H; a.nout = f.nout; a.eval_mode = f.eval_mode; a.kn = 0;
+    if (f.first_relu) a.g = f.W0;                        // row-major first-layer weight rides in the (unused) gain slot
     if (f.x_host) {
         a.x = nullptr;
         for (int r = 0; r < f.rows; ++r) memcpy(a.kx + r * 256, f.x_host + (int64_t)r * f.in_dim, sizeof(float) * f.in_dim);
     }
     if (f.noise_host && !f.eval_mode) { a.kn = 1; memcpy(a.knoise, f.noise_host, sizeof(float) * f.rows * f.nout); }
     const size_t lds = sizeof(float) * ((size_t)f.rows * f.H > 1024 ? (size_t)f.rows * f.H : 1024);
-    hipLaunchKernelGGL(act_fast_kernel, dim3(cdiv(f.H, 4)), dim3(256), lds, s, a);
+    if (f.first_relu) hipLaunchKernelGGL(act_fast_kernel<1>, dim3(cdiv(f.H, 4)), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(act_fast_kernel<0>, dim3(cdiv(f.H, 4)), dim3(256), lds, s, a);
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- pixel act(): the trunk Linear(39200 (+ meta), F) + LayerNorm + tanh of ONE encoding in one launch. Workgroup g takes a slab of the 39200
+// columns for all F outputs (the 7.8 MB of trunk weights are read exactly once, spread over the chip), leaves F partial dots; the last
+// workgroup to arrive sums them in workgroup order, adds the meta columns and the bias, normalises and writes tanh(LN(z)) (F floats).
+struct TrunkOneArgs {
+    const float *x, *meta, *W, *b, *gain, *beta;        // x: R floats; W: [F][D] with D = R + M
+    float *part, *out;                                  // part: [gridDim.x][F]
+    unsigned int* ticket;
+    int R, M, F, slab;
+};
+__global__ __launch_bounds__(256) void trunk_one_kernel(const TrunkOneArgs a) {
+    __shared__ float z[1024];
+    __shared__ float red[2][4];
+    __shared__ unsigned int last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, D = a.R + a.M;
+    const int k0 = blockIdx.x * a.slab, k1 = k0 + a.slab < a.R ? k0 + a.slab : a.R;
+    for (int f = wave; f < a.F; f += 4) {
+        const float* w = a.W + (int64_t)f * D;
+        float acc = 0.f;
+        for (int k = k0 + lane; k < k1; k += 64) acc = fmaf(a.x[k], w[k], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) a.part[(int64_t)blockIdx.x * a.F + f] = acc;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (!last) return;
+    const int G = gridDim.x;
+    for (int f = wave; f < a.F; f += 4) {               // fixed order: lane l holds workgroups l, l + 64, ...; wave tree
+        float v = 0.f;
+        for (int g = lane; g < G; g += 64) v += a.part[(int64_t)g * a.F + f];
+        v = wave_sum(v);
+        if (lane == 0) {
+            const float* w = a.W + (int64_t)f * D + a.R;
+            for (int j = 0; j < a.M; ++j) v = fmaf(a.meta[j], w[j], v);
+            z[f] = v + a.b[f];
+        }
+    }
+    __syncthreads();
+    float s1 = 0.f;
+    for (int f = tid; f < a.F; f += 256) s1 += z[f];
+    s1 = wave_sum(s1);
+    if (lane == 0) red[0][wave] = s1;
+    __syncthreads();
+    const float mean = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)a.F;
+    float s2 = 0.f;
+    for (int f = tid; f < a.F; f += 256) { const float d = z[f] - mean; s2 += d * d; }
+    s2 = wave_sum(s2);
+    if (lane == 0) red[1][wave] = s2;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf((red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (float)a.F + 1e-5f);
+    for (int f = tid; f < a.F; f += 256) a.out[f] = tanhf((z[f] - mean) * rstd * a.gain[f] + a.beta[f]);
+    if (tid == 0) *a.ticket = 0u;
+}
+
+int trunk_one(const float* x, const float* meta, const float* W, const float* b, const float* gain, const float* beta, float* part, unsigned int* ticket,
+              float* out, int R, int M, int F, hipStream_t s) {
+    EXORL_REQUIRE(F >= 1 && F <= 1024 && R >= 1 && M >= 0, "trunk_one: unsupported dims");
+    const int grid = 256;
+    TrunkOneArgs a{x, meta, W, b, gain, beta, part, out, ticket, R, M, F, (int)round_up(cdiv(R, grid), 4)};
+    hipLaunchKernelGGL(trunk_one_kernel, dim3(grid), dim3(256), 0, s, a);
     EXORL_LAUNCH_CHECK();
     return 0;
 }

@@ -157,6 +157,7 @@ struct exorl_pixel_agent {
     float *stats = nullptr, *metrics = nullptr;
     int32_t* shifts = nullptr;
     float* act_ws = nullptr;                     // B = 1 inference scratch
+    float* act_part = nullptr; unsigned int* act_ticket = nullptr;     // fused act(): trunk shares, head shares, trunk output; two tickets
     int64_t t = 0, t_enc = 0;                    // Adam step counts: critic_opt / actor_opt, encoder_opt (equal for plain DDPG)
     uint64_t noise_counter = 0, aug_counter = 0, act_counter = 0, rnd_aug_counter = 0;
     // Proto on pixels (proto.py:46-85): encoder_target (Polyak copy) and the encoder's second Adam state (proto_opt's)
@@ -221,6 +222,8 @@ static void pcarve(exorl_pixel_agent* a, PCarver& c) {
     const bool sf = g.sf_dim > 0;
     for (int i = 0; i < 2; ++i) take_mlp(a->critic.head[i], c, B, (a->q && !sf) ? a->q + i * B : nullptr, (a->dq && !sf) ? a->dq + i * B : nullptr);
     a->act_ws = c.take(exorl_encoder_workspace_floats(1, g.c_in, g.hw) + img + 4 * F + 2 * 1024 + 64);
+    a->act_part = c.take(256 * F + (int64_t)cdiv(g.hidden_dim, 4) * ACT_FAST_ROWS * 16 + F);   // trunk shares [256][F] | head shares | trunk output h[F]
+    a->act_ticket = reinterpret_cast<unsigned int*>(c.take(8));
 }
 
 // z = [x | meta] W0^T + b0 (split-K over the encoding's columns, one more slab for the meta columns), then LayerNorm + tanh.
@@ -629,6 +632,25 @@ int exorl_pixel_agent_act(exorl_pixel_agent_t* a, const unsigned char* obs_dev, 
     EXORL_TRY(exorl_u8_to_f32(obs_dev, img, x, s));           // act() sees the raw frame: no augmentation (ddpg.py:223-224)
     float* feat = nullptr;
     EXORL_TRY(exorl_encoder_forward_prec(a->flat[0][0], c.c_in, c.hw, x, 1, ews, &feat, a->cfg.precision, s));
+    Mlp& pol0 = a->actor.head[0];
+    if (act_fast_supported(1, F, c.hidden_dim, A) && F <= 256 && !(tune_variant() & 2)) {
+        // two launches behind the encoder: the 39200-wide trunk with an in-launch combine + LayerNorm + tanh, then the policy
+        // (Linear + ReLU recomputed per workgroup, four Linear(H, H) neurons per workgroup, head + tanh + TruncatedNormal draw in the last one)
+        const float* Pa = a->flat[1][0];
+        const PNet& n = a->actor;
+        float* tpart = a->act_part;
+        float* hpart = tpart + 256 * F;
+        float* hvec = hpart + (int64_t)cdiv(c.hidden_dim, 4) * ACT_FAST_ROWS * 16;
+        EXORL_TRY(trunk_one(feat, meta_dev, Pa + n.trunk.W, Pa + n.trunk.b, Pa + n.g, Pa + n.beta, tpart, a->act_ticket, hvec, a->R, c.meta_dim, F, s));
+        EXORL_REQUIRE(eval_mode || stddev > 0.f, "pixel_agent_act: stddev must be > 0 in sampling mode");
+        ActFast f{};
+        f.x_dev = hvec; f.P = Pa; f.first_relu = 1; f.W0 = pol0.L[0].W; f.b0 = pol0.L[0].b;
+        f.W1 = pol0.L[1].W; f.b1 = pol0.L[1].b; f.W2 = pol0.L[2].W; f.b2 = pol0.L[2].b;
+        f.part = hpart; f.ticket = a->act_ticket + 1; f.noise_dev = noise_dev; f.seed = c.seed;
+        f.counter = (eval_mode || noise_dev) ? 0ull : ((1ull << 63) | a->act_counter++);
+        f.out = action_out_dev; f.stddev = stddev; f.rows = 1; f.in_dim = F; f.H = c.hidden_dim; f.nout = A; f.eval_mode = eval_mode;
+        return act_fast(f, s);
+    }
     // B = 1 reuses the batch-sized trunk / policy buffers (act() is never called inside update())
     EXORL_TRY(trunk_forward(a, a->actor, a->flat[1][0], feat, meta_dev, 1, a->ta_n, prec, s));
     Mlp& pol = a->actor.head[0];

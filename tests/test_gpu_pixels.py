@@ -191,6 +191,51 @@ def test_pixel_ddpg_vs_reference(gold):
     assert a.shape == (A,) and np.all(np.abs(a) <= 1.0)
 
 
+def test_pixel_act_fused_path_matches_oracle_and_generic_path(lib):
+    """act() on one raw frame (ddpg.py:221-238): the fused path (encoder, then trunk_one_kernel and act_fast_kernel<1>: two launches for
+    Linear(39200 (+ meta), 50) + LayerNorm + tanh + the three-layer policy + tanh + the TruncatedNormal draw) against the oracle's fp32 actor and
+    against the generic multi-launch path (exorl_gemm_tune bit 2), eval and sampling mode, with and without meta columns."""
+    import _synth
+    from exorl_amd import agents
+    from oracle import nets
+    C_, HW, A, F, H, B = 3, 84, 6, 50, 1024, 8
+    rs = np.random.RandomState(5)
+    obs = rs.randint(0, 256, (C_, HW, HW)).astype(np.uint8)
+    noise = rs.standard_normal((1, A)).astype(np.float32)
+    # plain DDPG: against the oracle
+    ag = make_pixel_agent(C_, HW, A, F, H, B)
+    enc, actor, critic = load_pixel_params(ag, C_, A, F, H)
+    orc = pixels.OraclePixelDDPG(enc, actor, critic)
+    feat, _ = pixels.encoder_fwd(orc.enc, obs[None])
+    mu, _ = orc._actor(feat)
+    a_eval = ag.act(obs, {}, 10**6, True)
+    np.testing.assert_allclose(a_eval, mu[0], rtol=1e-4, atol=2e-6)
+    ag.noise_hook = lambda shape: noise
+    a_s = ag.act(obs, {}, 10**6, False)
+    np.testing.assert_allclose(a_s, nets.truncated_normal_sample(mu, noise, 0.2, None)[0], rtol=1e-4, atol=2e-6)
+    lib.exorl_gemm_tune(2)
+    try:
+        np.testing.assert_allclose(ag.act(obs, {}, 10**6, True), a_eval, rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(ag.act(obs, {}, 10**6, False), a_s, rtol=2e-5, atol=2e-6)
+    finally:
+        lib.exorl_gemm_tune(-1)
+    # a meta-conditioned agent (DIAYN: 16 skill columns behind the encoding): fused against generic
+    kw = dict(name='diayn', reward_free=True, obs_type='pixels', obs_shape=(C_, HW, HW), action_shape=(A,), device='cuda', lr=1e-4, feature_dim=F,
+              hidden_dim=H, critic_target_tau=0.01, num_expl_steps=0, update_every_steps=2, stddev_schedule=0.2, nstep=3, batch_size=B,
+              stddev_clip=0.3, init_critic=True, use_tb=True, use_wandb=False)
+    torch.manual_seed(3)
+    dg = agents.DIAYNAgent(update_skill_every_step=50, skill_dim=16, diayn_scale=1.0, update_encoder=True, skill_type='uniform', **kw)
+    meta = {'skill': np.eye(16, dtype=np.float32)[3]}
+    fused = dg.act(obs, meta, 10**6, True)
+    lib.exorl_gemm_tune(2)
+    try:
+        generic = dg.act(obs, meta, 10**6, True)
+    finally:
+        lib.exorl_gemm_tune(-1)
+    assert fused.shape == (A,) and np.all(np.abs(fused) <= 1.0)
+    np.testing.assert_allclose(fused, generic, rtol=2e-5, atol=2e-6)
+
+
 @pytest.mark.parametrize('precision', ['fp32', 'bf16x3', 'bf16x6'])
 def test_pixel_ddpg_batch_vs_oracle(precision):
     """Shipped widths (feature_dim 50, hidden 1024) at a batch that spans many workgroups; 64x64 frames with 9 stacked channels.

@@ -46,3 +46,21 @@ for precision in ('fp32', 'bf16x3'):
             print(f'{precision:7s} eval_mode={eval_mode!s:5s} {label:55s}: {e2e:7.1f} us per act() from Python, {dev:6.1f} us per call on the device stream', flush=True)
     lib.exorl_gemm_tune(-1)
     del ag
+
+# ---- pixel observations (config 4 shapes: (3, 84, 84) uint8, A = 9, feature 50, hidden 1024): encoder on one frame, then the fused trunk + policy
+for precision in ('fp32', 'bf16x6'):
+    pa = agents.DDPGAgent('ddpg', True, 'pixels', (3, 84, 84), (9,), 'cuda', 1e-4, 50, 1024, 0.01, 0, 2, 0.2, 3, 16, 0.3, True, False, False, precision=precision)
+    frame = np.random.RandomState(1).randint(0, 256, (3, 84, 84)).astype(np.uint8)
+    for label, tune in (('fused: encoder + trunk_one + policy kernel', -1), ('generic path (split-K GEMM + reduce + LN + 3 GEMMs + head + copies)', 2)):
+        lib.exorl_gemm_tune(tune)
+        for _ in range(20):
+            pa.act(frame, {}, 10**6, True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 500
+        for _ in range(n):
+            pa.act(frame, {}, 10**6, True)
+        e2e = (time.perf_counter() - t0) / n * 1e6
+        print(f'pixels {precision:7s} eval_mode=True  {label:70s}: {e2e:7.1f} us per act() from Python', flush=True)
+    lib.exorl_gemm_tune(-1)
+    del pa
