@@ -165,9 +165,11 @@ static int net_forward(const NetDesc& d, const float* P, const NetShadow& sh, co
 static bool forward2_supported(const NetDesc& d, int prec, const NetShadow& sa, const NetShadow& sb) {
     return fast16(prec, sa) && fast16(prec, sb) && sa.w0b && sb.w0b && trunk_fwd16_supported(d.H) && d.out_dim == 1 && d.n_heads == 2 && d.H % 4 == 0;
 }
+// fold_a (with no_head): net A's scalar heads are folded into the GEMM epilogue (Gemm16Problem::head_part) when the launch takes the 128 x TN
+// kernels — A's h2 buffer then holds, per head, rows x *slots_a partial dots instead of hidden activations (qhead sums them)
 static int net_forward2(const NetDesc& d, const float* Pa, const NetShadow& sa, const float* xa, const FwdBufs& fa, bool save_a,
                         const float* Pb, const NetShadow& sb, const float* xb, const FwdBufs& fb, bool save_b, int64_t ldx, int rows,
-                        hipStream_t s, bool no_head = false) {
+                        hipStream_t s, bool no_head = false, bool fold_a = false, int* slots_a = nullptr) {
     const int H = d.H;
     const int64_t act = (int64_t)rows * H, wst = (int64_t)H * round_up(d.in_dim, 32);
     const float* P[2] = {Pa, Pb};
@@ -194,6 +196,17 @@ static int net_forward2(const NetDesc& d, const float* Pa, const NetShadow& sa, 
             hb.it[nq] = HeadItem{f[k]->h2 + i * act, P[k] + d.W2 + i * d.head_stride, P[k] + d.b2 + i * d.head_stride, f[k]->out + (int64_t)i * rows};
             ++nq;
         }
+    if (slots_a) *slots_a = 0;
+    if (no_head && fold_a && slots_a && !(tune_variant() & 8)) {        // exorl_gemm_tune bit 8: keep the target's hidden activations (A/B)
+        const int slots = gemm16_head_slots(q, nq);
+        if (slots > 0 && (int64_t)slots <= H) {
+            for (int i = 0; i < d.n_heads; ++i) {
+                q[i].head_w = P[0] + d.W2 + i * d.head_stride;
+                q[i].head_part = f[0]->h2 + i * act;
+            }
+            *slots_a = slots;
+        }
+    }
     EXORL_TRY(gemm16_grouped(0, 0, q, nq, true, false, s));
     if (no_head) return 0;
     return head_fwd1_batch(hb, nq, rows, H, s);
@@ -373,6 +386,7 @@ struct exorl_agent {
     bool w1_early[2] = {false, false};   // [0] critic, [1] actor: the H x H part of this step's optimiser pass is already in flight
     bool staged_by_sampler = false;  // captured step: the sampler's gather kernel writes the staged inputs and runs step_begin
     bool want_metrics = true;    // the (B,1)-sized metric reductions are skipped when the caller never reads them (use_tb=False)
+    int tq_slots = 0;            // > 0: this step's target critic left per-row partial head dots in ft.h2 (folded into the forward GEMM)
 };
 
 namespace exorl {
@@ -560,6 +574,10 @@ static int run_qhead(exorl_agent* a, int mode, hipStream_t s) {
         q.a[2 + i] = a->ft.h2 + i * act; q.W[2 + i] = Pt + d.W2 + i * d.head_stride; q.b[2 + i] = Pt + d.b2 + i * d.head_stride;
     }
     q.q = a->fc.out; q.tq = a->ft.out; q.reward = a->reward; q.discount = a->discount;
+    q.tpart[0] = q.tpart[1] = nullptr; q.tslots = 0;
+    if (mode == 0 && a->tq_slots > 0) {          // the target's heads were folded into its forward GEMM (net_forward2): ft.h2 holds partial dots
+        q.tpart[0] = a->ft.h2; q.tpart[1] = a->ft.h2 + act; q.tslots = a->tq_slots;
+    }
     q.dz = bf ? nullptr : a->bc.dz2; q.dzb = bf ? a->bc.dz2b : nullptr; q.dzl = bf ? a->bc.dz2l : nullptr; q.act = act;
     q.P = mode == 0 ? a->pc.Ph : nullptr;
     q.abs_part = a->abs_part;
@@ -593,8 +611,10 @@ static int phase0(exorl_agent* a, float stddev, const float* noise_c, hipStream_
         EXORL_TRY(sample_actions2(a->fa.out, noise_c, cfg.kind == EXORL_AGENT_CRR ? nullptr : a->noise_a, cfg.seed,
                                   &a->state->noise_counter, stddev, cfg.stddev_clip, a->xc_next + O, a->xc_pi + O, W, B, A, s, &a->state->stddev));
     const bool qf = qfuse(a);
+    a->tq_slots = 0;
     if (!a->fk.on && forward2_supported(a->critic, prec, a->sh_target, a->sh_critic)) {
-        EXORL_TRY(net_forward2(a->critic, Pt, a->sh_target, a->xc_next, a->ft, false, Pc, a->sh_critic, a->xc_cur, a->fc, true, W, B, s, qf));
+        EXORL_TRY(net_forward2(a->critic, Pt, a->sh_target, a->xc_next, a->ft, false, Pc, a->sh_critic, a->xc_cur, a->fc, true, W, B, s, qf, qf,
+                               &a->tq_slots));
     } else {
         EXORL_TRY(a->fk.fork(s));               // target critic (td3_bc.py:126) and critic (td3_bc.py:130) forwards are independent
         EXORL_TRY(net_forward(a->critic, Pt, a->sh_target, a->xc_next, W, B, a->ft, false, false, prec, a->fk.side(s), nullptr, qf));

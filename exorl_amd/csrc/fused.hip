@@ -1176,7 +1176,9 @@ int head_chunks(int rows) { return cdiv(rows, HB_ROWS); }
 constexpr int QH_ROWS = 4;      // rows per workgroup: 256 workgroups at B = 1024 (8 rows left half the CUs idle and cost 17.6 us)
 // scalar critic heads forward + backward (see QHeadArgs). One workgroup per chunk of QH_ROWS rows, thread = 4 consecutive
 // columns of both critic nets; the h2 rows read for the dot products stay in registers for the dz2 pass.
-template <int MODE>
+// TP (mode 0): the target critic's two Q values arrive as per-row partial dots from the forward GEMM's epilogue (QHeadArgs::tpart, Gemm16Problem::
+// head_part) — its hidden activations were never written: 8 MB less stored by the GEMM and 8 MB less read here at H = B = 1024
+template <int MODE, bool TP>
 __global__ __launch_bounds__(256) void qhead_kernel(const QHeadArgs g) {
     __shared__ float part[4][4 * QH_ROWS];      // [wave][net * QH_ROWS + r]
     __shared__ float dq[2 * QH_ROWS];
@@ -1184,7 +1186,7 @@ __global__ __launch_bounds__(256) void qhead_kernel(const QHeadArgs g) {
     const int c4 = threadIdx.x, H = g.H, H4 = H >> 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nr = g.rows - row0 < QH_ROWS ? g.rows - row0 : QH_ROWS;
-    constexpr int nn = MODE == 0 ? 4 : 2;
+    constexpr int nn = (MODE == 0 && !TP) ? 4 : 2;
     const bool on = c4 < H4;
     float4 avs[2][QH_ROWS];
     float4 w[2];
@@ -1229,6 +1231,13 @@ __global__ __launch_bounds__(256) void qhead_kernel(const QHeadArgs g) {
             const float v = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x])) + g.b[n][0];
             part[0][threadIdx.x] = v;
             (n < 2 ? g.q : g.tq)[(int64_t)(n & 1) * g.rows + row0 + r] = v;
+        } else if (TP && MODE == 0 && n >= 2 && r < nr) {          // folded target heads: the GEMM's column-block dots, in block order
+            const float* tp = g.tpart[n - 2] + (int64_t)(row0 + r) * g.tslots;
+            float v = 0.f;
+            for (int j = 0; j < g.tslots; ++j) v += tp[j];
+            v += g.b[n][0];
+            part[0][threadIdx.x] = v;
+            g.tq[(int64_t)(n & 1) * g.rows + row0 + r] = v;
         }
     }
     __syncthreads();
@@ -1291,8 +1300,9 @@ int qhead_chunks(int rows) { return cdiv(rows, QH_ROWS); }
 
 int qhead(const QHeadArgs& q, hipStream_t s) {
     EXORL_REQUIRE(q.H % 4 == 0 && q.H <= 1024 && q.rows > 0 && (q.mode == 0 || q.mode == 1), "qhead: unsupported H=%d rows=%d", q.H, q.rows);
-    if (q.mode == 0) hipLaunchKernelGGL(qhead_kernel<0>, dim3(cdiv(q.rows, QH_ROWS)), dim3(256), 0, s, q);
-    else hipLaunchKernelGGL(qhead_kernel<1>, dim3(cdiv(q.rows, QH_ROWS)), dim3(256), 0, s, q);
+    if (q.mode == 0 && q.tpart[0]) hipLaunchKernelGGL((qhead_kernel<0, true>), dim3(cdiv(q.rows, QH_ROWS)), dim3(256), 0, s, q);
+    else if (q.mode == 0) hipLaunchKernelGGL((qhead_kernel<0, false>), dim3(cdiv(q.rows, QH_ROWS)), dim3(256), 0, s, q);
+    else hipLaunchKernelGGL((qhead_kernel<1, false>), dim3(cdiv(q.rows, QH_ROWS)), dim3(256), 0, s, q);
     EXORL_LAUNCH_CHECK();
     return 0;
 }

@@ -1345,6 +1345,33 @@ __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned cha
                 if (gb.accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
                 *dst = v;
             }
+    } else if (P.head_part) {
+        // folded scalar head: this wave's share of relu(acc + bias) . head_w for each of its rows; lanes l and l + 32 hold the two column
+        // interleaves of one row. Nothing of C is stored.
+#pragma unroll
+        for (int ta = 0; ta < SA; ++ta) {
+            float dot = 0.f;
+#pragma unroll
+            for (int tb = 0; tb < SB; ++tb) {
+                const int nb = n0 + wn * WC + tb * 32 + 4 * h;
+                const acc_t& a0 = acc[ta * SB + tb];
+                const acc_t& ax = accx[X3 ? ta * SB + tb : 0];
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float4 bias = P.bias ? *reinterpret_cast<const float4*>(P.bias + nb + 8 * g4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 w = *reinterpret_cast<const float4*>(P.head_w + nb + 8 * g4);
+                    float4 v;
+                    v.x = (X3 ? ax[4 * g4 + 0] + a0[4 * g4 + 0] : a0[4 * g4 + 0]) + bias.x;
+                    v.y = (X3 ? ax[4 * g4 + 1] + a0[4 * g4 + 1] : a0[4 * g4 + 1]) + bias.y;
+                    v.z = (X3 ? ax[4 * g4 + 2] + a0[4 * g4 + 2] : a0[4 * g4 + 2]) + bias.z;
+                    v.w = (X3 ? ax[4 * g4 + 3] + a0[4 * g4 + 3] : a0[4 * g4 + 3]) + bias.w;
+                    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    dot += (v.x * w.x + v.y * w.y) + (v.z * w.z + v.w * w.w);
+                }
+            }
+            dot += __shfl_xor(dot, 32);
+            if (h == 0) P.head_part[(int64_t)(m0 + wm * WR + ta * 32 + (lane & 31)) * (P.N / WC) + (n0 / WC + wn)] = dot;
+        }
     } else {
 #pragma unroll
     for (int ta = 0; ta < SA; ++ta)
@@ -1858,6 +1885,19 @@ int gemm16_grouped_mixed(const int* a_layouts, const Gemm16Problem* probs, int c
 
 // bf16-in-memory operands, fp32 output. Requirements (checked): 16-byte aligned rows for layout 0 (ld % 8 == 0,
 // K % 8 == 0), 4-byte aligned pairs for layout 1 (ld % 2 == 0, R % 2 == 0).
+int gemm16_head_slots(const Gemm16Problem* probs, int count) {
+    if (count < 1 || count > 4) return 0;
+    Gemm16Batch gb;
+    memset(&gb, 0, sizeof(gb));
+    bool x3 = true;
+    for (int i = 0; i < count; ++i) { gb.p[i] = probs[i]; x3 = x3 && probs[i].A_lo && probs[i].B_lo; }
+    const int tn = g16p_pick(gb, count, x3);
+    if (!tn) return 0;
+    for (int i = 0; i < count; ++i)
+        if (probs[i].N != probs[0].N) return 0;
+    return probs[0].N / (tn / 2);               // four waves: 2 x 2, each TN / 2 columns wide
+}
+
 int gemm16_grouped(int a_layout, int b_layout, const Gemm16Problem* probs, int count, bool relu, bool accumulate, hipStream_t s) {
     EXORL_REQUIRE(count >= 1 && count <= 4, "gemm16_grouped: count %d out of range", count);
     Gemm16Batch gb;
@@ -1881,6 +1921,11 @@ int gemm16_grouped(int a_layout, int b_layout, const Gemm16Problem* probs, int c
     }
     gb.relu = relu ? 1 : 0;
     gb.accumulate = accumulate ? 1 : 0;
+    for (int i = 0; i < count; ++i)
+        if (probs[i].head_part)
+            EXORL_REQUIRE(probs[i].head_w && a_layout == 0 && b_layout == 0 && !accumulate && gemm16_head_slots(probs, count) > 0 &&
+                          !(g_gemm16_variant >= 0 && (g_gemm16_variant & 4194304)),
+                          "gemm16_grouped: a folded head needs a forward launch on the 128 x TN kernels (ask gemm16_head_slots first)");
     if (a_layout == 0 && b_layout == 0) return launch16<0, 0>(gb, count, t64, t128, s);
     if (a_layout == 0 && b_layout == 1) return launch16<0, 1>(gb, count, t64, t128, s);
     if (a_layout == 1 && b_layout == 1) return launch16<1, 1>(gb, count, t64, t128, s);

@@ -28,7 +28,14 @@ struct Gemm16Problem {
     // hi*hi + hi*lo + lo*hi in fp32 accumulators (relative error ~2^-16: per-step losses stay within 1e-4 of the fp32 reference)
     const unsigned short* A_lo = nullptr;
     const unsigned short* B_lo = nullptr;
+    // Scalar head folded into the epilogue (the 128 x TN "p" kernels only; forward launches with relu): instead of storing C the workgroup leaves,
+    // per output row, the dot of relu(acc + bias) with head_w over each wave's column block: head_part[row][column block] (N / (TN / 2) floats per
+    // row, gemm16_head_slots() says how many). For a net whose hidden activations nobody reads again — the Polyak target critic of a TD step.
+    const float* head_w = nullptr;
+    float* head_part = nullptr;
 };
+// slots per row the "p" kernels would write for these problems' head_part (N / wave column block), or 0 when the launch would not take them
+int gemm16_head_slots(const Gemm16Problem* probs, int count);
 // operands stored as bf16 in memory (fast mode); same layout conventions as gemm_grouped
 int gemm16_grouped(int a_layout, int b_layout, const Gemm16Problem* probs, int count, bool relu, bool accumulate, hipStream_t s);
 // wgrad (a_layout 1) and dgrad (a_layout 0) problems of one backward pass in a single launch; b_layout 1, plain store
@@ -144,6 +151,8 @@ struct QHeadArgs {
     float* dz; unsigned short* dzb; unsigned short* dzl; int64_t act;     // dzl: lo plane (split-bf16) or null
     float* P;                // head partials [net][chunk][(1+1)H + 16] or null
     float* abs_part;         // [chunk][2]
+    const float* tpart[2];   // mode 0, folded target heads: per row `tslots` partial dots of target net 0 / 1 (gemm16 head_part) instead of a[2], a[3]
+    int tslots;
     int rows, H, mode;
     float inv_bg;
 };
