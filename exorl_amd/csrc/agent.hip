@@ -197,7 +197,7 @@ static int net_forward2(const NetDesc& d, const float* Pa, const NetShadow& sa, 
             ++nq;
         }
     if (slots_a) *slots_a = 0;
-    if (no_head && fold_a && slots_a && !(tune_variant() & 8)) {        // exorl_gemm_tune bit 8: keep the target's hidden activations (A/B)
+    if (no_head && fold_a && slots_a && !(tune_variant() & 1024)) {     // exorl_gemm_tune bit 1024: keep the target's hidden activations (A/B)
         const int slots = gemm16_head_slots(q, nq);
         if (slots > 0 && (int64_t)slots <= H) {
             for (int i = 0; i < d.n_heads; ++i) {
@@ -1022,7 +1022,7 @@ int exorl_agent_stats_buffer(exorl_agent_t* a, void** ptr, int64_t* numel) {
 
 // one launch for <= ACT_FAST_ROWS rows of a tanh-mean policy (every agent kind but CQL's tanh-Gaussian); obs / noise on the device or on the host
 static bool act_fast_ok(const exorl_agent* a, int n) {
-    return a->cfg.kind != EXORL_AGENT_CQL && act_fast_supported(n, a->cfg.obs_dim, a->cfg.hidden_dim, a->actor.out_dim) && !(tune_variant() & 2);
+    return a->cfg.kind != EXORL_AGENT_CQL && act_fast_supported(n, a->cfg.obs_dim, a->cfg.hidden_dim, a->actor.out_dim) && !(tune_variant() & 256);
 }
 static int act_fast_launch(exorl_agent* a, const float* obs_dev, const float* obs_host, int n, float stddev, int eval_mode, const float* noise_dev,
                            const float* noise_host, float* out, hipStream_t s) {

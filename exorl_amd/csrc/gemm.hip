@@ -1988,6 +1988,142 @@ static bool aligned_for_vec(const GemmProblem& p, int al, int bl) {
     return ok(p.A, p.lda, p.M, p.K, al) && ok(p.B, p.ldb, p.N, p.K, bl);
 }
 
+// ---- fp32-source operands onto the hi/lo-plane kernels (round 3) ------------------------------------------------------------------------
+// The callers of gemm_grouped keep fp32 activations and weights (intrinsic modules, the pixel agents' heads and 39200-wide module layers); the
+// generic kernel above splits them into hi/lo planes on their way into LDS — 64 x 64 tiles, register staging: ~62 TFLOP/s at 1024^3. The plane
+// kernels (gemm16p_*) run the SAME arithmetic (hi*hi + hi*lo + lo*hi, three fp32 accumulators summed small-first) at 230-300 TFLOP/s but want
+// bf16 planes in memory, M % 128 = 0, N % 64 = 0, K % 128 = 0. For problems large enough to pay for it this adapter writes zero-padded hi/lo
+// planes of both operands into a scratch arena (one elementwise pass each: 8 B per element moved), runs the plane kernels, and — when C does
+// not tile — copies the padded result back (bias, ReLU in the GEMM epilogue as always; accumulate in the copy). Groups of more than four
+// problems (Disagreement's five models) go in chunks. exorl_gemm_tune bit 65536 switches it off (A/B).
+struct PlaneArena { unsigned char* buf = nullptr; size_t bytes = 0; };
+static PlaneArena g_plane_arena;
+
+__global__ __launch_bounds__(256) void to_planes_kernel(const float* __restrict__ src, int64_t ld, int rows, int cols, unsigned short* __restrict__ hi,
+                                                        unsigned short* __restrict__ lo, int rows_p, int cols_p) {
+    // 8 consecutive columns per thread: two 16-byte loads (when aligned and in range), one 16-byte store per plane; padding is written as zeros
+    const int64_t groups = (int64_t)rows_p * (cols_p / 8);
+    const bool vec = (ld % 4 == 0) && (reinterpret_cast<uintptr_t>(src) % 16 == 0);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / (cols_p / 8)), c0 = (int)(i % (cols_p / 8)) * 8;
+        float v[8];
+        if (r < rows && vec && c0 + 8 <= cols) {
+            const float4 a = *reinterpret_cast<const float4*>(src + (int64_t)r * ld + c0), b = *reinterpret_cast<const float4*>(src + (int64_t)r * ld + c0 + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (r < rows && c0 + j < cols) ? src[(int64_t)r * ld + c0 + j] : 0.f;
+        }
+        uint4 h, l;
+        h.x = pack_bf16(v[0], v[1]); h.y = pack_bf16(v[2], v[3]); h.z = pack_bf16(v[4], v[5]); h.w = pack_bf16(v[6], v[7]);
+        l.x = pack_bf16(bf16_residual(v[0]), bf16_residual(v[1])); l.y = pack_bf16(bf16_residual(v[2]), bf16_residual(v[3]));
+        l.z = pack_bf16(bf16_residual(v[4]), bf16_residual(v[5])); l.w = pack_bf16(bf16_residual(v[6]), bf16_residual(v[7]));
+        *reinterpret_cast<uint4*>(hi + (int64_t)r * cols_p + c0) = h;
+        *reinterpret_cast<uint4*>(lo + (int64_t)r * cols_p + c0) = l;
+    }
+}
+// C[m][n] (+)= Cp[m][n] for the unpadded block
+__global__ __launch_bounds__(256) void from_padded_kernel(const float* __restrict__ cp, int64_t ldp, float* __restrict__ c, int64_t ldc, int M, int N, int accumulate) {
+    const int64_t n = (int64_t)M * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / N), j = (int)(i % N);
+        const float v = cp[(int64_t)m * ldp + j];
+        float* d = c + (int64_t)m * ldc + j;
+        *d = accumulate ? v + *d : v;
+    }
+}
+__global__ void pad_bias_kernel(const float* __restrict__ b, float* __restrict__ out, int N, int Np) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Np) out[i] = i < N ? b[i] : 0.f;
+}
+
+static bool planes_adapter_wants(int al, int bl, const GemmProblem* probs, int count) {
+    if (g_gemm16_variant >= 0 && (g_gemm16_variant & (65536 | 262144))) return false;
+    if (!((al == 0 && bl == 0) || (al == 0 && bl == 1) || (al == 1 && bl == 1))) return false;
+    for (int i = 0; i < count; ++i)
+        if (probs[i].M < 256 || probs[i].N < 256 || probs[i].K < 256) return false;       // conversion passes + padded tiles must be worth it
+    return true;
+}
+
+// 0 = done; -1 = not taken (the caller runs the generic kernel); > 0 = error
+static int planes_adapter(int al, int bl, const GemmProblem* probs, int count, bool relu, bool accumulate, hipStream_t s) {
+    struct Plan { int Mp, Np, Kp; size_t a_hi, a_lo, b_hi, b_lo, cp, bias; bool direct; };
+    {   // never inside a stream capture: the arena may be re-allocated later, a captured graph would keep the old addresses
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        EXORL_CHECK_HIP(hipStreamIsCapturing(s, &cs));
+        if (cs != hipStreamCaptureStatusNone) return -1;
+    }
+    for (int c0 = 0; c0 < count; c0 += 4) {
+        const int nc = count - c0 < 4 ? count - c0 : 4;
+        Plan pl[4];
+        size_t need = 0;
+        auto take = [&](size_t bytes) { const size_t o = need; need += (bytes + 255) & ~(size_t)255; return o; };
+        for (int i = 0; i < nc; ++i) {
+            const GemmProblem& p = probs[c0 + i];
+            Plan& q = pl[i];
+            q.Mp = (int)round_up(p.M, 128); q.Np = (int)round_up(p.N, 128); q.Kp = (int)round_up(p.K, 128);
+            q.a_hi = take((size_t)q.Mp * q.Kp * 2); q.a_lo = take((size_t)q.Mp * q.Kp * 2);
+            q.b_hi = take((size_t)q.Np * q.Kp * 2); q.b_lo = take((size_t)q.Np * q.Kp * 2);
+            q.direct = p.M % 128 == 0 && p.N % 128 == 0 && p.ldc % 4 == 0 && reinterpret_cast<uintptr_t>(p.C) % 16 == 0 &&
+                       (!p.bias || reinterpret_cast<uintptr_t>(p.bias) % 16 == 0);
+            q.cp = q.direct ? 0 : take((size_t)q.Mp * q.Np * 4);
+            q.bias = (q.direct || !p.bias) ? 0 : take((size_t)q.Np * 4);
+        }
+        if (need > g_plane_arena.bytes) {
+            EXORL_CHECK_HIP(hipDeviceSynchronize());                                // nothing in flight may still read the old arena
+            if (g_plane_arena.buf) EXORL_CHECK_HIP(hipFree(g_plane_arena.buf));
+            g_plane_arena.buf = nullptr; g_plane_arena.bytes = 0;
+            const size_t want = need + need / 8;
+            if (hipMalloc((void**)&g_plane_arena.buf, want) != hipSuccess) {
+                (void)hipGetLastError();
+                if (c0 == 0) return -1;
+                set_error("planes_adapter: could not grow the plane arena to %zu bytes", want);
+                return 3;
+            }
+            g_plane_arena.bytes = want;
+        }
+        unsigned char* base = g_plane_arena.buf;
+        Gemm16Problem q16[4];
+        for (int i = 0; i < nc; ++i) {
+            const GemmProblem& p = probs[c0 + i];
+            const Plan& q = pl[i];
+            auto u16 = [&](size_t o) { return reinterpret_cast<unsigned short*>(base + o); };
+            // storage shapes: layout 0 = [rows = M or N][K]; layout 1 = [K][M or N]
+            const int ar = al == 0 ? p.M : p.K, acol = al == 0 ? p.K : p.M, arp = al == 0 ? q.Mp : q.Kp, acp = al == 0 ? q.Kp : q.Mp;
+            const int br = bl == 0 ? p.N : p.K, bcol = bl == 0 ? p.K : p.N, brp = bl == 0 ? q.Np : q.Kp, bcp = bl == 0 ? q.Kp : q.Np;
+            auto grid = [](int64_t groups) { const int64_t b = (groups + 255) / 256; return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); };
+            hipLaunchKernelGGL(to_planes_kernel, dim3(grid((int64_t)arp * (acp / 8))), dim3(256), 0, s, p.A, p.lda, ar, acol, u16(q.a_hi), u16(q.a_lo), arp, acp);
+            hipLaunchKernelGGL(to_planes_kernel, dim3(grid((int64_t)brp * (bcp / 8))), dim3(256), 0, s, p.B, p.ldb, br, bcol, u16(q.b_hi), u16(q.b_lo), brp, bcp);
+            const float* bias = p.bias;
+            if (!q.direct && p.bias) {
+                hipLaunchKernelGGL(pad_bias_kernel, dim3(cdiv(q.Np, 256)), dim3(256), 0, s, p.bias, reinterpret_cast<float*>(base + q.bias), p.N, q.Np);
+                bias = reinterpret_cast<float*>(base + q.bias);
+            }
+            EXORL_LAUNCH_CHECK();
+            Gemm16Problem g{u16(q.a_hi), u16(q.b_hi), q.direct ? p.C : reinterpret_cast<float*>(base + q.cp), bias, q.Mp, q.Np, q.Kp, acp, bcp,
+                            q.direct ? p.ldc : (int64_t)q.Np};
+            g.A_lo = u16(q.a_lo); g.B_lo = u16(q.b_lo);
+            q16[i] = g;
+        }
+        bool all_direct = true;
+        for (int i = 0; i < nc; ++i) all_direct = all_direct && pl[i].direct;
+        // accumulate rides in the GEMM epilogue only when every C of the chunk is written in place; otherwise the copy-back adds
+        EXORL_TRY(gemm16_grouped(al, bl, q16, nc, relu, accumulate && all_direct, s));
+        for (int i = 0; i < nc; ++i) {
+            if (pl[i].direct) {
+                EXORL_REQUIRE(!accumulate || all_direct, "planes_adapter: mixed in-place / padded outputs with accumulate");
+                continue;
+            }
+            const GemmProblem& p = probs[c0 + i];
+            const int64_t n = (int64_t)p.M * p.N;
+            hipLaunchKernelGGL(from_padded_kernel, dim3((unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256)), dim3(256), 0, s,
+                               reinterpret_cast<const float*>(base + pl[i].cp), (int64_t)pl[i].Np, p.C, p.ldc, p.M, p.N, accumulate ? 1 : 0);
+            EXORL_LAUNCH_CHECK();
+        }
+    }
+    return 0;
+}
+
 // Launches up to 4 independent problems (same layouts / epilogue flags) as one grid.
 // Diagnostic (tools/debug/config4_ablation.py; no product path sets it): which split-bf16 products run with exact fp32 products instead.
 // bits: 1 / 2 forward (row-image A, row-image B) narrow / wide; 4 / 8 wgrad (k-image A and B); 16 / 32 dgrad (row-image A, k-image B);
@@ -2017,6 +2153,20 @@ int gemm_grouped(int precision, int a_layout, int b_layout, const GemmProblem* p
     }
     gb.relu = relu ? 1 : 0;
     gb.accumulate = accumulate ? 1 : 0;
+    if (precision == EXORL_PREC_BF16X3 && planes_adapter_wants(a_layout, b_layout, probs, count)) {
+        bool mixed = false;          // accumulate with some outputs in place and some padded: keep it simple, generic kernel
+        if (accumulate) {
+            int direct = 0;
+            for (int i = 0; i < count; ++i)
+                direct += probs[i].M % 128 == 0 && probs[i].N % 128 == 0 && probs[i].ldc % 4 == 0 && reinterpret_cast<uintptr_t>(probs[i].C) % 16 == 0 &&
+                          (!probs[i].bias || reinterpret_cast<uintptr_t>(probs[i].bias) % 16 == 0);
+            mixed = direct != 0 && direct != count;
+        }
+        if (!mixed) {
+            const int rc = planes_adapter(a_layout, b_layout, probs, count, relu, accumulate, s);
+            if (rc >= 0) return rc;
+        }
+    }
     if (precision == EXORL_PREC_F32) return launch_prec<EXORL_PREC_F32>(gb, count, a_layout, b_layout, max_tiles, vec, s);
     if (precision == EXORL_PREC_BF16) return launch_prec<EXORL_PREC_BF16>(gb, count, a_layout, b_layout, max_tiles, vec, s);
     if (precision == EXORL_PREC_BF16X3) return launch_prec<EXORL_PREC_BF16X3>(gb, count, a_layout, b_layout, max_tiles, vec, s);

@@ -633,7 +633,7 @@ int exorl_pixel_agent_act(exorl_pixel_agent_t* a, const unsigned char* obs_dev, 
     float* feat = nullptr;
     EXORL_TRY(exorl_encoder_forward_prec(a->flat[0][0], c.c_in, c.hw, x, 1, ews, &feat, a->cfg.precision, s));
     Mlp& pol0 = a->actor.head[0];
-    if (act_fast_supported(1, F, c.hidden_dim, A) && F <= 256 && !(tune_variant() & 2)) {
+    if (act_fast_supported(1, F, c.hidden_dim, A) && F <= 256 && !(tune_variant() & 256)) {
         // two launches behind the encoder: the 39200-wide trunk with an in-launch combine + LayerNorm + tanh, then the policy
         // (Linear + ReLU recomputed per workgroup, four Linear(H, H) neurons per workgroup, head + tanh + TruncatedNormal draw in the last one)
         const float* Pa = a->flat[1][0];

@@ -194,7 +194,7 @@ def test_pixel_ddpg_vs_reference(gold):
 def test_pixel_act_fused_path_matches_oracle_and_generic_path(lib):
     """act() on one raw frame (ddpg.py:221-238): the fused path (encoder, then trunk_one_kernel and act_fast_kernel<1>: two launches for
     Linear(39200 (+ meta), 50) + LayerNorm + tanh + the three-layer policy + tanh + the TruncatedNormal draw) against the oracle's fp32 actor and
-    against the generic multi-launch path (exorl_gemm_tune bit 2), eval and sampling mode, with and without meta columns."""
+    against the generic multi-launch path (exorl_gemm_tune bit 256), eval and sampling mode, with and without meta columns."""
     import _synth
     from exorl_amd import agents
     from oracle import nets
@@ -213,7 +213,7 @@ def test_pixel_act_fused_path_matches_oracle_and_generic_path(lib):
     ag.noise_hook = lambda shape: noise
     a_s = ag.act(obs, {}, 10**6, False)
     np.testing.assert_allclose(a_s, nets.truncated_normal_sample(mu, noise, 0.2, None)[0], rtol=1e-4, atol=2e-6)
-    lib.exorl_gemm_tune(2)
+    lib.exorl_gemm_tune(256)
     try:
         np.testing.assert_allclose(ag.act(obs, {}, 10**6, True), a_eval, rtol=2e-5, atol=2e-6)
         np.testing.assert_allclose(ag.act(obs, {}, 10**6, False), a_s, rtol=2e-5, atol=2e-6)
@@ -227,7 +227,7 @@ def test_pixel_act_fused_path_matches_oracle_and_generic_path(lib):
     dg = agents.DIAYNAgent(update_skill_every_step=50, skill_dim=16, diayn_scale=1.0, update_encoder=True, skill_type='uniform', **kw)
     meta = {'skill': np.eye(16, dtype=np.float32)[3]}
     fused = dg.act(obs, meta, 10**6, True)
-    lib.exorl_gemm_tune(2)
+    lib.exorl_gemm_tune(256)
     try:
         generic = dg.act(obs, meta, 10**6, True)
     finally:

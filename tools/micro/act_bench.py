@@ -1,6 +1,6 @@
 """Latency of act() on one observation: device time of the single-launch kernel (HIP events around 200 back-to-back calls) and
 end-to-end microseconds per call from Python (numpy observation in -> numpy action out, including the stream synchronise), against the generic
-multi-launch path (exorl_gemm_tune bit 2 routes exorl_agent_act back to net_forward + head + sampling + copy)."""
+multi-launch path (exorl_gemm_tune bit 256 routes exorl_agent_act back to net_forward + head + sampling + copy)."""
 import sys
 import time
 from pathlib import Path
@@ -19,7 +19,7 @@ for precision in ('fp32', 'bf16x3'):
     ag.num_expl_steps = 0
     obs = np.random.RandomState(0).standard_normal(O).astype(np.float32)
     for eval_mode in (True, False):
-        for label, tune in (('one launch (exorl_agent_act_host)', -1), ('generic path (net_forward + head + sample + copies)', 2)):
+        for label, tune in (('one launch (exorl_agent_act_host)', -1), ('generic path (net_forward + head + sample + copies)', 256)):
             lib.exorl_gemm_tune(tune)
             fast = tune < 0
             call = (lambda: ag.act(obs, 10, eval_mode)) if fast else (lambda: ag.engine.act(obs, 0.2, eval_mode).cpu().numpy()[0])
@@ -51,7 +51,7 @@ for precision in ('fp32', 'bf16x3'):
 for precision in ('fp32', 'bf16x6'):
     pa = agents.DDPGAgent('ddpg', True, 'pixels', (3, 84, 84), (9,), 'cuda', 1e-4, 50, 1024, 0.01, 0, 2, 0.2, 3, 16, 0.3, True, False, False, precision=precision)
     frame = np.random.RandomState(1).randint(0, 256, (3, 84, 84)).astype(np.uint8)
-    for label, tune in (('fused: encoder + trunk_one + policy kernel', -1), ('generic path (split-K GEMM + reduce + LN + 3 GEMMs + head + copies)', 2)):
+    for label, tune in (('fused: encoder + trunk_one + policy kernel', -1), ('generic path (split-K GEMM + reduce + LN + 3 GEMMs + head + copies)', 256)):
         lib.exorl_gemm_tune(tune)
         for _ in range(20):
             pa.act(frame, {}, 10**6, True)
