@@ -306,13 +306,48 @@ def main():
         import faulthandler
         import threading
         faulthandler.cancel_dump_traceback_later()
+        limit_s = float(os.environ.get('EXORL_BENCH_NATIVE_WATCHDOG_S', '120'))
+        # Two guards around the unverified leg. (1) a timer thread: on a hang, rank 0 prints the number in hand and every rank exits 0.
+        # (2) rank 0 only — a detached watcher process holding the read end of a pipe and a copy of the JSON line: if this process dies
+        # without saying so (a crash inside RCCL, the launcher tearing the job down because another rank crashed) the pipe closes and the
+        # watcher prints the line on the stdout it inherited. The watcher makes no GPU call and is forked, never exec'ed.
+        rfd = wfd = None
+        if rank == 0:
+            safe = dict(out)
+            safe['native_comm'] = {'status': 'the process ended inside the native-communicator leg: the torch.distributed-path number above stands'}
+            line = (json.dumps(safe) + '\n').encode()
+            rfd, wfd = os.pipe()
+            sys.stdout.flush()
+            if os.fork() == 0:                  # watcher
+                try:
+                    import select
+                    import signal
+                    os.close(wfd)
+                    os.setsid()
+                    signal.signal(signal.SIGTERM, signal.SIG_IGN)
+                    ready, _, _ = select.select([rfd], [], [], limit_s + 60.0)
+                    msg = os.read(rfd, 16) if ready else b''
+                    if not msg.startswith(b'done'):
+                        os.write(1, line)
+                finally:
+                    os._exit(0)
+            os.close(rfd)
+
+        def settle():                           # tell the watcher this process prints its own line
+            if wfd is not None:
+                try:
+                    os.write(wfd, b'done')
+                    os.close(wfd)
+                except OSError:
+                    pass
 
         def give_up():
             if rank == 0:
+                settle()
                 out['native_comm'] = {'status': 'timed out (watchdog): the torch.distributed-path number above stands'}
                 print(json.dumps(out), flush=True)
             os._exit(0)
-        dog = threading.Timer(float(os.environ.get('EXORL_BENCH_NATIVE_WATCHDOG_S', '120')), give_up)
+        dog = threading.Timer(limit_s, give_up)
         dog.daemon = True
         dog.start()
         native = None
@@ -334,6 +369,7 @@ def main():
         except Exception as e:                  # any failure of the unverified leg leaves the first number standing
             native = {'status': f'failed: {type(e).__name__}: {e}'[:300]}
         dog.cancel()
+        settle()
         if rank == 0:
             out['native_comm'] = native
 

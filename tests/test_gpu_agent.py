@@ -521,6 +521,18 @@ def test_graph_philox_fast_path_full_size_vs_oracle(precision):
         got = torch.cat([p.double().reshape(-1) for p in net.parameters()]).cpu().numpy()
         cos, out = _delta_report(f'graph+philox td3_bc {precision} {nm}', got, flat(want), flat(init), 1e-4)
         assert cos >= 0.9999 and out <= 0.02, (nm, cos, out)
+        # tensor by tensor, every element (biases and LayerNorm gains are < 0.3 % of the flat vector and a systematic error in
+        # one of them would not move the whole-net figures): direction and size of each tensor's own 4-step delta
+        for i, (p, w, p0) in enumerate(zip(net.parameters(), want, init)):
+            dg = p.double().cpu().numpy().reshape(-1) - np.asarray(p0, np.float64).reshape(-1)
+            dw = np.asarray(w, np.float64).reshape(-1) - np.asarray(p0, np.float64).reshape(-1)
+            if np.linalg.norm(dw) == 0.0:
+                assert np.linalg.norm(dg) == 0.0, (nm, i)
+                continue
+            tcos = float(dg @ dw / (np.linalg.norm(dg) * np.linalg.norm(dw) + 1e-300))
+            tnorm = float(np.linalg.norm(dg) / np.linalg.norm(dw))
+            bar_c, bar_n = (0.99999, 2e-3) if precision == 'fp32' else (0.9995, 2e-2)
+            assert tcos >= bar_c and abs(tnorm - 1.0) <= bar_n, (precision, nm, i, tuple(p.shape), tcos, tnorm)
 
 
 def test_graph_follows_a_moving_stddev_schedule():

@@ -341,8 +341,9 @@ def _frames(step, B, C_, HW):           # tools/gen_golden.py pixel_intr_frames
     return rs.randint(0, 256, (B, C_, HW, HW)).astype(np.uint8), rs.randint(0, 256, (B, C_, HW, HW)).astype(np.uint8)
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x6'])
 @pytest.mark.parametrize('kind', ['icm', 'icm_apt', 'disagreement', 'diayn', 'aps', 'smm', 'rnd'])
-def test_pixel_intrinsic_agents_vs_reference(gold, kind):
+def test_pixel_intrinsic_agents_vs_reference(gold, kind, precision):
     """The module agents on pixel observations against 3 update() calls of the reference's own classes (tests/golden/pixel_<kind>.npz,
     tools/gen_golden.py gen_pixel_intr): obs and next_obs are augmented and encoded once, the module and the encoder step on the module's
     loss, the reward comes from the updated module on the encodings made before that step, and the critic and actor see those encodings
@@ -350,7 +351,7 @@ def test_pixel_intrinsic_agents_vs_reference(gold, kind):
     import _synth
     z = np.load(gold / f'pixel_{kind}.npz')
     C_, HW, A, F, H, B, N, S = [int(v) for v in z['dims']]
-    ag, mod = _pixel_intr_agent(kind, C_, HW, A, F, H, B, S)
+    ag, mod = _pixel_intr_agent(kind, C_, HW, A, F, H, B, S, precision)       # bf16x6: the parity-grade fast mode of the pixel agents, same bars
     views = (('encoder', ag.encoder), ('actor', ag.actor), ('critic', ag.critic), (mod, getattr(ag, mod)))
     for i, (nm, view) in enumerate(views):
         shapes = [(k, tuple(v.shape)) for k, v in view.state_dict().items()]

@@ -138,7 +138,12 @@ def test_torch_twin_proto_pixels_matches_reference_config4(gold):
     keys = [str(k) for k in z['metric_keys']]
     obs, nobs, act, rew, disc, so, sn, u = _synth.config4_inputs(0, B, C, HW, A, NP)
     m = tw.update((obs, act, rew, disc, nobs), so, sn, u, noise.draw((B, A)), noise.draw((B, A)))
-    np.testing.assert_allclose([m[k] for k in keys], z['metrics'][0], rtol=1e-4, atol=2e-5, err_msg=f'{keys}')
+    # against the reference's fp64 run, with the band its own fp32 runs span (on this container's Xeon the twin reproduces `metrics` to 1e-5; on
+    # another CPU — the GPU box's EPYC — torch's fp32 convolutions round differently and the twin lands elsewhere inside the same band)
+    ref = z['metrics_fp64'][0]
+    band = np.max([np.abs(z[nm][0] - ref) for nm in ('metrics', 'metrics_1thread', 'metrics_no_onednn')], axis=0)
+    got = np.array([m[k] for k in keys])
+    assert np.all(np.abs(got - ref) <= np.maximum(1e-4 * np.abs(ref) + 2e-6, 2 * band)), dict(zip(keys, np.abs(got - ref) / (np.abs(ref) + 1e-12)))
     # the reference's own runs, as recorded: fp32 on oneDNN (all threads / one thread) and on torch's native convolutions against fp64
     d = lambda nm: np.abs(z[nm] - z['metrics_fp64']) / (np.abs(z['metrics_fp64']) + 1e-2)
     assert d('metrics').max() > 1e-3 and d('metrics_1thread').max() > 1e-3 and d('metrics_no_onednn').max() > 1e-4
