@@ -653,6 +653,152 @@ static int conv_wgrad_mfma(const float* dy, const float* in, float* P, float* Pb
     return 0;
 }
 
+// ---- first layer (c_in = 3 or 9 input channels, stride 2, pixel scaling): weight gradients on the matrix cores (round 3) -------------------
+// The fp32 FMA kernel above spends 525 us per launch at batch 1024 on 3 GFLOP and 307 MB — one LDS read per FMA. As a GEMM per image:
+// dW[co][k'] = sum_p dY[co][p] * X[p][k'], k' = ci * 9 + tap (27 or 81 columns), with the bias gradient as one more column of ones. M = 32 output
+// channels, N = 32 columns per accumulator tile (NT = 1 for 3 channels, 3 for 9), K = the image's output pixels in row-major order, 16 per MFMA.
+// Both operands are built in REGISTERS from fp32 tiles in LDS — dY[co][p] (8 consecutive pixels of one channel: two 16-byte reads), the raw
+// input rows (8 stride-2 taps per lane, scaled x / 255 - 0.5 as Encoder.forward does) — and split into NPL bf16 planes there; no plane ever
+// exists in memory. A workgroup = one image, 8 waves share the k16 steps of a chunk of RC output rows, accumulate over all chunks, and combine
+// their eight accumulators through LDS at the end. Partials in the layout of the fp32 kernel (summed in image order by the same column-sum).
+constexpr int W1_RC = 7;                    // output rows per chunk: 7 x 41 = 287 pixels = 18 k16 steps with one pixel of padding
+constexpr int W1_THREADS = 512;
+template <int NPL, int NT>
+__global__ __launch_bounds__(W1_THREADS) void conv1_wgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ in, float* __restrict__ P,
+                                                                      float* __restrict__ Pb, int ci_n, int ih, int iw, int oh, int ow) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char w1_lds[];
+    const int CP = ((W1_RC * ow + 15) / 16) * 16 + 4;                      // dY pitch per channel (floats): whole k16 steps + 4 (bank spread)
+    const int XR = 2 * W1_RC + 1;                                          // input rows a chunk touches
+    float* dyt = reinterpret_cast<float*>(w1_lds);                         // [32][CP]
+    float* xt = dyt + CONV_CO * CP;                                        // [ci_n][XR][iw]
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 5, col = lane & 31;
+    const float* dyn = dy + (int64_t)n * CONV_CO * oh * ow;
+    const float* inn = in + (int64_t)n * ci_n * ih * iw;
+    const int ncols = ci_n * 9;                                            // real columns; column `ncols` carries the bias gradient
+    cf32x16 acc[NT][NPL];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int c = 0; c < NPL; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.f;
+    // this lane's B columns: k' = 32 t + col -> (ci, ky, kx) offsets into the input tile
+    int boff[NT]; bool bok[NT], bone[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int kp = 32 * t + col;
+        bok[t] = kp < ncols; bone[t] = kp == ncols;
+        const int ci = bok[t] ? kp / 9 : 0, tap = bok[t] ? kp % 9 : 0;
+        boff[t] = (ci * XR + tap / 3) * iw + tap % 3;
+    }
+    auto planes = [](const float (&v)[8], cbf16x8 (&out)[NPL]) {
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = v[j];
+#pragma unroll
+        for (int c = 0; c < NPL; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const __bf16 h = (__bf16)r[j]; out[c][j] = h; r[j] -= (float)h; }
+    };
+    for (int r0 = 0; r0 < oh; r0 += W1_RC) {
+        const int nr = oh - r0 < W1_RC ? oh - r0 : W1_RC, npx = nr * ow, nsteps = (npx + 15) / 16;
+        __syncthreads();
+        for (int i = tid; i < CONV_CO * CP; i += W1_THREADS) {                 // dY chunk, zero beyond the chunk's pixels
+            const int co = i / CP, pp = i % CP;
+            dyt[i] = pp < npx ? dyn[(int64_t)co * oh * ow + (int64_t)r0 * ow + pp] : 0.f;
+        }
+        const int rows_in = 2 * nr + 1, iy0 = 2 * r0;
+        for (int i = tid; i < ci_n * XR * iw; i += W1_THREADS) {
+            const int ci = i / (XR * iw), rem = i % (XR * iw), yy = rem / iw, xx = rem % iw;
+            xt[i] = (yy < rows_in && iy0 + yy < ih) ? inn[((int64_t)ci * ih + iy0 + yy) * iw + xx] / 255.0f - 0.5f : 0.f;
+        }
+        __syncthreads();
+        for (int st = wave; st < nsteps; st += 8) {
+            const int p0 = st * 16 + 8 * kg;
+            float av[8];
+            {
+                const float4 a0 = *reinterpret_cast<const float4*>(dyt + col * CP + p0), a1 = *reinterpret_cast<const float4*>(dyt + col * CP + p0 + 4);
+                av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w; av[4] = a1.x; av[5] = a1.y; av[6] = a1.z; av[7] = a1.w;
+            }
+            cbf16x8 ap[NPL];
+            planes(av, ap);
+            int py[8], px[8];
+            {
+                int y = p0 / ow, x = p0 % ow;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { py[j] = y; px[j] = x; if (++x == ow) { x = 0; ++y; } }
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float bv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool inside = p0 + j < npx;
+                    const float xv = xt[boff[t] + (inside ? (2 * py[j]) * iw + 2 * px[j] : 0)];
+                    bv[j] = bok[t] ? (inside ? xv : 0.f) : (bone[t] ? 1.0f : 0.f);
+                }
+                cbf16x8 bp[NPL];
+                planes(bv, bp);
+                // plane products by magnitude class: c = 0: p0*p0; c = 1: p0*p1 + p1*p0; c = 2: p0*p2 + p2*p0 + p1*p1
+                acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bp[0], acc[t][0], 0, 0, 0);
+                if constexpr (NPL >= 2) {
+                    acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bp[1], acc[t][1], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], bp[0], acc[t][1], 0, 0, 0);
+                }
+                if constexpr (NPL == 3) {
+                    acc[t][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bp[2], acc[t][2], 0, 0, 0);
+                    acc[t][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], bp[0], acc[t][2], 0, 0, 0);
+                    acc[t][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], bp[1], acc[t][2], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // combine the eight waves' accumulators: [wave][t][co][col] floats through LDS (reusing the tiles), then one thread per (co, k')
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(w1_lds);                                        // [8][NT][32][32]
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = (r & 3) + 8 * (r >> 2) + 4 * kg;                                // C layout: row = co, column = lane & 31
+            float v = acc[t][0][r];
+            if constexpr (NPL == 2) v = acc[t][1][r] + v;
+            if constexpr (NPL == 3) v = (acc[t][2][r] + acc[t][1][r]) + v;
+            red[((wave * NT + t) * CONV_CO + co) * 32 + col] = v;
+        }
+    __syncthreads();
+    for (int i = tid; i < NT * CONV_CO * 32; i += W1_THREADS) {
+        const int t = i / (CONV_CO * 32), co = (i / 32) % CONV_CO, c = i % 32, kp = 32 * t + c;
+        if (kp > ncols) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += red[((w * NT + t) * CONV_CO + co) * 32 + c];
+        if (kp < ncols) P[((int64_t)n * CONV_CO + co) * ncols + kp] = v;
+        else Pb[(int64_t)n * CONV_CO + co] = v;
+    }
+}
+
+static bool conv1_wgrad_mfma_fits(int ci_n, int ih, int oh, int ow, int stride) {
+    return stride == 2 && (ci_n == 3 || ci_n == 9) && ow <= 48 && oh == ow && ih >= 2 * oh + 1;
+}
+static int conv1_wgrad_mfma(const float* dy, const float* in, float* P, float* Pb, int n, int ci_n, int ih, int iw, int oh, int ow, int prec, hipStream_t s) {
+    const int npl = prec == EXORL_PREC_BF16X6 ? 3 : (prec == EXORL_PREC_BF16X3 ? 2 : 1), nt = ci_n == 3 ? 1 : 3;
+    const int cp = ((W1_RC * ow + 15) / 16) * 16 + 4, xr = 2 * W1_RC + 1;
+    size_t lds = sizeof(float) * ((size_t)CONV_CO * cp + (size_t)ci_n * xr * iw);
+    const size_t red = sizeof(float) * 8 * nt * CONV_CO * 32;
+    lds = lds > red ? lds : red;
+    EXORL_REQUIRE(lds <= 160 * 1024, "conv1_wgrad_mfma: tiles do not fit LDS");
+#define EXORL_W1(NN, TT) do { \
+        static bool attr = false; \
+        if (!attr) { EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv1_wgrad_mfma_kernel<NN, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
+        hipLaunchKernelGGL((conv1_wgrad_mfma_kernel<NN, TT>), dim3(n), dim3(W1_THREADS), lds, s, dy, in, P, Pb, ci_n, ih, iw, oh, ow); } while (0)
+    if (nt == 1) { if (npl == 3) EXORL_W1(3, 1); else if (npl == 2) EXORL_W1(2, 1); else EXORL_W1(1, 1); }
+    else         { if (npl == 3) EXORL_W1(3, 3); else if (npl == 2) EXORL_W1(2, 3); else EXORL_W1(1, 3); }
+#undef EXORL_W1
+    EXORL_LAUNCH_CHECK();
+    return 0;
+}
+
 // d *= (a > 0): ReLU mask of the top activation against the gradient that arrives from the trunk's Linear
 __global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ d, const float* __restrict__ a, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = a[i] > 0.f ? d[i] : 0.f;
@@ -807,6 +953,8 @@ int exorl_encoder_backward_prec(const float* params_dev, int32_t c_in, int32_t h
         const int prec_w = (ov & 256) ? EXORL_PREC_F32 : prec, prec_d = (ov & 128) ? EXORL_PREC_F32 : prec;
         if (prec_w != EXORL_PREC_F32 && l > 0)
             EXORL_TRY(conv_wgrad_mfma(d, in, w.P, w.Pb, n, ih, ih, oh, oh, prec_w, s));
+        else if (prec_w != EXORL_PREC_F32 && l == 0 && conv1_wgrad_mfma_fits(ci, ih, oh, oh, stride) && !(tune_variant() & 131072))
+            EXORL_TRY(conv1_wgrad_mfma(d, in, w.P, w.Pb, n, ci, ih, ih, oh, oh, prec_w, s));     // exorl_gemm_tune bit 131072: the fp32 FMA kernel (A/B)
         else {
             hipLaunchKernelGGL(conv_wgrad_kernel, dim3(n), dim3(1024), lds, s, d, in, w.P, w.Pb, ci, ih, ih, oh, oh, stride, l == 0 ? 1 : 0);
             EXORL_LAUNCH_CHECK();
