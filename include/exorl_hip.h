@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EXORL_ABI_VERSION 7
+#define EXORL_ABI_VERSION 8      /* 8 (round 3): EXORL_PREC_BF16X6, exorl_agent_act_host, exorl_debug_precision_override */
 
 const char* exorl_last_error(void);
 int exorl_abi_version(void);

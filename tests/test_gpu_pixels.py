@@ -534,7 +534,7 @@ def test_pixel_agent_pickle_roundtrip_continues_bit_identically(kind):
             assert torch.equal(ag.queue, other.queue) and ag.queue_ptr == other.queue_ptr
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x6', 'bf16x3'])
 def test_config4_proto_pixels_shipped_dims_vs_oracle(precision):
     """BASELINE.json configs[3] at the sizes the 115 update()/s figure is quoted on — jaco frames (3, 84, 84) uint8, A = 9, feature_dim 50,
     hidden 1024, pred_dim 128, proj_dim 512, 512 prototypes, queue 2048, nstep 3 — except the batch: 256 instead of 1024, the largest the
@@ -583,12 +583,14 @@ def test_config4_proto_pixels_shipped_dims_vs_oracle(precision):
         # actor_loss 6.9e-4) does not: Adam's first steps move each of the 2 M trunk weights by lr * sign(g), and the sign of a gradient
         # below the split-bf16 error floor (~1e-5 of its sum of |terms|) is noise. Held to 1e-3 here; config 4 in this mode is documented
         # as outside the 1e-4 bar, the fp32 mode is inside it
-        bar = 2e-4 if precision == 'fp32' else 1e-3
+        # round 3: `bf16x6` (three planes) is held to the fp32 bar; the test at the config's own batch against the reference itself is
+        # test_config4_proto_pixels_b1024_vs_reference (this one keeps the numpy oracle in the loop at a batch it can turn round)
+        bar = 1e-3 if precision == 'bf16x3' else 2e-4
         for k, v in mo.items():
             assert abs(m[k] - v) <= bar * abs(v) + 1e-5, (precision, i, k, m[k], v)
             worst = max(worst, errs[k])
     print(f'[config 4] proto pixels {precision} B={B}: worst relative metric error {worst:.2e}')
-    np.testing.assert_allclose(ag.queue.cpu().numpy(), orc.proto.queue, rtol=2e-4, atol=2e-5 if precision == 'fp32' else 1e-4)
+    np.testing.assert_allclose(ag.queue.cpu().numpy(), orc.proto.queue, rtol=2e-4, atol=1e-4 if precision == 'bf16x3' else 2e-5)
 
 
 def _config4_agent(z, precision):
