@@ -273,7 +273,7 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
             if (xx >= sw) { xx -= sw; ++yy; }
         }
     };
-    fetch(0);
+    fetch(gridDim.y > 1 ? (int)blockIdx.y : 0);
     const float bv = bias ? bias[col] : 0.f;
     // One pass. FULL (every pass but the last): all four pixel quads of a lane lie inside the map and there is a next strip to fetch, so the
     // body has NO run-time branch around a memory instruction — which is what lets the compiler count: the wait in front of the next pass's
@@ -370,6 +370,10 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
         }
         __syncthreads();                   // every wave is past its MFMA reads before the next pass rewrites the input planes
     };
+    if (gridDim.y > 1) {                   // few images (act() on one frame): one pass per workgroup, gridDim.y = npass workgroups per image
+        if ((int)blockIdx.y < npass) body((int)blockIdx.y, std::false_type{});
+        return;
+    }
     for (int pass = 0; pass + 1 < npass; ++pass) body(pass, std::true_type{});
     body(npass - 1, std::false_type{});
 }
@@ -398,7 +402,9 @@ static int conv3x3_mfma(const float* in, const float* Wt, const float* bias, con
         EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-#define EXORL_CM(NN, MM) hipLaunchKernelGGL((conv3x3_mfma_kernel<NN, MM>), dim3(n), dim3(CM_THREADS), lds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu, plane)
+    // a handful of images (act(): one) cannot fill the chip with one workgroup each: spread an image's 256-pixel passes over workgroups
+    const int npass = (oh * ow + CM_PASS - 1) / CM_PASS, gy = n <= 8 ? npass : 1;
+#define EXORL_CM(NN, MM) hipLaunchKernelGGL((conv3x3_mfma_kernel<NN, MM>), dim3(n, gy), dim3(CM_THREADS), lds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu, plane)
     if (npl == 3)      { if (mask) EXORL_CM(3, true); else EXORL_CM(3, false); }
     else if (npl == 2) { if (mask) EXORL_CM(2, true); else EXORL_CM(2, false); }
     else               { if (mask) EXORL_CM(1, true); else EXORL_CM(1, false); }
