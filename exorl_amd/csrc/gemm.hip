@@ -139,6 +139,11 @@ __device__ __forceinline__ void store_tile(unsigned char* lds, int tid, const fl
     }
 }
 
+// measured (round 3): one LDS stage pays for three planes (Proto pixels 9.8 -> 9.5 ms, ICM pixels 27.2 -> 22.8 ms per update in bf16x6) and is
+// neutral to slightly worse for two (rnd 1528 -> 1514, icm_apt 1186 -> 1172 update()/s): two planes keep the double buffer
+#ifndef EXORL_GEMM_X3_SINGLE_STAGE
+#define EXORL_GEMM_X3_SINGLE_STAGE 0
+#endif
 template <int PREC, int AL, int BL, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
     constexpr int KU = (PREC == EXORL_PREC_F32) ? 4 : 8;   // k elements per 16-byte unit
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
     constexpr int NT = X6 ? 6 : (X3 ? 4 : 2);              // LDS tiles per stage: [A p0][B p0][A p1][B p1][A p2][B p2]
     // two stages; the three-plane mode needs 96 KB, past the 64 KB a static array may have: dynamic there
     extern __shared__ __attribute__((aligned(16))) unsigned char gk_dyn[];
-    __shared__ __attribute__((aligned(16))) unsigned char gk_static[X6 ? 16 : 2 * NT * TILEB];
+    __shared__ __attribute__((aligned(16))) unsigned char gk_static[X6 ? 16 : ((X3 && EXORL_GEMM_X3_SINGLE_STAGE) ? 1 : 2) * NT * TILEB];
     unsigned char* const smem_base = X6 ? gk_dyn : gk_static;
     auto smem = [&](int stage, int tile) { return smem_base + (stage * NT + tile) * TILEB; };
 
@@ -180,8 +185,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
     const int arow = wm * 32 + (lane & 31);
     const int brow = wn * 32 + (lane & 31);
 
+    // three planes: ONE LDS stage (48 KB, three workgroups per CU) instead of two (96 KB, one workgroup of four waves per CU — one wave per SIMD
+    // with nothing to hide a barrier or an LDS round trip behind); the next tile still travels in registers while this one is multiplied
+    constexpr bool SS = X6 || (X3 && EXORL_GEMM_X3_SINGLE_STAGE);
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+        const int cur = SS ? 0 : (kt & 1);
         if (kt + 1 < nk) {
             load_tile<AL, VEC, KU>(P.A, P.lda, M, K, m0, (kt + 1) * KPT, tid, ra);
             load_tile<BL, VEC, KU>(P.B, P.ldb, N, K, n0, (kt + 1) * KPT, tid, rb);
@@ -219,9 +227,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
                 }
             }
         }
+        if constexpr (SS) __syncthreads();             // every wave is done reading the stage before it is overwritten
         if (kt + 1 < nk) {
-            store_tile<AL, PREC, KU>(smem(cur ^ 1, 0), tid, ra);
-            store_tile<BL, PREC, KU>(smem(cur ^ 1, 1), tid, rb);
+            store_tile<AL, PREC, KU>(smem(SS ? 0 : cur ^ 1, 0), tid, ra);
+            store_tile<BL, PREC, KU>(smem(SS ? 0 : cur ^ 1, 1), tid, rb);
         }
         __syncthreads();
     }
@@ -1950,7 +1959,7 @@ static int launch_layout(const GemmBatch& gb, int count, int max_tiles, bool vec
         g_prof.flops.push_back(f);
         EXORL_CHECK_HIP(hipEventRecord(g_prof.ev[2 * g_prof.used], s));
     }
-    constexpr size_t dyn = PREC == EXORL_PREC_BF16X6 ? 2 * 6 * TILEB : 0;      // 96 KB: two stages of three planes of A and B
+    constexpr size_t dyn = PREC == EXORL_PREC_BF16X6 ? 6 * TILEB : 0;          // 48 KB: one stage of three planes of A and B
     if constexpr (PREC == EXORL_PREC_BF16X6) {
         static bool attr = false;
         if (!attr) {
