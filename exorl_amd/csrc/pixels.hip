@@ -207,6 +207,10 @@ constexpr int CM_PIX = 40;                 // bf16 elements per staged pixel (32
 constexpr int CM_THREADS = 512;            // 8 waves x 32 pixels = 256 output pixels per pass
 constexpr int CM_PASS = 256;
 constexpr int CM_MAXW = 48;                // widest staged row (output width + 2) this kernel takes: ow <= 46
+// k-steps unrolled together in the MFMA loop: 3 measured equal to 2 (9.4 vs 9.3 ms per Proto update in bf16x6, 242 vs 240 VGPRs)
+#ifndef CM_UNROLL
+#define CM_UNROLL 2
+#endif
 constexpr int CM_IPT = 15;                 // staged (channel pair, y, x) items per thread: 16 * rows * (ow + 2) <= 15 * 512 (host-checked)
 
 // A pass covers 256 consecutive output pixels in row-major order of the map (not a square tile: a 39-wide map would pay for 48 x 48),
@@ -329,8 +333,8 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
         int pa = p0 + 32 * wave + col;                                          // this lane's pixel of the A operand (clamped: tail lanes recompute the last pixel)
         pa = pa < npix ? pa : npix - 1;
         const int abase = ((pa / ow - y0) * sw + pa % ow) * CM_PIX + 8 * kg;
-#pragma unroll 2
-        for (int s = 0; s < 18; ++s) {                                          // two k-steps of fragments live at a time (VGPR budget: 256 at 8 waves)
+#pragma unroll CM_UNROLL
+        for (int s = 0; s < 18; ++s) {                                          // CM_UNROLL k-steps of fragments live at a time (VGPR budget: 256 at 8 waves)
             const int dy = (s >> 1) / 3, dx = (s >> 1) % 3;
             const int o = abase + (dy * sw + dx) * CM_PIX + (s & 1) * 16;
             const cbf16x8 ah = *reinterpret_cast<const cbf16x8*>(xh + o);
@@ -643,16 +647,19 @@ __global__ __launch_bounds__(WM_THREADS) void conv_wgrad_mfma_kernel(const float
 
 static int conv_wgrad_mfma(const float* dy, const float* in, float* P, float* Pb, int n, int ih, int iw, int oh, int ow, int prec, hipStream_t s) {
     const int npl = prec == EXORL_PREC_BF16X6 ? 3 : (prec == EXORL_PREC_BF16X3 ? 2 : 1);
-    const int th = npl == 3 ? 8 : 16;
+    const bool th4 = npl == 3 && (tune_variant() & 2048);            // measured and not adopted: 4 x 16 tiles (74 KB, two workgroups per CU): 9.6 vs 9.3 ms per Proto update
+    const int th = npl == 3 ? (th4 ? 4 : 8) : 16;
     const size_t lds = (size_t)npl * (CONV_CO * (th * CONV_TILE + 8) + 3 * CONV_CO * ((th + 2) * CONV_TILE + 8)) * sizeof(unsigned short);
     static bool attr = false;
     if (!attr) {
         EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wgrad_mfma_kernel<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wgrad_mfma_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wgrad_mfma_kernel<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wgrad_mfma_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    if (npl == 3)      hipLaunchKernelGGL((conv_wgrad_mfma_kernel<3, 8>), dim3(n), dim3(WM_THREADS), lds, s, dy, in, P, Pb, ih, iw, oh, ow);
+    if (th4)           hipLaunchKernelGGL((conv_wgrad_mfma_kernel<3, 4>), dim3(n), dim3(WM_THREADS), lds, s, dy, in, P, Pb, ih, iw, oh, ow);
+    else if (npl == 3) hipLaunchKernelGGL((conv_wgrad_mfma_kernel<3, 8>), dim3(n), dim3(WM_THREADS), lds, s, dy, in, P, Pb, ih, iw, oh, ow);
     else if (npl == 2) hipLaunchKernelGGL((conv_wgrad_mfma_kernel<2, 16>), dim3(n), dim3(WM_THREADS), lds, s, dy, in, P, Pb, ih, iw, oh, ow);
     else               hipLaunchKernelGGL((conv_wgrad_mfma_kernel<1, 16>), dim3(n), dim3(WM_THREADS), lds, s, dy, in, P, Pb, ih, iw, oh, ow);
     EXORL_LAUNCH_CHECK();
