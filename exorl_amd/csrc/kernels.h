@@ -370,6 +370,9 @@ struct Mlp {                                         // Linear-ReLU-...-Linear; 
 int mlp_forward(const Mlp& m, const float* P, const float* x, int64_t ldx, int rows, int prec, hipStream_t s);
 // dact[last] holds d(loss)/d(output); writes parameter gradients into G and, if dx, d(loss)/d(input) (rows, in0)
 int mlp_backward(const Mlp& m, const float* P, float* G, const float* x, int64_t ldx, int rows, float* dx, int prec, hipStream_t s);
+// n nets of identical shapes (twin Q heads, Disagreement's ensemble) layer by layer in shared launches; dx (rows, in0) receives the SUM of the nets' d/d(input)
+int mlp_forward_many(const Mlp* nets, int n, const float* P, const float* x, int64_t ldx, int rows, int prec, hipStream_t s);
+int mlp_backward_many(const Mlp* nets, int n, const float* P, float* G, const float* x, int64_t ldx, int rows, int prec, hipStream_t s, float* dx);
 int launch_concat(const float* a, int64_t lda, int ca, const float* b, int64_t ldb, int cb, float* dst, int rows, hipStream_t s);
 
 // ---- replay (replay.hip) internal entry points used by the agent's graph capture

@@ -50,14 +50,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 __global__ __launch_bounds__(256) void tanh_kernel(float* __restrict__ x, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] = tanhf(x[i]);
 }
-// dst[m][j] = a[m*lda + c0 + j] + b[m*ldb + c0 + j]
+// dst[m][j] = a[m*lda + c0 + j] + b[m*ldb + c0 + j]   (b == nullptr: a alone)
 __global__ __launch_bounds__(256) void add_cols_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b, int64_t ldb, int c0,
                                                        int nc, float* __restrict__ dst, int rows) {
     const int64_t n = (int64_t)rows * nc;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t m = i / nc;
         const int j = (int)(i - m * nc);
-        dst[i] = a[m * lda + c0 + j] + b[m * ldb + c0 + j];
+        dst[i] = b ? a[m * lda + c0 + j] + b[m * ldb + c0 + j] : a[m * lda + c0 + j];
     }
 }
 // straight-through sample (utils.py:135-138) then tanh: dpre = da * (1 - mu^2)
@@ -563,17 +563,19 @@ int exorl_pixel_agent_update(exorl_pixel_agent_t* a, float stddev, const int32_t
     NoiseSpec nc{noise_c, c.seed, 2 * a->noise_counter, nullptr};
     EXORL_TRY(sample_action(a->mu_n, nc, stddev, c.stddev_clip, 1, a->xq_t + F, FA, B, A, nullptr, s));
     // the target's Q heads reuse the critic's Mlp buffers (outputs to q), then are copied to tq
-    for (int i = 0; i < 2; ++i) EXORL_TRY(mlp_forward(a->critic.head[i], Pt, a->xq_t, FA, B, prec, s));
+    EXORL_TRY(mlp_forward_many(a->critic.head, 2, Pt, a->xq_t, FA, B, prec, s));          // Q1 and Q2 layer by layer in shared launches
     EXORL_TRY(sf_q());
     EXORL_CHECK_HIP(hipMemcpyAsync(a->tq, a->q, sizeof(float) * 2 * B, hipMemcpyDeviceToDevice, s));
     EXORL_TRY(trunk_forward(a, a->critic, Pc, a->feat_o, mt, B, a->tc, prec, s));
     EXORL_TRY(launch_concat(a->tc.h, F, F, a->action, A, A, a->xq_c, B, s));
-    for (int i = 0; i < 2; ++i) EXORL_TRY(mlp_forward(a->critic.head[i], Pc, a->xq_c, FA, B, prec, s));
+    EXORL_TRY(mlp_forward_many(a->critic.head, 2, Pc, a->xq_c, FA, B, prec, s));
     EXORL_TRY(sf_q());
     EXORL_TRY(critic_loss(a->q, a->tq, a->reward, a->discount, a->dq, a->metrics, B, inv_b, s));
     EXORL_TRY(sf_dout());
-    for (int i = 0; i < 2; ++i) EXORL_TRY(mlp_backward(a->critic.head[i], Pc, Gc, a->xq_c, FA, B, a->dxq[i], prec, s));
-    hipLaunchKernelGGL(add_cols_kernel, dim3(grid1((int64_t)B * F)), dim3(256), 0, s, a->dxq[0], (int64_t)FA, a->dxq[1], (int64_t)FA, 0, F, a->dh, B);
+    // both heads' backward passes layer by layer in shared launches; d/d(input) of the two is summed by the second head's accumulating dgrad
+    // (dx0 + dx1, the same fp32 addition add_cols_kernel used to make of two buffers)
+    EXORL_TRY(mlp_backward_many(a->critic.head, 2, Pc, Gc, a->xq_c, FA, B, prec, s, a->dxq[0]));
+    hipLaunchKernelGGL(add_cols_kernel, dim3(grid1((int64_t)B * F)), dim3(256), 0, s, a->dxq[0], (int64_t)FA, (const float*)nullptr, (int64_t)FA, 0, F, a->dh, B);
     EXORL_LAUNCH_CHECK();
     EXORL_TRY(trunk_backward(a, a->critic, Pc, Gc, a->feat_o, mt, B, a->tc, a->dh, a->train_encoder ? a->dfeat : nullptr, prec, s));
     if (a->train_encoder) EXORL_TRY(exorl_encoder_backward_prec(Pe, c.c_in, c.hw, a->aug_o, B, a->enc_ws_o, a->dfeat, Ge, a->cfg.precision, s));
@@ -590,13 +592,13 @@ int exorl_pixel_agent_update(exorl_pixel_agent_t* a, float stddev, const int32_t
     NoiseSpec na{noise_a, c.seed, 2 * a->noise_counter + 1, nullptr};
     EXORL_TRY(sample_action(a->mu_o, na, stddev, c.stddev_clip, 1, a->xq_c + F, FA, B, A, a->metrics + EXORL_M_ACTOR_LOGPROB, s));
     a->noise_counter += 1;
-    for (int i = 0; i < 2; ++i) EXORL_TRY(mlp_forward(a->critic.head[i], Pc, a->xq_c, FA, B, prec, s));
+    EXORL_TRY(mlp_forward_many(a->critic.head, 2, Pc, a->xq_c, FA, B, prec, s));
     EXORL_TRY(sf_q());
     EXORL_TRY(actor_stats(a->q, a->stats, B, s));
     EXORL_TRY(actor_dq(a->q, a->stats, a->dq, B, inv_b, 0.f, 0, s));
     EXORL_TRY(sf_dout());
-    for (int i = 0; i < 2; ++i) EXORL_TRY(mlp_backward(a->critic.head[i], Pc, Gc, a->xq_c, FA, B, a->dxq[i], prec, s));     // Gc: scratch now
-    hipLaunchKernelGGL(add_cols_kernel, dim3(grid1((int64_t)B * A)), dim3(256), 0, s, a->dxq[0], (int64_t)FA, a->dxq[1], (int64_t)FA, F, A, a->dmu, B);
+    EXORL_TRY(mlp_backward_many(a->critic.head, 2, Pc, Gc, a->xq_c, FA, B, prec, s, a->dxq[0]));     // Gc: scratch now
+    hipLaunchKernelGGL(add_cols_kernel, dim3(grid1((int64_t)B * A)), dim3(256), 0, s, a->dxq[0], (int64_t)FA, (const float*)nullptr, (int64_t)FA, F, A, a->dmu, B);
     hipLaunchKernelGGL(dpre_kernel, dim3(grid1((int64_t)B * A)), dim3(256), 0, s, a->dmu, a->mu_o, pol.dact[2], (int64_t)B * A);
     EXORL_LAUNCH_CHECK();
     EXORL_TRY(mlp_backward(pol, Pa, Ga, a->ta_o.h, F, B, a->dh, prec, s));
