@@ -921,8 +921,8 @@ static int rnd_forward(exorl_intr* it, const exorl_intr_batch& b, bool with_targ
     } else {
         hipLaunchKernelGGL(bn_clamp_kernel, dim3(O), dim3(256), 0, s, b.obs, b.obs_ld, it->xn, B, O, c.clip_val, it->bn);
         EXORL_LAUNCH_CHECK();
-        EXORL_TRY(mlp_forward(it->net[0], P, it->xn, O, B, c.precision, s));
-        if (with_target) EXORL_TRY(mlp_forward(it->net[1], P, it->xn, O, B, c.precision, s));
+        if (with_target) EXORL_TRY(mlp_forward_many(it->net, 2, P, it->xn, O, B, c.precision, s));      // predictor and frozen target: same input, same shapes
+        else EXORL_TRY(mlp_forward(it->net[0], P, it->xn, O, B, c.precision, s));
     }
     hipLaunchKernelGGL(rnd_err_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->net[0].act[2], it->net[1].act[2], it->fe, dpred, B, R);
     EXORL_LAUNCH_CHECK();

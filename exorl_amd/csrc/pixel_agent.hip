@@ -150,7 +150,7 @@ struct exorl_pixel_agent {
     unsigned char *obs = nullptr, *next_obs = nullptr;
     float *action = nullptr, *reward = nullptr, *discount = nullptr, *meta = nullptr;      // meta: (batch, meta_dim) skill / task rows
     float *aug_o = nullptr, *aug_n = nullptr, *enc_ws_o = nullptr, *enc_ws_n = nullptr, *feat_o = nullptr, *feat_n = nullptr;
-    float* splitk = nullptr;
+    float* splitk = nullptr; float* splitk2 = nullptr;     // split-K partials of a trunk forward (two: paired trunks share a launch)
     TrunkAct ta_n{}, ta_o{}, tt{}, tc{};         // actor on next_obs / obs, target critic, critic
     float *xq_t = nullptr, *xq_c = nullptr, *dxq[2] = {nullptr, nullptr};
     float *q = nullptr, *tq = nullptr, *dq = nullptr, *mu_n = nullptr, *mu_o = nullptr, *dmu = nullptr, *dh = nullptr, *dz = nullptr, *dfeat = nullptr;
@@ -206,6 +206,7 @@ static void pcarve(exorl_pixel_agent* a, PCarver& c) {
     const int64_t ews = exorl_encoder_workspace_floats((int32_t)B, g.c_in, g.hw);
     a->enc_ws_o = c.take(ews); a->enc_ws_n = c.take(ews);
     a->splitk = c.take((int64_t)(SPLITK + 1) * B * F);
+    a->splitk2 = c.take((int64_t)(SPLITK + 1) * B * F);
     for (TrunkAct* t : {&a->ta_n, &a->ta_o, &a->tt, &a->tc}) { t->z = c.take(B * F); t->h = c.take(B * F); t->xhat = c.take(B * F); t->rstd = c.take(B); }
     a->xq_t = c.take(B * (F + A)); a->xq_c = c.take(B * (F + A));
     a->dxq[0] = c.take(B * (F + A)); a->dxq[1] = c.take(B * (F + A));
@@ -251,6 +252,32 @@ static int trunk_forward(exorl_pixel_agent* a, const PNet& n, const float* P, co
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid1((int64_t)rows * F)), dim3(256), 0, s, a->splitk, P + n.trunk.b, t.z, (int64_t)rows * F, F, cnt);
     EXORL_LAUNCH_CHECK();
     return ln_tanh_fwd(t.z, P + n.g, P + n.beta, t.h, t.xhat, t.rstd, rows, F, 1, 0, 0, s);
+}
+
+// Two trunks on the SAME encoding (actor + target critic on next_obs, actor + critic on obs) in one launch with their k-slabs interleaved:
+// slab i of net A and of net B are neighbouring problems, their workgroups land on the same XCDs (linear id mod 8) one dispatch round apart,
+// and the second reads the 160 MB of encodings from L2 instead of HBM. Without meta columns only (2 x 16 problems = the launch limit).
+static int trunk_forward_pair(exorl_pixel_agent* a, const PNet& na, const float* Pa, const TrunkAct& ta, const PNet& nb, const float* Pb, const TrunkAct& tb,
+                              const float* x, int rows, int prec, hipStream_t s) {
+    const int F = na.F, R = a->R, D = na.D;
+    EXORL_REQUIRE(D == R && nb.D == R && nb.F == F, "trunk_forward_pair: needs two meta-free trunks of one width");
+    const int kc = (int)round_up(cdiv(R, SPLITK), 4);
+    GemmProblem p[2 * SPLITK];
+    int cnt = 0;
+    for (int i = 0; i < SPLITK; ++i) {
+        const int k0 = i * kc;
+        if (k0 >= R) break;
+        const int k = R - k0 < kc ? R - k0 : kc;
+        p[2 * cnt] = GemmProblem{x + k0, Pa + na.trunk.W + k0, a->splitk + (int64_t)cnt * rows * F, nullptr, rows, F, k, R, D, F};
+        p[2 * cnt + 1] = GemmProblem{x + k0, Pb + nb.trunk.W + k0, a->splitk2 + (int64_t)cnt * rows * F, nullptr, rows, F, k, R, D, F};
+        ++cnt;
+    }
+    EXORL_TRY(gemm_grouped(prec, 0, 0, p, 2 * cnt, false, false, s));
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid1((int64_t)rows * F)), dim3(256), 0, s, a->splitk, Pa + na.trunk.b, ta.z, (int64_t)rows * F, F, cnt);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid1((int64_t)rows * F)), dim3(256), 0, s, a->splitk2, Pb + nb.trunk.b, tb.z, (int64_t)rows * F, F, cnt);
+    EXORL_LAUNCH_CHECK();
+    EXORL_TRY(ln_tanh_fwd(ta.z, Pa + na.g, Pa + na.beta, ta.h, ta.xhat, ta.rstd, rows, F, 1, 0, 0, s));
+    return ln_tanh_fwd(tb.z, Pb + nb.g, Pb + nb.beta, tb.h, tb.xhat, tb.rstd, rows, F, 1, 0, 0, s);
 }
 
 // dh (rows, F) at the trunk output -> parameter grads (W0, b0, gain, beta) and optionally d/d(encoding) (rows, R)
@@ -552,13 +579,15 @@ int exorl_pixel_agent_update(exorl_pixel_agent_t* a, float stddev, const int32_t
     }
     a->have_feat_o = a->have_feat_n = false;
     // ---- update_critic (ddpg.py:240-268)
-    EXORL_TRY(trunk_forward(a, a->actor, Pa, a->feat_n, mt, B, a->ta_n, prec, s));
+    const bool pair = c.meta_dim == 0 && !(tune_variant() & 4096);      // exorl_gemm_tune bit 4096: separate trunk launches (A/B)
+    if (pair) EXORL_TRY(trunk_forward_pair(a, a->actor, Pa, a->ta_n, a->critic, Pt, a->tt, a->feat_n, B, prec, s));
+    else EXORL_TRY(trunk_forward(a, a->actor, Pa, a->feat_n, mt, B, a->ta_n, prec, s));
     Mlp& pol = a->actor.head[0];
     EXORL_TRY(mlp_forward(pol, Pa, a->ta_n.h, F, B, prec, s));
     EXORL_CHECK_HIP(hipMemcpyAsync(a->mu_n, pol.act[2], sizeof(float) * B * A, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(tanh_kernel, dim3(grid1((int64_t)B * A)), dim3(256), 0, s, a->mu_n, (int64_t)B * A);
     EXORL_LAUNCH_CHECK();
-    EXORL_TRY(trunk_forward(a, a->critic, Pt, a->feat_n, mt, B, a->tt, prec, s));
+    if (!pair) EXORL_TRY(trunk_forward(a, a->critic, Pt, a->feat_n, mt, B, a->tt, prec, s));
     EXORL_TRY(launch_concat(a->tt.h, F, F, a->mu_n, A, A, a->xq_t, B, s));           // action columns overwritten by the sample below
     NoiseSpec nc{noise_c, c.seed, 2 * a->noise_counter, nullptr};
     EXORL_TRY(sample_action(a->mu_n, nc, stddev, c.stddev_clip, 1, a->xq_t + F, FA, B, A, nullptr, s));
@@ -582,12 +611,13 @@ int exorl_pixel_agent_update(exorl_pixel_agent_t* a, float stddev, const int32_t
     EXORL_TRY(padam(a, 2, a->critic.total, nullptr, s));
     if (a->train_encoder) { a->t_enc += 1; EXORL_TRY(padam(a, 0, a->enc_total, nullptr, s)); }
     // ---- update_actor (ddpg.py:270-292) on obs.detach(): the encoding computed above, the critic just updated
-    EXORL_TRY(trunk_forward(a, a->actor, Pa, a->feat_o, mt, B, a->ta_o, prec, s));
+    if (pair) EXORL_TRY(trunk_forward_pair(a, a->actor, Pa, a->ta_o, a->critic, Pc, a->tc, a->feat_o, B, prec, s));
+    else EXORL_TRY(trunk_forward(a, a->actor, Pa, a->feat_o, mt, B, a->ta_o, prec, s));
     EXORL_TRY(mlp_forward(pol, Pa, a->ta_o.h, F, B, prec, s));
     EXORL_CHECK_HIP(hipMemcpyAsync(a->mu_o, pol.act[2], sizeof(float) * B * A, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(tanh_kernel, dim3(grid1((int64_t)B * A)), dim3(256), 0, s, a->mu_o, (int64_t)B * A);
     EXORL_LAUNCH_CHECK();
-    EXORL_TRY(trunk_forward(a, a->critic, Pc, a->feat_o, mt, B, a->tc, prec, s));
+    if (!pair) EXORL_TRY(trunk_forward(a, a->critic, Pc, a->feat_o, mt, B, a->tc, prec, s));
     EXORL_TRY(launch_concat(a->tc.h, F, F, a->mu_o, A, A, a->xq_c, B, s));
     NoiseSpec na{noise_a, c.seed, 2 * a->noise_counter + 1, nullptr};
     EXORL_TRY(sample_action(a->mu_o, na, stddev, c.stddev_clip, 1, a->xq_c + F, FA, B, A, a->metrics + EXORL_M_ACTOR_LOGPROB, s));
