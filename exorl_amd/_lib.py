@@ -165,6 +165,7 @@ PROTOTYPES = {
     'exorl_gemm_tune': (C.c_int, [c_int32]),
     'exorl_debug_precision_override': (C.c_int, [c_int32]),
     'exorl_debug_gemm_stamps': (C.c_int, [c_void_p, c_int32]),
+    'exorl_debug_conv_stamps': (C.c_int, [c_void_p, c_int32]),
     'exorl_profile_gemm': (C.c_int, [c_int32]),
     'exorl_profile_gemm_read': (C.c_int, [c_void_p, c_void_p, c_int32, P(c_int32)]),
     'exorl_profile_event_overhead': (C.c_int, [c_void_p, c_void_p]),

@@ -218,7 +218,11 @@ constexpr int CM_IPT = 15;                 // staged (channel pair, y, x) items 
 // NPL = operand planes: 1 plain bf16, 2 split-bf16 (hi*hi + hi*lo + lo*hi), 3 three-plane split (EXORL_PREC_BF16X6: + hi*l3 + l3*hi + lo*lo,
 // products accurate to 3 * 2^-24 — the parity-grade convolution of the pixel agents at ~2x the split-bf16 kernel's MFMA time, where the fp32
 // FMA kernel it replaces took 5.8x)
-template <int NPL, bool MASK>
+// STAMP (diagnostic build, exorl_gemm_tune bit 8192; no product launch takes it): waves 0 and 7 of every workgroup add up the shader-clock
+// cycles of each phase of a pass (convert + LDS write | barrier | fetch issue | MFMA loop with its LDS reads | stores | barrier) over
+// the workgroup's passes and leave them in g_conv_stamps[workgroup][2][8] (exorl_debug_conv_stamps reads them back).
+__device__ unsigned long long g_conv_stamps[1024 * 2 * 8];
+template <int NPL, bool MASK, bool STAMP = false>
 __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* __restrict__ in, const float* __restrict__ Wt,
                                                                   const float* __restrict__ bias, const float* __restrict__ mask,
                                                                   float* __restrict__ out, int ih, int iw, int oh, int ow, int pad, int relu,
@@ -283,11 +287,18 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
     // body has NO run-time branch around a memory instruction — which is what lets the compiler count: the wait in front of the next pass's
     // conversion becomes vmcnt(<this pass's stores>) instead of vmcnt(0), i.e. the stores of pass t drain under pass t + 1 instead of in
     // front of it (gfx9 counts stores in vmcnt too; with the guarded tail path in the loop every pass waited for its predecessor's stores).
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto now = [&]() -> unsigned long long {
+        if constexpr (STAMP) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return __builtin_amdgcn_s_memtime(); }
+        return 0ull;
+    };
+    const unsigned long long t_begin = now();
     auto body = [&](int pass, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
         int y0, rows;
         strip(pass, y0, rows);
         const int nj = rows * sw, p0 = pass * CM_PASS;
+        const unsigned long long t0 = now();
 #pragma unroll
         for (int u = 0; u < CM_IPT; ++u) {
             const int j = jl + 32 * u;
@@ -307,8 +318,11 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
                 }
             }
         }
+        const unsigned long long t1 = now();
         __syncthreads();
+        const unsigned long long t2 = now();
         if constexpr (FULL) fetch(pass + 1);
+        const unsigned long long t3 = now();
         // C layout of the 32x32 MFMA: reg r of lane l = pixel (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the wave's 32, channel l & 31 — four
         // consecutive pixels of one channel per register quad, i.e. 16 contiguous bytes of the NCHW map: the lane stores them itself
         // (and fetches the dgrad mask the same way, now, behind the MFMA work); no output staging, no second barrier.
@@ -354,6 +368,8 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
                 }
             }
         }
+        if constexpr (STAMP) asm volatile("" :: "v"(acc[0]), "v"(accx[0]), "v"(accy[0]));
+        const unsigned long long t4 = now();
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float v[4];
@@ -372,7 +388,19 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
                 for (int e = 0; e < 4; ++e)
                     if (pp + e < npix) orow[pp + e] = v[e];
         }
+        const unsigned long long t5 = now();
         __syncthreads();                   // every wave is past its MFMA reads before the next pass rewrites the input planes
+        if constexpr (STAMP) {
+            const unsigned long long t6 = now();
+            st[0] += t1 - t0; st[1] += t2 - t1; st[2] += t3 - t2; st[3] += t4 - t3; st[4] += t5 - t4; st[5] += t6 - t5;
+        }
+    };
+    auto leave = [&]() {
+        if constexpr (STAMP) {
+            st[6] = now() - t_begin;
+            if ((wave == 0 || wave == 7) && lane == 0 && blockIdx.x < 1024 && blockIdx.y == 0)
+                for (int i = 0; i < 8; ++i) g_conv_stamps[(blockIdx.x * 2 + (wave ? 1 : 0)) * 8 + i] = st[i];
+        }
     };
     if (gridDim.y > 1) {                   // few images (act() on one frame): one pass per workgroup, gridDim.y = npass workgroups per image
         if ((int)blockIdx.y < npass) body((int)blockIdx.y, std::false_type{});
@@ -380,8 +408,297 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
     }
     for (int pass = 0; pass + 1 < npass; ++pass) body(pass, std::true_type{});
     body(npass - 1, std::false_type{});
+    leave();
 }
 
+// ---- the same implicit GEMM with the waves specialised (round 3) ------------------------------------------------------------------------
+// Stamps of the kernel above (tools/micro/conv_stamp_bench.py, profiles/r03_conv_phase_stamps.txt): inside its MFMA loop the matrix pipe is
+// at its issue floor, but the loop is 41-45 % of the kernel — conversion + LDS writes (15 %), issuing the next strip's loads (13-15 %), stores and
+// the two barriers run with the pipe idle, because all eight waves walk the phases together and one workgroup owns the CU. Here waves 0-3
+// (one per SIMD) only multiply — a pass is 128 pixels, 32 per wave — and waves 4-7 (their SIMD mates) only stage: the input rows live in a
+// CIRCULAR buffer of rb full-width rows (slot = row mod rb), so while pass t is on the matrix cores the producers convert the rows pass t + 1
+// adds (<= CW_PI * 16 / (ow + 2) rows, fetched into registers one pass earlier) into the slots pass t - 1 has left; one barrier per pass.
+// Every input row is staged exactly once (the strip kernel restaged the 3-row halo: 10 rows per 6.6 rows of output). The consumers are alone
+// on their SIMD's matrix pipe, so they keep the next k-step's fragments in flight under the current step's MFMAs (explicit double buffer).
+constexpr int CW_PASS = 128;               // output pixels per pass
+constexpr int CW_PI = 12;                  // staged positions per producer thread and batch: 16 lanes x 12 = 192 positions of one channel pair
+template <int NPL, bool MASK, bool STAMP = false>
+__global__ __launch_bounds__(CM_THREADS) void conv3x3_ws_kernel(const float* __restrict__ in, const float* __restrict__ Wt,
+                                                                const float* __restrict__ bias, const float* __restrict__ mask,
+                                                                float* __restrict__ out, int ih, int iw, int oh, int ow, int pad, int relu,
+                                                                int plane_elems, int rb, int flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cm_lds[];
+    constexpr bool X3 = NPL >= 2, X6 = NPL == 3;
+    unsigned short* xh = reinterpret_cast<unsigned short*>(cm_lds);                       // [rb][ow + 2][CM_PIX] hi plane, rows by slot
+    unsigned short* xl = xh + plane_elems;
+    unsigned short* xt = xl + plane_elems;
+    cbf16x8* wh = reinterpret_cast<cbf16x8*>(xh + NPL * plane_elems);                     // [18 k-steps][64 lanes] B fragments
+    cbf16x8* wl = wh + 18 * 64;
+    cbf16x8* wt = wl + 18 * 64;
+    const int n = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool producer = (flags & 2) ? wave < 4 : wave >= 4;                              // wave-uniform role
+    const int cw = wave & 3;                                                               // consumer index: pixels 32 cw .. of a pass
+    if (producer && (flags & 1)) __builtin_amdgcn_s_setprio(1);
+    const int kg = lane >> 5, col = lane & 31;
+    const float* inn = in + (int64_t)n * CONV_CO * ih * iw;
+    {
+        const uint4* fr = reinterpret_cast<const uint4*>(Wt);
+        uint4* dst = reinterpret_cast<uint4*>(wh);
+        for (int i = tid; i < NPL * CM_FRAG; i += CM_THREADS) dst[i] = fr[i];
+    }
+    const int npix = oh * ow, npass = (npix + CW_PASS - 1) / CW_PASS, sw = ow + 2;
+    const int t0 = gridDim.y > 1 ? (int)blockIdx.y : 0, t1 = gridDim.y > 1 ? (t0 + 1 < npass ? t0 + 1 : npass) : npass;
+    if (t0 >= npass) return;
+    auto end_row = [&](int pass) {             // one past the last strip row pass touches (strip row y = input row y - pad)
+        const int p1 = (pass * CW_PASS + CW_PASS < npix ? pass * CW_PASS + CW_PASS : npix) - 1;
+        return p1 / ow + 3;
+    };
+    const int chunk = (16 * CW_PI) / sw;       // rows a batch can hold (host-checked against the most rows a pass adds)
+    // ---- producers: (channel pair, 16-lane slice) per thread; positions j = jl + 16 u of rows [ya, yb) in row-major order ------------------
+    // Everything about an item that does not depend on the batch is computed once: its byte offset inside the image (row relative to the
+    // batch's first row), its byte offset inside the ring (likewise), its row inside the batch (4 bits each) and whether its column is padding.
+    // A batch then costs one add per item for the two loads (raw buffer loads: the descriptor's range check answers 0, without a fault, for the
+    // few addresses that fall in front of or behind the tensor — first rows of image 0 under padding, tail items of the last image) and, at
+    // commit, an add, an unsigned wrap (sub + min), a select for tail items (they go to a per-thread dummy word behind the ring), the
+    // conversions and the stores — no branch, no division, no 64-bit address arithmetic (they made a batch ~540 instructions; it is ~200).
+    const int ptid = tid & 255, cp = ptid >> 4, jl = ptid & 15;
+    const int plane_b = ih * iw * 4;                                        // bytes of one channel of one image
+    const unsigned total_b = (unsigned)gridDim.x * CONV_CO * plane_b;       // host-checked < 2^31
+    const auto src0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)(total_b - plane_b), 0x00020000);               // even channel of the pair
+    const auto src1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in) + ih * iw, 0, (int)(total_b - plane_b), 0x00020000);     // odd channel: base one plane on
+    const int ring_b = rb * sw * CM_PIX * 2;                                // bytes of the ring inside a plane; the dummy words follow it
+    const int toff = ring_b + 4 * ptid;
+    typedef float cf32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 cbf16x2 __attribute__((ext_vector_type(2)));
+    int goff[CW_PI], loff[CW_PI];
+    unsigned ypk0 = 0, ypk1 = 0, xmask = 0;
+    {
+        int yy = 0, xx = jl;                   // sw >= 16 (host-checked): one carry per step of 16
+#pragma unroll
+        for (int u = 0; u < CW_PI; ++u) {
+            goff[u] = ((2 * cp * ih + yy) * iw + xx) * 4;
+            loff[u] = ((yy * sw + xx) * CM_PIX + 2 * cp) * 2;
+            if (u < 8) ypk0 |= (unsigned)yy << (4 * u);
+            else ypk1 |= (unsigned)yy << (4 * (u - 8));
+            xmask |= ((unsigned)(xx - pad) < (unsigned)iw ? 1u : 0u) << u;
+            xx += 16;
+            if (xx >= sw) { xx -= sw; ++yy; }
+        }
+    }
+    float ra0[CW_PI], ra1[CW_PI], rb0[CW_PI], rb1[CW_PI];       // two batches in flight: a row batch is fetched two passes before it is committed
+    // The loaded values are NOT touched in fetch: anything that consumes a load result makes the compiler wait for it on the spot, which
+    // put the whole memory latency into the "issue" phase (2-4 k cycles per pass in the stamps, here and in the strip kernel).
+    auto fetch = [&](int ya, float (&v0)[CW_PI], float (&v1)[CW_PI]) {
+        const int boff = ((n * CONV_CO * ih + ya - pad) * iw - pad) * 4;   // image, first row of the batch, padding; may be negative (wraps out of range)
+#pragma unroll
+        for (int u = 0; u < CW_PI; ++u) {
+            const int vo = goff[u] + boff;
+            v0[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src0, vo, 0, 0));
+            v1[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src1, vo, 0, 0));
+        }
+    };
+    auto commit = [&](int ya, int yb, const float (&v0)[CW_PI], const float (&v1)[CW_PI]) {
+        const int nrows = yb - ya, nvalid = (nrows * sw - jl + 15) >> 4;      // items u < nvalid lie inside the batch
+        const int lbase = (ya % rb) * sw * CM_PIX * 2;
+        unsigned okm = ~0u;                                                  // bit u: the item is a pixel of the map, not padding
+        if (pad) {                                                           // (dgrad launches) padding columns, and rows outside the map
+            unsigned rowin = 0;
+            for (int k = 0; k < nrows; ++k) rowin |= ((unsigned)(ya + k - pad) < (unsigned)ih ? 1u : 0u) << k;
+            okm = 0;
+#pragma unroll
+            for (int u = 0; u < CW_PI; ++u) {
+                const unsigned y = ((u < 8 ? ypk0 >> (4 * u) : ypk1 >> (4 * (u - 8))) & 15u);
+                okm |= ((rowin >> y) & 1u) << u;
+            }
+            okm &= xmask;
+        }
+#pragma unroll
+        for (int u = 0; u < CW_PI; ++u) {
+            unsigned o = (unsigned)(loff[u] + lbase);
+            const unsigned ow_ = o - (unsigned)ring_b;
+            o = o < ow_ ? o : ow_;                                           // slot wrap: o >= ring_b  ->  o - ring_b
+            o = u < nvalid ? o : (unsigned)toff;
+            cf32x2 v = {v0[u], v1[u]};
+            if (pad) { const bool ok = (okm >> u) & 1u; v[0] = ok ? v[0] : 0.f; v[1] = ok ? v[1] : 0.f; }
+            const cbf16x2 h = __builtin_convertvector(v, cbf16x2);
+            *reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(xh) + o) = __builtin_bit_cast(unsigned int, h);
+            if constexpr (X3) {
+                const cf32x2 r1 = v - __builtin_convertvector(h, cf32x2);
+                const cbf16x2 l = __builtin_convertvector(r1, cbf16x2);
+                *reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(xl) + o) = __builtin_bit_cast(unsigned int, l);
+                if constexpr (X6) {
+                    const cbf16x2 t = __builtin_convertvector(r1 - __builtin_convertvector(l, cf32x2), cbf16x2);
+                    *reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(xt) + o) = __builtin_bit_cast(unsigned int, t);
+                }
+            }
+        }
+    };
+    // ---- consumers: wave w multiplies pixels p0 + 32 w .. + 31 of the pass ---------------------------------------------------------------
+    const float bv = bias ? bias[col] : 0.f;
+    auto consume = [&](int pass, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int p0 = pass * CW_PASS;
+        const int pq = p0 + 32 * cw + 4 * kg;
+        float* orow = out + ((int64_t)n * CONV_CO + col) * npix;
+        float4 mq[4];
+        if constexpr (MASK) {
+            const float* mrow = mask + ((int64_t)n * CONV_CO + col) * npix;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int pp = pq + 8 * q;
+                if (FULL || pp + 3 < npix) mq[q] = *reinterpret_cast<const float4*>(mrow + pp);
+                else {
+                    mq[q].x = pp < npix ? mrow[pp] : 1.f; mq[q].y = pp + 1 < npix ? mrow[pp + 1] : 1.f;
+                    mq[q].z = pp + 2 < npix ? mrow[pp + 2] : 1.f; mq[q].w = 1.f;
+                }
+            }
+        }
+        int pa = p0 + 32 * cw + col;                                          // tail lanes recompute the last pixel
+        pa = pa < npix ? pa : npix - 1;
+        const int r = pa / ow, x = pa - r * ow;
+        int sl[3];
+        sl[0] = r % rb;
+        sl[1] = sl[0] + 1 >= rb ? sl[0] + 1 - rb : sl[0] + 1;
+        sl[2] = sl[1] + 1 >= rb ? sl[1] + 1 - rb : sl[1] + 1;
+        int ab[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) ab[d] = (sl[d] * sw + x) * CM_PIX + 8 * kg;
+        cf32x16 acc, accx, accy;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc[i] = 0.f; accx[i] = 0.f; accy[i] = 0.f; }
+        cbf16x8 fa[2][3], fb[2][3];
+        auto ld = [&](int s, int b) {
+            const int o = ab[(s >> 1) / 3] + ((s >> 1) % 3) * CM_PIX + (s & 1) * 16;
+            fa[b][0] = *reinterpret_cast<const cbf16x8*>(xh + o);
+            fb[b][0] = wh[s * 64 + lane];
+            if constexpr (X3) {
+                fa[b][1] = *reinterpret_cast<const cbf16x8*>(xl + o);
+                fb[b][1] = wl[s * 64 + lane];
+            }
+            if constexpr (X6) {
+                fa[b][2] = *reinterpret_cast<const cbf16x8*>(xt + o);
+                fb[b][2] = wt[s * 64 + lane];
+            }
+        };
+        ld(0, 0);
+#pragma unroll
+        for (int s = 0; s < 18; ++s) {
+            const int b = s & 1;
+            if (s + 1 < 18) ld(s + 1, b ^ 1);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][0], fb[b][0], acc, 0, 0, 0);
+            if constexpr (X3) accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][0], fb[b][1], accx, 0, 0, 0);
+            if constexpr (X6) accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][0], fb[b][2], accy, 0, 0, 0);
+            if constexpr (X3) accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][1], fb[b][0], accx, 0, 0, 0);
+            if constexpr (X6) {
+                accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][2], fb[b][0], accy, 0, 0, 0);
+                accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][1], fb[b][1], accy, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);          // keep the reads one step ahead, not eighteen (the scheduler hoisted them all and spilled)
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = (X6 ? (accy[4 * q + e] + accx[4 * q + e]) + acc[4 * q + e] : X3 ? accx[4 * q + e] + acc[4 * q + e] : acc[4 * q + e]) + bv;
+                if (relu) v[e] = fmaxf(v[e], 0.f);
+            }
+            if constexpr (MASK) {
+                v[0] = mq[q].x > 0.f ? v[0] : 0.f; v[1] = mq[q].y > 0.f ? v[1] : 0.f;
+                v[2] = mq[q].z > 0.f ? v[2] : 0.f; v[3] = mq[q].w > 0.f ? v[3] : 0.f;
+            }
+            const int pp = pq + 8 * q;
+            if (FULL || pp + 3 < npix) *reinterpret_cast<float4*>(orow + pp) = make_float4(v[0], v[1], v[2], v[3]);
+            else
+                for (int e = 0; e < 4; ++e)
+                    if (pp + e < npix) orow[pp + e] = v[e];
+        }
+    };
+    // STAMP (diagnostic, tuning bit 8192): wave 0 (consumer) {MFMA pass incl. stores issued, barrier wait, -, -, -, -, whole kernel, prologue} and
+    // wave 4 (producer) {commit, fetch issue, barrier wait, ...} into g_conv_stamps, summed over the passes
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto now = [&]() -> unsigned long long {
+        if constexpr (STAMP) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return __builtin_amdgcn_s_memtime(); }
+        return 0ull;
+    };
+    const unsigned long long t_begin = now();
+    // Prologue: the rows of pass t0 (<= two batches, both fetched before either is converted), then the batches of passes t0 + 1 and t0 + 2
+    // go in flight. Loop: while the consumers multiply pass t, the producers commit the rows pass t + 1 adds — fetched two passes ago, into the
+    // slots pass t - 1 released at the last barrier — and fetch those of pass t + 3 into the registers just emptied: a batch has two passes
+    // to arrive (with one, every commit waited out the whole memory latency and the producers set the pace: 6-7 k cycles per pass against
+    // the consumers' 1.7-3.5 k).
+    // The two roles run SEPARATE loops with the same number of barriers (one after the prologue, one per pass). In one shared loop the
+    // compiler's wait-count analysis merges the roles at the loop head: the consumers then wait out their own stores (vmcnt(0)) in front of
+    // every pass because their registers alias the producers' pending loads, and the producers cannot tell which of their two batches is the
+    // older one. The producer loop is unrolled by two for the same reason: batch A is always the older one at its commit, then batch B.
+    if (producer) {
+        const int ya = (t0 * CW_PASS) / ow, need = end_row(t0);
+        const int ym = ya + chunk < need ? ya + chunk : need, yn = ym + chunk < need ? ym + chunk : need;
+        fetch(ya, ra0, ra1);
+        if (ym < need) fetch(ym, rb0, rb1);
+        commit(ya, ym, ra0, ra1);
+        if (ym < need) commit(ym, yn, rb0, rb1);
+        for (int y = yn; y < need; y += chunk) {                  // maps so narrow that a pass spans more than two batches
+            fetch(y, ra0, ra1);
+            commit(y, y + chunk < need ? y + chunk : need, ra0, ra1);
+        }
+        // From here on every fetch and commit is unconditional: past the last pass a batch has no rows (end_row stops growing), its loads fall
+        // on the next image or out of the descriptor's range (answered with 0) and its stores on the dummy words. With conditions, the
+        // paths that skip a fetch made the compiler treat the batch being committed as the youngest one in flight — vmcnt(23..0) instead of
+        // vmcnt(47..24): every commit drained the batch fetched just before the barrier.
+        fetch(end_row(t0), ra0, ra1);
+        fetch(end_row(t0 + 1), rb0, rb1);
+        __syncthreads();
+        st[7] = now() - t_begin;
+        int t = t0;
+        for (; t + 1 < t1; t += 2) {
+            const unsigned long long ta = now();
+            commit(end_row(t), end_row(t + 1), ra0, ra1);          // the rows pass t + 1 adds, into slots pass t - 1 released at the last barrier
+            const unsigned long long tb = now();
+            fetch(end_row(t + 2), ra0, ra1);
+            const unsigned long long tc = now();
+            __syncthreads();
+            const unsigned long long td = now();
+            commit(end_row(t + 1), end_row(t + 2), rb0, rb1);
+            fetch(end_row(t + 3), rb0, rb1);
+            const unsigned long long te = now();
+            __syncthreads();
+            if constexpr (STAMP) { st[0] += tb - ta; st[1] += tc - tb; st[2] += td - tc; st[3] += te - td; st[4] += now() - te; }
+        }
+        if (t < t1) __syncthreads();                               // the last pass of an odd count: nothing left to stage
+    } else {
+        __syncthreads();
+        st[7] = now() - t_begin;
+        for (int t = t0; t < t1; ++t) {
+            const unsigned long long ta = now();
+            if (t + 1 < npass) consume(t, std::true_type{});
+            else consume(t, std::false_type{});
+            const unsigned long long tc = now();
+            __syncthreads();
+            if constexpr (STAMP) { st[0] += tc - ta; st[1] += now() - tc; }
+        }
+    }
+    if constexpr (STAMP) {
+        st[6] = now() - t_begin;
+        if ((wave == 0 || wave == 4) && lane == 0 && blockIdx.x < 1024 && blockIdx.y == 0)
+            for (int i = 0; i < 8; ++i) g_conv_stamps[(blockIdx.x * 2 + (producer ? 1 : 0)) * 8 + i] = st[i];
+    }
+}
+
+// wave-specialised kernel: rows of the circular buffer = the rows two consecutive passes span; its budgets
+static int conv3x3_ws_rows(int ow) { return (2 * CW_PASS + ow - 2) / ow + 1 + 2; }
+static bool conv3x3_ws_fits(int oh, int ow, int npl) {
+    const int sw = ow + 2, npix = oh * ow;
+    if (sw > CM_MAXW || sw < 16 || npix < 1) return false;
+    const int chunk = (16 * CW_PI) / sw, npass = (npix + CW_PASS - 1) / CW_PASS;
+    auto end_row = [&](int pass) { return ((pass * CW_PASS + CW_PASS < npix ? pass * CW_PASS + CW_PASS : npix) - 1) / ow + 3; };
+    for (int t = 0; t + 1 < npass; ++t)
+        if (end_row(t + 1) - end_row(t) > chunk) return false;                    // a pass adds more rows than one producer batch holds
+    if (chunk < 1) return false;
+    const size_t lds = (size_t)npl * round_up((int64_t)conv3x3_ws_rows(ow) * sw * CM_PIX + 512, 8) * sizeof(unsigned short) + (size_t)npl * 18 * 64 * 16;
+    return lds <= 160 * 1024 && chunk <= 15;
+}
 // true when the strip of a 256-pixel pass fits the kernel's fixed budgets
 static bool conv3x3_mfma_fits(int oh, int ow, int prec = EXORL_PREC_BF16X3) {
     const int rows = (CM_PASS + ow - 2) / ow + 1 + 2;         // most output rows 256 consecutive pixels can touch, + 2
@@ -406,9 +723,57 @@ static int conv3x3_mfma(const float* in, const float* Wt, const float* bias, con
         EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
+    if (!(tune_variant() & 1073741824) && conv3x3_ws_fits(oh, ow, npl) && (int64_t)n * CONV_CO * ih * iw * 4 < (1ll << 31)) {      // bit 1073741824: the strip kernel (A/B); 32-bit buffer offsets
+        const int rb = conv3x3_ws_rows(ow);
+        const int wplane = (int)round_up((int64_t)rb * (ow + 2) * CM_PIX + 512, 8);          // ring + 256 dummy words (tail items of a batch)
+        const size_t wlds = (size_t)npl * wplane * sizeof(unsigned short) + (size_t)npl * 18 * 64 * 16;
+        static bool wattr = false;
+        if (!wattr) {
+            EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            wattr = true;
+        }
+        const int wpass = (oh * ow + CW_PASS - 1) / CW_PASS, wgy = n <= 8 ? wpass : 1;
+        const int wflags = ((tune_variant() & 16) ? 1 : 0) | ((tune_variant() & 32) ? 2 : 0);      // experiments: producers at s_setprio 1 | roles swapped
+#define EXORL_CW(NN, MM) hipLaunchKernelGGL((conv3x3_ws_kernel<NN, MM>), dim3(n, wgy), dim3(CM_THREADS), wlds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu, wplane, rb, wflags)
+        if ((tune_variant() & 8192) && !mask && npl >= 2) {          // diagnostic: the stamped build
+            static bool sattr = false;
+            if (!sattr) {
+                EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                sattr = true;
+            }
+            if (npl == 3) hipLaunchKernelGGL((conv3x3_ws_kernel<3, false, true>), dim3(n, wgy), dim3(CM_THREADS), wlds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu, wplane, rb, wflags);
+            else hipLaunchKernelGGL((conv3x3_ws_kernel<2, false, true>), dim3(n, wgy), dim3(CM_THREADS), wlds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu, wplane, rb, wflags);
+            EXORL_LAUNCH_CHECK();
+            return 0;
+        }
+        if (npl == 3)      { if (mask) EXORL_CW(3, true); else EXORL_CW(3, false); }
+        else if (npl == 2) { if (mask) EXORL_CW(2, true); else EXORL_CW(2, false); }
+        else               { if (mask) EXORL_CW(1, true); else EXORL_CW(1, false); }
+#undef EXORL_CW
+        EXORL_LAUNCH_CHECK();
+        return 0;
+    }
     // a handful of images (act(): one) cannot fill the chip with one workgroup each: spread an image's 256-pixel passes over workgroups
     const int npass = (oh * ow + CM_PASS - 1) / CM_PASS, gy = n <= 8 ? npass : 1;
 #define EXORL_CM(NN, MM) hipLaunchKernelGGL((conv3x3_mfma_kernel<NN, MM>), dim3(n, gy), dim3(CM_THREADS), lds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu, plane)
+    if ((tune_variant() & 8192) && !mask && npl >= 2) {          // diagnostic: the stamped build of the forward kernel
+        static bool sattr = false;
+        if (!sattr) {
+            EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            sattr = true;
+        }
+        if (npl == 3) hipLaunchKernelGGL((conv3x3_mfma_kernel<3, false, true>), dim3(n, gy), dim3(CM_THREADS), lds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu, plane);
+        else hipLaunchKernelGGL((conv3x3_mfma_kernel<2, false, true>), dim3(n, gy), dim3(CM_THREADS), lds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu, plane);
+        EXORL_LAUNCH_CHECK();
+        return 0;
+    }
     if (npl == 3)      { if (mask) EXORL_CM(3, true); else EXORL_CM(3, false); }
     else if (npl == 2) { if (mask) EXORL_CM(2, true); else EXORL_CM(2, false); }
     else               { if (mask) EXORL_CM(1, true); else EXORL_CM(1, false); }
@@ -865,6 +1230,12 @@ int exorl_aug_shift(const unsigned char* x_dev, int32_t n, int32_t c, int32_t h,
 
 __global__ __launch_bounds__(256) void u8_to_f32_kernel(const unsigned char* __restrict__ x, float* __restrict__ out, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (float)x[i];
+}
+int exorl_debug_conv_stamps(uint64_t* out_host, int32_t n_words) {
+    EXORL_REQUIRE(out_host && n_words > 0 && n_words <= 1024 * 2 * 8, "debug_conv_stamps: bad arguments");
+    EXORL_CHECK_HIP(hipDeviceSynchronize());
+    EXORL_CHECK_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(exorl::g_conv_stamps), (size_t)n_words * sizeof(uint64_t)));
+    return 0;
 }
 int exorl_u8_to_f32(const unsigned char* x_dev, int64_t n, float* out_dev, void* stream) {
     EXORL_REQUIRE(x_dev && out_dev && n > 0, "u8_to_f32: bad arguments");

@@ -290,6 +290,10 @@ int exorl_debug_precision_override(int32_t mask);
 /* Diagnostic (tools/micro/stamp_bench.py; tuning bit 33554432 selects the stamped build of the forward H x H GEMM): per workgroup
  * {s_memtime x 4, s_memrealtime x 4} at entry / first k-step / last k-step / stores drained; 8 words per workgroup, <= 1024 workgroups. */
 int exorl_debug_gemm_stamps(uint64_t* out_host, int32_t n_words);
+/* Diagnostic (tools/micro/conv_stamp_bench.py; tuning bit 8192 selects the stamped build of the 32 -> 32 forward convolution): per
+ * workgroup (= image) and for waves 0 and 7, shader-clock cycles summed over the image's passes: {convert + LDS write, barrier, fetch
+ * issue, MFMA loop incl. its LDS reads, stores, barrier, whole kernel, 0}; 16 words per workgroup, <= 1024 workgroups. */
+int exorl_debug_conv_stamps(uint64_t* out_host, int32_t n_words);
 /* Measurement hook (bench.py roofline leg): time every GEMM launch with HIP events on its own stream. */
 int exorl_profile_gemm(int32_t enable);
 int exorl_profile_gemm_read(double* flops_out_host, float* ms_out_host, int32_t cap, int32_t* n_out);
