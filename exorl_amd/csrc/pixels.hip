@@ -384,9 +384,11 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
             }
             const int pp = pq + 8 * q;
             if (FULL || pp + 3 < npix) *reinterpret_cast<float4*>(orow + pp) = make_float4(v[0], v[1], v[2], v[3]);
-            else
+            else {
+#pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (pp + e < npix) orow[pp + e] = v[e];
+            }
         }
         const unsigned long long t5 = now();
         __syncthreads();                   // every wave is past its MFMA reads before the next pass rewrites the input planes
@@ -421,96 +423,96 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_mfma_kernel(const float* _
 // Every input row is staged exactly once (the strip kernel restaged the 3-row halo: 10 rows per 6.6 rows of output). The consumers are alone
 // on their SIMD's matrix pipe, so they keep the next k-step's fragments in flight under the current step's MFMAs (explicit double buffer).
 constexpr int CW_PASS = 128;               // output pixels per pass
-constexpr int CW_PI = 12;                  // staged positions per producer thread and batch: 16 lanes x 12 = 192 positions of one channel pair
-template <int NPL, bool MASK, bool STAMP = false>
+constexpr int CW_PI = 6;                   // staged positions per producer thread and batch: 32 lanes x 6 = 192 positions of one channel quad
+// bytes per staged position: the NPL planes of a pixel sit side by side (32 channels x 2 B = 64 B each, 80 B apart), so that a producer's
+// stores and a consumer's fragment reads reach all planes from ONE address register with immediate offsets; the stride keeps the 16 lanes of
+// a ds_read_b128 group on distinct banks (240 B = 60 dwords and 176 B = 44 dwords: both step through all multiples of 4 mod 64)
+__host__ __device__ constexpr int cw_pixb(int npl) { return npl == 3 ? 240 : npl == 2 ? 176 : 80; }
+constexpr int CW_DUMMY = 256 * 8 + 176;    // a dummy 8-byte word per producer thread, reached with the same plane offsets (+ 80, + 160) as a real position
+template <int NPL, bool MASK, bool STAMP = false>           // MASK = the dgrad launches: ReLU mask of the layer below AND zero padding (pad = 2)
 __global__ __launch_bounds__(CM_THREADS) void conv3x3_ws_kernel(const float* __restrict__ in, const float* __restrict__ Wt,
                                                                 const float* __restrict__ bias, const float* __restrict__ mask,
                                                                 float* __restrict__ out, int ih, int iw, int oh, int ow, int pad, int relu,
-                                                                int plane_elems, int rb, int flags) {
+                                                                int rb, int flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cm_lds[];
     constexpr bool X3 = NPL >= 2, X6 = NPL == 3;
-    unsigned short* xh = reinterpret_cast<unsigned short*>(cm_lds);                       // [rb][ow + 2][CM_PIX] hi plane, rows by slot
-    unsigned short* xl = xh + plane_elems;
-    unsigned short* xt = xl + plane_elems;
-    cbf16x8* wh = reinterpret_cast<cbf16x8*>(xh + NPL * plane_elems);                     // [18 k-steps][64 lanes] B fragments
-    cbf16x8* wl = wh + 18 * 64;
-    cbf16x8* wt = wl + 18 * 64;
+    constexpr int PIXB = cw_pixb(NPL);
+    const int npix = oh * ow, npass = (npix + CW_PASS - 1) / CW_PASS, sw = ow + 2;
+    const int ring_b = rb * sw * PIXB;                                                     // the ring: [rb rows by slot][ow + 2][PIXB]
+    unsigned char* ring = cm_lds;                                                          // then CW_DUMMY bytes for the tail items of a batch
+    cbf16x8* wh = reinterpret_cast<cbf16x8*>(cm_lds + ((ring_b + CW_DUMMY + 15) & ~15));   // [NPL][18 k-steps][64 lanes] B fragments
     const int n = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool producer = (flags & 2) ? wave < 4 : wave >= 4;                              // wave-uniform role
+    const bool producer = (flags & 2) ? wave >= 4 : wave < 4;                              // wave-uniform role; the older half stages (measured)
     const int cw = wave & 3;                                                               // consumer index: pixels 32 cw .. of a pass
-    if (producer && (flags & 1)) __builtin_amdgcn_s_setprio(1);
     const int kg = lane >> 5, col = lane & 31;
-    const float* inn = in + (int64_t)n * CONV_CO * ih * iw;
     {
         const uint4* fr = reinterpret_cast<const uint4*>(Wt);
         uint4* dst = reinterpret_cast<uint4*>(wh);
         for (int i = tid; i < NPL * CM_FRAG; i += CM_THREADS) dst[i] = fr[i];
     }
-    const int npix = oh * ow, npass = (npix + CW_PASS - 1) / CW_PASS, sw = ow + 2;
     const int t0 = gridDim.y > 1 ? (int)blockIdx.y : 0, t1 = gridDim.y > 1 ? (t0 + 1 < npass ? t0 + 1 : npass) : npass;
     if (t0 >= npass) return;
     auto end_row = [&](int pass) {             // one past the last strip row pass touches (strip row y = input row y - pad)
         const int p1 = (pass * CW_PASS + CW_PASS < npix ? pass * CW_PASS + CW_PASS : npix) - 1;
         return p1 / ow + 3;
     };
-    const int chunk = (16 * CW_PI) / sw;       // rows a batch can hold (host-checked against the most rows a pass adds)
-    // ---- producers: (channel pair, 16-lane slice) per thread; positions j = jl + 16 u of rows [ya, yb) in row-major order ------------------
+    const int chunk = (32 * CW_PI) / sw;       // rows a batch can hold (host-checked against the most rows a pass adds)
+    // ---- producers: (channel quad, 32-lane slice) per thread; positions j = jl + 32 u of rows [ya, yb) in row-major order -------------------
     // Everything about an item that does not depend on the batch is computed once: its byte offset inside the image (row relative to the
     // batch's first row), its byte offset inside the ring (likewise), its row inside the batch (4 bits each) and whether its column is padding.
-    // A batch then costs one add per item for the two loads (raw buffer loads: the descriptor's range check answers 0, without a fault, for the
-    // few addresses that fall in front of or behind the tensor — first rows of image 0 under padding, tail items of the last image) and, at
-    // commit, an add, an unsigned wrap (sub + min), a select for tail items (they go to a per-thread dummy word behind the ring), the
-    // conversions and the stores — no branch, no division, no 64-bit address arithmetic (they made a batch ~540 instructions; it is ~200).
-    const int ptid = tid & 255, cp = ptid >> 4, jl = ptid & 15;
+    // A batch then costs one add per item for its four loads (raw buffer loads through one descriptor per channel of the quad: the range check
+    // answers 0, without a fault, for the few addresses in front of or behind the tensor — first rows of image 0 under padding, tail items of
+    // the last image) and, at commit, an add, an unsigned wrap (sub + min), a select for tail items (they go to a per-thread dummy behind
+    // the ring), the conversions and one 8-byte store per plane — no branch, no division, no 64-bit address arithmetic.
+    const int ptid = tid & 255, cq = ptid >> 5, jl = ptid & 31;
     const int plane_b = ih * iw * 4;                                        // bytes of one channel of one image
     const unsigned total_b = (unsigned)gridDim.x * CONV_CO * plane_b;       // host-checked < 2^31
-    const auto src0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)(total_b - plane_b), 0x00020000);               // even channel of the pair
-    const auto src1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in) + ih * iw, 0, (int)(total_b - plane_b), 0x00020000);     // odd channel: base one plane on
-    const int ring_b = rb * sw * CM_PIX * 2;                                // bytes of the ring inside a plane; the dummy words follow it
-    const int toff = ring_b + 4 * ptid;
+    float* inq = const_cast<float*>(in);
+    const auto src0 = __builtin_amdgcn_make_buffer_rsrc(inq, 0, (int)(total_b - 3 * plane_b), 0x00020000);
+    const auto src1 = __builtin_amdgcn_make_buffer_rsrc(inq + ih * iw, 0, (int)(total_b - 3 * plane_b), 0x00020000);      // channel + 1: base one plane on
+    const auto src2 = __builtin_amdgcn_make_buffer_rsrc(inq + 2 * ih * iw, 0, (int)(total_b - 3 * plane_b), 0x00020000);
+    const auto src3 = __builtin_amdgcn_make_buffer_rsrc(inq + 3 * ih * iw, 0, (int)(total_b - 3 * plane_b), 0x00020000);
+    const int toff = ring_b + 8 * ptid;
     typedef float cf32x2 __attribute__((ext_vector_type(2)));
     typedef __bf16 cbf16x2 __attribute__((ext_vector_type(2)));
     int goff[CW_PI], loff[CW_PI];
-    unsigned ypk0 = 0, ypk1 = 0, xmask = 0;
-    {
-        int yy = 0, xx = jl;                   // sw >= 16 (host-checked): one carry per step of 16
+    unsigned ypk = 0, xmask = 0;
 #pragma unroll
-        for (int u = 0; u < CW_PI; ++u) {
-            goff[u] = ((2 * cp * ih + yy) * iw + xx) * 4;
-            loff[u] = ((yy * sw + xx) * CM_PIX + 2 * cp) * 2;
-            if (u < 8) ypk0 |= (unsigned)yy << (4 * u);
-            else ypk1 |= (unsigned)yy << (4 * (u - 8));
-            xmask |= ((unsigned)(xx - pad) < (unsigned)iw ? 1u : 0u) << u;
-            xx += 16;
-            if (xx >= sw) { xx -= sw; ++yy; }
-        }
+    for (int u = 0; u < CW_PI; ++u) {
+        const int j = jl + 32 * u, yy = j / sw, xx = j - yy * sw;
+        goff[u] = ((4 * cq * ih + yy) * iw + xx) * 4;
+        loff[u] = (yy * sw + xx) * PIXB + 8 * cq;
+        ypk |= (unsigned)yy << (4 * u);
+        xmask |= ((unsigned)(xx - pad) < (unsigned)iw ? 1u : 0u) << u;
     }
-    float ra0[CW_PI], ra1[CW_PI], rb0[CW_PI], rb1[CW_PI];       // two batches in flight: a row batch is fetched two passes before it is committed
+    typedef float Item[CW_PI];                                                // one channel of the quad for the items of a batch
+    Item qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;                              // two batches in flight: fetched two passes before they are committed
+#define QA qa0, qa1, qa2, qa3
+#define QB qb0, qb1, qb2, qb3
     // The loaded values are NOT touched in fetch: anything that consumes a load result makes the compiler wait for it on the spot, which
     // put the whole memory latency into the "issue" phase (2-4 k cycles per pass in the stamps, here and in the strip kernel).
-    auto fetch = [&](int ya, float (&v0)[CW_PI], float (&v1)[CW_PI]) {
+    auto fetch = [&](int ya, Item& q0, Item& q1, Item& q2, Item& q3) {
         const int boff = ((n * CONV_CO * ih + ya - pad) * iw - pad) * 4;   // image, first row of the batch, padding; may be negative (wraps out of range)
 #pragma unroll
         for (int u = 0; u < CW_PI; ++u) {
             const int vo = goff[u] + boff;
-            v0[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src0, vo, 0, 0));
-            v1[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src1, vo, 0, 0));
+            q0[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src0, vo, 0, 0));
+            q1[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src1, vo, 0, 0));
+            q2[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src2, vo, 0, 0));
+            q3[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src3, vo, 0, 0));
         }
     };
-    auto commit = [&](int ya, int yb, const float (&v0)[CW_PI], const float (&v1)[CW_PI]) {
-        const int nrows = yb - ya, nvalid = (nrows * sw - jl + 15) >> 4;      // items u < nvalid lie inside the batch
-        const int lbase = (ya % rb) * sw * CM_PIX * 2;
+    auto commit = [&](int ya, int yb, const Item& q0, const Item& q1, const Item& q2, const Item& q3) {
+        const int nrows = yb - ya, nvalid = (nrows * sw - jl + 31) >> 5;      // items u < nvalid lie inside the batch
+        const int lbase = (ya % rb) * sw * PIXB;
         unsigned okm = ~0u;                                                  // bit u: the item is a pixel of the map, not padding
-        if (pad) {                                                           // (dgrad launches) padding columns, and rows outside the map
+        if constexpr (MASK) {                                                // padding columns, and rows outside the map
             unsigned rowin = 0;
             for (int k = 0; k < nrows; ++k) rowin |= ((unsigned)(ya + k - pad) < (unsigned)ih ? 1u : 0u) << k;
             okm = 0;
 #pragma unroll
-            for (int u = 0; u < CW_PI; ++u) {
-                const unsigned y = ((u < 8 ? ypk0 >> (4 * u) : ypk1 >> (4 * (u - 8))) & 15u);
-                okm |= ((rowin >> y) & 1u) << u;
-            }
+            for (int u = 0; u < CW_PI; ++u) okm |= ((rowin >> ((ypk >> (4 * u)) & 15u)) & 1u) << u;
             okm &= xmask;
         }
 #pragma unroll
@@ -519,17 +521,21 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_ws_kernel(const float* __r
             const unsigned ow_ = o - (unsigned)ring_b;
             o = o < ow_ ? o : ow_;                                           // slot wrap: o >= ring_b  ->  o - ring_b
             o = u < nvalid ? o : (unsigned)toff;
-            cf32x2 v = {v0[u], v1[u]};
-            if (pad) { const bool ok = (okm >> u) & 1u; v[0] = ok ? v[0] : 0.f; v[1] = ok ? v[1] : 0.f; }
-            const cbf16x2 h = __builtin_convertvector(v, cbf16x2);
-            *reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(xh) + o) = __builtin_bit_cast(unsigned int, h);
+            cf32x2 v = {q0[u], q1[u]}, w = {q2[u], q3[u]};
+            if constexpr (MASK) {
+                const bool ok = (okm >> u) & 1u;
+                v[0] = ok ? v[0] : 0.f; v[1] = ok ? v[1] : 0.f; w[0] = ok ? w[0] : 0.f; w[1] = ok ? w[1] : 0.f;
+            }
+            const cbf16x2 hv = __builtin_convertvector(v, cbf16x2), hw_ = __builtin_convertvector(w, cbf16x2);
+            *reinterpret_cast<uint2*>(ring + o) = make_uint2(__builtin_bit_cast(unsigned, hv), __builtin_bit_cast(unsigned, hw_));
             if constexpr (X3) {
-                const cf32x2 r1 = v - __builtin_convertvector(h, cf32x2);
-                const cbf16x2 l = __builtin_convertvector(r1, cbf16x2);
-                *reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(xl) + o) = __builtin_bit_cast(unsigned int, l);
+                const cf32x2 rv = v - __builtin_convertvector(hv, cf32x2), rw = w - __builtin_convertvector(hw_, cf32x2);
+                const cbf16x2 lv = __builtin_convertvector(rv, cbf16x2), lw = __builtin_convertvector(rw, cbf16x2);
+                *reinterpret_cast<uint2*>(ring + o + 80) = make_uint2(__builtin_bit_cast(unsigned, lv), __builtin_bit_cast(unsigned, lw));
                 if constexpr (X6) {
-                    const cbf16x2 t = __builtin_convertvector(r1 - __builtin_convertvector(l, cf32x2), cbf16x2);
-                    *reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(xt) + o) = __builtin_bit_cast(unsigned int, t);
+                    const cbf16x2 tv = __builtin_convertvector(rv - __builtin_convertvector(lv, cf32x2), cbf16x2);
+                    const cbf16x2 tw = __builtin_convertvector(rw - __builtin_convertvector(lw, cf32x2), cbf16x2);
+                    *reinterpret_cast<uint2*>(ring + o + 160) = make_uint2(__builtin_bit_cast(unsigned, tv), __builtin_bit_cast(unsigned, tw));
                 }
             }
         }
@@ -554,31 +560,31 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_ws_kernel(const float* __r
                 }
             }
         }
-        int pa = p0 + 32 * cw + col;                                          // tail lanes recompute the last pixel
+        int pa = p0 + 32 * cw + col;                                            // tail lanes recompute the last pixel
         pa = pa < npix ? pa : npix - 1;
         const int r = pa / ow, x = pa - r * ow;
         int sl[3];
         sl[0] = r % rb;
         sl[1] = sl[0] + 1 >= rb ? sl[0] + 1 - rb : sl[0] + 1;
         sl[2] = sl[1] + 1 >= rb ? sl[1] + 1 - rb : sl[1] + 1;
-        int ab[3];
+        const unsigned char* ab[3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) ab[d] = (sl[d] * sw + x) * CM_PIX + 8 * kg;
+        for (int d = 0; d < 3; ++d) ab[d] = ring + (sl[d] * sw + x) * PIXB + 16 * kg;
         cf32x16 acc, accx, accy;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc[i] = 0.f; accx[i] = 0.f; accy[i] = 0.f; }
         cbf16x8 fa[2][3], fb[2][3];
         auto ld = [&](int s, int b) {
-            const int o = ab[(s >> 1) / 3] + ((s >> 1) % 3) * CM_PIX + (s & 1) * 16;
-            fa[b][0] = *reinterpret_cast<const cbf16x8*>(xh + o);
+            const unsigned char* o = ab[(s >> 1) / 3] + ((s >> 1) % 3) * PIXB + (s & 1) * 32;
+            fa[b][0] = *reinterpret_cast<const cbf16x8*>(o);
             fb[b][0] = wh[s * 64 + lane];
             if constexpr (X3) {
-                fa[b][1] = *reinterpret_cast<const cbf16x8*>(xl + o);
-                fb[b][1] = wl[s * 64 + lane];
+                fa[b][1] = *reinterpret_cast<const cbf16x8*>(o + 80);
+                fb[b][1] = wh[(18 + s) * 64 + lane];
             }
             if constexpr (X6) {
-                fa[b][2] = *reinterpret_cast<const cbf16x8*>(xt + o);
-                fb[b][2] = wt[s * 64 + lane];
+                fa[b][2] = *reinterpret_cast<const cbf16x8*>(o + 160);
+                fb[b][2] = wh[(36 + s) * 64 + lane];
             }
         };
         ld(0, 0);
@@ -610,24 +616,21 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_ws_kernel(const float* __r
             }
             const int pp = pq + 8 * q;
             if (FULL || pp + 3 < npix) *reinterpret_cast<float4*>(orow + pp) = make_float4(v[0], v[1], v[2], v[3]);
-            else
+            else {
+#pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (pp + e < npix) orow[pp + e] = v[e];
+            }
         }
     };
-    // STAMP (diagnostic, tuning bit 8192): wave 0 (consumer) {MFMA pass incl. stores issued, barrier wait, -, -, -, -, whole kernel, prologue} and
-    // wave 4 (producer) {commit, fetch issue, barrier wait, ...} into g_conv_stamps, summed over the passes
+    // STAMP (diagnostic, tuning bit 8192): consumer wave 0 {pass work, barrier wait, -, -, -, -, whole kernel, prologue} and the first producer wave
+    // {even passes: commit, fetch issue, barrier; odd passes: commit + fetch, barrier; -, whole kernel, prologue} into g_conv_stamps, summed over the passes
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto now = [&]() -> unsigned long long {
         if constexpr (STAMP) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return __builtin_amdgcn_s_memtime(); }
         return 0ull;
     };
     const unsigned long long t_begin = now();
-    // Prologue: the rows of pass t0 (<= two batches, both fetched before either is converted), then the batches of passes t0 + 1 and t0 + 2
-    // go in flight. Loop: while the consumers multiply pass t, the producers commit the rows pass t + 1 adds — fetched two passes ago, into the
-    // slots pass t - 1 released at the last barrier — and fetch those of pass t + 3 into the registers just emptied: a batch has two passes
-    // to arrive (with one, every commit waited out the whole memory latency and the producers set the pace: 6-7 k cycles per pass against
-    // the consumers' 1.7-3.5 k).
     // The two roles run SEPARATE loops with the same number of barriers (one after the prologue, one per pass). In one shared loop the
     // compiler's wait-count analysis merges the roles at the loop head: the consumers then wait out their own stores (vmcnt(0)) in front of
     // every pass because their registers alias the producers' pending loads, and the producers cannot tell which of their two batches is the
@@ -635,33 +638,34 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_ws_kernel(const float* __r
     if (producer) {
         const int ya = (t0 * CW_PASS) / ow, need = end_row(t0);
         const int ym = ya + chunk < need ? ya + chunk : need, yn = ym + chunk < need ? ym + chunk : need;
-        fetch(ya, ra0, ra1);
-        if (ym < need) fetch(ym, rb0, rb1);
-        commit(ya, ym, ra0, ra1);
-        if (ym < need) commit(ym, yn, rb0, rb1);
+        fetch(ya, QA);
+        if (ym < need) fetch(ym, QB);
+        commit(ya, ym, QA);
+        if (ym < need) commit(ym, yn, QB);
         for (int y = yn; y < need; y += chunk) {                  // maps so narrow that a pass spans more than two batches
-            fetch(y, ra0, ra1);
-            commit(y, y + chunk < need ? y + chunk : need, ra0, ra1);
+            fetch(y, QA);
+            commit(y, y + chunk < need ? y + chunk : need, QA);
         }
         // From here on every fetch and commit is unconditional: past the last pass a batch has no rows (end_row stops growing), its loads fall
         // on the next image or out of the descriptor's range (answered with 0) and its stores on the dummy words. With conditions, the
         // paths that skip a fetch made the compiler treat the batch being committed as the youngest one in flight — vmcnt(23..0) instead of
         // vmcnt(47..24): every commit drained the batch fetched just before the barrier.
-        fetch(end_row(t0), ra0, ra1);
-        fetch(end_row(t0 + 1), rb0, rb1);
+        fetch(end_row(t0), QA);
+        fetch(end_row(t0 + 1), QB);
         __syncthreads();
         st[7] = now() - t_begin;
         int t = t0;
         for (; t + 1 < t1; t += 2) {
             const unsigned long long ta = now();
-            commit(end_row(t), end_row(t + 1), ra0, ra1);          // the rows pass t + 1 adds, into slots pass t - 1 released at the last barrier
+            if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); st[5] += now() - ta; }      // the wait for batch A alone
+            commit(end_row(t), end_row(t + 1), QA);                // the rows pass t + 1 adds, into slots pass t - 1 released at the last barrier
             const unsigned long long tb = now();
-            fetch(end_row(t + 2), ra0, ra1);
+            fetch(end_row(t + 2), QA);
             const unsigned long long tc = now();
             __syncthreads();
             const unsigned long long td = now();
-            commit(end_row(t + 1), end_row(t + 2), rb0, rb1);
-            fetch(end_row(t + 3), rb0, rb1);
+            commit(end_row(t + 1), end_row(t + 2), QB);
+            fetch(end_row(t + 3), QB);
             const unsigned long long te = now();
             __syncthreads();
             if constexpr (STAMP) { st[0] += tb - ta; st[1] += tc - tb; st[2] += td - tc; st[3] += te - td; st[4] += now() - te; }
@@ -686,18 +690,23 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_ws_kernel(const float* __r
     }
 }
 
+#undef QA
+#undef QB
+
 // wave-specialised kernel: rows of the circular buffer = the rows two consecutive passes span; its budgets
 static int conv3x3_ws_rows(int ow) { return (2 * CW_PASS + ow - 2) / ow + 1 + 2; }
+static size_t conv3x3_ws_lds(int ow, int npl) {
+    const size_t ring = (size_t)conv3x3_ws_rows(ow) * (ow + 2) * cw_pixb(npl);
+    return ((ring + CW_DUMMY + 15) & ~(size_t)15) + (size_t)npl * 18 * 64 * 16;
+}
 static bool conv3x3_ws_fits(int oh, int ow, int npl) {
     const int sw = ow + 2, npix = oh * ow;
-    if (sw > CM_MAXW || sw < 16 || npix < 1) return false;
-    const int chunk = (16 * CW_PI) / sw, npass = (npix + CW_PASS - 1) / CW_PASS;
+    if (sw > CM_MAXW || npix < 1) return false;
+    const int chunk = (32 * CW_PI) / sw, npass = (npix + CW_PASS - 1) / CW_PASS;
     auto end_row = [&](int pass) { return ((pass * CW_PASS + CW_PASS < npix ? pass * CW_PASS + CW_PASS : npix) - 1) / ow + 3; };
     for (int t = 0; t + 1 < npass; ++t)
         if (end_row(t + 1) - end_row(t) > chunk) return false;                    // a pass adds more rows than one producer batch holds
-    if (chunk < 1) return false;
-    const size_t lds = (size_t)npl * round_up((int64_t)conv3x3_ws_rows(ow) * sw * CM_PIX + 512, 8) * sizeof(unsigned short) + (size_t)npl * 18 * 64 * 16;
-    return lds <= 160 * 1024 && chunk <= 15;
+    return chunk >= 1 && chunk <= 15 && conv3x3_ws_lds(ow, npl) <= 160 * 1024;
 }
 // true when the strip of a 256-pixel pass fits the kernel's fixed budgets
 static bool conv3x3_mfma_fits(int oh, int ow, int prec = EXORL_PREC_BF16X3) {
@@ -723,10 +732,11 @@ static int conv3x3_mfma(const float* in, const float* Wt, const float* bias, con
         EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    if (!(tune_variant() & 1073741824) && conv3x3_ws_fits(oh, ow, npl) && (int64_t)n * CONV_CO * ih * iw * 4 < (1ll << 31)) {      // bit 1073741824: the strip kernel (A/B); 32-bit buffer offsets
+    // the wave-specialised kernel: forward launches (no mask, no padding) and dgrad launches (mask and padding); 32-bit buffer offsets.
+    // exorl_gemm_tune bit 1073741824 keeps the strip kernel (A/B)
+    if (!(tune_variant() & 1073741824) && conv3x3_ws_fits(oh, ow, npl) && (int64_t)n * CONV_CO * ih * iw * 4 < (1ll << 31) && ((mask != nullptr) == (pad != 0))) {
         const int rb = conv3x3_ws_rows(ow);
-        const int wplane = (int)round_up((int64_t)rb * (ow + 2) * CM_PIX + 512, 8);          // ring + 256 dummy words (tail items of a batch)
-        const size_t wlds = (size_t)npl * wplane * sizeof(unsigned short) + (size_t)npl * 18 * 64 * 16;
+        const size_t wlds = conv3x3_ws_lds(ow, npl);
         static bool wattr = false;
         if (!wattr) {
             EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -738,8 +748,8 @@ static int conv3x3_mfma(const float* in, const float* Wt, const float* bias, con
             wattr = true;
         }
         const int wpass = (oh * ow + CW_PASS - 1) / CW_PASS, wgy = n <= 8 ? wpass : 1;
-        const int wflags = ((tune_variant() & 16) ? 1 : 0) | ((tune_variant() & 32) ? 2 : 0);      // experiments: producers at s_setprio 1 | roles swapped
-#define EXORL_CW(NN, MM) hipLaunchKernelGGL((conv3x3_ws_kernel<NN, MM>), dim3(n, wgy), dim3(CM_THREADS), wlds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu, wplane, rb, wflags)
+        const int wflags = (tune_variant() & 32) ? 2 : 0;          // experiment: the younger half of the workgroup stages
+#define EXORL_CW(NN, MM) hipLaunchKernelGGL((conv3x3_ws_kernel<NN, MM>), dim3(n, wgy), dim3(CM_THREADS), wlds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu, rb, wflags)
         if ((tune_variant() & 8192) && !mask && npl >= 2) {          // diagnostic: the stamped build
             static bool sattr = false;
             if (!sattr) {
@@ -747,8 +757,8 @@ static int conv3x3_mfma(const float* in, const float* Wt, const float* bias, con
                 EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 sattr = true;
             }
-            if (npl == 3) hipLaunchKernelGGL((conv3x3_ws_kernel<3, false, true>), dim3(n, wgy), dim3(CM_THREADS), wlds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu, wplane, rb, wflags);
-            else hipLaunchKernelGGL((conv3x3_ws_kernel<2, false, true>), dim3(n, wgy), dim3(CM_THREADS), wlds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu, wplane, rb, wflags);
+            if (npl == 3) hipLaunchKernelGGL((conv3x3_ws_kernel<3, false, true>), dim3(n, wgy), dim3(CM_THREADS), wlds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu, rb, wflags);
+            else hipLaunchKernelGGL((conv3x3_ws_kernel<2, false, true>), dim3(n, wgy), dim3(CM_THREADS), wlds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu, rb, wflags);
             EXORL_LAUNCH_CHECK();
             return 0;
         }
