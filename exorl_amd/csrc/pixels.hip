@@ -541,41 +541,81 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_ws_kernel(const float* __r
         }
     };
     // ---- consumers: wave w multiplies pixels p0 + 32 w .. + 31 of the pass ---------------------------------------------------------------
+    // A lane's A-operand pixel advances by 128 per pass: its row, column and ring slot are kept incrementally (one division at the start). The
+    // barrier of a pass sits right behind its k-loop — the stores, the bias/ReLU/mask arithmetic and the next pass's addresses do not touch the
+    // ring, so they run while the producers already refill it.
     const float bv = bias ? bias[col] : 0.f;
-    auto consume = [&](int pass, auto full_tag) {
-        constexpr bool FULL = decltype(full_tag)::value;
-        const int p0 = pass * CW_PASS;
-        const int pq = p0 + 32 * cw + 4 * kg;
-        float* orow = out + ((int64_t)n * CONV_CO + col) * npix;
-        float4 mq[4];
-        if constexpr (MASK) {
-            const float* mrow = mask + ((int64_t)n * CONV_CO + col) * npix;
+    const int adv_r = CW_PASS / ow, adv_x = CW_PASS - adv_r * ow;               // 128 pixels on = adv_r rows and adv_x columns (one carry)
+    int cr, cx, cs;                                                            // row, column, slot of the lane's pixel in the current pass
+    {
+        const int pa = t0 * CW_PASS + 32 * cw + col;
+        cr = pa / ow; cx = pa - cr * ow; cs = cr % rb;
+    }
+    const int last_r = (npix - 1) / ow, last_x = npix - 1 - last_r * ow, last_s = last_r % rb;      // tail lanes recompute the last pixel
+    unsigned ab[3];                                                            // ring byte offsets of the lane's pixel under tap rows 0..2
+    auto prep = [&](int pass) {
+        const bool in = pass * CW_PASS + 32 * cw + col < npix;
+        const int x = in ? cx : last_x;
+        int s0 = in ? cs : last_s;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int pp = pq + 8 * q;
-                if (FULL || pp + 3 < npix) mq[q] = *reinterpret_cast<const float4*>(mrow + pp);
-                else {
+        for (int d = 0; d < 3; ++d) {
+            ab[d] = (unsigned)((s0 * sw + x) * PIXB + 16 * kg);
+            s0 = s0 + 1 >= rb ? s0 + 1 - rb : s0 + 1;
+        }
+        cx += adv_x; cr += adv_r; cs += adv_r;                                 // the pixel of the pass after
+        if (cx >= ow) { cx -= ow; ++cr; ++cs; }
+        cs = cs >= rb ? cs - rb : cs;
+    };
+    // Two accumulator sets: while pass t accumulates into one, the finished sums of pass t - 1 in the other are combined, clamped, masked and
+    // stored BETWEEN the k-steps of pass t (the wave's own fillers beside its MFMAs are nearly free; as a block behind the k-loop they were
+    // 1.1-1.5 k cycles per pass on a wave that has its SIMD's matrix pipe to itself — 25-40 % on top of the k-loop).
+    cf32x16 a0, a1, a2, b0, b1, b2;
+    float4 mq[4];
+    auto mask_load = [&](int pass) {
+        if constexpr (MASK) {
+            const int pq = pass * CW_PASS + 32 * cw + 4 * kg;
+            const float* mrow = mask + ((int64_t)n * CONV_CO + col) * npix;
+            if (pass + 1 < npass) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mq[q] = *reinterpret_cast<const float4*>(mrow + pq + 8 * q);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int pp = pq + 8 * q;
                     mq[q].x = pp < npix ? mrow[pp] : 1.f; mq[q].y = pp + 1 < npix ? mrow[pp + 1] : 1.f;
-                    mq[q].z = pp + 2 < npix ? mrow[pp + 2] : 1.f; mq[q].w = 1.f;
+                    mq[q].z = pp + 2 < npix ? mrow[pp + 2] : 1.f; mq[q].w = pp + 3 < npix ? mrow[pp + 3] : 1.f;
                 }
             }
         }
-        int pa = p0 + 32 * cw + col;                                            // tail lanes recompute the last pixel
-        pa = pa < npix ? pa : npix - 1;
-        const int r = pa / ow, x = pa - r * ow;
-        int sl[3];
-        sl[0] = r % rb;
-        sl[1] = sl[0] + 1 >= rb ? sl[0] + 1 - rb : sl[0] + 1;
-        sl[2] = sl[1] + 1 >= rb ? sl[1] + 1 - rb : sl[1] + 1;
-        const unsigned char* ab[3];
+    };
+    float ov[4];
+    auto out_reg = [&](int i, const cf32x16& p0_, const cf32x16& p1_, const cf32x16& p2_) {          // output register i of a finished pass
+        float v = X6 ? (p2_[i] + p1_[i]) + p0_[i] : X3 ? p1_[i] + p0_[i] : p0_[i];
+        if (relu) v = fmaxf(v, 0.f);
+        if constexpr (MASK) {
+            const float m = (i & 3) == 0 ? mq[i >> 2].x : (i & 3) == 1 ? mq[i >> 2].y : (i & 3) == 2 ? mq[i >> 2].z : mq[i >> 2].w;
+            v = m > 0.f ? v : 0.f;
+        }
+        ov[i & 3] = v;
+    };
+    auto out_store = [&](int pass, int q, bool full) {
+        const int pp = pass * CW_PASS + 32 * cw + 4 * kg + 8 * q;
+        float* orow = out + ((int64_t)n * CONV_CO + col) * npix;
+        if (full || pp + 3 < npix) *reinterpret_cast<float4*>(orow + pp) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+        else {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) ab[d] = ring + (sl[d] * sw + x) * PIXB + 16 * kg;
-        cf32x16 acc, accx, accy;
+            for (int e = 0; e < 4; ++e)
+                if (pp + e < npix) orow[pp + e] = ov[e];
+        }
+    };
+    // k-loop of `pass` into (c0, c1, c2); PREV: the sums of pass - 1 in (p0_, p1_, p2_) leave between the k-steps (its mask was loaded by then)
+    auto kloop = [&](int pass, auto prev_tag, cf32x16& c0, cf32x16& c1, cf32x16& c2, const cf32x16& p0_, const cf32x16& p1_, const cf32x16& p2_) {
+        constexpr bool PREV = decltype(prev_tag)::value;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { acc[i] = 0.f; accx[i] = 0.f; accy[i] = 0.f; }
+        for (int i = 0; i < 16; ++i) { c0[i] = bv; c1[i] = 0.f; c2[i] = 0.f; }             // the bias rides in the hi*hi accumulator
         cbf16x8 fa[2][3], fb[2][3];
         auto ld = [&](int s, int b) {
-            const unsigned char* o = ab[(s >> 1) / 3] + ((s >> 1) % 3) * PIXB + (s & 1) * 32;
+            const unsigned char* o = ring + ab[(s >> 1) / 3] + ((s >> 1) % 3) * PIXB + (s & 1) * 32;
             fa[b][0] = *reinterpret_cast<const cbf16x8*>(o);
             fb[b][0] = wh[s * 64 + lane];
             if constexpr (X3) {
@@ -592,35 +632,29 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_ws_kernel(const float* __r
         for (int s = 0; s < 18; ++s) {
             const int b = s & 1;
             if (s + 1 < 18) ld(s + 1, b ^ 1);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][0], fb[b][0], acc, 0, 0, 0);
-            if constexpr (X3) accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][0], fb[b][1], accx, 0, 0, 0);
-            if constexpr (X6) accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][0], fb[b][2], accy, 0, 0, 0);
-            if constexpr (X3) accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][1], fb[b][0], accx, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][0], fb[b][0], c0, 0, 0, 0);
+            if constexpr (PREV) {
+                if (s >= 1 && s <= 16) {
+                    out_reg(s - 1, p0_, p1_, p2_);
+                    if (((s - 1) & 3) == 3) out_store(pass - 1, (s - 1) >> 2, true);
+                }
+            }
+            if constexpr (X3) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][0], fb[b][1], c1, 0, 0, 0);
+            if constexpr (X6) c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][0], fb[b][2], c2, 0, 0, 0);
+            if constexpr (X3) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][1], fb[b][0], c1, 0, 0, 0);
             if constexpr (X6) {
-                accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][2], fb[b][0], accy, 0, 0, 0);
-                accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][1], fb[b][1], accy, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][2], fb[b][0], c2, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][1], fb[b][1], c2, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);          // keep the reads one step ahead, not eighteen (the scheduler hoisted them all and spilled)
         }
+    };
+    auto epilogue = [&](int pass, const cf32x16& p0_, const cf32x16& p1_, const cf32x16& p2_) {      // the last pass of the workgroup
+        mask_load(pass);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] = (X6 ? (accy[4 * q + e] + accx[4 * q + e]) + acc[4 * q + e] : X3 ? accx[4 * q + e] + acc[4 * q + e] : acc[4 * q + e]) + bv;
-                if (relu) v[e] = fmaxf(v[e], 0.f);
-            }
-            if constexpr (MASK) {
-                v[0] = mq[q].x > 0.f ? v[0] : 0.f; v[1] = mq[q].y > 0.f ? v[1] : 0.f;
-                v[2] = mq[q].z > 0.f ? v[2] : 0.f; v[3] = mq[q].w > 0.f ? v[3] : 0.f;
-            }
-            const int pp = pq + 8 * q;
-            if (FULL || pp + 3 < npix) *reinterpret_cast<float4*>(orow + pp) = make_float4(v[0], v[1], v[2], v[3]);
-            else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (pp + e < npix) orow[pp + e] = v[e];
-            }
+        for (int i = 0; i < 16; ++i) {
+            out_reg(i, p0_, p1_, p2_);
+            if ((i & 3) == 3) out_store(pass, i >> 2, pass + 1 < npass);
         }
     };
     // STAMP (diagnostic, tuning bit 8192): consumer wave 0 {pass work, barrier wait, -, -, -, -, whole kernel, prologue} and the first producer wave
@@ -672,16 +706,38 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_ws_kernel(const float* __r
         }
         if (t < t1) __syncthreads();                               // the last pass of an odd count: nothing left to stage
     } else {
+        prep(t0);
         __syncthreads();
         st[7] = now() - t_begin;
-        for (int t = t0; t < t1; ++t) {
-            const unsigned long long ta = now();
-            if (t + 1 < npass) consume(t, std::true_type{});
-            else consume(t, std::false_type{});
-            const unsigned long long tc = now();
+        // pass t0 into set a; then pairs (b with a leaving, a with b leaving); the mask of pass t - 1 is fetched at the head of pass t's k-loop
+        unsigned long long ta = now();
+        kloop(t0, std::false_type{}, a0, a1, a2, a0, a1, a2);          // no previous pass: the last three arguments are not read
+        unsigned long long tc = now();
+        __syncthreads();
+        prep(t0 + 1);
+        if constexpr (STAMP) { st[0] += tc - ta; st[1] += now() - tc; }
+        int t = t0 + 1;
+        for (; t + 1 < t1; t += 2) {
+            ta = now();
+            mask_load(t - 1);
+            kloop(t, std::true_type{}, b0, b1, b2, a0, a1, a2);
+            tc = now();
             __syncthreads();
-            if constexpr (STAMP) { st[0] += tc - ta; st[1] += now() - tc; }
+            prep(t + 1);
+            const unsigned long long td = now();
+            mask_load(t);
+            kloop(t + 1, std::true_type{}, a0, a1, a2, b0, b1, b2);
+            const unsigned long long te = now();
+            __syncthreads();
+            prep(t + 2);
+            if constexpr (STAMP) { st[0] += (tc - ta) + (te - td); st[1] += (td - tc) + (now() - te); }
         }
+        if (t < t1) {
+            mask_load(t - 1);
+            kloop(t, std::true_type{}, b0, b1, b2, a0, a1, a2);
+            __syncthreads();
+            epilogue(t, b0, b1, b2);
+        } else epilogue(t - 1, a0, a1, a2);
     }
     if constexpr (STAMP) {
         st[6] = now() - t_begin;

@@ -47,6 +47,6 @@ else:
     mf = 18 * (6 if prec == L.PREC_BF16X6 else 3) * 32 * npass
     print(f'wave-specialised kernel, last layer (37 -> 35, {npass} passes per image); MFMA issue floor of a consumer wave {mf} cycles')
     c, p_ = st[:, 0], st[:, 1]
-    print(f'consumer wave 0: pass work {np.median(c[:, 0]):7.0f} | barrier wait {np.median(c[:, 1]):7.0f} | prologue {np.median(c[:, 7]):6.0f} | whole kernel {np.median(c[:, 6]):7.0f}')
+    print(f'consumer wave 0: k-loops (with the previous pass leaving) {np.median(c[:, 0]):7.0f} | barrier wait + next addresses {np.median(c[:, 1]):7.0f} | prologue {np.median(c[:, 7]):6.0f} | whole kernel {np.median(c[:, 6]):7.0f}')
     print(f'producer wave 4 (even passes: commit | fetch issue | barrier; odd passes: commit + fetch | barrier): {np.median(p_[:, 0]):7.0f} | {np.median(p_[:, 1]):7.0f} | '
           f'{np.median(p_[:, 2]):7.0f} ; {np.median(p_[:, 3]):7.0f} | {np.median(p_[:, 4]):7.0f} | prologue {np.median(p_[:, 7]):6.0f} | whole kernel {np.median(p_[:, 6]):7.0f} | of the even commits, waiting for the batch: {np.median(p_[:, 5]):7.0f}')
