@@ -1076,8 +1076,324 @@ __global__ __launch_bounds__(WM_THREADS) void conv_wgrad_mfma_kernel(const float
     }
 }
 
+// ---- the same weight gradients on the wave-specialised structure of conv3x3_ws_kernel (round 3) ------------------------------------------
+// The tile kernel above stages every 16 x 16 tile three times (one copy per dx), pays for 48 x 48 pixels on a 39 x 39 map and walks its
+// phases in lockstep: 430-530 us per launch for the flops the forward pass does in 116-158 us. Here K = the image's pixels in row-major order,
+// 16 per MFMA, 128 per pass; per tap dW[ci][co] += X(p + tap)^T dY(p):
+//   A (M = ci) comes from the forward kernel's ring of channels-last bf16 planes — staged once, every row once — through the hardware-
+//     transposing read (ds_read_b64_tr_b16: 4 pixels x 16 channels per 16-lane group; a position's planes are 64 B apart and positions
+//     192 B, so the four pixel rows of a read fall on four disjoint bank quarters);
+//   B (N = co) is dY[co][128 pixels] as bf16 planes in a double-buffered LDS image, 272-byte rows (ds_read_b128, conflict-free).
+// Waves 0-3 stage (X rows into the ring two batches ahead, dY one pass ahead, and the bias gradient as plain fp32 sums on the way);
+// waves 4-7 multiply: consumer w owns taps 2w and 2w + 1 for all eight k16 steps of a pass and tap 8 for steps 2w, 2w + 1 — 18 units of
+// NPL-plane products each per pass, the same MFMA count as a forward pass; the four tap-8 partials are added through LDS at the end.
+// Split modes keep two accumulators per tap: hi*hi, and every cross term (the cross terms are 2^-8 and 2^-16 of the sum: adding the smaller
+// ones into the larger costs 2^-32 of the result).
+constexpr int WW_DYP = 272;                 // bytes per dY channel row of the image: 128 pixels x 2 B + 16
+__host__ __device__ constexpr int ww_pixb(int npl) { return npl == 1 ? 64 : 192; }
+template <int NPL>
+__global__ __launch_bounds__(CM_THREADS) void conv_wgrad_ws_kernel(const float* __restrict__ dy, const float* __restrict__ in, float* __restrict__ P,
+                                                                   float* __restrict__ Pb, int ih, int iw, int oh, int ow, int rb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cm_lds[];
+    constexpr bool X3 = NPL >= 2, X6 = NPL == 3;
+    constexpr int PIXB = ww_pixb(NPL);
+    const int npix = oh * ow, npass = (npix + CW_PASS - 1) / CW_PASS, sw = ow + 2;
+    const int ring_b = rb * sw * PIXB;
+    unsigned char* ring = cm_lds;
+    unsigned char* dyimg = cm_lds + ((ring_b + CW_DUMMY + 15) & ~15);          // [2 buffers][NPL][32 co][WW_DYP]
+    constexpr int DYBUF = NPL * CONV_CO * WW_DYP;
+    const int n = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool producer = wave < 4;
+    auto end_row = [&](int pass) {
+        const int p1 = (pass * CW_PASS + CW_PASS < npix ? pass * CW_PASS + CW_PASS : npix) - 1;
+        return p1 / ow + 3;
+    };
+    typedef float cf32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 cbf16x2 __attribute__((ext_vector_type(2)));
+    if (producer) {
+        // ---- X rows: as conv3x3_ws_kernel (no padding), with the channel quad as the fast lane index: the 16 lanes of a ds_write_b64 group
+        // cover two whole positions (2 x 64 B, 192 B apart) instead of 16 positions 48 dwords apart (8-way on 32 banks)
+        const int chunk = (32 * CW_PI) / sw;
+        const int ptid = tid, cq = ptid & 7, jl = ptid >> 3;
+        const int plane_b = ih * iw * 4;
+        const unsigned total_b = (unsigned)gridDim.x * CONV_CO * plane_b;
+        float* inq = const_cast<float*>(in);
+        const auto src0 = __builtin_amdgcn_make_buffer_rsrc(inq, 0, (int)(total_b - 3 * plane_b), 0x00020000);
+        const auto src1 = __builtin_amdgcn_make_buffer_rsrc(inq + ih * iw, 0, (int)(total_b - 3 * plane_b), 0x00020000);
+        const auto src2 = __builtin_amdgcn_make_buffer_rsrc(inq + 2 * ih * iw, 0, (int)(total_b - 3 * plane_b), 0x00020000);
+        const auto src3 = __builtin_amdgcn_make_buffer_rsrc(inq + 3 * ih * iw, 0, (int)(total_b - 3 * plane_b), 0x00020000);
+        const int toff = ring_b + 8 * ptid;
+        int goff[CW_PI], loff[CW_PI];
+#pragma unroll
+        for (int u = 0; u < CW_PI; ++u) {
+            const int j = jl + 32 * u, yy = j / sw, xx = j - yy * sw;
+            goff[u] = ((4 * cq * ih + yy) * iw + xx) * 4;
+            loff[u] = (yy * sw + xx) * PIXB + 8 * cq;
+        }
+        typedef float Item[CW_PI];
+        Item qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;
+        auto fetch = [&](int ya, Item& q0, Item& q1, Item& q2, Item& q3) {
+            const int boff = (n * CONV_CO * ih + ya) * iw * 4;
+#pragma unroll
+            for (int u = 0; u < CW_PI; ++u) {
+                const int vo = goff[u] + boff;
+                q0[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src0, vo, 0, 0));
+                q1[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src1, vo, 0, 0));
+                q2[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src2, vo, 0, 0));
+                q3[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src3, vo, 0, 0));
+            }
+        };
+        auto commit = [&](int ya, int yb, const Item& q0, const Item& q1, const Item& q2, const Item& q3) {
+            const int nrows = yb - ya, nvalid = (nrows * sw - jl + 31) >> 5;
+            const int lbase = (ya % rb) * sw * PIXB;
+#pragma unroll
+            for (int u = 0; u < CW_PI; ++u) {
+                unsigned o = (unsigned)(loff[u] + lbase);
+                const unsigned ow_ = o - (unsigned)ring_b;
+                o = o < ow_ ? o : ow_;
+                o = u < nvalid ? o : (unsigned)toff;
+                const cf32x2 v = {q0[u], q1[u]}, w = {q2[u], q3[u]};
+                const cbf16x2 hv = __builtin_convertvector(v, cbf16x2), hw_ = __builtin_convertvector(w, cbf16x2);
+                *reinterpret_cast<uint2*>(ring + o) = make_uint2(__builtin_bit_cast(unsigned, hv), __builtin_bit_cast(unsigned, hw_));
+                if constexpr (X3) {
+                    const cf32x2 rv = v - __builtin_convertvector(hv, cf32x2), rw = w - __builtin_convertvector(hw_, cf32x2);
+                    const cbf16x2 lv = __builtin_convertvector(rv, cbf16x2), lw = __builtin_convertvector(rw, cbf16x2);
+                    *reinterpret_cast<uint2*>(ring + o + 64) = make_uint2(__builtin_bit_cast(unsigned, lv), __builtin_bit_cast(unsigned, lw));
+                    if constexpr (X6) {
+                        const cbf16x2 tv = __builtin_convertvector(rv - __builtin_convertvector(lv, cf32x2), cbf16x2);
+                        const cbf16x2 tw = __builtin_convertvector(rw - __builtin_convertvector(lw, cf32x2), cbf16x2);
+                        *reinterpret_cast<uint2*>(ring + o + 128) = make_uint2(__builtin_bit_cast(unsigned, tv), __builtin_bit_cast(unsigned, tw));
+                    }
+                }
+            }
+        };
+        // ---- dY: thread = (channel co, pixel quad ql of 8): quads ql + 8 i of a pass; fp32 running sum = the bias gradient
+        const int dco = ptid >> 3, dql = ptid & 7;
+        const unsigned dy_total = (unsigned)gridDim.x * CONV_CO * npix * 4;
+        const auto dsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, (int)dy_total, 0x00020000);
+        const int dgo = ((n * CONV_CO + dco) * npix + 4 * dql) * 4;             // byte offset of the thread's first quad of pass 0
+        const int dlo = dco * WW_DYP + 8 * dql;                                  // its byte offset in a plane of the image
+        typedef float cf32x4 __attribute__((ext_vector_type(4)));
+        cf32x4 da[4], db[4];
+        float bsum = 0.f;
+        auto dfetch = [&](int pass, cf32x4 (&d)[4]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)                  // dword loads: a quad may straddle the end of the tensor, and only whole dwords are range-checked for sure
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    d[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dsrc, dgo + (pass * CW_PASS + 32 * i + e) * 4, 0, 0));
+        };
+        auto dcommit = [&](int pass, const cf32x4 (&d)[4]) {
+            unsigned char* img = dyimg + (pass & 1) * DYBUF + dlo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                cf32x4 v = d[i];
+                const int pp = pass * CW_PASS + 4 * dql + 32 * i;
+                if (pp + 3 >= npix) {                                            // the image's last quads: pixels past the map are zeros
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = pp + e < npix ? v[e] : 0.f;
+                }
+                bsum += (v[0] + v[1]) + (v[2] + v[3]);
+                const cf32x2 v01 = {v[0], v[1]}, v23 = {v[2], v[3]};
+                const cbf16x2 h01 = __builtin_convertvector(v01, cbf16x2), h23 = __builtin_convertvector(v23, cbf16x2);
+                *reinterpret_cast<uint2*>(img + 64 * i) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+                if constexpr (X3) {
+                    const cf32x2 r01 = v01 - __builtin_convertvector(h01, cf32x2), r23 = v23 - __builtin_convertvector(h23, cf32x2);
+                    const cbf16x2 l01 = __builtin_convertvector(r01, cbf16x2), l23 = __builtin_convertvector(r23, cbf16x2);
+                    *reinterpret_cast<uint2*>(img + CONV_CO * WW_DYP + 64 * i) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+                    if constexpr (X6) {
+                        const cbf16x2 t01 = __builtin_convertvector(r01 - __builtin_convertvector(l01, cf32x2), cbf16x2);
+                        const cbf16x2 t23 = __builtin_convertvector(r23 - __builtin_convertvector(l23, cf32x2), cbf16x2);
+                        *reinterpret_cast<uint2*>(img + 2 * CONV_CO * WW_DYP + 64 * i) = make_uint2(__builtin_bit_cast(unsigned, t01), __builtin_bit_cast(unsigned, t23));
+                    }
+                }
+            }
+        };
+        // prologue: rows and dY of pass 0; batches of passes 1 and 2 and dY of passes 1, 2 in flight. Everything unconditional from there on
+        // (past the last pass a batch has no rows and dY reads answer 0 or are overwritten by nobody's reads).
+        {
+            const int need = end_row(0);
+            const int ym = chunk < need ? chunk : need, yn = ym + chunk < need ? ym + chunk : need;
+            fetch(0, qa0, qa1, qa2, qa3);
+            if (ym < need) fetch(ym, qb0, qb1, qb2, qb3);
+            dfetch(0, da);
+            commit(0, ym, qa0, qa1, qa2, qa3);
+            if (ym < need) commit(ym, yn, qb0, qb1, qb2, qb3);
+            for (int y = yn; y < need; y += chunk) {
+                fetch(y, qa0, qa1, qa2, qa3);
+                commit(y, y + chunk < need ? y + chunk : need, qa0, qa1, qa2, qa3);
+            }
+            dcommit(0, da);
+            fetch(end_row(0), qa0, qa1, qa2, qa3);
+            fetch(end_row(1), qb0, qb1, qb2, qb3);
+            dfetch(1, da);
+            dfetch(2, db);
+        }
+        __syncthreads();
+        int t = 0;
+        for (; t + 1 < npass; t += 2) {
+            commit(end_row(t), end_row(t + 1), qa0, qa1, qa2, qa3);
+            dcommit(t + 1, da);
+            fetch(end_row(t + 2), qa0, qa1, qa2, qa3);
+            dfetch(t + 3, da);
+            __syncthreads();
+            commit(end_row(t + 1), end_row(t + 2), qb0, qb1, qb2, qb3);
+            if (t + 2 < npass) dcommit(t + 2, db);
+            fetch(end_row(t + 3), qb0, qb1, qb2, qb3);
+            dfetch(t + 4, db);
+            __syncthreads();
+        }
+        if (t < npass) __syncthreads();
+        // bias gradient: the 8 lanes of a channel are neighbours
+        bsum += __shfl_xor(bsum, 1, 64);
+        bsum += __shfl_xor(bsum, 2, 64);
+        bsum += __shfl_xor(bsum, 4, 64);
+        if (dql == 0) Pb[(int64_t)n * CONV_CO + dco] = bsum;
+        __syncthreads();                       // the consumers' tap-8 exchange
+        return;
+    }
+    // ---- consumers ---------------------------------------------------------------------------------------------------------------------------
+    const int cw = wave & 3;
+    const int kg = lane >> 5, col = lane & 31;
+    // transposed A reads: lane 4 q + p of a 16-lane group supplies pixel row q, channels 16 (g & 1) + 4 p .. + 3 of the block; k = 8 (g >> 1) + q (+ 4)
+    const int grp = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+    const int colb = (16 * (grp & 1) + 4 * tp) * 2;
+    const int klo = 8 * (grp >> 1) + tq;
+    int tdel[3];                               // ring byte offset of the wave's taps relative to the pixel: (dy * sw + dx) * PIXB
+    {
+        const int taps[3] = {2 * cw, 2 * cw + 1, 8};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) tdel[j] = ((taps[j] / 3) * sw + taps[j] % 3) * PIXB;
+    }
+    // the lane's lo pixel (k = klo of step 0 of pass 0) as (column, ring byte offset of its row); advanced 4 (hi) and 12 (next step) at a time
+    int px = klo % ow, prow = (klo / ow) * sw * PIXB, ppix = klo;
+    const int rowb = sw * PIXB;
+    const int last_x = (npix - 1) % ow, last_row = (((npix - 1) / ow) % rb) * rowb;
+    auto advance = [&](int d) {
+        px += d; ppix += d;
+        if (px >= ow) { px -= ow; prow += rowb; prow = prow >= ring_b ? prow - ring_b : prow; }
+    };
+    auto pix_base = [&]() -> unsigned {        // ring offset of the lane's current pixel (the last pixel of the map for lanes past it), + its columns
+        const bool inm = ppix < npix;
+        return (unsigned)((inm ? prow : last_row) + (inm ? px : last_x) * PIXB + colb);
+    };
+    auto tap_addr = [&](unsigned base, int j) -> const unsigned char* {
+        unsigned o = base + (unsigned)tdel[j];
+        const unsigned o2 = o - (unsigned)ring_b;
+        o = o < o2 ? o : o2;
+        return ring + o;
+    };
+    typedef short v4s16 __attribute__((ext_vector_type(4)));
+    typedef short v8s16 __attribute__((ext_vector_type(8)));
+    auto tr_frag = [&](const unsigned char* lo, const unsigned char* hi) -> cbf16x8 {
+        const v4s16 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(lo));
+        const v4s16 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(hi));
+        const v8s16 v = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        return __builtin_bit_cast(cbf16x8, v);
+    };
+    cf32x16 acc[3], accx[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc[j][i] = 0.f; accx[j][i] = 0.f; }
+    auto unit = [&](int j, const cbf16x8 (&xa)[3], const cbf16x8 (&db)[3]) {            // one tap, one k16 step: NPL-plane products
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0], db[0], acc[j], 0, 0, 0);
+        if constexpr (X3) {
+            accx[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0], db[1], accx[j], 0, 0, 0);
+            accx[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[1], db[0], accx[j], 0, 0, 0);
+        }
+        if constexpr (X6) {
+            accx[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0], db[2], accx[j], 0, 0, 0);
+            accx[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[2], db[0], accx[j], 0, 0, 0);
+            accx[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[1], db[1], accx[j], 0, 0, 0);
+        }
+    };
+    __syncthreads();
+    for (int t = 0; t < npass; ++t) {
+        const unsigned char* dimg = dyimg + (t & 1) * DYBUF + col * WW_DYP + 16 * kg;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const unsigned blo = pix_base();
+            advance(4);
+            const unsigned bhi = pix_base();
+            advance(12);
+            cbf16x8 db[3], x0[3], x1[3];
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) db[pl] = *reinterpret_cast<const cbf16x8*>(dimg + pl * CONV_CO * WW_DYP + 32 * ks);
+            const unsigned char *l0 = tap_addr(blo, 0), *h0 = tap_addr(bhi, 0), *l1 = tap_addr(blo, 1), *h1 = tap_addr(bhi, 1);
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) { x0[pl] = tr_frag(l0 + 64 * pl, h0 + 64 * pl); x1[pl] = tr_frag(l1 + 64 * pl, h1 + 64 * pl); }
+            unit(0, x0, db);
+            unit(1, x1, db);
+            if ((ks >> 1) == cw) {                         // wave-uniform: this wave's quarter of tap 8
+                const unsigned char *l8 = tap_addr(blo, 2), *h8 = tap_addr(bhi, 2);
+                cbf16x8 x8[3];
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) x8[pl] = tr_frag(l8 + 64 * pl, h8 + 64 * pl);
+                unit(2, x8, db);
+            }
+        }
+        __syncthreads();
+    }
+    // C layout: reg r of lane l = row (r & 3) + 8 (r >> 2) + 4 (l >> 5) = ci, column l & 31 = co
+    float* Pn = P + (int64_t)n * CONV_CO * CONV_CO * 9;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = (r & 3) + 8 * (r >> 2) + 4 * kg;
+            Pn[(col * CONV_CO + ci) * 9 + 2 * cw + j] = X3 ? accx[j][r] + acc[j][r] : acc[j][r];
+        }
+    // tap 8: the four quarters through LDS (the ring is free now), summed in wave order by consumer 0
+    float* xch = reinterpret_cast<float*>(ring);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xch[(cw * 16 + r) * 64 + lane] = X3 ? accx[2][r] + acc[2][r] : acc[2][r];
+    __syncthreads();
+    if (cw == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = (r & 3) + 8 * (r >> 2) + 4 * kg;
+            Pn[(col * CONV_CO + ci) * 9 + 8] = ((xch[r * 64 + lane] + xch[(16 + r) * 64 + lane]) + xch[(32 + r) * 64 + lane]) + xch[(48 + r) * 64 + lane];
+        }
+    }
+}
+
+static size_t conv_wgrad_ws_lds(int ow, int npl) {
+    const size_t ring = (size_t)conv3x3_ws_rows(ow) * (ow + 2) * ww_pixb(npl);
+    return ((ring + CW_DUMMY + 15) & ~(size_t)15) + (size_t)2 * npl * CONV_CO * WW_DYP;
+}
+static bool conv_wgrad_ws_fits(int n, int ih, int iw, int oh, int ow, int npl) {
+    const int sw = ow + 2, npix = oh * ow;
+    if (ih != oh + 2 || iw != ow + 2 || ow < 16 || sw > CM_MAXW || npix < 3 * CW_PASS) return false;
+    const int chunk = (32 * CW_PI) / sw, npass = (npix + CW_PASS - 1) / CW_PASS;
+    auto end_row = [&](int pass) { return ((pass * CW_PASS + CW_PASS < npix ? pass * CW_PASS + CW_PASS : npix) - 1) / ow + 3; };
+    for (int t = 0; t + 1 < npass; ++t)
+        if (end_row(t + 1) - end_row(t) > chunk) return false;
+    if (end_row(0) > 2 * chunk + chunk) return false;
+    const size_t ring = (size_t)conv3x3_ws_rows(ow) * sw * ww_pixb(npl);
+    return chunk >= 1 && conv_wgrad_ws_lds(ow, npl) <= 160 * 1024 && ring >= 4 * 16 * 64 * 4 &&
+           (int64_t)n * CONV_CO * ih * iw * 4 < (1ll << 31) && (int64_t)n * CONV_CO * npix * 4 < (1ll << 31);
+}
+
 static int conv_wgrad_mfma(const float* dy, const float* in, float* P, float* Pb, int n, int ih, int iw, int oh, int ow, int prec, hipStream_t s) {
     const int npl = prec == EXORL_PREC_BF16X6 ? 3 : (prec == EXORL_PREC_BF16X3 ? 2 : 1);
+    if (!(tune_variant() & 64) && conv_wgrad_ws_fits(n, ih, iw, oh, ow, npl)) {          // exorl_gemm_tune bit 64: the tile kernel below (A/B)
+        const size_t wlds = conv_wgrad_ws_lds(ow, npl);
+        static bool wattr = false;
+        if (!wattr) {
+            EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wgrad_ws_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wgrad_ws_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wgrad_ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            wattr = true;
+        }
+        const int rb = conv3x3_ws_rows(ow);
+        if (npl == 3)      hipLaunchKernelGGL((conv_wgrad_ws_kernel<3>), dim3(n), dim3(CM_THREADS), wlds, s, dy, in, P, Pb, ih, iw, oh, ow, rb);
+        else if (npl == 2) hipLaunchKernelGGL((conv_wgrad_ws_kernel<2>), dim3(n), dim3(CM_THREADS), wlds, s, dy, in, P, Pb, ih, iw, oh, ow, rb);
+        else               hipLaunchKernelGGL((conv_wgrad_ws_kernel<1>), dim3(n), dim3(CM_THREADS), wlds, s, dy, in, P, Pb, ih, iw, oh, ow, rb);
+        EXORL_LAUNCH_CHECK();
+        return 0;
+    }
     const bool th4 = npl == 3 && (tune_variant() & 2048);            // measured and not adopted: 4 x 16 tiles (74 KB, two workgroups per CU): 9.6 vs 9.3 ms per Proto update
     const int th = npl == 3 ? (th4 ? 4 : 8) : 16;
     const size_t lds = (size_t)npl * (CONV_CO * (th * CONV_TILE + 8) + 3 * CONV_CO * ((th + 2) * CONV_TILE + 8)) * sizeof(unsigned short);
