@@ -613,8 +613,8 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_ws_kernel(const float* __r
         constexpr bool PREV = decltype(prev_tag)::value;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { c0[i] = bv; c1[i] = 0.f; c2[i] = 0.f; }             // the bias rides in the hi*hi accumulator
-        cbf16x8 fa[2][3], fb[2][3];
-        auto ld = [&](int s, int b) {
+        cbf16x8 fa[3][3], fb[3][3];            // fragments of three k-steps: the reads run TWO steps ahead (a step of the two-plane mode is 3 MFMAs =
+        auto ld = [&](int s, int b) {          // 96 cycles, less than an LDS round trip under load; one step ahead left a stall per step)
             const unsigned char* o = ring + ab[(s >> 1) / 3] + ((s >> 1) % 3) * PIXB + (s & 1) * 32;
             fa[b][0] = *reinterpret_cast<const cbf16x8*>(o);
             fb[b][0] = wh[s * 64 + lane];
@@ -628,10 +628,11 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_ws_kernel(const float* __r
             }
         };
         ld(0, 0);
+        ld(1, 1);
 #pragma unroll
         for (int s = 0; s < 18; ++s) {
-            const int b = s & 1;
-            if (s + 1 < 18) ld(s + 1, b ^ 1);
+            const int b = s % 3;
+            if (s + 2 < 18) ld(s + 2, (s + 2) % 3);
             c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][0], fb[b][0], c0, 0, 0, 0);
             if constexpr (PREV) {
                 if (s >= 1 && s <= 16) {
@@ -1310,29 +1311,40 @@ __global__ __launch_bounds__(CM_THREADS) void conv_wgrad_ws_kernel(const float* 
         }
     };
     __syncthreads();
+    // fragments of k16 step ks + 1 are read while step ks is on the matrix cores (two register sets, the steps of a pass fully unrolled)
+    // Tap 8's fragments are read inside the branch that multiplies them: read one step ahead under the same (wave-uniform) condition and
+    // multiplied in the next iteration's branch, the plain-bf16 build produced NaNs in tap 8 on some launches (tools/debug/wgrad_nan_probe.py).
+    cbf16x8 db[2][3], x0[2][3], x1[2][3];
+    unsigned b8lo[2], b8hi[2];                 // the pixel bases of a step, kept for its tap-8 unit
     for (int t = 0; t < npass; ++t) {
         const unsigned char* dimg = dyimg + (t & 1) * DYBUF + col * WW_DYP + 16 * kg;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
+        auto ld = [&](int ks, int b) {
             const unsigned blo = pix_base();
             advance(4);
             const unsigned bhi = pix_base();
             advance(12);
-            cbf16x8 db[3], x0[3], x1[3];
+            b8lo[b] = blo; b8hi[b] = bhi;
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) db[pl] = *reinterpret_cast<const cbf16x8*>(dimg + pl * CONV_CO * WW_DYP + 32 * ks);
+            for (int pl = 0; pl < NPL; ++pl) db[b][pl] = *reinterpret_cast<const cbf16x8*>(dimg + pl * CONV_CO * WW_DYP + 32 * ks);
             const unsigned char *l0 = tap_addr(blo, 0), *h0 = tap_addr(bhi, 0), *l1 = tap_addr(blo, 1), *h1 = tap_addr(bhi, 1);
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) { x0[pl] = tr_frag(l0 + 64 * pl, h0 + 64 * pl); x1[pl] = tr_frag(l1 + 64 * pl, h1 + 64 * pl); }
-            unit(0, x0, db);
-            unit(1, x1, db);
+            for (int pl = 0; pl < NPL; ++pl) { x0[b][pl] = tr_frag(l0 + 64 * pl, h0 + 64 * pl); x1[b][pl] = tr_frag(l1 + 64 * pl, h1 + 64 * pl); }
+        };
+        ld(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int b = ks & 1;
+            if (ks + 1 < 8) ld(ks + 1, b ^ 1);
+            unit(0, x0[b], db[b]);
+            unit(1, x1[b], db[b]);
             if ((ks >> 1) == cw) {                         // wave-uniform: this wave's quarter of tap 8
-                const unsigned char *l8 = tap_addr(blo, 2), *h8 = tap_addr(bhi, 2);
+                const unsigned char *l8 = tap_addr(b8lo[b], 2), *h8 = tap_addr(b8hi[b], 2);
                 cbf16x8 x8[3];
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) x8[pl] = tr_frag(l8 + 64 * pl, h8 + 64 * pl);
-                unit(2, x8, db);
+                unit(2, x8, db[b]);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
