@@ -140,6 +140,40 @@ def test_encoder_three_plane_convolutions_are_fp32_grade(lib):
     assert dist[3] < 2e-6 and dist[2] > 4 * dist[3], dist
 
 
+@pytest.mark.parametrize('n,hw', [(3, 84), (12, 84), (12, 64), (9, 48)])
+def test_wave_specialised_convolutions_match_the_strip_and_tile_kernels(lib, n, hw):
+    """conv3x3_ws_kernel / conv_wgrad_ws_kernel (the product path of the 32 -> 32 layers) against the round-2 strip / tile kernels they replaced
+    (exorl_gemm_tune bits 1073741824 and 64 keep those), same inputs, every precision mode: features, input-side gradients (through dgrad) and all
+    weight / bias gradients. n <= 8 takes the one-pass-per-workgroup launch of the forward kernel, n > 8 the per-image loop (what batch 1024
+    runs); 84-pixel frames give maps of 39 / 37 / 35, 64-pixel frames 29 / 27 / 25 (three passes where two batches cover a pass's rows), 48-pixel
+    frames 21 / 19 / 17 (the weight-gradient kernel declines maps under 384 pixels: only forward / dgrad differ there). Both sides form the
+    same products and differ in summation order only (the new forward kernel starts its accumulator at the bias, the weight-gradient kernel walks
+    the pixels in row-major passes instead of 16 x 16 tiles); a different last bit of an activation is then re-split into planes by the next
+    layer, so the bars are a few units of the mode's own product accuracy relative to the tensor's scale: 5e-6 three-plane, 2e-5 two-plane,
+    3e-2 plain bf16 (the bar that mode has against the oracle; one flipped bf16 rounding of an activation is 2^-8 of it). Measured over the four
+    cases: <= 7e-7, <= 5e-6, 1e-3 .. 7e-3. Measured
+    distances are printed."""
+    rs = np.random.RandomState(11)
+    p = []
+    for l in range(4):
+        ci = 3 if l == 0 else 32
+        p += [(rs.standard_normal((32, ci, 3, 3)) * np.sqrt(2.0 / (ci * 9))).astype(np.float32), (0.1 * rs.standard_normal(32)).astype(np.float32)]
+    x = rs.randint(0, 256, (n, 3, hw, hw)).astype(np.uint8)
+    edge = (hw - 3) // 2 + 1 - 6
+    dh = rs.standard_normal((n, 32 * edge * edge)).astype(np.float32)
+    for prec, tol in ((3, 5e-6), (2, 2e-5), (1, 3e-2)):
+        try:
+            lib.exorl_gemm_tune(1073741824 | 64)
+            h0, g0 = run_encoder(lib, p, x, dh, prec)
+        finally:
+            lib.exorl_gemm_tune(-1)
+        h1, g1 = run_encoder(lib, p, x, dh, prec)
+        assert np.isfinite(h1).all() and all(np.isfinite(g).all() for g in g1)
+        d = [float(np.abs(h1 - h0).max() / np.abs(h0).max())] + [float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30)) for a, b in zip(g1, g0)]
+        print(f'n={n} hw={hw} prec={prec}: ws vs strip/tile kernels, worst tensor distance {max(d):.1e}')
+        assert max(d) < tol, (prec, d)
+
+
 def _fwd_any(p, x):
     return pixels.encoder_fwd(p, x)
 
