@@ -425,7 +425,8 @@ class CRRAgent(_AgentBase):
 
 
 class CQLAgent(_AgentBase):
-    """agents/offline_learning/cql.py:59-286 (both the shipped cql.yaml and use_critic_lagrange=True; the latter single-GPU)."""
+    """agents/offline_learning/cql.py:59-286 (both the shipped cql.yaml and use_critic_lagrange=True; under torch.distributed the latter splits
+    phase 0 around a sum-all-reduce of the penalty, _run_update)."""
     KIND = 'cql'
 
     def __init__(self, name, obs_shape, action_shape, device, lr, hidden_dim, critic_target_tau, nstep, batch_size, use_tb, alpha,
@@ -476,7 +477,12 @@ class CQLAgent(_AgentBase):
             eng.update(1.0, nc, na)
             return
         dist = torch.distributed
-        eng.update_phase(0, 1.0, nc, na)
+        if self.use_critic_lagrange:              # the multiplier steps on the GLOBAL penalty before any critic gradient is formed (cql.py:199-213)
+            eng.update_phase(4, 1.0, nc, na)
+            dist.all_reduce(eng.stats())          # this rank's sum of logsumexp and of Q1 + Q2
+            eng.update_phase(5, 1.0, nc, na)
+        else:
+            eng.update_phase(0, 1.0, nc, na)
         dist.all_reduce(eng.flat(L.NET_CRITIC, L.T_GRAD))
         eng.update_phase(1, 1.0, nc, na)
         dist.all_reduce(eng.stats())              # sum of log_pi for the entropy temperature (cql.py:242-243)

@@ -471,8 +471,7 @@ static int describe(exorl_agent* a, const exorl_agent_cfg* cfg) {
                   "agent: APS needs 1 <= sf_dim <= 16 and obs_dim = observation + sf_dim (got sf_dim=%d obs_dim=%d)", cfg->sf_dim, cfg->obs_dim);
     EXORL_REQUIRE(cfg->kind != EXORL_AGENT_CQL || (cfg->n_samples >= 1 && cfg->n_samples <= 16 && cfg->act_dim <= 16),
                   "agent: CQL needs 1 <= n_samples <= 16 and action_dim <= 16 (got %d, %d)", cfg->n_samples, cfg->act_dim);
-    EXORL_REQUIRE(!cfg->use_critic_lagrange || (cfg->kind == EXORL_AGENT_CQL && cfg->world_size == 1),
-                  "agent: use_critic_lagrange is a single-GPU CQL option (the penalty is a batch-global scalar that steers its own multiplier)");
+    EXORL_REQUIRE(!cfg->use_critic_lagrange || cfg->kind == EXORL_AGENT_CQL, "agent: use_critic_lagrange is a CQL option");
     EXORL_REQUIRE(cfg->kind != EXORL_AGENT_CRR || (cfg->num_value_samples >= 1 && cfg->num_value_samples <= 64 &&
                   cfg->weight_func >= EXORL_CRR_IDENTITY && cfg->weight_func <= EXORL_CRR_EXP),
                   "agent: CRR needs 1 <= num_value_samples <= 64 and a valid weight_func (got %d, %d)", cfg->num_value_samples, cfg->weight_func);
@@ -738,7 +737,9 @@ static CqlNoise cql_noise(exorl_agent* a) {
     return z;
 }
 
-static int cql_phase0(exorl_agent* a, hipStream_t s) {
+// Phase 0 in two halves. One GPU (and data parallel without the Lagrange multiplier) runs them back to back. With use_critic_lagrange under
+// torch.distributed the host drives them as phases 4 and 5 and sum-all-reduces the statistics block in between (cql.hip, cql_critic_dq_kernel).
+static int cql_phase0a(exorl_agent* a, hipStream_t s, bool split) {
     const auto& cfg = a->cfg;
     const int B = cfg.batch, O = cfg.obs_dim, A = cfg.act_dim, W = O + A, n = cfg.n_samples, prec = cfg.precision;
     const int R = (3 * n + 1) * B;
@@ -754,13 +755,31 @@ static int cql_phase0(exorl_agent* a, hipStream_t s) {
     EXORL_TRY(net_forward(a->critic, a->flat[EXORL_NET_CRITIC_TARGET][EXORL_T_PARAM], a->sh_target, a->xc_next, W, B, a->ft, false, false,
                           prec, s));                                                                     // cql.py:160
     EXORL_TRY(net_forward(a->critic, Pc, a->sh_critic, a->x_all, W, R, a->fc, true, false, prec, s));     // cql.py:166,179-184 in one pass
+    if (split)      // this rank's penalty sums into stats[2], stats[3]
+        EXORL_TRY(cql_critic_dq(a->fc.out, a->ft.out, a->reward, a->discount, a->dq_all, a->metrics, B, n, cfg.alpha, a->inv_bg, s,
+                                a->cql + 1, &a->state->critic, cfg.target_cql_penalty, 1, a->stats + 2));
+    return 0;
+}
+
+static int cql_phase0b(exorl_agent* a, hipStream_t s, bool split) {
+    const auto& cfg = a->cfg;
+    const int B = cfg.batch, O = cfg.obs_dim, A = cfg.act_dim, W = O + A, n = cfg.n_samples, prec = cfg.precision;
+    const int R = (3 * n + 1) * B;
+    const float* Pc = a->flat[EXORL_NET_CRITIC][EXORL_T_PARAM];
     EXORL_TRY(cql_critic_dq(a->fc.out, a->ft.out, a->reward, a->discount, a->dq_all, a->metrics, B, n, cfg.alpha, a->inv_bg, s,
-                            cfg.use_critic_lagrange ? a->cql + 1 : nullptr, &a->state->critic, cfg.target_cql_penalty));
+                            cfg.use_critic_lagrange ? a->cql + 1 : nullptr, &a->state->critic, cfg.target_cql_penalty, split ? 2 : 0, a->stats + 2));
     DoutSpec d{};
     d.mode = EXORL_DOUT_BUFFER; d.buf = a->dq_all;
     EXORL_TRY(net_backward(a->critic, Pc, a->sh_critic, a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD], a->pc, a->x_all, W, R, a->fc, d, a->bc,
                            nullptr, 0, 0, prec, s, a->fk, a->fuse_opt ? &a->pend_c : nullptr));
     return 0;
+}
+
+static int cql_phase0(exorl_agent* a, hipStream_t s) {
+    EXORL_REQUIRE(!(a->cfg.use_critic_lagrange && a->cfg.world_size > 1), "agent_update_phase: CQL with use_critic_lagrange under data parallelism "
+                  "runs phase 0 as phases 4 and 5 with a sum-all-reduce of exorl_agent_stats in between");
+    EXORL_TRY(cql_phase0a(a, s, false));
+    return cql_phase0b(a, s, false);
 }
 
 static int cql_phase1(exorl_agent* a, hipStream_t s) {
@@ -951,6 +970,8 @@ int exorl_agent_update_phase(exorl_agent_t* a, int32_t phase, float stddev, cons
             case 1: return cql_phase1(a, s);
             case 2: return cql_phase2(a, s);
             case 3: return phase3(a, s);
+            case 4: return cql_phase0a(a, s, true);        // use_critic_lagrange under data parallelism: phase 0 up to the penalty sums ...
+            case 5: return cql_phase0b(a, s, true);        // ... and from the global penalty on
         }
     }
     switch (phase) {

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(1024) void cql_critic_dq_kernel(const float* __rest
                                                              const float* __restrict__ reward, const float* __restrict__ discount,
                                                              float* __restrict__ dq_all, float* __restrict__ metrics, int B, int n,
                                                              float cql_alpha_in, float inv_bg, CqlScalars* lag,
-                                                             const AdamConst* __restrict__ cp, float target_penalty) {
+                                                             const AdamConst* __restrict__ cp, float target_penalty, int mode, float* gsum) {
 #pragma clang fp contract(off)
     __shared__ float sm[7][16];
     __shared__ float sh_alpha;
@@ -129,13 +129,23 @@ __global__ __launch_bounds__(1024) void cql_critic_dq_kernel(const float* __rest
         }
     }
     block_sum_c<7>(v, sm);
+    // Data parallel with the Lagrange multiplier (mode 1, then 2; gsum = two floats of the agent's statistics block): the multiplier's step
+    // needs the penalty of the GLOBAL batch before any gradient can be formed, so a first launch only leaves this rank's two sums
+    // (sum lse, sum Q1 + Q2), the host sum-all-reduces them, and the second launch steps the multiplier from the global penalty — the same
+    // number on every rank, so the replicas' multipliers stay bit-identical — while its metrics stay this rank's partial means (they are
+    // all-reduced with the others).
+    if (mode == 1) {
+        if (threadIdx.x == 0) { gsum[0] = v[5]; gsum[1] = v[6]; }
+        return;
+    }
     if (threadIdx.x == 0) {
         const float lse = v[5] * inv_bg, pen = lse - v[6] * inv_bg;
         float alpha = cql_alpha_in;
         if (lag) {                           // alpha_loss = -0.5 * clamp(exp(log_alpha), 0, 1e6) * (penalty - target); Adam; re-read
             const AdamConst c = *cp;
             const float ea = expf(lag->log_alpha);
-            const float g = (ea >= 0.0f && ea <= 1000000.0f) ? -0.5f * (pen - target_penalty) * ea : 0.0f;
+            const float gpen = mode == 2 ? gsum[0] * inv_bg - gsum[1] * inv_bg : pen;
+            const float g = (ea >= 0.0f && ea <= 1000000.0f) ? -0.5f * (gpen - target_penalty) * ea : 0.0f;
             float m = lag->m, vv = lag->v, p = lag->log_alpha;
             m = m + c.one_minus_b1 * (g - m);
             vv = vv * c.b2 + (c.one_minus_b2 * g) * g;
@@ -176,9 +186,11 @@ __global__ __launch_bounds__(1024) void cql_critic_dq_kernel(const float* __rest
 }
 
 int cql_critic_dq(const float* q_all, const float* tq, const float* reward, const float* discount, float* dq_all, float* metrics,
-                  int B, int n, float cql_alpha, float inv_bg, hipStream_t s, CqlScalars* lag, const AdamConst* c_dev, float target_penalty) {
+                  int B, int n, float cql_alpha, float inv_bg, hipStream_t s, CqlScalars* lag, const AdamConst* c_dev, float target_penalty,
+                  int mode, float* gsum) {
+    EXORL_REQUIRE(mode == 0 || gsum, "cql_critic_dq: the data-parallel modes need the statistics block");
     hipLaunchKernelGGL(cql_critic_dq_kernel, dim3(1), dim3(1024), 0, s, q_all, tq, reward, discount, dq_all, metrics, B, n, cql_alpha, inv_bg,
-                       lag, c_dev, target_penalty);
+                       lag, c_dev, target_penalty, mode, gsum);
     EXORL_LAUNCH_CHECK();
     return 0;
 }

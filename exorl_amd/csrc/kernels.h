@@ -325,7 +325,8 @@ int cql_build_inputs(const float* obs, const float* action, const float* raw2, C
 // lag != nullptr: the penalty weight is exp(log_critic_alpha), stepped by Adam inside the kernel before it is used (cql.py:201-213)
 int cql_critic_dq(const float* q_all, const float* tq, const float* reward, const float* discount, float* dq_all, float* metrics,
                   int B, int n, float cql_alpha, float inv_bg, hipStream_t s, CqlScalars* lag = nullptr, const AdamConst* c_dev = nullptr,
-                  float target_penalty = 0.f);
+                  float target_penalty = 0.f,
+                  int mode = 0, float* gsum = nullptr);
 // rsample of pi(obs): y = tanh(mu + std z) -> xc_pi[:, O:]; stats[0] = sum log_pi (per element, cql.py:239)
 int cql_actor_sample(const float* raw_obs, CqlNoise nz, float* xc_pi, int64_t ld, float* stats, int B, int O, int A, hipStream_t s);
 // scalar Adam step on log_actor_alpha from the (all-reduced) sum of log_pi; writes alpha = exp(log_alpha) and metrics

@@ -178,7 +178,7 @@ typedef struct {
     int32_t num_value_samples; /* CRR: actions sampled per state for V(s) (crr.yaml: 10) */
     int32_t weight_func;       /* CRR: EXORL_CRR_* */
     int32_t n_samples;         /* CQL: action samples per source (cql.yaml: 3); `alpha` is then the CQL penalty weight */
-    int32_t use_critic_lagrange; /* CQL: learn the penalty weight (cql.py:201-213); single-GPU only */
+    int32_t use_critic_lagrange; /* CQL: learn the penalty weight (cql.py:201-213); data parallel through exorl_agent_update_phase 4 / 5, not with exorl_agent_set_comm */
     float   target_cql_penalty;  /* CQL Lagrange target (cql.yaml: 5.0) */
     int32_t reserved3;
 } exorl_agent_cfg;
@@ -217,7 +217,11 @@ int exorl_agent_update(exorl_agent_t* a, float stddev, const float* noise_critic
  *   phase 1 -> critic Adam + soft update, actor-side Q statistics ready (all-reduce the 4-float stats buffer)
  *   phase 2 -> actor grads ready        (all-reduce EXORL_NET_ACTOR / EXORL_T_GRAD flat buffer)
  *   phase 3 -> actor Adam
- * BC has phases 2 and 3 only. */
+ * BC has phases 2 and 3 only.
+ * CQL with use_critic_lagrange under data parallelism (cql.py:199-213: the multiplier's own step needs the penalty of the GLOBAL batch before
+ * any critic gradient exists): phase 0 is driven as
+ *   phase 4 -> forwards done, this rank's penalty sums in the stats buffer (all-reduce the 4-float stats buffer)
+ *   phase 5 -> multiplier stepped from the global penalty, critic grads ready (then as after phase 0). */
 int exorl_agent_update_phase(exorl_agent_t* a, int32_t phase, float stddev, const float* noise_critic_dev,
                              const float* noise_actor_dev, void* stream);
 int exorl_agent_stats_buffer(exorl_agent_t* a, void** ptr_dev, int64_t* numel);

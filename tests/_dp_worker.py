@@ -37,11 +37,11 @@ def build_agent(kind, precision, batch, use_tb):
         ag = agents.TD3Agent('td3', (O,), (A,), 'cuda:0', 1e-4, H, 0.01, '0.2', 1, batch, 0.3, use_tb, precision=precision)
     elif kind == 'crr':
         ag = agents.CRRAgent('crr', (O,), (A,), 'cuda:0', 1e-4, H, 0.01, 4, 'exp', '0.2', 1, batch, 0.3, use_tb, precision=precision)
-    elif kind == 'cql':
-        ag = agents.CQLAgent('cql', (O,), (A,), 'cuda:0', 1e-4, H, 0.01, 1, batch, use_tb, 0.01, 3, 5.0, False, precision=precision)
+    elif kind in ('cql', 'cqll'):           # cqll: use_critic_lagrange=True (the penalty weight is learnt, cql.py:199-213)
+        ag = agents.CQLAgent('cql', (O,), (A,), 'cuda:0', 1e-4, H, 0.01, 1, batch, use_tb, 0.01, 3, 5.0, kind == 'cqll', precision=precision)
     else:
         ag = agents.BCAgent('bc', (O,), (A,), 'cuda:0', 1e-4, H, batch, '0.2', use_tb, precision=precision)
-    ash, csh = param_shapes(kind, O, A, H)
+    ash, csh = param_shapes('cql' if kind == 'cqll' else kind, O, A, H)
     ag.actor.load_state_dict({k: torch.from_numpy(v) for k, v in _synth.synth_params(ash, 1).items()})
     if csh:
         ag.critic.load_state_dict({k: torch.from_numpy(v) for k, v in _synth.synth_params(csh, 2).items()})
@@ -64,7 +64,7 @@ def sliced_noise_hook(ns, rows, local_rows):
     return hook
 
 
-HOOKED = [('td3', 'fp32'), ('cql', 'fp32'), ('crr', 'fp32')]          # the kinds run through sliced_noise_hook (CQL: its own _run_update branch under torch.distributed)
+HOOKED = [('td3', 'fp32'), ('cql', 'fp32'), ('cqll', 'fp32'), ('crr', 'fp32')]          # the kinds run through sliced_noise_hook (CQL: its own _run_update branch under torch.distributed)
 
 
 # ---- reward-free agents (sharded actor / critic step, module step on the all-gathered batch: agents._IntrAgent._intr_step_dp) ----------
@@ -191,7 +191,8 @@ def main():
         torch.cuda.synchronize()
         tag = f'{kind}_{precision}'
         nets = [('actor', ag.actor), ('critic', ag.critic), ('critic_target', ag.critic_target)]
-        np.savez(out_dir / f'{tag}_rank{rank}.npz', **{n: torch.cat([p.reshape(-1) for p in net.parameters()]).cpu().numpy() for n, net in nets})
+        extra = {'cql_scalars': np.asarray(ag.engine.cql_alpha_state(), np.float64)} if kind in ('cql', 'cqll') else {}      # temperature (+ multiplier) and their Adam moments
+        np.savez(out_dir / f'{tag}_rank{rank}.npz', **{n: torch.cat([p.reshape(-1) for p in net.parameters()]).cpu().numpy() for n, net in nets}, **extra)
         result[tag] = metrics
         del ag, it
     run_unsup(rank, world, out_dir, result)
