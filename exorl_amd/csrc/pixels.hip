@@ -192,6 +192,59 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
     }
 }
 
+// ---- first layer, forward (stride 2, no padding): the same sums over row-major strips ------------------------------------------------------
+// PMC of conv3x3_kernel on this layer at batch 1024 (profiles/r03c_conv_pmc.txt): 182 MB fetched for an 87 MB input (33 x 33 halo tiles, 9 per
+// image) and 325 MB written for a 220 MB output (16-pixel row segments of a 41-wide map straddle cache lines), 146 us for 3 GFLOP. Here a
+// workgroup takes 256 consecutive output pixels of an image in row-major order: the input rows it needs are one contiguous run per channel
+// (read once, + two halo rows), a thread owns one pixel, and the 64 threads of a wave store 256 contiguous bytes per channel. The arithmetic
+// per output — channel-major, tap by tap, fp32 FMAs on weights held in SGPRs — is that of conv3x3_kernel, so the results are bit-identical.
+// Columns are de-interleaved in LDS (even columns, then odd columns of a row): the stride-2 taps of 64 neighbouring pixels then hit 64
+// consecutive words instead of every other one.
+constexpr int C1_PASS = 256;
+__global__ __launch_bounds__(256) void conv1_strip_kernel(const float* __restrict__ in, const float* __restrict__ Wt, const float* __restrict__ bias,
+                                                          float* __restrict__ out, int ci_n, int ih, int iw, int oh, int ow, int in_scale, int relu,
+                                                          int max_rows) {
+    extern __shared__ float lds[];
+    const int npix = oh * ow, n = blockIdx.y;
+    const int p0 = blockIdx.x * C1_PASS, p1 = (p0 + C1_PASS < npix ? p0 + C1_PASS : npix) - 1;
+    const int y0 = p0 / ow, nrows = 2 * (p1 / ow - y0) + 3;        // input rows 2 y0 .. 2 y1 + 2
+    const int he = (iw + 1) >> 1, rowp = 2 * he;                   // even columns [0, he), odd columns [he, 2 he) of a row
+    const float* inn = in + ((int64_t)n * ci_n * ih + 2 * y0) * iw;
+    for (int i = threadIdx.x; i < ci_n * nrows * iw; i += 256) {
+        const int xx = i % iw, rr = (i / iw) % nrows, ci = i / (iw * nrows);
+        float v = inn[((int64_t)ci * ih + rr) * iw + xx];
+        if (in_scale) v = v / 255.0f - 0.5f;
+        lds[(ci * max_rows + rr) * rowp + (xx & 1) * he + (xx >> 1)] = v;
+    }
+    __syncthreads();
+    const int p = p0 + threadIdx.x;
+    const int pc = p < npix ? p : npix - 1;                        // tail threads recompute the last pixel and do not store
+    const int oy = pc / ow, ox = pc - oy * ow;
+    float acc[CONV_CO];
+#pragma unroll
+    for (int co = 0; co < CONV_CO; ++co) acc[co] = 0.f;
+    for (int ci = 0; ci < ci_n; ++ci) {
+        const float* t = lds + (ci * max_rows + 2 * (oy - y0)) * rowp + ox;
+        const float* wci = Wt + (int64_t)ci * 9 * CONV_CO;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            const float v = t[ky * rowp + (kx & 1) * he + (kx >> 1)];       // column 2 ox + kx
+            const float* w = wci + tap * CONV_CO;
+#pragma unroll
+            for (int co = 0; co < CONV_CO; ++co) acc[co] += v * w[co];
+        }
+    }
+    if (p >= npix) return;
+    float* o = out + (int64_t)n * CONV_CO * npix + p;
+#pragma unroll
+    for (int co = 0; co < CONV_CO; ++co) {
+        float v = acc[co] + (bias ? bias[co] : 0.f);
+        if (relu) v = fmaxf(v, 0.f);
+        o[(int64_t)co * npix] = v;
+    }
+}
+
 // ---- the 32 -> 32 channel layers on the matrix cores (split-bf16 / bf16 modes) -----------------------------------------------------
 // Implicit GEMM per 16 x 16 output tile: M = 32 pixels (two tile rows), N = 32 output channels, K = 9 taps x 32 input channels with
 // k = tap * 32 + ci, so the A fragment of a k16 step (8 consecutive ci of one tap for one pixel) is 16 contiguous bytes of a
@@ -854,6 +907,21 @@ static int conv3x3(const float* in, const float* Wt, const float* bias, const fl
                    int oh, int ow, int stride, int pad, int in_scale, int relu, hipStream_t s, int prec = EXORL_PREC_F32, const float* frag = nullptr) {
     if (prec != EXORL_PREC_F32 && ci_n == CONV_CO && co_n == CONV_CO && stride == 1 && !in_scale && frag && conv3x3_mfma_fits(oh, ow, prec))
         return conv3x3_mfma(in, frag, bias, mask, out, n, ih, iw, oh, ow, pad, relu, prec, s);
+    if (stride == 2 && pad == 0 && !mask && co_n == CONV_CO && ow >= 8 && !(tune_variant() & 16)) {      // first layer forward; exorl_gemm_tune bit 16: the tile kernel (A/B)
+        const int max_rows = 2 * ((C1_PASS + ow - 2) / ow) + 3;
+        const size_t slds = (size_t)ci_n * max_rows * 2 * ((iw + 1) / 2) * sizeof(float);
+        if (slds <= 160 * 1024) {
+            static bool sattr = false;
+            if (!sattr) {
+                EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv1_strip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                sattr = true;
+            }
+            hipLaunchKernelGGL(conv1_strip_kernel, dim3(cdiv(oh * ow, C1_PASS), n), dim3(256), slds, s, in, Wt, bias, out, ci_n, ih, iw, oh, ow, in_scale,
+                               relu, max_rows);
+            EXORL_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     const int tin = (CONV_TILE - 1) * stride + 3;
     const size_t lds = (size_t)ci_n * tin * tin * sizeof(float);
     EXORL_REQUIRE(lds <= 160 * 1024 && co_n == CONV_CO, "conv3x3: tile does not fit LDS (ci=%d stride=%d) or co=%d != 32", ci_n, stride, co_n);
