@@ -482,11 +482,14 @@ constexpr int CW_PI = 6;                   // staged positions per producer thre
 // a ds_read_b128 group on distinct banks (240 B = 60 dwords and 176 B = 44 dwords: both step through all multiples of 4 mod 64)
 __host__ __device__ constexpr int cw_pixb(int npl) { return npl == 3 ? 240 : npl == 2 ? 176 : 80; }
 constexpr int CW_DUMMY = 256 * 8 + 176;    // a dummy 8-byte word per producer thread, reached with the same plane offsets (+ 80, + 160) as a real position
-template <int NPL, bool MASK, bool STAMP = false>           // MASK = the dgrad launches: ReLU mask of the layer below AND zero padding (pad = 2)
+// PERSIST: the workgroup walks images blockIdx.x, + gridDim.x, ... (launched with one workgroup per CU): the weight fragments are loaded once, and
+// the loads the producers issue past an image's last pass — wasted in the one-image form — fetch the first rows of the workgroup's NEXT image,
+// so that between two images only their conversion stands in front of the consumers (the per-image prologue was 15-20 % of the kernel).
+template <int NPL, bool MASK, bool STAMP = false, bool PERSIST = false>           // MASK = the dgrad launches: ReLU mask of the layer below AND zero padding (pad = 2)
 __global__ __launch_bounds__(CM_THREADS) void conv3x3_ws_kernel(const float* __restrict__ in, const float* __restrict__ Wt,
                                                                 const float* __restrict__ bias, const float* __restrict__ mask,
                                                                 float* __restrict__ out, int ih, int iw, int oh, int ow, int pad, int relu,
-                                                                int rb, int flags) {
+                                                                int rb, int flags, int nimg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cm_lds[];
     constexpr bool X3 = NPL >= 2, X6 = NPL == 3;
     constexpr int PIXB = cw_pixb(NPL);
@@ -494,7 +497,7 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_ws_kernel(const float* __r
     const int ring_b = rb * sw * PIXB;                                                     // the ring: [rb rows by slot][ow + 2][PIXB]
     unsigned char* ring = cm_lds;                                                          // then CW_DUMMY bytes for the tail items of a batch
     cbf16x8* wh = reinterpret_cast<cbf16x8*>(cm_lds + ((ring_b + CW_DUMMY + 15) & ~15));   // [NPL][18 k-steps][64 lanes] B fragments
-    const int n = blockIdx.x;
+    int n = blockIdx.x;                                                                    // the image (PERSIST: the current one)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool producer = (flags & 2) ? wave >= 4 : wave < 4;                              // wave-uniform role; the older half stages (measured)
     const int cw = wave & 3;                                                               // consumer index: pixels 32 cw .. of a pass
@@ -520,7 +523,7 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_ws_kernel(const float* __r
     // the ring), the conversions and one 8-byte store per plane — no branch, no division, no 64-bit address arithmetic.
     const int ptid = tid & 255, cq = ptid >> 5, jl = ptid & 31;
     const int plane_b = ih * iw * 4;                                        // bytes of one channel of one image
-    const unsigned total_b = (unsigned)gridDim.x * CONV_CO * plane_b;       // host-checked < 2^31
+    const unsigned total_b = (unsigned)nimg * CONV_CO * plane_b;            // host-checked < 2^31
     float* inq = const_cast<float*>(in);
     const auto src0 = __builtin_amdgcn_make_buffer_rsrc(inq, 0, (int)(total_b - 3 * plane_b), 0x00020000);
     const auto src1 = __builtin_amdgcn_make_buffer_rsrc(inq + ih * iw, 0, (int)(total_b - 3 * plane_b), 0x00020000);      // channel + 1: base one plane on
@@ -545,8 +548,8 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_ws_kernel(const float* __r
 #define QB qb0, qb1, qb2, qb3
     // The loaded values are NOT touched in fetch: anything that consumes a load result makes the compiler wait for it on the spot, which
     // put the whole memory latency into the "issue" phase (2-4 k cycles per pass in the stamps, here and in the strip kernel).
-    auto fetch = [&](int ya, Item& q0, Item& q1, Item& q2, Item& q3) {
-        const int boff = ((n * CONV_CO * ih + ya - pad) * iw - pad) * 4;   // image, first row of the batch, padding; may be negative (wraps out of range)
+    auto fetch_of = [&](int im, int ya, Item& q0, Item& q1, Item& q2, Item& q3) {
+        const int boff = (int)((((unsigned)im * CONV_CO * ih + ya - pad) * iw - pad) * 4u);   // image, first row of the batch, padding; may wrap out of range
 #pragma unroll
         for (int u = 0; u < CW_PI; ++u) {
             const int vo = goff[u] + boff;
@@ -556,6 +559,7 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_ws_kernel(const float* __r
             q3[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src3, vo, 0, 0));
         }
     };
+    auto fetch = [&](int ya, Item& q0, Item& q1, Item& q2, Item& q3) { fetch_of(n, ya, q0, q1, q2, q3); };
     auto commit = [&](int ya, int yb, const Item& q0, const Item& q1, const Item& q2, const Item& q3) {
         const int nrows = yb - ya, nvalid = (nrows * sw - jl + 31) >> 5;      // items u < nvalid lie inside the batch
         const int lbase = (ya % rb) * sw * PIXB;
@@ -600,10 +604,11 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_ws_kernel(const float* __r
     const float bv = bias ? bias[col] : 0.f;
     const int adv_r = CW_PASS / ow, adv_x = CW_PASS - adv_r * ow;               // 128 pixels on = adv_r rows and adv_x columns (one carry)
     int cr, cx, cs;                                                            // row, column, slot of the lane's pixel in the current pass
-    {
+    auto first_pixel = [&]() {
         const int pa = t0 * CW_PASS + 32 * cw + col;
         cr = pa / ow; cx = pa - cr * ow; cs = cr % rb;
-    }
+    };
+    first_pixel();
     const int last_r = (npix - 1) / ow, last_x = npix - 1 - last_r * ow, last_s = last_r % rb;      // tail lanes recompute the last pixel
     unsigned ab[3];                                                            // ring byte offsets of the lane's pixel under tap rows 0..2
     auto prep = [&](int pass) {
@@ -723,7 +728,81 @@ __global__ __launch_bounds__(CM_THREADS) void conv3x3_ws_kernel(const float* __r
     // compiler's wait-count analysis merges the roles at the loop head: the consumers then wait out their own stores (vmcnt(0)) in front of
     // every pass because their registers alias the producers' pending loads, and the producers cannot tell which of their two batches is the
     // older one. The producer loop is unrolled by two for the same reason: batch A is always the older one at its commit, then batch B.
-    if (producer) {
+    if constexpr (PERSIST) {
+        // launched with gridDim.y == 1 (t0 = 0, t1 = npass) and a first pass whose rows fit two batches (host-checked)
+        const int G = gridDim.x, need = end_row(0), ym = chunk < need ? chunk : need;
+        const bool odd = npass & 1;
+        if (producer) {
+            // Past pass npass - 3 the loop's fetches have no rows of this image left to get: row-batch index k = npass and npass + 2 now mean "the
+            // next image's first batch", k = npass + 1 its second. With the loop's fixed alternation of the two register sets that leaves the
+            // first batch in set A when npass is odd and in set B when it is even — the window below commits them in that order.
+            auto fetch_k = [&](int k, Item& q0, Item& q1, Item& q2, Item& q3) {
+                const bool nxt = k >= npass;
+                fetch_of(nxt ? n + G : n, nxt ? (k == npass + 1 ? ym : 0) : end_row(k - 1), q0, q1, q2, q3);
+            };
+            if (odd) { fetch(0, QA); fetch(ym, QB); } else { fetch(0, QB); fetch(ym, QA); }
+            for (; n < nimg; n += G) {
+                const unsigned long long tw = now();
+                if (odd) { commit(0, ym, QA); commit(ym, need, QB); } else { commit(0, ym, QB); commit(ym, need, QA); }
+                fetch(end_row(0), QA);
+                fetch(end_row(1), QB);
+                __syncthreads();
+                st[7] += now() - tw;
+                int t = 0;
+                for (; t + 1 < npass; t += 2) {
+                    const unsigned long long ta = now();
+                    commit(end_row(t), end_row(t + 1), QA);
+                    const unsigned long long tb = now();
+                    fetch_k(t + 3, QA);
+                    const unsigned long long tc = now();
+                    __syncthreads();
+                    const unsigned long long td = now();
+                    commit(end_row(t + 1), end_row(t + 2), QB);
+                    fetch_k(t + 4, QB);
+                    const unsigned long long te = now();
+                    __syncthreads();
+                    if constexpr (STAMP) { st[0] += tb - ta; st[1] += tc - tb; st[2] += td - tc; st[3] += te - td; st[4] += now() - te; }
+                }
+                if (t < npass) __syncthreads();
+            }
+        } else {
+            for (; n < nimg; n += G) {
+                const unsigned long long tw = now();
+                first_pixel();
+                prep(0);
+                __syncthreads();
+                st[7] += now() - tw;
+                unsigned long long ta = now();
+                kloop(0, std::false_type{}, a0, a1, a2, a0, a1, a2);
+                unsigned long long tc = now();
+                __syncthreads();
+                prep(1);
+                if constexpr (STAMP) { st[0] += tc - ta; st[1] += now() - tc; }
+                int t = 1;
+                for (; t + 1 < npass; t += 2) {
+                    ta = now();
+                    mask_load(t - 1);
+                    kloop(t, std::true_type{}, b0, b1, b2, a0, a1, a2);
+                    tc = now();
+                    __syncthreads();
+                    prep(t + 1);
+                    const unsigned long long td = now();
+                    mask_load(t);
+                    kloop(t + 1, std::true_type{}, a0, a1, a2, b0, b1, b2);
+                    const unsigned long long te = now();
+                    __syncthreads();
+                    prep(t + 2);
+                    if constexpr (STAMP) { st[0] += (tc - ta) + (te - td); st[1] += (td - tc) + (now() - te); }
+                }
+                if (t < npass) {
+                    mask_load(t - 1);
+                    kloop(t, std::true_type{}, b0, b1, b2, a0, a1, a2);
+                    __syncthreads();
+                    epilogue(t, b0, b1, b2);
+                } else epilogue(t - 1, a0, a1, a2);
+            }
+        }
+    } else if (producer) {
         const int ya = (t0 * CW_PASS) / ow, need = end_row(t0);
         const int ym = ya + chunk < need ? ya + chunk : need, yn = ym + chunk < need ? ym + chunk : need;
         fetch(ya, QA);
@@ -848,33 +927,35 @@ static int conv3x3_mfma(const float* in, const float* Wt, const float* bias, con
         const int rb = conv3x3_ws_rows(ow);
         const size_t wlds = conv3x3_ws_lds(ow, npl);
         static bool wattr = false;
+        static int ncu = 256;
         if (!wattr) {
-            EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define EXORL_WA(NN, MM, SS, PP) EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<NN, MM, SS, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+            EXORL_WA(3, true, false, false); EXORL_WA(3, false, false, false); EXORL_WA(2, true, false, false); EXORL_WA(2, false, false, false);
+            EXORL_WA(1, true, false, false); EXORL_WA(1, false, false, false);
+            EXORL_WA(3, true, false, true); EXORL_WA(3, false, false, true); EXORL_WA(2, true, false, true); EXORL_WA(2, false, false, true);
+            EXORL_WA(1, true, false, true); EXORL_WA(1, false, false, true);
+            EXORL_WA(3, false, true, true); EXORL_WA(2, false, true, true);
+#undef EXORL_WA
+            int dev = 0, v = 0;
+            EXORL_CHECK_HIP(hipGetDevice(&dev));
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
             wattr = true;
         }
         const int wpass = (oh * ow + CW_PASS - 1) / CW_PASS, wgy = n <= 8 ? wpass : 1;
         const int wflags = (tune_variant() & 32) ? 2 : 0;          // experiment: the younger half of the workgroup stages
-#define EXORL_CW(NN, MM) hipLaunchKernelGGL((conv3x3_ws_kernel<NN, MM>), dim3(n, wgy), dim3(CM_THREADS), wlds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu, rb, wflags)
-        if ((tune_variant() & 8192) && !mask && npl >= 2) {          // diagnostic: the stamped build
-            static bool sattr = false;
-            if (!sattr) {
-                EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                EXORL_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                sattr = true;
-            }
-            if (npl == 3) hipLaunchKernelGGL((conv3x3_ws_kernel<3, false, true>), dim3(n, wgy), dim3(CM_THREADS), wlds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu, rb, wflags);
-            else hipLaunchKernelGGL((conv3x3_ws_kernel<2, false, true>), dim3(n, wgy), dim3(CM_THREADS), wlds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu, rb, wflags);
-            EXORL_LAUNCH_CHECK();
-            return 0;
-        }
-        if (npl == 3)      { if (mask) EXORL_CW(3, true); else EXORL_CW(3, false); }
-        else if (npl == 2) { if (mask) EXORL_CW(2, true); else EXORL_CW(2, false); }
-        else               { if (mask) EXORL_CW(1, true); else EXORL_CW(1, false); }
+        // persistent form: one workgroup per CU walks the images; needs the first pass's rows in two batches. exorl_gemm_tune bit 8388608: one image per workgroup (A/B)
+        const int wchunk = (32 * CW_PI) / (ow + 2), wneed = ((CW_PASS < oh * ow ? CW_PASS : oh * ow) - 1) / ow + 3;
+        const bool persist = wgy == 1 && wneed <= 2 * wchunk && !(npl == 3 && mask) && !(tune_variant() & 8388608);      // (three planes + mask: 256 VGPRs and a spill)
+        const int gx = persist ? (n < ncu ? n : ncu) : n;
+#define EXORL_CW(NN, MM, SS) do { \
+            if (persist) hipLaunchKernelGGL((conv3x3_ws_kernel<NN, MM, SS, true>), dim3(gx, 1), dim3(CM_THREADS), wlds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu, rb, wflags, n); \
+            else hipLaunchKernelGGL((conv3x3_ws_kernel<NN, MM, false, false>), dim3(n, wgy), dim3(CM_THREADS), wlds, s, in, Wt, bias, mask, out, ih, iw, oh, ow, pad, relu, rb, wflags, n); \
+        } while (0)
+        if ((tune_variant() & 8192) && !mask && npl >= 2 && persist) {          // diagnostic: the stamped build (persistent form)
+            if (npl == 3) EXORL_CW(3, false, true); else EXORL_CW(2, false, true);
+        } else if (npl == 3) { if (mask) EXORL_CW(3, true, false); else EXORL_CW(3, false, false); }
+        else if (npl == 2) { if (mask) EXORL_CW(2, true, false); else EXORL_CW(2, false, false); }
+        else               { if (mask) EXORL_CW(1, true, false); else EXORL_CW(1, false, false); }
 #undef EXORL_CW
         EXORL_LAUNCH_CHECK();
         return 0;

@@ -45,7 +45,9 @@ if '--strip' in sys.argv:
 else:
     npass = (35 * 35 + 127) // 128
     mf = 18 * (6 if prec == L.PREC_BF16X6 else 3) * 32 * npass
-    print(f'wave-specialised kernel, last layer (37 -> 35, {npass} passes per image); MFMA issue floor of a consumer wave {mf} cycles')
+    print(f'wave-specialised kernel (persistent form: per-image averages), last layer (37 -> 35, {npass} passes per image); MFMA issue floor of a consumer wave {mf} cycles')
+    per_wg = max(1, -(-n // 256))             # persistent form: a workgroup walks n / 256 images and sums its stamps over them
+    st = st[:min(n, 256)] // per_wg
     c, p_ = st[:, 0], st[:, 1]
     print(f'consumer wave 0: k-loops (with the previous pass leaving) {np.median(c[:, 0]):7.0f} | barrier wait + next addresses {np.median(c[:, 1]):7.0f} | prologue {np.median(c[:, 7]):6.0f} | whole kernel {np.median(c[:, 6]):7.0f}')
     print(f'producer wave 4 (even passes: commit | fetch issue | barrier; odd passes: commit + fetch | barrier): {np.median(p_[:, 0]):7.0f} | {np.median(p_[:, 1]):7.0f} | '
