@@ -140,13 +140,14 @@ def test_encoder_three_plane_convolutions_are_fp32_grade(lib):
     assert dist[3] < 2e-6 and dist[2] > 4 * dist[3], dist
 
 
-@pytest.mark.parametrize('n,hw', [(3, 84), (12, 84), (12, 64), (9, 48)])
+@pytest.mark.parametrize('n,hw', [(3, 84), (12, 84), (12, 64), (9, 48), (300, 48)])
 def test_wave_specialised_convolutions_match_the_strip_and_tile_kernels(lib, n, hw):
     """conv3x3_ws_kernel / conv_wgrad_ws_kernel (the product path of the 32 -> 32 layers) against the round-2 strip / tile kernels they replaced
     (exorl_gemm_tune bits 1073741824 and 64 keep those), same inputs, every precision mode: features, input-side gradients (through dgrad) and all
     weight / bias gradients. n <= 8 takes the one-pass-per-workgroup launch of the forward kernel, n > 8 the per-image loop (what batch 1024
     runs); 84-pixel frames give maps of 39 / 37 / 35, 64-pixel frames 29 / 27 / 25 (three passes where two batches cover a pass's rows), 48-pixel
-    frames 21 / 19 / 17 (the weight-gradient kernel declines maps under 384 pixels: only forward / dgrad differ there). Both sides form the
+    frames 21 / 19 / 17 (the weight-gradient kernel declines maps under 384 pixels: only forward / dgrad differ there); 300 images put two
+    images on some workgroups of the persistent form and one on the others. Both sides form the
     same products and differ in summation order only (the new forward kernel starts its accumulator at the bias, the weight-gradient kernel walks
     the pixels in row-major passes instead of 16 x 16 tiles); a different last bit of an activation is then re-split into planes by the next
     layer, so the bars are a few units of the mode's own product accuracy relative to the tensor's scale: 5e-6 three-plane, 2e-5 two-plane,
@@ -170,8 +171,20 @@ def test_wave_specialised_convolutions_match_the_strip_and_tile_kernels(lib, n, 
         h1, g1 = run_encoder(lib, p, x, dh, prec)
         assert np.isfinite(h1).all() and all(np.isfinite(g).all() for g in g1)
         d = [float(np.abs(h1 - h0).max() / np.abs(h0).max())] + [float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30)) for a, b in zip(g1, g0)]
-        print(f'n={n} hw={hw} prec={prec}: ws vs strip/tile kernels, worst tensor distance {max(d):.1e}')
-        assert max(d) < tol, (prec, d)
+        print(f'n={n} hw={hw} prec={prec}: ws vs strip/tile kernels, features {d[0]:.1e}, worst gradient {max(d[1:]):.1e}')
+        # The gradients are compared on the small batches only. dh is random and independent of the activations, so one ReLU whose pre-activation
+        # the two forward kernels put on different sides of zero (they differ by 4e-6 in the two-plane mode) moves a bias gradient by 1 / sqrt(n
+        # pixels) of its size: from n = 200 on such flips exist (tools/debug/persist_probe.py: 1e-3 .. 4e-3 in the two-plane mode, none in the
+        # three-plane mode) — a property of the comparison, not of either kernel.
+        assert d[0] < tol and (n >= 200 or max(d) < tol), (prec, d)
+        # the persistent form (n > 8: one workgroup per CU walks the images; n = 300 gives workgroups two images and others one) against one image
+        # per workgroup (bit 8388608): the same sums in the same order, bit for bit
+        try:
+            lib.exorl_gemm_tune(8388608)
+            h2, g2 = run_encoder(lib, p, x, dh, prec)
+        finally:
+            lib.exorl_gemm_tune(-1)
+        assert np.array_equal(h1, h2) and all(np.array_equal(a, b) for a, b in zip(g1, g2)), (prec, 'persistent form differs')
 
 
 def _fwd_any(p, x):
