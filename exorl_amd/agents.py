@@ -213,7 +213,7 @@ class _AgentBase:
                 p.copy_(w.reshape(p.shape))
         self.engine.params_changed(sync_target=True)                   # critic_target.load_state_dict(critic.state_dict())
         self.engine.set_metrics(bool(getattr(self, 'use_tb', False) or getattr(self, 'use_wandb', False)))
-        if ws > 1 and not engine_kw.get('use_critic_lagrange'):
+        if ws > 1:
             from .comm import native_comm
             comm = native_comm(self.engine.device)          # RCCL inside the library when torch.distributed runs on nccl
             if comm is not None:

@@ -991,7 +991,11 @@ int exorl_agent_update_phase(exorl_agent_t* a, int32_t phase, float stddev, cons
 static int whole_step_body(exorl_agent* a, float stddev, const float* noise_c, const float* noise_a, hipStream_t s) {
     const bool dp = a->comm != nullptr;
     const int kind = a->cfg.kind;
-    int rc = exorl_agent_update_phase(a, 0, stddev, noise_c, noise_a, s);
+    // CQL's Lagrange multiplier steps on the penalty of the GLOBAL batch inside phase 0: with a communicator phase 0 runs as 4 | all-reduce | 5
+    const bool lag_dp = dp && kind == EXORL_AGENT_CQL && a->cfg.use_critic_lagrange;
+    int rc = exorl_agent_update_phase(a, lag_dp ? 4 : 0, stddev, noise_c, noise_a, s);
+    if (rc == 0 && lag_dp) rc = comm_allreduce_sum(a->comm, a->stats, 4, s);
+    if (rc == 0 && lag_dp) rc = exorl_agent_update_phase(a, 5, stddev, noise_c, noise_a, s);
     if (rc == 0 && dp && a->has_critic) rc = comm_allreduce_sum(a->comm, a->flat[EXORL_NET_CRITIC][EXORL_T_GRAD], a->critic.total, s);
     if (rc == 0) rc = exorl_agent_update_phase(a, 1, stddev, noise_c, noise_a, s);
     // TD3+BC's sum |Q| (lambda) / CQL's sum log pi (entropy temperature); the fused scalar-head path moves it inside phase 2
@@ -1024,7 +1028,6 @@ int exorl_agent_set_comm(exorl_agent_t* a, exorl_comm_t* c) {
     EXORL_REQUIRE(!a->graph_exec, "agent_set_comm: disable the captured graph first");
     EXORL_REQUIRE(!c || comm_nranks(c) == a->cfg.world_size, "agent_set_comm: communicator has %d ranks, the agent was built for world_size=%d "
                   "(its means are over batch * world_size)", comm_nranks(c), a->cfg.world_size);
-    EXORL_REQUIRE(!c || !a->cfg.use_critic_lagrange, "agent_set_comm: CQL with use_critic_lagrange is single-GPU");
     if (c && !a->comm_stream) {
         EXORL_CHECK_HIP(hipStreamCreateWithFlags(&a->comm_stream, hipStreamNonBlocking));
         EXORL_CHECK_HIP(hipEventCreateWithFlags(&a->ev_stats_ready, hipEventDisableTiming));

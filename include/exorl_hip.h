@@ -178,7 +178,7 @@ typedef struct {
     int32_t num_value_samples; /* CRR: actions sampled per state for V(s) (crr.yaml: 10) */
     int32_t weight_func;       /* CRR: EXORL_CRR_* */
     int32_t n_samples;         /* CQL: action samples per source (cql.yaml: 3); `alpha` is then the CQL penalty weight */
-    int32_t use_critic_lagrange; /* CQL: learn the penalty weight (cql.py:201-213); data parallel through exorl_agent_update_phase 4 / 5, not with exorl_agent_set_comm */
+    int32_t use_critic_lagrange; /* CQL: learn the penalty weight (cql.py:201-213); data parallel through exorl_agent_update_phase 4 / 5 (exorl_agent_update does that itself when a communicator is set) */
     float   target_cql_penalty;  /* CQL Lagrange target (cql.yaml: 5.0) */
     int32_t reserved3;
 } exorl_agent_cfg;

@@ -150,7 +150,7 @@ def test_two_process_sharded_reward_free_agents_equal_single_process(dp_run, kin
             np.testing.assert_allclose(r0[n], want, rtol=5e-5, atol=5e-7, err_msg=f'{kind} {n}')
 
 
-@pytest.mark.parametrize('kind,precision', [('td3_bc', 'fp32'), ('td3_bc', 'bf16x3'), ('cql', 'fp32'), ('bc', 'fp32')])
+@pytest.mark.parametrize('kind,precision', [('td3_bc', 'fp32'), ('td3_bc', 'bf16x3'), ('cql', 'fp32'), ('cqll', 'fp32'), ('bc', 'fp32')])
 def test_native_comm_single_rank_runs_the_dp_step(kind, precision):
     """exorl_comm_* and exorl_agent_set_comm on the box's one GPU: a 1-rank RCCL communicator makes every all-reduce an identity, so
     the LIBRARY-driven data-parallel step (gradients finalised into the flat buffers -> ncclAllReduce on the step's stream -> unfused
@@ -167,11 +167,13 @@ def test_native_comm_single_rank_runs_the_dp_step(kind, precision):
     probe = torch.arange(8, dtype=torch.float32, device='cuda')
     comm.allreduce(probe)
     assert torch.equal(probe.cpu(), torch.arange(8, dtype=torch.float32))
+    lagrange = kind == 'cqll'               # CQL with use_critic_lagrange: with a communicator the library runs phase 0 as 4 | all-reduce | 5
+    kind = 'cql' if lagrange else kind
     ash, csh = param_shapes(kind, O, A, H)
     pa, pc = list(_synth.synth_params(ash, 1).values()), (list(_synth.synth_params(csh, 2).values()) if csh else None)
 
     def engine(metrics):
-        e = AgentEngine(kind, O, A, H, B, precision=precision, alpha=0.01 if kind == 'cql' else 2.5)
+        e = AgentEngine(kind, O, A, H, B, precision=precision, alpha=0.01 if kind == 'cql' else 2.5, use_critic_lagrange=lagrange)
         for i, w in enumerate(pa):
             e.tensor(L.NET_ACTOR, i).copy_(torch.from_numpy(w).reshape(e.tensor(L.NET_ACTOR, i).shape))
         if pc:
@@ -201,6 +203,9 @@ def test_native_comm_single_rank_runs_the_dp_step(kind, precision):
         fused.update(0.2, nc, na)
         assert np.array_equal(native.metrics_raw(), hand.metrics_raw())
     nets = [L.NET_ACTOR] + ([L.NET_CRITIC, L.NET_CRITIC_TARGET] if pc else [])
+    if kind == 'cql':                       # temperature (and, with use_critic_lagrange, the multiplier) and their Adam moments
+        assert np.array_equal(native.cql_alpha_state(), hand.cql_alpha_state())
+        assert not lagrange or abs(float(native.cql_alpha_state()[3])) > 1e-6
     for net in nets:
         assert torch.equal(native.flat(net), hand.flat(net)), net
         d = (native_fast.flat(net) - fused.flat(net)).abs()
