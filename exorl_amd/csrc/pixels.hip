@@ -7,8 +7,12 @@
 //   wgrad            one workgroup = one image, thread = (co, ci) pair with its 9 taps in registers; per-image partials, summed in
 //                    image order by the column-sum kernel (deterministic, no atomics)
 // The ReLU mask of layer l is applied where d(a_l) is produced (dgrad epilogue), so no separate masking pass touches the maps.
-// In the bf16 / split-bf16 precision modes the three 32 -> 32 stride-1 layers run as MFMA implicit GEMMs instead (conv3x3_mfma_kernel,
-// conv_wgrad_mfma_kernel below); the fp32 kernels stay for precision fp32 and for the first layer.
+// In the bf16 / split-bf16 / three-plane precision modes the three 32 -> 32 stride-1 layers run as MFMA implicit GEMMs instead. Product path
+// (round 3): conv3x3_ws_kernel (forward, dgrad; persistent form for batches) and conv_wgrad_ws_kernel — wave-specialised workgroups over a
+// circular row buffer in LDS; the round-2 kernels conv3x3_mfma_kernel / conv_wgrad_mfma_kernel remain as the fallback for geometries those
+// decline and for A/B (exorl_gemm_tune bits 1073741824 / 64). The first layer: forward over row-major strips (conv1_strip_kernel, every mode),
+// weight gradients on MFMA with operands built in registers (conv1_wgrad_mfma_kernel); the tile kernels stay for precision fp32's other
+// layers and as fallbacks.
 #include <type_traits>
 
 #include "kernels.h"
