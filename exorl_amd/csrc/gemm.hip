@@ -1341,6 +1341,7 @@ __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned cha
 #pragma unroll
             for (int tb = 0; tb < SB; ++tb) {
                 const int nb = n0 + wn * WC + tb * 16 + 4 * (lane >> 4);
+                if (P.n_store && nb >= P.n_store) continue;
                 float4* dst = reinterpret_cast<float4*>(P.C + (int64_t)(m0 + wm * WR + ta * 16 + (lane & 15)) * P.ldc + nb);
                 const float4 bias = P.bias ? *reinterpret_cast<const float4*>(P.bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
                 const acc_t& a0 = acc[ta * SB + tb];
@@ -1393,6 +1394,7 @@ __device__ __forceinline__ void gemm16p_body(const Gemm16Batch& gb, unsigned cha
             const acc_t& ax = accx[X3 ? ta * SB + tb : 0];
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
+                if (P.n_store && nb + 8 * g4 >= P.n_store) continue;        // columns of the padded operand planes that C does not have
                 float4* dst = reinterpret_cast<float4*>(crow + 8 * g4);
                 const float4 bias = P.bias ? *reinterpret_cast<const float4*>(P.bias + nb + 8 * g4) : make_float4(0.f, 0.f, 0.f, 0.f);
                 float4 v;
@@ -2055,6 +2057,14 @@ static bool planes_adapter_wants(int al, int bl, const GemmProblem* probs, int c
 }
 
 // 0 = done; -1 = not taken (the caller runs the generic kernel); > 0 = error
+// C written in place by the plane kernels: whole row tiles, 16-byte rows and bias; a width that is not a multiple of the 128-column tile is
+// handled by the epilogue's column guard (n_store) as long as it is a multiple of 4 (round 3: the padded copy + from_padded_kernel pass of the
+// 39200-wide module layers was 0.7 ms of an ICM update on pixels and 2.0 ms of a Disagreement update; exorl_gemm_tune bit 134217728 brings it back)
+static bool adapter_direct(const GemmProblem& p) {
+    const bool wide_ok = p.N % 128 == 0 || (p.N % 4 == 0 && !(tune_variant() & 134217728));
+    return p.M % 128 == 0 && wide_ok && p.ldc % 4 == 0 && reinterpret_cast<uintptr_t>(p.C) % 16 == 0 &&
+           (!p.bias || reinterpret_cast<uintptr_t>(p.bias) % 16 == 0);
+}
 static int planes_adapter(int al, int bl, const GemmProblem* probs, int count, bool relu, bool accumulate, hipStream_t s) {
     struct Plan { int Mp, Np, Kp; size_t a_hi, a_lo, b_hi, b_lo, cp, bias; bool direct; };
     {   // never inside a stream capture: the arena may be re-allocated later, a captured graph would keep the old addresses
@@ -2073,8 +2083,7 @@ static int planes_adapter(int al, int bl, const GemmProblem* probs, int count, b
             q.Mp = (int)round_up(p.M, 128); q.Np = (int)round_up(p.N, 128); q.Kp = (int)round_up(p.K, 128);
             q.a_hi = take((size_t)q.Mp * q.Kp * 2); q.a_lo = take((size_t)q.Mp * q.Kp * 2);
             q.b_hi = take((size_t)q.Np * q.Kp * 2); q.b_lo = take((size_t)q.Np * q.Kp * 2);
-            q.direct = p.M % 128 == 0 && p.N % 128 == 0 && p.ldc % 4 == 0 && reinterpret_cast<uintptr_t>(p.C) % 16 == 0 &&
-                       (!p.bias || reinterpret_cast<uintptr_t>(p.bias) % 16 == 0);
+            q.direct = adapter_direct(p);
             q.cp = q.direct ? 0 : take((size_t)q.Mp * q.Np * 4);
             q.bias = (q.direct || !p.bias) ? 0 : take((size_t)q.Np * 4);
         }
@@ -2112,6 +2121,7 @@ static int planes_adapter(int al, int bl, const GemmProblem* probs, int count, b
             Gemm16Problem g{u16(q.a_hi), u16(q.b_hi), q.direct ? p.C : reinterpret_cast<float*>(base + q.cp), bias, q.Mp, q.Np, q.Kp, acp, bcp,
                             q.direct ? p.ldc : (int64_t)q.Np};
             g.A_lo = u16(q.a_lo); g.B_lo = u16(q.b_lo);
+            g.n_store = q.direct && p.N % 128 != 0 ? p.N : 0;          // written in place, the tile columns past N skipped in the epilogue
             q16[i] = g;
         }
         bool all_direct = true;
@@ -2167,8 +2177,7 @@ int gemm_grouped(int precision, int a_layout, int b_layout, const GemmProblem* p
         if (accumulate) {
             int direct = 0;
             for (int i = 0; i < count; ++i)
-                direct += probs[i].M % 128 == 0 && probs[i].N % 128 == 0 && probs[i].ldc % 4 == 0 && reinterpret_cast<uintptr_t>(probs[i].C) % 16 == 0 &&
-                          (!probs[i].bias || reinterpret_cast<uintptr_t>(probs[i].bias) % 16 == 0);
+                direct += adapter_direct(probs[i]);
             mixed = direct != 0 && direct != count;
         }
         if (!mixed) {

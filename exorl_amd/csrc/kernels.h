@@ -33,6 +33,9 @@ struct Gemm16Problem {
     // row, gemm16_head_slots() says how many). For a net whose hidden activations nobody reads again — the Polyak target critic of a TD step.
     const float* head_w = nullptr;
     float* head_part = nullptr;
+    // > 0 (the 128 x TN "p" kernels only; a multiple of 4): only columns [0, n_store) of C exist — N is the padded width of the operand planes.
+    // The planes adapter uses it for outputs whose width is not a multiple of the tile (39200-wide module layers) instead of a padded C + copy.
+    int n_store = 0;
 };
 // slots per row the "p" kernels would write for these problems' head_part (N / wave column block), or 0 when the launch would not take them
 int gemm16_head_slots(const Gemm16Problem* probs, int count);

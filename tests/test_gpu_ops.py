@@ -58,6 +58,48 @@ def test_gemm(lib, prec, al, bl, M, N, K):
 
 
 @pytest.mark.parametrize('al,bl', [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize('M,N,K', [(256, 328, 384), (512, 1000, 256), (256, 39200 // 8, 256), (384, 300, 640)])
+def test_gemm_split_bf16_adapter_ragged_width_in_place(lib, al, bl, M, N, K):
+    """fp32-source split-bf16 GEMMs with M, N, K >= 256 run on the hi/lo-plane kernels through the planes adapter (gemm.hip). A width that is not
+    a multiple of the 128-column tile (the pixel agents' 39200-wide module layers) is written IN PLACE with the tile columns past N skipped in the
+    epilogue (Gemm16Problem::n_store) instead of through a padded copy: the result against the float64 product, bias / ReLU / accumulate, a row
+    pitch wider than N whose guard columns must stay untouched, and bit-equality with the padded-copy path (exorl_gemm_tune bit 134217728).
+    M = 384 is three row tiles; (384, 300, 640) has K not a multiple of 128 as well."""
+    from exorl_amd import _lib as L
+    rs = np.random.RandomState(M + 3 * N + K + 11 * al + bl)
+    A = rs.standard_normal((M, K)).astype(np.float32)
+    B = rs.standard_normal((K, N)).astype(np.float32)
+    bias = rs.standard_normal(N).astype(np.float32)
+    ldc = N + 8
+    C0 = rs.standard_normal((M, ldc)).astype(np.float32)
+    A_st = A if al == 0 else np.ascontiguousarray(A.T)
+    B_st = np.ascontiguousarray(B.T) if bl == 0 else B
+    a, b, c, bi = dev(A_st), dev(B_st), dev(C0.copy()), dev(bias)
+    for relu, acc in ((0, 0), (1, 0), (0, 1)):
+        outs = []
+        for bits in (0, 134217728):
+            c.copy_(torch.from_numpy(C0))
+            try:
+                lib.exorl_gemm_tune(bits if bits else -1)
+                L.check(lib.exorl_gemm(2, al, bl, M, N, K, a.data_ptr(), A_st.shape[1], b.data_ptr(), B_st.shape[1], c.data_ptr(), ldc, bi.data_ptr(), relu, acc, None))
+            finally:
+                lib.exorl_gemm_tune(-1)
+            torch.cuda.synchronize()
+            outs.append(c.cpu().numpy().copy())
+        got = outs[0]
+        assert np.array_equal(got[:, N:], C0[:, N:]), 'guard columns written'
+        assert np.array_equal(outs[0], outs[1]), 'in-place and padded-copy results differ'
+        ref = A.astype(np.float64) @ B.astype(np.float64) + bias
+        if relu:
+            ref = np.maximum(ref, 0)
+        if acc:
+            ref = ref + C0[:, :N]
+        scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64) + 1.0
+        err = np.abs(got[:, :N] - ref) / scale
+        assert err.max() < 1.2e-5, (al, bl, M, N, K, relu, acc, err.max())
+
+
+@pytest.mark.parametrize('al,bl', [(0, 0), (0, 1), (1, 1)])
 @pytest.mark.parametrize('M,N,K', [(64, 64, 64), (128, 64, 32), (1024, 1024, 1024), (2048, 1024, 1024), (96, 200, 72), (8, 32, 8),
                                    (256, 384, 512), (128, 128, 256), (192, 128, 256)])
 def test_gemm_bf16_operands(lib, al, bl, M, N, K):
