@@ -172,6 +172,51 @@ __global__ __launch_bounds__(256) void icm_err_kernel(const float* __restrict__ 
     if (dapre && lane < A) dapre[(int64_t)row * A + lane] = nb > 0.f ? (-(d / nb) * invB) * (1.0f - ah * ah) : 0.f;
 }
 
+// The same errors for wide rows (pixel encodings: D = 39200): one WORKGROUP per row and 16-byte accesses. With one wave per row a batch of
+// 1024 rows is 1024 waves — four per CU — each walking 157 KB twice in 4-byte steps: 440-610 us per call where the 480 MB it moves cost ~100
+// (0.9 ms of an ICM update on pixels, 3.1 ms of a Disagreement update). The second pass re-reads the row from L2.
+__global__ __launch_bounds__(256) void icm_err_wide_kernel(const float* __restrict__ pred, int D, const float* __restrict__ tgt, int64_t ldt,
+                                                           const float* __restrict__ apre, const float* __restrict__ action, int A,
+                                                           float* __restrict__ fe, float* __restrict__ be, float* __restrict__ dpred,
+                                                           float* __restrict__ dapre, float invB) {
+    __shared__ float red[17];
+    const int row = blockIdx.x, lane = threadIdx.x & 63, n4 = D >> 2;
+    const float4* p4 = reinterpret_cast<const float4*>(pred + (int64_t)row * D);
+    const float4* t4 = reinterpret_cast<const float4*>(tgt + (int64_t)row * ldt);
+    float s = 0.f;
+    for (int j = threadIdx.x; j < n4; j += 256) {
+        const float4 t = t4[j], p = p4[j];
+        const float dx = t.x - p.x, dy = t.y - p.y, dz = t.z - p.z, dw = t.w - p.w;
+        s += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+    const float nf = sqrtf(block_sum(s, red));
+    if (threadIdx.x == 0) fe[row] = nf;
+    if (dpred) {
+        float4* g4 = reinterpret_cast<float4*>(dpred + (int64_t)row * D);
+        for (int j = threadIdx.x; j < n4; j += 256) {
+            const float4 t = t4[j], p = p4[j];
+            float4 g;
+            g.x = nf > 0.f ? -((t.x - p.x) / nf) * invB : 0.f; g.y = nf > 0.f ? -((t.y - p.y) / nf) * invB : 0.f;
+            g.z = nf > 0.f ? -((t.z - p.z) / nf) * invB : 0.f; g.w = nf > 0.f ? -((t.w - p.w) / nf) * invB : 0.f;
+            g4[j] = g;
+        }
+    }
+    if (!apre || threadIdx.x >= 64) return;
+    float ah = 0.f, d = 0.f;
+    if (lane < A) { ah = tanhf(apre[(int64_t)row * A + lane]); d = action[(int64_t)row * A + lane] - ah; }
+    const float nb = sqrtf(wave_sum(d * d));
+    if (lane == 0) be[row] = nb;
+    if (dapre && lane < A) dapre[(int64_t)row * A + lane] = nb > 0.f ? (-(d / nb) * invB) * (1.0f - ah * ah) : 0.f;
+}
+// one launch of the ICM errors: wide rows take the workgroup-per-row kernel (16-byte alignment of every row of pred / tgt / dpred required)
+static void launch_icm_err(const float* pred, int D, const float* tgt, int64_t ldt, const float* apre, const float* action, int A, float* fe, float* be,
+                           float* dpred, float* dapre, int rows, float invB, hipStream_t s) {
+    const bool wide = D >= 2048 && D % 4 == 0 && ldt % 4 == 0 && reinterpret_cast<uintptr_t>(pred) % 16 == 0 && reinterpret_cast<uintptr_t>(tgt) % 16 == 0 &&
+                      (!dpred || reinterpret_cast<uintptr_t>(dpred) % 16 == 0);
+    if (wide) hipLaunchKernelGGL(icm_err_wide_kernel, dim3(rows), dim3(256), 0, s, pred, D, tgt, ldt, apre, action, A, fe, be, dpred, dapre, invB);
+    else hipLaunchKernelGGL(icm_err_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, pred, D, tgt, ldt, apre, action, A, fe, be, dpred, dapre, rows, invB);
+}
+
 // reward = log(fe * scale + 1) (icm.py:86-92) + reward bookkeeping; single block
 __global__ __launch_bounds__(1024) void icm_reward_kernel(const float* __restrict__ fe, const float* extr, float* reward, int B, float scale,
                                                           float* __restrict__ metrics) {
@@ -956,9 +1001,8 @@ static int icm_errors(exorl_intr* it, const float* tgt, int64_t ldt, const float
     const auto& c = it->cfg;
     const int D = it->net[0].L[1].out;
     EXORL_REQUIRE(!inverse || lda == c.act_dim, "intr: ICM needs a dense action matrix (ld == action_dim)");
-    hipLaunchKernelGGL(icm_err_kernel, dim3(cdiv(c.batch, 4)), dim3(256), 0, s, it->net[0].act[1], D, tgt, ldt,
-                       inverse ? it->net[1].act[1] : nullptr, action, c.act_dim, it->fe, it->be, grads ? it->net[0].dact[1] : nullptr,
-                       grads ? it->net[1].dact[1] : nullptr, c.batch, 1.0f / (float)c.batch);
+    launch_icm_err(it->net[0].act[1], D, tgt, ldt, inverse ? it->net[1].act[1] : nullptr, action, c.act_dim, it->fe, it->be,
+                   grads ? it->net[0].dact[1] : nullptr, grads ? it->net[1].dact[1] : nullptr, c.batch, 1.0f / (float)c.batch, s);
     EXORL_LAUNCH_CHECK();
     return 0;
 }
@@ -1050,8 +1094,8 @@ static int disagreement_update(exorl_intr* it, const exorl_intr_batch& b, bool t
     if (train) {                                                                                     // disagreement.py:19-33,64-80
         EXORL_TRY(mlp_forward_many(it->net, n, P, it->xf, O + A, B, prec, s));          // the 5 models' layers share launches
         for (int m = 0; m < n; ++m) {
-            hipLaunchKernelGGL(icm_err_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->net[m].act[1], O, b.next_obs, b.next_obs_ld, nullptr, nullptr,
-                               A, it->fe + (int64_t)m * B, nullptr, it->net[m].dact[1], nullptr, B, 1.0f / ((float)B * (float)n));
+            launch_icm_err(it->net[m].act[1], O, b.next_obs, b.next_obs_ld, nullptr, nullptr, A, it->fe + (int64_t)m * B, nullptr, it->net[m].dact[1],
+                           nullptr, B, 1.0f / ((float)B * (float)n), s);
             EXORL_LAUNCH_CHECK();
         }
         EXORL_TRY(mlp_backward_many(it->net, n, P, G, it->xf, O + A, B, prec, s, b.dobs_out ? it->dxf : nullptr));
