@@ -640,6 +640,25 @@ __global__ __launch_bounds__(256) void vae_out_kernel(const float* __restrict__ 
     s = wave_sum(s);
     if (lane == 0) hsz[row] = s;
 }
+// wide rows (pixel encodings, W = 39200): one workgroup per row, 16-byte accesses (the wave-per-row kernel took 309 us for 480 MB)
+__global__ __launch_bounds__(256) void vae_out_wide_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ out, float* __restrict__ dout,
+                                                           float* __restrict__ hsz, int rows, int W) {
+    __shared__ float red[17];
+    const int row = blockIdx.x, n4 = W >> 2;
+    const float sc = -2.0f / ((float)rows * (float)W);
+    const float4* x4 = reinterpret_cast<const float4*>(x + (int64_t)row * ldx);
+    const float4* o4 = reinterpret_cast<const float4*>(out + (int64_t)row * W);
+    float4* g4 = reinterpret_cast<float4*>(dout + (int64_t)row * W);
+    float s = 0.f;
+    for (int j = threadIdx.x; j < n4; j += 256) {
+        const float4 a = x4[j], b = o4[j];
+        const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, dw = a.w - b.w;
+        s += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        g4[j] = make_float4(sc * dx, sc * dy, sc * dz, sc * dw);
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) hsz[row] = s;
+}
 // gradients at (mu, logvar) of beta * KL + reconstruction, given d/d code; kle_row = -0.5 sum (1 + lv - mu^2 - e^lv)
 __global__ __launch_bounds__(256) void vae_latent_kernel(const float* __restrict__ dcode, const float* __restrict__ mu, const float* __restrict__ lv,
                                                          const float* __restrict__ eps, float* __restrict__ dmu, float* __restrict__ dlv,
@@ -1193,7 +1212,10 @@ static int smm_update(exorl_intr* it, const exorl_intr_batch& b, bool train, hip
                        it->eps, it->code, (int64_t)B * C);
     EXORL_LAUNCH_CHECK();
     EXORL_TRY(mlp_forward(dec, P, it->code, C, B, prec, s));
-    hipLaunchKernelGGL(vae_out_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, b.obs, b.obs_ld, dec.act[2], dec.dact[2], it->hsz, B, W);
+    if (W >= 2048 && W % 4 == 0 && b.obs_ld % 4 == 0 && reinterpret_cast<uintptr_t>(b.obs) % 16 == 0 && reinterpret_cast<uintptr_t>(dec.act[2]) % 16 == 0 &&
+        reinterpret_cast<uintptr_t>(dec.dact[2]) % 16 == 0)
+        hipLaunchKernelGGL(vae_out_wide_kernel, dim3(B), dim3(256), 0, s, b.obs, b.obs_ld, dec.act[2], dec.dact[2], it->hsz, B, W);
+    else hipLaunchKernelGGL(vae_out_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, b.obs, b.obs_ld, dec.act[2], dec.dact[2], it->hsz, B, W);
     EXORL_LAUNCH_CHECK();
     EXORL_TRY(mlp_backward(dec, P, G, it->code, C, B, it->dcode, prec, s));
     hipLaunchKernelGGL(vae_latent_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, it->dcode, it->mu, it->lv, it->eps, it->dmu, it->dlv, it->fe, B, C, c.vae_beta);

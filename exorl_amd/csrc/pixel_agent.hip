@@ -95,10 +95,14 @@ __global__ __launch_bounds__(256) void bn2d_partial_kernel(const float* __restri
     const int64_t per = (int64_t)n * hw, lo = per * k / BN2_CHUNKS, hi = per * (k + 1) / BN2_CHUNKS;
     const double m = mean ? mean[ch] : 0.0;
     double acc = 0.0;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const int64_t img = i / hw, p = i - img * hw;
+    // (image, pixel) of element i kept incrementally: a 64-bit division per element was most of this kernel's 92 us on 87 MB
+    int64_t i = lo + threadIdx.x, img = i / hw, p = i - img * hw;
+    const int64_t step_img = (int64_t)blockDim.x / hw, step_p = (int64_t)blockDim.x - step_img * hw;
+    for (; i < hi; i += blockDim.x) {
         const double v = (double)x[(img * c + ch) * hw + p] - m;
         acc += mean ? v * v : v;
+        img += step_img; p += step_p;
+        if (p >= hw) { p -= hw; ++img; }
     }
     red[threadIdx.x] = acc;
     __syncthreads();

@@ -94,8 +94,11 @@ __global__ __launch_bounds__(256) void aug_shift_rows_kernel(const unsigned char
     __syncthreads();
     const unsigned char* img = x + ((int64_t)b * c + ch) * h * h;
     float* o = out + ((int64_t)b * c + ch) * h * h;
-    for (int e = threadIdx.x; e < h * h; e += 256) {
-        const int i = e / h, j = e % h;
+    // (row, column) of element e kept incrementally (a division and a remainder per element were a third of this kernel's instructions)
+    int i = (int)threadIdx.x / h, j = (int)threadIdx.x - i * h;
+    const int di = 256 / h, dj = 256 - di * h;
+    for (int e = threadIdx.x; e < h * h; e += 256, i += di, j += dj) {
+        if (j >= h) { j -= h; ++i; }
         const int y0 = c0[1][i], y1 = c1[1][i], x0 = c0[0][j], x1 = c1[0][j];
         const float wy0 = w0[1][i], wy1 = w1[1][i], wx0 = w0[0][j], wx1 = w1[0][j];
         const float t00 = (y0 >= 0 && x0 >= 0) ? (float)img[y0 * h + x0] : 0.f, t01 = (y0 >= 0 && x1 >= 0) ? (float)img[y0 * h + x1] : 0.f;
