@@ -1631,14 +1631,28 @@ __global__ __launch_bounds__(W1_THREADS) void conv1_wgrad_mfma_kernel(const floa
     for (int r0 = 0; r0 < oh; r0 += W1_RC) {
         const int nr = oh - r0 < W1_RC ? oh - r0 : W1_RC, npx = nr * ow, nsteps = (npx + 15) / 16;
         __syncthreads();
-        for (int i = tid; i < CONV_CO * CP; i += W1_THREADS) {                 // dY chunk, zero beyond the chunk's pixels
-            const int co = i / CP, pp = i % CP;
-            dyt[i] = pp < npx ? dyn[(int64_t)co * oh * ow + (int64_t)r0 * ow + pp] : 0.f;
+        // (channel, pixel) and (channel, row, column) of element i are kept incrementally: the divisions and remainders per element were a
+        // large share of this kernel's instructions (same elements, same values)
+        {
+            int co = tid / CP, pp = tid - co * CP;
+            const int dco = W1_THREADS / CP, dpp = W1_THREADS - dco * CP;
+            for (int i = tid; i < CONV_CO * CP; i += W1_THREADS) {             // dY chunk, zero beyond the chunk's pixels
+                dyt[i] = pp < npx ? dyn[(int64_t)co * oh * ow + (int64_t)r0 * ow + pp] : 0.f;
+                co += dco; pp += dpp;
+                if (pp >= CP) { pp -= CP; ++co; }
+            }
         }
         const int rows_in = 2 * nr + 1, iy0 = 2 * r0;
-        for (int i = tid; i < ci_n * XR * iw; i += W1_THREADS) {
-            const int ci = i / (XR * iw), rem = i % (XR * iw), yy = rem / iw, xx = rem % iw;
-            xt[i] = (yy < rows_in && iy0 + yy < ih) ? inn[((int64_t)ci * ih + iy0 + yy) * iw + xx] / 255.0f - 0.5f : 0.f;
+        {
+            const int plane = XR * iw;
+            int ci = tid / plane, rem = tid - ci * plane, yy = rem / iw, xx = rem - yy * iw;
+            const int srow = W1_THREADS / iw, dxx = W1_THREADS - srow * iw, dci = srow / XR, dyy = srow - dci * XR;
+            for (int i = tid; i < ci_n * plane; i += W1_THREADS) {
+                xt[i] = (yy < rows_in && iy0 + yy < ih) ? inn[((int64_t)ci * ih + iy0 + yy) * iw + xx] / 255.0f - 0.5f : 0.f;
+                xx += dxx; yy += dyy; ci += dci;
+                if (xx >= iw) { xx -= iw; ++yy; }
+                if (yy >= XR) { yy -= XR; ++ci; }
+            }
         }
         __syncthreads();
         for (int st = wave; st < nsteps; st += 8) {
